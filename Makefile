@@ -1,0 +1,22 @@
+# Builds libtennis_hip.so (gfx950 only) in-tree, plus the C oracle pieces.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+CSRC  := tennis_amd/csrc
+OUT   := tennis_amd/lib/libtennis_hip.so
+SRCS  := $(wildcard $(CSRC)/*.hip)
+OBJS  := $(SRCS:.hip=.o)
+HFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
+
+all: $(OUT)
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/tennis_hip.h
+	$(HIPCC) $(HFLAGS) -c $< -o $@
+
+$(OUT): $(OBJS)
+	@mkdir -p $(dir $(OUT))
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
+
+clean:
+	rm -f $(OBJS) $(OUT)
+
+.PHONY: all clean

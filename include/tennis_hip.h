@@ -1,0 +1,157 @@
+/*
+ * tennis_hip.h — C ABI of libtennis_hip.so: the MI355X (gfx950) hot path of
+ * HaydenFaulkner/Tennis, hand-written HIP behind the reference's model surface.
+ *
+ * The reference has NO FFI boundary of its own (pure Python on MXNet,
+ * SURVEY §8b).  Each entry point below replaces the device work that one
+ * reference call performs inside MXNet; the cited file:line is the reference
+ * call site that a maintainer would re-point at this library (INTEGRATION.md
+ * shows the ctypes stub).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative tn_status otherwise;
+ *     tn_last_error() gives a thread-local message for the last failure;
+ *   - all tensor pointers are DEVICE pointers on the ctx's device unless the
+ *     parameter name ends in _host; the caller owns every input/output buffer;
+ *     the library owns weights and workspace inside opaque handles;
+ *   - calls on one tn_ctx are ordered on its HIP stream and asynchronous;
+ *     tn_ctx_sync() waits.  A ctx is not re-entrant; use one ctx per thread.
+ *   - no allocation happens in *_forward.
+ */
+#ifndef TENNIS_HIP_H
+#define TENNIS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  TN_OK = 0,
+  TN_ERR_INVALID = -1,   /* bad argument / shape (mirrors the reference's asserts) */
+  TN_ERR_HIP = -2,       /* HIP runtime error */
+  TN_ERR_MISSING = -3,   /* a required parameter name was not supplied */
+  TN_ERR_NOMEM = -4
+} tn_status;
+
+/* Input frame layouts accepted by tn_densenet121_forward. */
+typedef enum {
+  TN_LAYOUT_NCHW_F32 = 0, /* reference layout: ToTensor+Normalize output (evaluate.py:96-97) */
+  TN_LAYOUT_NHWC_F16 = 1, /* native: normalised frames, fp16, 3 channels */
+  TN_LAYOUT_NHWC_U8 = 2   /* decoded RGB bytes; ToTensor+Normalize fused into the stem load */
+} tn_layout;
+
+typedef enum { TN_RNN_GRU = 0, TN_RNN_LSTM = 1 } tn_rnn_kind;
+typedef enum { TN_POOL_MAX = 0, TN_POOL_MEAN = 1 } tn_pool_kind;
+
+/* A named host tensor (Gluon parameter name -> fp32 data). */
+typedef struct {
+  const char *name;
+  const float *data_host;
+  int64_t numel;
+} tn_param;
+
+/* Per-kernel-family timing returned by tn_densenet121_profile. */
+typedef struct {
+  char name[32];      /* kernel family, e.g. "conv3x3_bnrelu" */
+  int launches;       /* launches of this family in one forward */
+  double ms;          /* summed HIP-event time of those launches */
+  double flops;       /* algorithmic FLOPs of those launches (2*MACs of the convs) */
+  double bytes;       /* algorithmic bytes moved (activations+weights, once each) */
+} tn_kernel_stat;
+
+typedef struct tn_ctx tn_ctx;
+typedef struct tn_encoder tn_encoder;
+typedef struct tn_dense tn_dense;
+typedef struct tn_birnn tn_birnn;
+
+int tn_version(void);
+const char *tn_last_error(void);
+
+/* ---- context: one per (device, stream) --------------------------------- */
+/* `stream` is the hipStream_t to launch on (e.g. torch's current stream; NULL is
+ * HIP's default stream).  With own_stream != 0 the library creates and owns a
+ * non-blocking stream instead and `stream` is ignored.  Replaces: mx.gpu(i)
+ * context selection, reference evaluate.py:85. */
+int tn_ctx_create(int device, void *stream, int own_stream, tn_ctx **out);
+void *tn_ctx_stream(tn_ctx *ctx);
+int tn_ctx_sync(tn_ctx *ctx);       /* replaces the implicit sync of .asnumpy(), evaluate.py:314 */
+int tn_ctx_destroy(tn_ctx *ctx);
+
+/* ---- frame encoder: DenseNet-121 .features ------------------------------ */
+/* Replaces get_model('DenseNet121', pretrained=True).features (reference
+ * evaluate.py:125, train.py:204, train_gnmt.py:150) and its forward
+ * net.backbone(x) (evaluate.py:313).  `params` are Gluon-named fp32 host
+ * tensors "<prefix>conv0_weight", "<prefix>stage1_batchnorm0_gamma", ...
+ * (H,W) is the input size (224 or 512 in the reference), feature_dim is
+ * 1024*floor(H/32/7)*floor(W/32/7) (1024 @224, 4096 @512; train.py:259). */
+int tn_densenet121_create(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix,
+                          int height, int width, int max_batch, tn_encoder **out);
+int tn_densenet121_feature_dim(const tn_encoder *enc);
+size_t tn_densenet121_workspace_bytes(const tn_encoder *enc);
+/* x: `batch` frames in `layout`; feat: (batch, feature_dim) fp32, NCHW-flatten order. */
+int tn_densenet121_forward(tn_encoder *enc, const void *x, tn_layout layout, int batch, float *feat);
+/* Same forward, but every launch is bracketed by HIP events on the ctx stream;
+ * fills up to max_stats families and syncs.  For bench.py's roofline. */
+int tn_densenet121_profile(tn_encoder *enc, const void *x, tn_layout layout, int batch, float *feat,
+                           tn_kernel_stat *stats, int max_stats, int *n_stats);
+/* Test hook: copy an internal NHWC fp16 activation of the LAST forward to a host
+ * fp32 buffer.  tap in {"stem","pool0","stage1".."stage4","trans1".."trans3",
+ * "stage<k>_l0_bottleneck"}; returns the element count through *numel. */
+int tn_densenet121_read_tap(tn_encoder *enc, const char *tap, int batch, float *out_host,
+                            size_t capacity, size_t *numel);
+int tn_densenet121_destroy(tn_encoder *enc);
+
+/* ---- nn.Dense(units, flatten=True) -------------------------------------- */
+/* Replaces FrameModel.classes / CNNRNN.classes (reference
+ * models/vision/definitions.py:25,32,101,108-109).  y = x W^T + b, fp32. */
+int tn_dense_create(tn_ctx *ctx, const float *weight_host, const float *bias_host, int units,
+                    int in_units, tn_dense **out);
+int tn_dense_forward(tn_dense *d, const float *x, int rows, float *y);
+int tn_dense_destroy(tn_dense *d);
+
+/* ---- gluon.rnn.GRU/LSTM(hidden, layout='NTC', bidirectional=True) ------- */
+/* Replaces CNNRNN.rnn (reference models/vision/definitions.py:94-96,106) and
+ * one bidirectional layer of GNMTEncoder (models/captioning/gnmt.py:141-148).
+ * params: "<prefix>{l,r}0_{i2h,h2h}_{weight,bias}"; gate order GRU [r,z,n],
+ * LSTM [i,f,g,o].  x (B,T,F) fp32 -> seq (B,T,2H) fp32 = concat(fwd,bwd);
+ * zero initial state.  valid_len (B,) int32 or NULL: steps >= valid_len are
+ * skipped and emit zeros; the reverse direction starts at valid_len-1.
+ * h_last/c_last (2,B,H) fp32 or NULL receive the final states [fwd,bwd]. */
+int tn_birnn_create(tn_ctx *ctx, tn_rnn_kind kind, int input_size, int hidden, const tn_param *params,
+                    int n_params, const char *prefix, int bidirectional, int max_rows, tn_birnn **out);
+int tn_birnn_forward(tn_birnn *r, const float *x, int batch, int steps, const int32_t *valid_len,
+                     float *seq, float *h_last, float *c_last);
+int tn_birnn_destroy(tn_birnn *r);
+
+/* ---- F.max / F.mean over axis 1 ------------------------------------------ */
+/* Replaces reference models/vision/definitions.py:66-69,107.  x (B,T,F) -> y (B,F). */
+int tn_temporal_pool(tn_ctx *ctx, const float *x, int batch, int steps, int feat, tn_pool_kind kind,
+                     float *y);
+
+/* ---- device PRF1 confusion histogram -------------------------------------- */
+/* Replaces the argmax + per-sample python loop of PRF1.update (reference
+ * metrics/vision.py:41-49).  logits (rows,classes) fp32, labels (rows,) int32;
+ * adds into mat (classes*classes) int64, row = label, col = argmax (first max). */
+int tn_prf1_update(tn_ctx *ctx, const float *logits, const int32_t *labels, int rows, int classes,
+                   int64_t *mat);
+
+/* ---- test hooks (used by tests/ only) -------------------------------------- */
+/* Run ONE encoder kernel on caller-provided device activations (fp16 NHWC) with
+ * host fp32 weights in Gluon layout, folded/packed exactly as
+ * tn_densenet121_create does; synchronous.  They let the parity tests pin each
+ * kernel against the oracle at ragged sizes and channel offsets. */
+int tn_dbg_conv1x1(tn_ctx *ctx, const void *x_f16, int ldx, int K, const float *scale_host,
+                   const float *shift_host, const float *w_host, int N, void *y_f16, int ldy, int yoff,
+                   int M, int pool, int H, int W);
+int tn_dbg_conv3x3(tn_ctx *ctx, const void *x_f16, const float *scale_host, const float *shift_host,
+                   const float *w_host, void *y_f16, int ldy, int yoff, int B, int H, int W);
+int tn_dbg_linear(tn_ctx *ctx, const float *x, const float *w, const float *bias, float *y, int M, int N,
+                  int K);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TENNIS_HIP_H */

@@ -1,0 +1,148 @@
+"""ctypes binding of libtennis_hip.so (include/tennis_hip.h).
+
+The HIP library is the product: there is no CPU fallback.  Importing this
+module without the built library, or calling into it without a GPU, raises.
+`import torch` happens first so that the library binds to the HIP runtime torch
+already loaded (same SONAME libamdhip64.so.7) and device pointers / streams are
+interchangeable with torch tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch  # noqa: F401  (must precede CDLL: shares the HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtennis_hip.so")
+
+LAYOUT_NCHW_F32, LAYOUT_NHWC_F16, LAYOUT_NHWC_U8 = 0, 1, 2
+RNN_GRU, RNN_LSTM = 0, 1
+POOL_MAX, POOL_MEAN = 0, 1
+
+
+class TnParam(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data_host", C.POINTER(C.c_float)), ("numel", C.c_int64)]
+
+
+class TnKernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_int), ("ms", C.c_double),
+                ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+_P = C.c_void_p
+_SIGS = {
+    "tn_version": (C.c_int, []),
+    "tn_last_error": (C.c_char_p, []),
+    "tn_ctx_create": (C.c_int, [C.c_int, _P, C.c_int, C.POINTER(_P)]),
+    "tn_ctx_stream": (_P, [_P]),
+    "tn_ctx_sync": (C.c_int, [_P]),
+    "tn_ctx_destroy": (C.c_int, [_P]),
+    "tn_densenet121_create": (C.c_int, [_P, C.POINTER(TnParam), C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int,
+                                        C.POINTER(_P)]),
+    "tn_densenet121_feature_dim": (C.c_int, [_P]),
+    "tn_densenet121_workspace_bytes": (C.c_size_t, [_P]),
+    "tn_densenet121_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "tn_densenet121_profile": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.POINTER(TnKernelStat), C.c_int,
+                                         C.POINTER(C.c_int)]),
+    "tn_densenet121_read_tap": (C.c_int, [_P, C.c_char_p, C.c_int, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "tn_densenet121_destroy": (C.c_int, [_P]),
+    "tn_dense_create": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "tn_dense_forward": (C.c_int, [_P, _P, C.c_int, _P]),
+    "tn_dense_destroy": (C.c_int, [_P]),
+    "tn_birnn_create": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(TnParam), C.c_int, C.c_char_p, C.c_int,
+                                  C.c_int, C.POINTER(_P)]),
+    "tn_birnn_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "tn_birnn_destroy": (C.c_int, [_P]),
+    "tn_temporal_pool": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "tn_prf1_update": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
+    "tn_dbg_conv1x1": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_int]),
+    "tn_dbg_conv3x3": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tn_dbg_linear": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
+}
+
+_lib = None
+
+
+def declared_symbols():
+    return sorted(_SIGS)
+
+
+def load():
+    """Load libtennis_hip.so; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `make` (or __graft_entry__.build()). "
+                "tennis_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().tn_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libtennis_hip {what} failed ({rc}): {msg}")
+
+
+def make_params(params: dict):
+    """dict[str, np.ndarray fp32] -> (TnParam array, keepalive list)."""
+    keep = []
+    arr = (TnParam * len(params))()
+    for i, (k, v) in enumerate(params.items()):
+        a = np.ascontiguousarray(v, dtype=np.float32)
+        name = k.encode()
+        keep += [a, name]
+        arr[i].name = name
+        arr[i].data_host = a.ctypes.data_as(C.POINTER(C.c_float))
+        arr[i].numel = a.size
+    return arr, keep
+
+
+class Context:
+    """One tn_ctx bound to a torch device and (by default) torch's current stream."""
+
+    def __init__(self, device: int = 0, stream=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("tennis_amd needs a ROCm GPU: torch.cuda.is_available() is False and there is no "
+                               "CPU fallback")
+        self.lib = load()
+        self.device = device
+        torch.cuda.set_device(device)
+        if stream is None:
+            stream = torch.cuda.current_stream(device)
+        self.torch_stream = stream
+        h = _P()
+        check(self.lib.tn_ctx_create(device, _P(stream.cuda_stream), 0, C.byref(h)), "tn_ctx_create")
+        self.handle = h
+
+    def sync(self):
+        check(self.lib.tn_ctx_sync(self.handle), "tn_ctx_sync")
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.tn_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device: int = 0) -> Context:
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+def ptr(t) -> _P:
+    return _P(t.data_ptr()) if t is not None else _P(None)

@@ -1,0 +1,536 @@
+// C ABI of libtennis_hip.so (see include/tennis_hip.h): context, DenseNet-121
+// frame encoder (weight folding/packing + launch schedule), Dense, bi-RNN,
+// temporal pooling and the PRF1 histogram.
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "linear.h"
+#include "rnn.h"
+
+// ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+void tn_set_error(const std::string &msg) { g_err = msg; }
+extern "C" const char *tn_last_error(void) { return g_err.c_str(); }
+extern "C" int tn_version(void) { return 100; }
+
+// ---- context ----------------------------------------------------------------
+extern "C" int tn_ctx_create(int device, void *stream, int own_stream, tn_ctx **out) {
+  TN_REQUIRE(out != nullptr, "tn_ctx_create: out is null");
+  int n = 0;
+  TN_HIP_CHECK(hipGetDeviceCount(&n));
+  TN_REQUIRE(device >= 0 && device < n, "tn_ctx_create: no such device");
+  TN_HIP_CHECK(hipSetDevice(device));
+  tn_ctx *c = new tn_ctx();
+  c->device = device;
+  c->own_stream = own_stream != 0;
+  if (c->own_stream) {
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete c;
+      tn_set_error(std::string("hipStreamCreate: ") + hipGetErrorString(e));
+      return TN_ERR_HIP;
+    }
+  } else {
+    c->stream = (hipStream_t)stream;
+  }
+  *out = c;
+  return TN_OK;
+}
+extern "C" void *tn_ctx_stream(tn_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+extern "C" int tn_ctx_sync(tn_ctx *ctx) {
+  TN_REQUIRE(ctx, "tn_ctx_sync: null ctx");
+  TN_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return TN_OK;
+}
+extern "C" int tn_ctx_destroy(tn_ctx *ctx) {
+  if (!ctx) return TN_OK;
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return TN_OK;
+}
+
+// ---- small host helpers -------------------------------------------------------
+namespace {
+
+struct DevPool {  // owns device allocations of one handle
+  std::vector<void *> ptrs;
+  size_t bytes = 0;
+  bool failed = false;
+  void *alloc(size_t n) {
+    void *p = nullptr;
+    if (hipMalloc(&p, n ? n : 16) != hipSuccess) { failed = true; return nullptr; }
+    ptrs.push_back(p);
+    bytes += n;
+    return p;
+  }
+  template <typename T>
+  T *upload(const std::vector<T> &h) {
+    T *d = (T *)alloc(h.size() * sizeof(T));
+    if (d && hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { failed = true; return nullptr; }
+    return d;
+  }
+  void release() {
+    for (void *p : ptrs) (void)hipFree(p);
+    ptrs.clear();
+  }
+};
+
+struct ParamMap {
+  std::map<std::string, const tn_param *> m;
+  ParamMap(const tn_param *p, int n) {
+    for (int i = 0; i < n; ++i) m[p[i].name] = &p[i];
+  }
+  const float *get(const std::string &name, int64_t numel) const {
+    auto it = m.find(name);
+    if (it == m.end()) {
+      tn_set_error("missing parameter: " + name);
+      return nullptr;
+    }
+    if (it->second->numel != numel) {
+      tn_set_error("parameter " + name + " has " + std::to_string(it->second->numel) + " elements, expected " +
+                   std::to_string(numel));
+      return nullptr;
+    }
+    return it->second->data_host;
+  }
+};
+
+constexpr float kBnEps = 1e-5f;
+
+// Folded inference BatchNorm: y = x*scale + shift.
+bool fold_bn(const ParamMap &pm, const std::string &name, int c, std::vector<float> &scale, std::vector<float> &shift) {
+  const float *g = pm.get(name + "_gamma", c), *b = pm.get(name + "_beta", c);
+  const float *mu = pm.get(name + "_running_mean", c), *var = pm.get(name + "_running_var", c);
+  if (!g || !b || !mu || !var) return false;
+  scale.resize(c);
+  shift.resize(c);
+  for (int i = 0; i < c; ++i) {
+    const float s = g[i] / std::sqrt(var[i] + kBnEps);
+    scale[i] = s;
+    shift[i] = b[i] - mu[i] * s;
+  }
+  return true;
+}
+
+std::vector<f16> to_f16(const float *w, size_t n) {
+  std::vector<f16> h(n);
+  for (size_t i = 0; i < n; ++i) h[i] = (f16)w[i];
+  return h;
+}
+
+// 3x3 weights (32,128,3,3) -> MFMA B fragments [72 k-steps][64 lanes][8]:
+// k-step s = tap*8 + kk; lane l: n = l&31, channel = kk*16 + (l>>5)*8 + j.
+std::vector<f16> pack_conv3x3(const float *w) {
+  std::vector<f16> p((size_t)72 * 64 * 8);
+  for (int s = 0; s < 72; ++s) {
+    const int tap = s >> 3, kk = s & 7, ky = tap / 3, kx = tap % 3;
+    for (int l = 0; l < 64; ++l)
+      for (int j = 0; j < 8; ++j) {
+        const int n = l & 31, c = kk * 16 + (l >> 5) * 8 + j;
+        p[((size_t)s * 64 + l) * 8 + j] = (f16)w[(((size_t)n * 128 + c) * 3 + ky) * 3 + kx];
+      }
+  }
+  return p;
+}
+
+// stem weights (64,3,7,7) * bn scale -> MFMA A fragments [7 ky][4 nfrag][64 lanes][8]:
+// lane l: n = nf*16 + (l&15); k slot (l>>4)*8 + j -> x-tap kx = slot>>2, channel c = slot&3.
+std::vector<f16> pack_stem(const float *w, const std::vector<float> &scale) {
+  std::vector<f16> p((size_t)7 * 4 * 64 * 8);
+  for (int ky = 0; ky < 7; ++ky)
+    for (int nf = 0; nf < 4; ++nf)
+      for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 8; ++j) {
+          const int n = nf * 16 + (l & 15), slot = (l >> 4) * 8 + j, kx = slot >> 2, c = slot & 3;
+          float v = 0.f;
+          if (kx < 7 && c < 3) v = w[(((size_t)n * 3 + c) * 7 + ky) * 7 + kx] * scale[n];
+          p[(((size_t)ky * 4 + nf) * 64 + l) * 8 + j] = (f16)v;
+        }
+  return p;
+}
+
+struct EventTimer {  // brackets launches with HIP events when enabled
+  bool on = false;
+  hipStream_t s = nullptr;
+  struct Rec { hipEvent_t a, b; int fam; };
+  std::vector<Rec> recs;
+  std::vector<tn_kernel_stat> fams;
+  int family(const char *name) {
+    for (size_t i = 0; i < fams.size(); ++i)
+      if (!strcmp(fams[i].name, name)) return (int)i;
+    tn_kernel_stat st;
+    memset(&st, 0, sizeof(st));
+    strncpy(st.name, name, sizeof(st.name) - 1);
+    fams.push_back(st);
+    return (int)fams.size() - 1;
+  }
+  void begin(const char *name, double flops, double bytes) {
+    if (!on) return;
+    Rec r;
+    r.fam = family(name);
+    (void)hipEventCreate(&r.a);
+    (void)hipEventCreate(&r.b);
+    fams[r.fam].launches += 1;
+    fams[r.fam].flops += flops;
+    fams[r.fam].bytes += bytes;
+    (void)hipEventRecord(r.a, s);
+    recs.push_back(r);
+  }
+  void end() {
+    if (!on) return;
+    (void)hipEventRecord(recs.back().b, s);
+  }
+  void finish() {
+    if (!on) return;
+    (void)hipStreamSynchronize(s);
+    for (auto &r : recs) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, r.a, r.b);
+      fams[r.fam].ms += ms;
+      (void)hipEventDestroy(r.a);
+      (void)hipEventDestroy(r.b);
+    }
+    recs.clear();
+  }
+};
+
+}  // namespace
+
+// ---- DenseNet-121 encoder --------------------------------------------------------
+struct tn_encoder {
+  tn_ctx *ctx;
+  DevPool pool;
+  int H, W, maxB, feat_dim;
+  int Hs, Ws;              // stem conv output
+  int Hb[4], Wb[4];        // dense block spatial sizes
+  int Cin[4], Cb[4];       // block input / total channels
+  int PH, PW;
+  f16 *stem_wp;
+  float *stem_shift;
+  struct DenseLayer { float *s1, *t1; f16 *w1; float *s2, *t2; f16 *w3p; int cin; };
+  std::vector<DenseLayer> layers[4];
+  struct Trans { float *s, *t; f16 *w; int cin, cout; } trans[3];
+  float *head_s, *head_t;
+  f16 *stem_out, *bott, *blockbuf[4];
+  size_t workspace_bytes;
+  int last_batch;
+};
+
+static const int kBlockCfg[4] = {6, 12, 24, 16};
+
+extern "C" int tn_densenet121_create(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix_c,
+                                     int height, int width, int max_batch, tn_encoder **out) {
+  TN_REQUIRE(ctx && params && out && prefix_c, "tn_densenet121_create: null argument");
+  TN_REQUIRE(max_batch > 0, "tn_densenet121_create: max_batch must be positive");
+  TN_REQUIRE(height >= 224 && width >= 224 && height <= 1024 && width <= 1024,
+             "tn_densenet121_create: input size must be in [224,1024] (AvgPool2D(7) needs a >=7x7 final map)");
+  TN_HIP_CHECK(hipSetDevice(ctx->device));
+  const std::string pre(prefix_c);
+  ParamMap pm(params, n_params);
+  tn_encoder *e = new tn_encoder();
+  e->ctx = ctx;
+  e->H = height; e->W = width; e->maxB = max_batch; e->last_batch = 0;
+  e->Hs = (height + 6 - 7) / 2 + 1; e->Ws = (width + 6 - 7) / 2 + 1;
+  int h = (e->Hs + 2 - 3) / 2 + 1, w = (e->Ws + 2 - 3) / 2 + 1, c = 64;
+  for (int b = 0; b < 4; ++b) {
+    e->Hb[b] = h; e->Wb[b] = w; e->Cin[b] = c; e->Cb[b] = c + 32 * kBlockCfg[b];
+    c = e->Cb[b] / 2; h /= 2; w /= 2;
+  }
+  e->PH = e->Hb[3] / 7; e->PW = e->Wb[3] / 7;
+  e->feat_dim = e->Cb[3] * e->PH * e->PW;
+  auto fail = [&](int code) { e->pool.release(); delete e; return code; };
+  if (e->PH < 1 || e->PW < 1) { tn_set_error("input too small for AvgPool2D(7)"); return fail(TN_ERR_INVALID); }
+  if (e->Wb[0] > 240) { tn_set_error("input too wide for the conv3x3 LDS tile"); return fail(TN_ERR_INVALID); }
+
+  std::vector<float> s, t;
+  {  // stem: conv0 + batchnorm0 (scale folded into the weights)
+    const float *w0 = pm.get(pre + "conv0_weight", 64 * 3 * 7 * 7);
+    if (!w0 || !fold_bn(pm, pre + "batchnorm0", 64, s, t)) return fail(TN_ERR_MISSING);
+    e->stem_wp = e->pool.upload(pack_stem(w0, s));
+    e->stem_shift = e->pool.upload(t);
+  }
+  int outer = 1;
+  for (int b = 0; b < 4; ++b) {
+    const std::string sp = pre + "stage" + std::to_string(b + 1) + "_";
+    for (int l = 0; l < kBlockCfg[b]; ++l) {
+      tn_encoder::DenseLayer L;
+      L.cin = e->Cin[b] + 32 * l;
+      const float *w1 = pm.get(sp + "conv" + std::to_string(2 * l) + "_weight", (int64_t)128 * L.cin);
+      const float *w3 = pm.get(sp + "conv" + std::to_string(2 * l + 1) + "_weight", 32 * 128 * 9);
+      if (!w1 || !w3) return fail(TN_ERR_MISSING);
+      if (!fold_bn(pm, sp + "batchnorm" + std::to_string(2 * l), L.cin, s, t)) return fail(TN_ERR_MISSING);
+      L.s1 = e->pool.upload(s); L.t1 = e->pool.upload(t);
+      L.w1 = e->pool.upload(to_f16(w1, (size_t)128 * L.cin));
+      if (!fold_bn(pm, sp + "batchnorm" + std::to_string(2 * l + 1), 128, s, t)) return fail(TN_ERR_MISSING);
+      L.s2 = e->pool.upload(s); L.t2 = e->pool.upload(t);
+      L.w3p = e->pool.upload(pack_conv3x3(w3));
+      e->layers[b].push_back(L);
+    }
+    if (b < 3) {
+      auto &T = e->trans[b];
+      T.cin = e->Cb[b]; T.cout = e->Cb[b] / 2;
+      const float *wt = pm.get(pre + "conv" + std::to_string(outer) + "_weight", (int64_t)T.cout * T.cin);
+      if (!wt || !fold_bn(pm, pre + "batchnorm" + std::to_string(outer), T.cin, s, t)) return fail(TN_ERR_MISSING);
+      T.s = e->pool.upload(s); T.t = e->pool.upload(t);
+      T.w = e->pool.upload(to_f16(wt, (size_t)T.cout * T.cin));
+      ++outer;
+    }
+  }
+  if (!fold_bn(pm, pre + "batchnorm" + std::to_string(outer), e->Cb[3], s, t)) return fail(TN_ERR_MISSING);
+  e->head_s = e->pool.upload(s); e->head_t = e->pool.upload(t);
+
+  const size_t weights_bytes = e->pool.bytes;
+  const size_t B = (size_t)max_batch;
+  e->stem_out = (f16 *)e->pool.alloc(B * e->Hs * e->Ws * 64 * sizeof(f16));
+  e->bott = (f16 *)e->pool.alloc(B * e->Hb[0] * e->Wb[0] * 128 * sizeof(f16));
+  for (int b = 0; b < 4; ++b)
+    e->blockbuf[b] = (f16 *)e->pool.alloc(B * e->Hb[b] * e->Wb[b] * e->Cb[b] * sizeof(f16));
+  e->workspace_bytes = e->pool.bytes - weights_bytes;
+  if (e->pool.failed) { tn_set_error("device allocation failed"); return fail(TN_ERR_NOMEM); }
+  *out = e;
+  return TN_OK;
+}
+
+extern "C" int tn_densenet121_feature_dim(const tn_encoder *enc) { return enc ? enc->feat_dim : 0; }
+extern "C" size_t tn_densenet121_workspace_bytes(const tn_encoder *enc) { return enc ? enc->workspace_bytes : 0; }
+
+static int encoder_run(tn_encoder *e, const void *x, tn_layout layout, int B, float *feat, EventTimer &tm) {
+  TN_REQUIRE(e && x && feat, "tn_densenet121_forward: null argument");
+  TN_REQUIRE(B > 0 && B <= e->maxB, "tn_densenet121_forward: batch exceeds max_batch");
+  TN_HIP_CHECK(hipSetDevice(e->ctx->device));
+  hipStream_t s = e->ctx->stream;
+  int rc;
+  const double fB = (double)B;
+  {
+    StemArgs a{x, (int)layout, B, e->H, e->W, e->stem_wp, e->stem_shift, e->stem_out, e->Hs, e->Ws};
+    const double px = fB * e->Hs * e->Ws;
+    tm.begin("stem_conv7x7_bn_relu", 2.0 * px * 64 * 147, fB * e->H * e->W * 3 * 2 + px * 64 * 2);
+    rc = launch_stem(a, s);
+    tm.end();
+    if (rc) return rc;
+    tm.begin("maxpool3x3s2", 0.0, px * 64 * 2 + fB * e->Hb[0] * e->Wb[0] * 64 * 2);
+    rc = launch_maxpool3x3s2(e->stem_out, B, e->Hs, e->Ws, 64, e->blockbuf[0], e->Cb[0], e->Hb[0], e->Wb[0], s);
+    tm.end();
+    if (rc) return rc;
+  }
+  for (int b = 0; b < 4; ++b) {
+    const int Hh = e->Hb[b], Ww = e->Wb[b];
+    const int M = B * Hh * Ww;
+    for (auto &L : e->layers[b]) {
+      Conv1x1Args a1{e->blockbuf[b], e->Cb[b], L.cin, L.s1, L.t1, L.w1, 128, e->bott, 128, 0, M, 0, Hh, Ww};
+      tm.begin("conv1x1_bnrelu", 2.0 * M * 128.0 * L.cin, (double)M * (L.cin + 128) * 2 + 128.0 * L.cin * 2);
+      rc = launch_conv1x1(a1, s);
+      tm.end();
+      if (rc) return rc;
+      Conv3x3Args a3{e->bott, L.s2, L.t2, L.w3p, e->blockbuf[b], e->Cb[b], L.cin, M, Hh, Ww};
+      tm.begin("conv3x3_bnrelu", 2.0 * M * 32.0 * 1152, (double)M * (128 + 32) * 2 + 32.0 * 1152 * 2);
+      rc = launch_conv3x3(a3, s);
+      tm.end();
+      if (rc) return rc;
+    }
+    if (b < 3) {
+      auto &T = e->trans[b];
+      const int Mo = B * e->Hb[b + 1] * e->Wb[b + 1];
+      Conv1x1Args at{e->blockbuf[b], e->Cb[b], T.cin, T.s, T.t, T.w, T.cout, e->blockbuf[b + 1], e->Cb[b + 1], 0,
+                     Mo, 1, Hh, Ww};
+      tm.begin("transition_conv1x1_avgpool", 2.0 * M * (double)T.cout * T.cin,
+               (double)M * T.cin * 2 + (double)Mo * T.cout * 2 + (double)T.cout * T.cin * 2);
+      rc = launch_conv1x1(at, s);
+      tm.end();
+      if (rc) return rc;
+    }
+  }
+  tm.begin("head_bnrelu_avgpool7", 0.0, fB * e->Hb[3] * e->Wb[3] * e->Cb[3] * 2 + fB * e->feat_dim * 4);
+  rc = launch_head(e->blockbuf[3], B, e->Hb[3], e->Wb[3], e->Cb[3], e->head_s, e->head_t, feat, e->PH, e->PW, s);
+  tm.end();
+  e->last_batch = B;
+  return rc;
+}
+
+extern "C" int tn_densenet121_forward(tn_encoder *enc, const void *x, tn_layout layout, int batch, float *feat) {
+  EventTimer tm;
+  return encoder_run(enc, x, layout, batch, feat, tm);
+}
+
+extern "C" int tn_densenet121_profile(tn_encoder *enc, const void *x, tn_layout layout, int batch, float *feat,
+                                      tn_kernel_stat *stats, int max_stats, int *n_stats) {
+  TN_REQUIRE(enc && stats && n_stats, "tn_densenet121_profile: null argument");
+  EventTimer tm;
+  tm.on = true;
+  tm.s = enc->ctx->stream;
+  const int rc = encoder_run(enc, x, layout, batch, feat, tm);
+  tm.finish();
+  if (rc) return rc;
+  const int n = (int)tm.fams.size() < max_stats ? (int)tm.fams.size() : max_stats;
+  for (int i = 0; i < n; ++i) stats[i] = tm.fams[i];
+  *n_stats = n;
+  return TN_OK;
+}
+
+extern "C" int tn_densenet121_read_tap(tn_encoder *e, const char *tap_c, int batch, float *out_host, size_t capacity,
+                                       size_t *numel) {
+  TN_REQUIRE(e && tap_c && out_host && numel, "tn_densenet121_read_tap: null argument");
+  TN_REQUIRE(batch > 0 && batch <= e->last_batch, "tn_densenet121_read_tap: batch exceeds the last forward");
+  const std::string tap(tap_c);
+  const f16 *src = nullptr;
+  int hh = 0, ww = 0, cc = 0, ld = 0;
+  if (tap == "stem") { src = e->stem_out; hh = e->Hs; ww = e->Ws; cc = 64; ld = 64; }
+  else if (tap == "pool0") { src = e->blockbuf[0]; hh = e->Hb[0]; ww = e->Wb[0]; cc = 64; ld = e->Cb[0]; }
+  else if (tap.rfind("stage", 0) == 0 && tap.size() == 6) {
+    const int b = tap[5] - '1';
+    TN_REQUIRE(b >= 0 && b < 4, "read_tap: bad stage");
+    src = e->blockbuf[b]; hh = e->Hb[b]; ww = e->Wb[b]; cc = e->Cb[b]; ld = cc;
+  } else if (tap.rfind("trans", 0) == 0 && tap.size() == 6) {
+    const int b = tap[5] - '1';
+    TN_REQUIRE(b >= 0 && b < 3, "read_tap: bad transition");
+    src = e->blockbuf[b + 1]; hh = e->Hb[b + 1]; ww = e->Wb[b + 1]; cc = e->Cb[b] / 2; ld = e->Cb[b + 1];
+  } else {
+    TN_REQUIRE(false, "read_tap: unknown tap");
+  }
+  const size_t px = (size_t)batch * hh * ww;
+  *numel = px * cc;
+  TN_REQUIRE(capacity >= *numel, "read_tap: host buffer too small");
+  TN_HIP_CHECK(hipStreamSynchronize(e->ctx->stream));
+  std::vector<f16> tmp(px * ld);
+  TN_HIP_CHECK(hipMemcpy(tmp.data(), src, tmp.size() * sizeof(f16), hipMemcpyDeviceToHost));
+  for (size_t p = 0; p < px; ++p)
+    for (int c = 0; c < cc; ++c) out_host[p * cc + c] = (float)tmp[p * ld + c];
+  return TN_OK;
+}
+
+extern "C" int tn_densenet121_destroy(tn_encoder *enc) {
+  if (!enc) return TN_OK;
+  (void)hipSetDevice(enc->ctx->device);
+  enc->pool.release();
+  delete enc;
+  return TN_OK;
+}
+
+// ---- Dense -----------------------------------------------------------------------
+struct tn_dense {
+  tn_ctx *ctx;
+  DevPool pool;
+  float *w, *b;
+  int units, in_units;
+};
+
+extern "C" int tn_dense_create(tn_ctx *ctx, const float *weight_host, const float *bias_host, int units,
+                               int in_units, tn_dense **out) {
+  TN_REQUIRE(ctx && weight_host && out, "tn_dense_create: null argument");
+  TN_REQUIRE(units > 0 && in_units > 0, "tn_dense_create: bad shape");
+  TN_HIP_CHECK(hipSetDevice(ctx->device));
+  tn_dense *d = new tn_dense();
+  d->ctx = ctx; d->units = units; d->in_units = in_units;
+  d->w = d->pool.upload(std::vector<float>(weight_host, weight_host + (size_t)units * in_units));
+  d->b = bias_host ? d->pool.upload(std::vector<float>(bias_host, bias_host + units)) : nullptr;
+  if (d->pool.failed) { d->pool.release(); delete d; tn_set_error("device allocation failed"); return TN_ERR_NOMEM; }
+  *out = d;
+  return TN_OK;
+}
+extern "C" int tn_dense_forward(tn_dense *d, const float *x, int rows, float *y) {
+  TN_REQUIRE(d && x && y, "tn_dense_forward: null argument");
+  TN_REQUIRE(rows >= 0, "tn_dense_forward: negative rows");
+  TN_HIP_CHECK(hipSetDevice(d->ctx->device));
+  return launch_linear_f32(x, d->in_units, d->w, d->in_units, d->b, y, d->units, rows, d->units, d->in_units, 0,
+                           d->ctx->stream);
+}
+extern "C" int tn_dense_destroy(tn_dense *d) {
+  if (!d) return TN_OK;
+  (void)hipSetDevice(d->ctx->device);
+  d->pool.release();
+  delete d;
+  return TN_OK;
+}
+
+// ---- bi-RNN ----------------------------------------------------------------------
+struct tn_birnn {
+  tn_ctx *ctx;
+  DevPool pool;
+  int gates, F, H, dirs, max_rows;
+  float *wi;   // [dirs*G*H][F]   both directions stacked -> one i2h GEMM
+  float *bi;   // [dirs*G*H]
+  float *whT;  // [dirs][H][G*H]
+  float *bh;   // [dirs][G*H]
+  float *gi;   // workspace [max_rows][dirs*G*H]
+};
+
+extern "C" int tn_birnn_create(tn_ctx *ctx, tn_rnn_kind kind, int input_size, int hidden, const tn_param *params,
+                               int n_params, const char *prefix_c, int bidirectional, int max_rows, tn_birnn **out) {
+  TN_REQUIRE(ctx && params && prefix_c && out, "tn_birnn_create: null argument");
+  TN_REQUIRE(kind == TN_RNN_GRU || kind == TN_RNN_LSTM, "tn_birnn_create: unknown cell kind");
+  TN_REQUIRE(input_size > 0 && hidden > 0 && hidden % 4 == 0 && max_rows > 0, "tn_birnn_create: bad shape");
+  const int G = kind == TN_RNN_GRU ? 3 : 4;
+  TN_REQUIRE(G * hidden <= 1024, "tn_birnn_create: gates*hidden must be <= 1024");
+  TN_HIP_CHECK(hipSetDevice(ctx->device));
+  const std::string pre(prefix_c);
+  ParamMap pm(params, n_params);
+  const int dirs = bidirectional ? 2 : 1, GH = G * hidden;
+  std::vector<float> wi((size_t)dirs * GH * input_size), bi((size_t)dirs * GH), whT((size_t)dirs * hidden * GH),
+      bh((size_t)dirs * GH);
+  for (int d = 0; d < dirs; ++d) {
+    const std::string dp = pre + (d == 0 ? "l0_" : "r0_");
+    const float *a = pm.get(dp + "i2h_weight", (int64_t)GH * input_size);
+    const float *b = pm.get(dp + "h2h_weight", (int64_t)GH * hidden);
+    const float *c = pm.get(dp + "i2h_bias", GH);
+    const float *e = pm.get(dp + "h2h_bias", GH);
+    if (!a || !b || !c || !e) return TN_ERR_MISSING;
+    memcpy(&wi[(size_t)d * GH * input_size], a, sizeof(float) * GH * input_size);
+    memcpy(&bi[(size_t)d * GH], c, sizeof(float) * GH);
+    memcpy(&bh[(size_t)d * GH], e, sizeof(float) * GH);
+    for (int j = 0; j < GH; ++j)
+      for (int k = 0; k < hidden; ++k) whT[((size_t)d * hidden + k) * GH + j] = b[(size_t)j * hidden + k];
+  }
+  tn_birnn *r = new tn_birnn();
+  r->ctx = ctx; r->gates = G; r->F = input_size; r->H = hidden; r->dirs = dirs; r->max_rows = max_rows;
+  r->wi = r->pool.upload(wi); r->bi = r->pool.upload(bi); r->whT = r->pool.upload(whT); r->bh = r->pool.upload(bh);
+  r->gi = (float *)r->pool.alloc((size_t)max_rows * dirs * GH * sizeof(float));
+  if (r->pool.failed) {
+    r->pool.release(); delete r; tn_set_error("device allocation failed"); return TN_ERR_NOMEM;
+  }
+  *out = r;
+  return TN_OK;
+}
+
+extern "C" int tn_birnn_forward(tn_birnn *r, const float *x, int batch, int steps, const int32_t *valid_len,
+                                float *seq, float *h_last, float *c_last) {
+  TN_REQUIRE(r && x && seq, "tn_birnn_forward: null argument");
+  TN_REQUIRE(batch > 0 && steps > 0 && (long)batch * steps <= r->max_rows, "tn_birnn_forward: B*T exceeds max_rows");
+  TN_HIP_CHECK(hipSetDevice(r->ctx->device));
+  hipStream_t s = r->ctx->stream;
+  const int GH = r->gates * r->H, N = r->dirs * GH, rows = batch * steps;
+  int rc = launch_linear_f32(x, r->F, r->wi, r->F, r->bi, r->gi, N, rows, N, r->F, 0, s);
+  if (rc) return rc;
+  if (valid_len) TN_HIP_CHECK(hipMemsetAsync(seq, 0, (size_t)rows * r->dirs * r->H * sizeof(float), s));
+  return launch_rnn_recurrent(r->gates, r->gi, N, r->whT, r->bh, valid_len, seq, r->dirs * r->H, h_last, c_last,
+                              batch, steps, r->H, r->dirs, s);
+}
+extern "C" int tn_birnn_destroy(tn_birnn *r) {
+  if (!r) return TN_OK;
+  (void)hipSetDevice(r->ctx->device);
+  r->pool.release();
+  delete r;
+  return TN_OK;
+}
+
+// ---- temporal pooling / PRF1 -------------------------------------------------------
+extern "C" int tn_temporal_pool(tn_ctx *ctx, const float *x, int batch, int steps, int feat, tn_pool_kind kind,
+                                float *y) {
+  TN_REQUIRE(ctx && x && y, "tn_temporal_pool: null argument");
+  TN_REQUIRE(batch > 0 && steps > 0 && feat > 0, "tn_temporal_pool: bad shape");
+  TN_REQUIRE(kind == TN_POOL_MAX || kind == TN_POOL_MEAN, "tn_temporal_pool: unknown pool kind");
+  TN_HIP_CHECK(hipSetDevice(ctx->device));
+  return launch_temporal_pool(x, batch, steps, feat, (int)kind, y, ctx->stream);
+}
+
+extern "C" int tn_prf1_update(tn_ctx *ctx, const float *logits, const int32_t *labels, int rows, int classes,
+                              int64_t *mat) {
+  TN_REQUIRE(ctx && logits && labels && mat, "tn_prf1_update: null argument");
+  TN_REQUIRE(rows >= 0 && classes > 0, "tn_prf1_update: bad shape");
+  if (rows == 0) return TN_OK;
+  TN_HIP_CHECK(hipSetDevice(ctx->device));
+  return launch_prf1(logits, labels, rows, classes, mat, ctx->stream);
+}

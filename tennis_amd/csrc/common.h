@@ -1,0 +1,103 @@
+// Shared device/host helpers for libtennis_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/tennis_hip.h"
+
+typedef _Float16 f16;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- error plumbing -------------------------------------------------------
+void tn_set_error(const std::string &msg);
+#define TN_HIP_CHECK(expr)                                                             \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      tn_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+      return TN_ERR_HIP;                                                               \
+    }                                                                                  \
+  } while (0)
+#define TN_REQUIRE(cond, msg)                                                          \
+  do {                                                                                 \
+    if (!(cond)) {                                                                     \
+      tn_set_error(std::string("invalid argument: ") + (msg));                         \
+      return TN_ERR_INVALID;                                                           \
+    }                                                                                  \
+  } while (0)
+
+struct tn_ctx {
+  int device;
+  hipStream_t stream;
+  bool own_stream;
+};
+
+// ---- device helpers -------------------------------------------------------
+// BN(inference)+ReLU on 8 fp16 values with fp32 scale/shift, rounded once to fp16.
+__device__ __forceinline__ f16x8 bn_relu8(f16x8 v, const float *__restrict__ s, const float *__restrict__ t) {
+  f16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float f = fmaf((float)v[j], s[j], t[j]);
+    r[j] = (f16)fmaxf(f, 0.0f);
+  }
+  return r;
+}
+
+// Byte offset of 16-byte chunk `chunk` of row `row` in an LDS tile whose rows are
+// ROWB bytes (ROWB/16 chunks, power of two), XOR-swizzled so that a ds_read_b128
+// lane group reading 16 different rows at the same chunk is conflict-free.
+template <int ROWB>
+__device__ __forceinline__ int swz(int row, int chunk) {
+  constexpr int NCH = ROWB / 16;
+  return row * ROWB + ((chunk ^ (row & (NCH - 1))) << 4);
+}
+
+// ---- launchers (defined in the kernel .hip files) --------------------------
+struct Conv1x1Args {
+  const f16 *x;       // [rows_in][ldx] NHWC activations (concat buffer)
+  int ldx;            // channel stride of x
+  int K;              // input channels used (multiple of 32)
+  const float *scale; // [K] folded BN scale
+  const float *shift; // [K]
+  const f16 *w;       // [N][K] fp16, K contiguous
+  int N;              // output channels (multiple of 128)
+  f16 *y;             // [M][ldy], written at column yoff
+  int ldy, yoff;
+  int M;              // output pixels (B*Ho*Wo)
+  int pool;           // 0: Ho=H ; 1: 2x2 average of BN+ReLU'd input before the GEMM
+  int H, W;           // input spatial size (used when pool)
+};
+int launch_conv1x1(const Conv1x1Args &a, hipStream_t s);
+
+struct Conv3x3Args {
+  const f16 *x;       // [M][128] bottleneck, dense
+  const float *scale; // [128]
+  const float *shift; // [128]
+  const f16 *wp;      // packed B fragments [72][64 lanes][8]
+  f16 *y;             // [M][ldy] at column yoff, 32 channels
+  int ldy, yoff;
+  int M, H, W;        // M = B*H*W
+};
+int launch_conv3x3(const Conv3x3Args &a, hipStream_t s);
+size_t conv3x3_lds_bytes(int W);
+
+struct StemArgs {
+  const void *x;
+  int layout;         // tn_layout
+  int B, H, W;        // input size
+  const f16 *wp;      // packed A fragments [7 ky][4 nfrag][64 lanes][8], BN scale folded
+  const float *shift; // [64]
+  f16 *y;             // [B][Ho][Wo][64]
+  int Ho, Wo;
+};
+int launch_stem(const StemArgs &a, hipStream_t s);
+
+int launch_maxpool3x3s2(const f16 *x, int B, int H, int W, int C, f16 *y, int ldy, int Ho, int Wo, hipStream_t s);
+int launch_head(const f16 *x, int B, int H, int W, int C, const float *scale, const float *shift,
+                float *feat, int PH, int PW, hipStream_t s);

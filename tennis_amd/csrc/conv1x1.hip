@@ -1,0 +1,218 @@
+// K2/K5 — fused BN+ReLU -> 1x1 convolution (+ optional 2x2 average pool) as an
+// MFMA GEMM on NHWC fp16 activations.  Replaces, per DenseNet layer, the
+// BatchNorm -> Activation -> Convolution(1x1) [-> Pooling(avg)] operator chain
+// that gluoncv's DenseNet .features launches (reference call site
+// models/vision/definitions.py:30; op inventory SURVEY §2c rows K2, K5).
+//
+//   Y[m][n] = sum_k relu(scale[k]*X[m][k]+shift[k]) * Wt[n][k]
+//
+// X is the dense block's concat buffer (row stride ldx >= K): reading the first
+// K channels of every pixel IS the concat (no concat kernel).
+// Tiling: 256 threads = 4 waves as 2(m) x 2(n); block tile (32*MI) x 128, BK=64;
+// v_mfma_f32_16x16x32_f16 with the weight fragment as the A operand so each lane
+// ends with 4 consecutive output channels of one pixel.  BN+ReLU is applied once
+// per element while staging global->registers->LDS (fp32 math, one rounding);
+// the next k-tile's global loads are in flight while the current tile computes.
+// The epilogue transposes through LDS so every output row is one coalesced
+// 256-byte store.  With POOL the four BN+ReLU'd input pixels of each pooled
+// pixel are averaged before the GEMM (avgpool and 1x1 conv commute), which also
+// cuts the transition GEMMs' work by 4x.
+#include "common.h"
+
+namespace {
+
+constexpr int BN_TILE = 128;
+constexpr int BK = 64;
+constexpr int CPITCH = 272;  // bytes per epilogue row: 128 halfs + 8 pad
+
+template <int MI>
+constexpr int smem_bytes() {
+  constexpr int tiles = 32 * MI * 128 + BN_TILE * 128;
+  constexpr int epi = 32 * MI * CPITCH;
+  return tiles > epi ? tiles : epi;
+}
+
+template <int MI, bool POOL>
+__global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
+  constexpr int BM = 32 * MI;
+  constexpr int NSRC = POOL ? 4 : 1;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[smem_bytes<MI>()];
+  unsigned char *Xs = smem;
+  unsigned char *Ws = smem + BM * 128;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wid = t >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN_TILE;
+  const int K = a.K;
+
+  // staging assignment: chunk column c (8 halfs) is fixed per thread
+  const int c = t & 7;
+  const int r0 = t >> 3;  // 0..31
+
+  // source row pointers for this thread's MI tile rows
+  const f16 *xsrc[MI][NSRC];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    int m = m0 + r0 + 32 * i;
+    if (m >= a.M) m = a.M - 1;
+    if constexpr (POOL) {
+      const int Wo = a.W >> 1, Ho = a.H >> 1;
+      const int px = m % Wo;
+      const int q = m / Wo;
+      const int py = q % Ho;
+      const int b = q / Ho;
+      const long base = ((long)(b * a.H + 2 * py) * a.W + 2 * px);
+      xsrc[i][0] = a.x + base * a.ldx;
+      xsrc[i][1] = a.x + (base + 1) * a.ldx;
+      xsrc[i][2] = a.x + (base + a.W) * a.ldx;
+      xsrc[i][3] = a.x + (base + a.W + 1) * a.ldx;
+    } else {
+      xsrc[i][0] = a.x + (long)m * a.ldx;
+    }
+  }
+  const f16 *wsrc = a.w + (long)(n0 + r0) * K;
+
+  f16x8 xr[MI][NSRC];
+  f16x8 wr[4];
+  float sc[8], sh[8];
+
+  auto load_tile = [&](int kt) {
+    const int kc = kt * BK + c * 8;
+    if (kc < K) {
+      const float4 s0 = *(const float4 *)(a.scale + kc);
+      const float4 s1 = *(const float4 *)(a.scale + kc + 4);
+      const float4 t0 = *(const float4 *)(a.shift + kc);
+      const float4 t1 = *(const float4 *)(a.shift + kc + 4);
+      sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w;
+      sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+      sh[0] = t0.x; sh[1] = t0.y; sh[2] = t0.z; sh[3] = t0.w;
+      sh[4] = t1.x; sh[5] = t1.y; sh[6] = t1.z; sh[7] = t1.w;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s) xr[i][s] = *(const f16x8 *)(xsrc[i][s] + kc);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wr[i] = *(const f16x8 *)(wsrc + (long)(32 * i) * K + kc);
+    }
+  };
+
+  auto store_tile = [&](int kt) {
+    const int kc = kt * BK + c * 8;
+    const bool kv = kc < K;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      f16x8 v;
+      if (kv) {
+        if constexpr (POOL) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc += fmaxf(fmaf((float)xr[i][s][j], sc[j], sh[j]), 0.f);
+            v[j] = (f16)(0.25f * acc);
+          }
+        } else {
+          v = bn_relu8(xr[i][0], sc, sh);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (f16)0.f;
+      }
+      *(f16x8 *)(Xs + swz<128>(r0 + 32 * i, c)) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f16x8 v = wr[i];
+      if (!kv) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (f16)0.f;
+      }
+      *(f16x8 *)(Ws + swz<128>(r0 + 32 * i, c)) = v;
+    }
+  };
+
+  f32x4 acc[4][MI];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (K + BK - 1) / BK;
+  const int frow = lane & 15;
+  const int fch = lane >> 4;
+
+  load_tile(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    store_tile(kt);
+    __syncthreads();
+    if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (kt * BK + ks * 32 < K) {
+        f16x8 xb[MI], wa[4];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          xb[mi] = *(const f16x8 *)(Xs + swz<128>(wm * 16 * MI + mi * 16 + frow, ks * 4 + fch));
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          wa[ni] = *(const f16x8 *)(Ws + swz<128>(wn * 64 + ni * 16 + frow, ks * 4 + fch));
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ni], xb[mi], acc[ni][mi], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: D[i=n][j=m]; lane holds n = (lane>>4)*4 + r, m = lane&15
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = wm * 16 * MI + mi * 16 + frow;
+      const int n = wn * 64 + ni * 16 + fch * 4;
+      f16x4 h;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[r] = (f16)acc[ni][mi][r];
+      *(f16x4 *)(smem + m * CPITCH + n * 2) = h;
+    }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MI * 2; ++i) {
+    const int id = t + 256 * i;
+    const int row = id >> 4, ch = id & 15;
+    const int m = m0 + row;
+    if (m < a.M) {
+      const uint4 v = *(const uint4 *)(smem + row * CPITCH + ch * 16);
+      *(uint4 *)(a.y + (long)m * a.ldy + a.yoff + n0 + ch * 8) = v;
+    }
+  }
+}
+
+}  // namespace
+
+int launch_conv1x1(const Conv1x1Args &a, hipStream_t s) {
+  TN_REQUIRE(a.K % 32 == 0 && a.N % BN_TILE == 0, "conv1x1: K%32 or N%128");
+  TN_REQUIRE(a.ldx % 8 == 0 && a.ldy % 8 == 0 && a.yoff % 8 == 0, "conv1x1: strides must be multiples of 8");
+  const dim3 block(256);
+  if (a.pool) {
+    const dim3 grid((a.M + 63) / 64, a.N / BN_TILE);
+    hipLaunchKernelGGL((conv1x1_kernel<2, true>), grid, block, 0, s, a);
+  } else if (a.M >= 128 * 512) {
+    const dim3 grid((a.M + 127) / 128, a.N / BN_TILE);
+    hipLaunchKernelGGL((conv1x1_kernel<4, false>), grid, block, 0, s, a);
+  } else if (a.M >= 64 * 512) {
+    const dim3 grid((a.M + 63) / 64, a.N / BN_TILE);
+    hipLaunchKernelGGL((conv1x1_kernel<2, false>), grid, block, 0, s, a);
+  } else {
+    const dim3 grid((a.M + 31) / 32, a.N / BN_TILE);
+    hipLaunchKernelGGL((conv1x1_kernel<1, false>), grid, block, 0, s, a);
+  }
+  TN_HIP_CHECK(hipGetLastError());
+  return TN_OK;
+}

@@ -1,0 +1,171 @@
+// K9/K10/K11 — gluon.rnn.GRU / LSTM (layout 'NTC', optionally bidirectional)
+// and the temporal max/mean that follows it (reference
+// models/vision/definitions.py:94-96,106-107 and 66-69; one bidirectional layer
+// of GNMTEncoder, models/captioning/gnmt.py:141-148).  fp32 throughout so the
+// sequential recurrence stays within 1e-3 of the CPU oracle.
+//
+//   (a) one big i2h GEMM over all B*T rows and both directions (linear.hip);
+//   (b) a persistent recurrent kernel: one workgroup per (direction, group of
+//       NB batch rows) walks all T steps without leaving the device.  Thread j
+//       owns gate row j: it streams column j of the k-major h2h matrix
+//       (L2-resident, coalesced across threads) against h held in LDS, the
+//       gate pre-activations meet in LDS and the same workgroup applies the
+//       gate non-linearities.  valid_length semantics of
+//       BidirectionalCell.unroll(valid_length=...) [EXT]: steps >= valid_len
+//       do not update state and emit zeros; the reverse pass starts at
+//       valid_len-1.
+#include "common.h"
+#include "linear.h"
+#include "rnn.h"
+
+namespace {
+
+constexpr int NB = 4;  // batch rows per workgroup
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int G>  // 3 = GRU [r,z,n], 4 = LSTM [i,f,g,o]
+__global__ void rnn_recurrent_kernel(const float *__restrict__ gi, int ldgi,  // [B*T][dirs*G*H] i2h + b_i2h
+                                     const float *__restrict__ whT,           // [dirs][H][G*H]
+                                     const float *__restrict__ bh,            // [dirs][G*H]
+                                     const int32_t *__restrict__ valid_len,   // [B] or null
+                                     float *__restrict__ seq, int ldo,        // [B*T][dirs*H]
+                                     float *__restrict__ h_last, float *__restrict__ c_last,  // [dirs][B][H]
+                                     int B, int T, int H) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int GH = G * H;
+  float *hs = lds;                 // [NB][H]
+  float *gh = hs + NB * H;         // [NB][GH]
+  float *cs = gh + NB * GH;        // [NB][H] (LSTM)
+  const int j = threadIdx.x;       // gate row
+  const int dir = blockIdx.y;
+  const int b0 = blockIdx.x * NB;
+  const float *wcol = whT + (long)dir * H * GH + j;
+  const float bj = bh[dir * GH + j];
+
+  for (int i = j; i < NB * H; i += GH) {
+    hs[i] = 0.f;
+    if (G == 4) cs[i] = 0.f;
+  }
+  int vl[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) vl[b] = (b0 + b < B) ? (valid_len ? valid_len[b0 + b] : T) : 0;
+  __syncthreads();
+
+  for (int s = 0; s < T; ++s) {
+    float acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = bj;
+    for (int k = 0; k < H; k += 4) {
+      const float w0 = wcol[(long)(k + 0) * GH], w1 = wcol[(long)(k + 1) * GH];
+      const float w2 = wcol[(long)(k + 2) * GH], w3 = wcol[(long)(k + 3) * GH];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float4 hv = *(const float4 *)(hs + b * H + k);
+        acc[b] = fmaf(w0, hv.x, acc[b]);
+        acc[b] = fmaf(w1, hv.y, acc[b]);
+        acc[b] = fmaf(w2, hv.z, acc[b]);
+        acc[b] = fmaf(w3, hv.w, acc[b]);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) gh[b * GH + j] = acc[b];
+    __syncthreads();
+    for (int idx = j; idx < NB * H; idx += GH) {
+      const int b = idx / H, u = idx - b * H;
+      const int bg = b0 + b;
+      if (bg >= B) continue;
+      const int vlen = valid_len ? valid_len[bg] : T;
+      if (s >= vlen) continue;
+      const int ti = dir ? (vlen - 1 - s) : s;
+      const float *g = gi + ((long)bg * T + ti) * ldgi + dir * GH;
+      const float *q = gh + b * GH;
+      float hn;
+      if (G == 3) {
+        const float r = sigmoidf_(g[u] + q[u]);
+        const float z = sigmoidf_(g[H + u] + q[H + u]);
+        const float n = tanhf(g[2 * H + u] + r * q[2 * H + u]);
+        hn = (1.f - z) * n + z * hs[idx];
+      } else {
+        const float ig = sigmoidf_(g[u] + q[u]);
+        const float fg = sigmoidf_(g[H + u] + q[H + u]);
+        const float gg = tanhf(g[2 * H + u] + q[2 * H + u]);
+        const float og = sigmoidf_(g[3 * H + u] + q[3 * H + u]);
+        const float c2 = fg * cs[idx] + ig * gg;
+        cs[idx] = c2;
+        hn = og * tanhf(c2);
+      }
+      hs[idx] = hn;
+      seq[((long)bg * T + ti) * ldo + dir * H + u] = hn;
+    }
+    __syncthreads();
+  }
+  (void)vl;
+  for (int idx = j; idx < NB * H; idx += GH) {
+    const int b = idx / H, u = idx - b * H;
+    if (b0 + b >= B) continue;
+    if (h_last) h_last[((long)dir * B + b0 + b) * H + u] = hs[idx];
+    if (c_last && G == 4) c_last[((long)dir * B + b0 + b) * H + u] = cs[idx];
+  }
+}
+
+__global__ void temporal_pool_kernel(const float *__restrict__ x, int B, int T, int F, int kind,
+                                     float *__restrict__ y) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)B * F) return;
+  const int b = (int)(id / F), f = (int)(id % F);
+  const float *p = x + (long)b * T * F + f;
+  float acc = kind == TN_POOL_MAX ? -INFINITY : 0.f;
+  for (int t = 0; t < T; ++t) {
+    const float v = p[(long)t * F];
+    acc = kind == TN_POOL_MAX ? fmaxf(acc, v) : acc + v;
+  }
+  y[id] = kind == TN_POOL_MAX ? acc : acc / (float)T;
+}
+
+__global__ void prf1_kernel(const float *__restrict__ logits, const int32_t *__restrict__ labels, int rows,
+                            int classes, unsigned long long *__restrict__ mat) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float *p = logits + (long)r * classes;
+  int best = 0;
+  float bv = p[0];
+  for (int c = 1; c < classes; ++c)
+    if (p[c] > bv) { bv = p[c]; best = c; }   // first maximum, like ndarray.argmax
+  const int lab = labels[r];
+  if (lab >= 0 && lab < classes) atomicAdd(mat + (long)lab * classes + best, 1ULL);
+}
+
+}  // namespace
+
+int launch_rnn_recurrent(int gates, const float *gi, int ldgi, const float *whT, const float *bh,
+                         const int32_t *valid_len, float *seq, int ldo, float *h_last, float *c_last, int B, int T,
+                         int H, int dirs, hipStream_t s) {
+  TN_REQUIRE(gates == 3 || gates == 4, "rnn: gates must be 3 or 4");
+  TN_REQUIRE(gates * H <= 1024 && H % 4 == 0, "rnn: gates*hidden must be <= 1024 and hidden % 4 == 0");
+  const dim3 grid((B + NB - 1) / NB, dirs), block(gates * H);
+  const size_t lds = (size_t)(NB * H * 2 + NB * gates * H) * sizeof(float);
+  if (gates == 3)
+    hipLaunchKernelGGL(rnn_recurrent_kernel<3>, grid, block, lds, s, gi, ldgi, whT, bh, valid_len, seq, ldo, h_last,
+                       c_last, B, T, H);
+  else
+    hipLaunchKernelGGL(rnn_recurrent_kernel<4>, grid, block, lds, s, gi, ldgi, whT, bh, valid_len, seq, ldo, h_last,
+                       c_last, B, T, H);
+  TN_HIP_CHECK(hipGetLastError());
+  return TN_OK;
+}
+
+int launch_temporal_pool(const float *x, int B, int T, int F, int kind, float *y, hipStream_t s) {
+  const long total = (long)B * F;
+  hipLaunchKernelGGL(temporal_pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, B, T, F, kind,
+                     y);
+  TN_HIP_CHECK(hipGetLastError());
+  return TN_OK;
+}
+
+int launch_prf1(const float *logits, const int32_t *labels, int rows, int classes, int64_t *mat, hipStream_t s) {
+  hipLaunchKernelGGL(prf1_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, logits, labels, rows, classes,
+                     (unsigned long long *)mat);
+  TN_HIP_CHECK(hipGetLastError());
+  return TN_OK;
+}

@@ -1,0 +1,177 @@
+"""Device-side building blocks: thin Python handles over the C ABI.
+
+Each class owns one opaque library handle (weights + workspace live in HBM
+inside it) and launches on the Context's HIP stream.  Tensors crossing this
+boundary are torch CUDA tensors used purely as device buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+
+
+def _layout_of(x: torch.Tensor, size_hw):
+    """Pick the tn_layout of a frame batch from dtype/shape (reference frames are
+    NCHW float32 after ToTensor+Normalize, evaluate.py:96-97)."""
+    h, w = size_hw
+    if x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3 and tuple(x.shape[2:]) == (h, w):
+        return _lib.LAYOUT_NCHW_F32
+    if x.dtype == torch.float16 and x.dim() == 4 and x.shape[3] == 3 and tuple(x.shape[1:3]) == (h, w):
+        return _lib.LAYOUT_NHWC_F16
+    if x.dtype == torch.uint8 and x.dim() == 4 and x.shape[3] == 3 and tuple(x.shape[1:3]) == (h, w):
+        return _lib.LAYOUT_NHWC_U8
+    raise ValueError(f"unsupported frame batch: shape {tuple(x.shape)} dtype {x.dtype} for a {h}x{w} encoder "
+                     "(expected NCHW float32, NHWC float16 or NHWC uint8)")
+
+
+class DenseNet121Features:
+    """``get_model('DenseNet121').features`` on the GPU (reference evaluate.py:125)."""
+
+    def __init__(self, params: dict, size: int | tuple = 224, max_batch: int = 256, prefix: str = "densenet0_",
+                 ctx: _lib.Context | None = None):
+        self.ctx = ctx or _lib.default_context()
+        self.lib = self.ctx.lib
+        self.size = (size, size) if isinstance(size, int) else tuple(size)
+        self.max_batch = max_batch
+        arr, keep = _lib.make_params({k: v for k, v in params.items() if k.startswith(prefix)})
+        h = C.c_void_p()
+        check(self.lib.tn_densenet121_create(self.ctx.handle, arr, len(arr), prefix.encode(), self.size[0],
+                                             self.size[1], max_batch, C.byref(h)), "tn_densenet121_create")
+        del keep
+        self.handle = h
+        self.feature_dim = self.lib.tn_densenet121_feature_dim(h)
+        self.workspace_bytes = self.lib.tn_densenet121_workspace_bytes(h)
+
+    def __call__(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        if not x.is_cuda:
+            raise ValueError("frames must already be on the GPU")
+        x = x.contiguous()
+        layout = _layout_of(x, self.size)
+        b = x.shape[0]
+        if out is None:
+            out = torch.empty((b, self.feature_dim), dtype=torch.float32, device=x.device)
+        check(self.lib.tn_densenet121_forward(self.handle, ptr(x), layout, b, ptr(out)), "tn_densenet121_forward")
+        return out
+
+    def profile(self, x: torch.Tensor):
+        """One forward with every launch bracketed by HIP events -> list of dicts."""
+        x = x.contiguous()
+        layout = _layout_of(x, self.size)
+        b = x.shape[0]
+        out = torch.empty((b, self.feature_dim), dtype=torch.float32, device=x.device)
+        stats = (_lib.TnKernelStat * 16)()
+        n = C.c_int(0)
+        check(self.lib.tn_densenet121_profile(self.handle, ptr(x), layout, b, ptr(out), stats, 16, C.byref(n)),
+              "tn_densenet121_profile")
+        return [dict(name=stats[i].name.decode(), launches=stats[i].launches, ms=stats[i].ms,
+                     flops=stats[i].flops, bytes=stats[i].bytes) for i in range(n.value)], out
+
+    def read_tap(self, tap: str, batch: int) -> np.ndarray:
+        buf = np.empty(self._tap_numel(batch), dtype=np.float32)
+        n = C.c_size_t(0)
+        check(self.lib.tn_densenet121_read_tap(self.handle, tap.encode(), batch,
+                                               buf.ctypes.data_as(C.c_void_p), buf.size, C.byref(n)),
+              "tn_densenet121_read_tap")
+        return buf[:n.value]
+
+    def _tap_numel(self, batch):
+        hs = (self.size[0] - 1) // 2 + 1
+        ws = (self.size[1] - 1) // 2 + 1
+        return batch * hs * ws * 64  # stem / stage1 taps are the largest
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.tn_densenet121_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class Dense:
+    """``nn.Dense(units, flatten=True)`` (reference definitions.py:25)."""
+
+    def __init__(self, weight: np.ndarray, bias: np.ndarray | None, ctx: _lib.Context | None = None):
+        self.ctx = ctx or _lib.default_context()
+        self.lib = self.ctx.lib
+        w = np.ascontiguousarray(weight, dtype=np.float32)
+        b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+        self.units, self.in_units = w.shape
+        h = C.c_void_p()
+        check(self.lib.tn_dense_create(self.ctx.handle, w.ctypes.data_as(C.c_void_p),
+                                       None if b is None else b.ctypes.data_as(C.c_void_p),
+                                       self.units, self.in_units, C.byref(h)), "tn_dense_create")
+        self.handle = h
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        x = x.reshape(x.shape[0], -1).contiguous().float()
+        if x.shape[1] != self.in_units:
+            raise ValueError(f"Dense expects {self.in_units} input units, got {x.shape[1]}")
+        y = torch.empty((x.shape[0], self.units), dtype=torch.float32, device=x.device)
+        check(self.lib.tn_dense_forward(self.handle, ptr(x), x.shape[0], ptr(y)), "tn_dense_forward")
+        return y
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.tn_dense_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class BiRNN:
+    """``mx.gluon.rnn.GRU/LSTM(hidden, layout='NTC', bidirectional=...)`` (definitions.py:94-96)."""
+
+    def __init__(self, mode: str, input_size: int, hidden: int, params: dict, prefix: str,
+                 bidirectional: bool = True, max_rows: int = 4096, ctx: _lib.Context | None = None):
+        self.ctx = ctx or _lib.default_context()
+        self.lib = self.ctx.lib
+        self.mode, self.hidden, self.input_size = mode, hidden, input_size
+        self.dirs = 2 if bidirectional else 1
+        self.max_rows = max_rows
+        arr, keep = _lib.make_params({k: v for k, v in params.items() if k.startswith(prefix)})
+        h = C.c_void_p()
+        kind = _lib.RNN_GRU if mode == "gru" else _lib.RNN_LSTM
+        check(self.lib.tn_birnn_create(self.ctx.handle, kind, input_size, hidden, arr, len(arr), prefix.encode(),
+                                       1 if bidirectional else 0, max_rows, C.byref(h)), "tn_birnn_create")
+        del keep
+        self.handle = h
+
+    def __call__(self, x: torch.Tensor, valid_length: torch.Tensor | None = None, return_state: bool = False):
+        x = x.contiguous().float()
+        b, t, f = x.shape
+        if f != self.input_size:
+            raise ValueError(f"rnn expects {self.input_size} input features, got {f}")
+        seq = torch.empty((b, t, self.dirs * self.hidden), dtype=torch.float32, device=x.device)
+        hl = torch.empty((self.dirs, b, self.hidden), dtype=torch.float32, device=x.device)
+        cl = torch.zeros_like(hl)
+        vl = None if valid_length is None else valid_length.to(device=x.device, dtype=torch.int32).contiguous()
+        check(self.lib.tn_birnn_forward(self.handle, ptr(x), b, t, ptr(vl), ptr(seq), ptr(hl), ptr(cl)),
+              "tn_birnn_forward")
+        return (seq, hl, cl) if return_state else seq
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.tn_birnn_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def temporal_pool(x: torch.Tensor, kind: str, ctx: _lib.Context | None = None) -> torch.Tensor:
+    """``F.max(x, axis=1)`` / ``F.mean(x, axis=1)`` (definitions.py:66-69,107)."""
+    ctx = ctx or _lib.default_context()
+    x = x.contiguous().float()
+    b, t = x.shape[:2]
+    f = int(np.prod(x.shape[2:]))
+    y = torch.empty((b,) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    check(ctx.lib.tn_temporal_pool(ctx.handle, ptr(x), b, t, f, _lib.POOL_MEAN if kind == "mean" else _lib.POOL_MAX,
+                                   ptr(y)), "tn_temporal_pool")
+    return y

@@ -1,0 +1,171 @@
+"""Seeded synthetic parameters for the hot path, keyed by Gluon parameter names.
+
+The reference never ships weights in-tree: the frame encoder comes from
+``gluoncv.model_zoo.get_model('DenseNet121', pretrained=True).features``
+(reference evaluate.py:125, train.py:204) and trained checkpoints live on
+Google Drive (reference models/README.md:2).  With no network, every test,
+the oracle and the bench use the seeded tensors made here.  Keys follow the
+Gluon naming convention [EXT, SURVEY App. B] so that a ``.params`` reader can
+drop real checkpoints in later (SURVEY §8b "Weights format").
+
+Shapes follow Gluon: conv ``(C_out, C_in, kh, kw)``, dense ``(units, in)``,
+RNN ``{l,r}0_i2h_weight (G*H, F)``, ``{l,r}0_h2h_weight (G*H, H)``.
+
+Statistics are chosen so that activations stay O(1) through all 120
+convolutions: He-normal conv weights; BN gamma near 1,
+beta near 0, running_mean near 0 and running_var near the analytic variance of
+the producing op.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+GROWTH = 32
+BN_SIZE = 4
+INIT_FEATURES = 64
+BLOCK_CONFIG = (6, 12, 24, 16)
+BN_EPS = 1e-5
+
+
+def densenet121_layout():
+    """Static description of DenseNet-121 ``.features``.
+
+    Returns a list of dicts, one per conv, in execution order:
+    ``{"name", "kind": stem|dense1x1|dense3x3|trans, "cin", "cout", "stage", "layer"}``
+    plus the matching BN name in ``"bn"`` (the BN that precedes the conv, or for
+    the stem the BN that follows it).
+    """
+    convs = [dict(name="conv0", bn="batchnorm0", kind="stem", cin=3, cout=INIT_FEATURES, stage=0, layer=0)]
+    c = INIT_FEATURES
+    outer = 1
+    for si, nl in enumerate(BLOCK_CONFIG):
+        st = si + 1
+        for li in range(nl):
+            convs.append(dict(name=f"stage{st}_conv{2 * li}", bn=f"stage{st}_batchnorm{2 * li}",
+                              kind="dense1x1", cin=c + GROWTH * li, cout=BN_SIZE * GROWTH, stage=st, layer=li))
+            convs.append(dict(name=f"stage{st}_conv{2 * li + 1}", bn=f"stage{st}_batchnorm{2 * li + 1}",
+                              kind="dense3x3", cin=BN_SIZE * GROWTH, cout=GROWTH, stage=st, layer=li))
+        c += GROWTH * nl
+        if si != len(BLOCK_CONFIG) - 1:
+            convs.append(dict(name=f"conv{outer}", bn=f"batchnorm{outer}", kind="trans",
+                              cin=c, cout=c // 2, stage=st, layer=0))
+            c //= 2
+            outer += 1
+    return convs, f"batchnorm{outer}", c  # final BN name, final channel count (1024)
+
+
+def _bn(rng, prefix, c, var_center=1.0):
+    return {
+        prefix + "_gamma": rng.uniform(0.8, 1.2, c).astype(np.float32),
+        prefix + "_beta": rng.normal(0.0, 0.1, c).astype(np.float32),
+        prefix + "_running_mean": rng.normal(0.0, 0.1, c).astype(np.float32),
+        prefix + "_running_var": (var_center * rng.uniform(0.8, 1.2, c)).astype(np.float32),
+    }
+
+
+def make_densenet121_weights(seed: int = 0, prefix: str = "densenet0_", in_channels: int = 3):
+    """Seeded DenseNet-121 ``.features`` parameters (6.87 M conv weights + 121 BN)."""
+    rng = np.random.default_rng(seed)
+    convs, final_bn, cfin = densenet121_layout()
+    p = {}
+    for cv in convs:
+        k = {"stem": 7, "dense1x1": 1, "dense3x3": 3, "trans": 1}[cv["kind"]]
+        cin = in_channels if cv["kind"] == "stem" else cv["cin"]
+        fan_in = cin * k * k
+        w = rng.normal(0.0, np.sqrt(2.0 / fan_in), (cv["cout"], cin, k, k)).astype(np.float32)
+        p[prefix + cv["name"] + "_weight"] = w
+        if cv["kind"] == "stem":
+            # BN follows the stem conv; normalised uniform-u8 pixels have E[x^2]~1.7
+            p.update(_bn(rng, prefix + cv["bn"], cv["cout"], var_center=3.4))
+        else:
+            p.update(_bn(rng, prefix + cv["bn"], cin))
+    p.update(_bn(rng, prefix + final_bn, cfin))
+    return p
+
+
+def make_dense_weights(seed: int, units: int, in_units: int, prefix: str):
+    """``nn.Dense`` parameters (reference definitions.py:25,58,60,101)."""
+    rng = np.random.default_rng(seed)
+    return {
+        prefix + "weight": rng.uniform(-0.07, 0.07, (units, in_units)).astype(np.float32),
+        prefix + "bias": rng.uniform(-0.1, 0.1, units).astype(np.float32),
+    }
+
+
+def make_rnn_weights(seed: int, mode: str, input_size: int, hidden: int, prefix: str,
+                     bidirectional: bool = True):
+    """``mx.gluon.rnn.GRU/LSTM`` single-layer parameters (reference definitions.py:94-96).
+
+    Gate order [EXT, SURVEY App. B]: GRU ``[r, z, n]``, LSTM ``[i, f, g, o]``.
+    """
+    g = {"gru": 3, "lstm": 4}[mode]
+    rng = np.random.default_rng(seed)
+    p = {}
+    for d in (["l", "r"] if bidirectional else ["l"]):
+        si = 1.0 / np.sqrt(input_size)
+        sh = 1.0 / np.sqrt(hidden)
+        p[f"{prefix}{d}0_i2h_weight"] = rng.uniform(-si, si, (g * hidden, input_size)).astype(np.float32)
+        p[f"{prefix}{d}0_h2h_weight"] = rng.uniform(-sh, sh, (g * hidden, hidden)).astype(np.float32)
+        p[f"{prefix}{d}0_i2h_bias"] = rng.uniform(-sh, sh, g * hidden).astype(np.float32)
+        p[f"{prefix}{d}0_h2h_bias"] = rng.uniform(-sh, sh, g * hidden).astype(np.float32)
+    return p
+
+
+def make_gnmt_weights(seed: int, cell_type: str, input_size: int, hidden: int, embed: int, vocab: int,
+                      num_layers: int = 2, num_bi_layers: int = 1, prefix: str = "gnmt_"):
+    """Parameters of the reference captioner (gnmt.py:71-111,197-222; train_gnmt.py:211-233).
+
+    Encoder: ``num_bi_layers`` bidirectional cell layers then uni-directional
+    cell layers; decoder: ``num_layers`` cells, first takes ``[embed, H]``,
+    others ``[H, H]``; scaled-Luong attention has one bias-free key projection
+    ``(H, H)`` [EXT]; ``tgt_proj`` Dense(V) with bias; ``tgt_embed`` (V, embed).
+    Default init in the reference is ``Uniform(0.1)`` (train_gnmt.py:231) with
+    ``LSTMBias(1.0)`` for i2h biases (gnmt.py:410).
+    """
+    g = {"gru": 3, "lstm": 4}[cell_type]
+    rng = np.random.default_rng(seed)
+    u = lambda *s: rng.uniform(-0.1, 0.1, s).astype(np.float32)
+    p = {}
+
+    def cell(pref, fin):
+        p[pref + "i2h_weight"] = u(g * hidden, fin)
+        p[pref + "h2h_weight"] = u(g * hidden, hidden)
+        p[pref + "i2h_bias"] = u(g * hidden)
+        p[pref + "h2h_bias"] = u(g * hidden)
+
+    fin = input_size
+    for i in range(num_layers):
+        if i < num_bi_layers:
+            cell(f"{prefix}enc_rnn{i}_l_", fin)
+            cell(f"{prefix}enc_rnn{i}_r_", fin)
+            fin = 2 * hidden
+        else:
+            cell(f"{prefix}enc_rnn{i}_", fin)
+            fin = hidden
+    for i in range(num_layers):
+        cell(f"{prefix}dec_rnn{i}_", (embed + hidden) if i == 0 else 2 * hidden)
+    p[prefix + "dec_attention_key_weight"] = u(hidden, hidden)
+    p[prefix + "tgt_proj_weight"] = u(vocab, hidden)
+    p[prefix + "tgt_proj_bias"] = u(vocab)
+    emb = rng.normal(0.0, 1.0, (vocab, embed)).astype(np.float32)
+    emb /= np.linalg.norm(emb, axis=1, keepdims=True)  # rows L2-normalised like data/embeddings-ex.txt
+    emb[:4] = 0.0  # <unk>,<pad>,<bos>,<eos> get zero vectors (Vocab.set_embedding)
+    p[prefix + "tgt_embed_weight"] = emb
+    return p
+
+
+def synthetic_frames_u8(n: int, size: int = 224, seed: int = 1234) -> np.ndarray:
+    """NHWC uint8 frames, uniform [0,255] (SURVEY §8d synthetic inputs)."""
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, (n, size, size, 3), dtype=np.uint8)
+
+
+IMAGENET_MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32)
+IMAGENET_STD = np.array([0.229, 0.224, 0.225], dtype=np.float32)
+
+
+def normalize_to_nchw_f32(frames_u8: np.ndarray) -> np.ndarray:
+    """``ToTensor`` + ``Normalize`` of the reference test transform (evaluate.py:96-97)."""
+    x = frames_u8.astype(np.float32) / 255.0
+    x = (x - IMAGENET_MEAN) / IMAGENET_STD
+    return np.ascontiguousarray(x.transpose(0, 3, 1, 2))

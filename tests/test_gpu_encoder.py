@@ -1,0 +1,84 @@
+"""-m gpu: the whole DenseNet-121 frame encoder through the C ABI vs the fp32 CPU oracle.
+
+Tolerance (BASELINE.json north_star): features/logits within 1e-3 absolute of the
+fp32 CPU path.  Inputs are fp16-representable so that input quantisation is not
+charged to the kernels; per-stage errors are recorded in gpurun_out/parity_report.json.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import densenet_np as dn
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from tennis_amd import weights as W
+    from tennis_amd.engine import DenseNet121Features
+    p = W.make_densenet121_weights(0)
+    p.update(W.make_dense_weights(1, 11, 1024, "framemodel0_dense0_"))
+    enc = DenseNet121Features(p, 224, max_batch=4)
+    frames = W.synthetic_frames_u8(2, 224)
+    x32 = W.normalize_to_nchw_f32(frames)
+    x16 = x32.astype(np.float16)          # NCHW fp16-representable values
+    taps = {}
+    ref = dn.densenet121_features(x16.astype(np.float32), p, taps=taps)
+    return dict(p=p, enc=enc, frames=frames, x16=x16, ref=ref, taps=taps)
+
+
+def test_encoder_stages(setup, report):
+    enc, x16 = setup["enc"], setup["x16"]
+    xd = torch.from_numpy(np.ascontiguousarray(x16.transpose(0, 2, 3, 1))).cuda()  # NHWC fp16
+    feat = enc(xd).cpu().numpy()
+    worst = {}
+    for tap in ["stem", "pool0", "stage1", "trans1", "stage2", "trans2", "stage3", "trans3", "stage4"]:
+        ref = setup["taps"][tap]
+        got = enc.read_tap(tap, 2).reshape(ref.shape)
+        e = float(np.abs(got - ref).max())
+        worst[tap] = e
+        report[f"encoder_tap_{tap}_maxabs"] = e
+        report[f"encoder_tap_{tap}_refabsmax"] = float(np.abs(ref).max())
+    e = float(np.abs(feat - setup["ref"]).max())
+    report["encoder_feat_maxabs_err"] = e
+    report["encoder_feat_mean_abs_err"] = float(np.abs(feat - setup["ref"]).mean())
+    # stage activations are fp16 (half-ulp up to 4e-3 at |x|~8): loose per-stage sanity bound
+    for tap, v in worst.items():
+        assert v < 0.1, (tap, v)
+    assert e < TOL, f"feature max abs err {e} vs fp32 oracle"
+
+
+def test_encoder_layouts_agree(setup, report):
+    """NCHW fp32 (reference layout), NHWC fp16 and NHWC u8 inputs give the same features."""
+    enc = setup["enc"]
+    x16 = setup["x16"]
+    f_nhwc = enc(torch.from_numpy(np.ascontiguousarray(x16.transpose(0, 2, 3, 1))).cuda()).cpu().numpy()
+    f_nchw = enc(torch.from_numpy(x16.astype(np.float32)).cuda()).cpu().numpy()
+    assert np.array_equal(f_nhwc, f_nchw)
+    f_u8 = enc(torch.from_numpy(setup["frames"]).cuda()).cpu().numpy()
+    e = float(np.abs(f_u8 - setup["ref"]).max())
+    report["encoder_u8_feat_maxabs_err"] = e
+    assert e < 5e-3, e   # u8 path re-derives the normalised pixel (one extra fp16 rounding of the input)
+
+
+def test_frame_logits(setup, report):
+    from tennis_amd.engine import Dense
+    p, enc = setup["p"], setup["enc"]
+    xd = torch.from_numpy(np.ascontiguousarray(setup["x16"].transpose(0, 2, 3, 1))).cuda()
+    cls = Dense(p["framemodel0_dense0_weight"], p["framemodel0_dense0_bias"])
+    logits = cls(enc(xd)).cpu().numpy()
+    ref = dn.dense(setup["ref"], p, "framemodel0_dense0_")
+    e = float(np.abs(logits - ref).max())
+    report["frame_logits_maxabs_err"] = e
+    assert e < TOL, e
+
+
+def test_determinism(setup):
+    enc = setup["enc"]
+    xd = torch.from_numpy(np.ascontiguousarray(setup["x16"].transpose(0, 2, 3, 1))).cuda()
+    a = enc(xd).cpu().numpy()
+    b = enc(xd).cpu().numpy()
+    assert np.array_equal(a, b)

@@ -1,0 +1,168 @@
+"""-m gpu: each HIP kernel on its own against the CPU oracle (through the C ABI).
+
+Kernel-level references emulate the kernel's two fp16 roundings (BN+ReLU output
+and fp16 weights) so that indexing/layout bugs show up as O(1) errors while the
+tolerance stays tight; the fp32-oracle comparison of the whole encoder lives in
+test_gpu_encoder.py.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import densenet_np as dn
+from oracle import rnn_np as rn
+from oracle import vision_np as vn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from tennis_amd import _lib
+    return _lib.default_context(0)
+
+
+def _h(x):  # round to fp16, back to fp32
+    return x.astype(np.float16).astype(np.float32)
+
+
+def _bnrelu_h(x, s, t):
+    return _h(np.maximum(x * s + t, 0.0).astype(np.float32))
+
+
+@pytest.mark.parametrize("M,K,ldx,N,yoff,ldy", [
+    (1000, 64, 256, 128, 0, 128),      # ragged M, block-1 first layer
+    (128 * 600, 96, 256, 128, 0, 128),  # BM=128 path, K tail (96 = 64+32)
+    (64 * 600 + 7, 224, 512, 128, 0, 128),  # BM=64 path
+    (300, 1024 - 32, 1024, 128, 8, 144),  # BM=32 path, output offset
+])
+def test_conv1x1(ctx, report, M, K, ldx, N, yoff, ldy):
+    from tennis_amd import _lib
+    rng = np.random.default_rng(M + K)
+    x = rng.normal(0, 1.5, (M, ldx)).astype(np.float16)
+    s = rng.uniform(0.5, 1.5, K).astype(np.float32)
+    t = rng.normal(0, 0.3, K).astype(np.float32)
+    w = rng.normal(0, np.sqrt(2.0 / K), (N, K)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.full((M, ldy), 7.0, dtype=torch.float16, device="cuda")
+    _lib.check(ctx.lib.tn_dbg_conv1x1(ctx.handle, _lib.ptr(xd), ldx, K, s.ctypes.data_as(C.c_void_p),
+                                      t.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), N, _lib.ptr(yd),
+                                      ldy, yoff, M, 0, 0, 0), "dbg_conv1x1")
+    y = yd.cpu().numpy().astype(np.float32)
+    ref = _bnrelu_h(x[:, :K].astype(np.float32), s, t) @ _h(w).T
+    err = np.abs(y[:, yoff:yoff + N] - ref).max()
+    report[f"conv1x1_M{M}_K{K}"] = float(err)
+    assert err < 2e-2 * max(1.0, np.abs(ref).max() / 8), err
+    # untouched columns keep their sentinel
+    if ldy > N:
+        mask = np.ones(ldy, bool); mask[yoff:yoff + N] = False
+        assert np.all(y[:, mask] == 7.0)
+
+
+@pytest.mark.parametrize("B,H,W,K,N", [(2, 28, 28, 512, 256), (3, 14, 14, 1024, 512), (1, 56, 56, 256, 128)])
+def test_conv1x1_pool(ctx, report, B, H, W, K, N):
+    from tennis_amd import _lib
+    rng = np.random.default_rng(B * H + K)
+    x = rng.normal(0, 1.5, (B, H, W, K)).astype(np.float16)
+    s = rng.uniform(0.5, 1.5, K).astype(np.float32)
+    t = rng.normal(0, 0.3, K).astype(np.float32)
+    w = rng.normal(0, np.sqrt(2.0 / K), (N, K)).astype(np.float32)
+    Mo = B * (H // 2) * (W // 2)
+    ldy = N + 64
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.zeros((Mo, ldy), dtype=torch.float16, device="cuda")
+    _lib.check(ctx.lib.tn_dbg_conv1x1(ctx.handle, _lib.ptr(xd), K, K, s.ctypes.data_as(C.c_void_p),
+                                      t.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), N, _lib.ptr(yd),
+                                      ldy, 0, Mo, 1, H, W), "dbg_conv1x1 pool")
+    y = yd.cpu().numpy().astype(np.float32)[:, :N]
+    a = np.maximum(x.astype(np.float32) * s + t, 0.0)
+    a = _h(dn.avgpool(a, 2))
+    ref = (a.reshape(-1, K) @ _h(w).T)
+    err = np.abs(y - ref).max()
+    report[f"conv1x1_pool_{B}x{H}x{W}x{K}"] = float(err)
+    assert err < 2e-2, err
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 14, 14), (3, 7, 7), (1, 56, 56), (2, 28, 28), (1, 9, 13)])
+def test_conv3x3(ctx, report, B, H, W):
+    from tennis_amd import _lib
+    rng = np.random.default_rng(B * 100 + H)
+    x = rng.normal(0, 1.5, (B, H, W, 128)).astype(np.float16)
+    s = rng.uniform(0.5, 1.5, 128).astype(np.float32)
+    t = rng.normal(0, 0.3, 128).astype(np.float32)
+    w = rng.normal(0, np.sqrt(2.0 / 1152), (32, 128, 3, 3)).astype(np.float32)
+    ldy, yoff = 96, 40
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.full((B * H * W, ldy), 3.0, dtype=torch.float16, device="cuda")
+    _lib.check(ctx.lib.tn_dbg_conv3x3(ctx.handle, _lib.ptr(xd), s.ctypes.data_as(C.c_void_p),
+                                      t.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), _lib.ptr(yd), ldy,
+                                      yoff, B, H, W), "dbg_conv3x3")
+    y = yd.cpu().numpy().astype(np.float32)
+    a = _bnrelu_h(x.astype(np.float32), s, t)
+    ref = dn.conv2d_nhwc(a, _h(w), 1, 1).reshape(-1, 32)
+    err = np.abs(y[:, yoff:yoff + 32] - ref).max()
+    report[f"conv3x3_{B}x{H}x{W}"] = float(err)
+    assert err < 2e-2, err
+    mask = np.ones(ldy, bool); mask[yoff:yoff + 32] = False
+    assert np.all(y[:, mask] == 3.0)
+
+
+@pytest.mark.parametrize("M,N,K", [(70, 11, 1024), (2048, 768, 1024), (33, 254, 356), (5, 7, 3)])
+def test_linear(ctx, report, M, N, K):
+    from tennis_amd import _lib
+    rng = np.random.default_rng(M + N + K)
+    x = rng.normal(0, 1, (M, K)).astype(np.float32)
+    w = rng.normal(0, 1 / np.sqrt(K), (N, K)).astype(np.float32)
+    b = rng.normal(0, 1, N).astype(np.float32)
+    xd, wd, bd = (torch.from_numpy(a).cuda() for a in (x, w, b))
+    yd = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    _lib.check(ctx.lib.tn_dbg_linear(ctx.handle, _lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(yd), M, N, K),
+               "dbg_linear")
+    ref = x.astype(np.float64) @ w.T.astype(np.float64) + b
+    err = np.abs(yd.cpu().numpy() - ref).max()
+    report[f"linear_{M}x{N}x{K}"] = float(err)
+    assert err < 1e-4, err
+
+
+@pytest.mark.parametrize("mode,B,T,F,H,use_vl", [("gru", 5, 9, 64, 128, False), ("lstm", 3, 7, 100, 128, False),
+                                                  ("gru", 6, 11, 48, 256, True), ("lstm", 2, 5, 32, 64, True)])
+def test_birnn(ctx, report, mode, B, T, F, H, use_vl):
+    from tennis_amd import weights as Wt
+    from tennis_amd.engine import BiRNN
+    p = Wt.make_rnn_weights(3, mode, F, H, "rnn_")
+    rng = np.random.default_rng(7)
+    x = rng.normal(0, 1, (B, T, F)).astype(np.float32)
+    vl = rng.integers(1, T + 1, B).astype(np.int32) if use_vl else None
+    if vl is not None:
+        vl[0] = T
+    net = BiRNN(mode, F, H, p, "rnn_", True, max_rows=B * T, ctx=ctx)
+    seq, hl, cl = net(torch.from_numpy(x).cuda(), None if vl is None else torch.from_numpy(vl).cuda(), True)
+    ref, (fh, fc), (bh, bc) = rn.birnn_layer(x, p, "rnn_", mode, vl)
+    err = np.abs(seq.cpu().numpy() - ref).max()
+    errh = max(np.abs(hl[0].cpu().numpy() - fh).max(), np.abs(hl[1].cpu().numpy() - bh).max())
+    report[f"birnn_{mode}_{B}x{T}x{F}x{H}_{use_vl}"] = float(max(err, errh))
+    assert err < 1e-4 and errh < 1e-4, (err, errh)
+    if mode == "lstm":
+        errc = max(np.abs(cl[0].cpu().numpy() - fc).max(), np.abs(cl[1].cpu().numpy() - bc).max())
+        assert errc < 1e-4, errc
+
+
+def test_temporal_pool_and_prf1(ctx):
+    from tennis_amd import _lib
+    from tennis_amd.engine import temporal_pool
+    rng = np.random.default_rng(5)
+    x = rng.normal(0, 1, (4, 9, 37)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    assert np.allclose(temporal_pool(xd, "max", ctx).cpu().numpy(), x.max(1))
+    assert np.allclose(temporal_pool(xd, "mean", ctx).cpu().numpy(), x.mean(1), atol=1e-6)
+    logits = rng.normal(0, 1, (513, 11)).astype(np.float32)
+    logits[3, 2] = logits[3, 5] = 9.0  # tie -> first maximum
+    labels = rng.integers(0, 11, 513).astype(np.int32)
+    mat = torch.zeros((11, 11), dtype=torch.int64, device="cuda")
+    _lib.check(ctx.lib.tn_prf1_update(ctx.handle, _lib.ptr(torch.from_numpy(logits).cuda()),
+                                      _lib.ptr(torch.from_numpy(labels).cuda()), 513, 11, _lib.ptr(mat)), "prf1")
+    m = vn.PRF1([str(i) for i in range(11)])
+    m.update([labels], [logits])
+    assert np.array_equal(mat.cpu().numpy(), m.mat.astype(np.int64))
