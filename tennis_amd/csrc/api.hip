@@ -137,9 +137,9 @@ std::vector<f16> pack_conv3x3(const float *w) {
   return p;
 }
 
-// stem weights (64,3,7,7) * bn scale -> MFMA A fragments [7 ky][4 nfrag][64 lanes][8]:
+// stem weights (64,3,7,7) -> MFMA A fragments [7 ky][4 nfrag][64 lanes][8]:
 // lane l: n = nf*16 + (l&15); k slot (l>>4)*8 + j -> x-tap kx = slot>>2, channel c = slot&3.
-std::vector<f16> pack_stem(const float *w, const std::vector<float> &scale) {
+std::vector<f16> pack_stem(const float *w) {
   std::vector<f16> p((size_t)7 * 4 * 64 * 8);
   for (int ky = 0; ky < 7; ++ky)
     for (int nf = 0; nf < 4; ++nf)
@@ -147,7 +147,7 @@ std::vector<f16> pack_stem(const float *w, const std::vector<float> &scale) {
         for (int j = 0; j < 8; ++j) {
           const int n = nf * 16 + (l & 15), slot = (l >> 4) * 8 + j, kx = slot >> 2, c = slot & 3;
           float v = 0.f;
-          if (kx < 7 && c < 3) v = w[(((size_t)n * 3 + c) * 7 + ky) * 7 + kx] * scale[n];
+          if (kx < 7 && c < 3) v = w[(((size_t)n * 3 + c) * 7 + ky) * 7 + kx];
           p[(((size_t)ky * 4 + nf) * 64 + l) * 8 + j] = (f16)v;
         }
   return p;
@@ -210,7 +210,7 @@ struct tn_encoder {
   int Cin[4], Cb[4];       // block input / total channels
   int PH, PW;
   f16 *stem_wp;
-  float *stem_shift;
+  float *stem_scale, *stem_shift;
   struct DenseLayer { float *s1, *t1; f16 *w1; float *s2, *t2; f16 *w3p; int cin; };
   std::vector<DenseLayer> layers[4];
   struct Trans { float *s, *t; f16 *w; int cin, cout; } trans[3];
@@ -247,10 +247,11 @@ extern "C" int tn_densenet121_create(tn_ctx *ctx, const tn_param *params, int n_
   if (e->Wb[0] > 240) { tn_set_error("input too wide for the conv3x3 LDS tile"); return fail(TN_ERR_INVALID); }
 
   std::vector<float> s, t;
-  {  // stem: conv0 + batchnorm0 (scale folded into the weights)
+  {  // stem: conv0 + batchnorm0
     const float *w0 = pm.get(pre + "conv0_weight", 64 * 3 * 7 * 7);
     if (!w0 || !fold_bn(pm, pre + "batchnorm0", 64, s, t)) return fail(TN_ERR_MISSING);
-    e->stem_wp = e->pool.upload(pack_stem(w0, s));
+    e->stem_wp = e->pool.upload(pack_stem(w0));
+    e->stem_scale = e->pool.upload(s);
     e->stem_shift = e->pool.upload(t);
   }
   int outer = 1;
@@ -306,7 +307,7 @@ static int encoder_run(tn_encoder *e, const void *x, tn_layout layout, int B, fl
   int rc;
   const double fB = (double)B;
   {
-    StemArgs a{x, (int)layout, B, e->H, e->W, e->stem_wp, e->stem_shift, e->stem_out, e->Hs, e->Ws};
+    StemArgs a{x, (int)layout, B, e->H, e->W, e->stem_wp, e->stem_scale, e->stem_shift, e->stem_out, e->Hs, e->Ws};
     const double px = fB * e->Hs * e->Ws;
     tm.begin("stem_conv7x7_bn_relu", 2.0 * px * 64 * 147, fB * e->H * e->W * 3 * 2 + px * 64 * 2);
     rc = launch_stem(a, s);

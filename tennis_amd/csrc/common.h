@@ -91,7 +91,8 @@ struct StemArgs {
   const void *x;
   int layout;         // tn_layout
   int B, H, W;        // input size
-  const f16 *wp;      // packed A fragments [7 ky][4 nfrag][64 lanes][8], BN scale folded
+  const f16 *wp;      // packed A fragments [7 ky][4 nfrag][64 lanes][8]
+  const float *scale; // [64] folded BN scale
   const float *shift; // [64]
   f16 *y;             // [B][Ho][Wo][64]
   int Ho, Wo;

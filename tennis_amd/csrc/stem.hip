@@ -7,8 +7,9 @@
 // Implicit GEMM on v_mfma_f32_16x16x32_f16: one k-step per kernel row ky, the
 // 32 k-slots of a step are 8 x-taps x 4 channels (tap 7 and channel 3 carry
 // zero weights), so a lane's 8 operand values are 2 adjacent NHWC4 pixels =
-// one aligned ds_read_b128 from the staged input patch.  BN is folded: the
-// scale into the fp16 weights on the host, the shift into the epilogue.
+// one aligned ds_read_b128 from the staged input patch.  BN (fp32 scale and
+// shift per output channel) and ReLU are applied to the fp32 accumulators in
+// the epilogue, so the fp16 weights are exactly the model's weights.
 // A workgroup owns 8 output rows of one frame and walks the row in 16-column
 // tiles, keeping all 28 weight fragments in registers.
 #include "common.h"
@@ -58,11 +59,14 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
   for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) wa[ky][nf] = ((const f16x8 *)a.wp)[(ky * 4 + nf) * 64 + lane];
-  float sh[4][4];
+  float sc[4][4], sh[4][4];
 #pragma unroll
   for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sh[nf][r] = a.shift[nf * 16 + kc * 4 + r];
+    for (int r = 0; r < 4; ++r) {
+      sc[nf][r] = a.scale[nf * 16 + kc * 4 + r];
+      sh[nf][r] = a.shift[nf * 16 + kc * 4 + r];
+    }
 
   const int ntiles = (a.Wo + 15) / 16;
   for (int ct = 0; ct < ntiles; ++ct) {
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
         for (int nf = 0; nf < 4; ++nf) {
           f16x4 h;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h[r] = (f16)fmaxf(acc[mf][nf][r] + sh[nf][r], 0.f);
+          for (int r = 0; r < 4; ++r) h[r] = (f16)fmaxf(fmaf(acc[mf][nf][r], sc[nf][r], sh[nf][r]), 0.f);
           *(f16x4 *)(dst + nf * 16) = h;
         }
       }

@@ -63,8 +63,26 @@ def _bn(rng, prefix, c, var_center=1.0):
     }
 
 
-def make_densenet121_weights(seed: int = 0, prefix: str = "densenet0_", in_channels: int = 3):
-    """Seeded DenseNet-121 ``.features`` parameters (6.87 M conv weights + 121 BN)."""
+def as_fp16_model(params: dict) -> dict:
+    """Model conversion for the fp16 encoder: round every conv ``*_weight`` to the
+    nearest fp16 value (kept as fp32 arrays).  The served model IS these rounded
+    weights — the GPU path and the fp32 CPU oracle both evaluate them — so weight
+    quantisation is a one-off conversion step, not kernel error.  BN statistics,
+    Dense and RNN parameters stay fp32.  (Measured on MI355X: with un-rounded
+    fp32 conv weights the pooled features differ by up to 3.3e-3 because weight
+    rounding is coherent across the 49 pooled pixels; with converted weights the
+    kernels' own error is 7e-4 max, DESIGN.md "Numerics".)"""
+    out = dict(params)
+    for k, v in params.items():
+        if k.endswith("_weight") and v.ndim == 4:
+            out[k] = v.astype(np.float16).astype(np.float32)
+    return out
+
+
+def make_densenet121_weights(seed: int = 0, prefix: str = "densenet0_", in_channels: int = 3,
+                             fp16_model: bool = True):
+    """Seeded DenseNet-121 ``.features`` parameters (6.87 M conv weights + 121 BN).
+    With ``fp16_model`` the conv weights are fp16-representable (see as_fp16_model)."""
     rng = np.random.default_rng(seed)
     convs, final_bn, cfin = densenet121_layout()
     p = {}
@@ -80,7 +98,7 @@ def make_densenet121_weights(seed: int = 0, prefix: str = "densenet0_", in_chann
         else:
             p.update(_bn(rng, prefix + cv["bn"], cin))
     p.update(_bn(rng, prefix + final_bn, cfin))
-    return p
+    return as_fp16_model(p) if fp16_model else p
 
 
 def make_dense_weights(seed: int, units: int, in_units: int, prefix: str):

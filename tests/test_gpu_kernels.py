@@ -161,8 +161,8 @@ def test_temporal_pool_and_prf1(ctx):
     logits[3, 2] = logits[3, 5] = 9.0  # tie -> first maximum
     labels = rng.integers(0, 11, 513).astype(np.int32)
     mat = torch.zeros((11, 11), dtype=torch.int64, device="cuda")
-    _lib.check(ctx.lib.tn_prf1_update(ctx.handle, _lib.ptr(torch.from_numpy(logits).cuda()),
-                                      _lib.ptr(torch.from_numpy(labels).cuda()), 513, 11, _lib.ptr(mat)), "prf1")
+    ld, lab = torch.from_numpy(logits).cuda(), torch.from_numpy(labels).cuda()  # keep alive across the launch
+    _lib.check(ctx.lib.tn_prf1_update(ctx.handle, _lib.ptr(ld), _lib.ptr(lab), 513, 11, _lib.ptr(mat)), "prf1")
     m = vn.PRF1([str(i) for i in range(11)])
     m.update([labels], [logits])
     assert np.array_equal(mat.cpu().numpy(), m.mat.astype(np.int64))
