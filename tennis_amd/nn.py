@@ -1,0 +1,124 @@
+"""Gluon-named leaf blocks backed by the HIP library: Dense, GRU/LSTM layers and
+the DenseNet-121 ``.features`` backbone (model_zoo.get_model)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import engine, weights as W
+from .block import Block, Parameter
+
+
+def _to_device(x):
+    """Accept numpy or torch (cpu/cuda); return a cuda tensor (device plumbing only)."""
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(x)
+    return x if x.is_cuda else x.cuda()
+
+
+class Dense(Block):
+    """``nn.Dense(units, flatten=True)`` with deferred input size (reference definitions.py:25)."""
+
+    def __init__(self, units, flatten=True, in_units=0, seed=1, **kwargs):
+        super().__init__(hint="dense", **kwargs)
+        self._units, self._in_units, self._seed = units, in_units, seed
+        self._own_params[self.prefix + "weight"] = Parameter(self.prefix + "weight")
+        self._own_params[self.prefix + "bias"] = Parameter(self.prefix + "bias")
+
+    def _materialize(self, in_units):
+        w = self._own_params[self.prefix + "weight"]
+        if w.data is None:
+            p = W.make_dense_weights(self._seed, self._units, in_units, self.prefix)
+            self._adopt(p)
+        self._in_units = w.data.shape[1]
+
+    def forward(self, x):
+        x = _to_device(x)
+        x = x.reshape(x.shape[0], -1)
+        self._materialize(x.shape[1])
+        if self._engine is None:
+            self._engine = engine.Dense(self._own_params[self.prefix + "weight"].data,
+                                        self._own_params[self.prefix + "bias"].data)
+        return self._engine(x)
+
+
+class _RNNLayer(Block):
+    _mode = "gru"
+
+    def __init__(self, hidden_size, num_layers=1, layout="NTC", bidirectional=False, input_size=0, seed=2,
+                 **kwargs):
+        super().__init__(hint=self._mode, **kwargs)
+        if num_layers != 1 or layout != "NTC":
+            raise NotImplementedError("only single-layer NTC recurrent layers are on the hot path "
+                                      "(reference definitions.py:94-96)")
+        self._hidden, self._bi, self._input_size, self._seed = hidden_size, bidirectional, input_size, seed
+        for d in (["l", "r"] if bidirectional else ["l"]):
+            for n in ("i2h_weight", "h2h_weight", "i2h_bias", "h2h_bias"):
+                k = f"{self.prefix}{d}0_{n}"
+                self._own_params[k] = Parameter(k)
+
+    def _materialize(self, f):
+        if next(iter(self._own_params.values())).data is None:
+            self._adopt(W.make_rnn_weights(self._seed, self._mode, f, self._hidden, self.prefix, self._bi))
+        self._input_size = self._own_params[f"{self.prefix}l0_i2h_weight"].data.shape[1]
+
+    def forward(self, x, valid_length=None):
+        x = _to_device(x)
+        b, t, f = x.shape
+        self._materialize(f)
+        if self._engine is None or self._engine.max_rows < b * t:
+            p = {k: v.data for k, v in self._own_params.items()}
+            self._engine = engine.BiRNN(self._mode, self._input_size, self._hidden, p, self.prefix, self._bi,
+                                        max_rows=max(b * t, 4096))
+        return self._engine(x, valid_length)
+
+
+class GRU(_RNNLayer):
+    """``mx.gluon.rnn.GRU`` (reference definitions.py:96)."""
+    _mode = "gru"
+
+
+class LSTM(_RNNLayer):
+    """``mx.gluon.rnn.LSTM`` (reference definitions.py:94)."""
+    _mode = "lstm"
+
+
+class DenseNet121Backbone(Block):
+    """``get_model('DenseNet121', ...).features`` (reference evaluate.py:125): frames -> (B, F) fp32."""
+
+    def __init__(self, seed=0, prefix="densenet0_", max_batch=256, **kwargs):
+        super().__init__(prefix=prefix, **kwargs)
+        self._seed, self._max_batch = seed, max_batch
+        convs, final_bn, cfin = W.densenet121_layout()
+        names = []
+        for cv in convs:
+            names.append(prefix + cv["name"] + "_weight")
+            names += [prefix + cv["bn"] + s for s in ("_gamma", "_beta", "_running_mean", "_running_var")]
+        names += [prefix + final_bn + s for s in ("_gamma", "_beta", "_running_mean", "_running_var")]
+        for n in names:
+            self._own_params[n] = Parameter(n)
+        self._size = None
+
+    def initialize(self, *a, **k):
+        super().initialize(*a, **k)
+        if next(iter(self._own_params.values())).data is None:
+            self._adopt(W.make_densenet121_weights(self._seed, self.prefix))
+
+    def _adopt(self, params):
+        super()._adopt(W.as_fp16_model({k: v for k, v in params.items() if k in self._own_params}))
+
+    def forward(self, x):
+        x = _to_device(x)
+        if next(iter(self._own_params.values())).data is None:
+            self.initialize()
+        if x.dim() != 4:
+            raise ValueError(f"backbone expects a 4-d frame batch, got shape {tuple(x.shape)}")
+        size = tuple(x.shape[2:]) if x.shape[1] == 3 and x.dtype == torch.float32 else tuple(x.shape[1:3])
+        b = x.shape[0]
+        if self._engine is None or self._size != size or self._engine.max_batch < b:
+            self._engine = None  # release the old workspace first
+            p = {k: v.data for k, v in self._own_params.items()}
+            self._engine = engine.DenseNet121Features(p, size, max_batch=max(b, min(self._max_batch, 64)),
+                                                      prefix=self.prefix)
+            self._size = size
+        return self._engine(x)

@@ -1,0 +1,195 @@
+"""-m "not gpu": the oracle against independent CPU implementations and the
+reference's own golden vectors; host logic; C-ABI surface."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import densenet_np as dn
+from oracle import rnn_np as rn
+from oracle import vision_np as vn
+from oracle.torch_ref import TorchDenseNet121
+from tennis_amd import weights as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_densenet_oracle_matches_torch_cpu():
+    p = W.make_densenet121_weights(0)
+    x = W.normalize_to_nchw_f32(W.synthetic_frames_u8(1, 224))
+    f = dn.densenet121_features(x, p)
+    ft = TorchDenseNet121(p)(torch.from_numpy(x)).numpy()
+    assert f.shape == (1, 1024)
+    assert np.abs(f - ft).max() < 2e-5
+    assert 0.1 < f.mean() < 3 and np.isfinite(f).all()      # activations stay O(1) through 120 convs
+
+
+def test_densenet_feature_width_tracks_input_size():
+    # AvgPool2D(7) floor + NCHW flatten: 1024 @224, 4096 @512 (reference train.py:259); check 256 -> 1024 cheaply
+    p = W.make_densenet121_weights(0)
+    x = np.random.default_rng(0).normal(0, 1, (1, 3, 256, 256)).astype(np.float32)
+    assert dn.densenet121_features(x, p).shape == (1, 1024)
+    ft = TorchDenseNet121(p)(torch.from_numpy(x)).numpy()
+    assert np.abs(dn.densenet121_features(x, p) - ft).max() < 2e-5
+
+
+def test_densenet_layout_counts():
+    convs, final_bn, c = W.densenet121_layout()
+    assert len(convs) == 120 and c == 1024 and final_bn == "batchnorm4"
+    p = W.make_densenet121_weights(0)
+    assert sum(v.size for k, v in p.items() if k.endswith("_weight")) == 6_870_208  # 6.870 M
+    macs = 0
+    h = 56
+    for cv in convs:
+        if cv["kind"] == "stem":
+            macs += 112 * 112 * 64 * 147
+        else:
+            k = 9 if cv["kind"] == "dense3x3" else 1
+            hw = {1: 56, 2: 28, 3: 14, 4: 7}[cv["stage"]] ** 2
+            macs += hw * cv["cin"] * cv["cout"] * k
+    assert abs(macs / 1e9 - 2.8331) < 1e-3
+
+
+@pytest.mark.parametrize("mode", ["gru", "lstm"])
+def test_rnn_oracle_matches_torch(mode):
+    b, t, f, h = 3, 7, 20, 16
+    p = W.make_rnn_weights(5, mode, f, h, "r_")
+    x = np.random.default_rng(1).normal(0, 1, (b, t, f)).astype(np.float32)
+    ref, _, _ = rn.birnn_layer(x, p, "r_", mode)
+    net = (torch.nn.GRU if mode == "gru" else torch.nn.LSTM)(f, h, batch_first=True, bidirectional=True)
+    with torch.no_grad():
+        for d, suf in (("l", ""), ("r", "_reverse")):
+            getattr(net, "weight_ih_l0" + suf).copy_(torch.from_numpy(p[f"r_{d}0_i2h_weight"]))
+            getattr(net, "weight_hh_l0" + suf).copy_(torch.from_numpy(p[f"r_{d}0_h2h_weight"]))
+            getattr(net, "bias_ih_l0" + suf).copy_(torch.from_numpy(p[f"r_{d}0_i2h_bias"]))
+            getattr(net, "bias_hh_l0" + suf).copy_(torch.from_numpy(p[f"r_{d}0_h2h_bias"]))
+        out = net(torch.from_numpy(x))[0].numpy()
+    assert np.abs(out - ref).max() < 1e-5
+
+
+def test_rnn_valid_length_semantics():
+    """Reverse pass starts at the last valid step; padded steps emit zeros and leave the state alone."""
+    b, t, f, h = 3, 6, 5, 4
+    p = W.make_rnn_weights(2, "gru", f, h, "r_")
+    x = np.random.default_rng(3).normal(0, 1, (b, t, f)).astype(np.float32)
+    vl = np.array([6, 3, 1])
+    out, (fh, _), (bh, _) = rn.birnn_layer(x, p, "r_", "gru", vl)
+    for i in range(b):
+        o_i, (fh_i, _), (bh_i, _) = rn.birnn_layer(x[i:i + 1, :vl[i]], p, "r_", "gru")
+        assert np.allclose(out[i, :vl[i]], o_i[0], atol=1e-6)
+        assert np.all(out[i, vl[i]:] == 0)
+        assert np.allclose(fh[i], fh_i[0], atol=1e-6) and np.allclose(bh[i], bh_i[0], atol=1e-6)
+
+
+def _prf1_inputs(case, classes):
+    rng = np.random.RandomState(case["seed"])
+    out = []
+    for _ in range(case["batches"]):
+        logits = rng.randn(case["n"], len(classes)).astype(np.float32)
+        labels = rng.randint(0, len(classes), case["n"]).astype(np.float32)
+        logits[np.arange(case["n"]), labels.astype(int)] += 1.5
+        out.append((labels, logits))
+    return out
+
+
+def test_prf1_against_reference_golden():
+    """Both the oracle PRF1 and the product PRF1 (host path) reproduce the vectors the
+    reference's own metrics/vision.py::PRF1 produced (tests/golden/make_reference_golden.py)."""
+    from tennis_amd.metrics.vision import PRF1
+    g = json.load(open(os.path.join(GOLD, "prf1_reference.json")))
+    for case in g["cases"]:
+        for cls in (vn.PRF1, lambda label_names: PRF1(label_names=label_names)):
+            m = cls(g["classes"])
+            for labels, logits in _prf1_inputs(case, g["classes"]):
+                m.update([labels], [logits])
+            got = m.get()
+            assert [k for k, _ in got] == [k for k, _ in case["scores"]]
+            assert len(got) == 39
+            assert np.allclose([v for _, v in got], [v for _, v in case["scores"]], rtol=0, atol=1e-12)
+            assert np.array_equal(m.mat, np.array(case["mat"]))
+
+
+def test_time_distributed_shape_contract():
+    """reference definitions.py:166-167: TimeDistributed(Debug()) maps (3,2,3,2,2) -> (3,2,4,1,1)."""
+    from tennis_amd.utils.layers import TimeDistributed
+    calls = []
+
+    def fake_model(x):
+        calls.append(tuple(x.shape))
+        return np.zeros((x.shape[0], 4, 1, 1), np.float32)
+    td = TimeDistributed(fake_model)
+    y = td(np.ones((3, 2, 3, 2, 2), np.float32))
+    assert y.shape == (3, 2, 4, 1, 1) and calls == [(6, 3, 2, 2)]
+    a, b = td.__class__(lambda x: (np.zeros((x.shape[0], 5)), np.zeros((x.shape[0], 2))))(np.ones((3, 2, 7)))
+    assert a.shape == (3, 2, 5) and b.shape == (3, 2, 2)
+    assert vn.time_distributed(lambda z: z.sum(-1), np.ones((3, 2, 7))).shape == (3, 2)
+
+
+def test_dataset_paths_and_windows():
+    from tennis_amd.dataset import DataLoader, TennisSet
+    assert TennisSet.get_feature_path("data/features/0006", "V006", 1234) == \
+        "data/features/0006/V006.mp4/0000001000/0000001234.npy"
+    assert TennisSet.get_image_path("data/frames", "V006", 999) == "data/frames/V006.mp4/0000000000/0000000999.jpg"
+    d = TennisSet(window=4, data_shape=32, frames_per_video=10)
+    assert d.window_frames(d._samples[0]) == [0, 0, 0, 1]          # offsets -2..1 clamped at 0
+    assert d.window_frames(d._samples[9]) == [7, 8, 9, 9]          # clamped at max_frame
+    x, label, idx = d[3]
+    assert x.shape == (4, 3, 32, 32) and x.dtype == np.float32 and idx == 3 and 0 <= label < 11
+    d2 = TennisSet(window=5, stride=2, every=2, data_shape=32, frames_per_video=11)
+    assert d2.window_frames(["V006", 4, "OTH"]) == [0, 2, 4, 6, 8]  # offsets -2..2, stride 2
+    assert d2.window_frames(["V006", 10, "OTH"])[-1] == 8           # max_frame = 11-2 = 9 snapped down to an `every` frame (dataset.py:196-200)
+    xb, lb, ib = next(iter(DataLoader(TennisSet(data_shape=32), batch_size=5)))
+    assert xb.shape == (5, 3, 32, 32) and lb.shape == (5,) and list(ib) == [0, 1, 2, 3, 4]
+    pad = TennisSet(data_shape=32, frames_per_video=10, save_feats=True, split_first=5, video_length=30,
+                    videos=("V006",))
+    assert len(pad) == 30 and all(s[2] == "OTH" for s in pad._samples[10:])
+
+
+def test_abi_library_exports_every_declared_symbol():
+    from tennis_amd import _lib
+    header = open(os.path.join(ROOT, "include", "tennis_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(tn_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 24
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/tennis_hip.h but not exported"
+    assert sorted(_lib.declared_symbols()) == declared            # the ctypes table covers the whole header
+    assert _lib.load().tn_version() >= 100
+
+
+def test_product_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from tennis_amd import _lib
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.Context(0)
+    from tennis_amd.model_zoo import get_model
+    from tennis_amd.models.vision.definitions import FrameModel
+    m = FrameModel(get_model("DenseNet121", pretrained=True).features, 11)
+    with pytest.raises((RuntimeError, AssertionError)):
+        m(np.zeros((1, 3, 224, 224), np.float32))
+
+
+def test_block_surface_roundtrip(tmp_path):
+    """initialize / collect_params / save_parameters / load_parameters keep Gluon names."""
+    from tennis_amd.models.vision.definitions import CNNRNN
+    m = CNNRNN(None, num_classes=11, type="lstm", hidden_size=8, prefix="cnnrnn0_")
+    m.initialize(); m.hybridize()
+    p = W.make_rnn_weights(1, "lstm", 12, 8, "cnnrnn0_lstm0_")
+    p.update(W.make_dense_weights(2, 11, 16, "cnnrnn0_dense0_"))
+    m.set_params(p)
+    f = str(tmp_path / "0003.params")
+    m.save_parameters(f)
+    m2 = CNNRNN(None, num_classes=11, type="lstm", hidden_size=8, prefix="cnnrnn0_")
+    m2.load_parameters(f)
+    for k, v in m.collect_params().items():
+        assert np.array_equal(v.data, m2.collect_params()[k].data)
+    assert "cnnrnn0_lstm0_r0_h2h_weight" in m.collect_params()
+    m.collect_params().reset_ctx([0])
+    for prm in m.collect_params().values():
+        prm.grad_req = "null"                                       # evaluate.py:152-154
