@@ -148,6 +148,17 @@ int tn_dbg_conv1x1(tn_ctx *ctx, const void *x_f16, int ldx, int K, const float *
                    int M, int pool, int H, int W);
 int tn_dbg_conv3x3(tn_ctx *ctx, const void *x_f16, const float *scale_host, const float *shift_host,
                    const float *w_host, void *y_f16, int ldy, int yoff, int B, int H, int W);
+/* Tuning hooks: asynchronous single launches on device-resident, pre-converted
+ * operands (fp16 [N][K] 1x1 weights; tn_dbg_pack_conv3x3 image for the 3x3). */
+int tn_dbg_pack_conv3x3(const float *w_host, uint16_t *out_host);
+int tn_dbg_conv1x1_dev(tn_ctx *ctx, const void *x_f16, int ldx, int K, const float *scale, const float *shift,
+                       const void *w_f16, int N, void *y_f16, int ldy, int yoff, int M, int pool, int H, int W,
+                       int variant);
+int tn_dbg_conv3x3_dev(tn_ctx *ctx, const void *x_f16, const float *scale, const float *shift,
+                       const void *wp_f16, void *y_f16, int ldy, int yoff, int B, int H, int W, int variant);
+int tn_dbg_dense_layer_dev(tn_ctx *ctx, void *buf_f16, int ldc, int K, const float *s1, const float *t1,
+                           const void *w1_f16, const float *s2, const float *t2, const void *w3p_f16, int B,
+                           int H, int W, unsigned long long *ts /* NULL or 8 stamps per workgroup */);
 int tn_dbg_linear(tn_ctx *ctx, const float *x, const float *w, const float *bias, float *y, int M, int N,
                   int K);
 

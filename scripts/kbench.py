@@ -1,0 +1,118 @@
+"""Kernel micro-benchmark on the GPU box: times one encoder kernel at the DenseNet-121
+layer shapes (batch 256) through the tuning hooks, on random data.
+
+  python scripts/kbench.py [--variants 0,1] [--kernels c3,c1] [--batch 256] [--iters 20]
+"""
+import argparse, ctypes as C, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from tennis_amd import _lib
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--variants", default="0")
+ap.add_argument("--kernels", default="c3,c1,tr")
+ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--iters", type=int, default=20)
+args = ap.parse_args()
+ctx = _lib.default_context(0)
+lib = ctx.lib
+B = args.batch
+rng = np.random.default_rng(0)
+
+def timed(fn, iters):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3  # us
+
+blocks = [(56, 64, 6), (28, 128, 12), (14, 256, 24), (7, 512, 16)]
+res = []
+for v in [int(s) for s in args.variants.split(",")]:
+    if "c3" in args.kernels:
+        w = rng.normal(0, 0.03, (32, 128, 3, 3)).astype(np.float32)
+        wp = np.empty(72 * 64 * 8, np.uint16)
+        lib.tn_dbg_pack_conv3x3(w.ctypes.data_as(C.c_void_p), wp.ctypes.data_as(C.c_void_p))
+        wpd = torch.from_numpy(wp.view(np.int16)).cuda()
+        sc = torch.rand(128, device="cuda") + 0.5; sh = torch.randn(128, device="cuda") * 0.3
+        for (hw, cin, nl) in blocks:
+            M = B * hw * hw
+            x = torch.randn((M, 128), device="cuda", dtype=torch.float16)
+            ctot = cin + 32 * nl
+            y = torch.zeros((M, ctot), device="cuda", dtype=torch.float16)
+            fn = lambda: _lib.check(lib.tn_dbg_conv3x3_dev(ctx.handle, _lib.ptr(x), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(wpd),
+                                                           _lib.ptr(y), ctot, cin, B, hw, hw, v))
+            us = timed(fn, args.iters)
+            fl = 2.0 * M * 32 * 1152
+            by = M * (128 + 32) * 2
+            res.append(dict(k="c3", v=v, hw=hw, us=round(us, 1), tf=round(fl / us / 1e6, 1), tbs=round(by / us / 1e6, 2)))
+            print(res[-1], flush=True)
+            del x, y
+    if "c1" in args.kernels:
+        for (hw, cin, nl) in blocks:
+            M = B * hw * hw
+            ctot = cin + 32 * nl
+            x = torch.randn((M, ctot), device="cuda", dtype=torch.float16)
+            y = torch.zeros((M, 128), device="cuda", dtype=torch.float16)
+            for K in sorted(set([cin, cin + 32 * (nl // 2), cin + 32 * (nl - 1)])):
+                wd = (torch.randn((128, K), device="cuda") * (2.0 / K) ** 0.5).half()
+                sc = torch.rand(K, device="cuda") + 0.5; sh = torch.randn(K, device="cuda") * 0.3
+                fn = lambda: _lib.check(lib.tn_dbg_conv1x1_dev(ctx.handle, _lib.ptr(x), ctot, K, _lib.ptr(sc), _lib.ptr(sh),
+                                                               _lib.ptr(wd), 128, _lib.ptr(y), 128, 0, M, 0, hw, hw, v))
+                us = timed(fn, args.iters)
+                fl = 2.0 * M * 128 * K
+                by = M * (K + 128) * 2
+                res.append(dict(k="c1", v=v, hw=hw, K=K, us=round(us, 1), tf=round(fl / us / 1e6, 1), tbs=round(by / us / 1e6, 2)))
+                print(res[-1], flush=True)
+            del x, y
+    if "tr" in args.kernels:
+        for (hw, cin, nl) in blocks[:3]:
+            M = B * hw * hw
+            K = cin + 32 * nl
+            N = K // 2
+            Mo = M // 4
+            x = torch.randn((M, K), device="cuda", dtype=torch.float16)
+            y = torch.zeros((Mo, N), device="cuda", dtype=torch.float16)
+            wd = (torch.randn((N, K), device="cuda") * (2.0 / K) ** 0.5).half()
+            sc = torch.rand(K, device="cuda") + 0.5; sh = torch.randn(K, device="cuda") * 0.3
+            fn = lambda: _lib.check(lib.tn_dbg_conv1x1_dev(ctx.handle, _lib.ptr(x), K, K, _lib.ptr(sc), _lib.ptr(sh),
+                                                           _lib.ptr(wd), N, _lib.ptr(y), N, 0, Mo, 1, hw, hw, v))
+            us = timed(fn, args.iters)
+            by = M * K * 2 + Mo * N * 2
+            res.append(dict(k="tr", v=v, hw=hw, K=K, us=round(us, 1), tf=round(2.0 * M * N * K / us / 1e6, 1), tbs=round(by / us / 1e6, 2)))
+            print(res[-1], flush=True)
+            del x, y
+    if "dl" in args.kernels:
+        w = rng.normal(0, 0.03, (32, 128, 3, 3)).astype(np.float32)
+        wp = np.empty(72 * 64 * 8, np.uint16)
+        lib.tn_dbg_pack_conv3x3(w.ctypes.data_as(C.c_void_p), wp.ctypes.data_as(C.c_void_p))
+        wpd = torch.from_numpy(wp.view(np.int16)).cuda()
+        s2 = torch.rand(128, device="cuda") + 0.5; t2 = torch.randn(128, device="cuda") * 0.3
+        for (hw, cin, nl) in blocks[:3]:
+            M = B * hw * hw
+            ctot = cin + 32 * nl
+            buf = torch.randn((M, ctot), device="cuda", dtype=torch.float16)
+            for K in sorted(set([cin, cin + 32 * (nl // 2), cin + 32 * (nl - 1)])):
+                wd = (torch.randn((128, K), device="cuda") * (2.0 / K) ** 0.5).half()
+                s1 = torch.rand(K, device="cuda") + 0.5; t1 = torch.randn(K, device="cuda") * 0.3
+                fn = lambda: _lib.check(lib.tn_dbg_dense_layer_dev(ctx.handle, _lib.ptr(buf), ctot, K, _lib.ptr(s1), _lib.ptr(t1),
+                                                                   _lib.ptr(wd), _lib.ptr(s2), _lib.ptr(t2), _lib.ptr(wpd), B, hw, hw, None))
+                us = timed(fn, args.iters)
+                nwg = B * (hw // {56: 7, 28: 14, 14: 14}[hw])
+                ts = torch.zeros((nwg, 8), dtype=torch.int64, device="cuda")
+                _lib.check(lib.tn_dbg_dense_layer_dev(ctx.handle, _lib.ptr(buf), ctot, K, _lib.ptr(s1), _lib.ptr(t1), _lib.ptr(wd),
+                                                      _lib.ptr(s2), _lib.ptr(t2), _lib.ptr(wpd), B, hw, hw, _lib.ptr(ts)))
+                torch.cuda.synchronize()
+                tsn = ts.cpu().numpy().astype(np.float64)
+                d = np.diff(tsn[:, :7], axis=1)
+                print("   phases(cycles, median over WGs): load+stage0 %d | Kloop %d | zero %d | epiA+bar %d | phaseB %d | reduce+store %d | total %d"
+                      % tuple(list(np.median(d, axis=0)) + [np.median(tsn[:, 6] - tsn[:, 0])]), flush=True)
+                fl = 2.0 * M * (128 * K + 32 * 1152)
+                by = M * (K + 32) * 2
+                res.append(dict(k="dl", v=v, hw=hw, K=K, us=round(us, 1), tf=round(fl / us / 1e6, 1), tbs=round(by / us / 1e6, 2)))
+                print(res[-1], flush=True)
+            del buf
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(res, open("gpurun_out/kbench.json", "w"), indent=1)

@@ -60,6 +60,12 @@ _SIGS = {
     "tn_dbg_conv1x1": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int]),
     "tn_dbg_conv3x3": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tn_dbg_pack_conv3x3": (C.c_int, [_P, _P]),
+    "tn_dbg_conv1x1_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tn_dbg_conv3x3_dev": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tn_dbg_dense_layer_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int,
+                                         _P]),
     "tn_dbg_linear": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
 }
 

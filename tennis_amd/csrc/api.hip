@@ -2,6 +2,7 @@
 // frame encoder (weight folding/packing + launch schedule), Dense, bi-RNN,
 // temporal pooling and the PRF1 histogram.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -122,6 +123,7 @@ std::vector<f16> to_f16(const float *w, size_t n) {
   return h;
 }
 
+}  // namespace
 // 3x3 weights (32,128,3,3) -> MFMA B fragments [72 k-steps][64 lanes][8]:
 // k-step s = tap*8 + kk; lane l: n = l&31, channel = kk*16 + (l>>5)*8 + j.
 std::vector<f16> pack_conv3x3(const float *w) {
@@ -136,6 +138,7 @@ std::vector<f16> pack_conv3x3(const float *w) {
   }
   return p;
 }
+namespace {
 
 // stem weights (64,3,7,7) -> MFMA A fragments [7 ky][4 nfrag][64 lanes][8]:
 // lane l: n = nf*16 + (l&15); k slot (l>>4)*8 + j -> x-tap kx = slot>>2, channel c = slot&3.
@@ -218,6 +221,7 @@ struct tn_encoder {
   f16 *stem_out, *bott, *blockbuf[4];
   size_t workspace_bytes;
   int last_batch;
+  bool fuse;
 };
 
 static const int kBlockCfg[4] = {6, 12, 24, 16};
@@ -234,6 +238,7 @@ extern "C" int tn_densenet121_create(tn_ctx *ctx, const tn_param *params, int n_
   tn_encoder *e = new tn_encoder();
   e->ctx = ctx;
   e->H = height; e->W = width; e->maxB = max_batch; e->last_batch = 0;
+  e->fuse = getenv("TN_NO_FUSE") == nullptr;
   e->Hs = (height + 6 - 7) / 2 + 1; e->Ws = (width + 6 - 7) / 2 + 1;
   int h = (e->Hs + 2 - 3) / 2 + 1, w = (e->Ws + 2 - 3) / 2 + 1, c = 64;
   for (int b = 0; b < 4; ++b) {
@@ -321,7 +326,17 @@ static int encoder_run(tn_encoder *e, const void *x, tn_layout layout, int B, fl
   for (int b = 0; b < 4; ++b) {
     const int Hh = e->Hb[b], Ww = e->Wb[b];
     const int M = B * Hh * Ww;
+    const bool fused = e->fuse && dense_layer_supported(Hh, Ww);
     for (auto &L : e->layers[b]) {
+      if (fused) {
+        DenseLayerArgs af{e->blockbuf[b], e->Cb[b], L.cin, L.s1, L.t1, L.w1, L.s2, L.t2, L.w3p, B, Hh, Ww};
+        tm.begin("dense_layer_fused", 2.0 * M * (128.0 * L.cin + 32.0 * 1152),
+                 (double)M * (L.cin + 32) * 2 + 128.0 * L.cin * 2 + 32.0 * 1152 * 2);
+        rc = launch_dense_layer(af, s);
+        tm.end();
+        if (rc) return rc;
+        continue;
+      }
       Conv1x1Args a1{e->blockbuf[b], e->Cb[b], L.cin, L.s1, L.t1, L.w1, 128, e->bott, 128, 0, M, 0, Hh, Ww};
       tm.begin("conv1x1_bnrelu", 2.0 * M * 128.0 * L.cin, (double)M * (L.cin + 128) * 2 + 128.0 * L.cin * 2);
       rc = launch_conv1x1(a1, s);

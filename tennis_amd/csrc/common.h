@@ -72,6 +72,7 @@ struct Conv1x1Args {
   int M;              // output pixels (B*Ho*Wo)
   int pool;           // 0: Ho=H ; 1: 2x2 average of BN+ReLU'd input before the GEMM
   int H, W;           // input spatial size (used when pool)
+  int variant = 0;    // tuning hook: 0 = default kernel choice
 };
 int launch_conv1x1(const Conv1x1Args &a, hipStream_t s);
 
@@ -83,9 +84,23 @@ struct Conv3x3Args {
   f16 *y;             // [M][ldy] at column yoff, 32 channels
   int ldy, yoff;
   int M, H, W;        // M = B*H*W
+  int variant = 0;    // tuning hook: 0 = default kernel choice
 };
 int launch_conv3x3(const Conv3x3Args &a, hipStream_t s);
 size_t conv3x3_lds_bytes(int W);
+
+struct DenseLayerArgs {
+  f16 *buf;            // concat buffer [B][H][W][ldc]: reads channels [0,K), writes [K,K+32)
+  int ldc, K;
+  const float *s1, *t1;  // [K]   folded BN1
+  const f16 *w1;         // [128][K]
+  const float *s2, *t2;  // [128] folded BN2
+  const f16 *w3p;        // packed 3x3 fragments [72][64][8]
+  int B, H, W;
+  unsigned long long *ts = nullptr;  // tuning hook: 8 s_memtime stamps per workgroup
+};
+bool dense_layer_supported(int H, int W);
+int launch_dense_layer(const DenseLayerArgs &a, hipStream_t s);
 
 struct StemArgs {
   const void *x;

@@ -20,6 +20,7 @@ namespace {
 constexpr int TILE_PX = 128;
 constexpr int RED_BYTES = 4 * TILE_PX * 32 * 4;  // 4 waves x 128 px x 32 n fp32 = 64 KiB
 
+template <int V>
 __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3x3Args a, int lds_px) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x;
@@ -30,6 +31,15 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3x3Args a, int lds_px)
   const int sbase = m0 - W - 1;  // linear pixel held by LDS slot 0 (may be negative)
   const int zero_off = lds_px * 256;  // 16 B of zeros live here
 
+  // V>=1: all 18 weight fragments of this wave are requested before anything else, so
+  // their L2 latency hides behind the staging phase instead of stalling every k-step
+  const f16x8 *wp = (const f16x8 *)a.wp + (long)(wid * 18) * 64 + lane;
+  f16x8 wpre[V >= 1 ? 18 : 1];
+  if constexpr (V >= 1) {
+#pragma unroll
+    for (int i = 0; i < 18; ++i) wpre[i] = wp[(long)i * 64];
+  }
+
   // ---- stage BN+ReLU'd input pixels -------------------------------------
   {
     const int ch = t & 15;  // 8-channel chunk, fixed per thread
@@ -39,16 +49,39 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3x3Args a, int lds_px)
       sc[j] = a.scale[ch * 8 + j];
       sh[j] = a.shift[ch * 8 + j];
     }
-    for (int p = t >> 4; p < lds_px; p += 16) {
-      const int gp = sbase + p;
-      f16x8 v;
-      if (gp >= 0 && gp < M) {
-        v = bn_relu8(*(const f16x8 *)(a.x + (long)gp * 128 + ch * 8), sc, sh);
-      } else {
+    if constexpr (V >= 1) {
+      // batches of 8 independent 16-B loads per thread, then transform + LDS write
+      for (int p0 = t >> 4; p0 < lds_px; p0 += 128) {
+        f16x8 raw[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (f16)0.f;
+        for (int i = 0; i < 8; ++i) {
+          int gp = sbase + p0 + 16 * i;
+          gp = gp < 0 ? 0 : (gp >= M ? M - 1 : gp);
+          raw[i] = *(const f16x8 *)(a.x + (long)gp * 128 + ch * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int p = p0 + 16 * i, gp = sbase + p;
+          f16x8 v = bn_relu8(raw[i], sc, sh);
+          if (gp < 0 || gp >= M) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (f16)0.f;
+          }
+          if (p < lds_px) *(f16x8 *)(smem + swz<256>(p, ch)) = v;
+        }
       }
-      *(f16x8 *)(smem + swz<256>(p, ch)) = v;
+    } else {
+      for (int p = t >> 4; p < lds_px; p += 16) {
+        const int gp = sbase + p;
+        f16x8 v;
+        if (gp >= 0 && gp < M) {
+          v = bn_relu8(*(const f16x8 *)(a.x + (long)gp * 128 + ch * 8), sc, sh);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (f16)0.f;
+        }
+        *(f16x8 *)(smem + swz<256>(p, ch)) = v;
+      }
     }
     if (t == 0) *(uint4 *)(smem + zero_off) = make_uint4(0, 0, 0, 0);
   }
@@ -85,15 +118,15 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3x3Args a, int lds_px)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
 
-  const f16x8 *wp = (const f16x8 *)a.wp + (long)(wid * 18) * 64 + lane;
-#pragma unroll 6
+#pragma unroll
   for (int i = 0; i < 18; ++i) {
     const int s = wid * 18 + i;
     const int tap = s >> 3;
     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
     const int chunk = ((s & 7) << 1) + khalf;
     const int doff = dy * W + dx;
-    const f16x8 wb = wp[(long)i * 64];
+    f16x8 wb;
+    if constexpr (V >= 1) wb = wpre[i]; else wb = wp[(long)i * 64];
     f16x8 xa[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -162,12 +195,17 @@ int launch_conv3x3(const Conv3x3Args &a, hipStream_t s) {
   const size_t lds = conv3x3_lds_bytes(a.W);
   static bool attr_set = false;
   if (!attr_set) {
-    TN_HIP_CHECK(hipFuncSetAttribute((const void *)conv3x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    TN_HIP_CHECK(hipFuncSetAttribute((const void *)conv3x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024));
+    TN_HIP_CHECK(hipFuncSetAttribute((const void *)conv3x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      160 * 1024));
     attr_set = true;
   }
   const dim3 grid((a.M + TILE_PX - 1) / TILE_PX), block(256);
-  hipLaunchKernelGGL(conv3x3_kernel, grid, block, lds, s, a, lds_px);
+  if (a.variant == 9)
+    hipLaunchKernelGGL(conv3x3_kernel<0>, grid, block, lds, s, a, lds_px);
+  else
+    hipLaunchKernelGGL(conv3x3_kernel<1>, grid, block, lds, s, a, lds_px);
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;
 }

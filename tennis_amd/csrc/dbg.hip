@@ -1,10 +1,13 @@
-// Test hooks: run a single encoder kernel on caller-provided device activations
-// so the -m gpu parity tests can pin each kernel against the oracle on its own
-// (per-kernel shapes, ragged M, channel offsets).  Weights arrive as host fp32 in
-// Gluon layout and are folded/packed exactly as tn_densenet121_create does.
+// Test / tuning hooks: run a single encoder kernel on caller-provided device
+// buffers so the -m gpu parity tests can pin each kernel against the oracle on
+// its own (ragged M, channel offsets) and scripts/kbench.py can time one kernel
+// at one layer shape.  Host-weight variants fold/pack exactly as
+// tn_densenet121_create does.
+#include <cstring>
 #include <vector>
 
 #include "common.h"
+#include "linear.h"
 
 namespace {
 template <typename T>
@@ -15,6 +18,35 @@ T *up(const std::vector<T> &h) {
   return d;
 }
 }  // namespace
+
+std::vector<f16> pack_conv3x3(const float *w);  // api.hip
+
+// fp32 (32,128,3,3) -> the packed fp16 fragment image the conv3x3 kernel consumes (72*64*8 halfs).
+extern "C" int tn_dbg_pack_conv3x3(const float *w_host, uint16_t *out_host) {
+  TN_REQUIRE(w_host && out_host, "tn_dbg_pack_conv3x3: null argument");
+  const std::vector<f16> p = pack_conv3x3(w_host);
+  memcpy(out_host, p.data(), p.size() * sizeof(f16));
+  return TN_OK;
+}
+
+// Asynchronous single launches on device-resident operands (weights already fp16 / packed).
+extern "C" int tn_dbg_conv1x1_dev(tn_ctx *ctx, const void *x_f16, int ldx, int K, const float *scale,
+                                  const float *shift, const void *w_f16, int N, void *y_f16, int ldy, int yoff, int M,
+                                  int pool, int H, int W, int variant) {
+  TN_REQUIRE(ctx && x_f16 && y_f16 && scale && shift && w_f16, "tn_dbg_conv1x1_dev: null argument");
+  Conv1x1Args a{(const f16 *)x_f16, ldx, K, scale, shift, (const f16 *)w_f16, N, (f16 *)y_f16, ldy, yoff, M, pool, H, W};
+  a.variant = variant;
+  return launch_conv1x1(a, ctx->stream);
+}
+
+extern "C" int tn_dbg_conv3x3_dev(tn_ctx *ctx, const void *x_f16, const float *scale, const float *shift,
+                                  const void *wp_f16, void *y_f16, int ldy, int yoff, int B, int H, int W,
+                                  int variant) {
+  TN_REQUIRE(ctx && x_f16 && y_f16 && scale && shift && wp_f16, "tn_dbg_conv3x3_dev: null argument");
+  Conv3x3Args a{(const f16 *)x_f16, scale, shift, (const f16 *)wp_f16, (f16 *)y_f16, ldy, yoff, B * H * W, H, W};
+  a.variant = variant;
+  return launch_conv3x3(a, ctx->stream);
+}
 
 // y[m][yoff+n] = sum_k relu(scale[k]*x[m][k]+shift[k]) * w[n][k]   (pool: 2x2 mean first)
 extern "C" int tn_dbg_conv1x1(tn_ctx *ctx, const void *x_f16, int ldx, int K, const float *scale_host,
@@ -28,8 +60,7 @@ extern "C" int tn_dbg_conv1x1(tn_ctx *ctx, const void *x_f16, int ldx, int K, co
   float *s = up(std::vector<float>(scale_host, scale_host + K));
   float *t = up(std::vector<float>(shift_host, shift_host + K));
   TN_REQUIRE(w && s && t, "tn_dbg_conv1x1: device allocation failed");
-  Conv1x1Args a{(const f16 *)x_f16, ldx, K, s, t, w, N, (f16 *)y_f16, ldy, yoff, M, pool, H, W};
-  const int rc = launch_conv1x1(a, ctx->stream);
+  const int rc = tn_dbg_conv1x1_dev(ctx, x_f16, ldx, K, s, t, w, N, y_f16, ldy, yoff, M, pool, H, W, 0);
   hipError_t e = hipStreamSynchronize(ctx->stream);
   (void)hipFree(w); (void)hipFree(s); (void)hipFree(t);
   if (rc) return rc;
@@ -42,21 +73,11 @@ extern "C" int tn_dbg_conv3x3(tn_ctx *ctx, const void *x_f16, const float *scale
                               const float *w_host, void *y_f16, int ldy, int yoff, int B, int H, int W) {
   TN_REQUIRE(ctx && x_f16 && y_f16 && scale_host && shift_host && w_host, "tn_dbg_conv3x3: null argument");
   TN_HIP_CHECK(hipSetDevice(ctx->device));
-  std::vector<f16> p((size_t)72 * 64 * 8);
-  for (int s = 0; s < 72; ++s) {
-    const int tap = s >> 3, kk = s & 7, ky = tap / 3, kx = tap % 3;
-    for (int l = 0; l < 64; ++l)
-      for (int j = 0; j < 8; ++j) {
-        const int n = l & 31, c = kk * 16 + (l >> 5) * 8 + j;
-        p[((size_t)s * 64 + l) * 8 + j] = (f16)w_host[(((size_t)n * 128 + c) * 3 + ky) * 3 + kx];
-      }
-  }
-  f16 *w = up(p);
+  f16 *w = up(pack_conv3x3(w_host));
   float *s = up(std::vector<float>(scale_host, scale_host + 128));
   float *t = up(std::vector<float>(shift_host, shift_host + 128));
   TN_REQUIRE(w && s && t, "tn_dbg_conv3x3: device allocation failed");
-  Conv3x3Args a{(const f16 *)x_f16, s, t, w, (f16 *)y_f16, ldy, yoff, B * H * W, H, W};
-  const int rc = launch_conv3x3(a, ctx->stream);
+  const int rc = tn_dbg_conv3x3_dev(ctx, x_f16, s, t, w, y_f16, ldy, yoff, B, H, W, 0);
   hipError_t e = hipStreamSynchronize(ctx->stream);
   (void)hipFree(w); (void)hipFree(s); (void)hipFree(t);
   if (rc) return rc;
@@ -64,8 +85,17 @@ extern "C" int tn_dbg_conv3x3(tn_ctx *ctx, const void *x_f16, const float *scale
   return TN_OK;
 }
 
+// One fused dense layer in place on buf (B,H,W,ldc): device-resident, pre-converted operands.
+extern "C" int tn_dbg_dense_layer_dev(tn_ctx *ctx, void *buf_f16, int ldc, int K, const float *s1, const float *t1,
+                                      const void *w1_f16, const float *s2, const float *t2, const void *w3p_f16,
+                                      int B, int H, int W, unsigned long long *ts) {
+  TN_REQUIRE(ctx && buf_f16 && s1 && t1 && w1_f16 && s2 && t2 && w3p_f16, "tn_dbg_dense_layer_dev: null argument");
+  DenseLayerArgs a{(f16 *)buf_f16, ldc, K, s1, t1, (const f16 *)w1_f16, s2, t2, (const f16 *)w3p_f16, B, H, W};
+  a.ts = ts;
+  return launch_dense_layer(a, ctx->stream);
+}
+
 // fp32 linear: y = x W^T + b
-#include "linear.h"
 extern "C" int tn_dbg_linear(tn_ctx *ctx, const float *x, const float *w, const float *bias, float *y, int M, int N,
                              int K) {
   TN_REQUIRE(ctx && x && w && y, "tn_dbg_linear: null argument");

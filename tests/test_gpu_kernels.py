@@ -166,3 +166,35 @@ def test_temporal_pool_and_prf1(ctx):
     m = vn.PRF1([str(i) for i in range(11)])
     m.update([labels], [logits])
     assert np.array_equal(mat.cpu().numpy(), m.mat.astype(np.int64))
+
+
+@pytest.mark.parametrize("B,H,K,ldc", [(2, 56, 64, 256), (1, 56, 224, 256), (3, 28, 128, 512), (2, 28, 480, 512),
+                                        (3, 14, 256, 1024), (2, 14, 992, 1024)])
+def test_dense_layer_fused(ctx, report, B, H, K, ldc):
+    """One fused dense layer (1x1 -> LDS bottleneck tile -> 3x3, in-place concat) vs the oracle."""
+    from tennis_amd import _lib
+    W_ = H
+    rng = np.random.default_rng(B * 1000 + H + K)
+    buf = rng.normal(0, 1.5, (B, H, W_, ldc)).astype(np.float16)
+    s1 = rng.uniform(0.5, 1.5, K).astype(np.float32); t1 = rng.normal(0, 0.3, K).astype(np.float32)
+    s2 = rng.uniform(0.5, 1.5, 128).astype(np.float32); t2 = rng.normal(0, 0.3, 128).astype(np.float32)
+    w1 = rng.normal(0, np.sqrt(2.0 / K), (128, K)).astype(np.float16)
+    w3 = rng.normal(0, np.sqrt(2.0 / 1152), (32, 128, 3, 3)).astype(np.float32)
+    wp = np.empty(72 * 64 * 8, np.uint16)
+    ctx.lib.tn_dbg_pack_conv3x3(w3.ctypes.data_as(C.c_void_p), wp.ctypes.data_as(C.c_void_p))
+    d = dict(buf=torch.from_numpy(buf).cuda(), s1=torch.from_numpy(s1).cuda(), t1=torch.from_numpy(t1).cuda(),
+             s2=torch.from_numpy(s2).cuda(), t2=torch.from_numpy(t2).cuda(), w1=torch.from_numpy(w1).cuda(),
+             wp=torch.from_numpy(wp.view(np.int16)).cuda())
+    _lib.check(ctx.lib.tn_dbg_dense_layer_dev(ctx.handle, _lib.ptr(d["buf"]), ldc, K, _lib.ptr(d["s1"]),
+                                              _lib.ptr(d["t1"]), _lib.ptr(d["w1"]), _lib.ptr(d["s2"]),
+                                              _lib.ptr(d["t2"]), _lib.ptr(d["wp"]), B, H, W_, None), "dense_layer")
+    out = d["buf"].cpu().numpy().astype(np.float32)
+    a1 = _bnrelu_h(buf[..., :K].astype(np.float32), s1, t1)
+    bott = (a1.reshape(-1, K) @ w1.astype(np.float32).T).reshape(B, H, W_, 128)
+    a2 = _h(np.maximum(bott * s2 + t2, 0).astype(np.float32))
+    ref = dn.conv2d_nhwc(a2, _h(w3), 1, 1)
+    err = np.abs(out[..., K:K + 32] - ref).max()
+    report[f"dense_layer_fused_{B}x{H}_K{K}"] = float(err)
+    assert err < 2e-2, err
+    keep = np.ones(ldc, bool); keep[K:K + 32] = False
+    assert np.array_equal(out[..., keep], buf[..., keep].astype(np.float32))
