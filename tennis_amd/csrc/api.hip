@@ -117,8 +117,10 @@ bool fold_bn(const ParamMap &pm, const std::string &name, int c, std::vector<flo
   return true;
 }
 
+// fp16 copy with 64 trailing zeros: the LDS-DMA k-tile of the fused dense layer may read up
+// to 32 halfs past the last row when K % 64 == 32
 std::vector<f16> to_f16(const float *w, size_t n) {
-  std::vector<f16> h(n);
+  std::vector<f16> h(n + 64, (f16)0.f);
   for (size_t i = 0; i < n; ++i) h[i] = (f16)w[i];
   return h;
 }
