@@ -158,7 +158,7 @@ int tn_dbg_conv3x3_dev(tn_ctx *ctx, const void *x_f16, const float *scale, const
                        const void *wp_f16, void *y_f16, int ldy, int yoff, int B, int H, int W, int variant);
 int tn_dbg_dense_layer_dev(tn_ctx *ctx, void *buf_f16, int ldc, int K, const float *s1, const float *t1,
                            const void *w1_f16, const float *s2, const float *t2, const void *w3p_f16, int B,
-                           int H, int W, unsigned long long *ts /* NULL or 8 stamps per workgroup */);
+                           int H, int W, unsigned long long *ts /* NULL or stamps */, int variant /* 0 auto, 1 big, 2 small */);
 int tn_dbg_linear(tn_ctx *ctx, const float *x, const float *w, const float *bias, float *y, int M, int N,
                   int K);
 

@@ -13,6 +13,7 @@ ap.add_argument("--variants", default="0")
 ap.add_argument("--kernels", default="c3,c1,tr")
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--pad", type=int, default=0)
 args = ap.parse_args()
 ctx = _lib.default_context(0)
 lib = ctx.lib
@@ -90,25 +91,16 @@ for v in [int(s) for s in args.variants.split(",")]:
         lib.tn_dbg_pack_conv3x3(w.ctypes.data_as(C.c_void_p), wp.ctypes.data_as(C.c_void_p))
         wpd = torch.from_numpy(wp.view(np.int16)).cuda()
         s2 = torch.rand(128, device="cuda") + 0.5; t2 = torch.randn(128, device="cuda") * 0.3
-        for (hw, cin, nl) in blocks[:3]:
+        for (hw, cin, nl) in blocks:
             M = B * hw * hw
-            ctot = cin + 32 * nl
+            ctot = cin + 32 * nl + args.pad
             buf = torch.randn((M, ctot), device="cuda", dtype=torch.float16)
             for K in sorted(set([cin, cin + 32 * (nl // 2), cin + 32 * (nl - 1)])):
                 wd = (torch.randn((128, K), device="cuda") * (2.0 / K) ** 0.5).half()
                 s1 = torch.rand(K, device="cuda") + 0.5; t1 = torch.randn(K, device="cuda") * 0.3
                 fn = lambda: _lib.check(lib.tn_dbg_dense_layer_dev(ctx.handle, _lib.ptr(buf), ctot, K, _lib.ptr(s1), _lib.ptr(t1),
-                                                                   _lib.ptr(wd), _lib.ptr(s2), _lib.ptr(t2), _lib.ptr(wpd), B, hw, hw, None))
+                                                                   _lib.ptr(wd), _lib.ptr(s2), _lib.ptr(t2), _lib.ptr(wpd), B, hw, hw, None, v))
                 us = timed(fn, args.iters)
-                nwg = B * (hw // {56: 7, 28: 14, 14: 14}[hw])
-                ts = torch.zeros((nwg, 8), dtype=torch.int64, device="cuda")
-                _lib.check(lib.tn_dbg_dense_layer_dev(ctx.handle, _lib.ptr(buf), ctot, K, _lib.ptr(s1), _lib.ptr(t1), _lib.ptr(wd),
-                                                      _lib.ptr(s2), _lib.ptr(t2), _lib.ptr(wpd), B, hw, hw, _lib.ptr(ts)))
-                torch.cuda.synchronize()
-                tsn = ts.cpu().numpy().astype(np.float64)
-                d = np.diff(tsn[:, :7], axis=1)
-                print("   phases(cycles, median over WGs): load+stage0 %d | Kloop %d | zero %d | epiA+bar %d | phaseB %d | reduce+store %d | total %d"
-                      % tuple(list(np.median(d, axis=0)) + [np.median(tsn[:, 6] - tsn[:, 0])]), flush=True)
                 fl = 2.0 * M * (128 * K + 32 * 1152)
                 by = M * (K + 32) * 2
                 res.append(dict(k="dl", v=v, hw=hw, K=K, us=round(us, 1), tf=round(fl / us / 1e6, 1), tbs=round(by / us / 1e6, 2)))

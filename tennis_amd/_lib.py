@@ -65,7 +65,7 @@ _SIGS = {
                                      C.c_int, C.c_int, C.c_int, C.c_int]),
     "tn_dbg_conv3x3_dev": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tn_dbg_dense_layer_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int,
-                                         _P]),
+                                         _P, C.c_int]),
     "tn_dbg_linear": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
 }
 

@@ -98,6 +98,7 @@ struct DenseLayerArgs {
   const f16 *w3p;        // packed 3x3 fragments [72][64][8]
   int B, H, W;
   unsigned long long *ts = nullptr;  // tuning hook: 8 s_memtime stamps per workgroup
+  int variant = 0;                   // tuning hook: 0 auto, 1 big tiles, 2 small tiles
 };
 bool dense_layer_supported(int H, int W);
 int launch_dense_layer(const DenseLayerArgs &a, hipStream_t s);

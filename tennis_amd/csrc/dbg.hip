@@ -88,10 +88,11 @@ extern "C" int tn_dbg_conv3x3(tn_ctx *ctx, const void *x_f16, const float *scale
 // One fused dense layer in place on buf (B,H,W,ldc): device-resident, pre-converted operands.
 extern "C" int tn_dbg_dense_layer_dev(tn_ctx *ctx, void *buf_f16, int ldc, int K, const float *s1, const float *t1,
                                       const void *w1_f16, const float *s2, const float *t2, const void *w3p_f16,
-                                      int B, int H, int W, unsigned long long *ts) {
+                                      int B, int H, int W, unsigned long long *ts, int variant) {
   TN_REQUIRE(ctx && buf_f16 && s1 && t1 && w1_f16 && s2 && t2 && w3p_f16, "tn_dbg_dense_layer_dev: null argument");
   DenseLayerArgs a{(f16 *)buf_f16, ldc, K, s1, t1, (const f16 *)w1_f16, s2, t2, (const f16 *)w3p_f16, B, H, W};
   a.ts = ts;
+  a.variant = variant;
   return launch_dense_layer(a, ctx->stream);
 }
 

@@ -1,0 +1,358 @@
+// Fused DenseNet dense layer (SURVEY §7 H1, §2c rows K2+K3+K4):
+//
+//   y[.., K:K+32] = conv3x3( relu(bn2( conv1x1( relu(bn1( x[.., 0:K] )) ) )) )
+//
+// one launch per layer, replacing gluoncv's BatchNorm-Activation-Conv1x1-BatchNorm-
+// Activation-Conv3x3-Concat chain (reference call site models/vision/definitions.py:30).
+// The 128-channel bottleneck never goes to HBM.  A workgroup (8 waves) owns ROUT full
+// image rows and computes the bottleneck of those rows plus one halo row above/below.
+//
+// Phase A (bottleneck GEMM, M = (ROUT+2)*W rows, N = 128, K): raw activations and the
+//   1x1 weights stream global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round
+//   trip) through a 3-stage ring with counted vmcnt waits and ONE raw s_barrier per
+//   k-tile, so two stages are always in flight behind the MFMAs.  The DMA destination is
+//   lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE address
+//   and again on the fragment read.  BN1+ReLU (fp32 math, one rounding) is applied to the
+//   pixel fragment after the ds_read; each wave owns all 128 output channels of its rows,
+//   so every element is transformed exactly once.  v_mfma_f32_16x16x32_f16 with the
+//   weight fragment as the A operand: a lane ends with 4 consecutive channels of a pixel.
+// Epilogue A: BN2+ReLU in fp32, fp16, scatter into an LDS tile of (ROUT+2) x (W+2) pixel
+//   slots of 256 B with the zero padding materialised (the conv pads after the activation).
+// Phase B: the 3x3 is a constant-offset walk over the flattened tile with
+//   v_mfma_f32_32x32x16_f16 — no bounds logic; K = 1152 is split by channel halves over
+//   wave pairs (partials meet in LDS); the packed 3x3 weights stream through a 2 x 8 KiB
+//   LDS ring, one tap per barrier, three taps of prefetch in registers.
+// Writing the 32 output channels at channel offset K of the same buffer IS the concat.
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+template <int W, int ROUT, int BM, int BK>
+struct DLGeom {
+  static constexpr int WP = W + 2;
+  static constexpr int TR = ROUT + 2;
+  static constexpr int NSLOT = TR * WP;
+  static constexpr int NF = (ROUT * WP + 31) / 32;           // 32-slot output fragments
+  static constexpr int MAXF = (NF + 3) / 4;                  // fragments per wave group
+  static constexpr int RSLOT = WP + 32 * NF + WP + 2;        // highest slot phase B touches + 1
+  static constexpr int TSLOT = NSLOT > RSLOT ? NSLOT : RSLOT;
+  static constexpr int TILE_BYTES = TSLOT * 256;
+  static constexpr int ROWB = BK * 2;                        // bytes per staged row
+  static constexpr int XS = BM * ROWB, WS = 128 * ROWB, STAGE = XS + WS;
+  static constexpr int NST = 3;
+  static constexpr int PIECES = STAGE / 1024, PPW = PIECES / 8, XPIECES = XS / 1024;
+  static constexpr int RPP = 1024 / ROWB;                    // rows per 1-KiB DMA piece
+  static constexpr int RING_A = NST * STAGE;
+  static constexpr int W3RING = TILE_BYTES;                  // 2 x 8 KiB ring of 3x3 weights
+  static constexpr int TAB = (TILE_BYTES + 16384 > RING_A) ? TILE_BYTES + 16384 : RING_A;
+  static constexpr int TAB2 = TAB;                           // s2[128], t2[128]
+  static constexpr int TAB1 = TAB + 1024;                    // s1[K], t1[K]  (K <= 1024)
+  static constexpr int RED_BYTES = 4 * MAXF * 4 * 1024;
+  static constexpr int LDS_BYTES = TAB + 1024 + 8192;
+  static constexpr int MIW = BM / 128;                       // 16-row pixel fragments per wave
+  static_assert(PIECES % 8 == 0, "DMA pieces must divide over 8 waves");
+  static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
+  static_assert(RED_BYTES <= TILE_BYTES, "reduction buffer does not fit");
+  static_assert(BM >= TR * W && BM % 128 == 0, "phase A tile too small");
+  static_assert(BK == 32 || BK == 64, "BK");
+};
+
+// swizzle of the 16-B chunk index inside a staged row (conflict-free ds_read_b128 of a
+// 16x32 MFMA operand fragment): 128-B rows: chunk ^ (row & 7); 64-B rows: chunk ^ g(row>>2)
+template <int BK>
+__device__ __forceinline__ int stage_swz(int row, int chunk) {
+  if constexpr (BK == 64) return chunk ^ (row & 7);
+  else return chunk ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3);
+}
+
+// One LDS-DMA piece: 64 lanes x 16 B, global (per-lane address) -> LDS (wave-uniform base
+// + lane*16).  Issued through inline asm on purpose: hipcc treats the builtin as an LDS
+// store it must order against every later ds_read and inserts s_waitcnt vmcnt(0) in front
+// of the fragment reads, which drains the whole ring each k-tile.  Hidden in asm, the only
+// waits are the counted ones below (cdna_hip_programming.md 5.7; M0 saved/restored).
+__device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int W, int ROUT, int BM, int BK>
+__global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
+  using G = DLGeom<W, ROUT, BM, BK>;
+  constexpr int WP = G::WP, TR = G::TR, NF = G::NF, MAXF = G::MAXF, MIW = G::MIW;
+  constexpr int ROWB = G::ROWB, PPW = G::PPW, RPP = G::RPP, CPR = ROWB / 16;  // chunks per row
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *tile = smem;                   // bottleneck tile (aliases the DMA ring)
+  unsigned char *ring = smem + G::W3RING;       // 3x3 weight ring
+  unsigned char *red = smem;                    // phase B partial sums (aliases the tile)
+  float *tab2 = (float *)(smem + G::TAB2);
+  float *tab1 = (float *)(smem + G::TAB1);
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int H = a.H, K = a.K, ldc = a.ldc;
+#define DL_STAMP(i) do { if (a.ts && t == 0) a.ts[(long)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+  DL_STAMP(0);
+  const int tiles_per_img = H / ROUT;
+  const int img = blockIdx.x / tiles_per_img;
+  const int r0 = (blockIdx.x - img * tiles_per_img) * ROUT;     // first output row
+  const int rlo = r0 > 0 ? r0 - 1 : 0;                           // first computed bottleneck row
+  const int rhi = (r0 + ROUT < H) ? r0 + ROUT + 1 : H;           // one past the last
+  const int MA = (rhi - rlo) * W;                                // real phase-A rows
+  const int top_pad = (r0 == 0) ? 1 : 0;                         // tile row 0 lies above the image
+  const f16 *xbase = a.buf + ((long)img * H * W + (long)rlo * W) * ldc;
+
+  // ======================= phase A: bottleneck = conv1x1(relu(bn1(x))) =======================
+  // per-lane DMA source pointers of this wave's PPW pieces (advance by BK halfs per k-tile)
+  const f16 *src[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int piece = wid * PPW + j;                 // wave-uniform
+    const int prow = lane / CPR, p = lane % CPR;     // row inside the piece, linear chunk position
+    if (piece < G::XPIECES) {
+      const int row = piece * RPP + prow;
+      const int m = row < MA ? row : MA - 1;
+      src[j] = xbase + (long)m * ldc + stage_swz<BK>(row, p) * 8;
+    } else {
+      const int row = (piece - G::XPIECES) * RPP + prow;
+      src[j] = a.w1 + (long)row * K + stage_swz<BK>(row, p) * 8;
+    }
+  }
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)smem);   // LDS byte address of smem
+  auto issue = [&](int st) {
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      dma16(src[j], lds0 + st * G::STAGE + (wid * PPW + j) * 1024);
+      src[j] += BK;
+    }
+  };
+  const int nk = (K + BK - 1) / BK;
+  issue(0);
+  if (nk > 1) issue(1);
+  // BN tables -> LDS (ordinary loads; their wait also covers the two DMA stages above)
+  for (int i = t; i < K; i += 512) {
+    tab1[i] = a.s1[i];
+    tab1[1024 + i] = a.t1[i];
+  }
+  if (t < 128) {
+    tab2[t] = a.s2[t];
+    tab2[128 + t] = a.t2[t];
+  }
+  __syncthreads();   // tables visible to every wave (also drains the first two DMA stages)
+
+  const int frow = lane & 15, fch = lane >> 4;
+  f32x4 acc[8][MIW];
+#pragma unroll
+  for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MIW; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int st = 0;
+  // one k-tile: wait until stage kt has landed (YOUNGER = stages issued after it that may still
+  // be in flight), barrier, refill the slot everyone just finished with, compute
+  auto ktile = [&](int kt, auto younger_tag) {
+    constexpr int YOUNGER = decltype(younger_tag)::value;
+    wait_vmcnt<YOUNGER * PPW>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt == 0) DL_STAMP(1);
+    if (kt + 2 < nk) issue(st >= 1 ? st - 1 : 2);   // slot (kt+2)%3, free since everyone passed the barrier
+    const unsigned char *Xs = smem + st * G::STAGE;
+    const unsigned char *Ws = Xs + G::XS;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      if (kt * BK + ks * 32 < K) {
+        const int kb = kt * BK + ks * 32 + fch * 8;
+        const float4 s0 = *(const float4 *)(tab1 + kb), s1 = *(const float4 *)(tab1 + kb + 4);
+        const float4 t0 = *(const float4 *)(tab1 + 1024 + kb), t1 = *(const float4 *)(tab1 + 1024 + kb + 4);
+        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float sh[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        f16x8 wa[8];
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) {
+          const int row = ni * 16 + frow;
+          wa[ni] = *(const f16x8 *)(Ws + row * ROWB + (stage_swz<BK>(row, ks * 4 + fch) << 4));
+        }
+#pragma unroll
+        for (int mi = 0; mi < MIW; ++mi) {
+          const int row = wid * (BM / 8) + mi * 16 + frow;
+          const f16x8 xraw = *(const f16x8 *)(Xs + row * ROWB + (stage_swz<BK>(row, ks * 4 + fch) << 4));
+          const f16x8 xb = bn_relu8(xraw, sc, sh);
+#pragma unroll
+          for (int ni = 0; ni < 8; ++ni)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ni], xb, acc[ni][mi], 0, 0, 0);
+        }
+      }
+    }
+    st = st == 2 ? 0 : st + 1;
+  };
+  {
+    int kt = 0;
+    for (; kt + 1 < nk; ++kt) ktile(kt, std::integral_constant<int, 1>{});   // steady state: one younger stage in flight
+    for (; kt < nk; ++kt) ktile(kt, std::integral_constant<int, 0>{});       // drain
+  }
+  __syncthreads();   // every wave is done reading the DMA ring; the tile may now be written
+
+  DL_STAMP(2);
+  // request the first three taps of the 3x3 weights now (one 16-B piece per thread per tap)
+  const f16x8 *w3 = (const f16x8 *)a.w3p + t;
+  f16x8 wq[3] = {w3[0], w3[512], w3[2 * 512]};
+
+  // ---- zero padding of the tile: the two pad columns of every row, out-of-image halo rows ----
+  {
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+    if (t < TR * 32) {
+      const int tr = t >> 5, side = (t >> 4) & 1, ch = t & 15;
+      *(uint4 *)(tile + (tr * WP + side * (WP - 1)) * 256 + ch * 16) = z4;
+    }
+    if (top_pad)
+      for (int idx = t; idx < WP * 16; idx += 512) *(uint4 *)(tile + idx * 16) = z4;
+    if (r0 + ROUT >= H)
+      for (int idx = t; idx < WP * 16; idx += 512) *(uint4 *)(tile + (TR - 1) * WP * 256 + idx * 16) = z4;
+  }
+  DL_STAMP(3);
+  // ---- epilogue A: BN2 + ReLU, fp16, scatter into the tile ----
+  // D[i=n][j=m]: lane holds channels n = ni*16 + fch*4 + r of pixel row m = .. + frow
+#pragma unroll
+  for (int mi = 0; mi < MIW; ++mi) {
+    const int m = wid * (BM / 8) + mi * 16 + frow;
+    const int rr = m / W, x = m - rr * W;
+    const int slot = (rr + top_pad) * WP + x + 1;
+    unsigned char *dst = tile + slot * 256 + (fch & 1) * 8;
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni) {
+      const float4 sv = *(const float4 *)(tab2 + ni * 16 + fch * 4);
+      const float4 tv = *(const float4 *)(tab2 + 128 + ni * 16 + fch * 4);
+      f16x4 hv;
+      hv[0] = (f16)fmaxf(fmaf(acc[ni][mi][0], sv.x, tv.x), 0.f);
+      hv[1] = (f16)fmaxf(fmaf(acc[ni][mi][1], sv.y, tv.y), 0.f);
+      hv[2] = (f16)fmaxf(fmaf(acc[ni][mi][2], sv.z, tv.z), 0.f);
+      hv[3] = (f16)fmaxf(fmaf(acc[ni][mi][3], sv.w, tv.w), 0.f);
+      const int chunk = ni * 2 + (fch >> 1);              // channels n>>3
+      if (m < MA) *(f16x4 *)(dst + ((chunk ^ (slot & 15)) << 4)) = hv;
+    }
+  }
+  *(f16x8 *)(ring + t * 16) = wq[0];   // tap 0 -> ring[0]
+  wq[0] = w3[3 * 512];                 // request tap 3
+  __syncthreads();
+  DL_STAMP(4);
+
+  // ======================= phase B: y = conv3x3(tile) ========================================
+  const int g = wid >> 1;            // fragment group 0..3
+  const int hh = wid & 1;            // channel half: channels [64*hh, 64*hh+64)
+  const int f0 = (g * NF) >> 2, f1 = ((g + 1) * NF) >> 2;   // this group's fragments [f0, f1)
+  const int px = lane & 31, khalf = lane >> 5;
+  f32x16 bacc[MAXF];
+#pragma unroll
+  for (int j = 0; j < MAXF; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bacc[j][r] = 0.f;
+
+  // NFR = fragments this wave really owns (wave-uniform); the loop body is branch-free so the
+  // compiler can run the LDS reads ahead of the MFMAs
+  auto phase_b = [&](auto nfr_tag) {
+    constexpr int NFR = decltype(nfr_tag)::value;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      // stage the next tap's weights while this tap computes; taps are fully unrolled so
+      // the three weight registers rotate with static indices (prefetch distance 3 taps)
+      if (tap + 1 < 9) {
+        *(f16x8 *)(ring + ((tap + 1) & 1) * 8192 + t * 16) = wq[(tap + 1) % 3];
+        if (tap + 4 < 9) wq[(tap + 1) % 3] = w3[(tap + 4) * 512];
+      }
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      const int off = WP + dy * WP + dx + px + 32 * f0;   // slot of this lane's pixel, fragment f0
+      const unsigned char *wring = ring + (tap & 1) * 8192 + (hh * 4) * 1024 + lane * 16;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const f16x8 wf = *(const f16x8 *)(wring + kk * 1024);
+        const int chunk = ((hh * 4 + kk) << 1) + khalf;
+        f16x8 xf[NFR];
+#pragma unroll
+        for (int j = 0; j < NFR; ++j) {
+          const int slot = off + 32 * j;
+          xf[j] = *(const f16x8 *)(tile + slot * 256 + ((chunk ^ (slot & 15)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NFR; ++j)
+          bacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xf[j], bacc[j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  };
+  if (f1 - f0 == MAXF) phase_b(std::integral_constant<int, MAXF>{});
+  else phase_b(std::integral_constant<int, (MAXF > 1 ? MAXF - 1 : 1)>{});
+
+  DL_STAMP(5);
+  // ---- combine the two channel halves through LDS, store 32 channels per pixel ----
+  if (hh == 1) {
+#pragma unroll
+    for (int j = 0; j < MAXF; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(f32x4 *)(red + ((g * MAXF + j) * 4 + q) * 1024 + lane * 16) =
+            (f32x4){bacc[j][4 * q], bacc[j][4 * q + 1], bacc[j][4 * q + 2], bacc[j][4 * q + 3]};
+  }
+  __syncthreads();
+  if (hh == 0) {
+    f16 *ybase = a.buf + ((long)img * H * W) * ldc + K;
+#pragma unroll
+    for (int j = 0; j < MAXF; ++j) {
+      if (f0 + j < f1) {
+        const int s = WP + 32 * (f0 + j) + px;       // tile slot of this lane's output pixel
+        const int tr = s / WP, xp = s - tr * WP;
+        const bool ok = xp >= 1 && xp <= W && tr >= 1 && tr <= ROUT;
+        f16 *dst = ybase + ((long)(r0 + tr - 1) * W + (xp - 1)) * ldc + 4 * khalf;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 o = *(const f32x4 *)(red + ((g * MAXF + j) * 4 + q) * 1024 + lane * 16);
+          f16x4 hv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hv[r] = (f16)(bacc[j][4 * q + r] + o[r]);
+          if (ok) *(f16x4 *)(dst + 8 * q) = hv;
+        }
+      }
+    }
+  }
+  DL_STAMP(6);
+}
+
+template <int W, int ROUT, int BM, int BK>
+int launch_geom(const DenseLayerArgs &a, hipStream_t s) {
+  using G = DLGeom<W, ROUT, BM, BK>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    TN_HIP_CHECK(hipFuncSetAttribute((const void *)dense_layer_kernel<W, ROUT, BM, BK>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    attr_set = true;
+  }
+  const dim3 grid(a.B * (a.H / ROUT)), block(512);
+  hipLaunchKernelGGL((dense_layer_kernel<W, ROUT, BM, BK>), grid, block, G::LDS_BYTES, s, a);
+  TN_HIP_CHECK(hipGetLastError());
+  return TN_OK;
+}
+
+}  // namespace
+
+bool dense_layer_big_supported(int H, int W) { return (H == 56 && W == 56) || (H == 28 && W == 28) || (H == 14 && W == 14); }
+
+int launch_dense_layer_big(const DenseLayerArgs &a, hipStream_t s) {
+  TN_REQUIRE(a.K % 32 == 0 && a.K <= 1024 && a.ldc % 8 == 0 && a.K + 32 <= a.ldc, "dense_layer: bad channel geometry");
+  if (a.H == 56 && a.W == 56) return launch_geom<56, 7, 512, 32>(a, s);
+  if (a.H == 28 && a.W == 28) return launch_geom<28, 14, 512, 32>(a, s);
+  if (a.H == 14 && a.W == 14) return launch_geom<14, 14, 256, 64>(a, s);
+  TN_REQUIRE(false, "dense_layer: unsupported spatial size");
+}

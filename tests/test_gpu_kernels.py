@@ -169,8 +169,10 @@ def test_temporal_pool_and_prf1(ctx):
 
 
 @pytest.mark.parametrize("B,H,K,ldc", [(2, 56, 64, 256), (1, 56, 224, 256), (3, 28, 128, 512), (2, 28, 480, 512),
-                                        (3, 14, 256, 1024), (2, 14, 992, 1024)])
-def test_dense_layer_fused(ctx, report, B, H, K, ldc):
+                                        (3, 14, 256, 1024), (2, 14, 992, 1024), (8, 7, 512, 1024), (5, 7, 992, 1024),
+                                        (8, 28, 160, 512)])
+@pytest.mark.parametrize("variant", [1, 2])
+def test_dense_layer_fused(ctx, report, B, H, K, ldc, variant):
     """One fused dense layer (1x1 -> LDS bottleneck tile -> 3x3, in-place concat) vs the oracle."""
     from tennis_amd import _lib
     W_ = H
@@ -187,14 +189,14 @@ def test_dense_layer_fused(ctx, report, B, H, K, ldc):
              wp=torch.from_numpy(wp.view(np.int16)).cuda())
     _lib.check(ctx.lib.tn_dbg_dense_layer_dev(ctx.handle, _lib.ptr(d["buf"]), ldc, K, _lib.ptr(d["s1"]),
                                               _lib.ptr(d["t1"]), _lib.ptr(d["w1"]), _lib.ptr(d["s2"]),
-                                              _lib.ptr(d["t2"]), _lib.ptr(d["wp"]), B, H, W_, None), "dense_layer")
+                                              _lib.ptr(d["t2"]), _lib.ptr(d["wp"]), B, H, W_, None, variant), "dense_layer")
     out = d["buf"].cpu().numpy().astype(np.float32)
     a1 = _bnrelu_h(buf[..., :K].astype(np.float32), s1, t1)
     bott = (a1.reshape(-1, K) @ w1.astype(np.float32).T).reshape(B, H, W_, 128)
     a2 = _h(np.maximum(bott * s2 + t2, 0).astype(np.float32))
     ref = dn.conv2d_nhwc(a2, _h(w3), 1, 1)
     err = np.abs(out[..., K:K + 32] - ref).max()
-    report[f"dense_layer_fused_{B}x{H}_K{K}"] = float(err)
+    report[f"dense_layer_fused_v{variant}_{B}x{H}_K{K}"] = float(err)
     assert err < 2e-2, err
     keep = np.ones(ldc, bool); keep[K:K + 32] = False
     assert np.array_equal(out[..., keep], buf[..., keep].astype(np.float32))
