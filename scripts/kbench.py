@@ -101,6 +101,16 @@ for v in [int(s) for s in args.variants.split(",")]:
                 fn = lambda: _lib.check(lib.tn_dbg_dense_layer_dev(ctx.handle, _lib.ptr(buf), ctot, K, _lib.ptr(s1), _lib.ptr(t1),
                                                                    _lib.ptr(wd), _lib.ptr(s2), _lib.ptr(t2), _lib.ptr(wpd), B, hw, hw, None, v))
                 us = timed(fn, args.iters)
+                big = (v != 2) and hw != 7
+                nwg = B * ({56: 8, 28: 2, 14: 1}[hw] if big else {56: 16, 28: 4, 14: 1, 7: 1}[hw])
+                ts = torch.zeros((nwg * 12,), dtype=torch.int64, device="cuda")
+                _lib.check(lib.tn_dbg_dense_layer_dev(ctx.handle, _lib.ptr(buf), ctot, K, _lib.ptr(s1), _lib.ptr(t1), _lib.ptr(wd),
+                                                      _lib.ptr(s2), _lib.ptr(t2), _lib.ptr(wpd), B, hw, hw, _lib.ptr(ts), v))
+                torch.cuda.synchronize()
+                tsn = ts.cpu().numpy().astype(np.float64)[:nwg * 8].reshape(nwg, 8)
+                d = np.diff(tsn[:, :7], axis=1)
+                print("   phases(cycles, median): prologue %d | Kloop %d | pad %d | epiA+bar %d | phaseB %d | reduce+store %d | total %d"
+                      % tuple(list(np.median(d, axis=0)) + [np.median(tsn[:, 6] - tsn[:, 0])]), flush=True)
                 fl = 2.0 * M * (128 * K + 32 * 1152)
                 by = M * (K + 32) * 2
                 res.append(dict(k="dl", v=v, hw=hw, K=K, us=round(us, 1), tf=round(fl / us / 1e6, 1), tbs=round(by / us / 1e6, 2)))

@@ -153,6 +153,11 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   }
   __syncthreads();   // tables visible to every wave (also drains the first two DMA stages)
 
+  // request the first three taps of the 3x3 weights already now (one 16-B piece per thread per
+  // tap): their latency hides behind the whole K loop instead of stalling epilogue A
+  const f16x8 *w3 = (const f16x8 *)a.w3p + t;
+  f16x8 wq[3] = {w3[0], w3[512], w3[2 * 512]};
+
   const int frow = lane & 15, fch = lane >> 4;
   f32x4 acc[8][MIW];
 #pragma unroll
@@ -207,9 +212,6 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   __syncthreads();   // every wave is done reading the DMA ring; the tile may now be written
 
   DL_STAMP(2);
-  // request the first three taps of the 3x3 weights now (one 16-B piece per thread per tap)
-  const f16x8 *w3 = (const f16x8 *)a.w3p + t;
-  f16x8 wq[3] = {w3[0], w3[512], w3[2 * 512]};
 
   // ---- zero padding of the tile: the two pad columns of every row, out-of-image halo rows ----
   {

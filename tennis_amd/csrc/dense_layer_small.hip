@@ -164,6 +164,16 @@ __global__ __launch_bounds__(NT) void dense_layer_kernel(DenseLayerArgs a) {
   for (int s = 0; s < NST - 1; ++s)
     if (s < nk) issue(s);
 
+  // request the first three taps of the 3x3 weights already now (two 16-B pieces per thread per
+  // tap): their latency hides behind the whole K loop instead of stalling epilogue A
+  const f16x8 *w3 = (const f16x8 *)a.w3p + t;
+  f16x8 wq[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    wq[i][0] = w3[i * 512];
+    wq[i][1] = w3[i * 512 + 256];
+  }
+
   const int frow = lane & 15, fch = lane >> 4;
   f32x4 acc[8][MIW];
 #pragma unroll
@@ -222,14 +232,6 @@ __global__ __launch_bounds__(NT) void dense_layer_kernel(DenseLayerArgs a) {
   __syncthreads();   // every wave is done reading the DMA ring; the tile may now be written
 
   DL_STAMP(2);
-  // request the first three taps of the 3x3 weights now (two 16-B pieces per thread per tap)
-  const f16x8 *w3 = (const f16x8 *)a.w3p + t;
-  f16x8 wq[3][2];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    wq[i][0] = w3[i * 512];
-    wq[i][1] = w3[i * 512 + 256];
-  }
   DL_STAMP(3);
   // ---- epilogue A: BN2 + ReLU -> fp16 into the tile; out-of-frame slots get zero ----
   // D[i=n][j=m]: lane holds channels n = ni*16 + fch*4 + r of tile slot s = .. + frow
