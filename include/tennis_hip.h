@@ -66,6 +66,7 @@ typedef struct tn_ctx tn_ctx;
 typedef struct tn_encoder tn_encoder;
 typedef struct tn_dense tn_dense;
 typedef struct tn_birnn tn_birnn;
+typedef struct tn_gnmt tn_gnmt;
 
 int tn_version(void);
 const char *tn_last_error(void);
@@ -137,6 +138,28 @@ int tn_temporal_pool(tn_ctx *ctx, const float *x, int batch, int steps, int feat
  * adds into mat (classes*classes) int64, row = label, col = argmax (first max). */
 int tn_prf1_update(tn_ctx *ctx, const float *logits, const int32_t *labels, int rows, int classes,
                    int64_t *mat);
+
+/* ---- GNMT captioner: encoder + attention decoder + beam search -------------- */
+/* Replaces get_gnmt_encoder_decoder / NMTModel / BeamSearchTranslator as assembled at
+ * reference train_gnmt.py:223-252 and driven by evaluate() (train_gnmt.py:264-302):
+ *   tn_gnmt_encode      = model.encode -> GNMTEncoder.forward (models/captioning/gnmt.py:136-160)
+ *                         + decoder.init_state_from_encoder (gnmt.py:224-252)
+ *   tn_gnmt_beam_search = BeamSearchTranslator.translate (utils/translation.py:55-82): the whole
+ *                         decode_step / log_softmax / BeamSearchSampler loop on the device.
+ * params: "<prefix>enc_rnn0_{l,r}_*", "<prefix>enc_rnn1_*", "<prefix>dec_rnn{0,1}_*"
+ * ({i2h,h2h}_{weight,bias}), "<prefix>dec_attention_key_weight" (H,H), "<prefix>tgt_proj_{weight,bias}",
+ * "<prefix>tgt_embed_weight" (V,E).  Only the reference defaults are built: cell_type gru,
+ * num_layers 2, num_bi_layers 1, scaled_luong attention, no residual, dropout off.
+ * src (B,T,F) fp32 features, valid_len (B,) int32; samples (B,beam,max_length+2) int32 padded
+ * with -1 (leading BOS), scores (B,beam) descending, valid_length (B,beam) int32;
+ * *length_host = number of meaningful columns of `samples` (the width the reference returns). */
+int tn_gnmt_create(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix, int cell_kind,
+                   int input_size, int hidden, int embed, int vocab, int num_layers, int num_bi_layers,
+                   int max_batch, int max_src_len, int beam, int max_length, tn_gnmt **out);
+int tn_gnmt_encode(tn_gnmt *g, const float *src, const int32_t *valid_len, int batch, int steps, float *mem_out);
+int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, float K, int max_length, int32_t *samples,
+                        float *scores, int32_t *valid_length, int *length_host);
+int tn_gnmt_destroy(tn_gnmt *g);
 
 /* ---- test hooks (used by tests/ only) -------------------------------------- */
 /* Run ONE encoder kernel on caller-provided device activations (fp16 NHWC) with

@@ -57,6 +57,12 @@ _SIGS = {
     "tn_birnn_destroy": (C.c_int, [_P]),
     "tn_temporal_pool": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "tn_prf1_update": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
+    "tn_gnmt_create": (C.c_int, [_P, C.POINTER(TnParam), C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "tn_gnmt_encode": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
+    "tn_gnmt_beam_search": (C.c_int, [_P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, _P, _P, _P,
+                                      C.POINTER(C.c_int)]),
+    "tn_gnmt_destroy": (C.c_int, [_P]),
     "tn_dbg_conv1x1": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int]),
     "tn_dbg_conv3x3": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -1,0 +1,457 @@
+// GNMT captioner, inference, fp32 throughout:
+//   encoder      GNMTEncoder.forward, reference models/captioning/gnmt.py:136-160
+//                (bi-GRU with valid_length + uni-GRU, reusing the tn_birnn kernels)
+//   init state   GNMTDecoder.init_state_from_encoder, gnmt.py:224-252
+//   decode step  GNMTDecoder.hybrid_forward, gnmt.py:345-404, behind NMTModel.decode_step
+//                [EXT]: tgt_embed -> GRUCell0([emb, att]) -> scaled-Luong attention ->
+//                GRUCell1([h0, ctx]) -> tgt_proj -> log_softmax (utils/translation.py:51-53)
+//   beam search  gluonnlp BeamSearchSampler/Scorer [EXT] as driven by
+//                BeamSearchTranslator.translate, utils/translation.py:55-82
+// The whole token loop is enqueued on the stream with no per-step host sync; the host
+// looks at a device flag every 16 steps only to stop early once every beam has finished.
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "linear.h"
+
+namespace {
+
+constexpr float kNeg = -1e18f;
+
+__global__ void embed_concat_kernel(const float *__restrict__ emb, const int32_t *__restrict__ tok,
+                                    const float *__restrict__ att, float *__restrict__ x, int R, int E, int H) {
+  const int r = blockIdx.x;
+  const float *e = emb + (long)tok[r] * E;
+  for (int i = threadIdx.x; i < E + H; i += blockDim.x) x[(long)r * (E + H) + i] = i < E ? e[i] : att[(long)r * H + i - E];
+}
+
+__device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// GRU cell gates [r,z,n]: h' = (1-z)*n + z*h ; optionally also writes h' into the first H
+// columns of a concat buffer xcat (row stride ldx)
+__global__ void gru_gate_kernel(const float *__restrict__ gi, const float *__restrict__ gh,
+                                const float *__restrict__ h, float *__restrict__ hn, float *__restrict__ xcat, int ldx,
+                                int R, int H) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)R * H) return;
+  const int r = (int)(id / H), u = (int)(id % H);
+  const float *a = gi + (long)r * 3 * H, *b = gh + (long)r * 3 * H;
+  const float rg = sigm(a[u] + b[u]);
+  const float zg = sigm(a[H + u] + b[H + u]);
+  const float ng = tanhf(a[2 * H + u] + rg * b[2 * H + u]);
+  const float v = (1.f - zg) * ng + zg * h[id];
+  hn[id] = v;
+  if (xcat) xcat[(long)r * ldx + u] = v;
+}
+
+// scaled-Luong attention for one decoder row per workgroup: scores over the source steps,
+// masked softmax (masked -> -1e18, weights * mask), context; writes ctx and xcat[:, H:2H]
+__global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ hq, const float *__restrict__ keyproj,
+                                                        const float *__restrict__ mem,
+                                                        const int32_t *__restrict__ valid_len, float *__restrict__ ctx,
+                                                        float *__restrict__ xcat, int beam, int T, int H) {
+  extern __shared__ float sm[];   // q[H] | w[T] | red[256]
+  float *q = sm, *w = sm + H, *red = w + T;
+  const int r = blockIdx.x, b = r / beam, t = threadIdx.x;
+  const float inv = 1.0f / sqrtf((float)H);
+  for (int i = t; i < H; i += 256) q[i] = hq[(long)r * H + i] * inv;
+  __syncthreads();
+  const int vl = valid_len[b];
+  const float *kp = keyproj + (long)b * T * H;
+  float mx = -INFINITY;
+  for (int s = t; s < T; s += 256) {
+    float a = 0.f;
+    const float *row = kp + (long)s * H;
+    for (int i = 0; i < H; ++i) a = fmaf(q[i], row[i], a);
+    a = s < vl ? a : kNeg;
+    w[s] = a;
+    mx = fmaxf(mx, a);
+  }
+  red[t] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) red[t] = fmaxf(red[t], red[t + o]);
+    __syncthreads();
+  }
+  mx = red[0];
+  __syncthreads();
+  float sum = 0.f;
+  for (int s = t; s < T; s += 256) {
+    const float e = expf(w[s] - mx);
+    w[s] = e;
+    sum += e;
+  }
+  red[t] = sum;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) red[t] += red[t + o];
+    __syncthreads();
+  }
+  const float rs = 1.0f / red[0];
+  __syncthreads();
+  for (int s = t; s < T; s += 256) w[s] = s < vl ? w[s] * rs : 0.f;
+  __syncthreads();
+  const float *mv = mem + (long)b * T * H;
+  for (int i = t; i < H; i += 256) {
+    float a = 0.f;
+    for (int s = 0; s < T; ++s) a = fmaf(w[s], mv[(long)s * H + i], a);
+    ctx[(long)r * H + i] = a;
+    xcat[(long)r * 2 * H + H + i] = a;
+  }
+}
+
+// One beam-search update per source clip (workgroup): log_softmax of the beam rows, length-
+// penalised candidate scores, top-`beam` over [beam*V | finished], bookkeeping.
+__global__ __launch_bounds__(256) void beam_update_kernel(
+    const float *__restrict__ logits, int V, int beam, int step, float alpha, float Kp, int eos,
+    float *__restrict__ scores, int32_t *__restrict__ alive, int32_t *__restrict__ vlen,
+    const int32_t *__restrict__ samples_in, int32_t *__restrict__ samples_out, int L, int32_t *__restrict__ tok,
+    int32_t *__restrict__ gather, int32_t *__restrict__ any_alive) {
+  extern __shared__ float sm[];   // cand[beam*V + beam] | lse[beam] | redv[256] | redi[256]
+  const int b = blockIdx.x, t = threadIdx.x, NC = beam * V + beam;
+  float *cand = sm, *lse = cand + NC, *redv = lse + beam;
+  int *redi = (int *)(redv + 256);
+  __shared__ int sel_idx[16];
+  __shared__ float sel_val[16];
+  // log-sum-exp per beam row
+  for (int k = 0; k < beam; ++k) {
+    const float *z = logits + ((long)b * beam + k) * V;
+    float mx = -INFINITY;
+    for (int v = t; v < V; v += 256) mx = fmaxf(mx, z[v]);
+    redv[t] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (t < o) redv[t] = fmaxf(redv[t], redv[t + o]); __syncthreads(); }
+    mx = redv[0];
+    __syncthreads();
+    float s = 0.f;
+    for (int v = t; v < V; v += 256) s += expf(z[v] - mx);
+    redv[t] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (t < o) redv[t] += redv[t + o]; __syncthreads(); }
+    if (t == 0) lse[k] = mx + logf(redv[0]);
+    __syncthreads();
+  }
+  const float lp = powf(Kp + (float)step, alpha) / powf(Kp + 1.f, alpha);
+  const float prev_lp = step == 1 ? 1.f : powf(Kp + (float)(step - 1), alpha) / powf(Kp + 1.f, alpha);
+  for (int c = t; c < NC; c += 256) {
+    float v;
+    if (c < beam * V) {
+      const int k = c / V, wv = c - k * V;
+      const float logp = logits[((long)b * beam + k) * V + wv] - lse[k];
+      v = alive[b * beam + k] ? (scores[b * beam + k] * prev_lp + logp) / lp : kNeg;
+    } else {
+      const int k = c - beam * V;
+      v = alive[b * beam + k] ? kNeg : scores[b * beam + k];
+    }
+    cand[c] = v;
+  }
+  __syncthreads();
+  // top-`beam`, descending, ties -> lowest index (stable argsort in the oracle)
+  for (int k = 0; k < beam; ++k) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = t; c < NC; c += 256) {
+      const float v = cand[c];
+      if (v > bv || (v == bv && c < bi)) { bv = v; bi = c; }
+    }
+    redv[t] = bv; redi[t] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (t < o) {
+        const float v2 = redv[t + o]; const int i2 = redi[t + o];
+        if (v2 > redv[t] || (v2 == redv[t] && i2 < redi[t])) { redv[t] = v2; redi[t] = i2; }
+      }
+      __syncthreads();
+    }
+    if (t == 0) { sel_idx[k] = redi[0]; sel_val[k] = redv[0]; cand[redi[0]] = -INFINITY; }
+    __syncthreads();
+  }
+  // bookkeeping (old values are read before any thread overwrites them)
+  __shared__ int o_alive[16], o_vlen[16];
+  if (t < beam) { o_alive[t] = alive[b * beam + t]; o_vlen[t] = vlen[b * beam + t]; }
+  __syncthreads();
+  if (t < beam) {
+    const int idx = sel_idx[t];
+    const bool use_prev = idx >= beam * V;
+    const int word = use_prev ? -1 : idx % V;
+    const int bid = use_prev ? idx - beam * V : idx / V;
+    scores[b * beam + t] = sel_val[t];
+    vlen[b * beam + t] = o_vlen[bid] + 1 - (use_prev ? 1 : 0);
+    const int al = o_alive[bid] && word != eos;
+    alive[b * beam + t] = al;
+    tok[b * beam + t] = word > 0 ? word : 0;
+    gather[b * beam + t] = b * beam + bid;
+    sel_idx[t] = bid;      // reuse: source beam
+    sel_val[t] = (float)word;
+    if (al) atomicOr(any_alive, 1);
+  }
+  __syncthreads();
+  // samples: copy the chosen parent's prefix (step entries: BOS + step-1 words), append the word
+  for (int k = 0; k < beam; ++k) {
+    const int32_t *src = samples_in + ((long)b * beam + sel_idx[k]) * L;
+    int32_t *dst = samples_out + ((long)b * beam + k) * L;
+    for (int i = t; i < step; i += 256) dst[i] = src[i];
+    if (t == 0) dst[step] = (int32_t)sel_val[k];
+  }
+}
+
+__global__ void gather_rows_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                   const int32_t *__restrict__ gather, int R, int H) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)R * H) return;
+  const int r = (int)(id / H), u = (int)(id % H);
+  dst[id] = src[(long)gather[r] * H + u];
+}
+
+__global__ void expand_rows_kernel(const float *__restrict__ src, float *__restrict__ dst, int B, int beam, int H) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)B * beam * H) return;
+  const int r = (int)(id / H), u = (int)(id % H);
+  dst[id] = src ? src[(long)(r / beam) * H + u] : 0.f;
+}
+
+__global__ void beam_init_kernel(float *scores, int32_t *alive, int32_t *vlen, int32_t *tok, int32_t *samples, int L,
+                                 int B, int beam, int bos) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= B * beam) return;
+  scores[id] = (id % beam) == 0 ? 0.f : kNeg;
+  alive[id] = 1;
+  vlen[id] = 1;
+  tok[id] = bos;
+  samples[(long)id * L] = bos;
+}
+
+__global__ void beam_finalize_kernel(const int32_t *alive, int32_t *vlen, int32_t *samples, int L, int last, int R,
+                                     int eos) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= R) return;
+  samples[(long)id * L + last] = alive[id] ? eos : -1;
+  vlen[id] += alive[id] ? 1 : 0;
+}
+
+struct DevBuf {
+  std::vector<void *> ptrs;
+  bool failed = false;
+  template <typename T>
+  T *alloc(size_t n) {
+    void *p = nullptr;
+    if (hipMalloc(&p, (n ? n : 1) * sizeof(T)) != hipSuccess) { failed = true; return nullptr; }
+    ptrs.push_back(p);
+    return (T *)p;
+  }
+  float *upload(const float *h, size_t n) {
+    float *d = alloc<float>(n);
+    if (d && hipMemcpy(d, h, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) failed = true;
+    return d;
+  }
+  void release() { for (void *p : ptrs) (void)hipFree(p); ptrs.clear(); }
+};
+
+}  // namespace
+
+struct tn_gnmt {
+  tn_ctx *ctx;
+  DevBuf pool;
+  tn_birnn *enc0, *enc1;   // bi layer (F -> 2H), uni layer (2H -> H)
+  int F, H, E, V, maxB, maxT, beam, maxL;
+  float *wi0, *wh0, *bi0, *bh0, *wi1, *wh1, *bi1, *bh1, *wk, *wp, *bp, *emb;
+  // per-call workspace
+  float *seq0, *mem, *keyproj, *hl0, *hl1, *cl;
+  int32_t *vl;
+  float *h0[2], *h1[2], *att[2], *x0, *x1, *gi, *gh, *logits, *scores;
+  int32_t *alive, *vlen, *tok, *gather, *samples[2], *flag;
+  int B, T;
+};
+
+extern "C" int tn_gnmt_create(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix_c, int cell_kind,
+                              int input_size, int hidden, int embed, int vocab, int num_layers, int num_bi_layers,
+                              int max_batch, int max_src_len, int beam, int max_length, tn_gnmt **out) {
+  TN_REQUIRE(ctx && params && prefix_c && out, "tn_gnmt_create: null argument");
+  TN_REQUIRE(cell_kind == TN_RNN_GRU, "tn_gnmt_create: only cell_type='gru' (the reference default, train_gnmt.py:62) is built");
+  TN_REQUIRE(num_layers == 2 && num_bi_layers == 1, "tn_gnmt_create: only num_layers=2, num_bi_layers=1 (reference defaults)");
+  TN_REQUIRE(beam >= 1 && beam <= 16 && vocab >= beam && max_length >= 1, "tn_gnmt_create: bad beam/vocab/max_length");
+  TN_REQUIRE(input_size > 0 && hidden > 0 && hidden % 4 == 0 && embed > 0 && max_batch > 0 && max_src_len > 0,
+             "tn_gnmt_create: bad shape");
+  TN_HIP_CHECK(hipSetDevice(ctx->device));
+  const std::string pre(prefix_c);
+  std::map<std::string, const tn_param *> pm;
+  for (int i = 0; i < n_params; ++i) pm[params[i].name] = &params[i];
+  auto get = [&](const std::string &name, int64_t numel) -> const float * {
+    auto it = pm.find(name);
+    if (it == pm.end()) { tn_set_error("missing parameter: " + name); return nullptr; }
+    if (it->second->numel != numel) { tn_set_error("parameter " + name + " has the wrong size"); return nullptr; }
+    return it->second->data_host;
+  };
+  tn_gnmt *g = new tn_gnmt();   // value-initialised: every pointer member starts null
+  g->ctx = ctx; g->F = input_size; g->H = hidden; g->E = embed; g->V = vocab; g->maxB = max_batch; g->maxT = max_src_len;
+  g->beam = beam; g->maxL = max_length + 2;
+  auto fail = [&](int code) { g->pool.release(); if (g->enc0) tn_birnn_destroy(g->enc0); if (g->enc1) tn_birnn_destroy(g->enc1); delete g; return code; };
+  // encoder layers: rename "<pre>enc_rnn0_{l,r}_*" -> "{l,r}0_*" for tn_birnn
+  std::vector<tn_param> p0, p1;
+  std::vector<std::string> names;
+  names.reserve(16);
+  const char *sfx[4] = {"i2h_weight", "h2h_weight", "i2h_bias", "h2h_bias"};
+  const int H = hidden, G3 = 3 * hidden;
+  for (int d = 0; d < 2; ++d)
+    for (int k = 0; k < 4; ++k) {
+      const std::string src = pre + "enc_rnn0_" + (d ? "r_" : "l_") + sfx[k];
+      const int64_t n = k == 0 ? (int64_t)G3 * input_size : k == 1 ? (int64_t)G3 * H : G3;
+      const float *v = get(src, n);
+      if (!v) return fail(TN_ERR_MISSING);
+      names.push_back(std::string(d ? "r0_" : "l0_") + sfx[k]);
+      p0.push_back(tn_param{nullptr, v, n});
+    }
+  for (size_t i = 0; i < p0.size(); ++i) p0[i].name = names[i].c_str();
+  std::vector<std::string> names1;
+  names1.reserve(8);
+  for (int k = 0; k < 4; ++k) {
+    const int64_t n = k == 0 ? (int64_t)G3 * 2 * H : k == 1 ? (int64_t)G3 * H : G3;
+    const float *v = get(pre + "enc_rnn1_" + sfx[k], n);
+    if (!v) return fail(TN_ERR_MISSING);
+    names1.push_back(std::string("l0_") + sfx[k]);
+    p1.push_back(tn_param{nullptr, v, n});
+  }
+  for (size_t i = 0; i < p1.size(); ++i) p1[i].name = names1[i].c_str();
+  int rc = tn_birnn_create(ctx, TN_RNN_GRU, input_size, H, p0.data(), (int)p0.size(), "", 1, max_batch * max_src_len, &g->enc0);
+  if (rc) return fail(rc);
+  rc = tn_birnn_create(ctx, TN_RNN_GRU, 2 * H, H, p1.data(), (int)p1.size(), "", 0, max_batch * max_src_len, &g->enc1);
+  if (rc) return fail(rc);
+  // decoder
+  const float *a;
+#define UP(dst, name, n) do { a = get(pre + name, (int64_t)(n)); if (!a) return fail(TN_ERR_MISSING); dst = g->pool.upload(a, (size_t)(n)); } while (0)
+  UP(g->wi0, "dec_rnn0_i2h_weight", (int64_t)G3 * (embed + H)); UP(g->wh0, "dec_rnn0_h2h_weight", (int64_t)G3 * H);
+  UP(g->bi0, "dec_rnn0_i2h_bias", G3); UP(g->bh0, "dec_rnn0_h2h_bias", G3);
+  UP(g->wi1, "dec_rnn1_i2h_weight", (int64_t)G3 * 2 * H); UP(g->wh1, "dec_rnn1_h2h_weight", (int64_t)G3 * H);
+  UP(g->bi1, "dec_rnn1_i2h_bias", G3); UP(g->bh1, "dec_rnn1_h2h_bias", G3);
+  UP(g->wk, "dec_attention_key_weight", (int64_t)H * H);
+  UP(g->wp, "tgt_proj_weight", (int64_t)vocab * H); UP(g->bp, "tgt_proj_bias", vocab);
+  UP(g->emb, "tgt_embed_weight", (int64_t)vocab * embed);
+#undef UP
+  const size_t BT = (size_t)max_batch * max_src_len, R = (size_t)max_batch * beam;
+  g->seq0 = g->pool.alloc<float>(BT * 2 * H); g->mem = g->pool.alloc<float>(BT * H); g->keyproj = g->pool.alloc<float>(BT * H);
+  g->hl0 = g->pool.alloc<float>(2 * (size_t)max_batch * H); g->hl1 = g->pool.alloc<float>((size_t)max_batch * H);
+  g->cl = g->pool.alloc<float>(2 * (size_t)max_batch * H); g->vl = g->pool.alloc<int32_t>(max_batch);
+  for (int i = 0; i < 2; ++i) {
+    g->h0[i] = g->pool.alloc<float>(R * H); g->h1[i] = g->pool.alloc<float>(R * H); g->att[i] = g->pool.alloc<float>(R * H);
+    g->samples[i] = g->pool.alloc<int32_t>(R * g->maxL);
+  }
+  g->x0 = g->pool.alloc<float>(R * (embed + H)); g->x1 = g->pool.alloc<float>(R * 2 * H);
+  g->gi = g->pool.alloc<float>(R * G3); g->gh = g->pool.alloc<float>(R * G3); g->logits = g->pool.alloc<float>(R * vocab);
+  g->scores = g->pool.alloc<float>(R); g->alive = g->pool.alloc<int32_t>(R); g->vlen = g->pool.alloc<int32_t>(R);
+  g->tok = g->pool.alloc<int32_t>(R); g->gather = g->pool.alloc<int32_t>(R); g->flag = g->pool.alloc<int32_t>(1);
+  if (g->pool.failed) { tn_set_error("device allocation failed"); return fail(TN_ERR_NOMEM); }
+  *out = g;
+  return TN_OK;
+}
+
+// GNMTEncoder.forward + the attention key projection; keeps mem / states inside the handle.
+// mem_out (B,T,H) may be NULL.
+extern "C" int tn_gnmt_encode(tn_gnmt *g, const float *src, const int32_t *valid_len, int batch, int steps, float *mem_out) {
+  TN_REQUIRE(g && src && valid_len, "tn_gnmt_encode: null argument");
+  TN_REQUIRE(batch > 0 && batch <= g->maxB && steps > 0 && steps <= g->maxT, "tn_gnmt_encode: batch/steps exceed the handle");
+  TN_HIP_CHECK(hipSetDevice(g->ctx->device));
+  hipStream_t s = g->ctx->stream;
+  const int H = g->H;
+  TN_HIP_CHECK(hipMemcpyAsync(g->vl, valid_len, sizeof(int32_t) * batch, hipMemcpyDeviceToDevice, s));
+  int rc = tn_birnn_forward(g->enc0, src, batch, steps, g->vl, g->seq0, g->hl0, g->cl);   // hl0 = [fwd, bwd] final states
+  if (rc) return rc;
+  rc = tn_birnn_forward(g->enc1, g->seq0, batch, steps, g->vl, g->mem, g->hl1, g->cl);
+  if (rc) return rc;
+  rc = launch_linear_f32(g->mem, H, g->wk, H, nullptr, g->keyproj, H, batch * steps, H, H, 0, s);
+  if (rc) return rc;
+  if (mem_out) TN_HIP_CHECK(hipMemcpyAsync(mem_out, g->mem, sizeof(float) * (size_t)batch * steps * H, hipMemcpyDeviceToDevice, s));
+  g->B = batch; g->T = steps;
+  return TN_OK;
+}
+
+// BeamSearchTranslator.translate after tn_gnmt_encode.  samples (B,beam,max_length+2) int32 padded
+// with -1, scores (B,beam), valid_length (B,beam) are DEVICE buffers; *length_host receives the
+// number of valid columns of `samples` (what the reference's sampler would have returned).
+extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, float K, int max_length, int32_t *samples,
+                                   float *scores, int32_t *valid_length, int *length_host) {
+  TN_REQUIRE(g && samples && scores && valid_length && length_host, "tn_gnmt_beam_search: null argument");
+  TN_REQUIRE(g->B > 0, "tn_gnmt_beam_search: call tn_gnmt_encode first");
+  TN_REQUIRE(max_length >= 1 && max_length + 2 <= g->maxL, "tn_gnmt_beam_search: max_length exceeds the handle");
+  TN_REQUIRE(bos >= 0 && bos < g->V && eos >= 0 && eos < g->V, "tn_gnmt_beam_search: bos/eos outside the vocabulary");
+  TN_HIP_CHECK(hipSetDevice(g->ctx->device));
+  hipStream_t s = g->ctx->stream;
+  const int B = g->B, T = g->T, H = g->H, E = g->E, V = g->V, beam = g->beam, R = B * beam, L = g->maxL, G3 = 3 * H;
+  TN_HIP_CHECK(hipMemsetAsync(g->samples[0], 0xff, sizeof(int32_t) * (size_t)R * L, s));
+  TN_HIP_CHECK(hipMemsetAsync(g->samples[1], 0xff, sizeof(int32_t) * (size_t)R * L, s));
+  const int nb = (R * H + 255) / 256;
+  // decoder layer 0 starts from the encoder's BACKWARD layer-0 state, layer 1 from the uni layer (gnmt.py:146-150,224-252)
+  hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)(g->hl0 + (size_t)B * H), g->h0[0], B, beam, H);
+  hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)g->hl1, g->h1[0], B, beam, H);
+  hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)nullptr, g->att[0], B, beam, H);
+  hipLaunchKernelGGL(beam_init_kernel, dim3((R + 255) / 256), dim3(256), 0, s, g->scores, g->alive, g->vlen, g->tok, g->samples[0], L, B, beam, bos);
+  int cur = 0, steps_done = 0, all_dead = 0;
+  const size_t att_lds = (size_t)(H + T + 256) * sizeof(float);
+  const size_t beam_lds = (size_t)(beam * V + beam + beam + 512) * sizeof(float);
+  for (int i = 0; i < max_length; ++i) {
+    const int nxt = cur ^ 1, step = i + 1;
+    if ((i & 15) == 0) TN_HIP_CHECK(hipMemsetAsync(g->flag, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(embed_concat_kernel, dim3(R), dim3(128), 0, s, g->emb, g->tok, g->att[cur], g->x0, R, E, H);
+    int rc = launch_linear_f32(g->x0, E + H, g->wi0, E + H, g->bi0, g->gi, G3, R, G3, E + H, 0, s);
+    if (rc) return rc;
+    rc = launch_linear_f32(g->h0[cur], H, g->wh0, H, g->bh0, g->gh, G3, R, G3, H, 0, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gru_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->h0[cur], g->h0[nxt], g->x1, 2 * H, R, H);
+    hipLaunchKernelGGL(attention_kernel, dim3(R), dim3(256), att_lds, s, g->h0[nxt], g->keyproj, g->mem, g->vl, g->att[nxt], g->x1, beam, T, H);
+    rc = launch_linear_f32(g->x1, 2 * H, g->wi1, 2 * H, g->bi1, g->gi, G3, R, G3, 2 * H, 0, s);
+    if (rc) return rc;
+    rc = launch_linear_f32(g->h1[cur], H, g->wh1, H, g->bh1, g->gh, G3, R, G3, H, 0, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gru_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->h1[cur], g->h1[nxt], (float *)nullptr, 0, R, H);
+    rc = launch_linear_f32(g->h1[nxt], H, g->wp, H, g->bp, g->logits, V, R, V, H, 0, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(beam_update_kernel, dim3(B), dim3(256), beam_lds, s, g->logits, V, beam, step, alpha, K, eos, g->scores,
+                       g->alive, g->vlen, g->samples[cur], g->samples[nxt], L, g->tok, g->gather, g->flag);
+    // re-gather the states by parent beam: nxt -> cur buffers, then swap roles
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, s, g->h0[nxt], g->h0[cur], g->gather, R, H);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, s, g->h1[nxt], g->h1[cur], g->gather, R, H);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, s, g->att[nxt], g->att[cur], g->gather, R, H);
+    // states are back in `cur`; only the samples ping-pong
+    {
+      int32_t *tmp = g->samples[0]; g->samples[0] = g->samples[1]; g->samples[1] = tmp;
+    }
+    TN_HIP_CHECK(hipGetLastError());
+    steps_done = step;
+    if ((i & 15) == 15 || i == max_length - 1) {   // look at the device flag every 16 steps
+      int32_t f = 1;
+      TN_HIP_CHECK(hipMemcpyAsync(&f, g->flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      TN_HIP_CHECK(hipStreamSynchronize(s));
+      if (!f) { all_dead = 1; break; }
+    }
+  }
+  // g->samples[0] now holds the newest samples
+  if (!all_dead) {
+    hipLaunchKernelGGL(beam_finalize_kernel, dim3((R + 255) / 256), dim3(256), 0, s, g->alive, g->vlen, g->samples[0], L, steps_done + 1, R, eos);
+    *length_host = steps_done + 2;
+  }
+  TN_HIP_CHECK(hipMemcpyAsync(samples, g->samples[0], sizeof(int32_t) * (size_t)R * L, hipMemcpyDeviceToDevice, s));
+  TN_HIP_CHECK(hipMemcpyAsync(scores, g->scores, sizeof(float) * R, hipMemcpyDeviceToDevice, s));
+  TN_HIP_CHECK(hipMemcpyAsync(valid_length, g->vlen, sizeof(int32_t) * R, hipMemcpyDeviceToDevice, s));
+  if (all_dead) {   // the sampler returns as soon as every beam has finished: width = longest sample
+    std::vector<int32_t> vl(R);
+    TN_HIP_CHECK(hipMemcpyAsync(vl.data(), g->vlen, sizeof(int32_t) * R, hipMemcpyDeviceToHost, s));
+    TN_HIP_CHECK(hipStreamSynchronize(s));
+    int mx = 0;
+    for (int v : vl) mx = v > mx ? v : mx;
+    *length_host = mx;
+  }
+  return TN_OK;
+}
+
+extern "C" int tn_gnmt_destroy(tn_gnmt *g) {
+  if (!g) return TN_OK;
+  (void)hipSetDevice(g->ctx->device);
+  tn_birnn_destroy(g->enc0);
+  tn_birnn_destroy(g->enc1);
+  g->pool.release();
+  delete g;
+  return TN_OK;
+}

@@ -175,3 +175,53 @@ def temporal_pool(x: torch.Tensor, kind: str, ctx: _lib.Context | None = None) -
     check(ctx.lib.tn_temporal_pool(ctx.handle, ptr(x), b, t, f, _lib.POOL_MEAN if kind == "mean" else _lib.POOL_MAX,
                                    ptr(y)), "tn_temporal_pool")
     return y
+
+
+class GNMTCaptioner:
+    """Encoder + attention decoder + beam search of the reference captioner on the GPU
+    (train_gnmt.py:223-252 assembly; evaluate() at train_gnmt.py:264-302)."""
+
+    def __init__(self, params: dict, input_size: int, hidden: int, embed: int, vocab: int, beam: int = 4,
+                 max_length: int = 150, max_batch: int = 32, max_src_len: int = 640, prefix: str = "gnmt_",
+                 cell_type: str = "gru", num_layers: int = 2, num_bi_layers: int = 1,
+                 ctx: _lib.Context | None = None):
+        self.ctx = ctx or _lib.default_context()
+        self.lib = self.ctx.lib
+        self.hidden, self.beam, self.max_length, self.vocab = hidden, beam, max_length, vocab
+        arr, keep = _lib.make_params({k: v for k, v in params.items() if k.startswith(prefix)})
+        h = C.c_void_p()
+        kind = _lib.RNN_GRU if cell_type == "gru" else _lib.RNN_LSTM
+        check(self.lib.tn_gnmt_create(self.ctx.handle, arr, len(arr), prefix.encode(), kind, input_size, hidden, embed,
+                                      vocab, num_layers, num_bi_layers, max_batch, max_src_len, beam, max_length,
+                                      C.byref(h)), "tn_gnmt_create")
+        del keep
+        self.handle = h
+        self._batch = 0
+
+    def encode(self, src: torch.Tensor, valid_length: torch.Tensor) -> torch.Tensor:
+        src = src.contiguous().float()
+        b, t, _ = src.shape
+        vl = valid_length.to(device=src.device).round().to(torch.int32).contiguous()
+        mem = torch.empty((b, t, self.hidden), dtype=torch.float32, device=src.device)
+        check(self.lib.tn_gnmt_encode(self.handle, ptr(src), ptr(vl), b, t, ptr(mem)), "tn_gnmt_encode")
+        self._batch = b
+        return mem
+
+    def beam_search(self, bos: int, eos: int, alpha: float = 1.0, K: float = 5.0, max_length: int | None = None):
+        ml = self.max_length if max_length is None else max_length
+        b, dev = self._batch, torch.device("cuda", self.ctx.device)
+        samples = torch.empty((b, self.beam, self.max_length + 2), dtype=torch.int32, device=dev)
+        scores = torch.empty((b, self.beam), dtype=torch.float32, device=dev)
+        vlen = torch.empty((b, self.beam), dtype=torch.int32, device=dev)
+        n = C.c_int(0)
+        check(self.lib.tn_gnmt_beam_search(self.handle, bos, eos, alpha, K, ml, ptr(samples), ptr(scores), ptr(vlen),
+                                           C.byref(n)), "tn_gnmt_beam_search")
+        return samples[:, :, :n.value].contiguous(), scores, vlen
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.tn_gnmt_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass

@@ -1,0 +1,116 @@
+"""Encoder and decoder of the captioner — mirror of reference models/captioning/gnmt.py
+(itself derived from gluon-nlp) and of the NMTModel the reference builds from gluonnlp
+(train_gnmt.py:228-229).  The blocks hold configuration and Gluon-named parameters; the
+compute runs in libtennis_hip.so (tn_gnmt_*).  Only the configuration the reference
+actually uses is built: cell_type 'gru', attention 'scaled_luong', use_residual False.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from ... import weights as W
+from ...block import Block, Parameter
+
+__all__ = ["GNMTEncoder", "GNMTDecoder", "get_gnmt_encoder_decoder", "NMTModel", "Vocab"]
+
+
+def _cell_params(block, pref):
+    for n in ("i2h_weight", "h2h_weight", "i2h_bias", "h2h_bias"):
+        block._own_params[pref + n] = Parameter(pref + n)
+
+
+class GNMTEncoder(Block):
+    """reference gnmt.py:30-160: num_bi_layers bidirectional layers, then uni-directional ones."""
+
+    def __init__(self, cell_type="lstm", num_layers=2, num_bi_layers=1, hidden_size=128, dropout=0.0,
+                 use_residual=True, prefix=None, **kwargs):
+        super().__init__(prefix=prefix)
+        assert num_bi_layers <= num_layers                                  # gnmt.py:78-80
+        self._cell_type, self._num_layers, self._num_bi_layers = cell_type, num_layers, num_bi_layers
+        self._hidden_size, self._dropout, self._use_residual = hidden_size, dropout, use_residual
+        for i in range(num_layers):
+            if i < num_bi_layers:
+                _cell_params(self, f"{self.prefix}rnn{i}_l_")
+                _cell_params(self, f"{self.prefix}rnn{i}_r_")
+            else:
+                _cell_params(self, f"{self.prefix}rnn{i}_")
+
+
+class GNMTDecoder(Block):
+    """reference gnmt.py:163-404."""
+
+    def __init__(self, cell_type="lstm", attention_cell="scaled_luong", num_layers=2, hidden_size=128, dropout=0.0,
+                 use_residual=True, output_attention=False, prefix=None, **kwargs):
+        super().__init__(prefix=prefix)
+        self._cell_type, self._num_layers, self._hidden_size = cell_type, num_layers, hidden_size
+        self._attention_cell, self._use_residual, self._output_attention = attention_cell, use_residual, output_attention
+        for i in range(num_layers):
+            _cell_params(self, f"{self.prefix}rnn{i}_")
+        self._own_params[self.prefix + "attention_key_weight"] = Parameter(self.prefix + "attention_key_weight")
+
+
+def get_gnmt_encoder_decoder(cell_type="lstm", attention_cell="scaled_luong", num_layers=2, num_bi_layers=1,
+                             hidden_size=128, dropout=0.0, use_residual=False, prefix="gnmt_", **kwargs):
+    """reference gnmt.py:407-455 (same defaults)."""
+    encoder = GNMTEncoder(cell_type=cell_type, num_layers=num_layers, num_bi_layers=num_bi_layers,
+                          hidden_size=hidden_size, dropout=dropout, use_residual=use_residual, prefix=prefix + "enc_")
+    decoder = GNMTDecoder(cell_type=cell_type, attention_cell=attention_cell, num_layers=num_layers,
+                          hidden_size=hidden_size, dropout=dropout, use_residual=use_residual, prefix=prefix + "dec_")
+    return encoder, decoder
+
+
+class Vocab:
+    """gluonnlp.Vocab(counter) as the reference uses it (dataset.py:57-58): indices 0..3 are
+    <unk>, <pad>, <bos>, <eos>; then tokens by descending frequency, ties alphabetical [EXT]."""
+
+    def __init__(self, counter: dict):
+        self.unknown_token, self.padding_token, self.bos_token, self.eos_token = "<unk>", "<pad>", "<bos>", "<eos>"
+        toks = sorted(counter.items(), key=lambda kv: (-kv[1], kv[0]))
+        self.idx_to_token = [self.unknown_token, self.padding_token, self.bos_token, self.eos_token] + [t for t, _ in toks]
+        self.token_to_idx = {t: i for i, t in enumerate(self.idx_to_token)}
+
+    def __len__(self):
+        return len(self.idx_to_token)
+
+    def __getitem__(self, tokens):
+        if isinstance(tokens, str):
+            return self.token_to_idx.get(tokens, 0)
+        return [self.token_to_idx.get(t, 0) for t in tokens]
+
+
+class NMTModel(Block):
+    """``gluonnlp.model.translation.NMTModel(src_vocab=None, tgt_vocab, encoder, decoder, embed_size,
+    prefix, src_embed, tgt_embed)`` as called at reference train_gnmt.py:228-229: feature-mode source
+    (identity src_embed), Embedding(V, embed) target, Dense(V) projection."""
+
+    def __init__(self, src_vocab=None, tgt_vocab=None, encoder=None, decoder=None, embed_size=100, prefix="gnmt_",
+                 src_embed=None, tgt_embed=None, input_size=1024, seed=7, **kwargs):
+        super().__init__(prefix=prefix)
+        self.tgt_vocab, self.encoder, self.decoder = tgt_vocab, encoder, decoder
+        self._embed_size, self._input_size, self._seed = embed_size, input_size, seed
+        for n in ("tgt_proj_weight", "tgt_proj_bias", "tgt_embed_weight"):
+            self._own_params[prefix + n] = Parameter(prefix + n)
+        if tgt_embed is not None:                      # train_gnmt.py:211-218: preloaded embedding table
+            self._own_params[prefix + "tgt_embed_weight"].data = np.ascontiguousarray(tgt_embed, dtype=np.float32)
+
+    def initialize(self, init=None, ctx=None, **kwargs):
+        super().initialize()
+        if any(v.data is None for v in self.collect_params().values()):
+            enc = self.encoder
+            p = W.make_gnmt_weights(self._seed, enc._cell_type, self._input_size, enc._hidden_size, self._embed_size,
+                                    len(self.tgt_vocab), enc._num_layers, enc._num_bi_layers, self.prefix)
+            have = {k: v.data for k, v in self.collect_params().items() if v.data is not None}
+            p.update(have)
+            self.set_params(p)
+
+    def _captioner(self, beam, max_length, max_batch, max_src_len):
+        from ...engine import GNMTCaptioner
+        key = (beam, max_length)
+        if self._engine is None or self._engine[0] != key or self._engine[2] < max_batch or self._engine[3] < max_src_len:
+            p = {k: v.data for k, v in self.collect_params().items()}
+            enc = self.encoder
+            cap = GNMTCaptioner(p, self._input_size, enc._hidden_size, self._embed_size, len(self.tgt_vocab), beam,
+                                max_length, max(max_batch, 32), max(max_src_len, 256), self.prefix, enc._cell_type,
+                                enc._num_layers, enc._num_bi_layers)
+            self._engine = (key, cap, max(max_batch, 32), max(max_src_len, 256))
+        return self._engine[1]
