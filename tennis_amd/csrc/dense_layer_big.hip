@@ -57,7 +57,7 @@ struct DLGeom {
   static constexpr int MIW = BM / 128;                       // 16-row pixel fragments per wave
   static_assert(PIECES % 8 == 0, "DMA pieces must divide over 8 waves");
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
-  static_assert(RED_BYTES <= TILE_BYTES, "reduction buffer does not fit");
+  static_assert(RED_BYTES + 32 * NF * 80 <= TILE_BYTES, "reduction + output row buffers do not fit");
   static_assert(BM >= TR * W && BM % 128 == 0, "phase A tile too small");
   static_assert(BK == 32 || BK == 64, "BK");
 };
@@ -106,9 +106,19 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   const int H = a.H, K = a.K, ldc = a.ldc;
 #define DL_STAMP(i) do { if (a.ts && t == 0) a.ts[(long)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
   DL_STAMP(0);
+  // all row-tiles of a frame share blockIdx % 8 (the XCD) when B % 8 == 0, so the halo rows two
+  // neighbouring tiles both read are L2 hits on that XCD instead of second HBM fetches
   const int tiles_per_img = H / ROUT;
-  const int img = blockIdx.x / tiles_per_img;
-  const int r0 = (blockIdx.x - img * tiles_per_img) * ROUT;     // first output row
+  int img, tix;
+  if ((a.B & 7) == 0) {
+    const int j = blockIdx.x >> 3;
+    img = (j / tiles_per_img) * 8 + (blockIdx.x & 7);
+    tix = j % tiles_per_img;
+  } else {
+    img = blockIdx.x / tiles_per_img;
+    tix = blockIdx.x % tiles_per_img;
+  }
+  const int r0 = tix * ROUT;                                     // first output row
   const int rlo = r0 > 0 ? r0 - 1 : 0;                           // first computed bottleneck row
   const int rhi = (r0 + ROUT < H) ? r0 + ROUT + 1 : H;           // one past the last
   const int MA = (rhi - rlo) * W;                                // real phase-A rows
@@ -309,24 +319,34 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
             (f32x4){bacc[j][4 * q], bacc[j][4 * q + 1], bacc[j][4 * q + 2], bacc[j][4 * q + 3]};
   }
   __syncthreads();
+  // the summed halves go through an LDS row buffer (80-B pitch per pixel slot: 64 B of data,
+  // pitch chosen against ds_write_b64 bank conflicts) so that the global
+  // store is 16 B per lane with 4 lanes covering one pixel's 32 channels contiguously
+  unsigned char *obuf = smem + G::RED_BYTES;
   if (hh == 0) {
-    f16 *ybase = a.buf + ((long)img * H * W) * ldc + K;
 #pragma unroll
     for (int j = 0; j < MAXF; ++j) {
       if (f0 + j < f1) {
-        const int s = WP + 32 * (f0 + j) + px;       // tile slot of this lane's output pixel
-        const int tr = s / WP, xp = s - tr * WP;
-        const bool ok = xp >= 1 && xp <= W && tr >= 1 && tr <= ROUT;
-        f16 *dst = ybase + ((long)(r0 + tr - 1) * W + (xp - 1)) * ldc + 4 * khalf;
+        const int srel = 32 * (f0 + j) + px;         // slot relative to the first output slot
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 o = *(const f32x4 *)(red + ((g * MAXF + j) * 4 + q) * 1024 + lane * 16);
           f16x4 hv;
 #pragma unroll
           for (int r = 0; r < 4; ++r) hv[r] = (f16)(bacc[j][4 * q + r] + o[r]);
-          if (ok) *(f16x4 *)(dst + 8 * q) = hv;
+          *(f16x4 *)(obuf + srel * 80 + (8 * q + 4 * khalf) * 2) = hv;
         }
       }
+    }
+  }
+  __syncthreads();
+  {
+    f16 *ybase = a.buf + ((long)img * H * W + (long)r0 * W) * ldc + K;
+    for (int id = t; id < ROUT * W * 4; id += 512) {
+      const int pi = id >> 2, c = id & 3;
+      const int r = pi / W, x = pi - r * W;
+      const uint4 v = *(const uint4 *)(obuf + (r * WP + x + 1) * 80 + c * 16);
+      *(uint4 *)(ybase + (long)pi * ldc + c * 8) = v;
     }
   }
   DL_STAMP(6);
