@@ -316,14 +316,21 @@ static int encoder_run(tn_encoder *e, const void *x, tn_layout layout, int B, fl
   {
     StemArgs a{x, (int)layout, B, e->H, e->W, e->stem_wp, e->stem_scale, e->stem_shift, e->stem_out, e->Hs, e->Ws};
     const double px = fB * e->Hs * e->Ws;
-    tm.begin("stem_conv7x7_bn_relu", 2.0 * px * 64 * 147, fB * e->H * e->W * 3 * 2 + px * 64 * 2);
-    rc = launch_stem(a, s);
-    tm.end();
-    if (rc) return rc;
-    tm.begin("maxpool3x3s2", 0.0, px * 64 * 2 + fB * e->Hb[0] * e->Wb[0] * 64 * 2);
-    rc = launch_maxpool3x3s2(e->stem_out, B, e->Hs, e->Ws, 64, e->blockbuf[0], e->Cb[0], e->Hb[0], e->Wb[0], s);
-    tm.end();
-    if (rc) return rc;
+    if (e->fuse) {
+      tm.begin("stem_conv_bn_relu_maxpool", 2.0 * px * 64 * 147, fB * e->H * e->W * 3 * 2 + fB * e->Hb[0] * e->Wb[0] * 64 * 2);
+      rc = launch_stem_pool(a, e->blockbuf[0], e->Cb[0], e->Hb[0], e->Wb[0], s);
+      tm.end();
+      if (rc) return rc;
+    } else {
+      tm.begin("stem_conv7x7_bn_relu", 2.0 * px * 64 * 147, fB * e->H * e->W * 3 * 2 + px * 64 * 2);
+      rc = launch_stem(a, s);
+      tm.end();
+      if (rc) return rc;
+      tm.begin("maxpool3x3s2", 0.0, px * 64 * 2 + fB * e->Hb[0] * e->Wb[0] * 64 * 2);
+      rc = launch_maxpool3x3s2(e->stem_out, B, e->Hs, e->Ws, 64, e->blockbuf[0], e->Cb[0], e->Hb[0], e->Wb[0], s);
+      tm.end();
+      if (rc) return rc;
+    }
   }
   for (int b = 0; b < 4; ++b) {
     const int Hh = e->Hb[b], Ww = e->Wb[b];
@@ -396,7 +403,10 @@ extern "C" int tn_densenet121_read_tap(tn_encoder *e, const char *tap_c, int bat
   const std::string tap(tap_c);
   const f16 *src = nullptr;
   int hh = 0, ww = 0, cc = 0, ld = 0;
-  if (tap == "stem") { src = e->stem_out; hh = e->Hs; ww = e->Ws; cc = 64; ld = 64; }
+  if (tap == "stem") {
+    TN_REQUIRE(!e->fuse, "read_tap: the stem map is not materialised when stem+maxpool are fused (use pool0)");
+    src = e->stem_out; hh = e->Hs; ww = e->Ws; cc = 64; ld = 64;
+  }
   else if (tap == "pool0") { src = e->blockbuf[0]; hh = e->Hb[0]; ww = e->Wb[0]; cc = 64; ld = e->Cb[0]; }
   else if (tap.rfind("stage", 0) == 0 && tap.size() == 6) {
     const int b = tap[5] - '1';

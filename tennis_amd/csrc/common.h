@@ -114,6 +114,8 @@ struct StemArgs {
   int Ho, Wo;
 };
 int launch_stem(const StemArgs &a, hipStream_t s);
+// fused stem + maxpool: writes the pooled map (Hp x Wp x 64) at row stride ldy
+int launch_stem_pool(const StemArgs &a, f16 *out, int ldy, int Hp, int Wp, hipStream_t s);
 
 int launch_maxpool3x3s2(const f16 *x, int B, int H, int W, int C, f16 *y, int ldy, int Ho, int Wo, hipStream_t s);
 int launch_head(const f16 *x, int B, int H, int W, int C, const float *scale, const float *shift,

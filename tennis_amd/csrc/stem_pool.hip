@@ -1,0 +1,167 @@
+// K1 fused — stem Convolution 7x7/2 pad 3 (3 -> 64) + BatchNorm + ReLU + MaxPool 3x3/2 pad 1,
+// the first four operators of gluoncv's DenseNet .features (reference call site
+// models/vision/definitions.py:30).  The 112x112x64 conv map never goes
+// to HBM: a workgroup owns a 4 x 14 tile of POOLED pixels, computes the 9 x 32 conv pixels
+// under it (one halo row/column recomputed) on v_mfma_f32_16x16x32_f16, applies BN+ReLU in
+// fp32, parks the fp16 result in LDS and max-pools it from there straight into channels
+// [0,64) of dense block 1's concat buffer.  Post-ReLU values are >= 0, so out-of-range conv
+// positions (MaxPool pads with -inf) are represented by 0.
+// Operand layout as in stem.hip: one k-step per kernel row ky; the 32 k-slots are 8 x-taps x
+// 4 channels (tap 7 and channel 3 carry zero weights), so a lane's 8 values are 2 adjacent
+// NHWC4 pixels = one aligned ds_read_b128 of the staged input patch.
+#include "common.h"
+
+namespace {
+
+constexpr int PR = 4, PC = 14;            // pooled tile
+constexpr int CR = 2 * PR + 1, CC = 32;   // conv tile (rows, cols; 29 of the 32 columns are needed)
+constexpr int IR = 2 * CR + 5;            // 23 input rows
+constexpr int IPITCH = 576;               // bytes per input patch row: 72 px * 8 B
+constexpr int CPX = 136;                  // bytes per conv pixel in LDS: 64 ch fp16 + 8 pad (bank spread)
+constexpr int NFRAG = CR * 2;             // 16-pixel fragments of the conv tile
+
+// raw channel triple of one input pixel (address clamped by the caller, always in bounds)
+template <int LAY>
+__device__ __forceinline__ void load_raw(const StemArgs &a, long pix, long plane, float (&v)[3]) {
+  if constexpr (LAY == TN_LAYOUT_NCHW_F32) {
+    const float *x = (const float *)a.x + pix;      // pix = b*3*plane + iy*W + ix
+    v[0] = x[0]; v[1] = x[plane]; v[2] = x[2 * plane];
+  } else if constexpr (LAY == TN_LAYOUT_NHWC_F16) {
+    const f16 *x = (const f16 *)a.x + pix * 3;      // pix = (b*H + iy)*W + ix
+    v[0] = (float)x[0]; v[1] = (float)x[1]; v[2] = (float)x[2];
+  } else {
+    const uint8_t *x = (const uint8_t *)a.x + pix * 3;
+    // ToTensor (/255) then Normalize (mean,std) — reference evaluate.py:96-97
+    v[0] = ((float)x[0] / 255.0f - 0.485f) / 0.229f;
+    v[1] = ((float)x[1] / 255.0f - 0.456f) / 0.224f;
+    v[2] = ((float)x[2] / 255.0f - 0.406f) / 0.225f;
+  }
+}
+
+template <int LAY>
+__global__ __launch_bounds__(256) void stem_pool_kernel(StemArgs a, f16 *__restrict__ out, int ldy, int Hp, int Wp) {
+  __shared__ __attribute__((aligned(16))) unsigned char patch[IR * IPITCH];
+  __shared__ __attribute__((aligned(16))) unsigned char ctile[CR * CC * CPX];
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int b = blockIdx.z;
+  const int pr0 = blockIdx.y * PR;
+  const int cy0 = 2 * pr0 - 1;                           // conv row of the tile origin
+  const int iy0 = 2 * cy0 - 3;                           // input row of the patch origin
+  const int pl = lane & 15, kc = lane >> 4;
+  const int ntc = (Wp + PC - 1) / PC;                    // column tiles walked by this workgroup
+
+  // all weight fragments stay in registers for the whole row strip: [ky][nfrag]
+  f16x8 wa[7][4];
+#pragma unroll
+  for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) wa[ky][nf] = ((const f16x8 *)a.wp)[(ky * 4 + nf) * 64 + lane];
+  float sc[4][4], sh[4][4];
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sc[nf][r] = a.scale[nf * 16 + kc * 4 + r];
+      sh[nf][r] = a.shift[nf * 16 + kc * 4 + r];
+    }
+
+  // input patch staging, split in two halves so the loads of tile ct+1 fly during the MFMAs of
+  // tile ct: request (clamped addresses, all loads issued back to back) / commit (zero what lies
+  // outside the frame, write NHWC4 fp16 to LDS)
+  constexpr int NPX = (IR * 72 + 255) / 256;    // 7 pixels per thread
+  float raw[NPX][3];
+  const long plane = (long)a.H * a.W;
+  auto request = [&](int ct) {
+    const int ix0 = 2 * (2 * ct * PC - 1) - 3;
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      const int p = t + 256 * i;
+      const int pr = p / 72, pc = p - pr * 72;
+      const int iy = iy0 + pr, ix = ix0 + pc;
+      const int cy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy), cx = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
+      const long pix = LAY == TN_LAYOUT_NCHW_F32 ? (long)b * 3 * plane + (long)cy * a.W + cx
+                                                  : ((long)b * a.H + cy) * a.W + cx;
+      load_raw<LAY>(a, pix, plane, raw[i]);
+    }
+  };
+  auto commit = [&](int ct) {
+    const int ix0 = 2 * (2 * ct * PC - 1) - 3;
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      const int p = t + 256 * i;
+      const int pr = p / 72, pc = p - pr * 72;
+      const int iy = iy0 + pr, ix = ix0 + pc;
+      const bool in = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      f16x4 v;
+      v[0] = in ? (f16)raw[i][0] : (f16)0.f;
+      v[1] = in ? (f16)raw[i][1] : (f16)0.f;
+      v[2] = in ? (f16)raw[i][2] : (f16)0.f;
+      v[3] = (f16)0.f;
+      if (p < IR * 72) *(f16x4 *)(patch + pr * IPITCH + pc * 8) = v;
+    }
+  };
+
+  request(0);
+  commit(0);
+  __syncthreads();
+  for (int ct = 0; ct < ntc; ++ct) {
+    const int pc0 = ct * PC, cx0 = 2 * pc0 - 1;
+    if (ct + 1 < ntc) request(ct + 1);
+    // conv + BN + ReLU -> LDS; fragments are dealt round-robin to the 4 waves
+    for (int f = wid; f < NFRAG; f += 4) {
+      const int r = f >> 1, c = (f & 1) * 16 + pl;          // conv row / column inside the tile
+      f32x4 acc[4];
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) acc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) {
+        const f16x8 xb = *(const f16x8 *)(patch + (2 * r + ky) * IPITCH + (c + kc) * 16);
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ky][nf], xb, acc[nf], 0, 0, 0);
+      }
+      const bool valid = (unsigned)(cy0 + r) < (unsigned)a.Ho && (unsigned)(cx0 + c) < (unsigned)a.Wo;
+      unsigned char *dst = ctile + (r * CC + c) * CPX + kc * 8;
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        f16x4 h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h[q] = (f16)fmaxf(fmaf(acc[nf][q], sc[nf][q], sh[nf][q]), 0.f);
+        if (!valid) h = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+        *(f16x4 *)(dst + nf * 32) = h;
+      }
+    }
+    __syncthreads();                      // conv tile complete; nobody reads the patch any more
+    if (ct + 1 < ntc) commit(ct + 1);
+    // 3x3/2 max pool out of LDS: one (pooled pixel, 4-channel group) per work item
+    for (int id = t; id < PR * PC * 16; id += 256) {
+      const int pp = id >> 4, cg = id & 15;
+      const int pr = pp / PC, pc = pp - pr * PC;
+      if (pr0 + pr >= Hp || pc0 + pc >= Wp) continue;
+      f16x4 o = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};      // packed fp16 max (exact: values are fp16 already)
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+          o = __builtin_elementwise_max(o, *(const f16x4 *)(ctile + ((2 * pr + dy) * CC + 2 * pc + dx) * CPX + cg * 8));
+      *(f16x4 *)(out + (((long)b * Hp + pr0 + pr) * Wp + pc0 + pc) * ldy + cg * 4) = o;
+    }
+    __syncthreads();                      // pooling done before the next tile overwrites ctile
+  }
+}
+
+}  // namespace
+
+// conv output (Ho,Wo) is implied by a.Ho/a.Wo; pooled output (Hp,Wp) = ((Ho-1)/2+1, (Wo-1)/2+1)
+int launch_stem_pool(const StemArgs &a, f16 *out, int ldy, int Hp, int Wp, hipStream_t s) {
+  TN_REQUIRE(a.layout >= 0 && a.layout <= 2, "stem: unknown input layout");
+  TN_REQUIRE(ldy % 4 == 0, "stem: output stride must be a multiple of 4");
+  const dim3 grid(1, (Hp + PR - 1) / PR, a.B), block(256);   // a workgroup walks one strip of 4 pooled rows
+  if (a.layout == TN_LAYOUT_NCHW_F32)
+    hipLaunchKernelGGL(stem_pool_kernel<TN_LAYOUT_NCHW_F32>, grid, block, 0, s, a, out, ldy, Hp, Wp);
+  else if (a.layout == TN_LAYOUT_NHWC_F16)
+    hipLaunchKernelGGL(stem_pool_kernel<TN_LAYOUT_NHWC_F16>, grid, block, 0, s, a, out, ldy, Hp, Wp);
+  else
+    hipLaunchKernelGGL(stem_pool_kernel<TN_LAYOUT_NHWC_U8>, grid, block, 0, s, a, out, ldy, Hp, Wp);
+  TN_HIP_CHECK(hipGetLastError());
+  return TN_OK;
+}
