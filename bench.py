@@ -39,6 +39,19 @@ def make_frames(batch, size, seed, device):
     return ((u8.float() / 255.0 - mean) / std).half().contiguous()
 
 
+def pmc_traffic(kernel_family):
+    """HBM bytes per launch of the dominant kernel family from the newest committed rocprofv3 PMC
+    summary (profiles/*_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2
+    FETCH correction).  PMC counters cannot be read from inside the timed process."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    fam = json.load(open(files[-1])).get("families", {})
+    key = "dense_layer_fused(all)" if kernel_family == "dense_layer_fused" else kernel_family
+    return fam.get(key, {}).get("hbm_bytes_per_dispatch_corrected")
+
+
 def cpu_baseline(params, frames_nhwc_f16, seconds_target=12.0):
     """Reference CPU path stand-in (oracle/torch_ref.py, fp32, oneDNN) on a bounded sample."""
     from oracle.torch_ref import TorchDenseNet121
@@ -136,7 +149,8 @@ def main():
         d = fams[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom),
+                    "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
                     "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2), "launches_per_step": d["launches"] // 3,
                     "families_ms_per_step": {k: round(v["ms"] / 3, 3) for k, v in fams.items()},
                     "encoder_tflops": round(FLOP_PER_FRAME * fps / world / 1e12, 2),

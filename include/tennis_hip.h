@@ -159,6 +159,13 @@ int tn_gnmt_create(tn_ctx *ctx, const tn_param *params, int n_params, const char
 int tn_gnmt_encode(tn_gnmt *g, const float *src, const int32_t *valid_len, int batch, int steps, float *mem_out);
 int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, float K, int max_length, int32_t *samples,
                         float *scores, int32_t *valid_length, int *length_host);
+/* Teacher forcing: model(src, tgt[:, :-1], ...) of evaluate() (train_gnmt.py:280) ->
+ * GNMTDecoder.decode_seq (gnmt.py:254-304).  tgt (B, ld) int32 DEVICE tokens, first `steps`
+ * columns are fed; logits (B, steps, V) fp32.  Needs a preceding tn_gnmt_encode. */
+int tn_gnmt_decode_seq(tn_gnmt *g, const int32_t *tgt, int ld, int steps, float *logits);
+/* MaskedSoftmaxCELoss [EXT gluonnlp] (train_gnmt.py:256,281): loss (B,) fp32. */
+int tn_masked_softmax_ce(tn_ctx *ctx, const float *logits, const int32_t *labels, int ld_labels,
+                         const int32_t *valid_len, int batch, int steps, int vocab, float *loss);
 int tn_gnmt_destroy(tn_gnmt *g);
 
 /* ---- test hooks (used by tests/ only) -------------------------------------- */

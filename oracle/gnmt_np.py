@@ -149,3 +149,27 @@ def beam_search(dec: Decoder, mem, enc_states, valid_length, bos, eos, beam=4, a
 def ids_to_sentences(samples, vlen, idx_to_token):
     """train_gnmt.py:289-294: best beam, strip BOS/EOS via [1 : valid_len-1]."""
     return [[idx_to_token[int(t)] for t in samples[i, 0, 1:int(vlen[i, 0]) - 1]] for i in range(samples.shape[0])]
+
+
+def decode_seq(dec: Decoder, mem, enc_states, valid_length, tgt):
+    """Teacher forcing: NMTModel.forward -> GNMTDecoder.decode_seq (gnmt.py:254-304) as called at
+    train_gnmt.py:280.  tgt (B,L) ids -> logits (B,L,V) (log-softmax NOT applied)."""
+    B, L = tgt.shape
+    rnn_states, att = dec.init_state(mem, enc_states, valid_length)
+    rows = np.arange(B)
+    p, pre = dec.p, dec.pre
+    outs = []
+    for i in range(L):
+        logp, rnn_states, att = dec.step(np.maximum(tgt[:, i], 0), rnn_states, att, rows)
+        # recover the un-normalised logits: recompute the projection from the top state
+        outs.append((rnn_states[-1] @ p[pre + "tgt_proj_weight"].T + p[pre + "tgt_proj_bias"]).astype(np.float32))
+    return np.stack(outs, axis=1)
+
+
+def masked_softmax_ce(logits, labels, valid_length):
+    """gluonnlp MaskedSoftmaxCELoss [EXT]: mean over the L steps of -logp[label] * (t < valid_len)."""
+    B, L, V = logits.shape
+    logp = _log_softmax(logits)
+    nll = -np.take_along_axis(logp, labels[:, :, None].astype(np.int64), axis=2)[:, :, 0]
+    mask = (np.arange(L)[None, :] < np.asarray(valid_length)[:, None])
+    return (nll * mask).mean(axis=1).astype(np.float32)

@@ -62,6 +62,8 @@ _SIGS = {
     "tn_gnmt_encode": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
     "tn_gnmt_beam_search": (C.c_int, [_P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, _P, _P, _P,
                                       C.POINTER(C.c_int)]),
+    "tn_gnmt_decode_seq": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "tn_masked_softmax_ce": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
     "tn_gnmt_destroy": (C.c_int, [_P]),
     "tn_dbg_conv1x1": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int]),

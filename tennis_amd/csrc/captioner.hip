@@ -233,6 +233,40 @@ __global__ void beam_finalize_kernel(const int32_t *alive, int32_t *vlen, int32_
   vlen[id] += alive[id] ? 1 : 0;
 }
 
+__global__ void take_column_kernel(const int32_t *__restrict__ tgt, int ld, int col, int32_t *__restrict__ tok, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) { const int v = tgt[(long)b * ld + col]; tok[b] = v > 0 ? v : 0; }
+}
+
+// MaskedSoftmaxCELoss [EXT gluonnlp]: per sample, mean over the L time steps of
+// -log_softmax(logits[b,t])[label[b,t]] * (t < valid_len[b]).  One workgroup per sample.
+__global__ __launch_bounds__(256) void masked_ce_kernel(const float *__restrict__ logits, const int32_t *__restrict__ labels,
+                                                        int ldl, const int32_t *__restrict__ valid_len, float *__restrict__ loss,
+                                                        int L, int V) {
+  __shared__ float red[256];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int vl = valid_len[b];
+  float total = 0.f;
+  for (int s = 0; s < L && s < vl; ++s) {
+    const float *z = logits + ((long)b * L + s) * V;
+    float mx = -INFINITY;
+    for (int v = t; v < V; v += 256) mx = fmaxf(mx, z[v]);
+    red[t] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] = fmaxf(red[t], red[t + o]); __syncthreads(); }
+    mx = red[0];
+    __syncthreads();
+    float sum = 0.f;
+    for (int v = t; v < V; v += 256) sum += expf(z[v] - mx);
+    red[t] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+    if (t == 0) total += -(z[labels[(long)b * ldl + s]] - mx - logf(red[0]));
+    __syncthreads();
+  }
+  if (t == 0) loss[b] = total / (float)L;
+}
+
 struct DevBuf {
   std::vector<void *> ptrs;
   bool failed = false;
@@ -443,6 +477,58 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
     for (int v : vl) mx = v > mx ? v : mx;
     *length_host = mx;
   }
+  return TN_OK;
+}
+
+// Teacher-forced decoding, NMTModel.forward -> GNMTDecoder.decode_seq (reference
+// models/captioning/gnmt.py:254-304) as called by evaluate() (train_gnmt.py:280): feeds
+// tgt[:, 0..L-1] one step at a time from the encoder state left by tn_gnmt_encode and writes the
+// projected logits (B, L, V).  tgt is a DEVICE (B, ld) int32 array.
+extern "C" int tn_gnmt_decode_seq(tn_gnmt *g, const int32_t *tgt, int ld, int steps, float *logits) {
+  TN_REQUIRE(g && tgt && logits, "tn_gnmt_decode_seq: null argument");
+  TN_REQUIRE(g->B > 0, "tn_gnmt_decode_seq: call tn_gnmt_encode first");
+  TN_REQUIRE(steps >= 1 && ld >= steps, "tn_gnmt_decode_seq: bad target length");
+  TN_HIP_CHECK(hipSetDevice(g->ctx->device));
+  hipStream_t s = g->ctx->stream;
+  const int B = g->B, T = g->T, H = g->H, E = g->E, V = g->V, G3 = 3 * H, R = B;
+  const int nb = (R * H + 255) / 256;
+  hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)(g->hl0 + (size_t)B * H), g->h0[0], B, 1, H);
+  hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)g->hl1, g->h1[0], B, 1, H);
+  hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)nullptr, g->att[0], B, 1, H);
+  const size_t att_lds = (size_t)(H + T + 256) * sizeof(float);
+  int cur = 0;
+  for (int i = 0; i < steps; ++i) {
+    const int nxt = cur ^ 1;
+    hipLaunchKernelGGL(take_column_kernel, dim3((B + 255) / 256), dim3(256), 0, s, tgt, ld, i, g->tok, B);
+    hipLaunchKernelGGL(embed_concat_kernel, dim3(R), dim3(128), 0, s, g->emb, g->tok, g->att[cur], g->x0, R, E, H);
+    int rc = launch_linear_f32(g->x0, E + H, g->wi0, E + H, g->bi0, g->gi, G3, R, G3, E + H, 0, s);
+    if (rc) return rc;
+    rc = launch_linear_f32(g->h0[cur], H, g->wh0, H, g->bh0, g->gh, G3, R, G3, H, 0, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gru_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->h0[cur], g->h0[nxt], g->x1, 2 * H, R, H);
+    hipLaunchKernelGGL(attention_kernel, dim3(R), dim3(256), att_lds, s, g->h0[nxt], g->keyproj, g->mem, g->vl, g->att[nxt], g->x1, 1, T, H);
+    rc = launch_linear_f32(g->x1, 2 * H, g->wi1, 2 * H, g->bi1, g->gi, G3, R, G3, 2 * H, 0, s);
+    if (rc) return rc;
+    rc = launch_linear_f32(g->h1[cur], H, g->wh1, H, g->bh1, g->gh, G3, R, G3, H, 0, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gru_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->h1[cur], g->h1[nxt], (float *)nullptr, 0, R, H);
+    rc = launch_linear_f32(g->h1[nxt], H, g->wp, H, g->bp, logits + (size_t)i * V, steps * V, R, V, H, 0, s);
+    if (rc) return rc;
+    cur = nxt;
+  }
+  TN_HIP_CHECK(hipGetLastError());
+  return TN_OK;
+}
+
+// MaskedSoftmaxCELoss of gluonnlp as used at reference train_gnmt.py:256,281: loss (B,) =
+// mean over the L steps of the label's negative log-probability, masked by valid_len.
+extern "C" int tn_masked_softmax_ce(tn_ctx *ctx, const float *logits, const int32_t *labels, int ld_labels,
+                                    const int32_t *valid_len, int batch, int steps, int vocab, float *loss) {
+  TN_REQUIRE(ctx && logits && labels && valid_len && loss, "tn_masked_softmax_ce: null argument");
+  TN_REQUIRE(batch > 0 && steps > 0 && vocab > 0 && ld_labels >= steps, "tn_masked_softmax_ce: bad shape");
+  TN_HIP_CHECK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(masked_ce_kernel, dim3(batch), dim3(256), 0, ctx->stream, logits, labels, ld_labels, valid_len, loss, steps, vocab);
+  TN_HIP_CHECK(hipGetLastError());
   return TN_OK;
 }
 

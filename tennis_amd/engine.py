@@ -207,6 +207,14 @@ class GNMTCaptioner:
         self._batch = b
         return mem
 
+    def decode_seq(self, tgt: torch.Tensor) -> torch.Tensor:
+        """Teacher-forced logits (B, L, V) for target tokens (B, L) after encode()."""
+        tgt = tgt.to(device=torch.device("cuda", self.ctx.device)).round().to(torch.int32).contiguous()
+        b, l = tgt.shape
+        logits = torch.empty((b, l, self.vocab), dtype=torch.float32, device=tgt.device)
+        check(self.lib.tn_gnmt_decode_seq(self.handle, ptr(tgt), l, l, ptr(logits)), "tn_gnmt_decode_seq")
+        return logits
+
     def beam_search(self, bos: int, eos: int, alpha: float = 1.0, K: float = 5.0, max_length: int | None = None):
         ml = self.max_length if max_length is None else max_length
         b, dev = self._batch, torch.device("cuda", self.ctx.device)
@@ -225,3 +233,17 @@ class GNMTCaptioner:
                 self.handle = None
         except Exception:
             pass
+
+
+def masked_softmax_ce(logits: torch.Tensor, labels: torch.Tensor, valid_length: torch.Tensor,
+                      ctx: _lib.Context | None = None) -> torch.Tensor:
+    """``gluonnlp.loss.MaskedSoftmaxCELoss`` (reference train_gnmt.py:256,281): (B,) losses."""
+    ctx = ctx or _lib.default_context()
+    logits = logits.contiguous().float()
+    b, l, v = logits.shape
+    lab = labels.to(logits.device).round().to(torch.int32).contiguous()
+    vl = valid_length.to(logits.device).round().to(torch.int32).contiguous()
+    loss = torch.empty((b,), dtype=torch.float32, device=logits.device)
+    check(ctx.lib.tn_masked_softmax_ce(ctx.handle, ptr(logits), ptr(lab), lab.shape[1], ptr(vl), b, l, v, ptr(loss)),
+          "tn_masked_softmax_ce")
+    return loss

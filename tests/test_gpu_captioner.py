@@ -67,3 +67,51 @@ def test_translator_surface():
     rmem, rstates = gn.encoder(src, np.array([9, 5, 7]), p, "gru", 32)
     rs, _, rvl = gn.beam_search(gn.Decoder(p, 32), rmem, rstates, np.array([9, 5, 7]), 2, 3, 4, 1.0, 5, 20)
     assert sents == gn.ids_to_sentences(rs, rvl, vocab.idx_to_token)
+
+
+def test_teacher_forcing_and_loss(report):
+    """model(src, tgt[:, :-1]) logits and MaskedSoftmaxCELoss (train_gnmt.py:280-281) vs the oracle."""
+    from tennis_amd import weights as W
+    from tennis_amd.engine import GNMTCaptioner, masked_softmax_ce
+    B, T, F, H, E, V, L = 4, 17, 48, 32, 16, 50, 9
+    p = W.make_gnmt_weights(11, "gru", F, H, E, V)
+    p["gnmt_tgt_proj_weight"] = (p["gnmt_tgt_proj_weight"] * 20).astype(np.float32)
+    rng = np.random.default_rng(11)
+    src = (np.abs(rng.normal(0, 1, (B, T, F))) * 0.5).astype(np.float32)
+    svl = np.array([17, 9, 12, 5], np.int32)
+    tgt = rng.integers(4, V, (B, L)).astype(np.int32)
+    tvl = np.array([9, 4, 7, 9], np.int32)
+    cap = GNMTCaptioner(p, F, H, E, V, beam=4, max_length=20, max_batch=B, max_src_len=T)
+    cap.encode(torch.from_numpy(src).cuda(), torch.from_numpy(svl).cuda())
+    logits = cap.decode_seq(torch.from_numpy(tgt[:, :-1]).cuda())
+    loss = masked_softmax_ce(logits, torch.from_numpy(tgt[:, 1:]).cuda(), torch.from_numpy(tvl - 1).cuda()).cpu().numpy()
+    rmem, rstates = gn.encoder(src, svl, p, "gru", H)
+    rl = gn.decode_seq(gn.Decoder(p, H), rmem, rstates, svl, tgt[:, :-1])
+    rloss = gn.masked_softmax_ce(rl, tgt[:, 1:], tvl - 1)
+    report["gnmt_teacher_forced_logits_maxabs_err"] = float(np.abs(logits.cpu().numpy() - rl).max())
+    assert np.abs(logits.cpu().numpy() - rl).max() < 1e-4
+    assert np.abs(loss - rloss).max() < 1e-5
+
+
+def test_captioning_evaluate_driver():
+    """CaptionSet + bucketed Pad batches + evaluate() (train_gnmt.py:264-302): sentences come back in
+    dataset order and equal the oracle's."""
+    from tennis_amd.captions import CaptionSet, bucketed_batches, evaluate
+    from tennis_amd.models.captioning.gnmt import NMTModel, get_gnmt_encoder_decoder
+    from tennis_amd.utils.translation import BeamSearchScorer, BeamSearchTranslator
+    train = CaptionSet(split="train", n_points=12, feature_dim=64, mean_frames=12, max_cap_len=50)
+    test = CaptionSet(split="test", n_points=7, feature_dim=64, mean_frames=12, vocab=train.vocab, inference=True)
+    assert test.vocab is train.vocab and test[0][1][0] == 2 and test[0][1][-1] == 3
+    enc, dec = get_gnmt_encoder_decoder(cell_type="gru", hidden_size=32, num_layers=2, num_bi_layers=1)
+    model = NMTModel(src_vocab=None, tgt_vocab=train.vocab, encoder=enc, decoder=dec, embed_size=16, prefix="gnmt_",
+                     input_size=64)
+    model.initialize()
+    tr = BeamSearchTranslator(model=model, beam_size=4, scorer=BeamSearchScorer(alpha=1.0, K=5), max_length=12)
+    loss, sents = evaluate(bucketed_batches(test, batch_size=3), model, tr, train)
+    assert len(sents) == 7 and all(s is not None for s in sents) and np.isfinite(loss)
+    p = {k: v.data for k, v in model.collect_params().items()}
+    for i in range(7):                                   # per-clip oracle, no padding involved
+        x, cap, tl, cl, idx = test[i]
+        rmem, rst = gn.encoder(x[None], np.array([tl]), p, "gru", 32)
+        rs, _, rvl = gn.beam_search(gn.Decoder(p, 32), rmem, rst, np.array([tl]), 2, 3, 4, 1.0, 5, 12)
+        assert sents[i] == gn.ids_to_sentences(rs, rvl, train.vocab.idx_to_token)[0]
