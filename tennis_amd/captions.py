@@ -112,7 +112,7 @@ def bucketed_batches(dataset, batch_size, num_buckets=5):
 def write_sentences(sentences, file_path):                             # utils/captioning.py:89-95
     with io.open(file_path, "w", encoding="utf-8") as of:
         for sent in sentences:
-            of.write((u" ".join(sent) if isinstance(sent, (list, tuple)) else sent) + u"\\n")
+            of.write((u" ".join(sent) if isinstance(sent, (list, tuple)) else sent) + u"\n")
 
 
 def evaluate(data_loader, model, translator, data_train):

@@ -193,3 +193,69 @@ def test_block_surface_roundtrip(tmp_path):
     m.collect_params().reset_ctx([0])
     for prm in m.collect_params().values():
         prm.grad_req = "null"                                       # evaluate.py:152-154
+
+
+def test_caption_set_batching_and_sentences(tmp_path):
+    """dataset.py:52-74 caption ids, utils/captioning.py Pad batches + write_sentences (host logic only)."""
+    from tennis_amd.captions import CaptionSet, bucketed_batches, pad_batchify, write_sentences
+    train = CaptionSet(split="train", n_points=10, feature_dim=8, mean_frames=6, max_cap_len=5)
+    v = train.vocab
+    assert v.idx_to_token[:4] == ["<unk>", "<pad>", "<bos>", "<eos>"]
+    x, cap, tl, cl = train[0]
+    assert cap.dtype == np.int32 and cap[0] == v["<bos>"] and cap[-1] == v["<eos>"] and cl == len(cap) <= 7
+    assert x.shape == (tl, 8)
+    test = CaptionSet(split="test", n_points=9, feature_dim=8, mean_frames=6, vocab=v, inference=True, every=2)
+    seen = []
+    for src, tgt, svl, tvl, ids in bucketed_batches(test, 4):
+        assert src.dtype == np.float32 and tgt.dtype == np.int32 and svl.dtype == np.float32
+        for r, i in enumerate(ids):
+            s = test[int(i)]
+            assert np.array_equal(src[r, :s[2]], s[0]) and not src[r, s[2]:].any()
+            assert np.array_equal(tgt[r, :s[3]], s[1]) and not tgt[r, s[3]:].any()
+        seen += ids.tolist()
+    assert sorted(seen) == list(range(9))
+    f = tmp_path / "out.txt"
+    write_sentences([["a", "b"], "c d"], str(f))
+    assert f.read_text() == "a b\nc d\n"
+
+
+def test_gnmt_oracle_properties():
+    """Beam 1 == greedy argmax decoding; padding the source does not change the result;
+    BOS first / EOS at valid_len-1; teacher-forced log-softmax row equals the step's logp."""
+    from oracle import gnmt_np as gn
+    from tennis_amd import weights as W
+    F, H, E, V = 24, 16, 8, 30
+    p = W.make_gnmt_weights(3, "gru", F, H, E, V)
+    p["gnmt_tgt_proj_weight"] = (p["gnmt_tgt_proj_weight"] * 20).astype(np.float32)
+    rng = np.random.default_rng(3)
+    x = np.abs(rng.normal(0, 1, (2, 9, F))).astype(np.float32)
+    vl = np.array([9, 6])
+    mem, st = gn.encoder(x, vl, p, "gru", H)
+    assert not mem[1, 6:].any()
+    dec = gn.Decoder(p, H)
+    s1, sc1, v1 = gn.beam_search(dec, mem, st, vl, 2, 3, beam=1, max_length=12)
+    states, att = dec.init_state(mem, st, vl)
+    for b in range(2):
+        rs, a, tok, out = [s[b:b + 1] for s in states], att[b:b + 1], np.array([2]), [2]
+        for _ in range(12):
+            logp, rs, a = dec.step(tok, rs, a, np.array([b]))
+            tok = logp.argmax(-1)
+            out.append(int(tok[0]))
+            if out[-1] == 3:
+                break
+        else:
+            out.append(3)
+        assert list(s1[b, 0, :v1[b, 0]]) == out
+    mem2, st2 = gn.encoder(x[1:, :6], vl[1:], p, "gru", H)
+    s2, _, v2 = gn.beam_search(gn.Decoder(p, H), mem2, st2, vl[1:], 2, 3, beam=4, max_length=12)
+    s4, _, v4 = gn.beam_search(dec, mem, st, vl, 2, 3, beam=4, max_length=12)
+    assert np.array_equal(v2[0], v4[1]) and np.array_equal(s2[0, 0, :v2[0, 0]], s4[1, 0, :v4[1, 0]])
+    assert (s4[:, :, 0] == 2).all()
+    for b in range(2):
+        for k in range(4):
+            assert s4[b, k, v4[b, k] - 1] == 3
+    tgt = rng.integers(4, V, (2, 5))
+    lg = gn.decode_seq(dec, mem, st, vl, tgt)
+    states, att = dec.init_state(mem, st, vl)
+    logp, _, _ = dec.step(tgt[:, 0], states, att, np.arange(2))
+    assert np.allclose(gn._log_softmax(lg[:, 0]), logp, atol=1e-6)
