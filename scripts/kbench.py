@@ -14,6 +14,7 @@ ap.add_argument("--kernels", default="c3,c1,tr")
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--pad", type=int, default=0)
+ap.add_argument("--blocks", default="0,1,2,3")
 args = ap.parse_args()
 ctx = _lib.default_context(0)
 lib = ctx.lib
@@ -30,6 +31,7 @@ def timed(fn, iters):
     return a.elapsed_time(b) / iters * 1e3  # us
 
 blocks = [(56, 64, 6), (28, 128, 12), (14, 256, 24), (7, 512, 16)]
+blocks = [blocks[int(i)] for i in args.blocks.split(',')]
 res = []
 for v in [int(s) for s in args.variants.split(",")]:
     if "c3" in args.kernels:
@@ -101,7 +103,7 @@ for v in [int(s) for s in args.variants.split(",")]:
                 fn = lambda: _lib.check(lib.tn_dbg_dense_layer_dev(ctx.handle, _lib.ptr(buf), ctot, K, _lib.ptr(s1), _lib.ptr(t1),
                                                                    _lib.ptr(wd), _lib.ptr(s2), _lib.ptr(t2), _lib.ptr(wpd), B, hw, hw, None, v))
                 us = timed(fn, args.iters)
-                big = (v != 2) and hw != 7
+                big = ((v & 15) != 2) and hw != 7
                 nwg = B * ({56: 8, 28: 2, 14: 1}[hw] if big else {56: 16, 28: 4, 14: 1, 7: 1}[hw])
                 ts = torch.zeros((nwg * 12,), dtype=torch.int64, device="cuda")
                 _lib.check(lib.tn_dbg_dense_layer_dev(ctx.handle, _lib.ptr(buf), ctot, K, _lib.ptr(s1), _lib.ptr(t1), _lib.ptr(wd),
