@@ -1,0 +1,7 @@
+#!/bin/bash
+# A/B the whole encoder on ONE box: scripts/ab.sh "ENV1=.. ENV2=.." "ENV..." ...   (each arg = one configuration)
+for rep in 1 2; do
+  for cfg in "$@"; do
+    env $cfg python bench.py --steps 20 --warmup 3 --no-cpu-baseline | python scripts/ab_fmt.py "$cfg"
+  done
+done

@@ -15,7 +15,9 @@ ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--pad", type=int, default=0)
 ap.add_argument("--blocks", default="0,1,2,3")
+ap.add_argument("--lib", default="")
 args = ap.parse_args()
+if args.lib: _lib.LIB_PATH = os.path.abspath(args.lib)
 ctx = _lib.default_context(0)
 lib = ctx.lib
 B = args.batch
@@ -103,16 +105,27 @@ for v in [int(s) for s in args.variants.split(",")]:
                 fn = lambda: _lib.check(lib.tn_dbg_dense_layer_dev(ctx.handle, _lib.ptr(buf), ctot, K, _lib.ptr(s1), _lib.ptr(t1),
                                                                    _lib.ptr(wd), _lib.ptr(s2), _lib.ptr(t2), _lib.ptr(wpd), B, hw, hw, None, v))
                 us = timed(fn, args.iters)
-                big = ((v & 15) != 2) and hw != 7
+                big = ((v & 3) != 2) and hw != 7
                 nwg = B * ({56: 8, 28: 2, 14: 1}[hw] if big else {56: 16, 28: 4, 14: 1, 7: 1}[hw])
                 ts = torch.zeros((nwg * 12,), dtype=torch.int64, device="cuda")
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
                 _lib.check(lib.tn_dbg_dense_layer_dev(ctx.handle, _lib.ptr(buf), ctot, K, _lib.ptr(s1), _lib.ptr(t1), _lib.ptr(wd),
                                                       _lib.ptr(s2), _lib.ptr(t2), _lib.ptr(wpd), B, hw, hw, _lib.ptr(ts), v))
+                e1.record()
                 torch.cuda.synchronize()
+                us1 = e0.elapsed_time(e1) * 1e3
                 tsn = ts.cpu().numpy().astype(np.float64)[:nwg * 8].reshape(nwg, 8)
                 d = np.diff(tsn[:, :7], axis=1)
                 print("   phases(cycles, median): prologue %d | Kloop %d | pad %d | epiA+bar %d | phaseB %d | reduce+store %d | total %d"
                       % tuple(list(np.median(d, axis=0)) + [np.median(tsn[:, 6] - tsn[:, 0])]), flush=True)
+                tot = tsn[:, 6] - tsn[:, 0]
+                ok = tsn[:, 0] > 0
+                xcd = np.arange(nwg) % 8
+                span = np.median([tsn[xcd == x, 6].max() - tsn[xcd == x, 0].min() for x in range(8)])
+                print("   total: mean %d p10 %d p90 %d max %d | span %d ticks in %.1f us -> %.2f ticks/ns | sum(total)/256 = %d"
+                      % (tot[ok].mean(), np.percentile(tot[ok], 10), np.percentile(tot[ok], 90), tot[ok].max(), span, us1, span / us1 / 1e3, tot[ok].sum() / 256), flush=True)
+                if not ok.all(): print("   WARNING: %d of %d WGs wrote no stamps" % ((~ok).sum(), len(ok)))
                 fl = 2.0 * M * (128 * K + 32 * 1152)
                 by = M * (K + 32) * 2
                 res.append(dict(k="dl", v=v, hw=hw, K=K, us=round(us, 1), tf=round(fl / us / 1e6, 1), tbs=round(by / us / 1e6, 2)))

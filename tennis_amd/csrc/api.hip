@@ -224,8 +224,13 @@ struct tn_encoder {
   size_t workspace_bytes;
   int last_batch;
   bool fuse, split;
-  hipStream_t side[2];
-  hipEvent_t ev_in, ev_done[2];
+  int nsplit;                 // side streams in use (TN_SPLIT, default 2)
+  int dl_variant;             // tuning hook: TN_DL_VARIANT -> DenseLayerArgs.variant
+  int chain_stagger;          // experiment: TN_STAGGER s_sleep(127) units for every other workgroup of a chained launch
+  bool chain;                 // whole-frame blocks (14x14, 7x7) run all their layers in one launch (TN_NO_CHAIN disables)
+  DenseLayerDev *chain_dev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t side[4];
+  hipEvent_t ev_in, ev_done[4];
 };
 
 static const int kBlockCfg[4] = {6, 12, 24, 16};
@@ -244,7 +249,12 @@ extern "C" int tn_densenet121_create(tn_ctx *ctx, const tn_param *params, int n_
   e->H = height; e->W = width; e->maxB = max_batch; e->last_batch = 0;
   e->fuse = getenv("TN_NO_FUSE") == nullptr;
   e->split = getenv("TN_NO_SPLIT") == nullptr;
-  for (int i = 0; i < 2; ++i) {
+  e->nsplit = getenv("TN_SPLIT") ? atoi(getenv("TN_SPLIT")) : 2;
+  if (e->nsplit != 4) e->nsplit = 2;
+  e->chain = getenv("TN_NO_CHAIN") == nullptr;
+  e->chain_stagger = getenv("TN_STAGGER") ? atoi(getenv("TN_STAGGER")) : 0;
+  e->dl_variant = getenv("TN_DL_VARIANT") ? atoi(getenv("TN_DL_VARIANT")) : 0;
+  for (int i = 0; i < 4; ++i) {
     if (hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_done[i], hipEventDisableTiming) != hipSuccess) {
       tn_set_error("could not create the side streams");
@@ -289,6 +299,11 @@ extern "C" int tn_densenet121_create(tn_ctx *ctx, const tn_param *params, int n_
       L.s2 = e->pool.upload(s); L.t2 = e->pool.upload(t);
       L.w3p = e->pool.upload(pack_conv3x3(w3));
       e->layers[b].push_back(L);
+    }
+    {
+      std::vector<DenseLayerDev> cd;
+      for (auto &L : e->layers[b]) cd.push_back(DenseLayerDev{L.s1, L.t1, L.w1, L.s2, L.t2, L.w3p});
+      e->chain_dev[b] = e->pool.upload(cd);
     }
     if (b < 3) {
       auto &T = e->trans[b];
@@ -354,9 +369,24 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
     const int Hh = e->Hb[b], Ww = e->Wb[b];
     const int M = B * Hh * Ww;
     const bool fused = e->fuse && dense_layer_supported(Hh, Ww);
+    if (fused && e->chain && e->dl_variant == 0 && Hh == Ww && (Hh == 14 || Hh == 7)) {
+      // one workgroup per frame walks the whole block: no launch gaps, no cold prologue per layer
+      auto &L0 = e->layers[b][0];
+      const int nl = (int)e->layers[b].size();
+      DenseLayerArgs af{bbuf[b], e->Cb[b], L0.cin, L0.s1, L0.t1, L0.w1, L0.s2, L0.t2, L0.w3p, B, Hh, Ww, nullptr, e->chain_stagger << 4, e->chain_dev[b], nl};
+      double fl = 0, by = 0;
+      for (auto &L : e->layers[b]) {
+        fl += 2.0 * M * (128.0 * L.cin + 32.0 * 1152);
+        by += (double)M * (L.cin + 32) * 2 + 128.0 * L.cin * 2 + 32.0 * 1152 * 2;
+      }
+      tm.begin("dense_block_chained", fl, by);
+      rc = launch_dense_layer(af, s);
+      tm.end();
+      if (rc) return rc;
+    } else
     for (auto &L : e->layers[b]) {
       if (fused) {
-        DenseLayerArgs af{bbuf[b], e->Cb[b], L.cin, L.s1, L.t1, L.w1, L.s2, L.t2, L.w3p, B, Hh, Ww};
+        DenseLayerArgs af{bbuf[b], e->Cb[b], L.cin, L.s1, L.t1, L.w1, L.s2, L.t2, L.w3p, B, Hh, Ww, nullptr, e->dl_variant};
         tm.begin("dense_layer_fused", 2.0 * M * (128.0 * L.cin + 32.0 * 1152),
                  (double)M * (L.cin + 32) * 2 + 128.0 * L.cin * 2 + 32.0 * 1152 * 2);
         rc = launch_dense_layer(af, s);
@@ -401,13 +431,14 @@ static int encoder_run(tn_encoder *e, const void *x, tn_layout layout, int B, fl
   // Large batches run as two half-batches on two side streams: the halves drift apart, so one
   // half's load-bound kernels (56^2 block) overlap the other's MFMA-bound ones (measured +6%).
   // The caller's stream is fenced with events on both sides, so stream order is preserved.
-  const bool split = e->split && !tm.on && B >= 64 && (B % 16) == 0;
+  const int ns = e->nsplit;
+  const bool split = e->split && !tm.on && B >= 32 * ns && (B % (8 * ns)) == 0;
   if (!split) return encoder_run_range(e, x, layout, 0, B, feat, s, tm);
   TN_HIP_CHECK(hipEventRecord(e->ev_in, s));
   int rc = TN_OK;
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < ns; ++h) {
     TN_HIP_CHECK(hipStreamWaitEvent(e->side[h], e->ev_in, 0));
-    const int r = encoder_run_range(e, x, layout, h * (B / 2), B / 2, feat, e->side[h], tm);
+    const int r = encoder_run_range(e, x, layout, h * (B / ns), B / ns, feat, e->side[h], tm);
     if (r) rc = r;
     TN_HIP_CHECK(hipEventRecord(e->ev_done[h], e->side[h]));
     TN_HIP_CHECK(hipStreamWaitEvent(s, e->ev_done[h], 0));
@@ -472,7 +503,7 @@ extern "C" int tn_densenet121_read_tap(tn_encoder *e, const char *tap_c, int bat
 extern "C" int tn_densenet121_destroy(tn_encoder *enc) {
   if (!enc) return TN_OK;
   (void)hipSetDevice(enc->ctx->device);
-  for (int i = 0; i < 2; ++i) { (void)hipStreamSynchronize(enc->side[i]); (void)hipStreamDestroy(enc->side[i]); (void)hipEventDestroy(enc->ev_done[i]); }
+  for (int i = 0; i < 4; ++i) { (void)hipStreamSynchronize(enc->side[i]); (void)hipStreamDestroy(enc->side[i]); (void)hipEventDestroy(enc->ev_done[i]); }
   (void)hipEventDestroy(enc->ev_in);
   enc->pool.release();
   delete enc;

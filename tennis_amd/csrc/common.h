@@ -49,6 +49,23 @@ __device__ __forceinline__ f16x8 bn_relu8(f16x8 v, const float *__restrict__ s, 
   return r;
 }
 
+// Same result (fp32 fma, one rounding, ReLU) in 12 VALU instructions instead of 20: v_fma_mixlo/mixhi_f16
+// take the fp16 element straight from the packed register, multiply-add in fp32 and round once into the
+// destination half; the ReLU runs on packed halves (max(round(f), 0) == round(max(f, 0))).
+__device__ __forceinline__ f16x8 bn_relu8_mix(f16x8 v, const float *__restrict__ s, const float *__restrict__ t) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 in = __builtin_bit_cast(u32x4, v);
+  u32x4 out;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=&v"(d) : "v"(in[j]), "v"(s[2 * j]), "v"(t[2 * j]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(in[j]), "v"(s[2 * j + 1]), "v"(t[2 * j + 1]));
+    asm("v_pk_max_f16 %0, %1, 0" : "=v"(out[j]) : "v"(d));
+  }
+  return __builtin_bit_cast(f16x8, out);
+}
+
 // Byte offset of 16-byte chunk `chunk` of row `row` in an LDS tile whose rows are
 // ROWB bytes (ROWB/16 chunks, power of two), XOR-swizzled so that a ds_read_b128
 // lane group reading 16 different rows at the same chunk is conflict-free.
@@ -89,6 +106,12 @@ struct Conv3x3Args {
 int launch_conv3x3(const Conv3x3Args &a, hipStream_t s);
 size_t conv3x3_lds_bytes(int W);
 
+struct DenseLayerDev {   // one layer's parameters as the chained kernels read them from device memory
+  const float *s1, *t1;
+  const f16 *w1;
+  const float *s2, *t2;
+  const f16 *w3p;
+};
 struct DenseLayerArgs {
   f16 *buf;            // concat buffer [B][H][W][ldc]: reads channels [0,K), writes [K,K+32)
   int ldc, K;
@@ -99,6 +122,8 @@ struct DenseLayerArgs {
   int B, H, W;
   unsigned long long *ts = nullptr;  // tuning hook: 8 s_memtime stamps per workgroup
   int variant = 0;                   // tuning hook: 0 auto, 1 big tiles, 2 small tiles
+  const DenseLayerDev *chain = nullptr;  // device array: run nchain consecutive layers (K, K+32, ...) in one launch
+  int nchain = 0;                        // (whole-frame tiles only: 14x14 and 7x7)
 };
 bool dense_layer_supported(int H, int W);
 int launch_dense_layer(const DenseLayerArgs &a, hipStream_t s);

@@ -27,6 +27,10 @@
 
 #include "common.h"
 
+#ifndef TN_EXP
+#define TN_EXP 0   // timing experiments only (scripts/kbench.py --lib): bit 0 skip phase B, 1 skip K loop, 2 skip epilogue A, 3 skip reduce+store
+#endif
+
 namespace {
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
@@ -48,6 +52,12 @@ struct DLGeom {
   static constexpr int PIECES = STAGE / 1024, PPW = PIECES / 8, XPIECES = XS / 1024;
   static constexpr int RPP = 1024 / ROWB;                    // rows per 1-KiB DMA piece
   static constexpr int RING_A = NST * STAGE;
+  // ping-pong K loop: X ring of wave-private row groups + shared W ring
+  static constexpr int SPB = BK / 32;                        // 32-channel sub-steps per stage
+  static constexpr int XPW = (BM / 8) * ROWB / 1024;         // X pieces a wave loads per stage (its own rows)
+  static constexpr int WPW = (128 * ROWB / 1024) / 8;        // W pieces a wave loads per stage
+  static constexpr int WRING = NST * XS;
+  static_assert(NST * (XS + WS) == RING_A, "ping-pong rings use the same LDS as the flat ring");
   static constexpr int W3RING = TILE_BYTES;                  // 2 x 8 KiB ring of 3x3 weights
   static constexpr int TAB = (TILE_BYTES + 16384 > RING_A) ? TILE_BYTES + 16384 : RING_A;
   static constexpr int TAB2 = TAB;                           // s2[128], t2[128]
@@ -88,7 +98,16 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int W, int ROUT, int BM, int BK>
+__device__ __forceinline__ void pp_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// CHAIN (whole-frame tiles only): the workgroup runs a.nchain consecutive layers of the block on its frame
+// inside one launch; layer l reads channels [0, K0 + 32 l) -- its own earlier outputs included, which the
+// same CU's L1 sees coherently once the stores have been waited for -- with parameters from a.chain[l].
+template <int W, int ROUT, int BM, int BK, int PP, bool CHAIN>
 __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   using G = DLGeom<W, ROUT, BM, BK>;
   constexpr int WP = G::WP, TR = G::TR, NF = G::NF, MAXF = G::MAXF, MIW = G::MIW;
@@ -101,9 +120,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   float *tab1 = (float *)(smem + G::TAB1);
 
   const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int H = a.H, K = a.K, ldc = a.ldc;
+  const int H = a.H, ldc = a.ldc;
 #define DL_STAMP(i) do { if (a.ts && t == 0) a.ts[(long)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
   DL_STAMP(0);
   // all row-tiles of a frame share blockIdx % 8 (the XCD) when B % 8 == 0, so the halo rows two
@@ -125,7 +142,184 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   const int top_pad = (r0 == 0) ? 1 : 0;                         // tile row 0 lies above the image
   const f16 *xbase = a.buf + ((long)img * H * W + (long)rlo * W) * ldc;
 
+  static_assert(!CHAIN || ROUT == W, "layer chaining needs whole-frame tiles");
+  if constexpr (CHAIN) {
+    // experiment: stagger half of the workgroups so that their HBM-bound K loops fall into the other
+    // half's MFMA/LDS-bound phases instead of every CU streaming (and then idling HBM) in lock step
+    if ((blockIdx.x >> 3) & 1)
+      for (int i = 0; i < (a.variant >> 4); ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  const int nlayers = CHAIN ? a.nchain : 1;
+  const int K0 = a.K;
+  for (int layer = 0; layer < nlayers; ++layer) {
+  // per-layer copies of the thread coordinates, laundered so that the compiler does not hoist every
+  // address computation of the body out of the layer loop (that costs ~80 VGPRs and spills)
+  int t_ = threadIdx.x;
+  if constexpr (CHAIN) asm volatile("" : "+v"(t_));
+  const int t = t_;
+  const int lane = t & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  if constexpr (CHAIN) {
+    const DenseLayerDev d = a.chain[layer];
+    a.K = K0 + 32 * layer;
+    a.s1 = d.s1; a.t1 = d.t1; a.w1 = d.w1; a.s2 = d.s2; a.t2 = d.t2; a.w3p = d.w3p;
+  }
+  const int K = a.K;
   // ======================= phase A: bottleneck = conv1x1(relu(bn1(x))) =======================
+  const int frow = lane & 15, fch = lane >> 4;
+  f32x4 acc[8][MIW];
+#pragma unroll
+  for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MIW; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)smem);   // LDS byte address of smem
+  const int nk = (K + BK - 1) / BK;
+  const f16x8 *w3 = (const f16x8 *)a.w3p + t;
+  f16x8 wq[3];
+  if constexpr (PP == 1 || PP == 3) {
+    constexpr bool XINC = (PP == 3);   // X refill pieces go out between the MFMA groups of the COMPUTE segment
+    // Ping-pong K loop.  The two waves of a SIMD (w, w+4) run half a step apart: while one is in its
+    // LOAD segment (fragment ds_reads, BN1+ReLU on the VALU, LDS-DMA issue) the other is in its COMPUTE
+    // segment (MFMAs only), one s_barrier per segment.  Each wave's pixel rows are private to it, so
+    // a wave refills its own rows of an X slot right after reading them (three stages ahead, no
+    // cross-wave hand-off); only the shared 1x1-weight stages are published through the barriers.
+    constexpr int XPW = G::XPW, WPW = G::WPW, SPB = G::SPB;
+    const int half = wid >> 2;
+    const f16 *xsrc[XPW], *wsrc[WPW];
+    {
+      const int prow = lane / CPR, p = lane % CPR;
+#pragma unroll
+      for (int j = 0; j < XPW; ++j) {
+        const int row = (wid * XPW + j) * RPP + prow;
+        const int m = row < MA ? row : MA - 1;
+        xsrc[j] = xbase + (long)m * ldc + stage_swz<BK>(row, p) * 8;
+      }
+#pragma unroll
+      for (int j = 0; j < WPW; ++j) {
+        const int row = (wid * WPW + j) * RPP + prow;
+        wsrc[j] = a.w1 + (long)row * K + stage_swz<BK>(row, p) * 8;
+      }
+    }
+    auto issue_x = [&](int slot) {
+#pragma unroll
+      for (int j = 0; j < XPW; ++j) {
+        dma16(xsrc[j], lds0 + slot * G::XS + (wid * XPW + j) * 1024);
+        xsrc[j] += BK;
+      }
+    };
+    auto issue_w = [&](int slot) {
+#pragma unroll
+      for (int j = 0; j < WPW; ++j) {
+        dma16(wsrc[j], lds0 + G::WRING + slot * G::WS + (wid * WPW + j) * 1024);
+        wsrc[j] += BK;
+      }
+    };
+    // BN tables -> LDS by DMA as well (issued first, so the counted wait below covers them): s1/t1 in
+    // 1-KiB pieces of 256 floats (waves 0-3 / 4-7), s2|t2 as one piece (wave 0)
+    {
+      const int p = wid & 3;
+      if (p * 256 < K) {
+        const float *base = (wid < 4) ? a.s1 : a.t1;
+        const int idx = p * 256 + lane * 4;
+        dma16(base + (idx < K ? idx : 0), lds0 + G::TAB1 + (wid < 4 ? 0 : 4096) + p * 1024);
+      }
+      if (wid == 0) dma16((lane < 32 ? a.s2 : a.t2 - 128) + lane * 4, lds0 + G::TAB2);
+    }
+    issue_x(0);
+    issue_w(0);
+    issue_x(1);      // K >= 64 = 2 stages for every geometry (BK = 64 is only used from K = 256)
+    issue_w(1);
+    if (nk > 2) {
+      issue_x(2);
+      wait_vmcnt<2 * XPW + WPW>();     // tables and stage 0 have landed; stages 1, 2 may be in flight
+    } else {
+      wait_vmcnt<XPW + WPW>();
+    }
+    __syncthreads();
+    DL_STAMP(1);
+    wq[0] = w3[0];
+    wq[1] = w3[512];
+    wq[2] = w3[2 * 512];
+
+    int st = 0;
+    // one stage = SPB sub-steps of 32 channels; IW / IX: refill W two and X three stages ahead at the
+    // stage's last sub-step; WN: DMA pieces that may stay in flight once stage q+1 has to have landed
+    auto stage = [&](int q, auto tw, auto tx, auto tn) {
+      constexpr bool IW = decltype(tw)::value, IX = decltype(tx)::value;
+      constexpr int WN = decltype(tn)::value;
+      const unsigned char *Xs = smem + st * G::XS;
+      const unsigned char *Ws = smem + G::WRING + st * G::WS;
+#pragma unroll
+      for (int i = 0; i < SPB; ++i) {
+        const int k0 = q * BK + i * 32;
+        if (k0 < K) {
+          // ---------------- LOAD segment ----------------
+          f16x8 xraw[MIW], wa[8], xb[MIW];
+#pragma unroll
+          for (int mi = 0; mi < MIW; ++mi) {
+            const int row = wid * (BM / 8) + mi * 16 + frow;
+            xraw[mi] = *(const f16x8 *)(Xs + row * ROWB + (stage_swz<BK>(row, i * 4 + fch) << 4));
+          }
+          const int kb = k0 + fch * 8;
+          const float4 s0 = *(const float4 *)(tab1 + kb), s1 = *(const float4 *)(tab1 + kb + 4);
+          const float4 t0 = *(const float4 *)(tab1 + 1024 + kb), t1 = *(const float4 *)(tab1 + 1024 + kb + 4);
+#pragma unroll
+          for (int ni = 0; ni < 8; ++ni) {
+            const int row = ni * 16 + frow;
+            wa[ni] = *(const f16x8 *)(Ws + row * ROWB + (stage_swz<BK>(row, i * 4 + fch) << 4));
+          }
+          if constexpr (IW) {
+            if (i == SPB - 1) issue_w(st >= 1 ? st - 1 : 2);        // W(q+2) -> slot (q+2)%3
+          }
+          const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+          const float sh[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+          for (int mi = 0; mi < MIW; ++mi) xb[mi] = bn_relu8_mix(xraw[mi], sc, sh);
+          if constexpr (IX && !XINC) {
+            if (i == SPB - 1) {
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // own X reads are done: refill the rows
+              issue_x(st);                                           // X(q+3) -> the slot just read
+            }
+          }
+          if (i == SPB - 1) wait_vmcnt<WN>();
+          pp_barrier();
+          // ---------------- COMPUTE segment ----------------
+#pragma unroll
+          for (int mi = 0; mi < MIW; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni)
+              acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ni], xb[mi], acc[ni][mi], 0, 0, 0);
+            if constexpr (IX && XINC) {
+              if (i == SPB - 1) {
+#pragma unroll
+                for (int j = 0; j < XPW; ++j)
+                  if (j >= mi * XPW / MIW && j < (mi + 1) * XPW / MIW) {
+                    dma16(xsrc[j], lds0 + st * G::XS + (wid * XPW + j) * 1024);
+                    xsrc[j] += BK;
+                  }
+              }
+            }
+          }
+          // the second half's very last COMPUTE segment needs no barrier: nobody waits for it before
+          // the __syncthreads that follows epilogue A (keeps the barrier counts of the halves equal)
+          if (!(half && k0 + 32 >= K)) pp_barrier();
+        }
+      }
+      st = st == 2 ? 0 : st + 1;
+    };
+    using std::integral_constant;
+    if (half) pp_barrier();                         // second half runs one segment behind
+    {
+      int q = 0;
+      // in-flight allowance once stage q+1 must have landed: [X(q+2), W(q+2), X(q+3)] when X is refilled
+      // in the LOAD segment, [X(q+2), W(q+2)] when it is refilled in the following COMPUTE segment
+      for (; q + 3 < nk; ++q) stage(q, integral_constant<bool, true>{}, integral_constant<bool, true>{}, integral_constant<int, (XINC ? 1 : 2) * XPW + WPW>{});
+      if (q + 2 < nk) { stage(q, integral_constant<bool, true>{}, integral_constant<bool, false>{}, integral_constant<int, XPW + WPW>{}); ++q; }
+      for (; q < nk; ++q) stage(q, integral_constant<bool, false>{}, integral_constant<bool, false>{}, integral_constant<int, 0>{});
+    }
+    // no wave reads the rings any more (the other half is at most inside its last COMPUTE segment):
+    // the tile that aliases them may be written
+  } else {
   // per-lane DMA source pointers of this wave's PPW pieces (advance by BK halfs per k-tile)
   const f16 *src[PPW];
 #pragma unroll
@@ -141,15 +335,15 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
       src[j] = a.w1 + (long)row * K + stage_swz<BK>(row, p) * 8;
     }
   }
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)smem);   // LDS byte address of smem
-  auto issue = [&](int st) {
+  auto issue_pieces = [&](int st, auto j0t, auto j1t) {
 #pragma unroll
-    for (int j = 0; j < PPW; ++j) {
+    for (int j = decltype(j0t)::value; j < decltype(j1t)::value; ++j) {
       dma16(src[j], lds0 + st * G::STAGE + (wid * PPW + j) * 1024);
       src[j] += BK;
     }
   };
-  const int nk = (K + BK - 1) / BK;
+  auto issue = [&](int st) { issue_pieces(st, std::integral_constant<int, 0>{}, std::integral_constant<int, PPW>{}); };
+  constexpr bool SPREAD = (PP == 2);   // refill pieces interleaved with the MFMA groups instead of up front
   issue(0);
   if (nk > 1) issue(1);
   // BN tables -> LDS (ordinary loads; their wait also covers the two DMA stages above)
@@ -165,15 +359,9 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
 
   // request the first three taps of the 3x3 weights already now (one 16-B piece per thread per
   // tap): their latency hides behind the whole K loop instead of stalling epilogue A
-  const f16x8 *w3 = (const f16x8 *)a.w3p + t;
-  f16x8 wq[3] = {w3[0], w3[512], w3[2 * 512]};
-
-  const int frow = lane & 15, fch = lane >> 4;
-  f32x4 acc[8][MIW];
-#pragma unroll
-  for (int ni = 0; ni < 8; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < MIW; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  wq[0] = w3[0];
+  wq[1] = w3[512];
+  wq[2] = w3[2 * 512];
 
   int st = 0;
   // one k-tile: wait until stage kt has landed (YOUNGER = stages issued after it that may still
@@ -184,7 +372,9 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (kt == 0) DL_STAMP(1);
-    if (kt + 2 < nk) issue(st >= 1 ? st - 1 : 2);   // slot (kt+2)%3, free since everyone passed the barrier
+    const bool refill = kt + 2 < nk;
+    const int rslot = st >= 1 ? st - 1 : 2;         // slot (kt+2)%3, free since everyone passed the barrier
+    if (!SPREAD && refill) issue(rslot);
     const unsigned char *Xs = smem + st * G::STAGE;
     const unsigned char *Ws = Xs + G::XS;
 #pragma unroll
@@ -205,21 +395,36 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
         for (int mi = 0; mi < MIW; ++mi) {
           const int row = wid * (BM / 8) + mi * 16 + frow;
           const f16x8 xraw = *(const f16x8 *)(Xs + row * ROWB + (stage_swz<BK>(row, ks * 4 + fch) << 4));
-          const f16x8 xb = bn_relu8(xraw, sc, sh);
+          const f16x8 xb = bn_relu8_mix(xraw, sc, sh);
 #pragma unroll
           for (int ni = 0; ni < 8; ++ni)
             acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ni], xb, acc[ni][mi], 0, 0, 0);
+          if constexpr (SPREAD) {
+            constexpr int NG = (BK / 32) * MIW;
+            const int gi = ks * MIW + mi;           // compile-time after unrolling
+            if (refill) {
+              // pieces [gi*PPW/NG, (gi+1)*PPW/NG) of the refill go out behind this group of 8 MFMAs
+#pragma unroll
+              for (int j = 0; j < PPW; ++j)
+                if (j >= gi * PPW / NG && j < (gi + 1) * PPW / NG) {
+                  dma16(src[j], lds0 + rslot * G::STAGE + (wid * PPW + j) * 1024);
+                  src[j] += BK;
+                }
+            }
+          }
         }
       }
     }
     st = st == 2 ? 0 : st + 1;
   };
   {
-    int kt = 0;
+    int kt = (TN_EXP & 2) ? nk : 0;
     for (; kt + 1 < nk; ++kt) ktile(kt, std::integral_constant<int, 1>{});   // steady state: one younger stage in flight
     for (; kt < nk; ++kt) ktile(kt, std::integral_constant<int, 0>{});       // drain
   }
   __syncthreads();   // every wave is done reading the DMA ring; the tile may now be written
+
+  }
 
   DL_STAMP(2);
 
@@ -239,7 +444,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   // ---- epilogue A: BN2 + ReLU, fp16, scatter into the tile ----
   // D[i=n][j=m]: lane holds channels n = ni*16 + fch*4 + r of pixel row m = .. + frow
 #pragma unroll
-  for (int mi = 0; mi < MIW; ++mi) {
+  for (int mi = 0; mi < ((TN_EXP & 4) ? 0 : MIW); ++mi) {
     const int m = wid * (BM / 8) + mi * 16 + frow;
     const int rr = m / W, x = m - rr * W;
     const int slot = (rr + top_pad) * WP + x + 1;
@@ -305,11 +510,13 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
       __syncthreads();
     }
   };
-  if (f1 - f0 == MAXF) phase_b(std::integral_constant<int, MAXF>{});
+  if (TN_EXP & 1) {
+  } else if (f1 - f0 == MAXF) phase_b(std::integral_constant<int, MAXF>{});
   else phase_b(std::integral_constant<int, (MAXF > 1 ? MAXF - 1 : 1)>{});
 
   DL_STAMP(5);
   // ---- combine the two channel halves through LDS, store 32 channels per pixel ----
+  if (TN_EXP & 8) return;   // (experiments never chain)
   if (hh == 1) {
 #pragma unroll
     for (int j = 0; j < MAXF; ++j)
@@ -350,19 +557,24 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     }
   }
   DL_STAMP(6);
+  if constexpr (CHAIN) {
+    wait_vmcnt<0>();      // this layer's stores have completed (stores count in vmcnt on gfx9) ...
+    __syncthreads();      // ... for every wave, before the next layer's loads of the same frame
+  }
+  }   // layer
 }
 
-template <int W, int ROUT, int BM, int BK>
+template <int W, int ROUT, int BM, int BK, int PP, bool CHAIN = false>
 int launch_geom(const DenseLayerArgs &a, hipStream_t s) {
   using G = DLGeom<W, ROUT, BM, BK>;
   static bool attr_set = false;
   if (!attr_set) {
-    TN_HIP_CHECK(hipFuncSetAttribute((const void *)dense_layer_kernel<W, ROUT, BM, BK>,
+    TN_HIP_CHECK(hipFuncSetAttribute((const void *)dense_layer_kernel<W, ROUT, BM, BK, PP, CHAIN>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     attr_set = true;
   }
   const dim3 grid(a.B * (a.H / ROUT)), block(512);
-  hipLaunchKernelGGL((dense_layer_kernel<W, ROUT, BM, BK>), grid, block, G::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((dense_layer_kernel<W, ROUT, BM, BK, PP, CHAIN>), grid, block, G::LDS_BYTES, s, a);
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;
 }
@@ -372,9 +584,23 @@ int launch_geom(const DenseLayerArgs &a, hipStream_t s) {
 bool dense_layer_big_supported(int H, int W) { return (H == 56 && W == 56) || (H == 28 && W == 28) || (H == 14 && W == 14); }
 
 int launch_dense_layer_big(const DenseLayerArgs &a, hipStream_t s) {
-  TN_REQUIRE(a.K % 32 == 0 && a.K <= 1024 && a.ldc % 8 == 0 && a.K + 32 <= a.ldc, "dense_layer: bad channel geometry");
-  if (a.H == 56 && a.W == 56) return launch_geom<56, 7, 512, 32>(a, s);
-  if (a.H == 28 && a.W == 28) return launch_geom<28, 14, 512, 32>(a, s);
-  if (a.H == 14 && a.W == 14) return launch_geom<14, 14, 256, 64>(a, s);
+  const int klast = a.K + 32 * (a.nchain > 0 ? a.nchain - 1 : 0);
+  TN_REQUIRE(a.K % 32 == 0 && klast <= 1024 && a.ldc % 8 == 0 && klast + 32 <= a.ldc, "dense_layer: bad channel geometry");
+  if (a.nchain > 0) {
+    TN_REQUIRE(a.H == 14 && a.W == 14 && a.chain, "dense_layer: layer chaining needs whole-frame tiles (14x14)");
+    return launch_geom<14, 14, 256, 64, 2, true>(a, s);
+  }
+  // K-loop flavour (tuning hook, variant bits 2-3): default 0 -> flat loop with the refill spread over the MFMA
+  // groups (measured best); 1 -> ping-pong halves, 2 -> flat with the refill up front, 3 -> ping-pong with the
+  // X refill inside the COMPUTE segment
+  static const int pp_of_bits[4] = {2, 1, 0, 3};
+  const int pp = pp_of_bits[(a.variant >> 2) & 3];
+#define TN_GEOM(W_, R_, BM_, BK_) \
+  (pp == 0 ? launch_geom<W_, R_, BM_, BK_, 0>(a, s) : pp == 1 ? launch_geom<W_, R_, BM_, BK_, 1>(a, s) : \
+   pp == 2 ? launch_geom<W_, R_, BM_, BK_, 2>(a, s) : launch_geom<W_, R_, BM_, BK_, 3>(a, s))
+  if (a.H == 56 && a.W == 56) return TN_GEOM(56, 7, 512, 32);
+  if (a.H == 28 && a.W == 28) return TN_GEOM(28, 14, 512, 32);
+  if (a.H == 14 && a.W == 14) return TN_GEOM(14, 14, 256, 64);
+#undef TN_GEOM
   TN_REQUIRE(false, "dense_layer: unsupported spatial size");
 }

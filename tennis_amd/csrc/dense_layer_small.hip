@@ -90,7 +90,8 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WT, int ROUT, int BM, int NST, int NRING>
+// CHAIN: see dense_layer_big.hip -- a.nchain consecutive layers on the workgroup's own frame in one launch
+template <int WT, int ROUT, int BM, int NST, int NRING, bool CHAIN>
 __global__ __launch_bounds__(NT) void dense_layer_kernel(DenseLayerArgs a) {
   using G = DLGeom<WT, ROUT, BM, NST, NRING>;
   constexpr int WP = G::WP, NSLOT = G::NSLOT, NF = G::NF, MAXF = G::MAXF, MIW = G::MIW, PPW = G::PPW;
@@ -100,9 +101,7 @@ __global__ __launch_bounds__(NT) void dense_layer_kernel(DenseLayerArgs a) {
   unsigned char *red = smem;                    // phase B partial sums (aliases the tile)
 
   const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int H = a.H, WI = a.W, K = a.K, ldc = a.ldc;
+  const int H = a.H, WI = a.W, ldc = a.ldc;
 #define DL_STAMP(i) do { if (a.ts && t == 0) a.ts[(long)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
   DL_STAMP(0);
   // ---- which tile: all tiles of a frame share blockIdx % 8 (the XCD) when B % 8 == 0 ----
@@ -128,6 +127,22 @@ __global__ __launch_bounds__(NT) void dense_layer_kernel(DenseLayerArgs a) {
     inimg = s < NSLOT && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)WI;
     return inimg ? y * WI + x : r0 * WI + x0;
   };
+  const int nlayers = CHAIN ? a.nchain : 1;
+  const int K0 = a.K;
+  for (int layer = 0; layer < nlayers; ++layer) {
+  // per-layer copies of the thread coordinates, laundered so that the compiler does not hoist every
+  // address computation of the body out of the layer loop (that costs ~80 VGPRs and spills)
+  int t_ = threadIdx.x;
+  if constexpr (CHAIN) asm volatile("" : "+v"(t_));
+  const int t = t_;
+  const int lane = t & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  if constexpr (CHAIN) {
+    const DenseLayerDev d = a.chain[layer];
+    a.K = K0 + 32 * layer;
+    a.s1 = d.s1; a.t1 = d.t1; a.w1 = d.w1; a.s2 = d.s2; a.t2 = d.t2; a.w3p = d.w3p;
+  }
+  const int K = a.K;
   const f16 *src[PPW];
 #pragma unroll
   for (int j = 0; j < PPW; ++j) {
@@ -358,19 +373,24 @@ __global__ __launch_bounds__(NT) void dense_layer_kernel(DenseLayerArgs a) {
     }
   }
   DL_STAMP(6);
+  if constexpr (CHAIN) {
+    wait_vmcnt<0>();      // this layer's stores have completed ...
+    __syncthreads();      // ... for every wave, before the next layer's loads of the same frame
+  }
+  }   // layer
 }
 
-template <int WT, int ROUT, int BM, int NST, int NRING>
+template <int WT, int ROUT, int BM, int NST, int NRING, bool CHAIN = false>
 int launch_geom(const DenseLayerArgs &a, hipStream_t s) {
   using G = DLGeom<WT, ROUT, BM, NST, NRING>;
   static bool attr_set = false;
   if (!attr_set) {
-    TN_HIP_CHECK(hipFuncSetAttribute((const void *)dense_layer_kernel<WT, ROUT, BM, NST, NRING>,
+    TN_HIP_CHECK(hipFuncSetAttribute((const void *)dense_layer_kernel<WT, ROUT, BM, NST, NRING, CHAIN>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     attr_set = true;
   }
   const dim3 grid(a.B * (a.H / ROUT) * (a.W / WT)), block(NT);
-  hipLaunchKernelGGL((dense_layer_kernel<WT, ROUT, BM, NST, NRING>), grid, block, G::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((dense_layer_kernel<WT, ROUT, BM, NST, NRING, CHAIN>), grid, block, G::LDS_BYTES, s, a);
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;
 }
@@ -382,7 +402,12 @@ bool dense_layer_small_supported(int H, int W) {
 }
 
 int launch_dense_layer_small(const DenseLayerArgs &a, hipStream_t s) {
-  TN_REQUIRE(a.K % 32 == 0 && a.K <= 1024 && a.ldc % 8 == 0 && a.K + 32 <= a.ldc, "dense_layer: bad channel geometry");
+  const int klast = a.K + 32 * (a.nchain > 0 ? a.nchain - 1 : 0);
+  TN_REQUIRE(a.K % 32 == 0 && klast <= 1024 && a.ldc % 8 == 0 && klast + 32 <= a.ldc, "dense_layer: bad channel geometry");
+  if (a.nchain > 0) {
+    TN_REQUIRE(a.H == 7 && a.W == 7 && a.chain, "dense_layer: layer chaining needs whole-frame tiles (7x7)");
+    return launch_geom<7, 7, 128, 3, 2, true>(a, s);
+  }
   if (a.H == 14 && a.W == 14) return launch_geom<14, 14, 256, 3, 1>(a, s);
   if (a.H == 7 && a.W == 7) return launch_geom<7, 7, 128, 3, 2>(a, s);
   if (a.H % 7 == 0 && a.W % 28 == 0) return launch_geom<28, 7, 320, 2, 1>(a, s);
