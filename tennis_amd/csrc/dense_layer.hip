@@ -12,9 +12,9 @@ int launch_dense_layer_small(const DenseLayerArgs &a, hipStream_t s);
 bool dense_layer_supported(int H, int W) { return dense_layer_big_supported(H, W) || dense_layer_small_supported(H, W); }
 
 int launch_dense_layer(const DenseLayerArgs &a, hipStream_t s) {
-  if (a.nchain > 0) return a.H == 14 ? launch_dense_layer_big(a, s) : launch_dense_layer_small(a, s);   // whole-frame chains
+  if (a.nchain > 0) return launch_dense_layer_big(a, s);   // whole-frame chains (14x14, 7x7)
   const bool big_ok = dense_layer_big_supported(a.H, a.W), small_ok = dense_layer_small_supported(a.H, a.W);
-  bool use_big = big_ok;                       // measured: big tiles win at 56^2, 28^2, 14^2; 7^2 only fits the small geometry
+  bool use_big = big_ok;                       // measured: the 8-wave geometry wins at every block size
   if ((a.variant & 3) == 1) use_big = true;
   if ((a.variant & 3) == 2) use_big = false;
   if (use_big && big_ok) return launch_dense_layer_big(a, s);

@@ -581,14 +581,14 @@ int launch_geom(const DenseLayerArgs &a, hipStream_t s) {
 
 }  // namespace
 
-bool dense_layer_big_supported(int H, int W) { return (H == 56 && W == 56) || (H == 28 && W == 28) || (H == 14 && W == 14); }
+bool dense_layer_big_supported(int H, int W) { return (H == 56 && W == 56) || (H == 28 && W == 28) || (H == 14 && W == 14) || (H == 7 && W == 7); }
 
 int launch_dense_layer_big(const DenseLayerArgs &a, hipStream_t s) {
   const int klast = a.K + 32 * (a.nchain > 0 ? a.nchain - 1 : 0);
   TN_REQUIRE(a.K % 32 == 0 && klast <= 1024 && a.ldc % 8 == 0 && klast + 32 <= a.ldc, "dense_layer: bad channel geometry");
   if (a.nchain > 0) {
-    TN_REQUIRE(a.H == 14 && a.W == 14 && a.chain, "dense_layer: layer chaining needs whole-frame tiles (14x14)");
-    return launch_geom<14, 14, 256, 64, 2, true>(a, s);
+    TN_REQUIRE(a.H == a.W && (a.H == 14 || a.H == 7) && a.chain, "dense_layer: layer chaining needs whole-frame tiles (14x14, 7x7)");
+    return a.H == 14 ? launch_geom<14, 14, 256, 64, 2, true>(a, s) : launch_geom<7, 7, 128, 64, 2, true>(a, s);
   }
   // K-loop flavour (tuning hook, variant bits 2-3): default 0 -> flat loop with the refill spread over the MFMA
   // groups (measured best); 1 -> ping-pong halves, 2 -> flat with the refill up front, 3 -> ping-pong with the
@@ -601,6 +601,7 @@ int launch_dense_layer_big(const DenseLayerArgs &a, hipStream_t s) {
   if (a.H == 56 && a.W == 56) return TN_GEOM(56, 7, 512, 32);
   if (a.H == 28 && a.W == 28) return TN_GEOM(28, 14, 512, 32);
   if (a.H == 14 && a.W == 14) return TN_GEOM(14, 14, 256, 64);
+  if (a.H == 7 && a.W == 7) return TN_GEOM(7, 7, 128, 64);
 #undef TN_GEOM
   TN_REQUIRE(false, "dense_layer: unsupported spatial size");
 }
