@@ -129,7 +129,11 @@ std::vector<f16> to_f16(const float *w, size_t n) {
 // 3x3 weights (32,128,3,3) -> MFMA B fragments [72 k-steps][64 lanes][8]:
 // k-step s = tap*8 + kk; lane l: n = l&31, channel = kk*16 + (l>>5)*8 + j.
 std::vector<f16> pack_conv3x3(const float *w) {
-  std::vector<f16> p((size_t)72 * 64 * 8);
+  // two MFMA operand layouts back to back (72*64*8 halves each):
+  //  [0]     v_mfma_f32_32x32x16_f16 A fragments [9 taps x 8 k16-steps][64 lanes][8]   (conv3x3.hip, dense_layer_small.hip)
+  //  [36864] v_mfma_f32_16x16x32_f16 A fragments [9 taps][4 k32-steps][2 n-frags][64 lanes][8]   (dense_layer_big.hip):
+  //          lane l: out channel nf*16 + (l&15), in channel kk*32 + (l>>4)*8 + j
+  std::vector<f16> p((size_t)2 * 72 * 64 * 8);
   for (int s = 0; s < 72; ++s) {
     const int tap = s >> 3, kk = s & 7, ky = tap / 3, kx = tap % 3;
     for (int l = 0; l < 64; ++l)
@@ -137,6 +141,17 @@ std::vector<f16> pack_conv3x3(const float *w) {
         const int n = l & 31, c = kk * 16 + (l >> 5) * 8 + j;
         p[((size_t)s * 64 + l) * 8 + j] = (f16)w[(((size_t)n * 128 + c) * 3 + ky) * 3 + kx];
       }
+  }
+  f16 *q = p.data() + (size_t)72 * 64 * 8;
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap % 3;
+    for (int kk = 0; kk < 4; ++kk)
+      for (int nf = 0; nf < 2; ++nf)
+        for (int l = 0; l < 64; ++l)
+          for (int j = 0; j < 8; ++j) {
+            const int n = nf * 16 + (l & 15), c = kk * 32 + (l >> 4) * 8 + j;
+            q[((((size_t)tap * 4 + kk) * 2 + nf) * 64 + l) * 8 + j] = (f16)w[(((size_t)n * 128 + c) * 3 + ky) * 3 + kx];
+          }
   }
   return p;
 }

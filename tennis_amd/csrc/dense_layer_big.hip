@@ -42,7 +42,8 @@ struct DLGeom {
   static constexpr int TR = ROUT + 2;
   static constexpr int NSLOT = TR * WP;
   static constexpr int NF = (ROUT * WP + 31) / 32;           // 32-slot output fragments
-  static constexpr int MAXF = (NF + 3) / 4;                  // fragments per wave group
+  static constexpr int NF16 = (ROUT * WP + 15) / 16;         // 16-slot output fragments of phase B
+  static constexpr int MAXU = (NF16 + 7) / 8;                // ... per wave
   static constexpr int RSLOT = WP + 32 * NF + WP + 2;        // highest slot phase B touches + 1
   static constexpr int TSLOT = NSLOT > RSLOT ? NSLOT : RSLOT;
   static constexpr int TILE_BYTES = TSLOT * 256;
@@ -62,12 +63,11 @@ struct DLGeom {
   static constexpr int TAB = (TILE_BYTES + 16384 > RING_A) ? TILE_BYTES + 16384 : RING_A;
   static constexpr int TAB2 = TAB;                           // s2[128], t2[128]
   static constexpr int TAB1 = TAB + 1024;                    // s1[K], t1[K]  (K <= 1024)
-  static constexpr int RED_BYTES = 4 * MAXF * 4 * 1024;
   static constexpr int LDS_BYTES = TAB + 1024 + 8192;
   static constexpr int MIW = BM / 128;                       // 16-row pixel fragments per wave
   static_assert(PIECES % 8 == 0, "DMA pieces must divide over 8 waves");
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
-  static_assert(RED_BYTES + 32 * NF * 80 <= TILE_BYTES, "reduction + output row buffers do not fit");
+  static_assert(16 * NF16 * 80 <= TILE_BYTES, "output row buffer does not fit");
   static_assert(BM >= TR * W && BM % 128 == 0, "phase A tile too small");
   static_assert(BK == 32 || BK == 64, "BK");
 };
@@ -110,12 +110,11 @@ __device__ __forceinline__ void pp_barrier() {
 template <int W, int ROUT, int BM, int BK, int PP, bool CHAIN>
 __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   using G = DLGeom<W, ROUT, BM, BK>;
-  constexpr int WP = G::WP, TR = G::TR, NF = G::NF, MAXF = G::MAXF, MIW = G::MIW;
+  constexpr int WP = G::WP, TR = G::TR, MIW = G::MIW;
   constexpr int ROWB = G::ROWB, PPW = G::PPW, RPP = G::RPP, CPR = ROWB / 16;  // chunks per row
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *tile = smem;                   // bottleneck tile (aliases the DMA ring)
   unsigned char *ring = smem + G::W3RING;       // 3x3 weight ring
-  unsigned char *red = smem;                    // phase B partial sums (aliases the tile)
   float *tab2 = (float *)(smem + G::TAB2);
   float *tab1 = (float *)(smem + G::TAB1);
 
@@ -174,7 +173,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     for (int mi = 0; mi < MIW; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)smem);   // LDS byte address of smem
   const int nk = (K + BK - 1) / BK;
-  const f16x8 *w3 = (const f16x8 *)a.w3p + t;
+  const f16x8 *w3 = (const f16x8 *)a.w3p + 72 * 64 + t;   // second half of the packed buffer: the 16x16x32 layout
   f16x8 wq[3];
   if constexpr (PP == 1 || PP == 3) {
     constexpr bool XINC = (PP == 3);   // X refill pieces go out between the MFMA groups of the COMPUTE segment
@@ -468,15 +467,20 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   DL_STAMP(4);
 
   // ======================= phase B: y = conv3x3(tile) ========================================
-  const int g = wid >> 1;            // fragment group 0..3
-  const int hh = wid & 1;            // channel half: channels [64*hh, 64*hh+64)
-  const int f0 = (g * NF) >> 2, f1 = ((g + 1) * NF) >> 2;   // this group's fragments [f0, f1)
-  const int px = lane & 31, khalf = lane >> 5;
-  f32x16 bacc[MAXF];
+  // 16-slot output fragments, v_mfma_f32_16x16x32_f16 with the packed weights as the A operand (a lane
+  // ends with 4 consecutive output channels of its pixel).  A wave owns whole fragments over the full
+  // K = 9 x 128, so there are no partial sums to combine; the fragments are dealt out so that the two
+  // waves of a SIMD (w, w+4) together get NF16/4 of them.
+  constexpr int NF16 = G::NF16, MAXU = G::MAXU;
+  const int wpos = (wid & 3) * 2 + (wid >> 2);
+  const int u0 = (wpos * NF16) >> 3, u1 = ((wpos + 1) * NF16) >> 3;   // this wave's fragments [u0, u1)
+  const int px = lane & 15, kg = lane >> 4;
+  f32x4 bacc[MAXU > 0 ? MAXU : 1][2];
 #pragma unroll
-  for (int j = 0; j < MAXF; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bacc[j][r] = 0.f;
+  for (int j = 0; j < MAXU; ++j) {
+    bacc[j][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bacc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 
   // NFR = fragments this wave really owns (wave-uniform); the loop body is branch-free so the
   // compiler can run the LDS reads ahead of the MFMAs
@@ -491,58 +495,51 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
         if (tap + 4 < 9) wq[(tap + 1) % 3] = w3[(tap + 4) * 512];
       }
       const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-      const int off = WP + dy * WP + dx + px + 32 * f0;   // slot of this lane's pixel, fragment f0
-      const unsigned char *wring = ring + (tap & 1) * 8192 + (hh * 4) * 1024 + lane * 16;
+      const int off = WP + dy * WP + dx + px + 16 * u0;   // slot of this lane's pixel, fragment u0
+      const unsigned char *wring = ring + (tap & 1) * 8192 + lane * 16;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        const f16x8 wf = *(const f16x8 *)(wring + kk * 1024);
-        const int chunk = ((hh * 4 + kk) << 1) + khalf;
-        f16x8 xf[NFR];
+        f16x8 wf0 = {0, 0, 0, 0, 0, 0, 0, 0}, wf1 = wf0;
+        if constexpr (NFR > 0) {
+          wf0 = *(const f16x8 *)(wring + (kk * 2) * 1024);
+          wf1 = *(const f16x8 *)(wring + (kk * 2 + 1) * 1024);
+        }
+        const int chunk = kk * 4 + kg;
+        f16x8 xf[NFR > 0 ? NFR : 1];
 #pragma unroll
         for (int j = 0; j < NFR; ++j) {
-          const int slot = off + 32 * j;
+          const int slot = off + 16 * j;
           xf[j] = *(const f16x8 *)(tile + slot * 256 + ((chunk ^ (slot & 15)) << 4));
         }
 #pragma unroll
-        for (int j = 0; j < NFR; ++j)
-          bacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xf[j], bacc[j], 0, 0, 0);
+        for (int j = 0; j < NFR; ++j) {
+          bacc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0, xf[j], bacc[j][0], 0, 0, 0);
+          bacc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1, xf[j], bacc[j][1], 0, 0, 0);
+        }
       }
       __syncthreads();
     }
   };
   if (TN_EXP & 1) {
-  } else if (f1 - f0 == MAXF) phase_b(std::integral_constant<int, MAXF>{});
-  else phase_b(std::integral_constant<int, (MAXF > 1 ? MAXF - 1 : 1)>{});
+  } else if (u1 - u0 == MAXU) phase_b(std::integral_constant<int, MAXU>{});
+  else phase_b(std::integral_constant<int, MAXU - 1>{});
 
   DL_STAMP(5);
-  // ---- combine the two channel halves through LDS, store 32 channels per pixel ----
   if (TN_EXP & 8) return;   // (experiments never chain)
-  if (hh == 1) {
+  // ---- fp16, through an LDS row buffer (80-B pitch per slot: 64 B of data, pitch chosen against
+  // ds_write_b64 bank conflicts) so that the global store is 16 B per lane with 4 lanes covering one
+  // pixel's 32 channels contiguously.  The buffer aliases the tile: every wave is past the last tap ----
+  unsigned char *obuf = smem;
 #pragma unroll
-    for (int j = 0; j < MAXF; ++j)
+  for (int j = 0; j < MAXU; ++j) {
+    if (u0 + j < u1) {
+      const int srel = 16 * (u0 + j) + px;           // slot relative to the first output slot
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *(f32x4 *)(red + ((g * MAXF + j) * 4 + q) * 1024 + lane * 16) =
-            (f32x4){bacc[j][4 * q], bacc[j][4 * q + 1], bacc[j][4 * q + 2], bacc[j][4 * q + 3]};
-  }
-  __syncthreads();
-  // the summed halves go through an LDS row buffer (80-B pitch per pixel slot: 64 B of data,
-  // pitch chosen against ds_write_b64 bank conflicts) so that the global
-  // store is 16 B per lane with 4 lanes covering one pixel's 32 channels contiguously
-  unsigned char *obuf = smem + G::RED_BYTES;
-  if (hh == 0) {
+      for (int nf = 0; nf < 2; ++nf) {
+        f16x4 hv;
 #pragma unroll
-    for (int j = 0; j < MAXF; ++j) {
-      if (f0 + j < f1) {
-        const int srel = 32 * (f0 + j) + px;         // slot relative to the first output slot
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 o = *(const f32x4 *)(red + ((g * MAXF + j) * 4 + q) * 1024 + lane * 16);
-          f16x4 hv;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) hv[r] = (f16)(bacc[j][4 * q + r] + o[r]);
-          *(f16x4 *)(obuf + srel * 80 + (8 * q + 4 * khalf) * 2) = hv;
-        }
+        for (int r = 0; r < 4; ++r) hv[r] = (f16)bacc[j][nf][r];
+        *(f16x4 *)(obuf + srel * 80 + (nf * 16 + kg * 4) * 2) = hv;
       }
     }
   }

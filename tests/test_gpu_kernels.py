@@ -182,7 +182,7 @@ def test_dense_layer_fused(ctx, report, B, H, K, ldc, variant):
     s2 = rng.uniform(0.5, 1.5, 128).astype(np.float32); t2 = rng.normal(0, 0.3, 128).astype(np.float32)
     w1 = rng.normal(0, np.sqrt(2.0 / K), (128, K)).astype(np.float16)
     w3 = rng.normal(0, np.sqrt(2.0 / 1152), (32, 128, 3, 3)).astype(np.float32)
-    wp = np.empty(72 * 64 * 8, np.uint16)
+    wp = np.empty(2 * 72 * 64 * 8, np.uint16)   # both MFMA operand layouts
     ctx.lib.tn_dbg_pack_conv3x3(w3.ctypes.data_as(C.c_void_p), wp.ctypes.data_as(C.c_void_p))
     d = dict(buf=torch.from_numpy(buf).cuda(), s1=torch.from_numpy(s1).cuda(), t1=torch.from_numpy(t1).cuda(),
              s2=torch.from_numpy(s2).cuda(), t2=torch.from_numpy(t2).cuda(), w1=torch.from_numpy(w1).cuda(),
