@@ -15,7 +15,7 @@ import numpy as np
 import torch  # noqa: F401  (must precede CDLL: shares the HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtennis_hip.so")
+LIB_PATH = os.environ.get("TENNIS_HIP_LIB") or os.path.join(_HERE, "lib", "libtennis_hip.so")   # env: A/B builds while tuning
 
 LAYOUT_NCHW_F32, LAYOUT_NHWC_F16, LAYOUT_NHWC_U8 = 0, 1, 2
 RNN_GRU, RNN_LSTM = 0, 1
