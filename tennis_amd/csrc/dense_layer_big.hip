@@ -28,7 +28,7 @@
 #include "common.h"
 
 #ifndef TN_EXP
-#define TN_EXP 0   // timing experiments only (scripts/kbench.py --lib): bit 0 skip phase B, 1 skip K loop, 2 skip epilogue A, 3 skip reduce+store
+#define TN_EXP 0   // timing experiments only (scripts/kbench.py --lib): bit 0 skip phase B, 1 skip K loop, 2 skip epilogue A, 3 skip the store (note: skipping a consumer lets the compiler drop its producer's MFMAs too), 4 K loop streams only (no LDS reads / MFMA)
 #endif
 
 namespace {
@@ -378,6 +378,9 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     const unsigned char *Ws = Xs + G::XS;
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
+      if (TN_EXP & 16) {
+        if (SPREAD && refill && ks == 0) issue(rslot);
+      } else
       if (kt * BK + ks * 32 < K) {
         const int kb = kt * BK + ks * 32 + fch * 8;
         const float4 s0 = *(const float4 *)(tab1 + kb), s1 = *(const float4 *)(tab1 + kb + 4);

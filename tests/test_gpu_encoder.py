@@ -82,3 +82,18 @@ def test_determinism(setup):
     a = enc(xd).cpu().numpy()
     b = enc(xd).cpu().numpy()
     assert np.array_equal(a, b)
+
+
+def test_chained_blocks_match_per_layer_launches(monkeypatch):
+    """TN_CHAIN=1: the 14x14 and 7x7 blocks run all their layers inside one launch per block (one workgroup
+    per frame); same kernels, same order of operations -> bit-identical features."""
+    import os
+    from tennis_amd import weights as W
+    from tennis_amd.engine import DenseNet121Features
+    p = W.make_densenet121_weights(5)
+    x = torch.from_numpy(W.normalize_to_nchw_f32(W.synthetic_frames_u8(8, 224))).cuda()
+    monkeypatch.delenv("TN_CHAIN", raising=False)
+    ref = DenseNet121Features(p, 224, max_batch=8)(x).cpu().numpy()
+    monkeypatch.setenv("TN_CHAIN", "1")
+    got = DenseNet121Features(p, 224, max_batch=8)(x).cpu().numpy()
+    assert np.array_equal(ref, got)
