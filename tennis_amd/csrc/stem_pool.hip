@@ -38,7 +38,9 @@ __device__ __forceinline__ void load_raw(const StemArgs &a, long pix, long plane
   }
 }
 
-template <int LAY>
+// VEC (frame width a multiple of 8): the patch is fetched as aligned groups of 8 pixels per thread with
+// 16-byte (fp16 / f32) or 8-byte (u8) loads instead of one element per load.
+template <int LAY, bool VEC>
 __global__ __launch_bounds__(256) void stem_pool_kernel(StemArgs a, f16 *__restrict__ out, int ldy, int Hp, int Wp) {
   __shared__ __attribute__((aligned(16))) unsigned char patch[IR * IPITCH];
   __shared__ __attribute__((aligned(16))) unsigned char ctile[CR * CC * CPX];
@@ -68,13 +70,40 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(StemArgs a, f16 *__restr
   // input patch staging, split in two halves so the loads of tile ct+1 fly during the MFMAs of
   // tile ct: request (clamped addresses, all loads issued back to back) / commit (zero what lies
   // outside the frame, write NHWC4 fp16 to LDS)
-  constexpr int NPX = (IR * 72 + 255) / 256;    // 7 pixels per thread
-  float raw[NPX][3];
+  constexpr int NPX = (IR * 72 + 255) / 256;    // 7 pixels per thread (element-wise path)
+  constexpr int GPR = 10;                        // 8-pixel groups per patch row (vector path): px [ix0-3, ix0+77)
+  constexpr int NQ = LAY == TN_LAYOUT_NCHW_F32 ? 6 : 3;   // 16-B (8-B for u8) loads per group
+  float raw[VEC ? 1 : NPX][3];
+  uint4 vq[VEC ? NQ : 1];
   const long plane = (long)a.H * a.W;
+  const int vpr = t / GPR, vg = t - vpr * GPR;   // vector path: this thread's patch row and group
   auto request = [&](int ct) {
     const int ix0 = 2 * (2 * ct * PC - 1) - 3;
+    if constexpr (VEC) {
+      // ix0 = 56 ct - 5: the groups start at the 8-aligned pixel ix0 - 3 (the frame width is a multiple of 8,
+      // so a group lies entirely inside or entirely outside the frame)
+      const int iy = iy0 + vpr, gx = ix0 - 3 + 8 * vg;
+      const int cy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy), cx = gx < 0 ? 0 : (gx > a.W - 8 ? a.W - 8 : gx);
+      if (t < IR * GPR) {
+        if constexpr (LAY == TN_LAYOUT_NHWC_F16) {
+          const uint4 *src = (const uint4 *)((const f16 *)a.x + (((long)b * a.H + cy) * a.W + cx) * 3);
+          vq[0] = src[0]; vq[1] = src[1]; vq[2] = src[2];
+        } else if constexpr (LAY == TN_LAYOUT_NHWC_U8) {
+          const uint2 *src = (const uint2 *)((const uint8_t *)a.x + (((long)b * a.H + cy) * a.W + cx) * 3);
+          const uint2 q0 = src[0], q1 = src[1], q2 = src[2];
+          vq[0] = make_uint4(q0.x, q0.y, q1.x, q1.y); vq[1] = make_uint4(q2.x, q2.y, 0, 0);
+        } else {
 #pragma unroll
-    for (int i = 0; i < NPX; ++i) {
+          for (int c = 0; c < 3; ++c) {
+            const uint4 *src = (const uint4 *)((const float *)a.x + ((long)b * 3 + c) * plane + (long)cy * a.W + cx);
+            vq[2 * c] = src[0]; vq[2 * c + 1] = src[1];
+          }
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < (VEC ? 0 : NPX); ++i) {
       const int p = t + 256 * i;
       const int pr = p / 72, pc = p - pr * 72;
       const int iy = iy0 + pr, ix = ix0 + pc;
@@ -86,8 +115,47 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(StemArgs a, f16 *__restr
   };
   auto commit = [&](int ct) {
     const int ix0 = 2 * (2 * ct * PC - 1) - 3;
+    if constexpr (VEC) {
+      const int iy = iy0 + vpr, gx = ix0 - 3 + 8 * vg;
+      const bool in = (unsigned)iy < (unsigned)a.H && gx >= 0 && gx <= a.W - 8;
+      f16 v[8][3];
+      if constexpr (LAY == TN_LAYOUT_NHWC_F16) {
+        const f16x8 h0 = __builtin_bit_cast(f16x8, vq[0]), h1 = __builtin_bit_cast(f16x8, vq[1]), h2 = __builtin_bit_cast(f16x8, vq[2]);
 #pragma unroll
-    for (int i = 0; i < NPX; ++i) {
+        for (int i = 0; i < 24; ++i) v[i / 3][i % 3] = i < 8 ? h0[i] : (i < 16 ? h1[i - 8] : h2[i - 16]);
+      } else if constexpr (LAY == TN_LAYOUT_NHWC_U8) {
+        const unsigned w[6] = {vq[0].x, vq[0].y, vq[0].z, vq[0].w, vq[1].x, vq[1].y};
+        const float mean[3] = {0.485f, 0.456f, 0.406f}, sdev[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+          const float u = (float)((w[i >> 2] >> ((i & 3) * 8)) & 255u);
+          // ToTensor (/255) then Normalize (mean,std) -- reference evaluate.py:96-97 (same arithmetic as load_raw)
+          v[i / 3][i % 3] = (f16)((u / 255.0f - mean[i % 3]) / sdev[i % 3]);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float f[8] = {__builtin_bit_cast(float, vq[2 * c].x), __builtin_bit_cast(float, vq[2 * c].y),
+                              __builtin_bit_cast(float, vq[2 * c].z), __builtin_bit_cast(float, vq[2 * c].w),
+                              __builtin_bit_cast(float, vq[2 * c + 1].x), __builtin_bit_cast(float, vq[2 * c + 1].y),
+                              __builtin_bit_cast(float, vq[2 * c + 1].z), __builtin_bit_cast(float, vq[2 * c + 1].w)};
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i][c] = (f16)f[i];
+        }
+      }
+      if (t < IR * GPR) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int q = 8 * vg - 3 + i;          // patch pixel index (0 = ix0)
+          f16x4 o = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+          if (in) { o[0] = v[i][0]; o[1] = v[i][1]; o[2] = v[i][2]; }
+          if (q >= 0 && q < 72) *(f16x4 *)(patch + vpr * IPITCH + q * 8) = o;
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < (VEC ? 0 : NPX); ++i) {
       const int p = t + 256 * i;
       const int pr = p / 72, pc = p - pr * 72;
       const int iy = iy0 + pr, ix = ix0 + pc;
@@ -156,12 +224,14 @@ int launch_stem_pool(const StemArgs &a, f16 *out, int ldy, int Hp, int Wp, hipSt
   TN_REQUIRE(a.layout >= 0 && a.layout <= 2, "stem: unknown input layout");
   TN_REQUIRE(ldy % 4 == 0, "stem: output stride must be a multiple of 4");
   const dim3 grid(1, (Hp + PR - 1) / PR, a.B), block(256);   // a workgroup walks one strip of 4 pooled rows
-  if (a.layout == TN_LAYOUT_NCHW_F32)
-    hipLaunchKernelGGL(stem_pool_kernel<TN_LAYOUT_NCHW_F32>, grid, block, 0, s, a, out, ldy, Hp, Wp);
-  else if (a.layout == TN_LAYOUT_NHWC_F16)
-    hipLaunchKernelGGL(stem_pool_kernel<TN_LAYOUT_NHWC_F16>, grid, block, 0, s, a, out, ldy, Hp, Wp);
-  else
-    hipLaunchKernelGGL(stem_pool_kernel<TN_LAYOUT_NHWC_U8>, grid, block, 0, s, a, out, ldy, Hp, Wp);
+  static const bool novec = getenv("TN_STEM_NOVEC") != nullptr;   // tuning hook
+  const bool vec = (a.W % 8 == 0) && a.W >= 80 && !novec;
+#define TN_STEM(L) do { if (vec) hipLaunchKernelGGL((stem_pool_kernel<L, true>), grid, block, 0, s, a, out, ldy, Hp, Wp); \
+                        else hipLaunchKernelGGL((stem_pool_kernel<L, false>), grid, block, 0, s, a, out, ldy, Hp, Wp); } while (0)
+  if (a.layout == TN_LAYOUT_NCHW_F32) TN_STEM(TN_LAYOUT_NCHW_F32);
+  else if (a.layout == TN_LAYOUT_NHWC_F16) TN_STEM(TN_LAYOUT_NHWC_F16);
+  else TN_STEM(TN_LAYOUT_NHWC_U8);
+#undef TN_STEM
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;
 }
