@@ -44,8 +44,19 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
   const int lane = t & 63;
   const int wid = t >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int m0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN_TILE;
+  // POOL launches use a 1-D grid: the N/128 column tiles of one pixel tile get consecutive slots on the
+  // same XCD (linear id % 8), so the activations they all read come from HBM once and from that XCD's
+  // L2 for the others (the transitions read every input N/128 times otherwise)
+  int mt = blockIdx.x, nt = blockIdx.y;
+  if constexpr (POOL) {
+    const int NT = a.N / BN_TILE, L = blockIdx.x;
+    const int grp = L / (8 * NT), rem = L - grp * 8 * NT;
+    mt = grp * 8 + (rem & 7);
+    nt = rem >> 3;
+    if (mt * BM >= a.M) return;      // padding of the last group of 8 pixel tiles
+  }
+  const int m0 = mt * BM;
+  const int n0 = nt * BN_TILE;
   const int K = a.K;
 
   // staging assignment: chunk column c (8 halfs) is fixed per thread
@@ -201,7 +212,8 @@ int launch_conv1x1(const Conv1x1Args &a, hipStream_t s) {
   TN_REQUIRE(a.ldx % 8 == 0 && a.ldy % 8 == 0 && a.yoff % 8 == 0, "conv1x1: strides must be multiples of 8");
   const dim3 block(256);
   if (a.pool) {
-    const dim3 grid((a.M + 63) / 64, a.N / BN_TILE);
+    const int mtiles = (a.M + 63) / 64, NT = a.N / BN_TILE;
+    const dim3 grid(((mtiles + 7) / 8) * 8 * NT);
     hipLaunchKernelGGL((conv1x1_kernel<2, true>), grid, block, 0, s, a);
   } else if (a.M >= 128 * 512) {
     const dim3 grid((a.M + 127) / 128, a.N / BN_TILE);
