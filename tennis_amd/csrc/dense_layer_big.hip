@@ -122,39 +122,48 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   const int H = a.H, ldc = a.ldc;
 #define DL_STAMP(i) do { if (a.ts && t == 0) a.ts[(long)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
   DL_STAMP(0);
-  // all row-tiles of a frame share blockIdx % 8 (the XCD) when B % 8 == 0, so the halo rows two
+  // all row-tiles of a frame share (virtual) blockIdx % 8 (the XCD) when B % 8 == 0, so the halo rows two
   // neighbouring tiles both read are L2 hits on that XCD instead of second HBM fetches
   const int tiles_per_img = H / ROUT;
-  int img, tix;
-  if ((a.B & 7) == 0) {
-    const int j = blockIdx.x >> 3;
-    img = (j / tiles_per_img) * 8 + (blockIdx.x & 7);
-    tix = j % tiles_per_img;
-  } else {
-    img = blockIdx.x / tiles_per_img;
-    tix = blockIdx.x % tiles_per_img;
-  }
-  const int r0 = tix * ROUT;                                     // first output row
-  const int rlo = r0 > 0 ? r0 - 1 : 0;                           // first computed bottleneck row
-  const int rhi = (r0 + ROUT < H) ? r0 + ROUT + 1 : H;           // one past the last
-  const int MA = (rhi - rlo) * W;                                // real phase-A rows
-  const int top_pad = (r0 == 0) ? 1 : 0;                         // tile row 0 lies above the image
-  const f16 *xbase = a.buf + ((long)img * H * W + (long)rlo * W) * ldc;
-
+  struct TileAt { int img, r0, MA, top_pad; const f16 *xbase; };
+  auto tile_at = [&](int vb) {
+    int img, tix;
+    if ((a.B & 7) == 0) {
+      const int j = vb >> 3;
+      img = (j / tiles_per_img) * 8 + (vb & 7);
+      tix = j % tiles_per_img;
+    } else {
+      img = vb / tiles_per_img;
+      tix = vb % tiles_per_img;
+    }
+    TileAt ta;
+    ta.img = img;
+    ta.r0 = tix * ROUT;                                             // first output row
+    const int rlo = ta.r0 > 0 ? ta.r0 - 1 : 0;                      // first computed bottleneck row
+    const int rhi = (ta.r0 + ROUT < H) ? ta.r0 + ROUT + 1 : H;      // one past the last
+    ta.MA = (rhi - rlo) * W;                                        // real phase-A rows
+    ta.top_pad = (ta.r0 == 0) ? 1 : 0;                              // tile row 0 lies above the image
+    ta.xbase = a.buf + ((long)img * H * W + (long)rlo * W) * ldc;
+    return ta;
+  };
   static_assert(!CHAIN || ROUT == W, "layer chaining needs whole-frame tiles");
-  if constexpr (CHAIN) {
-    // experiment: stagger half of the workgroups so that their HBM-bound K loops fall into the other
-    // half's MFMA/LDS-bound phases instead of every CU streaming (and then idling HBM) in lock step
-    if ((blockIdx.x >> 3) & 1)
-      for (int i = 0; i < (a.variant >> 4); ++i) __builtin_amdgcn_s_sleep(127);
-  }
+  // Persistent tiles (flat K loops, one layer per launch): the grid is one workgroup per CU and each walks
+  // the tiles vb = blockIdx.x, blockIdx.x + gridDim.x, ...  Right after a tile's phase B (ring region free
+  // again) it already requests the first two stages of its NEXT tile, so that tile's cold-start latency and
+  // this tile's store drain overlap instead of adding up once per tile.
+  const int nvb = a.B * tiles_per_img;
+  bool first_tile = true;
+  for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x, first_tile = false) {
+  const TileAt ta = tile_at(vb);
+  const int img = ta.img, r0 = ta.r0, MA = ta.MA, top_pad = ta.top_pad;
+  const f16 *xbase = ta.xbase;
   const int nlayers = CHAIN ? a.nchain : 1;
   const int K0 = a.K;
   for (int layer = 0; layer < nlayers; ++layer) {
   // per-layer copies of the thread coordinates, laundered so that the compiler does not hoist every
-  // address computation of the body out of the layer loop (that costs ~80 VGPRs and spills)
+  // address computation of the body out of the tile / layer loops (that costs ~80 VGPRs and spills)
   int t_ = threadIdx.x;
-  if constexpr (CHAIN) asm volatile("" : "+v"(t_));
+  asm volatile("" : "+v"(t_));
   const int t = t_;
   const int lane = t & 63;
   const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -175,6 +184,31 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   const int nk = (K + BK - 1) / BK;
   const f16x8 *w3 = (const f16x8 *)a.w3p + 72 * 64 + t;   // second half of the packed buffer: the 16x16x32 layout
   f16x8 wq[3];
+  // flat K loops: per-lane DMA source pointers of this wave's PPW pieces (advance by BK halfs per k-tile)
+  const f16 *src[PPW];
+  auto set_src = [&](const f16 *xb, int ma) {
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int piece = wid * PPW + j;                 // wave-uniform
+      const int prow = lane / CPR, p = lane % CPR;     // row inside the piece, linear chunk position
+      if (piece < G::XPIECES) {
+        const int row = piece * RPP + prow;
+        const int m = row < ma ? row : ma - 1;
+        src[j] = xb + (long)m * ldc + stage_swz<BK>(row, p) * 8;
+      } else {
+        const int row = (piece - G::XPIECES) * RPP + prow;
+        src[j] = a.w1 + (long)row * K + stage_swz<BK>(row, p) * 8;
+      }
+    }
+  };
+  auto issue_pieces = [&](int st, auto j0t, auto j1t) {
+#pragma unroll
+    for (int j = decltype(j0t)::value; j < decltype(j1t)::value; ++j) {
+      dma16(src[j], lds0 + st * G::STAGE + (wid * PPW + j) * 1024);
+      src[j] += BK;
+    }
+  };
+  auto issue = [&](int st) { issue_pieces(st, std::integral_constant<int, 0>{}, std::integral_constant<int, PPW>{}); };
   if constexpr (PP == 1 || PP == 3) {
     constexpr bool XINC = (PP == 3);   // X refill pieces go out between the MFMA groups of the COMPUTE segment
     // Ping-pong K loop.  The two waves of a SIMD (w, w+4) run half a step apart: while one is in its
@@ -319,42 +353,22 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     // no wave reads the rings any more (the other half is at most inside its last COMPUTE segment):
     // the tile that aliases them may be written
   } else {
-  // per-lane DMA source pointers of this wave's PPW pieces (advance by BK halfs per k-tile)
-  const f16 *src[PPW];
-#pragma unroll
-  for (int j = 0; j < PPW; ++j) {
-    const int piece = wid * PPW + j;                 // wave-uniform
-    const int prow = lane / CPR, p = lane % CPR;     // row inside the piece, linear chunk position
-    if (piece < G::XPIECES) {
-      const int row = piece * RPP + prow;
-      const int m = row < MA ? row : MA - 1;
-      src[j] = xbase + (long)m * ldc + stage_swz<BK>(row, p) * 8;
-    } else {
-      const int row = (piece - G::XPIECES) * RPP + prow;
-      src[j] = a.w1 + (long)row * K + stage_swz<BK>(row, p) * 8;
-    }
-  }
-  auto issue_pieces = [&](int st, auto j0t, auto j1t) {
-#pragma unroll
-    for (int j = decltype(j0t)::value; j < decltype(j1t)::value; ++j) {
-      dma16(src[j], lds0 + st * G::STAGE + (wid * PPW + j) * 1024);
-      src[j] += BK;
-    }
-  };
-  auto issue = [&](int st) { issue_pieces(st, std::integral_constant<int, 0>{}, std::integral_constant<int, PPW>{}); };
   constexpr bool SPREAD = (PP == 2);   // refill pieces interleaved with the MFMA groups instead of up front
-  issue(0);
-  if (nk > 1) issue(1);
-  // BN tables -> LDS (ordinary loads; their wait also covers the two DMA stages above)
-  for (int i = t; i < K; i += 512) {
-    tab1[i] = a.s1[i];
-    tab1[1024 + i] = a.t1[i];
+  if (first_tile) {
+    set_src(xbase, MA);
+    issue(1);            // stage kt lives in slot (1 + kt) % 3: slot 0 is where the previous tile's
+    if (nk > 1) issue(2);   // output row buffer sits while the next tile's first stages are requested
+    // BN tables -> LDS (ordinary loads; their wait also covers the two DMA stages above)
+    for (int i = t; i < K; i += 512) {
+      tab1[i] = a.s1[i];
+      tab1[1024 + i] = a.t1[i];
+    }
+    if (t < 128) {
+      tab2[t] = a.s2[t];
+      tab2[128 + t] = a.t2[t];
+    }
+    __syncthreads();   // tables visible to every wave (also drains the first two DMA stages)
   }
-  if (t < 128) {
-    tab2[t] = a.s2[t];
-    tab2[128 + t] = a.t2[t];
-  }
-  __syncthreads();   // tables visible to every wave (also drains the first two DMA stages)
 
   // request the first three taps of the 3x3 weights already now (one 16-B piece per thread per
   // tap): their latency hides behind the whole K loop instead of stalling epilogue A
@@ -362,7 +376,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   wq[1] = w3[512];
   wq[2] = w3[2 * 512];
 
-  int st = 0;
+  int st = 1;
   // one k-tile: wait until stage kt has landed (YOUNGER = stages issued after it that may still
   // be in flight), barrier, refill the slot everyone just finished with, compute
   auto ktile = [&](int kt, auto younger_tag) {
@@ -532,6 +546,14 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   // ---- fp16, through an LDS row buffer (80-B pitch per slot: 64 B of data, pitch chosen against
   // ds_write_b64 bank conflicts) so that the global store is 16 B per lane with 4 lanes covering one
   // pixel's 32 channels contiguously.  The buffer aliases the tile: every wave is past the last tap ----
+  if constexpr (!CHAIN && (PP == 0 || PP == 2)) {
+    if (vb + (int)gridDim.x < nvb) {      // the tile and the 3x3 ring are dead: request the next tile's first stages
+      const TileAt nx = tile_at(vb + gridDim.x);
+      set_src(nx.xbase, nx.MA);
+      issue(1);
+      if (nk > 1) issue(2);
+    }
+  }
   unsigned char *obuf = smem;
 #pragma unroll
   for (int j = 0; j < MAXU; ++j) {
@@ -562,6 +584,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     __syncthreads();      // ... for every wave, before the next layer's loads of the same frame
   }
   }   // layer
+  }   // tile
 }
 
 template <int W, int ROUT, int BM, int BK, int PP, bool CHAIN = false>
@@ -573,7 +596,19 @@ int launch_geom(const DenseLayerArgs &a, hipStream_t s) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     attr_set = true;
   }
-  const dim3 grid(a.B * (a.H / ROUT)), block(512);
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    TN_HIP_CHECK(hipGetDevice(&dev));
+    TN_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    ncu = prop.multiProcessorCount > 0 ? (prop.multiProcessorCount / 8) * 8 : 256;
+    if (getenv("TN_PERSIST_WGS")) ncu = atoi(getenv("TN_PERSIST_WGS"));   // tuning hook
+  }
+  const int nvb = a.B * (a.H / ROUT);
+  // one workgroup per CU walking its tiles (flat K loops, single layer); otherwise one workgroup per tile
+  const bool persist = !CHAIN && (PP == 0 || PP == 2) && !(a.variant & 16) && nvb > ncu && ncu > 0;
+  const dim3 grid(persist ? ncu : nvb), block(512);
   hipLaunchKernelGGL((dense_layer_kernel<W, ROUT, BM, BK, PP, CHAIN>), grid, block, G::LDS_BYTES, s, a);
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;
