@@ -97,3 +97,35 @@ def test_chained_blocks_match_per_layer_launches(monkeypatch):
     monkeypatch.setenv("TN_CHAIN", "1")
     got = DenseNet121Features(p, 224, max_batch=8)(x).cpu().numpy()
     assert np.array_equal(ref, got)
+
+
+def test_unfused_fallback_path(setup, report, monkeypatch):
+    """TN_NO_FUSE=1: the layer-wise kernels (conv1x1 / conv3x3 / stem / maxpool) that serve input sizes the fused
+    tiles do not cover; same oracle, same tolerance."""
+    from tennis_amd.engine import DenseNet121Features
+    monkeypatch.setenv("TN_NO_FUSE", "1")
+    enc = DenseNet121Features(setup["p"], 224, max_batch=2)
+    got = enc(torch.from_numpy(setup["x16"].astype(np.float32)).cuda()).cpu().numpy()
+    err = float(np.abs(got - setup["ref"]).max())
+    report["features_unfused_maxabs_err"] = err
+    assert err < TOL
+
+
+def test_encoder_512_features_4096(report):
+    """data_shape 512 (reference train.py:259: feature size 4096 = 1024 x 2 x 2, NCHW flatten) — blocks of
+    128/64/32/16 pixels run on the layer-wise kernels; checked against the torch-CPU fp32 restatement
+    (itself pinned to the numpy oracle in tests/test_cpu_oracle.py)."""
+    from oracle.torch_ref import TorchDenseNet121
+    from tennis_amd import weights as W
+    from tennis_amd.engine import DenseNet121Features
+    p = W.make_densenet121_weights(0)
+    x16 = W.normalize_to_nchw_f32(W.synthetic_frames_u8(1, 512)).astype(np.float16)
+    enc = DenseNet121Features(p, 512, max_batch=1)
+    assert enc.feature_dim == 4096
+    got = enc(torch.from_numpy(x16.astype(np.float32)).cuda()).cpu().numpy()
+    with torch.no_grad():
+        ref = TorchDenseNet121(p)(torch.from_numpy(x16.astype(np.float32))).numpy()
+    assert got.shape == ref.shape == (1, 4096)
+    err = float(np.abs(got - ref).max())
+    report["features_512_maxabs_err"] = err
+    assert err < TOL
