@@ -66,6 +66,20 @@ __device__ __forceinline__ f16x8 bn_relu8_mix(f16x8 v, const float *__restrict__
   return __builtin_bit_cast(f16x8, out);
 }
 
+// relu(acc*s+t) for 4 fp32 accumulators -> 4 fp16 (fp32 fma, one rounding, packed ReLU): 6 VALU instead of 10.
+__device__ __forceinline__ f16x4 bn_relu4_from_f32(f32x4 v, float4 s, float4 t) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  unsigned d0, d1;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3" : "=&v"(d0) : "v"(v[0]), "v"(s.x), "v"(t.x));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3" : "+v"(d0) : "v"(v[1]), "v"(s.y), "v"(t.y));
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3" : "=&v"(d1) : "v"(v[2]), "v"(s.z), "v"(t.z));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3" : "+v"(d1) : "v"(v[3]), "v"(s.w), "v"(t.w));
+  u32x2 o;
+  asm("v_pk_max_f16 %0, %1, 0" : "=v"(o[0]) : "v"(d0));
+  asm("v_pk_max_f16 %0, %1, 0" : "=v"(o[1]) : "v"(d1));
+  return __builtin_bit_cast(f16x4, o);
+}
+
 // Byte offset of 16-byte chunk `chunk` of row `row` in an LDS tile whose rows are
 // ROWB bytes (ROWB/16 chunks, power of two), XOR-swizzled so that a ds_read_b128
 // lane group reading 16 different rows at the same chunk is conflict-free.

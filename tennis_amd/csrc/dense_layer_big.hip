@@ -459,23 +459,29 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   DL_STAMP(3);
   // ---- epilogue A: BN2 + ReLU, fp16, scatter into the tile ----
   // D[i=n][j=m]: lane holds channels n = ni*16 + fch*4 + r of pixel row m = .. + frow
+  {
+    unsigned char *dst[MIW];
+    int sl15[MIW];
+    bool ok[MIW];
 #pragma unroll
-  for (int mi = 0; mi < ((TN_EXP & 4) ? 0 : MIW); ++mi) {
-    const int m = wid * (BM / 8) + mi * 16 + frow;
-    const int rr = m / W, x = m - rr * W;
-    const int slot = (rr + top_pad) * WP + x + 1;
-    unsigned char *dst = tile + slot * 256 + (fch & 1) * 8;
+    for (int mi = 0; mi < MIW; ++mi) {
+      const int m = wid * (BM / 8) + mi * 16 + frow;
+      const int rr = m / W, x = m - rr * W;
+      const int slot = (rr + top_pad) * WP + x + 1;
+      dst[mi] = tile + slot * 256 + (fch & 1) * 8;
+      sl15[mi] = slot & 15;
+      ok[mi] = m < MA;
+    }
 #pragma unroll
-    for (int ni = 0; ni < 8; ++ni) {
+    for (int ni = 0; ni < ((TN_EXP & 4) ? 0 : 8); ++ni) {
       const float4 sv = *(const float4 *)(tab2 + ni * 16 + fch * 4);
       const float4 tv = *(const float4 *)(tab2 + 128 + ni * 16 + fch * 4);
-      f16x4 hv;
-      hv[0] = (f16)fmaxf(fmaf(acc[ni][mi][0], sv.x, tv.x), 0.f);
-      hv[1] = (f16)fmaxf(fmaf(acc[ni][mi][1], sv.y, tv.y), 0.f);
-      hv[2] = (f16)fmaxf(fmaf(acc[ni][mi][2], sv.z, tv.z), 0.f);
-      hv[3] = (f16)fmaxf(fmaf(acc[ni][mi][3], sv.w, tv.w), 0.f);
       const int chunk = ni * 2 + (fch >> 1);              // channels n>>3
-      if (m < MA) *(f16x4 *)(dst + ((chunk ^ (slot & 15)) << 4)) = hv;
+#pragma unroll
+      for (int mi = 0; mi < MIW; ++mi) {
+        const f16x4 hv = bn_relu4_from_f32(acc[ni][mi], sv, tv);
+        if (ok[mi]) *(f16x4 *)(dst[mi] + ((chunk ^ sl15[mi]) << 4)) = hv;
+      }
     }
   }
   *(f16x8 *)(ring + t * 16) = wq[0];   // tap 0 -> ring[0]
