@@ -1,0 +1,52 @@
+"""Secondary stages of the path at the BASELINE.json configs (not the headline metric):
+  C3  CNN features -> bi-GRU(128) -> max over T -> Dense(11): clip batch 32 x T=64 x F=1024
+  C5  GNMT captioner on features: B=32 clips, T=214, F=1024, H=256, E=100, V=254, beam 5, max_len 150
+Prints one JSON object; inputs are synthetic and resident on the device."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from tennis_amd import weights as W
+from tennis_amd.engine import BiRNN, Dense, GNMTCaptioner, temporal_pool
+
+dev = torch.device("cuda:0")
+
+
+def timed(fn, iters):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+out = {}
+rng = np.random.default_rng(0)
+# ---- C3 -------------------------------------------------------------------------------------------------------
+B, T, F, H = 32, 64, 1024, 128
+p = W.make_rnn_weights(0, "gru", F, H, "cnnrnn0_gru0_")
+p.update(W.make_dense_weights(1, 11, 2 * H, "cnnrnn0_dense0_"))
+rnn = BiRNN("gru", F, H, p, "cnnrnn0_gru0_", max_rows=B * T)
+fc = Dense(p["cnnrnn0_dense0_weight"], p["cnnrnn0_dense0_bias"])
+x = torch.from_numpy(np.abs(rng.normal(0, 1, (B, T, F))).astype(np.float32) * 0.5).to(dev)
+def c3():
+    seq = rnn(x)
+    return fc(temporal_pool(seq, "max"))
+s = timed(c3, 50)
+out["C3_bigru_head"] = {"ms_per_clip_batch": round(s * 1e3, 3), "clips_per_s": round(B / s, 1), "frames_per_s": round(B * T / s, 1),
+                        "gflop": 3.624, "tflops": round(3.624e9 / s / 1e12, 3)}
+# ---- C5 -------------------------------------------------------------------------------------------------------
+B, T, F, H, E, V, beam, ml = 32, 214, 1024, 256, 100, 254, 5, 150
+p = W.make_gnmt_weights(0, "gru", F, H, E, V)
+cap = GNMTCaptioner(p, F, H, E, V, beam=beam, max_length=ml, max_batch=B, max_src_len=T)
+src = torch.from_numpy(np.abs(rng.normal(0, 1, (B, T, F))).astype(np.float32) * 0.5).to(dev)
+vl = torch.from_numpy(np.clip(rng.integers(60, 600, B), 1, T).astype(np.int32)).to(dev)
+s_enc = timed(lambda: cap.encode(src, vl), 20)
+def c5():
+    cap.encode(src, vl)
+    return cap.beam_search(2, 3, 1.0, 5.0)
+s_all = timed(c5, 5)
+smp, sc, svl = c5()
+out["C5_gnmt"] = {"encode_ms": round(s_enc * 1e3, 2), "encode_plus_beam_ms": round(s_all * 1e3, 2),
+                  "clips_per_s": round(B / s_all, 1), "steps_run": int(svl.max().item()) - 1,
+                  "note": "random-init weights: beams rarely emit EOS, so this is the max_length=150 worst case"}
+print(json.dumps(out))
