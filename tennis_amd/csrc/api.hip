@@ -242,7 +242,7 @@ struct tn_encoder {
   int nsplit;                 // side streams in use (TN_SPLIT, default 2)
   int dl_variant;             // tuning hook: TN_DL_VARIANT -> DenseLayerArgs.variant
   int chain_stagger;          // experiment: TN_STAGGER s_sleep(127) units for every other workgroup of a chained launch
-  bool chain;                 // whole-frame blocks (14x14, 7x7) run all their layers in one launch (TN_CHAIN=1 enables)
+  bool chain;                 // whole-frame blocks (14x14, 7x7) run all their layers in one launch (TN_NO_CHAIN disables)
   DenseLayerDev *chain_dev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipStream_t side[4];
   hipEvent_t ev_in, ev_done[4];
@@ -266,7 +266,7 @@ extern "C" int tn_densenet121_create(tn_ctx *ctx, const tn_param *params, int n_
   e->split = getenv("TN_NO_SPLIT") == nullptr;
   e->nsplit = getenv("TN_SPLIT") ? atoi(getenv("TN_SPLIT")) : 2;
   if (e->nsplit != 4) e->nsplit = 2;
-  e->chain = getenv("TN_CHAIN") != nullptr;   // off by default: with the two half-batch streams it measured ~2% slower end to end
+  e->chain = getenv("TN_NO_CHAIN") == nullptr;   // measured: -20% on the 14x14 / 7x7 blocks, +2.8% end to end
   e->chain_stagger = getenv("TN_STAGGER") ? atoi(getenv("TN_STAGGER")) : 0;
   e->dl_variant = getenv("TN_DL_VARIANT") ? atoi(getenv("TN_DL_VARIANT")) : 0;
   for (int i = 0; i < 4; ++i) {

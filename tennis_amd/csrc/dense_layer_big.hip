@@ -152,8 +152,8 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   // again) it already requests the first two stages of its NEXT tile, so that tile's cold-start latency and
   // this tile's store drain overlap instead of adding up once per tile.
   const int nvb = a.B * tiles_per_img;
-  bool first_tile = true;
-  for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x, first_tile = false) {
+  bool primed = false;      // the first two stages (and the tables) of the next tile / layer have already been requested
+  for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
   const TileAt ta = tile_at(vb);
   const int img = ta.img, r0 = ta.r0, MA = ta.MA, top_pad = ta.top_pad;
   const f16 *xbase = ta.xbase;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   f16x8 wq[3];
   // flat K loops: per-lane DMA source pointers of this wave's PPW pieces (advance by BK halfs per k-tile)
   const f16 *src[PPW];
-  auto set_src = [&](const f16 *xb, int ma) {
+  auto set_src = [&](const f16 *xb, int ma, const f16 *w1p, int kv) {
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
       const int piece = wid * PPW + j;                 // wave-uniform
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
         src[j] = xb + (long)m * ldc + stage_swz<BK>(row, p) * 8;
       } else {
         const int row = (piece - G::XPIECES) * RPP + prow;
-        src[j] = a.w1 + (long)row * K + stage_swz<BK>(row, p) * 8;
+        src[j] = w1p + (long)row * kv + stage_swz<BK>(row, p) * 8;
       }
     }
   };
@@ -354,8 +354,8 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     // the tile that aliases them may be written
   } else {
   constexpr bool SPREAD = (PP == 2);   // refill pieces interleaved with the MFMA groups instead of up front
-  if (first_tile) {
-    set_src(xbase, MA);
+  if (!primed) {
+    set_src(xbase, MA, a.w1, K);
     issue(1);            // stage kt lives in slot (1 + kt) % 3: slot 0 is where the previous tile's
     if (nk > 1) issue(2);   // output row buffer sits while the next tile's first stages are requested
     // BN tables -> LDS (ordinary loads; their wait also covers the two DMA stages above)
@@ -369,6 +369,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     }
     __syncthreads();   // tables visible to every wave (also drains the first two DMA stages)
   }
+  primed = false;
 
   // request the first three taps of the 3x3 weights already now (one 16-B piece per thread per
   // tap): their latency hides behind the whole K loop instead of stalling epilogue A
@@ -552,12 +553,30 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   // ---- fp16, through an LDS row buffer (80-B pitch per slot: 64 B of data, pitch chosen against
   // ds_write_b64 bank conflicts) so that the global store is 16 B per lane with 4 lanes covering one
   // pixel's 32 channels contiguously.  The buffer aliases the tile: every wave is past the last tap ----
-  if constexpr (!CHAIN && (PP == 0 || PP == 2)) {
-    if (vb + (int)gridDim.x < nvb) {      // the tile and the 3x3 ring are dead: request the next tile's first stages
-      const TileAt nx = tile_at(vb + gridDim.x);
-      set_src(nx.xbase, nx.MA);
+  float nxs[2] = {0.f, 0.f}, nxt[2] = {0.f, 0.f}, nx2 = 0.f;   // CHAIN: the next layer's BN tables on their way
+  int nxK = 0;
+  if constexpr (PP == 0 || PP == 2) {
+    if constexpr (!CHAIN) {
+      if (vb + (int)gridDim.x < nvb) {    // the tile and the 3x3 ring are dead: request the next tile's first stages
+        const TileAt nx = tile_at(vb + gridDim.x);
+        set_src(nx.xbase, nx.MA, a.w1, K);
+        issue(1);
+        if (nk > 1) issue(2);
+        primed = true;
+      }
+    } else if (layer + 1 < nlayers) {     // same frame, next layer: its first 128 input channels exist already
+      const DenseLayerDev dn = a.chain[layer + 1];
+      nxK = K + 32;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = t + 512 * i;
+        if (idx < nxK) { nxs[i] = dn.s1[idx]; nxt[i] = dn.t1[idx]; }
+      }
+      if (t < 256) nx2 = t < 128 ? dn.s2[t] : dn.t2[t - 128];
+      set_src(xbase, MA, dn.w1, nxK);
       issue(1);
-      if (nk > 1) issue(2);
+      issue(2);
+      primed = true;
     }
   }
   unsigned char *obuf = smem;
@@ -586,6 +605,14 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   }
   DL_STAMP(6);
   if constexpr (CHAIN) {
+    if (nxK) {            // the next layer's tables (nobody reads the old ones any more)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = t + 512 * i;
+        if (idx < nxK) { tab1[idx] = nxs[i]; tab1[1024 + idx] = nxt[i]; }
+      }
+      if (t < 256) tab2[t] = nx2;
+    }
     wait_vmcnt<0>();      // this layer's stores have completed (stores count in vmcnt on gfx9) ...
     __syncthreads();      // ... for every wave, before the next layer's loads of the same frame
   }

@@ -85,16 +85,17 @@ def test_determinism(setup):
 
 
 def test_chained_blocks_match_per_layer_launches(monkeypatch):
-    """TN_CHAIN=1: the 14x14 and 7x7 blocks run all their layers inside one launch per block (one workgroup
-    per frame); same kernels, same order of operations -> bit-identical features."""
+    """Default: the 14x14 and 7x7 blocks run all their layers inside one launch per block (one workgroup per
+    frame, the next layer's first stages and tables requested during the current layer's store); TN_NO_CHAIN=1
+    launches every layer separately.  Same arithmetic in the same order -> bit-identical features."""
     import os
     from tennis_amd import weights as W
     from tennis_amd.engine import DenseNet121Features
     p = W.make_densenet121_weights(5)
     x = torch.from_numpy(W.normalize_to_nchw_f32(W.synthetic_frames_u8(8, 224))).cuda()
-    monkeypatch.delenv("TN_CHAIN", raising=False)
+    monkeypatch.setenv("TN_NO_CHAIN", "1")
     ref = DenseNet121Features(p, 224, max_batch=8)(x).cpu().numpy()
-    monkeypatch.setenv("TN_CHAIN", "1")
+    monkeypatch.delenv("TN_NO_CHAIN", raising=False)
     got = DenseNet121Features(p, 224, max_batch=8)(x).cpu().numpy()
     assert np.array_equal(ref, got)
 
