@@ -241,7 +241,6 @@ struct tn_encoder {
   bool fuse, split;
   int nsplit;                 // side streams in use (TN_SPLIT, default 2)
   int dl_variant;             // tuning hook: TN_DL_VARIANT -> DenseLayerArgs.variant
-  int chain_stagger;          // experiment: TN_STAGGER s_sleep(127) units for every other workgroup of a chained launch
   bool chain;                 // whole-frame blocks (14x14, 7x7) run all their layers in one launch (TN_NO_CHAIN disables)
   DenseLayerDev *chain_dev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipStream_t side[4];
@@ -267,7 +266,6 @@ extern "C" int tn_densenet121_create(tn_ctx *ctx, const tn_param *params, int n_
   e->nsplit = getenv("TN_SPLIT") ? atoi(getenv("TN_SPLIT")) : 2;
   if (e->nsplit != 4) e->nsplit = 2;
   e->chain = getenv("TN_NO_CHAIN") == nullptr;   // measured: -20% on the 14x14 / 7x7 blocks, +2.8% end to end
-  e->chain_stagger = getenv("TN_STAGGER") ? atoi(getenv("TN_STAGGER")) : 0;
   e->dl_variant = getenv("TN_DL_VARIANT") ? atoi(getenv("TN_DL_VARIANT")) : 0;
   for (int i = 0; i < 4; ++i) {
     if (hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) != hipSuccess ||
@@ -388,7 +386,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
       // one workgroup per frame walks the whole block: no launch gaps, no cold prologue per layer
       auto &L0 = e->layers[b][0];
       const int nl = (int)e->layers[b].size();
-      DenseLayerArgs af{bbuf[b], e->Cb[b], L0.cin, L0.s1, L0.t1, L0.w1, L0.s2, L0.t2, L0.w3p, B, Hh, Ww, nullptr, e->chain_stagger << 4, e->chain_dev[b], nl};
+      DenseLayerArgs af{bbuf[b], e->Cb[b], L0.cin, L0.s1, L0.t1, L0.w1, L0.s2, L0.t2, L0.w3p, B, Hh, Ww, nullptr, 0, e->chain_dev[b], nl};
       double fl = 0, by = 0;
       for (auto &L : e->layers[b]) {
         fl += 2.0 * M * (128.0 * L.cin + 32.0 * 1152);
