@@ -49,8 +49,7 @@ def pmc_traffic(kernel_family):
     if not files:
         return None
     fam = json.load(open(files[-1])).get("families", {})
-    key = "dense_layer_fused(all)" if kernel_family == "dense_layer_fused" else kernel_family
-    return fam.get(key, {}).get("hbm_bytes_per_dispatch_corrected")
+    return fam.get(kernel_family, {}).get("hbm_bytes_per_dispatch_corrected")
 
 
 def cpu_baseline(params, frames_nhwc_f16, seconds_target=12.0):

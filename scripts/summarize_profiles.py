@@ -6,10 +6,16 @@ usage: python scripts/summarize_profiles.py <tag>        e.g.  r01_d
 PMC units and the gfx950 correction follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE
 are KB per dispatch; FETCH_SIZE counts 64 B per 128-B request -> hbm_bytes = (2*FETCH + WRITE) * 1024.
 """
-import csv, glob, json, shutil, sys, collections
+import csv, glob, json, os, shutil, sys, collections
+
+
+def newest(pattern):
+    """gpurun_out/ accumulates the files of earlier calls: use only the newest match."""
+    files = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+    return files[-1:]
 
 tag = sys.argv[1]
-st = glob.glob("gpurun_out/prof_stats/**/*kernel_stats.csv", recursive=True)
+st = newest("gpurun_out/prof_stats/**/*kernel_stats.csv")
 if st:
     shutil.copy(st[0], f"profiles/{tag}_kernel_stats_bench_steps5.csv")
 
@@ -24,7 +30,7 @@ def family(name):
 
 def collect(d, counter):
     acc = collections.defaultdict(lambda: [0, 0.0])
-    for f in glob.glob(f"gpurun_out/{d}/**/*counter_collection.csv", recursive=True):
+    for f in newest(f"gpurun_out/{d}/**/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
@@ -35,6 +41,15 @@ def collect(d, counter):
     return acc
 
 
+def collect_raw(d, counter):
+    rows = []
+    for f in newest(f"gpurun_out/{d}/**/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                rows.append((r["Kernel_Name"], float(r["Counter_Value"])))
+    return rows
+
+
 fe, wr = collect("prof_fetch", "FETCH_SIZE"), collect("prof_write", "WRITE_SIZE")
 if fe and wr:
     out = {"command": "rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- python bench.py --steps 2 "
@@ -42,7 +57,6 @@ if fe and wr:
            "units": "FETCH_SIZE / WRITE_SIZE are KB per dispatch as reported by rocprofv3; gfx950 correction "
                     "(MI355X_MICROARCH.md, HBM): hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024",
            "families": {}}
-    tot = [0, 0.0, 0.0]
     for fam in fe:
         n, f = fe[fam]
         w = wr[fam][1] / max(1, wr[fam][0])
@@ -50,12 +64,16 @@ if fe and wr:
         out["families"][fam] = {"dispatches": n, "FETCH_SIZE_KB_per_dispatch": round(f, 1),
                                 "WRITE_SIZE_KB_per_dispatch": round(w, 1),
                                 "hbm_bytes_per_dispatch_corrected": int((2 * f + w) * 1024)}
-        if fam.startswith("dense_"):
-            tot[0] += n; tot[1] += f * n; tot[2] += w * n
-    if tot[0]:
-        f, w = tot[1] / tot[0], tot[2] / tot[0]
-        out["families"]["dense_layer_fused(all)"] = {"dispatches": tot[0], "FETCH_SIZE_KB_per_dispatch": round(f, 1),
-                                                     "WRITE_SIZE_KB_per_dispatch": round(w, 1),
-                                                     "hbm_bytes_per_dispatch_corrected": int((2 * f + w) * 1024)}
+    # bench.py's kernel families: per-layer launches (56^2, 28^2 blocks) and chained whole-block launches
+    raw_f, raw_w = collect_raw("prof_fetch", "FETCH_SIZE"), collect_raw("prof_write", "WRITE_SIZE")
+    for fam, pred in (("dense_layer_fused", lambda n: "dense_layer_kernel" in n and "false>" in n),
+                      ("dense_block_chained", lambda n: "dense_layer_kernel" in n and "true>" in n)):
+        fv = [v for n, v in raw_f if pred(n)]
+        wv = [v for n, v in raw_w if pred(n)]
+        if fv and wv:
+            f, w = sum(fv) / len(fv), sum(wv) / len(wv)
+            out["families"][fam] = {"dispatches": len(fv), "FETCH_SIZE_KB_per_dispatch": round(f, 1),
+                                    "WRITE_SIZE_KB_per_dispatch": round(w, 1),
+                                    "hbm_bytes_per_dispatch_corrected": int((2 * f + w) * 1024)}
     json.dump(out, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
     print(json.dumps(out["families"], indent=1))
