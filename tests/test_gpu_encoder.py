@@ -130,3 +130,23 @@ def test_encoder_512_features_4096(report):
     err = float(np.abs(got - ref).max())
     report["features_512_maxabs_err"] = err
     assert err < TOL
+
+
+def test_full_batch_256_matches_small_batches(report):
+    """BASELINE.json configs[1] size (256 frames: two-stream split, XCD-remapped persistent tiles, chained blocks):
+    every frame's features must equal, bit for bit, what the same frame gives in a batch of 4 (un-split, one tile
+    per workgroup) - frames are independent and the per-frame arithmetic order does not depend on the batch."""
+    from tennis_amd import weights as W
+    from tennis_amd.engine import DenseNet121Features
+    p = W.make_densenet121_weights(2)
+    base = torch.from_numpy(W.normalize_to_nchw_f32(W.synthetic_frames_u8(4, 224))).cuda()
+    small = DenseNet121Features(p, 224, max_batch=4)(base)
+    idx = torch.arange(256, device="cuda") % 4
+    big_in = base[idx].permute(0, 2, 3, 1).contiguous().half()          # NHWC fp16, as bench.py feeds it
+    enc = DenseNet121Features(p, 224, max_batch=256)
+    big = enc(big_in)
+    ref = DenseNet121Features(p, 224, max_batch=4)(base.permute(0, 2, 3, 1).contiguous().half())
+    assert torch.equal(big, ref[idx])
+    report["full_batch_vs_small_batch_bit_identical"] = True
+    # and the NHWC fp16 hand-over agrees with the reference NCHW fp32 layout to fp16 input rounding
+    assert float((ref - small).abs().max()) < 2e-3
