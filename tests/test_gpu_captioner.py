@@ -115,3 +115,44 @@ def test_captioning_evaluate_driver():
         rmem, rst = gn.encoder(x[None], np.array([tl]), p, "gru", 32)
         rs, _, rvl = gn.beam_search(gn.Decoder(p, 32), rmem, rst, np.array([tl]), 2, 3, 4, 1.0, 5, 12)
         assert sents[i] == gn.ids_to_sentences(rs, rvl, train.vocab.idx_to_token)[0]
+
+
+def test_full_size_c5_properties(report):
+    """BASELINE.json config C5 size (32 clips, T=214, F=1024, H=256, E=100, V=254, beam 5, max_len 150) — too long
+    for the numpy oracle, so size-independent properties: (1) batch invariance: clip i decoded in the batch of 32
+    gives the same token ids / lengths as decoded alone; (2) BOS first, EOS at valid_length-1, -1 padding behind;
+    (3) scores descending over beams; (4) beam 1 == greedy argmax of the teacher-forced logits."""
+    from tennis_amd import weights as W
+    from tennis_amd.engine import GNMTCaptioner
+    B, T, F, H, E, V, beam, ml = 32, 214, 1024, 256, 100, 254, 5, 150
+    p = W.make_gnmt_weights(9, "gru", F, H, E, V)
+    p["gnmt_tgt_proj_weight"] = (p["gnmt_tgt_proj_weight"] * 30.0).astype(np.float32)
+    p["gnmt_tgt_proj_bias"][3] += 0.5
+    rng = np.random.default_rng(9)
+    src = torch.from_numpy((np.abs(rng.normal(0, 1, (B, T, F))) * 0.5).astype(np.float32)).cuda()
+    vl = torch.from_numpy(np.clip(rng.integers(60, 600, B), 1, T).astype(np.int32)).cuda()
+    cap = GNMTCaptioner(p, F, H, E, V, beam=beam, max_length=ml, max_batch=B, max_src_len=T)
+    cap.encode(src, vl)
+    s, sc, svl = [x.cpu().numpy() for x in cap.beam_search(2, 3, 1.0, 5.0)]
+    assert (s[:, :, 0] == 2).all() and np.all(np.diff(sc, axis=1) <= 1e-6)
+    L = s.shape[2]
+    for b in range(B):
+        for k in range(beam):
+            n = int(svl[b, k])
+            assert s[b, k, n - 1] == 3 and (s[b, k, n:] == -1).all() and (s[b, k, 1:n - 1] >= 0).all()
+    one = GNMTCaptioner(p, F, H, E, V, beam=beam, max_length=ml, max_batch=1, max_src_len=T)
+    for b in (0, 7, 31):
+        one.encode(src[b:b + 1].contiguous(), vl[b:b + 1].contiguous())
+        s1, sc1, v1 = [x.cpu().numpy() for x in one.beam_search(2, 3, 1.0, 5.0)]
+        n = int(v1[0, 0])
+        assert np.array_equal(v1[0], svl[b]) and np.array_equal(s1[0, 0, :n], s[b, 0, :n])
+    g = GNMTCaptioner(p, F, H, E, V, beam=1, max_length=ml, max_batch=B, max_src_len=T)
+    g.encode(src, vl)
+    s1, _, v1 = [x.cpu().numpy() for x in g.beam_search(2, 3, 1.0, 5.0)]
+    n = int(v1.max())
+    tgt = np.where(s1[:, 0, :n - 1] < 0, 3, s1[:, 0, :n - 1]).astype(np.int32)      # feed the greedy path back in
+    logits = g.decode_seq(torch.from_numpy(tgt).cuda()).cpu().numpy()
+    for b in range(B):
+        m = min(int(v1[b, 0]) - 1, ml)       # predictions for positions 1..m (an <eos> forced at max_length is no argmax)
+        assert np.array_equal(logits[b, :m].argmax(-1), s1[b, 0, 1:m + 1])
+    report["gnmt_c5_full_size_properties"] = True
