@@ -128,3 +128,22 @@ def test_save_features_and_evaluate_model(zoo, tmp_path, report):
     assert xw.shape == (3, 1024)
     assert ev.main(["--root", root, "--model_id", "0007", "--save_feats", "--frames_per_video", "2",
                     "--batch_size", "4"]) == 0
+
+
+def test_cnnrnn_full_size_c3(report):
+    """BASELINE.json config C3 size: clip batch 32 x T=64 x F=1024 -> bi-GRU / bi-LSTM(128) -> max over T -> Dense(11),
+    against the numpy oracle at the full size (the persistent recurrent kernel runs all 64 steps in one launch)."""
+    from tennis_amd import weights as W
+    from tennis_amd.models.vision.definitions import CNNRNN
+    x = np.abs(np.random.default_rng(5).normal(0, 1, (32, 64, 1024))).astype(np.float32) * 0.5
+    for mode in ("gru", "lstm"):
+        m = CNNRNN(None, num_classes=11, type=mode, hidden_size=128, prefix="cnnrnn0_")
+        m.initialize()
+        p = W.make_rnn_weights(6, mode, 1024, 128, f"cnnrnn0_{mode}0_")
+        p.update(W.make_dense_weights(7, 11, 256, "cnnrnn0_dense0_"))
+        m.set_params(p)
+        got = m(x).cpu().numpy()
+        ref, _ = vn.cnnrnn(x, p, mode, feats=True, rnn_prefix=f"cnnrnn0_{mode}0_")
+        e = float(np.abs(got - ref).max())
+        report[f"CNNRNN_{mode}_C3_full_size_logits_maxabs_err"] = e
+        assert got.shape == (32, 11) and e < 1e-4
