@@ -9,7 +9,13 @@
 // Operand layout as in stem.hip: one k-step per kernel row ky; the 32 k-slots are 8 x-taps x
 // 4 channels (tap 7 and channel 3 carry zero weights), so a lane's 8 values are 2 adjacent
 // NHWC4 pixels = one aligned ds_read_b128 of the staged input patch.
+#include <type_traits>
+
 #include "common.h"
+
+#ifndef TN_STEM_EXP
+#define TN_STEM_EXP 0   // timing experiments: bit 0 skip the conv fragments, bit 1 skip the pooling / store loop
+#endif
 
 namespace {
 
@@ -52,19 +58,22 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(StemArgs a, f16 *__restr
   const int pl = lane & 15, kc = lane >> 4;
   const int ntc = (Wp + PC - 1) / PC;                    // column tiles walked by this workgroup
 
-  // all weight fragments stay in registers for the whole row strip: [ky][nfrag]
-  f16x8 wa[7][4];
+  // a wave owns one half of the output channels (n-fragments 2*nh, 2*nh+1): its 14 weight fragments and BN
+  // constants stay in registers for the whole row strip (all four n-fragments would cost 112 VGPRs and a
+  // third of the occupancy); the other half of each pixel fragment belongs to the partner wave
+  const int nh = wid & 1;
+  f16x8 wa[7][2];
 #pragma unroll
   for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) wa[ky][nf] = ((const f16x8 *)a.wp)[(ky * 4 + nf) * 64 + lane];
-  float sc[4][4], sh[4][4];
+    for (int nf = 0; nf < 2; ++nf) wa[ky][nf] = ((const f16x8 *)a.wp)[(ky * 4 + 2 * nh + nf) * 64 + lane];
+  float sc[2][4], sh[2][4];
 #pragma unroll
-  for (int nf = 0; nf < 4; ++nf)
+  for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      sc[nf][r] = a.scale[nf * 16 + kc * 4 + r];
-      sh[nf][r] = a.shift[nf * 16 + kc * 4 + r];
+      sc[nf][r] = a.scale[(2 * nh + nf) * 16 + kc * 4 + r];
+      sh[nf][r] = a.shift[(2 * nh + nf) * 16 + kc * 4 + r];
     }
 
   // input patch staging, split in two halves so the loads of tile ct+1 fly during the MFMAs of
@@ -175,33 +184,53 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(StemArgs a, f16 *__restr
   for (int ct = 0; ct < ntc; ++ct) {
     const int pc0 = ct * PC, cx0 = 2 * pc0 - 1;
     if (ct + 1 < ntc) request(ct + 1);
-    // conv + BN + ReLU -> LDS; fragments are dealt round-robin to the 4 waves
-    for (int f = wid; f < NFRAG; f += 4) {
-      const int r = f >> 1, c = (f & 1) * 16 + pl;          // conv row / column inside the tile
-      f32x4 acc[4];
+    // conv + BN + ReLU -> LDS; wave pair p = wid>>1 takes the pixel fragments p, p+2, ..., two at a time so that
+    // the patch reads of one kernel row hide behind the MFMAs of the previous one
+    auto conv_frags = [&](auto nft, int fa, int fb) {
+      constexpr int NFR = decltype(nft)::value;
+      const int fr[2] = {fa, fb};
+      f32x4 acc[NFR][2];
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf) acc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < NFR; ++q)
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) acc[q][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ky = 0; ky < 7; ++ky) {
-        const f16x8 xb = *(const f16x8 *)(patch + (2 * r + ky) * IPITCH + (c + kc) * 16);
+        f16x8 xb[NFR];
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ky][nf], xb, acc[nf], 0, 0, 0);
+        for (int q = 0; q < NFR; ++q) {
+          const int r = fr[q] >> 1, c = (fr[q] & 1) * 16 + pl;
+          xb[q] = *(const f16x8 *)(patch + (2 * r + ky) * IPITCH + (c + kc) * 16);
+        }
+#pragma unroll
+        for (int q = 0; q < NFR; ++q)
+#pragma unroll
+          for (int nf = 0; nf < 2; ++nf) acc[q][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ky][nf], xb[q], acc[q][nf], 0, 0, 0);
       }
-      const bool valid = (unsigned)(cy0 + r) < (unsigned)a.Ho && (unsigned)(cx0 + c) < (unsigned)a.Wo;
-      unsigned char *dst = ctile + (r * CC + c) * CPX + kc * 8;
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf) {
-        f16x4 h;
+      for (int q = 0; q < NFR; ++q) {
+        const int r = fr[q] >> 1, c = (fr[q] & 1) * 16 + pl;          // conv row / column inside the tile
+        const bool valid = (unsigned)(cy0 + r) < (unsigned)a.Ho && (unsigned)(cx0 + c) < (unsigned)a.Wo;
+        unsigned char *dst = ctile + (r * CC + c) * CPX + kc * 8 + nh * 64;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) h[q] = (f16)fmaxf(fmaf(acc[nf][q], sc[nf][q], sh[nf][q]), 0.f);
-        if (!valid) h = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-        *(f16x4 *)(dst + nf * 32) = h;
+        for (int nf = 0; nf < 2; ++nf) {
+          f16x4 h;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) h[j] = (f16)fmaxf(fmaf(acc[q][nf][j], sc[nf][j], sh[nf][j]), 0.f);
+          if (!valid) h = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+          *(f16x4 *)(dst + nf * 32) = h;
+        }
       }
+    };
+    if (!(TN_STEM_EXP & 1)) {
+      int f = wid >> 1;
+      for (; f + 2 < NFRAG; f += 4) conv_frags(std::integral_constant<int, 2>{}, f, f + 2);
+      if (f < NFRAG) conv_frags(std::integral_constant<int, 1>{}, f, f);
     }
     __syncthreads();                      // conv tile complete; nobody reads the patch any more
     if (ct + 1 < ntc) commit(ct + 1);
     // 3x3/2 max pool out of LDS: one (pooled pixel, 4-channel group) per work item
-    for (int id = t; id < PR * PC * 16; id += 256) {
+    for (int id = t; id < ((TN_STEM_EXP & 2) ? 0 : PR * PC * 16); id += 256) {
       const int pp = id >> 4, cg = id & 15;
       const int pr = pp / PC, pc = pp - pr * PC;
       if (pr0 + pr >= Hp || pc0 + pc >= Wp) continue;
