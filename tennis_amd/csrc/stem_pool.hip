@@ -184,11 +184,11 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(StemArgs a, f16 *__restr
   for (int ct = 0; ct < ntc; ++ct) {
     const int pc0 = ct * PC, cx0 = 2 * pc0 - 1;
     if (ct + 1 < ntc) request(ct + 1);
-    // conv + BN + ReLU -> LDS; wave pair p = wid>>1 takes the pixel fragments p, p+2, ..., two at a time so that
+    // conv + BN + ReLU -> LDS; wave pair p = wid>>1 takes the pixel fragments p, p+2, ..., three at a time so that
     // the patch reads of one kernel row hide behind the MFMAs of the previous one
-    auto conv_frags = [&](auto nft, int fa, int fb) {
+    auto conv_frags = [&](auto nft, int fa, int fb, int fc) {
       constexpr int NFR = decltype(nft)::value;
-      const int fr[2] = {fa, fb};
+      const int fr[3] = {fa, fb, fc};
       f32x4 acc[NFR][2];
 #pragma unroll
       for (int q = 0; q < NFR; ++q)
@@ -223,9 +223,8 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(StemArgs a, f16 *__restr
       }
     };
     if (!(TN_STEM_EXP & 1)) {
-      int f = wid >> 1;
-      for (; f + 2 < NFRAG; f += 4) conv_frags(std::integral_constant<int, 2>{}, f, f + 2);
-      if (f < NFRAG) conv_frags(std::integral_constant<int, 1>{}, f, f);
+      static_assert(NFRAG == 18, "9 fragments per wave pair = 3 triples");
+      for (int f = wid >> 1; f < NFRAG; f += 6) conv_frags(std::integral_constant<int, 3>{}, f, f + 2, f + 4);
     }
     __syncthreads();                      // conv tile complete; nobody reads the patch any more
     if (ct + 1 < ntc) commit(ct + 1);
