@@ -92,8 +92,23 @@ def main():
                                                    [float(y) for y in x] for x in r]))
         except TypeError:
             pass
+    # plain-text inputs (tokenized=False): the mteval-13a / v14-international tokenizers, BPE joins and
+    # compound splitting, upper/lower case, an empty hypothesis
+    trefs = [["The near player serves an ace, 120 mph (wide)!", "A fore-hand return; it's OUT.",
+              "Far player's back@@ hand lob - long 3.5 m", "point won"],
+             ["Near player serves a 120mph ace wide.", "The forehand return is out", "A back@@ hand lob goes long, 3.5m",
+              "the point is won"]]
+    thyps = ["The near player serves an ace (wide), 120 mph!", "A fore-hand return is out.",
+             "far player's back@@ hand lob long - 3.5 m", ""]
+    text = []
+    for kwargs in [dict(tokenized=False), dict(tokenized=False, tokenizer="intl"), dict(tokenized=False, tokenizer=None),
+                   dict(tokenized=False, lower_case=True, smooth=True),
+                   dict(tokenized=False, bpe=True, split_compound_word=True, lower_case=True)]:
+        r = compute_bleu(trefs, thyps, **kwargs)
+        text.append(dict(kwargs=kwargs, result=[float(x) if not isinstance(x, (list, tuple)) else
+                                                [float(y) for y in x] for x in r]))
     with open(os.path.join(HERE, "bleu_reference.json"), "w") as f:
-        json.dump(dict(refs=refs, hyps=hyps, cases=out), f)
+        json.dump(dict(refs=refs, hyps=hyps, cases=out, text_refs=trefs, text_hyps=thyps, text_cases=text), f)
     print("wrote", len(cases), "PRF1 cases,", len(out), "BLEU cases")
 
 

@@ -259,3 +259,21 @@ def test_gnmt_oracle_properties():
     states, att = dec.init_state(mem, st, vl)
     logp, _, _ = dec.step(tgt[:, 0], states, att, np.arange(2))
     assert np.allclose(gn._log_softmax(lg[:, 0]), logp, atol=1e-6)
+
+
+def test_bleu_pinned_to_reference_golden():
+    """tennis_amd.metrics.bleu.compute_bleu vs vectors produced by the reference's own metrics/bleu.py
+    (tests/golden/make_reference_golden.py): tokenised and plain-text inputs, both tokenisers, smoothing,
+    case folding, BPE joins, compound splitting, an empty hypothesis."""
+    import json
+    from tennis_amd.metrics.bleu import compute_bleu
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bleu_reference.json")))
+    n = 0
+    for refs, hyps, cases in ((g["refs"], g["hyps"], g["cases"]), (g["text_refs"], g["text_hyps"], g["text_cases"])):
+        for c in cases:
+            got = compute_bleu(refs, hyps, **c["kwargs"])
+            exp = c["result"]
+            assert abs(got[0] - exp[0]) < 1e-12 and np.allclose(got[1], exp[1], atol=1e-12)
+            assert abs(got[2] - exp[2]) < 1e-12 and got[3] == exp[3] and got[4] == exp[4]
+            n += 1
+    assert n == 9
