@@ -115,8 +115,12 @@ class Block:
     def load_parameters(self, filename, ctx=None, allow_missing=False, ignore_extra=False):
         if not os.path.exists(filename):
             raise FileNotFoundError(filename)
-        with np.load(filename) as z:
-            loaded = {k: z[k] for k in z.files}
+        from .params_io import is_mxnet_params, load_mxnet_params
+        if is_mxnet_params(filename):       # an MXNet NDArray list (mx.nd.save / Gluon save with prefixed names)
+            loaded = load_mxnet_params(filename)
+        else:
+            with np.load(filename) as z:
+                loaded = {k: z[k] for k in z.files}
         self.set_params(loaded)
         if not allow_missing:
             missing = [k for k, v in self.collect_params().items() if v.data is None and k not in loaded]

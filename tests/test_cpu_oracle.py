@@ -277,3 +277,36 @@ def test_bleu_pinned_to_reference_golden():
             assert abs(got[2] - exp[2]) < 1e-12 and got[3] == exp[3] and got[4] == exp[4]
             n += 1
     assert n == 9
+
+
+def test_mxnet_params_container_round_trip(tmp_path):
+    """tennis_amd.params_io: NDArray-list container (V2 records) write -> read, dtype flags, 0-d / empty shapes,
+    'arg:' / 'aux:' prefixes, and Block.load_parameters picking the format by its magic."""
+    import struct
+    from tennis_amd import params_io as pio
+    from tennis_amd import weights as W
+    from tennis_amd.models.vision.definitions import FrameModel
+    from tennis_amd.model_zoo import get_model
+    rng = np.random.default_rng(0)
+    d = {"arg:fc_weight": rng.normal(size=(11, 7)).astype(np.float32), "aux:bn_moving_var": rng.random(5).astype(np.float32),
+         "half": rng.normal(size=(2, 3, 4)).astype(np.float16), "ids": np.arange(6, dtype=np.int64).reshape(2, 3),
+         "bytes": np.arange(5, dtype=np.uint8)}
+    f = str(tmp_path / "x.params")
+    pio.save_mxnet_params(f, d)
+    assert pio.is_mxnet_params(f)
+    back = pio.load_mxnet_params(f)
+    assert set(back) == {"fc_weight", "bn_moving_var", "half", "ids", "bytes"}
+    for k, v in d.items():
+        k = k.split(":")[-1]
+        assert back[k].dtype == v.dtype and np.array_equal(back[k], v)
+    with open(f, "rb") as fh:                       # the header the format description gives
+        assert struct.unpack("<QQQ", fh.read(24)) == (0x112, 0, 5) and struct.unpack("<I", fh.read(4))[0] == 0xF993FAC9
+    # a model's parameters through the container
+    p = W.make_densenet121_weights(0)
+    p.update(W.make_dense_weights(1, 11, 1024, "framemodel0_dense0_"))
+    g = str(tmp_path / "0006.params")
+    pio.save_mxnet_params(g, p)
+    fm = FrameModel(get_model("DenseNet121", pretrained=False).features, 11, prefix="framemodel0_")
+    fm.load_parameters(g)
+    got = {k: v.data for k, v in fm.collect_params().items()}
+    assert set(got) == set(p) and all(np.array_equal(got[k], p[k]) for k in p)
