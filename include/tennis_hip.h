@@ -132,6 +132,25 @@ int tn_birnn_destroy(tn_birnn *r);
 int tn_temporal_pool(tn_ctx *ctx, const float *x, int batch, int steps, int feat, tn_pool_kind kind,
                      float *y);
 
+/* ---- temporal-head training step ------------------------------ */
+/* bi-GRU(hidden) over features -> max over T -> Dense(classes) -> SoftmaxCrossEntropyLoss, backward, SGD with
+ * momentum and weight decay: the frozen-backbone recipe of reference train.py (gluon.Trainer(..., 'sgd', {lr,
+ * momentum, wd}) :298-299; SoftmaxCrossEntropyLoss :324; ag.record / ag.backward / trainer.step(batch_size)
+ * :410-424) on the CNNRNN model of models/vision/definitions.py:94-110 in feature mode.
+ * Parameters use the Gluon names (<rnn_prefix>{l0,r0}_{i2h,h2h}_{weight,bias}, <dense_prefix>{weight,bias}).
+ * forward_backward leaves d(sum of per-sample losses)/d(param) in the gradient buffer; the caller may all-reduce
+ * that buffer over ranks (tn_head_buffers gives the flat device arrays) before tn_head_sgd_step, whose update is
+ * MXNet's sgd_mom_update: mom = momentum*mom - lr*(rescale_grad*grad + wd*w); w += mom. */
+typedef struct tn_head tn_head;
+int tn_head_create(tn_ctx *ctx, int input_size, int hidden, int classes, const tn_param *params, int n_params,
+                   const char *rnn_prefix, const char *dense_prefix, int max_batch, int max_steps, tn_head **out);
+int tn_head_forward_backward(tn_head *h, const float *x, const int32_t *labels, int batch, int steps, float *loss,
+                             float *logits);
+int tn_head_buffers(tn_head *h, float **params_dev, float **grads_dev, int64_t *numel);
+int tn_head_sgd_step(tn_head *h, float lr, float momentum, float wd, float rescale_grad);
+int tn_head_read_param(tn_head *h, const char *name, int gradient, float *out_host, int64_t capacity, int64_t *numel);
+int tn_head_destroy(tn_head *h);
+
 /* ---- device PRF1 confusion histogram -------------------------------------- */
 /* Replaces the argmax + per-sample python loop of PRF1.update (reference
  * metrics/vision.py:41-49).  logits (rows,classes) fp32, labels (rows,) int32;

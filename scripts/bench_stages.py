@@ -6,7 +6,7 @@ import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tennis_amd import weights as W
-from tennis_amd.engine import BiRNN, Dense, GNMTCaptioner, temporal_pool
+from tennis_amd.engine import BiRNN, Dense, GNMTCaptioner, TemporalHeadTrainer, temporal_pool
 
 dev = torch.device("cuda:0")
 
@@ -34,6 +34,14 @@ def c3():
 s = timed(c3, 50)
 out["C3_bigru_head"] = {"ms_per_clip_batch": round(s * 1e3, 3), "clips_per_s": round(B / s, 1), "frames_per_s": round(B * T / s, 1),
                         "gflop": 3.624, "tflops": round(3.624e9 / s / 1e12, 3)}
+tr = TemporalHeadTrainer(p, F, H, 11, max_batch=B, max_steps=T)
+yl = torch.from_numpy(rng.integers(0, 11, B).astype(np.int32)).to(dev)
+def c3t():
+    tr.forward_backward(x, yl)
+    tr.step(B, 1e-3, 0.9, 1e-4)
+s = timed(c3t, 50)
+out["C3_train_step"] = {"ms_per_clip_batch": round(s * 1e3, 3), "clips_per_s": round(B / s, 1),
+                        "note": "forward + softmax CE + BPTT + weight-gradient GEMMs + SGD momentum update, fp32"}
 # ---- C5 -------------------------------------------------------------------------------------------------------
 B, T, F, H, E, V, beam, ml = 32, 214, 1024, 256, 100, 254, 5, 150
 p = W.make_gnmt_weights(0, "gru", F, H, E, V)

@@ -11,6 +11,7 @@
 #include "common.h"
 #include "linear.h"
 #include "rnn.h"
+#include "train.h"
 
 // ---------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -626,6 +627,158 @@ extern "C" int tn_birnn_destroy(tn_birnn *r) {
   (void)hipSetDevice(r->ctx->device);
   r->pool.release();
   delete r;
+  return TN_OK;
+}
+
+// ---- temporal-head training step -----------------------------------------------------
+struct tn_head {
+  tn_ctx *ctx;
+  DevPool pool;
+  int F, H, C, maxB, maxT;
+  long n;                          // parameters in the flat buffers
+  long o_wi, o_bi, o_wh, o_bh, o_wd, o_bd;
+  float *w, *g, *mom;              // [n] parameters, gradients, momentum
+  float *whT;                      // [2][H][3H] transposed h2h for the forward recurrence
+  float *gi, *seq, *gates, *pooled, *dlog, *dpool, *dseq, *dgi, *dgh, *hprev, *logits, *loss;
+  int32_t *arg;
+  std::string rnn_prefix, dense_prefix;
+};
+
+static int head_refresh_whT(tn_head *h) {
+  for (int d = 0; d < 2; ++d) {
+    const int rc = launch_transpose_f32(h->w + h->o_wh + (long)d * 3 * h->H * h->H, 3 * h->H, h->H,
+                                        h->whT + (long)d * h->H * 3 * h->H, h->ctx->stream);
+    if (rc) return rc;
+  }
+  return TN_OK;
+}
+
+extern "C" int tn_head_create(tn_ctx *ctx, int input_size, int hidden, int classes, const tn_param *params,
+                              int n_params, const char *rnn_prefix, const char *dense_prefix, int max_batch,
+                              int max_steps, tn_head **out) {
+  TN_REQUIRE(ctx && params && rnn_prefix && dense_prefix && out, "tn_head_create: null argument");
+  TN_REQUIRE(input_size > 0 && hidden > 0 && hidden % 4 == 0 && 3 * hidden <= 1024 && classes > 0 && max_batch > 0 &&
+                 max_steps > 0, "tn_head_create: bad shape");
+  TN_HIP_CHECK(hipSetDevice(ctx->device));
+  ParamMap pm(params, n_params);
+  const int F = input_size, H = hidden, C = classes, GH = 3 * hidden;
+  tn_head *h = new tn_head();
+  h->ctx = ctx; h->F = F; h->H = H; h->C = C; h->maxB = max_batch; h->maxT = max_steps;
+  h->rnn_prefix = rnn_prefix; h->dense_prefix = dense_prefix;
+  h->o_wi = 0; h->o_bi = h->o_wi + 2L * GH * F; h->o_wh = h->o_bi + 2L * GH; h->o_bh = h->o_wh + 2L * GH * H;
+  h->o_wd = h->o_bh + 2L * GH; h->o_bd = h->o_wd + (long)C * 2 * H; h->n = h->o_bd + C;
+  std::vector<float> w(h->n);
+  auto fail = [&](int rc) { h->pool.release(); delete h; return rc; };
+  for (int d = 0; d < 2; ++d) {
+    const std::string dp = h->rnn_prefix + (d == 0 ? "l0_" : "r0_");
+    const float *a = pm.get(dp + "i2h_weight", (int64_t)GH * F), *b = pm.get(dp + "h2h_weight", (int64_t)GH * H);
+    const float *c = pm.get(dp + "i2h_bias", GH), *e = pm.get(dp + "h2h_bias", GH);
+    if (!a || !b || !c || !e) return fail(TN_ERR_MISSING);
+    memcpy(&w[h->o_wi + (long)d * GH * F], a, sizeof(float) * GH * F);
+    memcpy(&w[h->o_bi + (long)d * GH], c, sizeof(float) * GH);
+    memcpy(&w[h->o_wh + (long)d * GH * H], b, sizeof(float) * GH * H);
+    memcpy(&w[h->o_bh + (long)d * GH], e, sizeof(float) * GH);
+  }
+  const float *wd = pm.get(h->dense_prefix + "weight", (int64_t)C * 2 * H), *bd = pm.get(h->dense_prefix + "bias", C);
+  if (!wd || !bd) return fail(TN_ERR_MISSING);
+  memcpy(&w[h->o_wd], wd, sizeof(float) * C * 2 * H);
+  memcpy(&w[h->o_bd], bd, sizeof(float) * C);
+  h->w = h->pool.upload(w);
+  const size_t rows = (size_t)max_batch * max_steps;
+  auto fl = [&](size_t n) { return (float *)h->pool.alloc(n * sizeof(float)); };
+  h->g = fl(h->n); h->mom = fl(h->n); h->whT = fl(2L * H * GH);
+  h->gi = fl(rows * 2 * GH); h->seq = fl(rows * 2 * H); h->gates = fl(2 * rows * 4 * H);
+  h->pooled = fl((size_t)max_batch * 2 * H); h->dlog = fl((size_t)max_batch * C); h->dpool = fl((size_t)max_batch * 2 * H);
+  h->dseq = fl(rows * 2 * H); h->dgi = fl(rows * 2 * GH); h->dgh = fl(rows * 2 * GH); h->hprev = fl(2 * rows * H);
+  h->logits = fl((size_t)max_batch * C); h->loss = fl(max_batch);
+  h->arg = (int32_t *)h->pool.alloc((size_t)max_batch * 2 * H * sizeof(int32_t));
+  if (h->pool.failed) { tn_set_error("device allocation failed"); return fail(TN_ERR_NOMEM); }
+  TN_HIP_CHECK(hipMemsetAsync(h->mom, 0, h->n * sizeof(float), ctx->stream));
+  TN_HIP_CHECK(hipMemsetAsync(h->g, 0, h->n * sizeof(float), ctx->stream));
+  const int rc = head_refresh_whT(h);
+  if (rc) return fail(rc);
+  *out = h;
+  return TN_OK;
+}
+
+extern "C" int tn_head_forward_backward(tn_head *h, const float *x, const int32_t *labels, int B, int T, float *loss,
+                                        float *logits) {
+  TN_REQUIRE(h && x && labels, "tn_head_forward_backward: null argument");
+  TN_REQUIRE(B > 0 && B <= h->maxB && T > 0 && T <= h->maxT, "tn_head_forward_backward: batch / steps exceed the maxima");
+  TN_HIP_CHECK(hipSetDevice(h->ctx->device));
+  hipStream_t s = h->ctx->stream;
+  const int F = h->F, H = h->H, C = h->C, GH = 3 * h->H, M = B * T;
+  float *w = h->w, *g = h->g;
+  int rc;
+#define TN_TRY(e) do { rc = (e); if (rc) return rc; } while (0)
+  // forward: one i2h GEMM for both directions, recurrence with saved gates, max over T (argmax kept), Dense
+  TN_TRY(launch_linear_f32(x, F, w + h->o_wi, F, w + h->o_bi, h->gi, 2 * GH, M, 2 * GH, F, 0, s));
+  TN_TRY(launch_gru_train_fwd(h->gi, h->whT, w + h->o_bh, h->seq, h->gates, B, T, H, s));
+  TN_TRY(launch_pool_max_arg(h->seq, B, T, 2 * H, h->pooled, h->arg, s));
+  TN_TRY(launch_linear_f32(h->pooled, 2 * H, w + h->o_wd, 2 * H, w + h->o_bd, h->logits, C, B, C, 2 * H, 0, s));
+  TN_TRY(launch_softmax_ce(h->logits, labels, B, C, h->loss, h->dlog, s));
+  // backward
+  TN_TRY(launch_dense_bwd(h->dlog, h->pooled, w + h->o_wd, B, C, 2 * H, g + h->o_wd, g + h->o_bd, h->dpool, s));
+  TN_TRY(launch_scatter_pool_grad(h->dpool, h->arg, B, T, 2 * H, h->dseq, s));
+  TN_TRY(launch_gru_train_bwd(h->seq, h->gates, h->dseq, w + h->o_wh, h->dgi, h->dgh, h->hprev, B, T, H, s));
+  TN_TRY(launch_gemm_tn_f32(h->dgi, 2 * GH, x, F, g + h->o_wi, F, 2 * GH, F, M, s));      // dW_ih = dGI^T X
+  TN_TRY(launch_colsum_f32(h->dgi, 2 * GH, M, 2 * GH, g + h->o_bi, s));
+  for (int d = 0; d < 2; ++d)                                                              // dW_hh = dGH^T H_prev
+    TN_TRY(launch_gemm_tn_f32(h->dgh + d * GH, 2 * GH, h->hprev + (long)d * M * H, H, g + h->o_wh + (long)d * GH * H, H,
+                              GH, H, M, s));
+  TN_TRY(launch_colsum_f32(h->dgh, 2 * GH, M, 2 * GH, g + h->o_bh, s));
+#undef TN_TRY
+  if (loss) TN_HIP_CHECK(hipMemcpyAsync(loss, h->loss, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
+  if (logits) TN_HIP_CHECK(hipMemcpyAsync(logits, h->logits, sizeof(float) * B * C, hipMemcpyDeviceToDevice, s));
+  return TN_OK;
+}
+
+extern "C" int tn_head_buffers(tn_head *h, float **params_dev, float **grads_dev, int64_t *numel) {
+  TN_REQUIRE(h, "tn_head_buffers: null handle");
+  if (params_dev) *params_dev = h->w;
+  if (grads_dev) *grads_dev = h->g;
+  if (numel) *numel = h->n;
+  return TN_OK;
+}
+
+extern "C" int tn_head_sgd_step(tn_head *h, float lr, float momentum, float wd, float rescale_grad) {
+  TN_REQUIRE(h, "tn_head_sgd_step: null handle");
+  TN_HIP_CHECK(hipSetDevice(h->ctx->device));
+  int rc = launch_sgd_momentum(h->w, h->g, h->mom, h->n, lr, momentum, wd, rescale_grad, h->ctx->stream);
+  if (rc) return rc;
+  return head_refresh_whT(h);
+}
+
+extern "C" int tn_head_read_param(tn_head *h, const char *name_c, int gradient, float *out_host, int64_t capacity,
+                                  int64_t *numel) {
+  TN_REQUIRE(h && name_c && out_host && numel, "tn_head_read_param: null argument");
+  const std::string name(name_c);
+  const long GH = 3L * h->H;
+  long off = -1, cnt = 0;
+  for (int d = 0; d < 2; ++d) {
+    const std::string dp = h->rnn_prefix + (d == 0 ? "l0_" : "r0_");
+    if (name == dp + "i2h_weight") { off = h->o_wi + d * GH * h->F; cnt = GH * h->F; }
+    if (name == dp + "i2h_bias") { off = h->o_bi + d * GH; cnt = GH; }
+    if (name == dp + "h2h_weight") { off = h->o_wh + d * GH * h->H; cnt = GH * h->H; }
+    if (name == dp + "h2h_bias") { off = h->o_bh + d * GH; cnt = GH; }
+  }
+  if (name == h->dense_prefix + "weight") { off = h->o_wd; cnt = (long)h->C * 2 * h->H; }
+  if (name == h->dense_prefix + "bias") { off = h->o_bd; cnt = h->C; }
+  TN_REQUIRE(off >= 0, "tn_head_read_param: unknown parameter name");
+  TN_REQUIRE(capacity >= cnt, "tn_head_read_param: host buffer too small");
+  TN_HIP_CHECK(hipSetDevice(h->ctx->device));
+  TN_HIP_CHECK(hipStreamSynchronize(h->ctx->stream));
+  TN_HIP_CHECK(hipMemcpy(out_host, (gradient ? h->g : h->w) + off, sizeof(float) * cnt, hipMemcpyDeviceToHost));
+  *numel = cnt;
+  return TN_OK;
+}
+
+extern "C" int tn_head_destroy(tn_head *h) {
+  if (!h) return TN_OK;
+  (void)hipSetDevice(h->ctx->device);
+  (void)hipStreamSynchronize(h->ctx->stream);
+  h->pool.release();
+  delete h;
   return TN_OK;
 }
 

@@ -247,3 +247,86 @@ def masked_softmax_ce(logits: torch.Tensor, labels: torch.Tensor, valid_length: 
     check(ctx.lib.tn_masked_softmax_ce(ctx.handle, ptr(logits), ptr(lab), lab.shape[1], ptr(vl), b, l, v, ptr(loss)),
           "tn_masked_softmax_ce")
     return loss
+
+
+class TemporalHeadTrainer:
+    """Training step of ``CNNRNN(model=None, type='gru')`` in feature mode (reference definitions.py:94-110) the way
+    train.py drives it: ``SoftmaxCrossEntropyLoss`` per sample (:324), ``ag.backward`` of the per-sample losses and
+    ``gluon.Trainer(params, 'sgd', {learning_rate, momentum, wd}).step(batch_size)`` (:298-299, :410-424).
+
+    ``forward_backward`` leaves the gradient of the SUM of the per-sample losses in a flat device buffer
+    (``grads``); with several ranks all-reduce that buffer (``torch.distributed.all_reduce(trainer.grads)``)
+    before ``step(batch_size)``, whose ``rescale_grad = 1 / batch_size`` is Gluon's."""
+
+    def __init__(self, params: dict, input_size: int, hidden: int = 128, classes: int = 11, max_batch: int = 32,
+                 max_steps: int = 64, rnn_prefix: str = "cnnrnn0_gru0_", dense_prefix: str = "cnnrnn0_dense0_",
+                 ctx: _lib.Context | None = None):
+        self.ctx = ctx or _lib.default_context()
+        self.lib = self.ctx.lib
+        self.input_size, self.hidden, self.classes = input_size, hidden, classes
+        self.rnn_prefix, self.dense_prefix = rnn_prefix, dense_prefix
+        arr, keep = _lib.make_params({k: v for k, v in params.items() if k.startswith(rnn_prefix) or k.startswith(dense_prefix)})
+        h = C.c_void_p()
+        check(self.lib.tn_head_create(self.ctx.handle, input_size, hidden, classes, arr, len(arr), rnn_prefix.encode(),
+                                      dense_prefix.encode(), max_batch, max_steps, C.byref(h)), "tn_head_create")
+        del keep
+        self.handle = h
+        pw, pg, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(self.lib.tn_head_buffers(h, C.byref(pw), C.byref(pg), C.byref(n)), "tn_head_buffers")
+        self.numel = n.value
+        self._pw, self._pg = pw.value, pg.value
+
+    def _view(self, addr):
+        """torch view of a flat fp32 device buffer owned by the library (for all-reduce / inspection)."""
+        class _Arr:
+            __cuda_array_interface__ = {"shape": (self.numel,), "typestr": "<f4", "data": (addr, False), "version": 3}
+        return torch.as_tensor(_Arr(), device=f"cuda:{self.ctx.device}")
+
+    @property
+    def grads(self) -> torch.Tensor:
+        return self._view(self._pg)
+
+    @property
+    def params(self) -> torch.Tensor:
+        return self._view(self._pw)
+
+    def forward_backward(self, x: torch.Tensor, labels: torch.Tensor):
+        x = x.contiguous().float()
+        b, t, f = x.shape
+        labels = labels.to(device=x.device, dtype=torch.int32).contiguous()
+        loss = torch.empty((b,), dtype=torch.float32, device=x.device)
+        logits = torch.empty((b, self.classes), dtype=torch.float32, device=x.device)
+        check(self.lib.tn_head_forward_backward(self.handle, ptr(x), ptr(labels), b, t, ptr(loss), ptr(logits)),
+              "tn_head_forward_backward")
+        return loss, logits
+
+    def step(self, batch_size: int, lr: float, momentum: float = 0.9, wd: float = 1e-4):
+        check(self.lib.tn_head_sgd_step(self.handle, lr, momentum, wd, 1.0 / batch_size), "tn_head_sgd_step")
+
+    def get(self, name: str, gradient: bool = False) -> np.ndarray:
+        cap = 3 * self.hidden * max(self.input_size, self.hidden, 2 * self.classes) + 16
+        out = np.empty(cap, np.float32)
+        n = C.c_int64()
+        check(self.lib.tn_head_read_param(self.handle, name.encode(), 1 if gradient else 0,
+                                          out.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(n)), "tn_head_read_param")
+        return out[:n.value].copy()
+
+    def state_dict(self) -> dict:
+        h, f, c = self.hidden, self.input_size, self.classes
+        out = {}
+        for d in ("l0_", "r0_"):
+            out[self.rnn_prefix + d + "i2h_weight"] = self.get(self.rnn_prefix + d + "i2h_weight").reshape(3 * h, f)
+            out[self.rnn_prefix + d + "h2h_weight"] = self.get(self.rnn_prefix + d + "h2h_weight").reshape(3 * h, h)
+            out[self.rnn_prefix + d + "i2h_bias"] = self.get(self.rnn_prefix + d + "i2h_bias")
+            out[self.rnn_prefix + d + "h2h_bias"] = self.get(self.rnn_prefix + d + "h2h_bias")
+        out[self.dense_prefix + "weight"] = self.get(self.dense_prefix + "weight").reshape(c, 2 * h)
+        out[self.dense_prefix + "bias"] = self.get(self.dense_prefix + "bias")
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.tn_head_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass

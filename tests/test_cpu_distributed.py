@@ -42,3 +42,61 @@ def test_rank_batches_partition():
         assert seen[0][0] == 0 and seen[-1][1] == n
         assert all(a[1] == c[0] for a, c in zip(seen, seen[1:]))
         assert sharding.local_rows(n, b, w) * w >= n
+
+
+def _dp_train_worker(rank, world, port, q):
+    """Data-parallel recipe of tennis_amd.train.allreduce_and_step on CPU (gloo): each rank holds the gradient of the
+    summed loss of ITS half of the batch (oracle), all-reduce SUM, update with rescale 1/global_batch -> the same
+    parameters as one process on the whole batch."""
+    import os
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from oracle import train_np as tn
+    from tennis_amd import weights as W
+    from tennis_amd.train import allreduce_and_step
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, T, F, H, C_ = 8, 6, 16, 8, 11
+    p = W.make_rnn_weights(1, "gru", F, H, "cnnrnn0_gru0_")
+    p.update(W.make_dense_weights(2, C_, 2 * H, "cnnrnn0_dense0_"))
+    rng = np.random.default_rng(0)
+    x = rng.normal(0, 1, (B, T, F)).astype(np.float32)
+    y = rng.integers(0, C_, B)
+    keys = sorted(p)
+    sl = slice(rank * B // world, (rank + 1) * B // world)
+
+    class FakeHead:                       # the trainer surface allreduce_and_step uses: .grads (flat tensor), .step()
+        def __init__(self):
+            _, _, g = tn.forward_backward(x[sl], y[sl], p)
+            self.grads = torch.from_numpy(np.concatenate([g[k].ravel() for k in keys]))
+            self.new = None
+
+        def step(self, batch_size, lr, momentum, wd):
+            g, off = {}, 0
+            flat = self.grads.numpy()
+            for k in keys:
+                g[k] = flat[off:off + p[k].size].reshape(p[k].shape); off += p[k].size
+            self.new, _ = tn.sgd_momentum({k: v.astype(np.float64) for k, v in p.items()}, g, {}, lr, momentum, wd,
+                                          1.0 / batch_size)
+    h = FakeHead()
+    allreduce_and_step(h, B, 0.01, 0.9, 1e-4)
+    _, _, gfull = tn.forward_backward(x, y, p)
+    ref, _ = tn.sgd_momentum({k: v.astype(np.float64) for k, v in p.items()}, gfull, {}, 0.01, 0.9, 1e-4, 1.0 / B)
+    q.put((rank, max(float(np.abs(h.new[k] - ref[k]).max()) for k in keys)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_training_step_matches_single_process():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400) + 411
+    procs = [ctx.Process(target=_dp_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for pr in procs:
+        pr.join(timeout=60)
+    assert all(e < 1e-12 for _, e in res), res
