@@ -28,7 +28,7 @@
 #include "common.h"
 
 #ifndef TN_EXP
-#define TN_EXP 0   // timing experiments only (scripts/kbench.py --lib): bit 0 skip phase B, 1 skip K loop, 2 skip epilogue A, 3 skip the store (note: skipping a consumer lets the compiler drop its producer's MFMAs too), 4 K loop streams only (no LDS reads / MFMA)
+#define TN_EXP 0   // timing experiments only (scripts/kbench.py --lib): bit 0 skip phase B, 1 skip K loop, 2 skip epilogue A, 3 skip the store (note: skipping a consumer lets the compiler drop its producer's MFMAs too), 4 K loop streams only (no LDS reads / MFMA), 5 no refill inside the K loop (compute on whatever the ring holds)
 #endif
 
 namespace {
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (kt == 0) DL_STAMP(1);
-    const bool refill = kt + 2 < nk;
+    const bool refill = !(TN_EXP & 32) && kt + 2 < nk;
     const int rslot = st >= 1 ? st - 1 : 2;         // slot (kt+2)%3, free since everyone passed the barrier
     if (!SPREAD && refill) issue(rslot);
     const unsigned char *Xs = smem + st * G::STAGE;
