@@ -60,10 +60,11 @@ def _log_softmax(z):
 
 
 class Decoder:
-    """One-step GNMT decoder + target embedding + projection (GRU cells)."""
+    """One-step GNMT decoder + target embedding + projection (GRU or LSTM cells).  The recurrent state travels
+    as a flat list of (R,H) arrays: [h0, h1] for GRU, [h0, c0, h1, c1] for LSTM (the cell output is h)."""
 
-    def __init__(self, p, hidden, num_layers=2, prefix="gnmt_"):
-        self.p, self.h, self.nl, self.pre = p, hidden, num_layers, prefix
+    def __init__(self, p, hidden, num_layers=2, prefix="gnmt_", cell="gru"):
+        self.p, self.h, self.nl, self.pre, self.cell = p, hidden, num_layers, prefix, cell
 
     def init_state(self, mem, enc_states, valid_length):
         """gnmt.py:224-252"""
@@ -71,6 +72,8 @@ class Decoder:
         self.mem = mem
         self.keyproj = (mem @ self.p[self.pre + "dec_attention_key_weight"].T).astype(np.float32)
         self.mask = (np.arange(t)[None, :] < np.asarray(valid_length)[:, None])
+        if self.cell == "lstm":                       # gnmt.py:224-252: the encoder's [h, c] per layer
+            return [a.copy() for s in enc_states for a in (s[0], s[1])], np.zeros((b, mem.shape[2]), np.float32)
         return [s[0].copy() for s in enc_states], np.zeros((b, mem.shape[2]), np.float32)
 
     def step(self, tokens, rnn_states, att, rows):
@@ -79,10 +82,17 @@ class Decoder:
         p, pre, H = self.p, self.pre + "dec_", self.h
         emb = p[self.pre + "tgt_embed_weight"][tokens]
         x = np.concatenate([emb, att], axis=-1)
+        lstm = self.cell == "lstm"
+
+        def cell(i, inp):
+            w = [p[f"{pre}rnn{i}_i2h_weight"], p[f"{pre}rnn{i}_h2h_weight"], p[f"{pre}rnn{i}_i2h_bias"], p[f"{pre}rnn{i}_h2h_bias"]]
+            if lstm:
+                return rn.lstm_cell(inp, rnn_states[2 * i], rnn_states[2 * i + 1], *w)
+            return rn.gru_cell(inp, rnn_states[i], *w), None
+
         new_states = []
-        h0 = rn.gru_cell(x, rnn_states[0], p[pre + "rnn0_i2h_weight"], p[pre + "rnn0_h2h_weight"],
-                         p[pre + "rnn0_i2h_bias"], p[pre + "rnn0_h2h_bias"])
-        new_states.append(h0)
+        h0, c0 = cell(0, x)
+        new_states += [h0, c0] if lstm else [h0]
         q = (h0 / np.float32(np.sqrt(H))).astype(np.float32)
         score = np.einsum("rh,rth->rt", q, self.keyproj[rows]).astype(np.float32)
         m = self.mask[rows]
@@ -92,9 +102,8 @@ class Decoder:
         ctx = np.einsum("rt,rth->rh", w, self.mem[rows]).astype(np.float32)
         out = h0
         for i in range(1, self.nl):
-            out = rn.gru_cell(np.concatenate([out, ctx], axis=-1), rnn_states[i], p[f"{pre}rnn{i}_i2h_weight"],
-                              p[f"{pre}rnn{i}_h2h_weight"], p[f"{pre}rnn{i}_i2h_bias"], p[f"{pre}rnn{i}_h2h_bias"])
-            new_states.append(out)
+            out, ci = cell(i, np.concatenate([out, ctx], axis=-1))
+            new_states += [out, ci] if lstm else [out]
         logits = out @ p[self.pre + "tgt_proj_weight"].T + p[self.pre + "tgt_proj_bias"]
         return _log_softmax(logits.astype(np.float32)), new_states, ctx
 
@@ -162,7 +171,8 @@ def decode_seq(dec: Decoder, mem, enc_states, valid_length, tgt):
     for i in range(L):
         logp, rnn_states, att = dec.step(np.maximum(tgt[:, i], 0), rnn_states, att, rows)
         # recover the un-normalised logits: recompute the projection from the top state
-        outs.append((rnn_states[-1] @ p[pre + "tgt_proj_weight"].T + p[pre + "tgt_proj_bias"]).astype(np.float32))
+        top = rnn_states[-2] if dec.cell == "lstm" else rnn_states[-1]
+        outs.append((top @ p[pre + "tgt_proj_weight"].T + p[pre + "tgt_proj_bias"]).astype(np.float32))
     return np.stack(outs, axis=1)
 
 

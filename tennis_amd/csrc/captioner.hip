@@ -48,6 +48,25 @@ __global__ void gru_gate_kernel(const float *__restrict__ gi, const float *__res
   if (xcat) xcat[(long)r * ldx + u] = v;
 }
 
+// LSTM cell gates [i,f,g,o] (gluon rnn.LSTMCell [EXT], same order as the fused layer): c' = f*c + i*g, h' = o*tanh(c')
+__global__ void lstm_gate_kernel(const float *__restrict__ gi, const float *__restrict__ gh,
+                                 const float *__restrict__ c, float *__restrict__ hn, float *__restrict__ cn,
+                                 float *__restrict__ xcat, int ldx, int R, int H) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)R * H) return;
+  const int r = (int)(id / H), u = (int)(id % H);
+  const float *a = gi + (long)r * 4 * H, *b = gh + (long)r * 4 * H;
+  const float ig = sigm(a[u] + b[u]);
+  const float fg = sigm(a[H + u] + b[H + u]);
+  const float gg = tanhf(a[2 * H + u] + b[2 * H + u]);
+  const float og = sigm(a[3 * H + u] + b[3 * H + u]);
+  const float c2 = fg * c[id] + ig * gg;
+  const float v = og * tanhf(c2);
+  cn[id] = c2;
+  hn[id] = v;
+  if (xcat) xcat[(long)r * ldx + u] = v;
+}
+
 // scaled-Luong attention for one decoder row per workgroup: scores over the source steps,
 // masked softmax (masked -> -1e18, weights * mask), context; writes ctx and xcat[:, H:2H]
 __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ hq, const float *__restrict__ keyproj,
@@ -294,7 +313,9 @@ struct tn_gnmt {
   int F, H, E, V, maxB, maxT, beam, maxL;
   float *wi0, *wh0, *bi0, *bh0, *wi1, *wh1, *bi1, *bh1, *wk, *wp, *bp, *emb;
   // per-call workspace
-  float *seq0, *mem, *keyproj, *hl0, *hl1, *cl;
+  int G;                   // gates per cell: 3 GRU, 4 LSTM
+  float *seq0, *mem, *keyproj, *hl0, *hl1, *cl0, *cl1;
+  float *c0[2], *c1[2];    // LSTM cell states of the two decoder layers
   int32_t *vl;
   float *h0[2], *h1[2], *att[2], *x0, *x1, *gi, *gh, *logits, *scores;
   int32_t *alive, *vlen, *tok, *gather, *samples[2], *flag;
@@ -305,7 +326,7 @@ extern "C" int tn_gnmt_create(tn_ctx *ctx, const tn_param *params, int n_params,
                               int input_size, int hidden, int embed, int vocab, int num_layers, int num_bi_layers,
                               int max_batch, int max_src_len, int beam, int max_length, tn_gnmt **out) {
   TN_REQUIRE(ctx && params && prefix_c && out, "tn_gnmt_create: null argument");
-  TN_REQUIRE(cell_kind == TN_RNN_GRU, "tn_gnmt_create: only cell_type='gru' (the reference default, train_gnmt.py:62) is built");
+  TN_REQUIRE(cell_kind == TN_RNN_GRU || cell_kind == TN_RNN_LSTM, "tn_gnmt_create: cell_type must be 'gru' or 'lstm'");
   TN_REQUIRE(num_layers == 2 && num_bi_layers == 1, "tn_gnmt_create: only num_layers=2, num_bi_layers=1 (reference defaults)");
   TN_REQUIRE(beam >= 1 && beam <= 16 && vocab >= beam && max_length >= 1, "tn_gnmt_create: bad beam/vocab/max_length");
   TN_REQUIRE(input_size > 0 && hidden > 0 && hidden % 4 == 0 && embed > 0 && max_batch > 0 && max_src_len > 0,
@@ -322,14 +343,14 @@ extern "C" int tn_gnmt_create(tn_ctx *ctx, const tn_param *params, int n_params,
   };
   tn_gnmt *g = new tn_gnmt();   // value-initialised: every pointer member starts null
   g->ctx = ctx; g->F = input_size; g->H = hidden; g->E = embed; g->V = vocab; g->maxB = max_batch; g->maxT = max_src_len;
-  g->beam = beam; g->maxL = max_length + 2;
+  g->beam = beam; g->maxL = max_length + 2; g->G = cell_kind == TN_RNN_GRU ? 3 : 4;
   auto fail = [&](int code) { g->pool.release(); if (g->enc0) tn_birnn_destroy(g->enc0); if (g->enc1) tn_birnn_destroy(g->enc1); delete g; return code; };
   // encoder layers: rename "<pre>enc_rnn0_{l,r}_*" -> "{l,r}0_*" for tn_birnn
   std::vector<tn_param> p0, p1;
   std::vector<std::string> names;
   names.reserve(16);
   const char *sfx[4] = {"i2h_weight", "h2h_weight", "i2h_bias", "h2h_bias"};
-  const int H = hidden, G3 = 3 * hidden;
+  const int H = hidden, G3 = g->G * hidden;   // (G3: gates * hidden, 3H or 4H)
   for (int d = 0; d < 2; ++d)
     for (int k = 0; k < 4; ++k) {
       const std::string src = pre + "enc_rnn0_" + (d ? "r_" : "l_") + sfx[k];
@@ -350,9 +371,9 @@ extern "C" int tn_gnmt_create(tn_ctx *ctx, const tn_param *params, int n_params,
     p1.push_back(tn_param{nullptr, v, n});
   }
   for (size_t i = 0; i < p1.size(); ++i) p1[i].name = names1[i].c_str();
-  int rc = tn_birnn_create(ctx, TN_RNN_GRU, input_size, H, p0.data(), (int)p0.size(), "", 1, max_batch * max_src_len, &g->enc0);
+  int rc = tn_birnn_create(ctx, (tn_rnn_kind)cell_kind, input_size, H, p0.data(), (int)p0.size(), "", 1, max_batch * max_src_len, &g->enc0);
   if (rc) return fail(rc);
-  rc = tn_birnn_create(ctx, TN_RNN_GRU, 2 * H, H, p1.data(), (int)p1.size(), "", 0, max_batch * max_src_len, &g->enc1);
+  rc = tn_birnn_create(ctx, (tn_rnn_kind)cell_kind, 2 * H, H, p1.data(), (int)p1.size(), "", 0, max_batch * max_src_len, &g->enc1);
   if (rc) return fail(rc);
   // decoder
   const float *a;
@@ -368,9 +389,11 @@ extern "C" int tn_gnmt_create(tn_ctx *ctx, const tn_param *params, int n_params,
   const size_t BT = (size_t)max_batch * max_src_len, R = (size_t)max_batch * beam;
   g->seq0 = g->pool.alloc<float>(BT * 2 * H); g->mem = g->pool.alloc<float>(BT * H); g->keyproj = g->pool.alloc<float>(BT * H);
   g->hl0 = g->pool.alloc<float>(2 * (size_t)max_batch * H); g->hl1 = g->pool.alloc<float>((size_t)max_batch * H);
-  g->cl = g->pool.alloc<float>(2 * (size_t)max_batch * H); g->vl = g->pool.alloc<int32_t>(max_batch);
+  g->cl0 = g->pool.alloc<float>(2 * (size_t)max_batch * H); g->cl1 = g->pool.alloc<float>((size_t)max_batch * H);
+  g->vl = g->pool.alloc<int32_t>(max_batch);
   for (int i = 0; i < 2; ++i) {
     g->h0[i] = g->pool.alloc<float>(R * H); g->h1[i] = g->pool.alloc<float>(R * H); g->att[i] = g->pool.alloc<float>(R * H);
+    g->c0[i] = g->pool.alloc<float>(R * H); g->c1[i] = g->pool.alloc<float>(R * H);
     g->samples[i] = g->pool.alloc<int32_t>(R * g->maxL);
   }
   g->x0 = g->pool.alloc<float>(R * (embed + H)); g->x1 = g->pool.alloc<float>(R * 2 * H);
@@ -391,9 +414,9 @@ extern "C" int tn_gnmt_encode(tn_gnmt *g, const float *src, const int32_t *valid
   hipStream_t s = g->ctx->stream;
   const int H = g->H;
   TN_HIP_CHECK(hipMemcpyAsync(g->vl, valid_len, sizeof(int32_t) * batch, hipMemcpyDeviceToDevice, s));
-  int rc = tn_birnn_forward(g->enc0, src, batch, steps, g->vl, g->seq0, g->hl0, g->cl);   // hl0 = [fwd, bwd] final states
+  int rc = tn_birnn_forward(g->enc0, src, batch, steps, g->vl, g->seq0, g->hl0, g->cl0);   // hl0 / cl0 = [fwd, bwd] final states
   if (rc) return rc;
-  rc = tn_birnn_forward(g->enc1, g->seq0, batch, steps, g->vl, g->mem, g->hl1, g->cl);
+  rc = tn_birnn_forward(g->enc1, g->seq0, batch, steps, g->vl, g->mem, g->hl1, g->cl1);
   if (rc) return rc;
   rc = launch_linear_f32(g->mem, H, g->wk, H, nullptr, g->keyproj, H, batch * steps, H, H, 0, s);
   if (rc) return rc;
@@ -413,7 +436,8 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
   TN_REQUIRE(bos >= 0 && bos < g->V && eos >= 0 && eos < g->V, "tn_gnmt_beam_search: bos/eos outside the vocabulary");
   TN_HIP_CHECK(hipSetDevice(g->ctx->device));
   hipStream_t s = g->ctx->stream;
-  const int B = g->B, T = g->T, H = g->H, E = g->E, V = g->V, beam = g->beam, R = B * beam, L = g->maxL, G3 = 3 * H;
+  const int B = g->B, T = g->T, H = g->H, E = g->E, V = g->V, beam = g->beam, R = B * beam, L = g->maxL, G3 = g->G * H;
+  const bool lstm = g->G == 4;
   TN_HIP_CHECK(hipMemsetAsync(g->samples[0], 0xff, sizeof(int32_t) * (size_t)R * L, s));
   TN_HIP_CHECK(hipMemsetAsync(g->samples[1], 0xff, sizeof(int32_t) * (size_t)R * L, s));
   const int nb = (R * H + 255) / 256;
@@ -421,6 +445,10 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
   hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)(g->hl0 + (size_t)B * H), g->h0[0], B, beam, H);
   hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)g->hl1, g->h1[0], B, beam, H);
   hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)nullptr, g->att[0], B, beam, H);
+  if (lstm) {
+    hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)(g->cl0 + (size_t)B * H), g->c0[0], B, beam, H);
+    hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)g->cl1, g->c1[0], B, beam, H);
+  }
   hipLaunchKernelGGL(beam_init_kernel, dim3((R + 255) / 256), dim3(256), 0, s, g->scores, g->alive, g->vlen, g->tok, g->samples[0], L, B, beam, bos);
   int cur = 0, steps_done = 0, all_dead = 0;
   const size_t att_lds = (size_t)(H + T + 256) * sizeof(float);
@@ -433,13 +461,15 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
     if (rc) return rc;
     rc = launch_linear_f32(g->h0[cur], H, g->wh0, H, g->bh0, g->gh, G3, R, G3, H, 0, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(gru_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->h0[cur], g->h0[nxt], g->x1, 2 * H, R, H);
+    if (lstm) hipLaunchKernelGGL(lstm_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->c0[cur], g->h0[nxt], g->c0[nxt], g->x1, 2 * H, R, H);
+    else hipLaunchKernelGGL(gru_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->h0[cur], g->h0[nxt], g->x1, 2 * H, R, H);
     hipLaunchKernelGGL(attention_kernel, dim3(R), dim3(256), att_lds, s, g->h0[nxt], g->keyproj, g->mem, g->vl, g->att[nxt], g->x1, beam, T, H);
     rc = launch_linear_f32(g->x1, 2 * H, g->wi1, 2 * H, g->bi1, g->gi, G3, R, G3, 2 * H, 0, s);
     if (rc) return rc;
     rc = launch_linear_f32(g->h1[cur], H, g->wh1, H, g->bh1, g->gh, G3, R, G3, H, 0, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(gru_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->h1[cur], g->h1[nxt], (float *)nullptr, 0, R, H);
+    if (lstm) hipLaunchKernelGGL(lstm_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->c1[cur], g->h1[nxt], g->c1[nxt], (float *)nullptr, 0, R, H);
+    else hipLaunchKernelGGL(gru_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->h1[cur], g->h1[nxt], (float *)nullptr, 0, R, H);
     rc = launch_linear_f32(g->h1[nxt], H, g->wp, H, g->bp, g->logits, V, R, V, H, 0, s);
     if (rc) return rc;
     hipLaunchKernelGGL(beam_update_kernel, dim3(B), dim3(256), beam_lds, s, g->logits, V, beam, step, alpha, K, eos, g->scores,
@@ -448,6 +478,10 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
     hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, s, g->h0[nxt], g->h0[cur], g->gather, R, H);
     hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, s, g->h1[nxt], g->h1[cur], g->gather, R, H);
     hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, s, g->att[nxt], g->att[cur], g->gather, R, H);
+    if (lstm) {
+      hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, s, g->c0[nxt], g->c0[cur], g->gather, R, H);
+      hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, s, g->c1[nxt], g->c1[cur], g->gather, R, H);
+    }
     // states are back in `cur`; only the samples ping-pong
     {
       int32_t *tmp = g->samples[0]; g->samples[0] = g->samples[1]; g->samples[1] = tmp;
@@ -490,11 +524,16 @@ extern "C" int tn_gnmt_decode_seq(tn_gnmt *g, const int32_t *tgt, int ld, int st
   TN_REQUIRE(steps >= 1 && ld >= steps, "tn_gnmt_decode_seq: bad target length");
   TN_HIP_CHECK(hipSetDevice(g->ctx->device));
   hipStream_t s = g->ctx->stream;
-  const int B = g->B, T = g->T, H = g->H, E = g->E, V = g->V, G3 = 3 * H, R = B;
+  const int B = g->B, T = g->T, H = g->H, E = g->E, V = g->V, G3 = g->G * H, R = B;
+  const bool lstm = g->G == 4;
   const int nb = (R * H + 255) / 256;
   hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)(g->hl0 + (size_t)B * H), g->h0[0], B, 1, H);
   hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)g->hl1, g->h1[0], B, 1, H);
   hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)nullptr, g->att[0], B, 1, H);
+  if (lstm) {
+    hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)(g->cl0 + (size_t)B * H), g->c0[0], B, 1, H);
+    hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)g->cl1, g->c1[0], B, 1, H);
+  }
   const size_t att_lds = (size_t)(H + T + 256) * sizeof(float);
   int cur = 0;
   for (int i = 0; i < steps; ++i) {
@@ -505,13 +544,15 @@ extern "C" int tn_gnmt_decode_seq(tn_gnmt *g, const int32_t *tgt, int ld, int st
     if (rc) return rc;
     rc = launch_linear_f32(g->h0[cur], H, g->wh0, H, g->bh0, g->gh, G3, R, G3, H, 0, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(gru_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->h0[cur], g->h0[nxt], g->x1, 2 * H, R, H);
+    if (lstm) hipLaunchKernelGGL(lstm_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->c0[cur], g->h0[nxt], g->c0[nxt], g->x1, 2 * H, R, H);
+    else hipLaunchKernelGGL(gru_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->h0[cur], g->h0[nxt], g->x1, 2 * H, R, H);
     hipLaunchKernelGGL(attention_kernel, dim3(R), dim3(256), att_lds, s, g->h0[nxt], g->keyproj, g->mem, g->vl, g->att[nxt], g->x1, 1, T, H);
     rc = launch_linear_f32(g->x1, 2 * H, g->wi1, 2 * H, g->bi1, g->gi, G3, R, G3, 2 * H, 0, s);
     if (rc) return rc;
     rc = launch_linear_f32(g->h1[cur], H, g->wh1, H, g->bh1, g->gh, G3, R, G3, H, 0, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(gru_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->h1[cur], g->h1[nxt], (float *)nullptr, 0, R, H);
+    if (lstm) hipLaunchKernelGGL(lstm_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->c1[cur], g->h1[nxt], g->c1[nxt], (float *)nullptr, 0, R, H);
+    else hipLaunchKernelGGL(gru_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->h1[cur], g->h1[nxt], (float *)nullptr, 0, R, H);
     rc = launch_linear_f32(g->h1[nxt], H, g->wp, H, g->bp, logits + (size_t)i * V, steps * V, R, V, H, 0, s);
     if (rc) return rc;
     cur = nxt;

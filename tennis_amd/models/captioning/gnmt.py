@@ -2,7 +2,7 @@
 (itself derived from gluon-nlp) and of the NMTModel the reference builds from gluonnlp
 (train_gnmt.py:228-229).  The blocks hold configuration and Gluon-named parameters; the
 compute runs in libtennis_hip.so (tn_gnmt_*).  Only the configuration the reference
-actually uses is built: cell_type 'gru', attention 'scaled_luong', use_residual False.
+actually uses is built: cell_type 'gru' (flag default) or 'lstm', attention 'scaled_luong', use_residual False.
 """
 from __future__ import annotations
 

@@ -9,21 +9,21 @@ from oracle import gnmt_np as gn
 pytestmark = pytest.mark.gpu
 
 
-def _case(seed, B, T, F, H, E, V, beam, max_length, eos_bias=0.0, proj_scale=1.0):
+def _case(seed, B, T, F, H, E, V, beam, max_length, eos_bias=0.0, proj_scale=1.0, cell="gru"):
     from tennis_amd import weights as W
     from tennis_amd.engine import GNMTCaptioner
-    p = W.make_gnmt_weights(seed, "gru", F, H, E, V)
+    p = W.make_gnmt_weights(seed, cell, F, H, E, V)
     p["gnmt_tgt_proj_weight"] = (p["gnmt_tgt_proj_weight"] * proj_scale).astype(np.float32)   # peakier word distribution
     p["gnmt_tgt_proj_bias"][3] += eos_bias          # steer how early <eos> wins
     rng = np.random.default_rng(seed)
     src = (np.abs(rng.normal(0, 1, (B, T, F))) * 0.5).astype(np.float32)
     vl = rng.integers(max(1, T // 3), T + 1, B).astype(np.int32)
     vl[0] = T
-    cap = GNMTCaptioner(p, F, H, E, V, beam=beam, max_length=max_length, max_batch=B, max_src_len=T)
+    cap = GNMTCaptioner(p, F, H, E, V, beam=beam, max_length=max_length, max_batch=B, max_src_len=T, cell_type=cell)
     mem = cap.encode(torch.from_numpy(src).cuda(), torch.from_numpy(vl).cuda()).cpu().numpy()
     samples, scores, vlen = cap.beam_search(2, 3, 1.0, 5.0)
-    rmem, rstates = gn.encoder(src, vl, p, "gru", H)
-    dec = gn.Decoder(p, H)
+    rmem, rstates = gn.encoder(src, vl, p, cell, H)
+    dec = gn.Decoder(p, H, cell=cell)
     rs, rsc, rvl = gn.beam_search(dec, rmem, rstates, vl, 2, 3, beam, 1.0, 5, max_length)
     return (mem, samples.cpu().numpy(), scores.cpu().numpy(), vlen.cpu().numpy()), (rmem, rs, rsc, rvl)
 
@@ -33,11 +33,13 @@ def _case(seed, B, T, F, H, E, V, beam, max_length, eos_bias=0.0, proj_scale=1.0
     dict(seed=2, B=5, T=23, F=64, H=32, E=20, V=40, beam=4, max_length=40, eos_bias=1.2),      # every beam finishes early
     dict(seed=2, B=5, T=23, F=64, H=32, E=20, V=40, beam=4, max_length=40, proj_scale=40.0),   # finished + unfinished beams mixed
     dict(seed=3, B=4, T=60, F=1024, H=128, E=100, V=254, beam=5, max_length=30, proj_scale=30.0),  # config C5 shape
+    dict(seed=4, B=3, T=13, F=32, H=16, E=12, V=30, beam=4, max_length=14, cell="lstm"),                    # LSTM cells
+    dict(seed=5, B=5, T=23, F=64, H=32, E=20, V=40, beam=4, max_length=40, proj_scale=40.0, cell="lstm"),
 ])
 def test_beam_search_matches_oracle(cfg, report):
     (mem, s, sc, vl), (rmem, rs, rsc, rvl) = _case(**cfg)
     assert np.abs(mem - rmem).max() < 1e-4
-    report[f"gnmt_seed{cfg['seed']}_ps{cfg.get('proj_scale', 1.0)}_score_maxabs_err"] = float(np.abs(sc - rsc).max())
+    report[f"gnmt_{cfg.get('cell', 'gru')}_seed{cfg['seed']}_ps{cfg.get('proj_scale', 1.0)}_score_maxabs_err"] = float(np.abs(sc - rsc).max())
     assert s.shape == rs.shape, (s.shape, rs.shape)
     assert np.array_equal(vl, rvl)
     assert np.array_equal(s, rs)                       # caption token ids equal
@@ -156,3 +158,21 @@ def test_full_size_c5_properties(report):
         m = min(int(v1[b, 0]) - 1, ml)       # predictions for positions 1..m (an <eos> forced at max_length is no argmax)
         assert np.array_equal(logits[b, :m].argmax(-1), s1[b, 0, 1:m + 1])
     report["gnmt_c5_full_size_properties"] = True
+
+
+def test_teacher_forcing_lstm_cells():
+    """decode_seq with cell_type='lstm' (h and c carried from the encoder, gnmt.py:224-252) vs the oracle."""
+    from tennis_amd import weights as W
+    from tennis_amd.engine import GNMTCaptioner
+    B, T, F, H, E, V, L = 3, 11, 24, 16, 8, 30, 7
+    p = W.make_gnmt_weights(13, "lstm", F, H, E, V)
+    rng = np.random.default_rng(13)
+    src = (np.abs(rng.normal(0, 1, (B, T, F))) * 0.5).astype(np.float32)
+    svl = np.array([11, 6, 9], np.int32)
+    tgt = rng.integers(4, V, (B, L)).astype(np.int32)
+    cap = GNMTCaptioner(p, F, H, E, V, beam=2, max_length=10, max_batch=B, max_src_len=T, cell_type="lstm")
+    cap.encode(torch.from_numpy(src).cuda(), torch.from_numpy(svl).cuda())
+    logits = cap.decode_seq(torch.from_numpy(tgt).cuda()).cpu().numpy()
+    rmem, rstates = gn.encoder(src, svl, p, "lstm", H)
+    rl = gn.decode_seq(gn.Decoder(p, H, cell="lstm"), rmem, rstates, svl, tgt)
+    assert np.abs(logits - rl).max() < 1e-4
