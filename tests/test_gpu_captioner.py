@@ -48,13 +48,14 @@ def test_beam_search_matches_oracle(cfg, report):
     assert np.all(s[:, :, 0] == 2)
 
 
-def test_translator_surface():
+@pytest.mark.parametrize("cell", ["gru", "lstm"])
+def test_translator_surface(cell):
     """NMTModel + BeamSearchTranslator + ids -> tokens as in reference train_gnmt.py:287-300."""
     from tennis_amd.models.captioning.gnmt import NMTModel, Vocab, get_gnmt_encoder_decoder
     from tennis_amd.utils.translation import BeamSearchScorer, BeamSearchTranslator
     words = "the player serves near far left right a forehand backhand return in out".split()
     vocab = Vocab({w: i + 1 for i, w in enumerate(words)})
-    enc, dec = get_gnmt_encoder_decoder(cell_type="gru", hidden_size=32, dropout=0.2, num_layers=2, num_bi_layers=1)
+    enc, dec = get_gnmt_encoder_decoder(cell_type=cell, hidden_size=32, dropout=0.2, num_layers=2, num_bi_layers=1)
     model = NMTModel(src_vocab=None, tgt_vocab=vocab, encoder=enc, decoder=dec, embed_size=12, prefix="gnmt_",
                      input_size=48)
     model.initialize()
@@ -66,8 +67,8 @@ def test_translator_surface():
     sents = [[vocab.idx_to_token[e] for e in best[i][1:(vl0[i] - 1)]] for i in range(3)]
     assert len(sents) == 3 and all(isinstance(w, str) for s in sents for w in s)
     p = {k: v.data for k, v in model.collect_params().items()}
-    rmem, rstates = gn.encoder(src, np.array([9, 5, 7]), p, "gru", 32)
-    rs, _, rvl = gn.beam_search(gn.Decoder(p, 32), rmem, rstates, np.array([9, 5, 7]), 2, 3, 4, 1.0, 5, 20)
+    rmem, rstates = gn.encoder(src, np.array([9, 5, 7]), p, cell, 32)
+    rs, _, rvl = gn.beam_search(gn.Decoder(p, 32, cell=cell), rmem, rstates, np.array([9, 5, 7]), 2, 3, 4, 1.0, 5, 20)
     assert sents == gn.ids_to_sentences(rs, rvl, vocab.idx_to_token)
 
 
