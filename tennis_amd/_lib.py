@@ -57,7 +57,7 @@ _SIGS = {
     "tn_birnn_destroy": (C.c_int, [_P]),
     "tn_temporal_pool": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "tn_prf1_update": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
-    "tn_head_create": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(TnParam), C.c_int, C.c_char_p, C.c_char_p, C.c_int,
+    "tn_head_create": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(TnParam), C.c_int, C.c_char_p, C.c_char_p, C.c_int,
                                  C.c_int, C.POINTER(_P)]),
     "tn_head_forward_backward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P]),
     "tn_head_buffers": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64)]),

@@ -635,10 +635,11 @@ struct tn_head {
   tn_ctx *ctx;
   DevPool pool;
   int F, H, C, maxB, maxT;
+  int G;                           // gates per cell: 3 GRU, 4 LSTM
   long n;                          // parameters in the flat buffers
   long o_wi, o_bi, o_wh, o_bh, o_wd, o_bd;
   float *w, *g, *mom;              // [n] parameters, gradients, momentum
-  float *whT;                      // [2][H][3H] transposed h2h for the forward recurrence
+  float *whT;                      // [2][H][G*H] transposed h2h for the forward recurrence
   float *gi, *seq, *gates, *pooled, *dlog, *dpool, *dseq, *dgi, *dgh, *hprev, *logits, *loss;
   int32_t *arg;
   std::string rnn_prefix, dense_prefix;
@@ -646,24 +647,26 @@ struct tn_head {
 
 static int head_refresh_whT(tn_head *h) {
   for (int d = 0; d < 2; ++d) {
-    const int rc = launch_transpose_f32(h->w + h->o_wh + (long)d * 3 * h->H * h->H, 3 * h->H, h->H,
-                                        h->whT + (long)d * h->H * 3 * h->H, h->ctx->stream);
+    const int rc = launch_transpose_f32(h->w + h->o_wh + (long)d * h->G * h->H * h->H, h->G * h->H, h->H,
+                                        h->whT + (long)d * h->H * h->G * h->H, h->ctx->stream);
     if (rc) return rc;
   }
   return TN_OK;
 }
 
-extern "C" int tn_head_create(tn_ctx *ctx, int input_size, int hidden, int classes, const tn_param *params,
+extern "C" int tn_head_create(tn_ctx *ctx, tn_rnn_kind kind, int input_size, int hidden, int classes, const tn_param *params,
                               int n_params, const char *rnn_prefix, const char *dense_prefix, int max_batch,
                               int max_steps, tn_head **out) {
   TN_REQUIRE(ctx && params && rnn_prefix && dense_prefix && out, "tn_head_create: null argument");
-  TN_REQUIRE(input_size > 0 && hidden > 0 && hidden % 4 == 0 && 3 * hidden <= 1024 && classes > 0 && max_batch > 0 &&
-                 max_steps > 0, "tn_head_create: bad shape");
+  TN_REQUIRE(kind == TN_RNN_GRU || kind == TN_RNN_LSTM, "tn_head_create: type must be 'gru' or 'lstm'");
+  const int G = kind == TN_RNN_GRU ? 3 : 4;
+  TN_REQUIRE(input_size > 0 && hidden > 0 && hidden % 4 == 0 && G * hidden <= 1024 && classes > 0 && max_batch > 0 &&
+                 max_steps > 0, "tn_head_create: bad shape (gates*hidden must be <= 1024, hidden % 4 == 0)");
   TN_HIP_CHECK(hipSetDevice(ctx->device));
   ParamMap pm(params, n_params);
-  const int F = input_size, H = hidden, C = classes, GH = 3 * hidden;
+  const int F = input_size, H = hidden, C = classes, GH = G * hidden;
   tn_head *h = new tn_head();
-  h->ctx = ctx; h->F = F; h->H = H; h->C = C; h->maxB = max_batch; h->maxT = max_steps;
+  h->ctx = ctx; h->G = G; h->F = F; h->H = H; h->C = C; h->maxB = max_batch; h->maxT = max_steps;
   h->rnn_prefix = rnn_prefix; h->dense_prefix = dense_prefix;
   h->o_wi = 0; h->o_bi = h->o_wi + 2L * GH * F; h->o_wh = h->o_bi + 2L * GH; h->o_bh = h->o_wh + 2L * GH * H;
   h->o_wd = h->o_bh + 2L * GH; h->o_bd = h->o_wd + (long)C * 2 * H; h->n = h->o_bd + C;
@@ -687,7 +690,7 @@ extern "C" int tn_head_create(tn_ctx *ctx, int input_size, int hidden, int class
   const size_t rows = (size_t)max_batch * max_steps;
   auto fl = [&](size_t n) { return (float *)h->pool.alloc(n * sizeof(float)); };
   h->g = fl(h->n); h->mom = fl(h->n); h->whT = fl(2L * H * GH);
-  h->gi = fl(rows * 2 * GH); h->seq = fl(rows * 2 * H); h->gates = fl(2 * rows * 4 * H);
+  h->gi = fl(rows * 2 * GH); h->seq = fl(rows * 2 * H); h->gates = fl(2 * rows * (G + 1) * H);
   h->pooled = fl((size_t)max_batch * 2 * H); h->dlog = fl((size_t)max_batch * C); h->dpool = fl((size_t)max_batch * 2 * H);
   h->dseq = fl(rows * 2 * H); h->dgi = fl(rows * 2 * GH); h->dgh = fl(rows * 2 * GH); h->hprev = fl(2 * rows * H);
   h->logits = fl((size_t)max_batch * C); h->loss = fl(max_batch);
@@ -707,26 +710,30 @@ extern "C" int tn_head_forward_backward(tn_head *h, const float *x, const int32_
   TN_REQUIRE(B > 0 && B <= h->maxB && T > 0 && T <= h->maxT, "tn_head_forward_backward: batch / steps exceed the maxima");
   TN_HIP_CHECK(hipSetDevice(h->ctx->device));
   hipStream_t s = h->ctx->stream;
-  const int F = h->F, H = h->H, C = h->C, GH = 3 * h->H, M = B * T;
+  const int F = h->F, H = h->H, C = h->C, GH = h->G * h->H, M = B * T;
+  const bool lstm = h->G == 4;
   float *w = h->w, *g = h->g;
   int rc;
 #define TN_TRY(e) do { rc = (e); if (rc) return rc; } while (0)
   // forward: one i2h GEMM for both directions, recurrence with saved gates, max over T (argmax kept), Dense
   TN_TRY(launch_linear_f32(x, F, w + h->o_wi, F, w + h->o_bi, h->gi, 2 * GH, M, 2 * GH, F, 0, s));
-  TN_TRY(launch_gru_train_fwd(h->gi, h->whT, w + h->o_bh, h->seq, h->gates, B, T, H, s));
+  if (lstm) TN_TRY(launch_lstm_train_fwd(h->gi, h->whT, w + h->o_bh, h->seq, h->gates, B, T, H, s));
+  else TN_TRY(launch_gru_train_fwd(h->gi, h->whT, w + h->o_bh, h->seq, h->gates, B, T, H, s));
   TN_TRY(launch_pool_max_arg(h->seq, B, T, 2 * H, h->pooled, h->arg, s));
   TN_TRY(launch_linear_f32(h->pooled, 2 * H, w + h->o_wd, 2 * H, w + h->o_bd, h->logits, C, B, C, 2 * H, 0, s));
   TN_TRY(launch_softmax_ce(h->logits, labels, B, C, h->loss, h->dlog, s));
   // backward
   TN_TRY(launch_dense_bwd(h->dlog, h->pooled, w + h->o_wd, B, C, 2 * H, g + h->o_wd, g + h->o_bd, h->dpool, s));
   TN_TRY(launch_scatter_pool_grad(h->dpool, h->arg, B, T, 2 * H, h->dseq, s));
-  TN_TRY(launch_gru_train_bwd(h->seq, h->gates, h->dseq, w + h->o_wh, h->dgi, h->dgh, h->hprev, B, T, H, s));
+  if (lstm) TN_TRY(launch_lstm_train_bwd(h->seq, h->gates, h->dseq, w + h->o_wh, h->dgi, h->hprev, B, T, H, s));
+  else TN_TRY(launch_gru_train_bwd(h->seq, h->gates, h->dseq, w + h->o_wh, h->dgi, h->dgh, h->hprev, B, T, H, s));
+  const float *dgh = lstm ? h->dgi : h->dgh;   // LSTM: one pre-activation gradient feeds both branches
   TN_TRY(launch_gemm_tn_f32(h->dgi, 2 * GH, x, F, g + h->o_wi, F, 2 * GH, F, M, s));      // dW_ih = dGI^T X
   TN_TRY(launch_colsum_f32(h->dgi, 2 * GH, M, 2 * GH, g + h->o_bi, s));
   for (int d = 0; d < 2; ++d)                                                              // dW_hh = dGH^T H_prev
-    TN_TRY(launch_gemm_tn_f32(h->dgh + d * GH, 2 * GH, h->hprev + (long)d * M * H, H, g + h->o_wh + (long)d * GH * H, H,
+    TN_TRY(launch_gemm_tn_f32(dgh + d * GH, 2 * GH, h->hprev + (long)d * M * H, H, g + h->o_wh + (long)d * GH * H, H,
                               GH, H, M, s));
-  TN_TRY(launch_colsum_f32(h->dgh, 2 * GH, M, 2 * GH, g + h->o_bh, s));
+  TN_TRY(launch_colsum_f32(dgh, 2 * GH, M, 2 * GH, g + h->o_bh, s));
 #undef TN_TRY
   if (loss) TN_HIP_CHECK(hipMemcpyAsync(loss, h->loss, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
   if (logits) TN_HIP_CHECK(hipMemcpyAsync(logits, h->logits, sizeof(float) * B * C, hipMemcpyDeviceToDevice, s));
@@ -753,7 +760,7 @@ extern "C" int tn_head_read_param(tn_head *h, const char *name_c, int gradient, 
                                   int64_t *numel) {
   TN_REQUIRE(h && name_c && out_host && numel, "tn_head_read_param: null argument");
   const std::string name(name_c);
-  const long GH = 3L * h->H;
+  const long GH = (long)h->G * h->H;
   long off = -1, cnt = 0;
   for (int d = 0; d < 2; ++d) {
     const std::string dp = h->rnn_prefix + (d == 0 ? "l0_" : "r0_");

@@ -13,6 +13,10 @@ int launch_dense_bwd(const float *dlogits, const float *pooled, const float *wd,
 int launch_scatter_pool_grad(const float *dpooled, const int32_t *arg, int B, int T, int F, float *dseq, hipStream_t s);
 int launch_gru_train_bwd(const float *seq, const float *gates, const float *dseq, const float *wh, float *dgi,
                          float *dgh, float *hprev, int B, int T, int H, hipStream_t s);
+int launch_lstm_train_fwd(const float *gi, const float *whT, const float *bh, float *seq, float *gates, int B, int T,
+                          int H, hipStream_t s);
+int launch_lstm_train_bwd(const float *seq, const float *gates, const float *dseq, const float *wh, float *dgi,
+                          float *hprev, int B, int T, int H, hipStream_t s);
 int launch_gemm_tn_f32(const float *A, int lda, const float *Bm, int ldb, float *Cm, int ldc, int M, int N, int K,
                        hipStream_t s);
 int launch_colsum_f32(const float *A, int lda, int rows, int cols, float *out, hipStream_t s);

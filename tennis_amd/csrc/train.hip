@@ -204,6 +204,142 @@ __global__ void gru_train_bwd_kernel(const float *__restrict__ seq, const float 
   }
 }
 
+// ---- LSTM (gate order [i, f, g, o], mx.gluon.rnn.LSTM) ----------------------------------------------------------
+// gates buffer: [dir][B*T][5H] = i | f | g | o | c_t
+__global__ void lstm_train_fwd_kernel(const float *__restrict__ gi,    // [B*T][2*4H]  x W_ih^T + b_ih, both directions
+                                      const float *__restrict__ whT,   // [2][H][4H]
+                                      const float *__restrict__ bh,    // [2][4H]
+                                      float *__restrict__ seq,         // [B*T][2H]
+                                      float *__restrict__ gates, int B, int T, int H) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int GH = 4 * H;
+  float *hs = lds;             // [NB][H]
+  float *cs = hs + NB * H;     // [NB][H]
+  float *gh = cs + NB * H;     // [NB][4H]
+  const int j = threadIdx.x, dir = blockIdx.y, b0 = blockIdx.x * NB;
+  const float *wcol = whT + (long)dir * H * GH + j;
+  const float bj = bh[dir * GH + j];
+  for (int i = j; i < NB * H; i += GH) { hs[i] = 0.f; cs[i] = 0.f; }
+  __syncthreads();
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? T - 1 - s : s;
+    float acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = bj;
+    for (int k = 0; k < H; k += 4) {
+      const float w0 = wcol[(long)(k + 0) * GH], w1 = wcol[(long)(k + 1) * GH];
+      const float w2 = wcol[(long)(k + 2) * GH], w3 = wcol[(long)(k + 3) * GH];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float4 hv = *(const float4 *)(hs + b * H + k);
+        acc[b] = fmaf(w0, hv.x, acc[b]);
+        acc[b] = fmaf(w1, hv.y, acc[b]);
+        acc[b] = fmaf(w2, hv.z, acc[b]);
+        acc[b] = fmaf(w3, hv.w, acc[b]);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) gh[b * GH + j] = acc[b];
+    __syncthreads();
+    for (int idx = j; idx < NB * H; idx += GH) {
+      const int b = idx / H, u = idx - b * H, bg = b0 + b;
+      if (bg >= B) continue;
+      const long row = (long)bg * T + t;
+      const float *g = gi + row * (2 * GH) + dir * GH;
+      const float *q = gh + b * GH;
+      const float ig = sigm(g[u] + q[u]);
+      const float fg = sigm(g[H + u] + q[H + u]);
+      const float gg = tanhf(g[2 * H + u] + q[2 * H + u]);
+      const float og = sigm(g[3 * H + u] + q[3 * H + u]);
+      const float c2 = fg * cs[idx] + ig * gg;
+      const float hn = og * tanhf(c2);
+      float *sv = gates + ((long)dir * B * T + row) * (5 * H);
+      sv[u] = ig; sv[H + u] = fg; sv[2 * H + u] = gg; sv[3 * H + u] = og; sv[4 * H + u] = c2;
+      cs[idx] = c2;
+      hs[idx] = hn;
+      seq[row * (2 * H) + dir * H + u] = hn;
+    }
+    __syncthreads();
+  }
+}
+
+// BPTT of one LSTM direction for NB batch rows: thread j = (gate block g of 4, unit u).  The pre-activation
+// gradient is the same for the i2h and the h2h branch, so only dgi is written (the caller uses it for both).
+__global__ void lstm_train_bwd_kernel(const float *__restrict__ seq, const float *__restrict__ gates,
+                                      const float *__restrict__ dseq, const float *__restrict__ wh,   // [2][4H][H]
+                                      float *__restrict__ dgi,                                        // [B*T][2*4H]
+                                      float *__restrict__ hprev,                                      // [2][B*T][H]
+                                      int B, int T, int H) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int GH = 4 * H;
+  float *dh = lds;                  // [NB][H]   gradient flowing into h_t from the later step
+  float *dc = dh + NB * H;          // [NB][H]   ... into c_t
+  float *dgs = dc + NB * H;         // [NB][4H]  this step's pre-activation gradients
+  float *part = dgs + NB * GH;      // [NB][4][H]
+  const int j = threadIdx.x, dir = blockIdx.y, b0 = blockIdx.x * NB;
+  const int g = j / H, u = j - g * H;
+  const float *wrow = wh + (long)dir * GH * H + (long)g * H * H + u;   // W_hh[g*H + jj][u], jj = 0..H-1
+  for (int i = j; i < NB * H; i += GH) { dh[i] = 0.f; dc[i] = 0.f; }
+  __syncthreads();
+  for (int s = T - 1; s >= 0; --s) {
+    const int t = dir ? T - 1 - s : s;
+    const int tp = dir ? t + 1 : t - 1;
+    for (int idx = j; idx < NB * H; idx += GH) {
+      const int b = idx / H, uu = idx - b * H, bg = b0 + b;
+      float d_i = 0.f, d_f = 0.f, d_g = 0.f, d_o = 0.f, dcp = 0.f;
+      if (bg < B) {
+        const long row = (long)bg * T + t;
+        const float *sv = gates + ((long)dir * B * T + row) * (5 * H);
+        const float ig = sv[uu], fg = sv[H + uu], gg = sv[2 * H + uu], og = sv[3 * H + uu], c2 = sv[4 * H + uu];
+        float hp = 0.f, cp = 0.f;
+        if (s > 0) {
+          const long rp = (long)bg * T + tp;
+          hp = seq[rp * (2 * H) + dir * H + uu];
+          cp = gates[((long)dir * B * T + rp) * (5 * H) + 4 * H + uu];
+        }
+        const float tc = tanhf(c2);
+        const float dht = dh[idx] + dseq[row * (2 * H) + dir * H + uu];
+        const float dct = dc[idx] + dht * og * (1.f - tc * tc);
+        d_o = dht * tc * og * (1.f - og);
+        d_i = dct * gg * ig * (1.f - ig);
+        d_f = dct * cp * fg * (1.f - fg);
+        d_g = dct * ig * (1.f - gg * gg);
+        dcp = dct * fg;
+        float *o1 = dgi + row * (2 * GH) + dir * GH;
+        o1[uu] = d_i; o1[H + uu] = d_f; o1[2 * H + uu] = d_g; o1[3 * H + uu] = d_o;
+        hprev[((long)dir * B * T + row) * H + uu] = hp;
+      }
+      dgs[b * GH + uu] = d_i; dgs[b * GH + H + uu] = d_f; dgs[b * GH + 2 * H + uu] = d_g; dgs[b * GH + 3 * H + uu] = d_o;
+      dc[idx] = dcp;
+    }
+    __syncthreads();
+    float acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+    for (int jj = 0; jj < H; jj += 4) {
+      const float w0 = wrow[(long)(jj + 0) * H], w1 = wrow[(long)(jj + 1) * H];
+      const float w2 = wrow[(long)(jj + 2) * H], w3 = wrow[(long)(jj + 3) * H];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float4 dv = *(const float4 *)(dgs + b * GH + g * H + jj);
+        acc[b] = fmaf(w0, dv.x, acc[b]);
+        acc[b] = fmaf(w1, dv.y, acc[b]);
+        acc[b] = fmaf(w2, dv.z, acc[b]);
+        acc[b] = fmaf(w3, dv.w, acc[b]);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) part[(b * 4 + g) * H + u] = acc[b];
+    __syncthreads();
+    for (int idx = j; idx < NB * H; idx += GH) {
+      const int b = idx / H, uu = idx - b * H;
+      dh[idx] = part[(b * 4 + 0) * H + uu] + part[(b * 4 + 1) * H + uu] + part[(b * 4 + 2) * H + uu] +
+                part[(b * 4 + 3) * H + uu];
+    }
+    __syncthreads();
+  }
+}
+
 // C[M][N] = A^T B, A [K][lda] (M columns), B [K][ldb] (N columns); 64x64 tile, 256 threads x 4x4 outputs
 __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const float *__restrict__ A, int lda,
                                                           const float *__restrict__ Bm, int ldb,
@@ -301,6 +437,19 @@ int launch_gru_train_bwd(const float *seq, const float *gates, const float *dseq
                          float *dgh, float *hprev, int B, int T, int H, hipStream_t s) {
   hipLaunchKernelGGL(gru_train_bwd_kernel, dim3((B + NB - 1) / NB, 2), dim3(3 * H),
                      (size_t)(NB * H + NB * 3 * H + NB * 3 * H) * 4, s, seq, gates, dseq, wh, dgi, dgh, hprev, B, T, H);
+  TN_LAUNCH_CHECK();
+}
+int launch_lstm_train_fwd(const float *gi, const float *whT, const float *bh, float *seq, float *gates, int B, int T,
+                          int H, hipStream_t s) {
+  TN_REQUIRE(4 * H <= 1024 && H % 4 == 0, "lstm_train: 4*hidden must be <= 1024 and hidden % 4 == 0");
+  hipLaunchKernelGGL(lstm_train_fwd_kernel, dim3((B + NB - 1) / NB, 2), dim3(4 * H), (size_t)(2 * NB * H + NB * 4 * H) * 4,
+                     s, gi, whT, bh, seq, gates, B, T, H);
+  TN_LAUNCH_CHECK();
+}
+int launch_lstm_train_bwd(const float *seq, const float *gates, const float *dseq, const float *wh, float *dgi,
+                          float *hprev, int B, int T, int H, hipStream_t s) {
+  hipLaunchKernelGGL(lstm_train_bwd_kernel, dim3((B + NB - 1) / NB, 2), dim3(4 * H),
+                     (size_t)(2 * NB * H + NB * 4 * H + NB * 4 * H) * 4, s, seq, gates, dseq, wh, dgi, hprev, B, T, H);
   TN_LAUNCH_CHECK();
 }
 int launch_gemm_tn_f32(const float *A, int lda, const float *Bm, int ldb, float *Cm, int ldc, int M, int N, int K,

@@ -250,7 +250,7 @@ def masked_softmax_ce(logits: torch.Tensor, labels: torch.Tensor, valid_length: 
 
 
 class TemporalHeadTrainer:
-    """Training step of ``CNNRNN(model=None, type='gru')`` in feature mode (reference definitions.py:94-110) the way
+    """Training step of ``CNNRNN(model=None, type='gru' | 'lstm')`` in feature mode (reference definitions.py:94-110) the way
     train.py drives it: ``SoftmaxCrossEntropyLoss`` per sample (:324), ``ag.backward`` of the per-sample losses and
     ``gluon.Trainer(params, 'sgd', {learning_rate, momentum, wd}).step(batch_size)`` (:298-299, :410-424).
 
@@ -259,15 +259,20 @@ class TemporalHeadTrainer:
     before ``step(batch_size)``, whose ``rescale_grad = 1 / batch_size`` is Gluon's."""
 
     def __init__(self, params: dict, input_size: int, hidden: int = 128, classes: int = 11, max_batch: int = 32,
-                 max_steps: int = 64, rnn_prefix: str = "cnnrnn0_gru0_", dense_prefix: str = "cnnrnn0_dense0_",
-                 ctx: _lib.Context | None = None):
+                 max_steps: int = 64, rnn_prefix: str | None = None, dense_prefix: str = "cnnrnn0_dense0_",
+                 ctx: _lib.Context | None = None, type: str = "gru"):
+        if type not in ("gru", "lstm"):
+            raise ValueError(f"type must be 'gru' or 'lstm', got {type!r}")
+        if rnn_prefix is None:
+            rnn_prefix = f"cnnrnn0_{type}0_"
+        self.type, self.gates = type, 3 if type == "gru" else 4
         self.ctx = ctx or _lib.default_context()
         self.lib = self.ctx.lib
         self.input_size, self.hidden, self.classes = input_size, hidden, classes
         self.rnn_prefix, self.dense_prefix = rnn_prefix, dense_prefix
         arr, keep = _lib.make_params({k: v for k, v in params.items() if k.startswith(rnn_prefix) or k.startswith(dense_prefix)})
         h = C.c_void_p()
-        check(self.lib.tn_head_create(self.ctx.handle, input_size, hidden, classes, arr, len(arr), rnn_prefix.encode(),
+        check(self.lib.tn_head_create(self.ctx.handle, _lib.RNN_GRU if type == "gru" else _lib.RNN_LSTM, input_size, hidden, classes, arr, len(arr), rnn_prefix.encode(),
                                       dense_prefix.encode(), max_batch, max_steps, C.byref(h)), "tn_head_create")
         del keep
         self.handle = h
@@ -304,7 +309,7 @@ class TemporalHeadTrainer:
         check(self.lib.tn_head_sgd_step(self.handle, lr, momentum, wd, 1.0 / batch_size), "tn_head_sgd_step")
 
     def get(self, name: str, gradient: bool = False) -> np.ndarray:
-        cap = 3 * self.hidden * max(self.input_size, self.hidden, 2 * self.classes) + 16
+        cap = self.gates * self.hidden * max(self.input_size, self.hidden, 2 * self.classes) + 16
         out = np.empty(cap, np.float32)
         n = C.c_int64()
         check(self.lib.tn_head_read_param(self.handle, name.encode(), 1 if gradient else 0,
@@ -315,8 +320,8 @@ class TemporalHeadTrainer:
         h, f, c = self.hidden, self.input_size, self.classes
         out = {}
         for d in ("l0_", "r0_"):
-            out[self.rnn_prefix + d + "i2h_weight"] = self.get(self.rnn_prefix + d + "i2h_weight").reshape(3 * h, f)
-            out[self.rnn_prefix + d + "h2h_weight"] = self.get(self.rnn_prefix + d + "h2h_weight").reshape(3 * h, h)
+            out[self.rnn_prefix + d + "i2h_weight"] = self.get(self.rnn_prefix + d + "i2h_weight").reshape(self.gates * h, f)
+            out[self.rnn_prefix + d + "h2h_weight"] = self.get(self.rnn_prefix + d + "h2h_weight").reshape(self.gates * h, h)
             out[self.rnn_prefix + d + "i2h_bias"] = self.get(self.rnn_prefix + d + "i2h_bias")
             out[self.rnn_prefix + d + "h2h_bias"] = self.get(self.rnn_prefix + d + "h2h_bias")
         out[self.dense_prefix + "weight"] = self.get(self.dense_prefix + "weight").reshape(c, 2 * h)

@@ -312,26 +312,28 @@ def test_mxnet_params_container_round_trip(tmp_path):
     assert set(got) == set(p) and all(np.array_equal(got[k], p[k]) for k in p)
 
 
-def test_train_oracle_matches_torch_autograd():
-    """oracle/train_np.py (bi-GRU -> max over T -> Dense -> softmax CE, gradient of the summed loss) against torch
-    autograd on the CPU: nn.GRU(bidirectional, batch_first) has the same gate order and equations."""
+@pytest.mark.parametrize("cell", ["gru", "lstm"])
+def test_train_oracle_matches_torch_autograd(cell):
+    """oracle/train_np.py (bi-GRU | bi-LSTM -> max over T -> Dense -> softmax CE, gradient of the summed loss) against
+    torch autograd on the CPU: nn.GRU / nn.LSTM (bidirectional, batch_first) have the same gate order and equations."""
     from oracle import train_np as tn
     from tennis_amd import weights as W
     B, T, F, H, C_ = 3, 5, 12, 8, 11
-    p = W.make_rnn_weights(2, "gru", F, H, "cnnrnn0_gru0_")
+    pre = f"cnnrnn0_{cell}0_"
+    p = W.make_rnn_weights(2, cell, F, H, pre)
     p.update(W.make_dense_weights(3, C_, 2 * H, "cnnrnn0_dense0_"))
     rng = np.random.default_rng(1)
     x = rng.normal(0, 1, (B, T, F)).astype(np.float32)
     y = rng.integers(0, C_, B)
-    loss, logits, g = tn.forward_backward(x, y, p)
-    gru = torch.nn.GRU(F, H, batch_first=True, bidirectional=True).double()
+    loss, logits, g = tn.forward_backward(x, y, p, cell=cell)
+    gru = (torch.nn.GRU if cell == "gru" else torch.nn.LSTM)(F, H, batch_first=True, bidirectional=True).double()
     fc = torch.nn.Linear(2 * H, C_).double()
     with torch.no_grad():
         for d, suf in (("l0_", ""), ("r0_", "_reverse")):
-            getattr(gru, "weight_ih_l0" + suf).copy_(torch.from_numpy(p["cnnrnn0_gru0_" + d + "i2h_weight"]))
-            getattr(gru, "weight_hh_l0" + suf).copy_(torch.from_numpy(p["cnnrnn0_gru0_" + d + "h2h_weight"]))
-            getattr(gru, "bias_ih_l0" + suf).copy_(torch.from_numpy(p["cnnrnn0_gru0_" + d + "i2h_bias"]))
-            getattr(gru, "bias_hh_l0" + suf).copy_(torch.from_numpy(p["cnnrnn0_gru0_" + d + "h2h_bias"]))
+            getattr(gru, "weight_ih_l0" + suf).copy_(torch.from_numpy(p[pre + d + "i2h_weight"]))
+            getattr(gru, "weight_hh_l0" + suf).copy_(torch.from_numpy(p[pre + d + "h2h_weight"]))
+            getattr(gru, "bias_ih_l0" + suf).copy_(torch.from_numpy(p[pre + d + "i2h_bias"]))
+            getattr(gru, "bias_hh_l0" + suf).copy_(torch.from_numpy(p[pre + d + "h2h_bias"]))
         fc.weight.copy_(torch.from_numpy(p["cnnrnn0_dense0_weight"])); fc.bias.copy_(torch.from_numpy(p["cnnrnn0_dense0_bias"]))
     out, _ = gru(torch.from_numpy(x).double())
     lg = fc(out.max(dim=1).values)
@@ -339,9 +341,9 @@ def test_train_oracle_matches_torch_autograd():
     ls.sum().backward()
     assert np.allclose(loss, ls.detach().numpy(), atol=1e-10) and np.allclose(logits, lg.detach().numpy(), atol=1e-10)
     for d, suf in (("l0_", ""), ("r0_", "_reverse")):
-        assert np.allclose(g["cnnrnn0_gru0_" + d + "i2h_weight"], getattr(gru, "weight_ih_l0" + suf).grad.numpy(), atol=1e-9)
-        assert np.allclose(g["cnnrnn0_gru0_" + d + "h2h_weight"], getattr(gru, "weight_hh_l0" + suf).grad.numpy(), atol=1e-9)
-        assert np.allclose(g["cnnrnn0_gru0_" + d + "i2h_bias"], getattr(gru, "bias_ih_l0" + suf).grad.numpy(), atol=1e-9)
-        assert np.allclose(g["cnnrnn0_gru0_" + d + "h2h_bias"], getattr(gru, "bias_hh_l0" + suf).grad.numpy(), atol=1e-9)
+        assert np.allclose(g[pre + d + "i2h_weight"], getattr(gru, "weight_ih_l0" + suf).grad.numpy(), atol=1e-9)
+        assert np.allclose(g[pre + d + "h2h_weight"], getattr(gru, "weight_hh_l0" + suf).grad.numpy(), atol=1e-9)
+        assert np.allclose(g[pre + d + "i2h_bias"], getattr(gru, "bias_ih_l0" + suf).grad.numpy(), atol=1e-9)
+        assert np.allclose(g[pre + d + "h2h_bias"], getattr(gru, "bias_hh_l0" + suf).grad.numpy(), atol=1e-9)
     assert np.allclose(g["cnnrnn0_dense0_weight"], fc.weight.grad.numpy(), atol=1e-9)
     assert np.allclose(g["cnnrnn0_dense0_bias"], fc.bias.grad.numpy(), atol=1e-9)

@@ -1,4 +1,4 @@
-"""-m gpu: training step of the temporal head (bi-GRU -> max over T -> Dense -> softmax CE, SGD momentum + wd)
+"""-m gpu: training step of the temporal head (bi-GRU | bi-LSTM -> max over T -> Dense -> softmax CE, SGD momentum + wd)
 through the C ABI vs oracle/train_np.py (itself pinned to torch autograd on the CPU)."""
 import numpy as np
 import pytest
@@ -9,9 +9,9 @@ from oracle import train_np as tn
 pytestmark = pytest.mark.gpu
 
 
-def _setup(seed, B, T, F, H, C_):
+def _setup(seed, B, T, F, H, C_, cell="gru"):
     from tennis_amd import weights as W
-    p = W.make_rnn_weights(seed, "gru", F, H, "cnnrnn0_gru0_")
+    p = W.make_rnn_weights(seed, cell, F, H, f"cnnrnn0_{cell}0_")
     p.update(W.make_dense_weights(seed + 1, C_, 2 * H, "cnnrnn0_dense0_"))
     rng = np.random.default_rng(seed)
     x = (np.abs(rng.normal(0, 1, (B, T, F))) * 0.5).astype(np.float32)
@@ -19,14 +19,15 @@ def _setup(seed, B, T, F, H, C_):
     return p, x, y
 
 
+@pytest.mark.parametrize("cell", ["gru", "lstm"])
 @pytest.mark.parametrize("B,T,F,H", [(3, 5, 24, 8), (6, 9, 64, 32), (32, 64, 1024, 128)])   # last: BASELINE config C3
-def test_gradients_and_sgd_step(report, B, T, F, H):
+def test_gradients_and_sgd_step(report, B, T, F, H, cell):
     from tennis_amd.engine import TemporalHeadTrainer
     C_ = 11
-    p, x, y = _setup(4, B, T, F, H, C_)
-    tr = TemporalHeadTrainer(p, F, H, C_, max_batch=B, max_steps=T)
+    p, x, y = _setup(4, B, T, F, H, C_, cell)
+    tr = TemporalHeadTrainer(p, F, H, C_, max_batch=B, max_steps=T, type=cell)
     loss, logits = tr.forward_backward(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda())
-    rl, rlg, rg = tn.forward_backward(x, y, p)
+    rl, rlg, rg = tn.forward_backward(x, y, p, cell=cell)
     assert np.abs(loss.cpu().numpy() - rl).max() < 1e-4 and np.abs(logits.cpu().numpy() - rlg).max() < 1e-4
     worst = 0.0
     for k, g in rg.items():
@@ -34,7 +35,7 @@ def test_gradients_and_sgd_step(report, B, T, F, H):
         err = np.abs(got - g).max() / max(1e-6, np.abs(g).max())
         worst = max(worst, err)
         assert err < 2e-4, (k, err)
-    report[f"train_head_grad_rel_err_B{B}_T{T}_F{F}"] = float(worst)
+    report[f"train_head_{cell}_grad_rel_err_B{B}_T{T}_F{F}"] = float(worst)
     # one SGD step with Gluon's rescale 1/batch_size, momentum 0.9, wd 1e-4 (train.py flags), then a second one
     lr, mo, wd = 1e-2, 0.9, 1e-4
     tr.step(B, lr, mo, wd)
@@ -43,7 +44,7 @@ def test_gradients_and_sgd_step(report, B, T, F, H):
     for k in p1:
         assert np.abs(st[k] - p1[k]).max() < 1e-5 * max(1.0, np.abs(p1[k]).max()), k
     tr.forward_backward(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda())
-    _, _, rg2 = tn.forward_backward(x, y, {k: v.astype(np.float32) for k, v in p1.items()})
+    _, _, rg2 = tn.forward_backward(x, y, {k: v.astype(np.float32) for k, v in p1.items()}, cell=cell)
     tr.step(B, lr, mo, wd)
     p2, _ = tn.sgd_momentum(p1, rg2, m1, lr, mo, wd, 1.0 / B)
     st = tr.state_dict()
@@ -51,16 +52,17 @@ def test_gradients_and_sgd_step(report, B, T, F, H):
         assert np.abs(st[k] - p2[k]).max() < 5e-5 * max(1.0, np.abs(p2[k]).max()), k
 
 
-def test_training_reduces_the_loss_and_grads_view():
-    """A few dozen steps on one fixed batch drive the summed loss down; the flat gradient view is what a
+@pytest.mark.parametrize("cell", ["gru", "lstm"])
+def test_training_reduces_the_loss_and_grads_view(cell):
+    """A hundred steps on one fixed batch drive the summed loss down; the flat gradient view is what a
     data-parallel all-reduce would operate on."""
     from tennis_amd.engine import TemporalHeadTrainer
     B, T, F, H, C_ = 16, 12, 48, 16, 11
-    p, x, y = _setup(7, B, T, F, H, C_)
-    tr = TemporalHeadTrainer(p, F, H, C_, max_batch=B, max_steps=T)
+    p, x, y = _setup(7, B, T, F, H, C_, cell)
+    tr = TemporalHeadTrainer(p, F, H, C_, max_batch=B, max_steps=T, type=cell)
     xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
     first = None
-    for i in range(60):
+    for i in range(120):     # (the fp64 oracle's curve: GRU 2.41 -> 0.05, LSTM 2.41 -> 0.82)
         loss, _ = tr.forward_backward(xd, yd)
         if first is None:
             first = float(loss.mean())
