@@ -127,6 +127,17 @@ int tn_birnn_forward(tn_birnn *r, const float *x, int batch, int steps, const in
                      float *seq, float *h_last, float *c_last);
 int tn_birnn_destroy(tn_birnn *r);
 
+/* ---- test transform, geometric half: Resize + CenterCrop on decoded frames ----- */
+/* Replaces transforms.Resize(data_shape + 32) + transforms.CenterCrop(data_shape) of the reference's
+ * transform_test (evaluate.py:93-96; gluon Resize -> mx.image.imresize interp=1 = cv::resize INTER_LINEAR on
+ * 8-bit RGB [EXT]; CenterCrop offset int((s - c) / 2)).  src (batch, src_h, src_w, 3) uint8 RGB, dst
+ * (batch, crop, crop, 3) uint8 = TN_LAYOUT_NHWC_U8 for tn_densenet121_forward, whose stem load applies
+ * ToTensor + Normalize (evaluate.py:96-97).  Both DEVICE buffers; bit-exact integer arithmetic. */
+typedef struct tn_preproc tn_preproc;
+int tn_preproc_create(tn_ctx *ctx, int src_h, int src_w, int resize, int crop, tn_preproc **out);
+int tn_preproc_forward(tn_preproc *p, const uint8_t *src, int batch, uint8_t *dst);
+int tn_preproc_destroy(tn_preproc *p);
+
 /* ---- F.max / F.mean over axis 1 ------------------------------------------ */
 /* Replaces reference models/vision/definitions.py:66-69,107.  x (B,T,F) -> y (B,F). */
 int tn_temporal_pool(tn_ctx *ctx, const float *x, int batch, int steps, int feat, tn_pool_kind kind,

@@ -1,6 +1,7 @@
 """Secondary stages of the path at the BASELINE.json configs (not the headline metric):
   C3  CNN features -> bi-GRU(128) -> max over T -> Dense(11): clip batch 32 x T=64 x F=1024
   C5  GNMT captioner on features: B=32 clips, T=214, F=1024, H=256, E=100, V=254, beam 5, max_len 150
+  input side: Resize(256)+CenterCrop(224) of 720p uint8 frames (tn_preproc_*)
 Prints one JSON object; inputs are synthetic and resident on the device."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -57,4 +58,11 @@ smp, sc, svl = c5()
 out["C5_gnmt"] = {"encode_ms": round(s_enc * 1e3, 2), "encode_plus_beam_ms": round(s_all * 1e3, 2),
                   "clips_per_s": round(B / s_all, 1), "steps_run": int(svl.max().item()) - 1,
                   "note": "random-init weights: beams rarely emit EOS, so this is the max_length=150 worst case"}
+# ---- input side: Resize(256) + CenterCrop(224) of 256 decoded 720p frames, resident in HBM ---------------------------
+from tennis_amd import transforms as TT
+tf = TT.Compose([TT.Resize(256), TT.CenterCrop(224), TT.ToTensor(), TT.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])
+fr = torch.randint(0, 256, (256, 720, 1280, 3), dtype=torch.uint8, device=dev)
+s = timed(lambda: tf(fr), 20)
+out["resize_crop_720p"] = {"ms_per_256_frames": round(s * 1e3, 3), "frames_per_s": round(256 / s, 1),
+                           "note": "4 source pixels per output pixel: 0.6 MB of the 2.76 MB frame are touched"}
 print(json.dumps(out))

@@ -55,6 +55,9 @@ _SIGS = {
                                   C.c_int, C.POINTER(_P)]),
     "tn_birnn_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
     "tn_birnn_destroy": (C.c_int, [_P]),
+    "tn_preproc_create": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "tn_preproc_forward": (C.c_int, [_P, _P, C.c_int, _P]),
+    "tn_preproc_destroy": (C.c_int, [_P]),
     "tn_temporal_pool": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "tn_prf1_update": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
     "tn_head_create": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(TnParam), C.c_int, C.c_char_p, C.c_char_p, C.c_int,

@@ -11,15 +11,25 @@ that ``save_feats=True`` adds per video (dataset.py:333-345) and the
 ``(img, label, idx)`` return with the same shapes: (3,H,W) / (T,3,H,W) float32
 frames or (F,) / (T,F) features loaded from ``.npy``.
 
-Not kept: JPEG decoding / split files / annotations (the 217 GB TenniSet frames
-are not available; SURVEY §8f-3 lists the real input side as 'next').  Frames are
-generated deterministically from (video, frame) so every rank and the oracle see
-the same pixels.
+Two sources.  ON DISK, used when ``<root>/splits/<split_id>/<split>.txt`` exists: the
+reference's layout (data/README.md) — split lines ``video frame``, per-video label files
+``annotations/labels/<video>.txt`` (``frame class``), JPEG frames under ``frames/<video>.mp4/<chunk>/<frame>.jpg``
+decoded on the host (the reference decodes on the host too: ``mx.image.imread``), events = runs of equal labels,
+video lengths from the frame directories, optional ``annotations/points.txt`` + ``captions.txt``, ``save_feats``
+padding and ``_balance_classes`` (dataset.py:268-287,300-452).  Frames missing on disk are ignored, as in the
+reference's second pass; extracting them from the ``.mp4`` is not done here.  SYNTHETIC otherwise (the 217 GB
+TenniSet frames are not available): frames are generated deterministically from (video, frame) so every rank and
+the oracle see the same pixels.
+
+A transform with ``device_batched = True`` (``tennis_amd.transforms.Compose``) is not applied per frame:
+``__getitem__`` returns the decoded uint8 frame and ``DataLoader`` runs the transform once per batch on the GPU.
 """
 from __future__ import annotations
 
+import logging
 import math
 import os
+import random
 import zlib
 
 import numpy as np
@@ -70,7 +80,21 @@ class TennisSet:
             self.feat_dir = os.path.join(root, "features", feats_model)
             self._load_feats = True
 
-        self.classes = list(CLASSES)
+        self.classes = self._get_classes(root)
+        self._splits_dir = os.path.join(root, "splits")
+        self._annotations_dir = os.path.join(root, "annotations")
+        self._labels_dir = os.path.join(root, "annotations", "labels")
+        self._events, self._points, self._videos = [], {}, list(videos)
+        self.on_disk = os.path.exists(os.path.join(self._splits_dir, split_id, split + ".txt"))
+        if self.on_disk:
+            self._samples, self._videos, self._events, self._points = self.load_data(split_id)
+            self._video_lengths = self._get_video_lengths()
+        else:
+            self._synthesise(videos, frames_per_video, split_first, video_length, every, save_feats, seed)
+        if self._balance and self.on_disk:                                 # dataset.py:74-75 (synthetic labels are uniform)
+            self._samples = self._balance_classes()
+
+    def _synthesise(self, videos, frames_per_video, split_first, video_length, every, save_feats, seed):
         vlen = video_length if video_length is not None else split_first + frames_per_video
         self._video_lengths = {v: vlen for v in videos}
         rng = np.random.default_rng(seed)
@@ -91,6 +115,100 @@ class TennisSet:
                         if 0 <= f < vlen:
                             pads.append([v, f, "OTH"])
         self._samples += pads
+
+    # ---- on-disk source (reference dataset.py:300-452) ------------------------------
+    @staticmethod
+    def _get_classes(root="data"):                                          # dataset.py:249-261
+        names_file = os.path.join(root, "classes.names")
+        if os.path.exists(names_file):
+            with open(names_file) as f:
+                return [line.strip() for line in f if line.strip()]
+        return list(CLASSES)
+
+    def load_data(self, split_id="01"):
+        """-> samples [[video, frame, class]], videos, events [[video, first, last, class]], points {id: [...]}"""
+        with open(os.path.join(self._splits_dir, split_id, self._split + ".txt")) as f:
+            samples = [[ln.split()[0], int(ln.split()[1])] for ln in f if ln.strip()]
+        videos = list({s[0] for s in samples})
+        labels = {v: {} for v in videos}
+        if self._save_feats:                                               # :333-345
+            for v in videos:
+                fr = [s[1] for s in samples if s[0] == v]
+                lo, hi = min(fr), max(fr)
+                for i in range(1, 256):
+                    samples += [[v, lo - i], [v, hi + i]]
+                    labels[v][lo - i] = labels[v][hi + i] = "OTH"
+        kept = []
+        for s in samples:                                                  # :347-372, second pass: ignore
+            if os.path.exists(self.get_image_path(self._frames_dir, s[0], s[1])):
+                kept.append(s)
+            else:
+                logging.info("%s does not exist, will ignore sample.", self.get_image_path(self._frames_dir, s[0], s[1]))
+        samples = kept
+        for v in videos:                                                   # :377-383 (the files override the padding's OTH)
+            with open(os.path.join(self._labels_dir, v + ".txt")) as f:
+                for ln in f:
+                    parts = ln.split()
+                    if parts:
+                        labels[v][int(parts[0])] = parts[1]
+        in_set = {v: [] for v in videos}
+        for s in samples:                                                  # :391-393
+            s.append(labels[s[0]][s[1]])
+            in_set[s[0]].append(s[1])
+        events = []
+        for v in in_set:                                                   # :396-409: runs of one class; the first run is
+            cur, start, last = "OTH", -1, -1                               # emitted as OTH even when it is empty
+            for fr in sorted(in_set[v]):
+                if start < 0:
+                    start = last = fr
+                if labels[v][fr] != cur:
+                    events.append([v, start, last, cur])
+                    cur, start = labels[v][fr], fr
+                last = fr
+            events.append([v, start, last, cur])
+        points = {}
+        pts_file, cap_file = (os.path.join(self._annotations_dir, n) for n in ("points.txt", "captions.txt"))
+        if os.path.exists(pts_file) and os.path.exists(cap_file):          # :411-433
+            with open(pts_file) as f:
+                pts = [ln.split() for ln in f if ln.strip()]
+            with open(cap_file) as f:
+                caps = dict(ln.rstrip("\n").split("\t")[:2] for ln in f if ln.strip())
+            for p in pts:
+                if p[1] in videos and int(p[2]) in in_set[p[1]]:
+                    points[p[0]] = p[1:] + [caps[p[0]]]
+        return samples, videos, events, points
+
+    def _get_video_lengths(self):                                          # :438-452: name of the last frame file
+        lengths = {}
+        for s in self._samples:
+            v = s[0]
+            if v not in lengths:
+                vdir = os.path.join(self._frames_dir, v + ".mp4")
+                largest_dir = sorted(os.listdir(vdir))[-1]
+                assert largest_dir.isdigit(), f"Expects the directory {vdir} to only contain numbered subdirs"
+                lengths[v] = int(sorted(os.listdir(os.path.join(vdir, largest_dir)))[-1][:-4])
+        return lengths
+
+    def _balance_classes(self):
+        """dataset.py:268-287: thin out 'OTH' to the size of the next most frequent class with uniform random
+        sampling (python's ``random``; seed it for a reproducible subset)."""
+        counts = self.class_counts()
+        ratio = max(counts[1:]) / float(counts[0] + 1)
+        return [s for s in self._samples if not (s[2] == "OTH" and random.uniform(0, 1) > ratio)]
+
+    def stats(self):                                                       # dataset.py:96-131, frame branch
+        frame_counts, event_counts = self.class_counts(), [0] * len(self.classes)
+        for e in self._events:
+            event_counts[self.classes.index(e[3])] += 1
+        out = "Split: {}\n".format(self._split)
+        out += "{0: <6} {1: <8} {2: <8} {3: <5}\n".format("Class", "# Frames", "# Events", "FperE")
+        for i, c in enumerate(self.classes):
+            out += "{0: <6} {1: <8} {2: <8} {3: <5}\n".format(c, frame_counts[i], event_counts[i],
+                                                              int(frame_counts[i] / (event_counts[i] + .00001)))
+        return out
+
+    def __str__(self):
+        return "\n\n" + self.__class__.__name__ + "\n" + self.stats() + "\n"
 
     # ---- reference helpers -------------------------------------------------
     def __len__(self):
@@ -124,14 +242,20 @@ class TennisSet:
 
     # ---- synthetic frame source ----------------------------------------------
     def frame_u8(self, video, frame) -> np.ndarray:
-        """HWC uint8 RGB 'decoded JPEG' for (video, frame), deterministic."""
+        """HWC uint8 RGB frame: the decoded JPEG (``mx.image.imread(path, 1)``, dataset.py:204,216) when the data
+        is on disk, else a deterministic synthetic frame."""
+        if self.on_disk:
+            from PIL import Image
+            with Image.open(self.get_image_path(self._frames_dir, video, frame)) as im:
+                return np.asarray(im.convert("RGB"))
         s = zlib.crc32(f"{video}:{frame}:{self._seed}".encode())
         return np.random.default_rng(s).integers(0, 256, (self._data_shape, self._data_shape, 3), dtype=np.uint8)
 
     def _load(self, video, frame):
         if self._load_feats:
             return np.load(self.get_feature_path(self.feat_dir, video, frame)).astype(np.float32)
-        return self._transform(self.frame_u8(video, frame))
+        img = self.frame_u8(video, frame)
+        return img if getattr(self._transform, "device_batched", False) else self._transform(img)
 
     def window_frames(self, sample):
         """Frame numbers a window sample reads (dataset.py:190-201)."""
@@ -168,5 +292,11 @@ class DataLoader:
         n = len(self.dataset)
         for s in range(0, n, self.batch_size):
             items = [self.dataset[i] for i in range(s, min(n, s + self.batch_size))]
+            tf = getattr(self.dataset, "_transform", None)
+            if getattr(tf, "device_batched", False) and not self.dataset._load_feats:
+                data = tf(np.stack([it[0] for it in items]))               # one Resize+CenterCrop launch per batch
+                yield (data, np.array([it[1] for it in items], dtype=np.float32),
+                       np.array([it[2] for it in items], dtype=np.int64))
+                continue
             yield (np.stack([it[0] for it in items]), np.array([it[1] for it in items], dtype=np.float32),
                    np.array([it[2] for it in items], dtype=np.int64))

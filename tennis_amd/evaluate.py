@@ -15,6 +15,7 @@ import time
 import numpy as np
 import torch
 
+from . import transforms
 from .dataset import DataLoader, TennisSet
 from .metrics.vision import PRF1
 from .model_zoo import get_model
@@ -80,7 +81,15 @@ def build_parser():
 def main(argv=None):
     flags = build_parser().parse_args(argv)
     every = [int(s) for s in flags.every.split(",")]
-    test_set = TennisSet(root=flags.root, split=flags.split, every=every[2], padding=flags.padding,
+    # evaluate.py:91-98: Resize(s + 32) / CenterCrop(s) / ToTensor / Normalize, here one GPU launch per batch; the
+    # synthetic source already produces data_shape frames, so only data on disk goes through it
+    transform_test = None
+    if flags.feats_model is None and os.path.exists(os.path.join(flags.root, "splits", flags.split_id, flags.split + ".txt")):
+        transform_test = transforms.Compose([transforms.Resize(flags.data_shape + 32),
+                                             transforms.CenterCrop(flags.data_shape),
+                                             transforms.ToTensor(),
+                                             transforms.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])
+    test_set = TennisSet(root=flags.root, transform=transform_test, split=flags.split, every=every[2], padding=flags.padding,
                          stride=flags.stride, window=flags.window, model_id=flags.model_id,
                          split_id=flags.split_id, balance=False, feats_model=flags.feats_model,
                          save_feats=flags.save_feats, data_shape=flags.data_shape,

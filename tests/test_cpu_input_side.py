@@ -1,0 +1,128 @@
+"""CPU: the input side of the path — the image oracle's properties and the on-disk TennisSet source
+(split files, label files, JPEG frames, events, save_feats padding, _balance_classes) on a tiny dataset written here."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import image_np as im
+
+
+def test_resize_oracle_properties():
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (72, 128, 3), dtype=np.uint8)
+    assert np.array_equal(im.resize_bilinear_u8(x, 72, 128), x)                       # identity
+    box = im.resize_bilinear_u8(x, 36, 64)                                           # exact 2x: 2x2 box average
+    a = x.astype(np.int64)
+    assert np.array_equal(box, ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2))
+    flat = np.full((50, 70, 3), 137, np.uint8)
+    assert np.all(im.resize_bilinear_u8(flat, 33, 91) == 137)                        # constants survive the fixed point
+    ramp = np.repeat(np.arange(0, 200, 2, dtype=np.uint8)[None, :, None], 10, axis=0).repeat(3, axis=2)
+    r = im.resize_bilinear_u8(ramp, 10, 37).astype(int)
+    assert np.all(np.diff(r[0, :, 0]) >= 0)                                          # monotone ramps stay monotone
+    out = im.test_transform_u8(rng.integers(0, 256, (720, 1280, 3), dtype=np.uint8), 224)
+    assert out.shape == (224, 224, 3) and out.dtype == np.uint8
+
+
+def test_resize_oracle_close_to_pillow_when_upscaling():
+    """Pillow's BILINEAR has no antialiasing support when enlarging and uses the same half-pixel centres: the two
+    fixed-point implementations agree within one grey level (a sanity anchor; OpenCV itself is absent)."""
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    x = rng.integers(0, 256, (45, 80, 3), dtype=np.uint8)
+    ours = im.resize_bilinear_u8(x, 144, 256).astype(int)
+    pil = np.asarray(Image.fromarray(x).resize((256, 144), Image.BILINEAR)).astype(int)
+    assert np.abs(ours - pil).max() <= 1
+
+
+def test_center_crop_offsets():
+    x = np.arange(256 * 256 * 3, dtype=np.uint32).reshape(256, 256, 3)
+    c = im.center_crop(x, 224)
+    assert c.shape == (224, 224, 3) and c[0, 0, 0] == x[16, 16, 0]
+    assert im.center_crop(np.zeros((101, 77, 3)), 50).shape == (50, 50, 3)           # int((w - new_w) / 2)
+
+
+def _write_dataset(root, rng, n_frames=(14, 9), size=(48, 64), tail="HFL"):
+    """data/README.md layout with two tiny videos; returns {(video, frame): decoded uint8 array}."""
+    from PIL import Image
+    classes = ["OTH", "SFI", "SFF", "SFL", "SNI", "SNF", "SNL", "HFL", "HFR", "HNL", "HNR"]
+    os.makedirs(os.path.join(root, "splits", "02"))
+    os.makedirs(os.path.join(root, "annotations", "labels"))
+    with open(os.path.join(root, "classes.names"), "w") as f:
+        f.write("\n".join(classes) + "\n")
+    split_lines, labels = [], {}
+    for vi, (v, n) in enumerate(zip(("V010", "V011"), n_frames)):
+        lab = ["OTH"] * 4 + ["SFI"] * 3 + ["OTH"] * 2 + [tail] * (n - 9)
+        labels[v] = lab
+        with open(os.path.join(root, "annotations", "labels", v + ".txt"), "w") as f:
+            for fr in range(n):
+                f.write(f"{fr} {lab[fr]}\n")
+        for fr in range(n):
+            path = os.path.join(root, "frames", v + ".mp4", "0000000000", f"{fr:010d}.jpg")
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            Image.fromarray(rng.integers(0, 256, size + (3,), dtype=np.uint8)).save(path, quality=90)
+        for fr in range(2, n - 2):                 # the split covers the middle of each video
+            split_lines.append(f"{v} {fr}")
+    with open(os.path.join(root, "splits", "02", "test.txt"), "w") as f:
+        f.write("\n".join(split_lines) + "\n")
+    with open(os.path.join(root, "annotations", "points.txt"), "w") as f:
+        f.write("P0 V010 4 6\nP1 V011 4 6\nP2 V099 1 2\n")
+    with open(os.path.join(root, "annotations", "captions.txt"), "w") as f:
+        f.write("P0\tserve in\nP1\tserve far\nP2\tnot in the split\n")
+    return labels
+
+
+def test_tennisset_on_disk(tmp_path):
+    from PIL import Image
+    from tennis_amd.dataset import TennisSet
+    root = str(tmp_path / "data")
+    labels = _write_dataset(root, np.random.default_rng(3))
+    ts = TennisSet(root=root, split="test", split_id="02", balance=False, transform=lambda a: a)
+    assert ts.on_disk and len(ts) == (14 - 4) + (9 - 4)
+    assert sorted(ts._videos) == ["V010", "V011"]
+    for v, fr, c in ts._samples:
+        assert c == labels[v][fr]
+    assert ts._video_lengths == {"V010": 13, "V011": 8}                # name of the last frame file (dataset.py:438-452)
+    # events: runs of one class over the frames of the split; the reference emits the (possibly empty) leading OTH run
+    ev = [e for e in ts._events if e[0] == "V010"]
+    assert ev == [["V010", 2, 3, "OTH"], ["V010", 4, 6, "SFI"], ["V010", 7, 8, "OTH"], ["V010", 9, 11, "HFL"]]
+    assert set(ts._points) == {"P0", "P1"} and ts._points["P0"] == ["V010", "4", "6", "serve in"]
+    img, label, idx = ts[3]
+    v, fr, c = ts._samples[3]
+    with Image.open(ts.get_image_path(ts._frames_dir, v, fr)) as ref:
+        assert np.array_equal(img, np.asarray(ref.convert("RGB")))
+    assert label == ts.classes.index(c) and idx == 3
+    assert "Class" in ts.stats() and "SFI" in str(ts)
+    # window sampling clamps to [0, max_frame] (dataset.py:190-201)
+    tw = TennisSet(root=root, split="test", split_id="02", balance=False, window=5, stride=2, transform=lambda a: a)
+    last = [s for s in tw._samples if s[0] == "V011"][-1]
+    assert tw.window_frames(last) == [min(max(0, last[1] + o * 2), 7) for o in (-2, -1, 0, 1, 2)]
+    assert tw[0][0].shape == (5, 48, 64, 3)
+
+
+def test_save_feats_padding_ignores_missing_frames(tmp_path):
+    from tennis_amd.dataset import TennisSet
+    root = str(tmp_path / "data")
+    _write_dataset(root, np.random.default_rng(4))
+    ts = TennisSet(root=root, split="test", split_id="02", balance=False, save_feats=True)
+    # +-255 around [2, n-3] per video: only frames that exist on disk survive, labelled by the label files
+    assert len(ts) == 14 + 9
+    assert sorted(s[1] for s in ts._samples if s[0] == "V011") == list(range(9))
+    assert ts.save_feature_path(0).endswith(os.path.join("features", "0000", "V010.mp4", "0000000000", "0000000002.npy"))
+
+
+def test_balance_classes(tmp_path):
+    from tennis_amd.dataset import TennisSet
+    root = str(tmp_path / "data")
+    _write_dataset(root, np.random.default_rng(5), n_frames=(60, 9), tail="OTH")
+    full = TennisSet(root=root, split="test", split_id="02", balance=False)
+    counts = full.class_counts()
+    random.seed(11)
+    bal = TennisSet(root=root, split="test", split_id="02", balance=True)
+    # restate dataset.py:268-287 with the same seed
+    random.seed(11)
+    ratio = max(counts[1:]) / float(counts[0] + 1)
+    expect = [s for s in full._samples if not (s[2] == "OTH" and random.uniform(0, 1) > ratio)]
+    assert bal._samples == expect
+    assert bal.class_counts()[1:] == counts[1:] and 0 < bal.class_counts()[0] < counts[0] // 2
