@@ -68,17 +68,13 @@ __global__ void lstm_gate_kernel(const float *__restrict__ gi, const float *__re
 }
 
 // scaled-Luong attention for one decoder row per workgroup: scores over the source steps,
-// masked softmax (masked -> -1e18, weights * mask), context; writes ctx and xcat[:, H:2H]
-__global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ hq, const float *__restrict__ keyproj,
-                                                        const float *__restrict__ mem,
-                                                        const int32_t *__restrict__ valid_len, float *__restrict__ ctx,
-                                                        float *__restrict__ xcat, int beam, int T, int H) {
-  extern __shared__ float sm[];   // q[H] | w[T] | red[256]
+// masked softmax (masked -> -1e18, weights * mask), context; writes ctx and xcat[r, H:2H].
+// q[H] (already scaled by 1/sqrt(H)) sits at the start of the dynamic LDS: q[H] | w[T] | red[256]
+__device__ __forceinline__ void attention_row(float *sm, int r, int b, const float *__restrict__ keyproj,
+                                              const float *__restrict__ mem, const int32_t *__restrict__ valid_len,
+                                              float *__restrict__ ctx, float *__restrict__ xcat, int ldx, int T, int H) {
   float *q = sm, *w = sm + H, *red = w + T;
-  const int r = blockIdx.x, b = r / beam, t = threadIdx.x;
-  const float inv = 1.0f / sqrtf((float)H);
-  for (int i = t; i < H; i += 256) q[i] = hq[(long)r * H + i] * inv;
-  __syncthreads();
+  const int t = threadIdx.x;
   const int vl = valid_len[b];
   const float *kp = keyproj + (long)b * T * H;
   float mx = -INFINITY;
@@ -119,48 +115,175 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
     float a = 0.f;
     for (int s = 0; s < T; ++s) a = fmaf(w[s], mv[(long)s * H + i], a);
     ctx[(long)r * H + i] = a;
-    xcat[(long)r * 2 * H + H + i] = a;
+    xcat[(long)r * ldx + H + i] = a;
   }
 }
 
-// One beam-search update per source clip (workgroup): log_softmax of the beam rows, length-
-// penalised candidate scores, top-`beam` over [beam*V | finished], bookkeeping.
-__global__ __launch_bounds__(256) void beam_update_kernel(
-    const float *__restrict__ logits, int V, int beam, int step, float alpha, float Kp, int eos,
-    float *__restrict__ scores, int32_t *__restrict__ alive, int32_t *__restrict__ vlen,
-    const int32_t *__restrict__ samples_in, int32_t *__restrict__ samples_out, int L, int32_t *__restrict__ tok,
-    int32_t *__restrict__ gather, int32_t *__restrict__ any_alive) {
-  extern __shared__ float sm[];   // cand[beam*V + beam] | lse[beam] | redv[256] | redi[256]
-  const int b = blockIdx.x, t = threadIdx.x, NC = beam * V + beam;
-  float *cand = sm, *lse = cand + NC, *redv = lse + beam;
-  int *redi = (int *)(redv + 256);
-  __shared__ int sel_idx[16];
-  __shared__ float sel_val[16];
-  // log-sum-exp per beam row
-  for (int k = 0; k < beam; ++k) {
-    const float *z = logits + ((long)b * beam + k) * V;
-    float mx = -INFINITY;
-    for (int v = t; v < V; v += 256) mx = fmaxf(mx, z[v]);
-    redv[t] = mx;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (t < o) redv[t] = fmaxf(redv[t], redv[t + o]); __syncthreads(); }
-    mx = redv[0];
-    __syncthreads();
-    float s = 0.f;
-    for (int v = t; v < V; v += 256) s += expf(z[v] - mx);
-    redv[t] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (t < o) redv[t] += redv[t + o]; __syncthreads(); }
-    if (t == 0) lse[k] = mx + logf(redv[0]);
-    __syncthreads();
+__global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ hq, const float *__restrict__ keyproj,
+                                                        const float *__restrict__ mem,
+                                                        const int32_t *__restrict__ valid_len, float *__restrict__ ctx,
+                                                        float *__restrict__ xcat, int beam, int T, int H) {
+  extern __shared__ float sm[];
+  const int r = blockIdx.x;
+  const float inv = 1.0f / sqrtf((float)H);
+  for (int i = threadIdx.x; i < H; i += 256) sm[i] = hq[(long)r * H + i] * inv;
+  __syncthreads();
+  attention_row(sm, r, r / beam, keyproj, mem, valid_len, ctx, xcat, 2 * H, T, H);
+}
+
+// Beam-search step, launch 2 of 4: the first decoder cell's gate arithmetic on the fused pre-activations
+// g0 (R,4H) — GRU columns [r, z, n_i2h, n_h2h] (r and z already summed over both branches), LSTM [i, f, g, o] —
+// then the attention of that row.  h_prev is read from the step input x0 (its last H columns), the new state
+// goes to hn (R,H) (+ cn for LSTM) and to the first H columns of x1 (row stride ldx1).
+__global__ __launch_bounds__(256) void dec_attention_kernel(
+    const float *__restrict__ g0, const float *__restrict__ hprev, int ldh, const float *__restrict__ cprev, int lstm,
+    float *__restrict__ hn, float *__restrict__ cn, float *__restrict__ x1, int ldx1,
+    const float *__restrict__ keyproj, const float *__restrict__ mem, const int32_t *__restrict__ valid_len,
+    float *__restrict__ ctx, int beam, int T, int H) {
+  extern __shared__ float sm[];
+  const int r = blockIdx.x;
+  const float inv = 1.0f / sqrtf((float)H);
+  const float *g = g0 + (long)r * 4 * H;
+  for (int u = threadIdx.x; u < H; u += 256) {
+    float v;
+    if (lstm) {
+      const float ig = sigm(g[u]), fg = sigm(g[H + u]), gg = tanhf(g[2 * H + u]), og = sigm(g[3 * H + u]);
+      const float c2 = fg * cprev[(long)r * H + u] + ig * gg;
+      cn[(long)r * H + u] = c2;
+      v = og * tanhf(c2);
+    } else {
+      const float rg = sigm(g[u]), zg = sigm(g[H + u]);
+      const float ng = tanhf(g[2 * H + u] + rg * g[3 * H + u]);
+      v = (1.f - zg) * ng + zg * hprev[(long)r * ldh + u];
+    }
+    hn[(long)r * H + u] = v;
+    x1[(long)r * ldx1 + u] = v;
+    sm[u] = v * inv;
   }
+  __syncthreads();
+  attention_row(sm, r, r / beam, keyproj, mem, valid_len, ctx, x1, ldx1, T, H);
+}
+
+// ---- block-wide reductions of the beam kernel (1024 threads = 16 waves; red: 16 floats, redi: 16 ints) ----
+constexpr int kBeamThreads = 1024;
+__device__ __forceinline__ float block_max(float v, float *red) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < kBeamThreads / 64; ++i) r = fmaxf(r, red[i]);
+  return r;
+}
+__device__ __forceinline__ float block_sum(float v, float *red) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < kBeamThreads / 64; ++i) r += red[i];
+  return r;
+}
+// arg-max with ties to the lowest index (the oracle's stable descending argsort)
+__device__ __forceinline__ void block_argmax(float &v, int &idx, float *red, int *redi) {
+  for (int o = 32; o > 0; o >>= 1) {
+    const float v2 = __shfl_xor(v, o, 64);
+    const int i2 = __shfl_xor(idx, o, 64);
+    if (v2 > v || (v2 == v && i2 < idx)) { v = v2; idx = i2; }
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = v; redi[threadIdx.x >> 6] = idx; }
+  __syncthreads();
+  v = red[0]; idx = redi[0];
+  for (int i = 1; i < kBeamThreads / 64; ++i)
+    if (red[i] > v || (red[i] == v && redi[i] < idx)) { v = red[i]; idx = redi[i]; }
+}
+
+// Beam-search step, launch 4 of 4, one workgroup per source clip:
+//   second decoder cell's gates on g1 (R,4H) (column layout as in dec_attention_kernel; h_prev / c_prev are
+//   the clip's rows of x1[:, 2H:3H] / c1cur) -> projection to the vocabulary (Wp^T streamed once for all
+//   beams, 4 partial sums over K) -> log_softmax -> length-penalised candidates -> top-`beam` over
+//   [beam*V | finished] -> bookkeeping -> the NEXT step's inputs, re-gathered by parent beam:
+//   x0 = [embed(word), ctx[parent], h0[parent]], x1[:, 2H:3H] = h1[parent], c0cur / c1cur (LSTM).
+template <int NBM>
+__global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
+    const float *__restrict__ g1, float *__restrict__ x1, int lstm, float *__restrict__ c1cur,
+    const float *__restrict__ wpT, const float *__restrict__ bp, const float *__restrict__ h0n,
+    const float *__restrict__ ctx, const float *__restrict__ c0n, float *__restrict__ x0, float *__restrict__ c0cur,
+    const float *__restrict__ emb, int H, int E, int V, int beam, int step, float alpha, float Kp, int eos,
+    float *__restrict__ scores, int32_t *__restrict__ alive, int32_t *__restrict__ vlen,
+    const int32_t *__restrict__ samples_in, int32_t *__restrict__ samples_out, int L, int32_t *__restrict__ any_alive) {
+  extern __shared__ float sm[];   // h1n[NBM*H] | c1n[NBM*H] | logits[beam*V] | part[4*beam*V] (cand aliases part) | lse[16]
+  const int b = blockIdx.x, t = threadIdx.x, NC = beam * V + beam, K0 = E + 2 * H, K1 = 3 * H;
+  float *h1n = sm, *c1n = h1n + NBM * H, *logits = c1n + NBM * H, *part = logits + beam * V, *cand = part;
+  float *lse = part + 4 * beam * V;
+  __shared__ float red[16], sel_val[16];
+  __shared__ int redi[16], sel_idx[16], o_alive[16], o_vlen[16];
+  // ---- cell 1 ----
+  for (int idx = t; idx < NBM * H; idx += kBeamThreads) {
+    const int k = idx / H, u = idx - k * H;
+    float v = 0.f, c2 = 0.f;
+    if (k < beam) {
+      const long r = (long)b * beam + k;
+      const float *g = g1 + r * 4 * H;
+      if (lstm) {
+        const float ig = sigm(g[u]), fg = sigm(g[H + u]), gg = tanhf(g[2 * H + u]), og = sigm(g[3 * H + u]);
+        c2 = fg * c1cur[r * H + u] + ig * gg;
+        v = og * tanhf(c2);
+      } else {
+        const float rg = sigm(g[u]), zg = sigm(g[H + u]);
+        const float ng = tanhf(g[2 * H + u] + rg * g[3 * H + u]);
+        v = (1.f - zg) * ng + zg * x1[r * K1 + 2 * H + u];
+      }
+    }
+    h1n[idx] = v;
+    c1n[idx] = c2;
+  }
+  __syncthreads();
+  // ---- projection: thread = (quarter of K, vocabulary column) ----
+  {
+    const int kq = t >> 8, tv = t & 255, kn = H / 4, k0 = kq * kn;
+    for (int v = tv; v < V; v += 256) {
+      float acc[NBM];
+#pragma unroll
+      for (int q = 0; q < NBM; ++q) acc[q] = 0.f;
+#pragma unroll 8
+      for (int k = k0; k < k0 + kn; ++k) {
+        const float w = wpT[(long)k * V + v];
+#pragma unroll
+        for (int q = 0; q < NBM; ++q) acc[q] = fmaf(w, h1n[q * H + k], acc[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < NBM; ++q)
+        if (q < beam) part[(kq * beam + q) * V + v] = acc[q];
+    }
+  }
+  __syncthreads();
+  for (int c = t; c < beam * V; c += kBeamThreads) {
+    const int v = c % V;
+    logits[c] = bp[v] + ((part[c] + part[beam * V + c]) + (part[2 * beam * V + c] + part[3 * beam * V + c]));
+  }
+  __syncthreads();
+  // ---- log-sum-exp per beam row ----
+  for (int k = 0; k < beam; ++k) {
+    const float *z = logits + k * V;
+    float mx = -INFINITY;
+    for (int v = t; v < V; v += kBeamThreads) mx = fmaxf(mx, z[v]);
+    mx = block_max(mx, red);
+    float sum = 0.f;
+    for (int v = t; v < V; v += kBeamThreads) sum += expf(z[v] - mx);
+    sum = block_sum(sum, red);
+    if (t == 0) lse[k] = mx + logf(sum);
+  }
+  __syncthreads();
+  // ---- candidates (part is dead: cand aliases it) ----
   const float lp = powf(Kp + (float)step, alpha) / powf(Kp + 1.f, alpha);
   const float prev_lp = step == 1 ? 1.f : powf(Kp + (float)(step - 1), alpha) / powf(Kp + 1.f, alpha);
-  for (int c = t; c < NC; c += 256) {
+  for (int c = t; c < NC; c += kBeamThreads) {
     float v;
     if (c < beam * V) {
-      const int k = c / V, wv = c - k * V;
-      const float logp = logits[((long)b * beam + k) * V + wv] - lse[k];
+      const int k = c / V;
+      const float logp = logits[c] - lse[k];
       v = alive[b * beam + k] ? (scores[b * beam + k] * prev_lp + logp) / lp : kNeg;
     } else {
       const int k = c - beam * V;
@@ -169,28 +292,19 @@ __global__ __launch_bounds__(256) void beam_update_kernel(
     cand[c] = v;
   }
   __syncthreads();
-  // top-`beam`, descending, ties -> lowest index (stable argsort in the oracle)
+  // ---- top-`beam`, descending, ties -> lowest index ----
   for (int k = 0; k < beam; ++k) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int c = t; c < NC; c += 256) {
+    for (int c = t; c < NC; c += kBeamThreads) {
       const float v = cand[c];
       if (v > bv || (v == bv && c < bi)) { bv = v; bi = c; }
     }
-    redv[t] = bv; redi[t] = bi;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (t < o) {
-        const float v2 = redv[t + o]; const int i2 = redi[t + o];
-        if (v2 > redv[t] || (v2 == redv[t] && i2 < redi[t])) { redv[t] = v2; redi[t] = i2; }
-      }
-      __syncthreads();
-    }
-    if (t == 0) { sel_idx[k] = redi[0]; sel_val[k] = redv[0]; cand[redi[0]] = -INFINITY; }
+    block_argmax(bv, bi, red, redi);
+    if (t == 0) { sel_idx[k] = bi; sel_val[k] = bv; cand[bi] = -INFINITY; }
     __syncthreads();
   }
-  // bookkeeping (old values are read before any thread overwrites them)
-  __shared__ int o_alive[16], o_vlen[16];
+  // ---- bookkeeping (old values are read before any thread overwrites them) ----
   if (t < beam) { o_alive[t] = alive[b * beam + t]; o_vlen[t] = vlen[b * beam + t]; }
   __syncthreads();
   if (t < beam) {
@@ -202,28 +316,52 @@ __global__ __launch_bounds__(256) void beam_update_kernel(
     vlen[b * beam + t] = o_vlen[bid] + 1 - (use_prev ? 1 : 0);
     const int al = o_alive[bid] && word != eos;
     alive[b * beam + t] = al;
-    tok[b * beam + t] = word > 0 ? word : 0;
-    gather[b * beam + t] = b * beam + bid;
     sel_idx[t] = bid;      // reuse: source beam
     sel_val[t] = (float)word;
     if (al) atomicOr(any_alive, 1);
   }
   __syncthreads();
-  // samples: copy the chosen parent's prefix (step entries: BOS + step-1 words), append the word
+  // ---- samples: copy the chosen parent's prefix (step entries: BOS + step-1 words), append the word ----
   for (int k = 0; k < beam; ++k) {
     const int32_t *src = samples_in + ((long)b * beam + sel_idx[k]) * L;
     int32_t *dst = samples_out + ((long)b * beam + k) * L;
-    for (int i = t; i < step; i += 256) dst[i] = src[i];
+    for (int i = t; i < step; i += kBeamThreads) dst[i] = src[i];
     if (t == 0) dst[step] = (int32_t)sel_val[k];
+  }
+  // ---- next step's inputs, states re-gathered by parent beam ----
+  for (int idx = t; idx < beam * K0; idx += kBeamThreads) {
+    const int k = idx / K0, i = idx - k * K0;
+    const long r = (long)b * beam + k, pr = (long)b * beam + sel_idx[k];
+    const int word = (int)sel_val[k];
+    float v;
+    if (i < E) v = emb[(long)(word > 0 ? word : 0) * E + i];
+    else if (i < E + H) v = ctx[pr * H + i - E];
+    else v = h0n[pr * H + i - E - H];
+    x0[r * K0 + i] = v;
+  }
+  for (int idx = t; idx < beam * H; idx += kBeamThreads) {
+    const int k = idx / H, u = idx - k * H;
+    const long r = (long)b * beam + k, pr = (long)b * beam + sel_idx[k];
+    x1[r * K1 + 2 * H + u] = h1n[sel_idx[k] * H + u];
+    if (lstm) {
+      c1cur[r * H + u] = c1n[sel_idx[k] * H + u];
+      c0cur[r * H + u] = c0n[pr * H + u];
+    }
   }
 }
 
-__global__ void gather_rows_kernel(const float *__restrict__ src, float *__restrict__ dst,
-                                   const int32_t *__restrict__ gather, int R, int H) {
-  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= (long)R * H) return;
-  const int r = (int)(id / H), u = (int)(id % H);
-  dst[id] = src[(long)gather[r] * H + u];
+// first step's inputs: x0 = [embed(bos), 0, h0 of the clip], x1[:, 2H:3H] = h1 of the clip, cell states (LSTM)
+__global__ void dec_init_kernel(const float *__restrict__ emb, int bos, const float *__restrict__ h0c,
+                                const float *__restrict__ h1c, const float *__restrict__ c0c,
+                                const float *__restrict__ c1c, float *__restrict__ x0, float *__restrict__ x1,
+                                float *__restrict__ c0cur, float *__restrict__ c1cur, int beam, int H, int E) {
+  const int r = blockIdx.x, b = r / beam, K0 = E + 2 * H, K1 = 3 * H;
+  for (int i = threadIdx.x; i < K0; i += blockDim.x)
+    x0[(long)r * K0 + i] = i < E ? emb[(long)bos * E + i] : i < E + H ? 0.f : h0c[(long)b * H + i - E - H];
+  for (int u = threadIdx.x; u < H; u += blockDim.x) {
+    x1[(long)r * K1 + 2 * H + u] = h1c[(long)b * H + u];
+    if (c0c) { c0cur[(long)r * H + u] = c0c[(long)b * H + u]; c1cur[(long)r * H + u] = c1c[(long)b * H + u]; }
+  }
 }
 
 __global__ void expand_rows_kernel(const float *__restrict__ src, float *__restrict__ dst, int B, int beam, int H) {
@@ -319,6 +457,9 @@ struct tn_gnmt {
   int32_t *vl;
   float *h0[2], *h1[2], *att[2], *x0, *x1, *gi, *gh, *logits, *scores;
   int32_t *alive, *vlen, *tok, *gather, *samples[2], *flag;
+  // fused beam-search step: stacked [i2h | h2h] weights (4H rows each), transposed projection, step buffers
+  float *w0c, *b0c, *w1c, *b1c, *wpT;
+  float *sx0, *sx1, *g0, *g1, *h0n, *ctxn, *c0n, *c0cur, *c1cur;
   int B, T;
 };
 
@@ -386,6 +527,41 @@ extern "C" int tn_gnmt_create(tn_ctx *ctx, const tn_param *params, int n_params,
   UP(g->wp, "tgt_proj_weight", (int64_t)vocab * H); UP(g->bp, "tgt_proj_bias", vocab);
   UP(g->emb, "tgt_embed_weight", (int64_t)vocab * embed);
 #undef UP
+  {
+    // one GEMM per decoder cell: rows of the stacked matrix = 4H gate columns over [cell input | h_prev].
+    // LSTM: [Wi | Wh], bias bi + bh.  GRU: r and z likewise; the candidate keeps its two branches apart
+    // (n = tanh(n_i2h + r * n_h2h)): rows 2H..3H = [Wi_n | 0], rows 3H..4H = [0 | Wh_n].
+    auto stack = [&](const std::string &cell, int in_dim, float **w_out, float **b_out) -> bool {
+      const float *wi = get(pre + cell + "i2h_weight", (int64_t)G3 * in_dim), *wh = get(pre + cell + "h2h_weight", (int64_t)G3 * H);
+      const float *bi = get(pre + cell + "i2h_bias", G3), *bh = get(pre + cell + "h2h_bias", G3);
+      if (!wi || !wh || !bi || !bh) return false;
+      const int Kc = in_dim + H;
+      std::vector<float> w((size_t)4 * H * Kc, 0.f), bv(4 * H, 0.f);
+      for (int row = 0; row < 4 * H; ++row) {
+        float *d = &w[(size_t)row * Kc];
+        if (g->G == 4 || row < 2 * H) {
+          memcpy(d, wi + (size_t)row * in_dim, sizeof(float) * in_dim);
+          memcpy(d + in_dim, wh + (size_t)row * H, sizeof(float) * H);
+          bv[row] = bi[row] + bh[row];
+        } else if (row < 3 * H) {
+          memcpy(d, wi + (size_t)row * in_dim, sizeof(float) * in_dim);
+          bv[row] = bi[row];
+        } else {
+          memcpy(d + in_dim, wh + (size_t)(row - H) * H, sizeof(float) * H);
+          bv[row] = bh[row - H];
+        }
+      }
+      *w_out = g->pool.upload(w.data(), w.size());
+      *b_out = g->pool.upload(bv.data(), bv.size());
+      return true;
+    };
+    if (!stack("dec_rnn0_", embed + H, &g->w0c, &g->b0c) || !stack("dec_rnn1_", 2 * H, &g->w1c, &g->b1c)) return fail(TN_ERR_MISSING);
+    const float *wp = get(pre + "tgt_proj_weight", (int64_t)vocab * H);
+    std::vector<float> wt((size_t)H * vocab);
+    for (int v = 0; v < vocab; ++v)
+      for (int k = 0; k < H; ++k) wt[(size_t)k * vocab + v] = wp[(size_t)v * H + k];
+    g->wpT = g->pool.upload(wt.data(), wt.size());
+  }
   const size_t BT = (size_t)max_batch * max_src_len, R = (size_t)max_batch * beam;
   g->seq0 = g->pool.alloc<float>(BT * 2 * H); g->mem = g->pool.alloc<float>(BT * H); g->keyproj = g->pool.alloc<float>(BT * H);
   g->hl0 = g->pool.alloc<float>(2 * (size_t)max_batch * H); g->hl1 = g->pool.alloc<float>((size_t)max_batch * H);
@@ -400,6 +576,10 @@ extern "C" int tn_gnmt_create(tn_ctx *ctx, const tn_param *params, int n_params,
   g->gi = g->pool.alloc<float>(R * G3); g->gh = g->pool.alloc<float>(R * G3); g->logits = g->pool.alloc<float>(R * vocab);
   g->scores = g->pool.alloc<float>(R); g->alive = g->pool.alloc<int32_t>(R); g->vlen = g->pool.alloc<int32_t>(R);
   g->tok = g->pool.alloc<int32_t>(R); g->gather = g->pool.alloc<int32_t>(R); g->flag = g->pool.alloc<int32_t>(1);
+  g->sx0 = g->pool.alloc<float>(R * (embed + 2 * H)); g->sx1 = g->pool.alloc<float>(R * 3 * H);
+  g->g0 = g->pool.alloc<float>(R * 4 * H); g->g1 = g->pool.alloc<float>(R * 4 * H);
+  g->h0n = g->pool.alloc<float>(R * H); g->ctxn = g->pool.alloc<float>(R * H); g->c0n = g->pool.alloc<float>(R * H);
+  g->c0cur = g->pool.alloc<float>(R * H); g->c1cur = g->pool.alloc<float>(R * H);
   if (g->pool.failed) { tn_set_error("device allocation failed"); return fail(TN_ERR_NOMEM); }
   *out = g;
   return TN_OK;
@@ -436,53 +616,43 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
   TN_REQUIRE(bos >= 0 && bos < g->V && eos >= 0 && eos < g->V, "tn_gnmt_beam_search: bos/eos outside the vocabulary");
   TN_HIP_CHECK(hipSetDevice(g->ctx->device));
   hipStream_t s = g->ctx->stream;
-  const int B = g->B, T = g->T, H = g->H, E = g->E, V = g->V, beam = g->beam, R = B * beam, L = g->maxL, G3 = g->G * H;
+  const int B = g->B, T = g->T, H = g->H, E = g->E, V = g->V, beam = g->beam, R = B * beam, L = g->maxL;
+  const int K0 = E + 2 * H, K1 = 3 * H;
   const bool lstm = g->G == 4;
+  const int nbm = beam <= 4 ? 4 : beam <= 8 ? 8 : 16;
+  const size_t att_lds = (size_t)(H + T + 256) * sizeof(float);
+  const size_t beam_lds = ((size_t)2 * nbm * H + (size_t)5 * beam * V + 16) * sizeof(float);
+  TN_REQUIRE(beam_lds <= 64 * 1024 && att_lds <= 64 * 1024,
+             "tn_gnmt_beam_search: beam * (2*hidden + 5*vocab) or hidden + source length exceeds the step kernels' 64 KiB of LDS");
   TN_HIP_CHECK(hipMemsetAsync(g->samples[0], 0xff, sizeof(int32_t) * (size_t)R * L, s));
   TN_HIP_CHECK(hipMemsetAsync(g->samples[1], 0xff, sizeof(int32_t) * (size_t)R * L, s));
-  const int nb = (R * H + 255) / 256;
   // decoder layer 0 starts from the encoder's BACKWARD layer-0 state, layer 1 from the uni layer (gnmt.py:146-150,224-252)
-  hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)(g->hl0 + (size_t)B * H), g->h0[0], B, beam, H);
-  hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)g->hl1, g->h1[0], B, beam, H);
-  hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)nullptr, g->att[0], B, beam, H);
-  if (lstm) {
-    hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)(g->cl0 + (size_t)B * H), g->c0[0], B, beam, H);
-    hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)g->cl1, g->c1[0], B, beam, H);
-  }
+  hipLaunchKernelGGL(dec_init_kernel, dim3(R), dim3(256), 0, s, (const float *)g->emb, bos, (const float *)(g->hl0 + (size_t)B * H),
+                     (const float *)g->hl1, lstm ? (const float *)(g->cl0 + (size_t)B * H) : (const float *)nullptr,
+                     (const float *)g->cl1, g->sx0, g->sx1, g->c0cur, g->c1cur, beam, H, E);
   hipLaunchKernelGGL(beam_init_kernel, dim3((R + 255) / 256), dim3(256), 0, s, g->scores, g->alive, g->vlen, g->tok, g->samples[0], L, B, beam, bos);
-  int cur = 0, steps_done = 0, all_dead = 0;
-  const size_t att_lds = (size_t)(H + T + 256) * sizeof(float);
-  const size_t beam_lds = (size_t)(beam * V + beam + beam + 512) * sizeof(float);
+  int steps_done = 0, all_dead = 0;
+  // one step = 4 launches: the loop is bound by launch-to-launch dependency latency, not by arithmetic
   for (int i = 0; i < max_length; ++i) {
-    const int nxt = cur ^ 1, step = i + 1;
+    const int step = i + 1;
     if ((i & 15) == 0) TN_HIP_CHECK(hipMemsetAsync(g->flag, 0, sizeof(int32_t), s));
-    hipLaunchKernelGGL(embed_concat_kernel, dim3(R), dim3(128), 0, s, g->emb, g->tok, g->att[cur], g->x0, R, E, H);
-    int rc = launch_linear_f32(g->x0, E + H, g->wi0, E + H, g->bi0, g->gi, G3, R, G3, E + H, 0, s);
+    int rc = launch_linear_f32(g->sx0, K0, g->w0c, K0, g->b0c, g->g0, 4 * H, R, 4 * H, K0, 0, s);
     if (rc) return rc;
-    rc = launch_linear_f32(g->h0[cur], H, g->wh0, H, g->bh0, g->gh, G3, R, G3, H, 0, s);
+    hipLaunchKernelGGL(dec_attention_kernel, dim3(R), dim3(256), att_lds, s, (const float *)g->g0, (const float *)(g->sx0 + E + H), K0,
+                       (const float *)g->c0cur, lstm ? 1 : 0, g->h0n, g->c0n, g->sx1, K1, (const float *)g->keyproj,
+                       (const float *)g->mem, (const int32_t *)g->vl, g->ctxn, beam, T, H);
+    rc = launch_linear_f32(g->sx1, K1, g->w1c, K1, g->b1c, g->g1, 4 * H, R, 4 * H, K1, 0, s);
     if (rc) return rc;
-    if (lstm) hipLaunchKernelGGL(lstm_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->c0[cur], g->h0[nxt], g->c0[nxt], g->x1, 2 * H, R, H);
-    else hipLaunchKernelGGL(gru_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->h0[cur], g->h0[nxt], g->x1, 2 * H, R, H);
-    hipLaunchKernelGGL(attention_kernel, dim3(R), dim3(256), att_lds, s, g->h0[nxt], g->keyproj, g->mem, g->vl, g->att[nxt], g->x1, beam, T, H);
-    rc = launch_linear_f32(g->x1, 2 * H, g->wi1, 2 * H, g->bi1, g->gi, G3, R, G3, 2 * H, 0, s);
-    if (rc) return rc;
-    rc = launch_linear_f32(g->h1[cur], H, g->wh1, H, g->bh1, g->gh, G3, R, G3, H, 0, s);
-    if (rc) return rc;
-    if (lstm) hipLaunchKernelGGL(lstm_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->c1[cur], g->h1[nxt], g->c1[nxt], (float *)nullptr, 0, R, H);
-    else hipLaunchKernelGGL(gru_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->h1[cur], g->h1[nxt], (float *)nullptr, 0, R, H);
-    rc = launch_linear_f32(g->h1[nxt], H, g->wp, H, g->bp, g->logits, V, R, V, H, 0, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(beam_update_kernel, dim3(B), dim3(256), beam_lds, s, g->logits, V, beam, step, alpha, K, eos, g->scores,
-                       g->alive, g->vlen, g->samples[cur], g->samples[nxt], L, g->tok, g->gather, g->flag);
-    // re-gather the states by parent beam: nxt -> cur buffers, then swap roles
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, s, g->h0[nxt], g->h0[cur], g->gather, R, H);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, s, g->h1[nxt], g->h1[cur], g->gather, R, H);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, s, g->att[nxt], g->att[cur], g->gather, R, H);
-    if (lstm) {
-      hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, s, g->c0[nxt], g->c0[cur], g->gather, R, H);
-      hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, s, g->c1[nxt], g->c1[cur], g->gather, R, H);
-    }
-    // states are back in `cur`; only the samples ping-pong
+#define TN_BEAM_LAUNCH(NBM)                                                                                              \
+  hipLaunchKernelGGL(dec_beam_kernel<NBM>, dim3(B), dim3(kBeamThreads), beam_lds, s, (const float *)g->g1, g->sx1,       \
+                     lstm ? 1 : 0, g->c1cur, (const float *)g->wpT, (const float *)g->bp, (const float *)g->h0n,          \
+                     (const float *)g->ctxn, (const float *)g->c0n, g->sx0, g->c0cur, (const float *)g->emb, H, E, V,     \
+                     beam, step, alpha, K, eos, g->scores, g->alive, g->vlen, (const int32_t *)g->samples[0],             \
+                     g->samples[1], L, g->flag)
+    if (nbm == 4) TN_BEAM_LAUNCH(4);
+    else if (nbm == 8) TN_BEAM_LAUNCH(8);
+    else TN_BEAM_LAUNCH(16);
+#undef TN_BEAM_LAUNCH
     {
       int32_t *tmp = g->samples[0]; g->samples[0] = g->samples[1]; g->samples[1] = tmp;
     }
