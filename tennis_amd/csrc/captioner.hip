@@ -75,17 +75,35 @@ __device__ __forceinline__ void attention_row(float *sm, int r, int b, const flo
                                               float *__restrict__ ctx, float *__restrict__ xcat, int ldx, int T, int H) {
   float *q = sm, *w = sm + H, *red = w + T;
   const int t = threadIdx.x;
-  const int vl = valid_len[b];
+  const int vl = min(max(valid_len[b], 0), T);
   const float *kp = keyproj + (long)b * T * H;
-  float mx = -INFINITY;
-  for (int s = t; s < T; s += 256) {
-    float a = 0.f;
-    const float *row = kp + (long)s * H;
-    for (int i = 0; i < H; ++i) a = fmaf(q[i], row[i], a);
-    a = s < vl ? a : kNeg;
-    w[s] = a;
-    mx = fmaxf(mx, a);
+  // scores: one wave per source step, lanes along H (coalesced 16-byte loads), four steps in flight
+  {
+    const int lane = t & 63, wid = t >> 6;
+    for (int s0 = wid * 4; s0 < vl; s0 += 16) {
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int i = lane * 4; i < H; i += 256) {
+        const float4 qv = *(const float4 *)(q + i);
+        float4 kv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          kv[j] = s0 + j < vl ? *(const float4 *)(kp + (long)(s0 + j) * H + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          a[j] = fmaf(qv.w, kv[j].w, fmaf(qv.z, kv[j].z, fmaf(qv.y, kv[j].y, fmaf(qv.x, kv[j].x, a[j]))));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = a[j];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0 && s0 + j < vl) w[s0 + j] = v;
+      }
+    }
+    for (int s = vl + t; s < T; s += 256) w[s] = kNeg;     // masked source steps
   }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int s = t; s < T; s += 256) mx = fmaxf(mx, w[s]);
   red[t] = mx;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -111,9 +129,11 @@ __device__ __forceinline__ void attention_row(float *sm, int r, int b, const flo
   for (int s = t; s < T; s += 256) w[s] = s < vl ? w[s] * rs : 0.f;
   __syncthreads();
   const float *mv = mem + (long)b * T * H;
+  const int tv = vl;                                           // weights beyond valid_len are exactly 0
   for (int i = t; i < H; i += 256) {
     float a = 0.f;
-    for (int s = 0; s < T; ++s) a = fmaf(w[s], mv[(long)s * H + i], a);
+#pragma unroll 8
+    for (int s = 0; s < tv; ++s) a = fmaf(w[s], mv[(long)s * H + i], a);
     ctx[(long)r * H + i] = a;
     xcat[(long)r * ldx + H + i] = a;
   }
@@ -131,72 +151,164 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
   attention_row(sm, r, r / beam, keyproj, mem, valid_len, ctx, xcat, 2 * H, T, H);
 }
 
-// Beam-search step, launch 2 of 4: the first decoder cell's gate arithmetic on the fused pre-activations
-// g0 (R,4H) — GRU columns [r, z, n_i2h, n_h2h] (r and z already summed over both branches), LSTM [i, f, g, o] —
-// then the attention of that row.  h_prev is read from the step input x0 (its last H columns), the new state
-// goes to hn (R,H) (+ cn for LSTM) and to the first H columns of x1 (row stride ldx1).
-__global__ __launch_bounds__(256) void dec_attention_kernel(
+// ---- beam-search step kernels: 1024 threads = 16 waves ----
+constexpr int kBeamThreads = 1024;
+#ifdef TN_DEC_STAMPS   // tuning builds only (EXTRA=-DTN_DEC_STAMPS): phase boundaries of workgroup 0, 100 MHz ticks
+__device__ long long g_dec_stamps[24];
+#define DEC_STAMP(i) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) g_dec_stamps[i] = wall_clock64(); } while (0)
+#else
+#define DEC_STAMP(i)
+#endif
+// Beam-search step, launch 2 of 4, one workgroup (16 waves) per `rows` consecutive decoder rows of one clip (rows = 1:
+// the step is bound by instruction issue at the clocks a mostly idle chip runs at, so it pays to spread the rows over
+// CUs even though each re-reads the clip's key projection and memory from L2):
+//   first decoder cell's gate arithmetic on the stacked pre-activations g0 (R,4H) — GRU columns
+//   [r, z, n_i2h, n_h2h] (r and z already summed over both branches), LSTM [i, f, g, o]; h_prev = last H columns
+//   of the step input x0 — the new state goes to hn (R,H) (+ cn) and to x1[:, 0:H];
+//   scaled-Luong scores against the TRANSPOSED key projection kpT (B,H,T) (thread = (quarter of H, source step):
+//   coalesced along T), masked softmax (one wave per beam row), context from mem (B,T,H) (thread = (quarter of
+//   the valid steps, unit)) -> ctx (R,H) and x1[:, H:2H].
+template <int NBM>
+__global__ __launch_bounds__(kBeamThreads) void dec_attention_kernel(
     const float *__restrict__ g0, const float *__restrict__ hprev, int ldh, const float *__restrict__ cprev, int lstm,
     float *__restrict__ hn, float *__restrict__ cn, float *__restrict__ x1, int ldx1,
-    const float *__restrict__ keyproj, const float *__restrict__ mem, const int32_t *__restrict__ valid_len,
-    float *__restrict__ ctx, int beam, int T, int H) {
-  extern __shared__ float sm[];
-  const int r = blockIdx.x;
+    const float *__restrict__ kpT, const float *__restrict__ mem, const int32_t *__restrict__ valid_len,
+    float *__restrict__ ctx, int beam, int rows, int T, int H) {
+  constexpr int NP = (NBM + 3) & ~3;
+  extern __shared__ float sm[];   // q[H][NP] | w[T][NP] | part[4][rows][max(T,H)]
+  float *q = sm, *w = q + H * NP, *part = w + T * NP;
+  const int r0 = blockIdx.x * rows, b = r0 / beam, t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int vl = min(max(valid_len[b], 0), T);
   const float inv = 1.0f / sqrtf((float)H);
-  const float *g = g0 + (long)r * 4 * H;
-  for (int u = threadIdx.x; u < H; u += 256) {
-    float v;
-    if (lstm) {
-      const float ig = sigm(g[u]), fg = sigm(g[H + u]), gg = tanhf(g[2 * H + u]), og = sigm(g[3 * H + u]);
-      const float c2 = fg * cprev[(long)r * H + u] + ig * gg;
-      cn[(long)r * H + u] = c2;
-      v = og * tanhf(c2);
-    } else {
-      const float rg = sigm(g[u]), zg = sigm(g[H + u]);
-      const float ng = tanhf(g[2 * H + u] + rg * g[3 * H + u]);
-      v = (1.f - zg) * ng + zg * hprev[(long)r * ldh + u];
+  DEC_STAMP(0);
+  // ---- cell 0 ----
+  for (int idx = t; idx < NBM * H; idx += kBeamThreads) {
+    const int k = idx / H, u = idx - k * H;
+    float v = 0.f;
+    if (k < rows) {
+      const long r = (long)r0 + k;
+      const float *g = g0 + r * 4 * H;
+      if (lstm) {
+        const float ig = sigm(g[u]), fg = sigm(g[H + u]), gg = tanhf(g[2 * H + u]), og = sigm(g[3 * H + u]);
+        const float c2 = fg * cprev[r * H + u] + ig * gg;
+        cn[r * H + u] = c2;
+        v = og * tanhf(c2);
+      } else {
+        const float rg = sigm(g[u]), zg = sigm(g[H + u]);
+        const float ng = tanhf(g[2 * H + u] + rg * g[3 * H + u]);
+        v = (1.f - zg) * ng + zg * hprev[r * ldh + u];
+      }
+      hn[r * H + u] = v;
+      x1[r * ldx1 + u] = v;
     }
-    hn[(long)r * H + u] = v;
-    x1[(long)r * ldx1 + u] = v;
-    sm[u] = v * inv;
+    q[u * NP + k] = v * inv;
   }
   __syncthreads();
-  attention_row(sm, r, r / beam, keyproj, mem, valid_len, ctx, x1, ldx1, T, H);
+  DEC_STAMP(1);
+  // ---- scores: 4 partial sums over H per (row, source step) ----
+  {
+    const int hq = t >> 8, hn4 = H / 4, h0 = hq * hn4;
+    const float *kp = kpT + (long)b * H * T;
+    for (int s = t & 255; s < vl; s += 256) {
+      float acc[NBM];
+#pragma unroll
+      for (int j = 0; j < NBM; ++j) acc[j] = 0.f;
+      // loads are batched by hand (16 in flight): left to itself the compiler waits for each load before its fma
+      int h = h0;
+      for (; h + 16 <= h0 + hn4; h += 16) {
+        float kv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) kv[i] = kp[(long)(h + i) * T + s];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+          for (int j = 0; j < NBM; ++j) acc[j] = fmaf(kv[i], q[(h + i) * NP + j], acc[j]);
+      }
+      for (; h < h0 + hn4; ++h) {
+        const float kv = kp[(long)h * T + s];
+#pragma unroll
+        for (int j = 0; j < NBM; ++j) acc[j] = fmaf(kv, q[h * NP + j], acc[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < NBM; ++j)
+        if (j < rows) part[(hq * rows + j) * T + s] = acc[j];
+    }
+  }
+  __syncthreads();
+  DEC_STAMP(2);
+  // ---- masked softmax: wave k owns beam row k (masked -> -1e18, weights * mask) ----
+  if (wid < rows) {
+    const float *p0 = part + wid * T, *p1 = p0 + rows * T, *p2 = p1 + rows * T, *p3 = p2 + rows * T;
+    float mx = -INFINITY;
+    for (int s = lane; s < T; s += 64) {
+      const float a = s < vl ? (p0[s] + p1[s]) + (p2[s] + p3[s]) : kNeg;
+      w[s * NP + wid] = a;
+      mx = fmaxf(mx, a);
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int s = lane; s < T; s += 64) {
+      const float e = expf(w[s * NP + wid] - mx);
+      w[s * NP + wid] = e;
+      sum += e;
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float rs = 1.0f / sum;
+    for (int s = lane; s < T; s += 64) w[s * NP + wid] = s < vl ? w[s * NP + wid] * rs : 0.f;
+  } else if (wid < NP) {
+    for (int s = lane; s < T; s += 64) w[s * NP + wid] = 0.f;      // padded rows feed unused accumulators
+  }
+  __syncthreads();
+  DEC_STAMP(3);
+  // ---- context: 4 partial sums over the valid steps per (row, unit); weights beyond valid_len are exactly 0 ----
+  {
+    const int sq = t >> 8, sn = (vl + 3) / 4, s0 = sq * sn, s1 = min(vl, s0 + sn);
+    const float *mv = mem + (long)b * T * H;
+    for (int u = t & 255; u < H; u += 256) {
+      float acc[NBM];
+#pragma unroll
+      for (int j = 0; j < NBM; ++j) acc[j] = 0.f;
+      int s = s0;
+      for (; s + 16 <= s1; s += 16) {
+        float m[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m[i] = mv[(long)(s + i) * H + u];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+          for (int j = 0; j < NBM; ++j) acc[j] = fmaf(w[(s + i) * NP + j], m[i], acc[j]);
+      }
+      for (; s < s1; ++s) {
+        const float m = mv[(long)s * H + u];
+#pragma unroll
+        for (int j = 0; j < NBM; ++j) acc[j] = fmaf(w[s * NP + j], m, acc[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < NBM; ++j)
+        if (j < rows) part[(sq * rows + j) * H + u] = acc[j];
+    }
+  }
+  __syncthreads();
+  for (int idx = t; idx < rows * H; idx += kBeamThreads) {
+    const int k = idx / H, u = idx - k * H;
+    const long r = (long)r0 + k;
+    const float a = (part[idx] + part[rows * H + idx]) + (part[2 * rows * H + idx] + part[3 * rows * H + idx]);
+    ctx[r * H + u] = a;
+    x1[r * ldx1 + H + u] = a;
+  }
+  DEC_STAMP(4);
 }
 
-// ---- block-wide reductions of the beam kernel (1024 threads = 16 waves; red: 16 floats, redi: 16 ints) ----
-constexpr int kBeamThreads = 1024;
-__device__ __forceinline__ float block_max(float v, float *red) {
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+// (B,T,H) -> (B,H,T): the key projection as the per-clip attention kernel reads it
+__global__ void transpose_bth_kernel(const float *__restrict__ src, float *__restrict__ dst, int T, int H) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, t0 = blockIdx.y * 32, h0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8)
+    if (t0 + i < T && h0 + tx < H) tile[i][tx] = src[((long)b * T + t0 + i) * H + h0 + tx];
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  float r = red[0];
-  for (int i = 1; i < kBeamThreads / 64; ++i) r = fmaxf(r, red[i]);
-  return r;
-}
-__device__ __forceinline__ float block_sum(float v, float *red) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  float r = red[0];
-  for (int i = 1; i < kBeamThreads / 64; ++i) r += red[i];
-  return r;
-}
-// arg-max with ties to the lowest index (the oracle's stable descending argsort)
-__device__ __forceinline__ void block_argmax(float &v, int &idx, float *red, int *redi) {
-  for (int o = 32; o > 0; o >>= 1) {
-    const float v2 = __shfl_xor(v, o, 64);
-    const int i2 = __shfl_xor(idx, o, 64);
-    if (v2 > v || (v2 == v && i2 < idx)) { v = v2; idx = i2; }
-  }
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = v; redi[threadIdx.x >> 6] = idx; }
-  __syncthreads();
-  v = red[0]; idx = redi[0];
-  for (int i = 1; i < kBeamThreads / 64; ++i)
-    if (red[i] > v || (red[i] == v && redi[i] < idx)) { v = red[i]; idx = redi[i]; }
+  for (int i = ty; i < 32; i += 8)
+    if (h0 + i < H && t0 + tx < T) dst[((long)b * H + h0 + i) * T + t0 + tx] = tile[tx][i];
 }
 
 // Beam-search step, launch 4 of 4, one workgroup per source clip:
@@ -213,12 +325,15 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
     const float *__restrict__ emb, int H, int E, int V, int beam, int step, float alpha, float Kp, int eos,
     float *__restrict__ scores, int32_t *__restrict__ alive, int32_t *__restrict__ vlen,
     const int32_t *__restrict__ samples_in, int32_t *__restrict__ samples_out, int L, int32_t *__restrict__ any_alive) {
-  extern __shared__ float sm[];   // h1n[NBM*H] | c1n[NBM*H] | logits[beam*V] | part[4*beam*V] (cand aliases part) | lse[16]
+  extern __shared__ float sm[];   // h1n[H][NP] | c1n[H][NP] | logits[beam*V] | part[4*beam*V] (cand aliases part) | lse[16]
   const int b = blockIdx.x, t = threadIdx.x, NC = beam * V + beam, K0 = E + 2 * H, K1 = 3 * H;
-  float *h1n = sm, *c1n = h1n + NBM * H, *logits = c1n + NBM * H, *part = logits + beam * V, *cand = part;
+  constexpr int NP = (NBM + 3) & ~3;   // LDS pitch of one k: NBM beam rows padded to 16-byte multiples
+  float *h1n = sm, *c1n = h1n + NP * H, *logits = c1n + NP * H, *part = logits + beam * V, *cand = part;
   float *lse = part + 4 * beam * V;
-  __shared__ float red[16], sel_val[16];
-  __shared__ int redi[16], sel_idx[16], o_alive[16], o_vlen[16];
+  __shared__ float sel_val[16], o_score[16], lps[2];
+  __shared__ int sel_idx[16], sel_par[16], sel_word[16], o_alive[16], o_vlen[16];
+  const int lane = t & 63, wid = t >> 6;
+  DEC_STAMP(8);
   // ---- cell 1 ----
   for (int idx = t; idx < NBM * H; idx += kBeamThreads) {
     const int k = idx / H, u = idx - k * H;
@@ -236,10 +351,11 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
         v = (1.f - zg) * ng + zg * x1[r * K1 + 2 * H + u];
       }
     }
-    h1n[idx] = v;
-    c1n[idx] = c2;
+    h1n[u * NP + k] = v;       // k-major: a projection thread reads its NBM rows with one or two wide LDS loads
+    c1n[u * NP + k] = c2;
   }
   __syncthreads();
+  DEC_STAMP(9);
   // ---- projection: thread = (quarter of K, vocabulary column) ----
   {
     const int kq = t >> 8, tv = t & 255, kn = H / 4, k0 = kq * kn;
@@ -247,11 +363,20 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
       float acc[NBM];
 #pragma unroll
       for (int q = 0; q < NBM; ++q) acc[q] = 0.f;
-#pragma unroll 8
-      for (int k = k0; k < k0 + kn; ++k) {
+      int k = k0;
+      for (; k + 16 <= k0 + kn; k += 16) {      // 16 loads in flight (batched by hand, see dec_attention_kernel)
+        float w[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[i] = wpT[(long)(k + i) * V + v];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+          for (int q = 0; q < NBM; ++q) acc[q] = fmaf(w[i], h1n[(k + i) * NP + q], acc[q]);
+      }
+      for (; k < k0 + kn; ++k) {
         const float w = wpT[(long)k * V + v];
 #pragma unroll
-        for (int q = 0; q < NBM; ++q) acc[q] = fmaf(w, h1n[q * H + k], acc[q]);
+        for (int q = 0; q < NBM; ++q) acc[q] = fmaf(w, h1n[k * NP + q], acc[q]);
       }
 #pragma unroll
       for (int q = 0; q < NBM; ++q)
@@ -264,49 +389,99 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
     logits[c] = bp[v] + ((part[c] + part[beam * V + c]) + (part[2 * beam * V + c] + part[3 * beam * V + c]));
   }
   __syncthreads();
-  // ---- log-sum-exp per beam row ----
-  for (int k = 0; k < beam; ++k) {
-    const float *z = logits + k * V;
+  DEC_STAMP(10);
+  // ---- log-sum-exp: wave k owns beam row k; the old beam state moves to LDS meanwhile ----
+  if (wid < beam) {
+    const float *z = logits + wid * V;
     float mx = -INFINITY;
-    for (int v = t; v < V; v += kBeamThreads) mx = fmaxf(mx, z[v]);
-    mx = block_max(mx, red);
+    for (int v = lane; v < V; v += 64) mx = fmaxf(mx, z[v]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     float sum = 0.f;
-    for (int v = t; v < V; v += kBeamThreads) sum += expf(z[v] - mx);
-    sum = block_sum(sum, red);
-    if (t == 0) lse[k] = mx + logf(sum);
+    for (int v = lane; v < V; v += 64) sum += expf(z[v] - mx);
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) lse[wid] = mx + logf(sum);
+  } else if (wid == 15) {
+    if (lane < beam) { o_alive[lane] = alive[b * beam + lane]; o_vlen[lane] = vlen[b * beam + lane]; o_score[lane] = scores[b * beam + lane]; }
+    if (lane == 0) {
+      lps[0] = powf(Kp + (float)step, alpha) / powf(Kp + 1.f, alpha);
+      lps[1] = step == 1 ? 1.f : powf(Kp + (float)(step - 1), alpha) / powf(Kp + 1.f, alpha);
+    }
   }
   __syncthreads();
+  DEC_STAMP(11);
   // ---- candidates (part is dead: cand aliases it) ----
-  const float lp = powf(Kp + (float)step, alpha) / powf(Kp + 1.f, alpha);
-  const float prev_lp = step == 1 ? 1.f : powf(Kp + (float)(step - 1), alpha) / powf(Kp + 1.f, alpha);
+  const float lp = lps[0], prev_lp = lps[1];
   for (int c = t; c < NC; c += kBeamThreads) {
     float v;
     if (c < beam * V) {
       const int k = c / V;
       const float logp = logits[c] - lse[k];
-      v = alive[b * beam + k] ? (scores[b * beam + k] * prev_lp + logp) / lp : kNeg;
+      v = o_alive[k] ? (o_score[k] * prev_lp + logp) / lp : kNeg;
     } else {
       const int k = c - beam * V;
-      v = alive[b * beam + k] ? kNeg : scores[b * beam + k];
+      v = o_alive[k] ? kNeg : o_score[k];
     }
     cand[c] = v;
   }
   __syncthreads();
-  // ---- top-`beam`, descending, ties -> lowest index ----
-  for (int k = 0; k < beam; ++k) {
-    float bv = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int c = t; c < NC; c += kBeamThreads) {
-      const float v = cand[c];
-      if (v > bv || (v == bv && c < bi)) { bv = v; bi = c; }
-    }
-    block_argmax(bv, bi, red, redi);
-    if (t == 0) { sel_idx[k] = bi; sel_val[k] = bv; cand[bi] = -INFINITY; }
-    __syncthreads();
+  DEC_STAMP(12);
+  // ---- top-`beam`, descending, ties -> lowest index: one wave, no block barriers.  A lane keeps the best of its
+  // strided candidates as a 64-bit key (order-preserving float bits | inverted index) and rescans only when it
+  // loses that best; the wave maximum is a DPP reduction (row shifts + row broadcasts), result in lane 63 ----
+  if (wid == 0) {
+    auto lane_best = [&](unsigned &hi, unsigned &lo) {
+      float bv = -INFINITY;
+      int bi = 0x7fffffff;
+      int c = lane;
+      for (; c + 7 * 64 < NC; c += 8 * 64) {          // LDS reads batched by hand, as the global ones above
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = cand[c + i * 64];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (x[i] > bv) { bv = x[i]; bi = c + i * 64; }   // ascending index: ties keep the lowest
+      }
+      for (; c < NC; c += 64) {
+        const float x = cand[c];
+        if (x > bv) { bv = x; bi = c; }
+      }
+      const unsigned u = __float_as_uint(bv);
+      hi = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+      lo = 0xffffffffu - (unsigned)bi;
+      if (bi == 0x7fffffff) { hi = 0u; lo = 0u; }          // no candidate left in this lane
+    };
+    unsigned hi, lo;
+    lane_best(hi, lo);
+    for (int k = 0; k < beam; ++k) {
+      unsigned h = hi, l = lo;
+#define TN_DPP_MAX(ctrl, rmask)                                                                       \
+  {                                                                                                   \
+    const unsigned l2 = (unsigned)__builtin_amdgcn_update_dpp((int)l, (int)l, ctrl, rmask, 0xf, false); \
+    const unsigned h2 = (unsigned)__builtin_amdgcn_update_dpp((int)h, (int)h, ctrl, rmask, 0xf, false); \
+    const bool gt = h2 > h || (h2 == h && l2 > l);                                                     \
+    l = gt ? l2 : l;                                                                                  \
+    h = gt ? h2 : h;                                                                                  \
   }
-  // ---- bookkeeping (old values are read before any thread overwrites them) ----
-  if (t < beam) { o_alive[t] = alive[b * beam + t]; o_vlen[t] = vlen[b * beam + t]; }
+      TN_DPP_MAX(0x111, 0xf)   // row_shr:1
+      TN_DPP_MAX(0x112, 0xf)   // row_shr:2
+      TN_DPP_MAX(0x114, 0xf)   // row_shr:4
+      TN_DPP_MAX(0x118, 0xf)   // row_shr:8   -> lane 15 of every row holds the row maximum
+      TN_DPP_MAX(0x142, 0xa)   // row_bcast:15 into rows 1, 3
+      TN_DPP_MAX(0x143, 0xc)   // row_bcast:31 into rows 2, 3 -> lane 63 holds the wave maximum
+#undef TN_DPP_MAX
+      const unsigned wl = (unsigned)__builtin_amdgcn_readlane((int)l, 63);
+      const int i = (int)(0xffffffffu - wl);
+      if (lo == wl && (hi | lo) != 0u) {            // this lane owned the winner: record, drop it, rescan its stride
+        sel_idx[k] = i;
+        sel_val[k] = cand[i];
+        cand[i] = -INFINITY;
+        lane_best(hi, lo);
+      }
+    }
+  }
   __syncthreads();
+  DEC_STAMP(13);
+  // ---- bookkeeping ----
   if (t < beam) {
     const int idx = sel_idx[t];
     const bool use_prev = idx >= beam * V;
@@ -316,23 +491,25 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
     vlen[b * beam + t] = o_vlen[bid] + 1 - (use_prev ? 1 : 0);
     const int al = o_alive[bid] && word != eos;
     alive[b * beam + t] = al;
-    sel_idx[t] = bid;      // reuse: source beam
-    sel_val[t] = (float)word;
+    sel_par[t] = bid;
+    sel_word[t] = word;
     if (al) atomicOr(any_alive, 1);
   }
   __syncthreads();
+  DEC_STAMP(14);
   // ---- samples: copy the chosen parent's prefix (step entries: BOS + step-1 words), append the word ----
   for (int k = 0; k < beam; ++k) {
-    const int32_t *src = samples_in + ((long)b * beam + sel_idx[k]) * L;
+    const int32_t *src = samples_in + ((long)b * beam + sel_par[k]) * L;
     int32_t *dst = samples_out + ((long)b * beam + k) * L;
     for (int i = t; i < step; i += kBeamThreads) dst[i] = src[i];
-    if (t == 0) dst[step] = (int32_t)sel_val[k];
+    if (t == 0) dst[step] = sel_word[k];
   }
+  DEC_STAMP(15);
   // ---- next step's inputs, states re-gathered by parent beam ----
   for (int idx = t; idx < beam * K0; idx += kBeamThreads) {
     const int k = idx / K0, i = idx - k * K0;
-    const long r = (long)b * beam + k, pr = (long)b * beam + sel_idx[k];
-    const int word = (int)sel_val[k];
+    const long r = (long)b * beam + k, pr = (long)b * beam + sel_par[k];
+    const int word = sel_word[k];
     float v;
     if (i < E) v = emb[(long)(word > 0 ? word : 0) * E + i];
     else if (i < E + H) v = ctx[pr * H + i - E];
@@ -341,13 +518,14 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
   }
   for (int idx = t; idx < beam * H; idx += kBeamThreads) {
     const int k = idx / H, u = idx - k * H;
-    const long r = (long)b * beam + k, pr = (long)b * beam + sel_idx[k];
-    x1[r * K1 + 2 * H + u] = h1n[sel_idx[k] * H + u];
+    const long r = (long)b * beam + k, pr = (long)b * beam + sel_par[k];
+    x1[r * K1 + 2 * H + u] = h1n[u * NP + sel_par[k]];
     if (lstm) {
-      c1cur[r * H + u] = c1n[sel_idx[k] * H + u];
+      c1cur[r * H + u] = c1n[u * NP + sel_par[k]];
       c0cur[r * H + u] = c0n[pr * H + u];
     }
   }
+  DEC_STAMP(16);
 }
 
 // first step's inputs: x0 = [embed(bos), 0, h0 of the clip], x1[:, 2H:3H] = h1 of the clip, cell states (LSTM)
@@ -459,7 +637,7 @@ struct tn_gnmt {
   int32_t *alive, *vlen, *tok, *gather, *samples[2], *flag;
   // fused beam-search step: stacked [i2h | h2h] weights (4H rows each), transposed projection, step buffers
   float *w0c, *b0c, *w1c, *b1c, *wpT;
-  float *sx0, *sx1, *g0, *g1, *h0n, *ctxn, *c0n, *c0cur, *c1cur;
+  float *sx0, *sx1, *g0, *g1, *h0n, *ctxn, *c0n, *c0cur, *c1cur, *keyprojT;
   int B, T;
 };
 
@@ -579,7 +757,7 @@ extern "C" int tn_gnmt_create(tn_ctx *ctx, const tn_param *params, int n_params,
   g->sx0 = g->pool.alloc<float>(R * (embed + 2 * H)); g->sx1 = g->pool.alloc<float>(R * 3 * H);
   g->g0 = g->pool.alloc<float>(R * 4 * H); g->g1 = g->pool.alloc<float>(R * 4 * H);
   g->h0n = g->pool.alloc<float>(R * H); g->ctxn = g->pool.alloc<float>(R * H); g->c0n = g->pool.alloc<float>(R * H);
-  g->c0cur = g->pool.alloc<float>(R * H); g->c1cur = g->pool.alloc<float>(R * H);
+  g->c0cur = g->pool.alloc<float>(R * H); g->c1cur = g->pool.alloc<float>(R * H); g->keyprojT = g->pool.alloc<float>(BT * H);
   if (g->pool.failed) { tn_set_error("device allocation failed"); return fail(TN_ERR_NOMEM); }
   *out = g;
   return TN_OK;
@@ -600,6 +778,9 @@ extern "C" int tn_gnmt_encode(tn_gnmt *g, const float *src, const int32_t *valid
   if (rc) return rc;
   rc = launch_linear_f32(g->mem, H, g->wk, H, nullptr, g->keyproj, H, batch * steps, H, H, 0, s);
   if (rc) return rc;
+  hipLaunchKernelGGL(transpose_bth_kernel, dim3((H + 31) / 32, (steps + 31) / 32, batch), dim3(256), 0, s, (const float *)g->keyproj,
+                     g->keyprojT, steps, H);
+  TN_HIP_CHECK(hipGetLastError());
   if (mem_out) TN_HIP_CHECK(hipMemcpyAsync(mem_out, g->mem, sizeof(float) * (size_t)batch * steps * H, hipMemcpyDeviceToDevice, s));
   g->B = batch; g->T = steps;
   return TN_OK;
@@ -619,11 +800,11 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
   const int B = g->B, T = g->T, H = g->H, E = g->E, V = g->V, beam = g->beam, R = B * beam, L = g->maxL;
   const int K0 = E + 2 * H, K1 = 3 * H;
   const bool lstm = g->G == 4;
-  const int nbm = beam <= 4 ? 4 : beam <= 8 ? 8 : 16;
-  const size_t att_lds = (size_t)(H + T + 256) * sizeof(float);
-  const size_t beam_lds = ((size_t)2 * nbm * H + (size_t)5 * beam * V + 16) * sizeof(float);
+  const int nbm = beam <= 4 ? 4 : beam == 5 ? 5 : beam <= 8 ? 8 : 16;   // beam 5: the reference's flag default
+  const size_t att_lds = ((size_t)(H + T) * 4 + (size_t)4 * (T > H ? T : H)) * sizeof(float);   // one row per workgroup
+  const size_t beam_lds = ((size_t)2 * ((nbm + 3) & ~3) * H + (size_t)5 * beam * V + 16) * sizeof(float);
   TN_REQUIRE(beam_lds <= 64 * 1024 && att_lds <= 64 * 1024,
-             "tn_gnmt_beam_search: beam * (2*hidden + 5*vocab) or hidden + source length exceeds the step kernels' 64 KiB of LDS");
+             "tn_gnmt_beam_search: beam * (2*hidden + 5*vocab) or 8 * max(hidden, source length) exceeds the step kernels' 64 KiB of LDS");
   TN_HIP_CHECK(hipMemsetAsync(g->samples[0], 0xff, sizeof(int32_t) * (size_t)R * L, s));
   TN_HIP_CHECK(hipMemsetAsync(g->samples[1], 0xff, sizeof(int32_t) * (size_t)R * L, s));
   // decoder layer 0 starts from the encoder's BACKWARD layer-0 state, layer 1 from the uni layer (gnmt.py:146-150,224-252)
@@ -638,9 +819,9 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
     if ((i & 15) == 0) TN_HIP_CHECK(hipMemsetAsync(g->flag, 0, sizeof(int32_t), s));
     int rc = launch_linear_f32(g->sx0, K0, g->w0c, K0, g->b0c, g->g0, 4 * H, R, 4 * H, K0, 0, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(dec_attention_kernel, dim3(R), dim3(256), att_lds, s, (const float *)g->g0, (const float *)(g->sx0 + E + H), K0,
-                       (const float *)g->c0cur, lstm ? 1 : 0, g->h0n, g->c0n, g->sx1, K1, (const float *)g->keyproj,
-                       (const float *)g->mem, (const int32_t *)g->vl, g->ctxn, beam, T, H);
+    hipLaunchKernelGGL(dec_attention_kernel<1>, dim3(R), dim3(kBeamThreads), att_lds, s, (const float *)g->g0,
+                       (const float *)(g->sx0 + E + H), K0, (const float *)g->c0cur, lstm ? 1 : 0, g->h0n, g->c0n, g->sx1, K1,
+                       (const float *)g->keyprojT, (const float *)g->mem, (const int32_t *)g->vl, g->ctxn, beam, 1, T, H);
     rc = launch_linear_f32(g->sx1, K1, g->w1c, K1, g->b1c, g->g1, 4 * H, R, 4 * H, K1, 0, s);
     if (rc) return rc;
 #define TN_BEAM_LAUNCH(NBM)                                                                                              \
@@ -650,6 +831,7 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
                      beam, step, alpha, K, eos, g->scores, g->alive, g->vlen, (const int32_t *)g->samples[0],             \
                      g->samples[1], L, g->flag)
     if (nbm == 4) TN_BEAM_LAUNCH(4);
+    else if (nbm == 5) TN_BEAM_LAUNCH(5);
     else if (nbm == 8) TN_BEAM_LAUNCH(8);
     else TN_BEAM_LAUNCH(16);
 #undef TN_BEAM_LAUNCH
@@ -742,6 +924,14 @@ extern "C" int tn_masked_softmax_ce(tn_ctx *ctx, const float *logits, const int3
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;
 }
+
+#ifdef TN_DEC_STAMPS
+extern "C" int tn_dbg_dec_stamps(long long *out) {
+  TN_HIP_CHECK(hipDeviceSynchronize());
+  TN_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dec_stamps), sizeof(long long) * 24));
+  return TN_OK;
+}
+#endif
 
 extern "C" int tn_gnmt_destroy(tn_gnmt *g) {
   if (!g) return TN_OK;

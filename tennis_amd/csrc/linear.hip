@@ -10,70 +10,97 @@
 
 namespace {
 
+constexpr int kPD = 4;   // k-tiles of 16 in flight per thread (registers) ahead of the one being multiplied
+
+// F = 16x16 fragments per wave in each direction: tile = (32 F) x (32 F), 4 waves in a 2 x 2 arrangement (F = 2 is
+// what is launched; skinny problems go to linear_f32_skinny_kernel below).
+template <int F>
 __global__ __launch_bounds__(256) void linear_f32_kernel(const float *__restrict__ X, int ldx,
                                                          const float *__restrict__ Wt, int ldw,
                                                          const float *__restrict__ bias, float *__restrict__ Y,
                                                          int ldy, int M, int N, int K, int accumulate) {
-  __shared__ float As[64][17];
-  __shared__ float Bs[64][17];
+  constexpr int BT = 32 * F;             // tile rows (M) = tile columns (N)
+  __shared__ float As[2][BT][17];
+  __shared__ float Bs[2][BT][17];
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  const int srow = t >> 2, sk = (t & 3) * 4;
+  const int m0 = blockIdx.y * BT, n0 = blockIdx.x * BT;
+  // staging: F = 2: every thread loads one float4 of X and one of W per k-tile; F = 1: threads 0..127 load X, 128..255 W
+  const int srow = F == 2 ? t >> 2 : (t & 127) >> 2, sk = (t & 3) * 4;
+  const bool doA = F == 2 || t < 128, doB = F == 2 || t >= 128;
   const bool vec = ((ldx | ldw | K) & 3) == 0 && (((uintptr_t)X | (uintptr_t)Wt) & 15) == 0;
+  const int am = m0 + srow, bn = n0 + srow;
+  const float *xrow = X + (long)am * ldx, *wrow = Wt + (long)bn * ldw;
+  const int nk = (K + 15) / 16;
 
-  f32x4 acc[2][2];
+  f32x4 acc[F][F];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < F; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < F; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    float av[4] = {0.f, 0.f, 0.f, 0.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
-    const int am = m0 + srow, bn = n0 + srow, kk = k0 + sk;
+  // kPD k-tiles stay in flight in registers while one is multiplied; the MFMA order over k is that of a plain loop
+  float av[kPD][4], bv[kPD][4];
+  auto fetch = [&](int it, float *a4, float *b4) {
+    const int kk = it * 16 + sk;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a4[j] = 0.f; b4[j] = 0.f; }
+    if (it >= nk) return;
     if (vec) {
-      if (am < M && kk < K) { const float4 v = *(const float4 *)(X + (long)am * ldx + kk); av[0] = v.x; av[1] = v.y; av[2] = v.z; av[3] = v.w; }
-      if (bn < N && kk < K) { const float4 v = *(const float4 *)(Wt + (long)bn * ldw + kk); bv[0] = v.x; bv[1] = v.y; bv[2] = v.z; bv[3] = v.w; }
+      if (doA && am < M && kk < K) { const float4 v = *(const float4 *)(xrow + kk); a4[0] = v.x; a4[1] = v.y; a4[2] = v.z; a4[3] = v.w; }
+      if (doB && bn < N && kk < K) { const float4 v = *(const float4 *)(wrow + kk); b4[0] = v.x; b4[1] = v.y; b4[2] = v.z; b4[3] = v.w; }
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (am < M && kk + j < K) av[j] = X[(long)am * ldx + kk + j];
-        if (bn < N && kk + j < K) bv[j] = Wt[(long)bn * ldw + kk + j];
+        if (doA && am < M && kk + j < K) a4[j] = xrow[kk + j];
+        if (doB && bn < N && kk + j < K) b4[j] = wrow[kk + j];
       }
     }
-    __syncthreads();
+  };
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      As[srow][sk + j] = av[j];
-      Bs[srow][sk + j] = bv[j];
-    }
-    __syncthreads();
+  for (int p = 0; p < kPD; ++p) fetch(p, av[p], bv[p]);
+
+  for (int it0 = 0; it0 < nk; it0 += kPD) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int kq = ks * 4 + (lane >> 4);
-      float a[2], b[2];
+    for (int p = 0; p < kPD; ++p) {
+      const int it = it0 + p;
+      if (it < nk) {              // block-uniform
+        const int buf = it & 1;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        a[i] = As[wm * 32 + i * 16 + (lane & 15)][kq];
-        b[i] = Bs[wn * 32 + i * 16 + (lane & 15)][kq];
+        for (int j = 0; j < 4; ++j) {
+          if (doA) As[buf][srow][sk + j] = av[p][j];
+          if (doB) Bs[buf][srow][sk + j] = bv[p][j];
+        }
+        fetch(it + kPD, av[p], bv[p]);
+        __syncthreads();          // one barrier per k-tile: the other buffer is still being read by slower waves
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int kq = ks * 4 + (lane >> 4);
+          float a[F], b[F];
+#pragma unroll
+          for (int i = 0; i < F; ++i) {
+            a[i] = As[buf][wm * 16 * F + i * 16 + (lane & 15)][kq];
+            b[i] = Bs[buf][wn * 16 * F + i * 16 + (lane & 15)][kq];
+          }
+#pragma unroll
+          for (int i = 0; i < F; ++i)
+#pragma unroll
+            for (int j = 0; j < F; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
       }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
   // D[i=m][j=n]: lane: n = lane&15, m = (lane>>4)*4 + r
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < F; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 32 + j * 16 + (lane & 15);
+    for (int j = 0; j < F; ++j) {
+      const int n = n0 + wn * 16 * F + j * 16 + (lane & 15);
       if (n >= N) continue;
       const float bz = bias ? bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
+        const int m = m0 + wm * 16 * F + i * 16 + (lane >> 4) * 4 + r;
         if (m < M) {
           float *dst = Y + (long)m * ldy + n;
           const float v = acc[i][j][r] + bz;
@@ -83,13 +110,95 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float *__restrict
     }
 }
 
+// Skinny problems (fewer than two 64x64 tiles per CU): 32x32 tile, one 16x16 fragment per wave, BK = 32 so that a
+// k-tile carries 8 MFMAs per barrier.  Same k order per output element as linear_f32_kernel (one accumulator chain).
+__global__ __launch_bounds__(256) void linear_f32_skinny_kernel(const float *__restrict__ X, int ldx,
+                                                                const float *__restrict__ Wt, int ldw,
+                                                                const float *__restrict__ bias, float *__restrict__ Y,
+                                                                int ldy, int M, int N, int K, int accumulate) {
+  __shared__ float As[2][32][33];
+  __shared__ float Bs[2][32][33];
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int srow = t >> 3, sk = (t & 7) * 4;
+  const bool vec = ((ldx | ldw | K) & 3) == 0 && (((uintptr_t)X | (uintptr_t)Wt) & 15) == 0;
+  const int am = m0 + srow, bn = n0 + srow;
+  const float *xrow = X + (long)am * ldx, *wrow = Wt + (long)bn * ldw;
+  const int nk = (K + 31) / 32;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int PD = 3;
+  float av[PD][4], bv[PD][4];
+  auto fetch = [&](int it, float *a4, float *b4) {
+    const int kk = it * 32 + sk;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a4[j] = 0.f; b4[j] = 0.f; }
+    if (it >= nk) return;
+    if (vec) {
+      if (am < M && kk < K) { const float4 v = *(const float4 *)(xrow + kk); a4[0] = v.x; a4[1] = v.y; a4[2] = v.z; a4[3] = v.w; }
+      if (bn < N && kk < K) { const float4 v = *(const float4 *)(wrow + kk); b4[0] = v.x; b4[1] = v.y; b4[2] = v.z; b4[3] = v.w; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (am < M && kk + j < K) a4[j] = xrow[kk + j];
+        if (bn < N && kk + j < K) b4[j] = wrow[kk + j];
+      }
+    }
+  };
+#pragma unroll
+  for (int p = 0; p < PD; ++p) fetch(p, av[p], bv[p]);
+  for (int it0 = 0; it0 < nk; it0 += PD) {
+#pragma unroll
+    for (int p = 0; p < PD; ++p) {
+      const int it = it0 + p;
+      if (it < nk) {              // block-uniform
+        const int buf = it & 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          As[buf][srow][sk + j] = av[p][j];
+          Bs[buf][srow][sk + j] = bv[p][j];
+        }
+        fetch(it + PD, av[p], bv[p]);
+        __syncthreads();
+        float a[8], b[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          a[ks] = As[buf][wm * 16 + (lane & 15)][ks * 4 + (lane >> 4)];
+          b[ks] = Bs[buf][wn * 16 + (lane & 15)][ks * 4 + (lane >> 4)];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], b[ks], acc, 0, 0, 0);
+      }
+    }
+  }
+  const int n = n0 + wn * 16 + (lane & 15);
+  if (n < N) {
+    const float bz = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm * 16 + (lane >> 4) * 4 + r;
+      if (m < M) {
+        float *dst = Y + (long)m * ldy + n;
+        const float v = acc[r] + bz;
+        *dst = accumulate ? (*dst + v) : v;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 int launch_linear_f32(const float *X, int ldx, const float *Wt, int ldw, const float *bias, float *Y, int ldy,
                       int M, int N, int K, int accumulate, hipStream_t s) {
   if (M <= 0 || N <= 0) return TN_OK;
-  const dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
-  hipLaunchKernelGGL(linear_f32_kernel, grid, block, 0, s, X, ldx, Wt, ldw, bias, Y, ldy, M, N, K, accumulate);
+  const long big = (long)((N + 63) / 64) * ((M + 63) / 64);
+  if (big >= 512) {
+    const dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
+    hipLaunchKernelGGL(linear_f32_kernel<2>, grid, block, 0, s, X, ldx, Wt, ldw, bias, Y, ldy, M, N, K, accumulate);
+  } else {   // fewer than two 64x64 tiles per CU: quarter-size tiles put four times as many CUs to work
+    const dim3 grid((N + 31) / 32, (M + 31) / 32), block(256);
+    hipLaunchKernelGGL(linear_f32_skinny_kernel, grid, block, 0, s, X, ldx, Wt, ldw, bias, Y, ldy, M, N, K, accumulate);
+  }
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;
 }
