@@ -20,18 +20,25 @@
 
 namespace {
 
-constexpr int NB = 4;  // batch rows per workgroup
-
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <int G>  // 3 = GRU [r,z,n], 4 = LSTM [i,f,g,o]
-__global__ void rnn_recurrent_kernel(const float *__restrict__ gi, int ldgi,  // [B*T][dirs*G*H] i2h + b_i2h
-                                     const float *__restrict__ whT,           // [dirs][H][G*H]
-                                     const float *__restrict__ bh,            // [dirs][G*H]
-                                     const int32_t *__restrict__ valid_len,   // [B] or null
-                                     float *__restrict__ seq, int ldo,        // [B*T][dirs*H]
-                                     float *__restrict__ h_last, float *__restrict__ c_last,  // [dirs][B][H]
-                                     int B, int T, int H) {
+// One workgroup = one direction x NB batch rows, all T steps; thread j owns gate row j of W_hh.
+//   * Per step a CU needs 4*G*H*H bytes of W_hh: at 64 B/clk of L1 fill that stream alone costs as much as the
+//     arithmetic, so the first KR k-values of the thread's weight column live in REGISTERS for the whole sequence
+//     (KR = H when the block is small enough for a 256-register budget: nothing is re-read), the rest is streamed
+//     with 16 loads in flight (batched by hand: the compiler otherwise waits for every group of four).
+//   * NB = 4 rows when the batch fills the chip, 1 otherwise: the step is also bound by FMA issue and by the LDS
+//     reads of h (both ~ NB*H per thread), so small batches are spread over four times as many CUs.
+// The dot product runs over k in ascending order whatever KR and NB are (bit-identical results).
+template <int G, int NB, int KR, int MAXT>  // G: 3 = GRU [r,z,n], 4 = LSTM [i,f,g,o]
+__global__ __launch_bounds__(MAXT) void rnn_recurrent_kernel(
+    const float *__restrict__ gi, int ldgi,  // [B*T][dirs*G*H] i2h + b_i2h
+    const float *__restrict__ whT,           // [dirs][H][G*H]
+    const float *__restrict__ bh,            // [dirs][G*H]
+    const int32_t *__restrict__ valid_len,   // [B] or null
+    float *__restrict__ seq, int ldo,        // [B*T][dirs*H]
+    float *__restrict__ h_last, float *__restrict__ c_last,  // [dirs][B][H]
+    int B, int T, int H) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int GH = G * H;
   float *hs = lds;                 // [NB][H]
@@ -42,21 +49,49 @@ __global__ void rnn_recurrent_kernel(const float *__restrict__ gi, int ldgi,  //
   const int b0 = blockIdx.x * NB;
   const float *wcol = whT + (long)dir * H * GH + j;
   const float bj = bh[dir * GH + j];
+  float wr[KR > 0 ? KR : 1];
+#pragma unroll
+  for (int k = 0; k < KR; ++k) wr[k] = wcol[(long)k * GH];
 
   for (int i = j; i < NB * H; i += GH) {
     hs[i] = 0.f;
     if (G == 4) cs[i] = 0.f;
   }
-  int vl[NB];
-#pragma unroll
-  for (int b = 0; b < NB; ++b) vl[b] = (b0 + b < B) ? (valid_len ? valid_len[b0 + b] : T) : 0;
   __syncthreads();
 
   for (int s = 0; s < T; ++s) {
     float acc[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[b] = bj;
-    for (int k = 0; k < H; k += 4) {
+#pragma unroll
+    for (int k = 0; k < KR; k += 4) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float4 hv = *(const float4 *)(hs + b * H + k);
+        acc[b] = fmaf(wr[k + 0], hv.x, acc[b]);
+        acc[b] = fmaf(wr[k + 1], hv.y, acc[b]);
+        acc[b] = fmaf(wr[k + 2], hv.z, acc[b]);
+        acc[b] = fmaf(wr[k + 3], hv.w, acc[b]);
+      }
+    }
+    int k = KR;
+    for (; k + 16 <= H; k += 16) {
+      float w[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) w[i] = wcol[(long)(k + i) * GH];
+#pragma unroll
+      for (int i = 0; i < 16; i += 4) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const float4 hv = *(const float4 *)(hs + b * H + k + i);
+          acc[b] = fmaf(w[i + 0], hv.x, acc[b]);
+          acc[b] = fmaf(w[i + 1], hv.y, acc[b]);
+          acc[b] = fmaf(w[i + 2], hv.z, acc[b]);
+          acc[b] = fmaf(w[i + 3], hv.w, acc[b]);
+        }
+      }
+    }
+    for (; k < H; k += 4) {
       const float w0 = wcol[(long)(k + 0) * GH], w1 = wcol[(long)(k + 1) * GH];
       const float w2 = wcol[(long)(k + 2) * GH], w3 = wcol[(long)(k + 3) * GH];
 #pragma unroll
@@ -100,7 +135,6 @@ __global__ void rnn_recurrent_kernel(const float *__restrict__ gi, int ldgi,  //
     }
     __syncthreads();
   }
-  (void)vl;
   for (int idx = j; idx < NB * H; idx += GH) {
     const int b = idx / H, u = idx - b * H;
     if (b0 + b >= B) continue;
@@ -143,14 +177,28 @@ int launch_rnn_recurrent(int gates, const float *gi, int ldgi, const float *whT,
                          int H, int dirs, hipStream_t s) {
   TN_REQUIRE(gates == 3 || gates == 4, "rnn: gates must be 3 or 4");
   TN_REQUIRE(gates * H <= 1024 && H % 4 == 0, "rnn: gates*hidden must be <= 1024 and hidden % 4 == 0");
-  const dim3 grid((B + NB - 1) / NB, dirs), block(gates * H);
-  const size_t lds = (size_t)(NB * H * 2 + NB * gates * H) * sizeof(float);
-  if (gates == 3)
-    hipLaunchKernelGGL(rnn_recurrent_kernel<3>, grid, block, lds, s, gi, ldgi, whT, bh, valid_len, seq, ldo, h_last,
-                       c_last, B, T, H);
-  else
-    hipLaunchKernelGGL(rnn_recurrent_kernel<4>, grid, block, lds, s, gi, ldgi, whT, bh, valid_len, seq, ldo, h_last,
-                       c_last, B, T, H);
+  const int threads = gates * H;
+  // rows per workgroup: 4 when that still gives every CU a workgroup, else 1 (latency-bound small batches)
+  const int nb = ((B + 3) / 4) * dirs >= 256 ? 4 : 1;
+  // register-resident prefix of each weight column, bounded by the VGPR budget the block size leaves
+  const int kr = (threads <= 512 && H >= 128) ? 128 : (threads <= 768 && H >= 96) ? 96 : H >= 64 ? 64 : 0;
+  const dim3 grid((B + nb - 1) / nb, dirs), block(threads);
+  const size_t lds = (size_t)(nb * H * 2 + nb * gates * H) * sizeof(float);
+#define TN_RNN_LAUNCH(G_, NB_, KR_, MT_)                                                                               \
+  hipLaunchKernelGGL((rnn_recurrent_kernel<G_, NB_, KR_, MT_>), grid, block, lds, s, gi, ldgi, whT, bh, valid_len, seq, \
+                     ldo, h_last, c_last, B, T, H)
+#define TN_RNN_PICK(G_, NB_)                                   \
+  do {                                                         \
+    if (kr == 128) TN_RNN_LAUNCH(G_, NB_, 128, 512);           \
+    else if (kr == 96) TN_RNN_LAUNCH(G_, NB_, 96, 768);        \
+    else if (kr == 64) TN_RNN_LAUNCH(G_, NB_, 64, 1024);       \
+    else TN_RNN_LAUNCH(G_, NB_, 0, 1024);                      \
+  } while (0)
+  // (register-resident weights only with one row per workgroup: with four the unrolled prefix spills)
+  if (gates == 3) { if (nb == 4) TN_RNN_LAUNCH(3, 4, 0, 1024); else TN_RNN_PICK(3, 1); }
+  else { if (nb == 4) TN_RNN_LAUNCH(4, 4, 0, 1024); else TN_RNN_PICK(4, 1); }
+#undef TN_RNN_PICK
+#undef TN_RNN_LAUNCH
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;
 }
