@@ -717,8 +717,8 @@ extern "C" int tn_head_forward_backward(tn_head *h, const float *x, const int32_
 #define TN_TRY(e) do { rc = (e); if (rc) return rc; } while (0)
   // forward: one i2h GEMM for both directions, recurrence with saved gates, max over T (argmax kept), Dense
   TN_TRY(launch_linear_f32(x, F, w + h->o_wi, F, w + h->o_bi, h->gi, 2 * GH, M, 2 * GH, F, 0, s));
-  if (lstm) TN_TRY(launch_lstm_train_fwd(h->gi, h->whT, w + h->o_bh, h->seq, h->gates, B, T, H, s));
-  else TN_TRY(launch_gru_train_fwd(h->gi, h->whT, w + h->o_bh, h->seq, h->gates, B, T, H, s));
+  TN_TRY(launch_rnn_recurrent(h->G, h->gi, 2 * GH, h->whT, w + h->o_bh, nullptr, h->seq, 2 * H, nullptr, nullptr, B, T, H, 2, s,
+                              h->gates));
   TN_TRY(launch_pool_max_arg(h->seq, B, T, 2 * H, h->pooled, h->arg, s));
   TN_TRY(launch_linear_f32(h->pooled, 2 * H, w + h->o_wd, 2 * H, w + h->o_bd, h->logits, C, B, C, 2 * H, 0, s));
   TN_TRY(launch_softmax_ce(h->logits, labels, B, C, h->loss, h->dlog, s));

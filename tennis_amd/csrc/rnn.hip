@@ -38,6 +38,7 @@ __global__ __launch_bounds__(MAXT) void rnn_recurrent_kernel(
     const int32_t *__restrict__ valid_len,   // [B] or null
     float *__restrict__ seq, int ldo,        // [B*T][dirs*H]
     float *__restrict__ h_last, float *__restrict__ c_last,  // [dirs][B][H]
+    float *__restrict__ save,                // [dirs][B*T][(G+1)*H] or null: what BPTT needs (train.hip)
     int B, int T, int H) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int GH = G * H;
@@ -121,6 +122,10 @@ __global__ __launch_bounds__(MAXT) void rnn_recurrent_kernel(
         const float z = sigmoidf_(g[H + u] + q[H + u]);
         const float n = tanhf(g[2 * H + u] + r * q[2 * H + u]);
         hn = (1.f - z) * n + z * hs[idx];
+        if (save) {
+          float *sv = save + ((long)dir * B * T + (long)bg * T + ti) * (4 * H);
+          sv[u] = r; sv[H + u] = z; sv[2 * H + u] = n; sv[3 * H + u] = q[2 * H + u];
+        }
       } else {
         const float ig = sigmoidf_(g[u] + q[u]);
         const float fg = sigmoidf_(g[H + u] + q[H + u]);
@@ -129,6 +134,10 @@ __global__ __launch_bounds__(MAXT) void rnn_recurrent_kernel(
         const float c2 = fg * cs[idx] + ig * gg;
         cs[idx] = c2;
         hn = og * tanhf(c2);
+        if (save) {
+          float *sv = save + ((long)dir * B * T + (long)bg * T + ti) * (5 * H);
+          sv[u] = ig; sv[H + u] = fg; sv[2 * H + u] = gg; sv[3 * H + u] = og; sv[4 * H + u] = c2;
+        }
       }
       hs[idx] = hn;
       seq[((long)bg * T + ti) * ldo + dir * H + u] = hn;
@@ -174,7 +183,7 @@ __global__ void prf1_kernel(const float *__restrict__ logits, const int32_t *__r
 
 int launch_rnn_recurrent(int gates, const float *gi, int ldgi, const float *whT, const float *bh,
                          const int32_t *valid_len, float *seq, int ldo, float *h_last, float *c_last, int B, int T,
-                         int H, int dirs, hipStream_t s) {
+                         int H, int dirs, hipStream_t s, float *save) {
   TN_REQUIRE(gates == 3 || gates == 4, "rnn: gates must be 3 or 4");
   TN_REQUIRE(gates * H <= 1024 && H % 4 == 0, "rnn: gates*hidden must be <= 1024 and hidden % 4 == 0");
   const int threads = gates * H;
@@ -186,7 +195,7 @@ int launch_rnn_recurrent(int gates, const float *gi, int ldgi, const float *whT,
   const size_t lds = (size_t)(nb * H * 2 + nb * gates * H) * sizeof(float);
 #define TN_RNN_LAUNCH(G_, NB_, KR_, MT_)                                                                               \
   hipLaunchKernelGGL((rnn_recurrent_kernel<G_, NB_, KR_, MT_>), grid, block, lds, s, gi, ldgi, whT, bh, valid_len, seq, \
-                     ldo, h_last, c_last, B, T, H)
+                     ldo, h_last, c_last, save, B, T, H)
 #define TN_RNN_PICK(G_, NB_)                                   \
   do {                                                         \
     if (kr == 128) TN_RNN_LAUNCH(G_, NB_, 128, 512);           \

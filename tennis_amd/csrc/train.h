@@ -3,8 +3,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-int launch_gru_train_fwd(const float *gi, const float *whT, const float *bh, float *seq, float *gates, int B, int T,
-                         int H, hipStream_t s);
 int launch_pool_max_arg(const float *x, int B, int T, int F, float *y, int32_t *arg, hipStream_t s);
 int launch_softmax_ce(const float *logits, const int32_t *labels, int B, int C, float *loss, float *dlogits,
                       hipStream_t s);
@@ -13,8 +11,6 @@ int launch_dense_bwd(const float *dlogits, const float *pooled, const float *wd,
 int launch_scatter_pool_grad(const float *dpooled, const int32_t *arg, int B, int T, int F, float *dseq, hipStream_t s);
 int launch_gru_train_bwd(const float *seq, const float *gates, const float *dseq, const float *wh, float *dgi,
                          float *dgh, float *hprev, int B, int T, int H, hipStream_t s);
-int launch_lstm_train_fwd(const float *gi, const float *whT, const float *bh, float *seq, float *gates, int B, int T,
-                          int H, hipStream_t s);
 int launch_lstm_train_bwd(const float *seq, const float *gates, const float *dseq, const float *wh, float *dgi,
                           float *hprev, int B, int T, int H, hipStream_t s);
 int launch_gemm_tn_f32(const float *A, int lda, const float *Bm, int ldb, float *Cm, int ldc, int M, int N, int K,

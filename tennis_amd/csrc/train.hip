@@ -3,7 +3,8 @@
 // reference train.py:298-299 (gluon.Trainer 'sgd'), :324 (SoftmaxCrossEntropyLoss), :410-424 (record / backward /
 // trainer.step(batch_size)) with models/vision/definitions.py:94-110 as the model.  fp32 throughout.
 //
-// Forward keeps what BPTT needs (r, z, n and the h2h candidate term per step); backward walks the steps in the
+// The forward recurrence is rnn.hip's persistent kernel with its `save` output (r, z, n and the h2h candidate term per
+// step; LSTM: i, f, g, o, c); backward walks the steps in the
 // reverse of each direction's own order inside one persistent workgroup per (direction, 4 batch rows), the
 // weight gradients are three transposed GEMMs over all B*T rows afterwards.
 #include "common.h"
@@ -11,63 +12,8 @@
 
 namespace {
 
-constexpr int NB = 4;   // batch rows per workgroup of the recurrent kernels
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-// gates buffer: [dir][B*T][4H] = r | z | n | (W_hn h + b_hn)
-__global__ void gru_train_fwd_kernel(const float *__restrict__ gi,    // [B*T][2*3H]  x W_ih^T + b_ih, both directions
-                                     const float *__restrict__ whT,   // [2][H][3H]
-                                     const float *__restrict__ bh,    // [2][3H]
-                                     float *__restrict__ seq,         // [B*T][2H]
-                                     float *__restrict__ gates, int B, int T, int H) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int GH = 3 * H;
-  float *hs = lds;             // [NB][H]
-  float *gh = hs + NB * H;     // [NB][3H]
-  const int j = threadIdx.x, dir = blockIdx.y, b0 = blockIdx.x * NB;
-  const float *wcol = whT + (long)dir * H * GH + j;
-  const float bj = bh[dir * GH + j];
-  for (int i = j; i < NB * H; i += GH) hs[i] = 0.f;
-  __syncthreads();
-  for (int s = 0; s < T; ++s) {
-    const int t = dir ? T - 1 - s : s;
-    float acc[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) acc[b] = bj;
-    for (int k = 0; k < H; k += 4) {
-      const float w0 = wcol[(long)(k + 0) * GH], w1 = wcol[(long)(k + 1) * GH];
-      const float w2 = wcol[(long)(k + 2) * GH], w3 = wcol[(long)(k + 3) * GH];
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const float4 hv = *(const float4 *)(hs + b * H + k);
-        acc[b] = fmaf(w0, hv.x, acc[b]);
-        acc[b] = fmaf(w1, hv.y, acc[b]);
-        acc[b] = fmaf(w2, hv.z, acc[b]);
-        acc[b] = fmaf(w3, hv.w, acc[b]);
-      }
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) gh[b * GH + j] = acc[b];
-    __syncthreads();
-    for (int idx = j; idx < NB * H; idx += GH) {
-      const int b = idx / H, u = idx - b * H, bg = b0 + b;
-      if (bg >= B) continue;
-      const long row = (long)bg * T + t;
-      const float *g = gi + row * (2 * GH) + dir * GH;
-      const float *q = gh + b * GH;
-      const float r = sigm(g[u] + q[u]);
-      const float z = sigm(g[H + u] + q[H + u]);
-      const float n = tanhf(g[2 * H + u] + r * q[2 * H + u]);
-      const float hn = (1.f - z) * n + z * hs[idx];
-      float *sv = gates + ((long)dir * B * T + row) * (4 * H);
-      sv[u] = r; sv[H + u] = z; sv[2 * H + u] = n; sv[3 * H + u] = q[2 * H + u];
-      hs[idx] = hn;
-      seq[row * (2 * H) + dir * H + u] = hn;
-    }
-    __syncthreads();
-  }
-}
 
 __global__ void pool_max_arg_kernel(const float *__restrict__ x, int B, int T, int F, float *__restrict__ y,
                                     int32_t *__restrict__ arg) {
@@ -135,8 +81,11 @@ __global__ void scatter_pool_grad_kernel(const float *__restrict__ dpooled, cons
   dseq[id] = arg[(long)b * F + f] == t ? dpooled[(long)b * F + f] : 0.f;
 }
 
-// BPTT of one direction for NB batch rows: thread j = (gate block g, unit u)
-__global__ void gru_train_bwd_kernel(const float *__restrict__ seq, const float *__restrict__ gates,
+// BPTT of one direction for NB batch rows: thread j = (gate block g, unit u).  As in rnn.hip's forward kernel the
+// first KR values of the thread's W_hh column (loop-invariant over the steps) stay in registers, the rest is streamed
+// 16 loads at a time, and small batches run one row per workgroup.
+template <int NB, int KR, int MAXT>
+__global__ __launch_bounds__(MAXT) void gru_train_bwd_kernel(const float *__restrict__ seq, const float *__restrict__ gates,
                                      const float *__restrict__ dseq, const float *__restrict__ wh,   // [2][3H][H]
                                      float *__restrict__ dgi, float *__restrict__ dgh,               // [B*T][2*3H]
                                      float *__restrict__ hprev,                                      // [2][B*T][H]
@@ -149,6 +98,9 @@ __global__ void gru_train_bwd_kernel(const float *__restrict__ seq, const float 
   const int j = threadIdx.x, dir = blockIdx.y, b0 = blockIdx.x * NB;
   const int g = j / H, u = j - g * H;
   const float *wrow = wh + (long)dir * GH * H + (long)g * H * H + u;   // W_hh[g*H + jj][u], jj = 0..H-1
+  float wr[KR > 0 ? KR : 1];
+#pragma unroll
+  for (int k = 0; k < KR; ++k) wr[k] = wrow[(long)k * H];
   for (int i = j; i < NB * H; i += GH) dh[i] = 0.f;
   __syncthreads();
   for (int s = T - 1; s >= 0; --s) {          // reverse of the direction's own walking order
@@ -181,7 +133,35 @@ __global__ void gru_train_bwd_kernel(const float *__restrict__ seq, const float 
     float acc[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[b] = 0.f;
-    for (int jj = 0; jj < H; jj += 4) {
+#pragma unroll
+    for (int jj = 0; jj < KR; jj += 4) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float4 dv = *(const float4 *)(dgs + b * GH + g * H + jj);
+        acc[b] = fmaf(wr[jj + 0], dv.x, acc[b]);
+        acc[b] = fmaf(wr[jj + 1], dv.y, acc[b]);
+        acc[b] = fmaf(wr[jj + 2], dv.z, acc[b]);
+        acc[b] = fmaf(wr[jj + 3], dv.w, acc[b]);
+      }
+    }
+    int jj = KR;
+    for (; jj + 16 <= H; jj += 16) {
+      float w[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) w[i] = wrow[(long)(jj + i) * H];
+#pragma unroll
+      for (int i = 0; i < 16; i += 4) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const float4 dv = *(const float4 *)(dgs + b * GH + g * H + jj + i);
+          acc[b] = fmaf(w[i + 0], dv.x, acc[b]);
+          acc[b] = fmaf(w[i + 1], dv.y, acc[b]);
+          acc[b] = fmaf(w[i + 2], dv.z, acc[b]);
+          acc[b] = fmaf(w[i + 3], dv.w, acc[b]);
+        }
+      }
+    }
+    for (; jj < H; jj += 4) {
       const float w0 = wrow[(long)(jj + 0) * H], w1 = wrow[(long)(jj + 1) * H];
       const float w2 = wrow[(long)(jj + 2) * H], w3 = wrow[(long)(jj + 3) * H];
 #pragma unroll
@@ -204,68 +184,11 @@ __global__ void gru_train_bwd_kernel(const float *__restrict__ seq, const float 
   }
 }
 
-// ---- LSTM (gate order [i, f, g, o], mx.gluon.rnn.LSTM) ----------------------------------------------------------
-// gates buffer: [dir][B*T][5H] = i | f | g | o | c_t
-__global__ void lstm_train_fwd_kernel(const float *__restrict__ gi,    // [B*T][2*4H]  x W_ih^T + b_ih, both directions
-                                      const float *__restrict__ whT,   // [2][H][4H]
-                                      const float *__restrict__ bh,    // [2][4H]
-                                      float *__restrict__ seq,         // [B*T][2H]
-                                      float *__restrict__ gates, int B, int T, int H) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int GH = 4 * H;
-  float *hs = lds;             // [NB][H]
-  float *cs = hs + NB * H;     // [NB][H]
-  float *gh = cs + NB * H;     // [NB][4H]
-  const int j = threadIdx.x, dir = blockIdx.y, b0 = blockIdx.x * NB;
-  const float *wcol = whT + (long)dir * H * GH + j;
-  const float bj = bh[dir * GH + j];
-  for (int i = j; i < NB * H; i += GH) { hs[i] = 0.f; cs[i] = 0.f; }
-  __syncthreads();
-  for (int s = 0; s < T; ++s) {
-    const int t = dir ? T - 1 - s : s;
-    float acc[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) acc[b] = bj;
-    for (int k = 0; k < H; k += 4) {
-      const float w0 = wcol[(long)(k + 0) * GH], w1 = wcol[(long)(k + 1) * GH];
-      const float w2 = wcol[(long)(k + 2) * GH], w3 = wcol[(long)(k + 3) * GH];
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const float4 hv = *(const float4 *)(hs + b * H + k);
-        acc[b] = fmaf(w0, hv.x, acc[b]);
-        acc[b] = fmaf(w1, hv.y, acc[b]);
-        acc[b] = fmaf(w2, hv.z, acc[b]);
-        acc[b] = fmaf(w3, hv.w, acc[b]);
-      }
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) gh[b * GH + j] = acc[b];
-    __syncthreads();
-    for (int idx = j; idx < NB * H; idx += GH) {
-      const int b = idx / H, u = idx - b * H, bg = b0 + b;
-      if (bg >= B) continue;
-      const long row = (long)bg * T + t;
-      const float *g = gi + row * (2 * GH) + dir * GH;
-      const float *q = gh + b * GH;
-      const float ig = sigm(g[u] + q[u]);
-      const float fg = sigm(g[H + u] + q[H + u]);
-      const float gg = tanhf(g[2 * H + u] + q[2 * H + u]);
-      const float og = sigm(g[3 * H + u] + q[3 * H + u]);
-      const float c2 = fg * cs[idx] + ig * gg;
-      const float hn = og * tanhf(c2);
-      float *sv = gates + ((long)dir * B * T + row) * (5 * H);
-      sv[u] = ig; sv[H + u] = fg; sv[2 * H + u] = gg; sv[3 * H + u] = og; sv[4 * H + u] = c2;
-      cs[idx] = c2;
-      hs[idx] = hn;
-      seq[row * (2 * H) + dir * H + u] = hn;
-    }
-    __syncthreads();
-  }
-}
-
+// ---- LSTM (gate order [i, f, g, o], mx.gluon.rnn.LSTM); saved per step: i | f | g | o | c_t ----
 // BPTT of one LSTM direction for NB batch rows: thread j = (gate block g of 4, unit u).  The pre-activation
 // gradient is the same for the i2h and the h2h branch, so only dgi is written (the caller uses it for both).
-__global__ void lstm_train_bwd_kernel(const float *__restrict__ seq, const float *__restrict__ gates,
+template <int NB, int KR, int MAXT>
+__global__ __launch_bounds__(MAXT) void lstm_train_bwd_kernel(const float *__restrict__ seq, const float *__restrict__ gates,
                                       const float *__restrict__ dseq, const float *__restrict__ wh,   // [2][4H][H]
                                       float *__restrict__ dgi,                                        // [B*T][2*4H]
                                       float *__restrict__ hprev,                                      // [2][B*T][H]
@@ -279,6 +202,9 @@ __global__ void lstm_train_bwd_kernel(const float *__restrict__ seq, const float
   const int j = threadIdx.x, dir = blockIdx.y, b0 = blockIdx.x * NB;
   const int g = j / H, u = j - g * H;
   const float *wrow = wh + (long)dir * GH * H + (long)g * H * H + u;   // W_hh[g*H + jj][u], jj = 0..H-1
+  float wr[KR > 0 ? KR : 1];
+#pragma unroll
+  for (int k = 0; k < KR; ++k) wr[k] = wrow[(long)k * H];
   for (int i = j; i < NB * H; i += GH) { dh[i] = 0.f; dc[i] = 0.f; }
   __syncthreads();
   for (int s = T - 1; s >= 0; --s) {
@@ -316,7 +242,35 @@ __global__ void lstm_train_bwd_kernel(const float *__restrict__ seq, const float
     float acc[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[b] = 0.f;
-    for (int jj = 0; jj < H; jj += 4) {
+#pragma unroll
+    for (int jj = 0; jj < KR; jj += 4) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float4 dv = *(const float4 *)(dgs + b * GH + g * H + jj);
+        acc[b] = fmaf(wr[jj + 0], dv.x, acc[b]);
+        acc[b] = fmaf(wr[jj + 1], dv.y, acc[b]);
+        acc[b] = fmaf(wr[jj + 2], dv.z, acc[b]);
+        acc[b] = fmaf(wr[jj + 3], dv.w, acc[b]);
+      }
+    }
+    int jj = KR;
+    for (; jj + 16 <= H; jj += 16) {
+      float w[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) w[i] = wrow[(long)(jj + i) * H];
+#pragma unroll
+      for (int i = 0; i < 16; i += 4) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const float4 dv = *(const float4 *)(dgs + b * GH + g * H + jj + i);
+          acc[b] = fmaf(w[i + 0], dv.x, acc[b]);
+          acc[b] = fmaf(w[i + 1], dv.y, acc[b]);
+          acc[b] = fmaf(w[i + 2], dv.z, acc[b]);
+          acc[b] = fmaf(w[i + 3], dv.w, acc[b]);
+        }
+      }
+    }
+    for (; jj < H; jj += 4) {
       const float w0 = wrow[(long)(jj + 0) * H], w1 = wrow[(long)(jj + 1) * H];
       const float w2 = wrow[(long)(jj + 2) * H], w3 = wrow[(long)(jj + 3) * H];
 #pragma unroll
@@ -340,48 +294,113 @@ __global__ void lstm_train_bwd_kernel(const float *__restrict__ seq, const float
   }
 }
 
-// C[M][N] = A^T B, A [K][lda] (M columns), B [K][ldb] (N columns); 64x64 tile, 256 threads x 4x4 outputs
+// C[M][N] = A^T B, A [K][lda] (M columns), B [K][ldb] (N columns): the weight gradients dW = dG^T X over all B*T rows.
+// Exact-f32 MFMA 16x16x4, 64x64 tile, 4 waves each 32x32.  Both operands are k-major in memory, which is what the
+// fragments want (lane = (column, k)): rows of 64 columns are staged as they lie, no transposes.  kTnPD k-tiles of 16
+// stay in flight in registers (the compiler does not overlap a plain load -> LDS -> MFMA loop by itself).
+constexpr int kTnPD = 4;
 __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const float *__restrict__ A, int lda,
                                                           const float *__restrict__ Bm, int ldb,
                                                           float *__restrict__ Cm, int ldc, int M, int N, int K) {
-  __shared__ float As[16][64 + 4], Bs[16][64 + 4];
-  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  __shared__ float As[2][16][64 + 4], Bs[2][16][64 + 4];
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6, wm = wid >> 1, wn = wid & 1;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  float acc[4][4] = {};
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    for (int i = t; i < 16 * 64; i += 256) {
-      const int kk = i >> 6, c = i & 63;
-      As[kk][c] = (k0 + kk < K && m0 + c < M) ? A[(long)(k0 + kk) * lda + m0 + c] : 0.f;
-      Bs[kk][c] = (k0 + kk < K && n0 + c < N) ? Bm[(long)(k0 + kk) * ldb + n0 + c] : 0.f;
+  const int sk = t >> 4, sc = (t & 15) * 4;           // staging: k row, 4 columns
+  const bool vec = ((lda | ldb) & 3) == 0 && (((uintptr_t)A | (uintptr_t)Bm) & 15) == 0 && m0 + 64 <= M && n0 + 64 <= N;
+  const int nk = (K + 15) / 16;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) acc[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float av[kTnPD][4], bv[kTnPD][4];
+  auto fetch = [&](int it, float *a4, float *b4) {
+    const int k = it * 16 + sk;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { a4[q] = 0.f; b4[q] = 0.f; }
+    if (it >= nk || k >= K) return;
+    if (vec) {
+      const float4 va = *(const float4 *)(A + (long)k * lda + m0 + sc), vb = *(const float4 *)(Bm + (long)k * ldb + n0 + sc);
+      a4[0] = va.x; a4[1] = va.y; a4[2] = va.z; a4[3] = va.w;
+      b4[0] = vb.x; b4[1] = vb.y; b4[2] = vb.z; b4[3] = vb.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (m0 + sc + q < M) a4[q] = A[(long)k * lda + m0 + sc + q];
+        if (n0 + sc + q < N) b4[q] = Bm[(long)k * ldb + n0 + sc + q];
+      }
     }
-    __syncthreads();
+  };
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      float a[4], b[4];
+  for (int p = 0; p < kTnPD; ++p) fetch(p, av[p], bv[p]);
+  for (int it0 = 0; it0 < nk; it0 += kTnPD) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
+    for (int p = 0; p < kTnPD; ++p) {
+      const int it = it0 + p;
+      if (it < nk) {              // block-uniform
+        const int buf = it & 1;
+        *(float4 *)&As[buf][sk][sc] = make_float4(av[p][0], av[p][1], av[p][2], av[p][3]);
+        *(float4 *)&Bs[buf][sk][sc] = make_float4(bv[p][0], bv[p][1], bv[p][2], bv[p][3]);
+        fetch(it + kTnPD, av[p], bv[p]);
+        __syncthreads();
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int ks = 0; ks < 4; ++ks) {
+          const int kq = ks * 4 + (lane >> 4);
+          float a[2], b[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[i][q] = fmaf(a[i], b[q], acc[i][q]);
+          for (int i = 0; i < 2; ++i) {
+            a[i] = As[buf][kq][wm * 32 + i * 16 + (lane & 15)];
+            b[i] = Bs[buf][kq][wn * 32 + i * 16 + (lane & 15)];
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[q], acc[i][q], 0, 0, 0);
+        }
+      }
     }
-    __syncthreads();
   }
+  // D[i=m][j=n]: lane: n = lane&15, m = (lane>>4)*4 + r
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + q;
-      if (m < M && n < N) Cm[(long)m * ldc + n] = acc[i][q];
+    for (int q = 0; q < 2; ++q) {
+      const int n = n0 + wn * 32 + q * 16 + (lane & 15);
+      if (n >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
+        if (m < M) Cm[(long)m * ldc + n] = acc[i][q][r];
+      }
     }
 }
 
-__global__ void colsum_f32_kernel(const float *__restrict__ A, int lda, int rows, int cols, float *__restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+// column sums of A [rows][lda] (the bias gradients): 64 columns per workgroup, 16 row groups, 16 loads in flight,
+// partials combined in a fixed order
+__global__ __launch_bounds__(1024) void colsum_f32_kernel(const float *__restrict__ A, int lda, int rows, int cols,
+                                                          float *__restrict__ out) {
+  __shared__ float part[16][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
   float a = 0.f;
-  for (int r = 0; r < rows; ++r) a += A[(long)r * lda + c];
-  out[c] = a;
+  if (c < cols) {
+    int r = rg;
+    for (; r + 15 * 16 < rows; r += 16 * 16) {
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = A[(long)(r + i * 16) * lda + c];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a += v[i];
+    }
+    for (; r < rows; r += 16) a += A[(long)r * lda + c];
+  }
+  part[rg][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (rg == 0 && c < cols) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += part[i][threadIdx.x];
+    out[c] = s;
+  }
 }
 
 // MXNet sgd_mom_update [EXT]: mom = momentum*mom - lr*(rescale*grad + wd*w); w += mom
@@ -405,13 +424,6 @@ __global__ void transpose_f32_kernel(const float *__restrict__ src, int rows, in
 
 #define TN_LAUNCH_CHECK() do { TN_HIP_CHECK(hipGetLastError()); return TN_OK; } while (0)
 
-int launch_gru_train_fwd(const float *gi, const float *whT, const float *bh, float *seq, float *gates, int B, int T,
-                         int H, hipStream_t s) {
-  TN_REQUIRE(3 * H <= 1024 && H % 4 == 0, "gru_train: 3*hidden must be <= 1024 and hidden % 4 == 0");
-  hipLaunchKernelGGL(gru_train_fwd_kernel, dim3((B + NB - 1) / NB, 2), dim3(3 * H), (size_t)(NB * H + NB * 3 * H) * 4, s,
-                     gi, whT, bh, seq, gates, B, T, H);
-  TN_LAUNCH_CHECK();
-}
 int launch_pool_max_arg(const float *x, int B, int T, int F, float *y, int32_t *arg, hipStream_t s) {
   hipLaunchKernelGGL(pool_max_arg_kernel, dim3(((long)B * F + 255) / 256), dim3(256), 0, s, x, B, T, F, y, arg);
   TN_LAUNCH_CHECK();
@@ -433,23 +445,29 @@ int launch_scatter_pool_grad(const float *dpooled, const int32_t *arg, int B, in
                      F, dseq);
   TN_LAUNCH_CHECK();
 }
+// rows per workgroup / register-resident prefix: the same policy as launch_rnn_recurrent (rnn.hip)
+#define TN_BPTT_DISPATCH(KERNEL, GATES, ...)                                                                      \
+  do {                                                                                                            \
+    const int threads = GATES * H;                                                                                \
+    TN_REQUIRE(threads <= 1024 && H % 4 == 0, "train: gates*hidden must be <= 1024 and hidden % 4 == 0");        \
+    const int nb = ((B + 3) / 4) * 2 >= 256 ? 4 : 1;                                                              \
+    const int kr = (threads <= 512 && H >= 128) ? 128 : (threads <= 768 && H >= 96) ? 96 : H >= 64 ? 64 : 0;      \
+    const dim3 grid((B + nb - 1) / nb, 2), block(threads);                                                        \
+    const size_t lds = (size_t)(nb * H * (GATES == 4 ? 2 : 1) + 2 * nb * GATES * H) * sizeof(float);              \
+    if (nb == 4) hipLaunchKernelGGL((KERNEL<4, 0, 1024>), grid, block, lds, s, __VA_ARGS__);                      \
+    else if (kr == 128) hipLaunchKernelGGL((KERNEL<1, 128, 512>), grid, block, lds, s, __VA_ARGS__);              \
+    else if (kr == 96) hipLaunchKernelGGL((KERNEL<1, 96, 768>), grid, block, lds, s, __VA_ARGS__);                \
+    else if (kr == 64) hipLaunchKernelGGL((KERNEL<1, 64, 1024>), grid, block, lds, s, __VA_ARGS__);               \
+    else hipLaunchKernelGGL((KERNEL<1, 0, 1024>), grid, block, lds, s, __VA_ARGS__);                              \
+  } while (0)
 int launch_gru_train_bwd(const float *seq, const float *gates, const float *dseq, const float *wh, float *dgi,
                          float *dgh, float *hprev, int B, int T, int H, hipStream_t s) {
-  hipLaunchKernelGGL(gru_train_bwd_kernel, dim3((B + NB - 1) / NB, 2), dim3(3 * H),
-                     (size_t)(NB * H + NB * 3 * H + NB * 3 * H) * 4, s, seq, gates, dseq, wh, dgi, dgh, hprev, B, T, H);
-  TN_LAUNCH_CHECK();
-}
-int launch_lstm_train_fwd(const float *gi, const float *whT, const float *bh, float *seq, float *gates, int B, int T,
-                          int H, hipStream_t s) {
-  TN_REQUIRE(4 * H <= 1024 && H % 4 == 0, "lstm_train: 4*hidden must be <= 1024 and hidden % 4 == 0");
-  hipLaunchKernelGGL(lstm_train_fwd_kernel, dim3((B + NB - 1) / NB, 2), dim3(4 * H), (size_t)(2 * NB * H + NB * 4 * H) * 4,
-                     s, gi, whT, bh, seq, gates, B, T, H);
+  TN_BPTT_DISPATCH(gru_train_bwd_kernel, 3, seq, gates, dseq, wh, dgi, dgh, hprev, B, T, H);
   TN_LAUNCH_CHECK();
 }
 int launch_lstm_train_bwd(const float *seq, const float *gates, const float *dseq, const float *wh, float *dgi,
                           float *hprev, int B, int T, int H, hipStream_t s) {
-  hipLaunchKernelGGL(lstm_train_bwd_kernel, dim3((B + NB - 1) / NB, 2), dim3(4 * H),
-                     (size_t)(2 * NB * H + NB * 4 * H + NB * 4 * H) * 4, s, seq, gates, dseq, wh, dgi, hprev, B, T, H);
+  TN_BPTT_DISPATCH(lstm_train_bwd_kernel, 4, seq, gates, dseq, wh, dgi, hprev, B, T, H);
   TN_LAUNCH_CHECK();
 }
 int launch_gemm_tn_f32(const float *A, int lda, const float *Bm, int ldb, float *Cm, int ldc, int M, int N, int K,
@@ -459,7 +477,7 @@ int launch_gemm_tn_f32(const float *A, int lda, const float *Bm, int ldb, float 
   TN_LAUNCH_CHECK();
 }
 int launch_colsum_f32(const float *A, int lda, int rows, int cols, float *out, hipStream_t s) {
-  hipLaunchKernelGGL(colsum_f32_kernel, dim3((cols + 127) / 128), dim3(128), 0, s, A, lda, rows, cols, out);
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3((cols + 63) / 64), dim3(1024), 0, s, A, lda, rows, cols, out);
   TN_LAUNCH_CHECK();
 }
 int launch_sgd_momentum(float *w, const float *g, float *mom, long n, float lr, float momentum, float wd,
