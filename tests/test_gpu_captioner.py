@@ -35,6 +35,12 @@ def _case(seed, B, T, F, H, E, V, beam, max_length, eos_bias=0.0, proj_scale=1.0
     dict(seed=3, B=4, T=60, F=1024, H=128, E=100, V=254, beam=5, max_length=30, proj_scale=30.0),  # config C5 shape
     dict(seed=4, B=3, T=13, F=32, H=16, E=12, V=30, beam=4, max_length=14, cell="lstm"),                    # LSTM cells
     dict(seed=5, B=5, T=23, F=64, H=32, E=20, V=40, beam=4, max_length=40, proj_scale=40.0, cell="lstm"),
+    # the other instantiations of the step kernels: beam rows padded to 4 / 8 / 16, source longer than one pass of
+    # the attention kernel (T > 256), vocabulary wider than one pass of the projection (V > 256), hidden % 64 != 0
+    dict(seed=6, B=3, T=17, F=32, H=16, E=12, V=30, beam=1, max_length=16, proj_scale=30.0),
+    dict(seed=7, B=3, T=17, F=32, H=24, E=10, V=30, beam=3, max_length=16, proj_scale=30.0),
+    dict(seed=8, B=2, T=300, F=48, H=32, E=16, V=300, beam=7, max_length=20, proj_scale=40.0),
+    dict(seed=9, B=2, T=40, F=48, H=32, E=16, V=61, beam=10, max_length=20, proj_scale=40.0, cell="lstm"),
 ])
 def test_beam_search_matches_oracle(cfg, report):
     (mem, s, sc, vl), (rmem, rs, rsc, rvl) = _case(**cfg)
