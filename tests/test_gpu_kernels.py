@@ -109,7 +109,8 @@ def test_conv3x3(ctx, report, B, H, W):
     assert np.all(y[:, mask] == 3.0)
 
 
-@pytest.mark.parametrize("M,N,K", [(70, 11, 1024), (2048, 768, 1024), (33, 254, 356), (5, 7, 3)])
+@pytest.mark.parametrize("M,N,K", [(70, 11, 1024), (2048, 768, 1024), (33, 254, 356), (5, 7, 3),
+                                   (4100, 520, 200), (4100, 513, 203), (160, 1024, 612)])   # 64x64-tile kernel (>= 512 tiles), scalar-load path, decoder cell
 def test_linear(ctx, report, M, N, K):
     from tennis_amd import _lib
     rng = np.random.default_rng(M + N + K)
@@ -127,7 +128,13 @@ def test_linear(ctx, report, M, N, K):
 
 
 @pytest.mark.parametrize("mode,B,T,F,H,use_vl", [("gru", 5, 9, 64, 128, False), ("lstm", 3, 7, 100, 128, False),
-                                                  ("gru", 6, 11, 48, 256, True), ("lstm", 2, 5, 32, 64, True)])
+                                                  ("gru", 6, 11, 48, 256, True), ("lstm", 2, 5, 32, 64, True),
+                                                  # the other shapes of the recurrent kernel: 1024-thread block (64
+                                                  # weights in registers, the rest streamed), no register prefix,
+                                                  # ragged tails (hidden % 16 != 0), four rows per workgroup
+                                                  ("lstm", 2, 4, 16, 256, True), ("gru", 3, 5, 16, 32, False),
+                                                  ("gru", 2, 4, 16, 100, True), ("lstm", 3, 4, 16, 84, False),
+                                                  ("gru", 520, 3, 8, 32, True), ("lstm", 516, 2, 8, 36, False)])
 def test_birnn(ctx, report, mode, B, T, F, H, use_vl):
     from tennis_amd import weights as Wt
     from tennis_amd.engine import BiRNN
