@@ -7,8 +7,8 @@ The reference drives its models through a handful of Gluon methods
 ``save_parameters`` (train.py:497) and attribute access to children.  This module
 keeps those names and meanings; the compute behind ``__call__`` is the HIP
 library.  Parameters are fp32 numpy arrays keyed by Gluon names and are stored
-in ``.npz`` containers under the same names (a ``.params`` reader can be added
-on top).
+in MXNet ``.params`` containers under Gluon's structural names (what ``save_parameters``
+of the reference writes) or ``.npz`` under the prefixed names; both load back.
 """
 from __future__ import annotations
 
@@ -107,9 +107,32 @@ class Block:
             if k in params:
                 self._own_params[k].data = np.ascontiguousarray(params[k], dtype=np.float32)
 
-    def save_parameters(self, filename):
+    # -- structural names ----------------------------------------------------
+    def _structural_params(self, path: str = "") -> dict:
+        """``Block._collect_params_with_prefix`` of Gluon [EXT]: the names ``save_parameters`` / ``load_parameters``
+        use — attribute path of the child blocks (``backbone``, ``classes``, ``td.model``, ``rnn``; sequential
+        children by index), then the parameter's own name without the block prefix (``weight``, ``gamma``,
+        ``l0_i2h_weight`` ...).  -> {structural name: prefixed name}."""
+        out = {}
+        for k in self._own_params:
+            out[path + (k[len(self.prefix):] if k.startswith(self.prefix) else k)] = k
+        for name, child in self._children.items():
+            out.update(child._structural_params(path + name + "."))
+        return out
+
+    def save_parameters(self, filename, structural=None):
+        """``<name>.params`` (the only form the reference writes, train.py:497) -> the MXNet NDArray-list container
+        with Gluon's structural names, which ``mx.gluon.Block.load_parameters`` of the reference reads back;
+        any other extension -> ``.npz`` with the prefixed names."""
         pd = {k: v.data for k, v in self.collect_params().items() if v.data is not None}
-        with open(filename, "wb") as f:  # keep the caller's extension (e.g. '0007.params')
+        if structural is None:
+            structural = str(filename).endswith(".params")
+        if structural:
+            from .params_io import save_mxnet_params
+            names = {v: k for k, v in self._structural_params().items()}
+            save_mxnet_params(filename, {names[k]: a for k, a in pd.items()})
+            return
+        with open(filename, "wb") as f:
             np.savez(f, **pd)
 
     def load_parameters(self, filename, ctx=None, allow_missing=False, ignore_extra=False):
@@ -121,6 +144,13 @@ class Block:
         else:
             with np.load(filename) as z:
                 loaded = {k: z[k] for k in z.files}
+        smap = self._structural_params()
+        known = set(self.collect_params())
+        if any(k in smap and k not in known for k in loaded):       # Gluon save_parameters: structural names
+            loaded = {smap.get(k, k): v for k, v in loaded.items()}
+        extra = [k for k in loaded if k not in known]
+        if extra and not ignore_extra:
+            raise AssertionError(f"Parameter '{extra[0]}' loaded from file '{filename}' is not present in this block")
         self.set_params(loaded)
         if not allow_missing:
             missing = [k for k, v in self.collect_params().items() if v.data is None and k not in loaded]

@@ -104,6 +104,39 @@ class DenseNet121Backbone(Block):
         if next(iter(self._own_params.values())).data is None:
             self._adopt(W.make_densenet121_weights(self._seed, self.prefix))
 
+    def _structural_params(self, path: str = "") -> dict:
+        """Structural names of gluon ``model_zoo.vision.densenet121().features`` [EXT]: a HybridSequential of
+        0 conv 7x7, 1 BatchNorm, 2 relu, 3 maxpool, then (dense block, transition) pairs at 4..10, 11 BatchNorm,
+        12 relu, 13 avgpool, 14 flatten.  A dense block is a HybridSequential of layers; a layer is
+        HybridConcurrent[0 Identity, 1 HybridSequential(0 BN, 1 relu, 2 conv 1x1, 3 BN, 4 relu, 5 conv 3x3)];
+        a transition is HybridSequential(0 BN, 1 relu, 2 conv 1x1, 3 avgpool)."""
+        bn = ("gamma", "beta", "running_mean", "running_var")
+        out = {}
+        pre = self.prefix
+
+        def put_bn(spath, pname):
+            for s_ in bn:
+                out[f"{path}{spath}.{s_}"] = f"{pre}{pname}_{s_}"
+        out[f"{path}0.weight"] = pre + "conv0_weight"
+        put_bn("1", "batchnorm0")
+        child, outer = 4, 1
+        for b, nl in enumerate((6, 12, 24, 16)):
+            sp = f"stage{b + 1}_"
+            for l in range(nl):
+                put_bn(f"{child}.{l}.1.0", f"{sp}batchnorm{2 * l}")
+                out[f"{path}{child}.{l}.1.2.weight"] = f"{pre}{sp}conv{2 * l}_weight"
+                put_bn(f"{child}.{l}.1.3", f"{sp}batchnorm{2 * l + 1}")
+                out[f"{path}{child}.{l}.1.5.weight"] = f"{pre}{sp}conv{2 * l + 1}_weight"
+            child += 1
+            if b < 3:
+                put_bn(f"{child}.0", f"batchnorm{outer}")
+                out[f"{path}{child}.2.weight"] = f"{pre}conv{outer}_weight"
+                child += 1
+                outer += 1
+        put_bn(str(child), f"batchnorm{outer}")
+        assert set(out.values()) == set(self._own_params), "structural table out of sync with the layout"
+        return out
+
     def _adopt(self, params):
         super()._adopt(W.as_fp16_model({k: v for k, v in params.items() if k in self._own_params}))
 

@@ -126,3 +126,51 @@ def test_balance_classes(tmp_path):
     expect = [s for s in full._samples if not (s[2] == "OTH" and random.uniform(0, 1) > ratio)]
     assert bal._samples == expect
     assert bal.class_counts()[1:] == counts[1:] and 0 < bal.class_counts()[0] < counts[0] // 2
+
+
+def test_structural_parameter_names_and_params_round_trip(tmp_path):
+    """Gluon's save_parameters / load_parameters use structural names (attribute path + parameter name); the files
+    the reference writes (train.py:497) and reads (evaluate.py:198,212,239) carry them."""
+    from tennis_amd.model_zoo import get_model
+    from tennis_amd.models.vision.definitions import CNNRNN, FrameModel
+    from tennis_amd.params_io import is_mxnet_params, load_mxnet_params
+    fm = FrameModel(get_model("DenseNet121", pretrained=True, seed=3).features, 11, prefix="framemodel0_")
+    fm.initialize()
+    fm.classes._materialize(1024)
+    smap = fm._structural_params()
+    assert len(smap) == 604 + 2
+    assert smap["backbone.0.weight"].endswith("conv0_weight")
+    assert smap["backbone.4.0.1.2.weight"].endswith("stage1_conv0_weight")          # block 1, layer 0, 1x1 conv
+    assert smap["backbone.4.5.1.5.weight"].endswith("stage1_conv11_weight")         # block 1, layer 5, 3x3 conv
+    assert smap["backbone.5.0.running_var"].endswith("batchnorm1_running_var")      # transition 1
+    assert smap["backbone.5.2.weight"].endswith("_conv1_weight")
+    assert smap["backbone.10.15.1.3.gamma"].endswith("stage4_batchnorm31_gamma")    # block 4, last layer, second BN
+    assert smap["backbone.11.beta"].endswith("batchnorm4_beta")                     # final BN
+    assert smap["classes.weight"] == "framemodel0_dense0_weight" and smap["classes.bias"] == "framemodel0_dense0_bias"
+    path = str(tmp_path / "0007.params")
+    fm.save_parameters(path)
+    assert is_mxnet_params(path)
+    on_disk = load_mxnet_params(path)
+    assert set(on_disk) == set(smap) and on_disk["classes.weight"].shape == (11, 1024)
+    fresh = FrameModel(get_model("DenseNet121", pretrained=True, seed=9).features, 11, prefix="framemodel1_")
+    fresh.initialize()
+    fresh.load_parameters(path)
+    a, b = fm.collect_params(), fresh.collect_params()
+    for (ka, va), (kb, vb) in zip(a.items(), b.items()):
+        assert ka.split("_", 1)[1] == kb.split("_", 1)[1] and np.array_equal(va.data, vb.data), (ka, kb)
+    # the .npz form with prefixed names still loads; unknown names are an error unless ignore_extra (Gluon's behaviour)
+    npz = str(tmp_path / "w.npz")
+    fm.save_parameters(npz)
+    fm.load_parameters(npz)
+    bad = dict(np.load(npz))
+    bad["framemodel0_dense0_nonsense"] = np.zeros(3, np.float32)
+    np.savez(str(tmp_path / "bad.npz"), **bad)
+    with pytest.raises(AssertionError):
+        fm.load_parameters(str(tmp_path / "bad.npz"))
+    fm.load_parameters(str(tmp_path / "bad.npz"), ignore_extra=True)
+    # the temporal model in feature mode: rnn + classes
+    cr = CNNRNN(None, num_classes=11, type="lstm", hidden_size=16, prefix="cnnrnn0_")
+    cr.rnn._materialize(24)
+    cr.classes._materialize(32)
+    names = set(cr._structural_params())
+    assert {"rnn.l0_i2h_weight", "rnn.r0_h2h_bias", "classes.weight", "classes.bias"} <= names and len(names) == 10
