@@ -160,8 +160,8 @@ __device__ long long g_dec_stamps[24];
 #define DEC_STAMP(i)
 #endif
 // Beam-search step, launch 2 of 4, one workgroup (16 waves) per `rows` consecutive decoder rows of one clip (rows = 1:
-// the step is bound by instruction issue at the clocks a mostly idle chip runs at, so it pays to spread the rows over
-// CUs even though each re-reads the clip's key projection and memory from L2):
+// the step is latency-bound — few workgroups, dependent L2 round trips — so it pays to spread the rows over CUs even
+// though each re-reads the clip's key projection and memory from L2):
 //   first decoder cell's gate arithmetic on the stacked pre-activations g0 (R,4H) — GRU columns
 //   [r, z, n_i2h, n_h2h] (r and z already summed over both branches), LSTM [i, f, g, o]; h_prev = last H columns
 //   of the step input x0 — the new state goes to hn (R,H) (+ cn) and to x1[:, 0:H];
