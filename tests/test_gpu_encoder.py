@@ -150,3 +150,27 @@ def test_full_batch_256_matches_small_batches(report):
     report["full_batch_vs_small_batch_bit_identical"] = True
     # and the NHWC fp16 hand-over agrees with the reference NCHW fp32 layout to fp16 input rounding
     assert float((ref - small).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("B", [1, 3, 5, 13, 40, 64, 72])
+def test_ragged_batch_sizes(B):
+    """Batch sizes that are not multiples of 8 take the un-remapped tile order, 40 / 72 are too small or too ragged for
+    the two-stream split, 64 is the smallest split batch: every frame must come out exactly as in a batch of 4."""
+    from tennis_amd import weights as W
+    from tennis_amd.engine import DenseNet121Features
+    p = W.make_densenet121_weights(2)
+    base = torch.from_numpy(W.normalize_to_nchw_f32(W.synthetic_frames_u8(4, 224))).cuda().permute(0, 2, 3, 1).contiguous().half()
+    ref = DenseNet121Features(p, 224, max_batch=4)(base)
+    idx = (torch.arange(B, device="cuda") * 3) % 4
+    got = DenseNet121Features(p, 224, max_batch=B)(base[idx].contiguous())
+    assert got.shape == (B, 1024) and torch.equal(got, ref[idx])
+
+
+def test_batch_larger_than_handle_is_an_error():
+    from tennis_amd import weights as W
+    from tennis_amd.engine import DenseNet121Features
+    p = W.make_densenet121_weights(2)
+    enc = DenseNet121Features(p, 224, max_batch=2)
+    x = torch.zeros((3, 224, 224, 3), dtype=torch.float16, device="cuda")
+    with pytest.raises(RuntimeError, match="max_batch"):
+        enc(x)
