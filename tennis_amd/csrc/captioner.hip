@@ -7,6 +7,9 @@
 //                GRUCell1([h0, ctx]) -> tgt_proj -> log_softmax (utils/translation.py:51-53)
 //   beam search  gluonnlp BeamSearchSampler/Scorer [EXT] as driven by
 //                BeamSearchTranslator.translate, utils/translation.py:55-82
+// One decode step = four launches, shared by the beam search and by teacher forcing (decode_seq): a stacked-gate
+// GEMM per cell (linear.hip), dec_attention_kernel (cell-0 gates + attention) and dec_beam_kernel (cell-1 gates +
+// projection + beam update + the next step's gathered inputs) resp. dec_tf_cell1_kernel + the projection GEMM.
 // The whole token loop is enqueued on the stream with no per-step host sync; the host
 // looks at a device flag every 16 steps only to stop early once every beam has finished.
 #include <cmath>
@@ -22,134 +25,7 @@ namespace {
 
 constexpr float kNeg = -1e18f;
 
-__global__ void embed_concat_kernel(const float *__restrict__ emb, const int32_t *__restrict__ tok,
-                                    const float *__restrict__ att, float *__restrict__ x, int R, int E, int H) {
-  const int r = blockIdx.x;
-  const float *e = emb + (long)tok[r] * E;
-  for (int i = threadIdx.x; i < E + H; i += blockDim.x) x[(long)r * (E + H) + i] = i < E ? e[i] : att[(long)r * H + i - E];
-}
-
 __device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
-
-// GRU cell gates [r,z,n]: h' = (1-z)*n + z*h ; optionally also writes h' into the first H
-// columns of a concat buffer xcat (row stride ldx)
-__global__ void gru_gate_kernel(const float *__restrict__ gi, const float *__restrict__ gh,
-                                const float *__restrict__ h, float *__restrict__ hn, float *__restrict__ xcat, int ldx,
-                                int R, int H) {
-  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= (long)R * H) return;
-  const int r = (int)(id / H), u = (int)(id % H);
-  const float *a = gi + (long)r * 3 * H, *b = gh + (long)r * 3 * H;
-  const float rg = sigm(a[u] + b[u]);
-  const float zg = sigm(a[H + u] + b[H + u]);
-  const float ng = tanhf(a[2 * H + u] + rg * b[2 * H + u]);
-  const float v = (1.f - zg) * ng + zg * h[id];
-  hn[id] = v;
-  if (xcat) xcat[(long)r * ldx + u] = v;
-}
-
-// LSTM cell gates [i,f,g,o] (gluon rnn.LSTMCell [EXT], same order as the fused layer): c' = f*c + i*g, h' = o*tanh(c')
-__global__ void lstm_gate_kernel(const float *__restrict__ gi, const float *__restrict__ gh,
-                                 const float *__restrict__ c, float *__restrict__ hn, float *__restrict__ cn,
-                                 float *__restrict__ xcat, int ldx, int R, int H) {
-  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= (long)R * H) return;
-  const int r = (int)(id / H), u = (int)(id % H);
-  const float *a = gi + (long)r * 4 * H, *b = gh + (long)r * 4 * H;
-  const float ig = sigm(a[u] + b[u]);
-  const float fg = sigm(a[H + u] + b[H + u]);
-  const float gg = tanhf(a[2 * H + u] + b[2 * H + u]);
-  const float og = sigm(a[3 * H + u] + b[3 * H + u]);
-  const float c2 = fg * c[id] + ig * gg;
-  const float v = og * tanhf(c2);
-  cn[id] = c2;
-  hn[id] = v;
-  if (xcat) xcat[(long)r * ldx + u] = v;
-}
-
-// scaled-Luong attention for one decoder row per workgroup: scores over the source steps,
-// masked softmax (masked -> -1e18, weights * mask), context; writes ctx and xcat[r, H:2H].
-// q[H] (already scaled by 1/sqrt(H)) sits at the start of the dynamic LDS: q[H] | w[T] | red[256]
-__device__ __forceinline__ void attention_row(float *sm, int r, int b, const float *__restrict__ keyproj,
-                                              const float *__restrict__ mem, const int32_t *__restrict__ valid_len,
-                                              float *__restrict__ ctx, float *__restrict__ xcat, int ldx, int T, int H) {
-  float *q = sm, *w = sm + H, *red = w + T;
-  const int t = threadIdx.x;
-  const int vl = min(max(valid_len[b], 0), T);
-  const float *kp = keyproj + (long)b * T * H;
-  // scores: one wave per source step, lanes along H (coalesced 16-byte loads), four steps in flight
-  {
-    const int lane = t & 63, wid = t >> 6;
-    for (int s0 = wid * 4; s0 < vl; s0 += 16) {
-      float a[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int i = lane * 4; i < H; i += 256) {
-        const float4 qv = *(const float4 *)(q + i);
-        float4 kv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          kv[j] = s0 + j < vl ? *(const float4 *)(kp + (long)(s0 + j) * H + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          a[j] = fmaf(qv.w, kv[j].w, fmaf(qv.z, kv[j].z, fmaf(qv.y, kv[j].y, fmaf(qv.x, kv[j].x, a[j]))));
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float v = a[j];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane == 0 && s0 + j < vl) w[s0 + j] = v;
-      }
-    }
-    for (int s = vl + t; s < T; s += 256) w[s] = kNeg;     // masked source steps
-  }
-  __syncthreads();
-  float mx = -INFINITY;
-  for (int s = t; s < T; s += 256) mx = fmaxf(mx, w[s]);
-  red[t] = mx;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (t < o) red[t] = fmaxf(red[t], red[t + o]);
-    __syncthreads();
-  }
-  mx = red[0];
-  __syncthreads();
-  float sum = 0.f;
-  for (int s = t; s < T; s += 256) {
-    const float e = expf(w[s] - mx);
-    w[s] = e;
-    sum += e;
-  }
-  red[t] = sum;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (t < o) red[t] += red[t + o];
-    __syncthreads();
-  }
-  const float rs = 1.0f / red[0];
-  __syncthreads();
-  for (int s = t; s < T; s += 256) w[s] = s < vl ? w[s] * rs : 0.f;
-  __syncthreads();
-  const float *mv = mem + (long)b * T * H;
-  const int tv = vl;                                           // weights beyond valid_len are exactly 0
-  for (int i = t; i < H; i += 256) {
-    float a = 0.f;
-#pragma unroll 8
-    for (int s = 0; s < tv; ++s) a = fmaf(w[s], mv[(long)s * H + i], a);
-    ctx[(long)r * H + i] = a;
-    xcat[(long)r * ldx + H + i] = a;
-  }
-}
-
-__global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ hq, const float *__restrict__ keyproj,
-                                                        const float *__restrict__ mem,
-                                                        const int32_t *__restrict__ valid_len, float *__restrict__ ctx,
-                                                        float *__restrict__ xcat, int beam, int T, int H) {
-  extern __shared__ float sm[];
-  const int r = blockIdx.x;
-  const float inv = 1.0f / sqrtf((float)H);
-  for (int i = threadIdx.x; i < H; i += 256) sm[i] = hq[(long)r * H + i] * inv;
-  __syncthreads();
-  attention_row(sm, r, r / beam, keyproj, mem, valid_len, ctx, xcat, 2 * H, T, H);
-}
 
 // ---- beam-search step kernels: 1024 threads = 16 waves ----
 constexpr int kBeamThreads = 1024;
@@ -528,6 +404,45 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
   DEC_STAMP(16);
 }
 
+// Teacher forcing (decode_seq): the same four-launch step as the beam search with beam = 1.  Before a step its inputs
+// are assembled from the given token and the previous step's outputs (the encoder states / zero attention at step 0);
+// after it the second cell's gates give h1 (the row the projection GEMM then maps to logits).
+__global__ void dec_tf_prep_kernel(const float *__restrict__ emb, const int32_t *__restrict__ tgt, int ld, int col,
+                                   const float *__restrict__ ctx_prev, const float *__restrict__ h0_prev,
+                                   const float *__restrict__ h1_prev, const float *__restrict__ c0_prev,
+                                   const float *__restrict__ c1_prev, float *__restrict__ x0, float *__restrict__ x1,
+                                   float *__restrict__ c0cur, float *__restrict__ c1cur, int H, int E) {
+  const int r = blockIdx.x, K0 = E + 2 * H, K1 = 3 * H;
+  const int tok = tgt[(long)r * ld + col];
+  const float *e = emb + (long)(tok > 0 ? tok : 0) * E;
+  for (int i = threadIdx.x; i < K0; i += blockDim.x)
+    x0[(long)r * K0 + i] = i < E ? e[i] : i < E + H ? (ctx_prev ? ctx_prev[(long)r * H + i - E] : 0.f) : h0_prev[(long)r * H + i - E - H];
+  for (int u = threadIdx.x; u < H; u += blockDim.x) {
+    x1[(long)r * K1 + 2 * H + u] = h1_prev[(long)r * H + u];
+    if (c0_prev) { c0cur[(long)r * H + u] = c0_prev[(long)r * H + u]; c1cur[(long)r * H + u] = c1_prev[(long)r * H + u]; }
+  }
+}
+
+__global__ void dec_tf_cell1_kernel(const float *__restrict__ g1, const float *__restrict__ x1, int lstm,
+                                    const float *__restrict__ c1cur, float *__restrict__ h1n, float *__restrict__ c1n,
+                                    int R, int H) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)R * H) return;
+  const long r = id / H;
+  const int u = (int)(id - r * H);
+  const float *g = g1 + r * 4 * H;
+  if (lstm) {
+    const float ig = sigm(g[u]), fg = sigm(g[H + u]), gg = tanhf(g[2 * H + u]), og = sigm(g[3 * H + u]);
+    const float c2 = fg * c1cur[id] + ig * gg;
+    c1n[id] = c2;
+    h1n[id] = og * tanhf(c2);
+  } else {
+    const float rg = sigm(g[u]), zg = sigm(g[H + u]);
+    const float ng = tanhf(g[2 * H + u] + rg * g[3 * H + u]);
+    h1n[id] = (1.f - zg) * ng + zg * x1[r * 3 * H + 2 * H + u];
+  }
+}
+
 // first step's inputs: x0 = [embed(bos), 0, h0 of the clip], x1[:, 2H:3H] = h1 of the clip, cell states (LSTM)
 __global__ void dec_init_kernel(const float *__restrict__ emb, int bos, const float *__restrict__ h0c,
                                 const float *__restrict__ h1c, const float *__restrict__ c0c,
@@ -540,13 +455,6 @@ __global__ void dec_init_kernel(const float *__restrict__ emb, int bos, const fl
     x1[(long)r * K1 + 2 * H + u] = h1c[(long)b * H + u];
     if (c0c) { c0cur[(long)r * H + u] = c0c[(long)b * H + u]; c1cur[(long)r * H + u] = c1c[(long)b * H + u]; }
   }
-}
-
-__global__ void expand_rows_kernel(const float *__restrict__ src, float *__restrict__ dst, int B, int beam, int H) {
-  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= (long)B * beam * H) return;
-  const int r = (int)(id / H), u = (int)(id % H);
-  dst[id] = src ? src[(long)(r / beam) * H + u] : 0.f;
 }
 
 __global__ void beam_init_kernel(float *scores, int32_t *alive, int32_t *vlen, int32_t *tok, int32_t *samples, int L,
@@ -566,11 +474,6 @@ __global__ void beam_finalize_kernel(const int32_t *alive, int32_t *vlen, int32_
   if (id >= R) return;
   samples[(long)id * L + last] = alive[id] ? eos : -1;
   vlen[id] += alive[id] ? 1 : 0;
-}
-
-__global__ void take_column_kernel(const int32_t *__restrict__ tgt, int ld, int col, int32_t *__restrict__ tok, int B) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < B) { const int v = tgt[(long)b * ld + col]; tok[b] = v > 0 ? v : 0; }
 }
 
 // MaskedSoftmaxCELoss [EXT gluonnlp]: per sample, mean over the L time steps of
@@ -627,17 +530,16 @@ struct tn_gnmt {
   DevBuf pool;
   tn_birnn *enc0, *enc1;   // bi layer (F -> 2H), uni layer (2H -> H)
   int F, H, E, V, maxB, maxT, beam, maxL;
-  float *wi0, *wh0, *bi0, *bh0, *wi1, *wh1, *bi1, *bh1, *wk, *wp, *bp, *emb;
+  float *wk, *wp, *bp, *emb;
   // per-call workspace
   int G;                   // gates per cell: 3 GRU, 4 LSTM
   float *seq0, *mem, *keyproj, *hl0, *hl1, *cl0, *cl1;
-  float *c0[2], *c1[2];    // LSTM cell states of the two decoder layers
   int32_t *vl;
-  float *h0[2], *h1[2], *att[2], *x0, *x1, *gi, *gh, *logits, *scores;
-  int32_t *alive, *vlen, *tok, *gather, *samples[2], *flag;
+  float *scores;
+  int32_t *alive, *vlen, *tok, *samples[2], *flag;
   // fused beam-search step: stacked [i2h | h2h] weights (4H rows each), transposed projection, step buffers
   float *w0c, *b0c, *w1c, *b1c, *wpT;
-  float *sx0, *sx1, *g0, *g1, *h0n, *ctxn, *c0n, *c0cur, *c1cur, *keyprojT;
+  float *sx0, *sx1, *g0, *g1, *h0n, *ctxn, *c0n, *c0cur, *c1cur, *keyprojT, *h1n, *c1n;
   int B, T;
 };
 
@@ -697,10 +599,6 @@ extern "C" int tn_gnmt_create(tn_ctx *ctx, const tn_param *params, int n_params,
   // decoder
   const float *a;
 #define UP(dst, name, n) do { a = get(pre + name, (int64_t)(n)); if (!a) return fail(TN_ERR_MISSING); dst = g->pool.upload(a, (size_t)(n)); } while (0)
-  UP(g->wi0, "dec_rnn0_i2h_weight", (int64_t)G3 * (embed + H)); UP(g->wh0, "dec_rnn0_h2h_weight", (int64_t)G3 * H);
-  UP(g->bi0, "dec_rnn0_i2h_bias", G3); UP(g->bh0, "dec_rnn0_h2h_bias", G3);
-  UP(g->wi1, "dec_rnn1_i2h_weight", (int64_t)G3 * 2 * H); UP(g->wh1, "dec_rnn1_h2h_weight", (int64_t)G3 * H);
-  UP(g->bi1, "dec_rnn1_i2h_bias", G3); UP(g->bh1, "dec_rnn1_h2h_bias", G3);
   UP(g->wk, "dec_attention_key_weight", (int64_t)H * H);
   UP(g->wp, "tgt_proj_weight", (int64_t)vocab * H); UP(g->bp, "tgt_proj_bias", vocab);
   UP(g->emb, "tgt_embed_weight", (int64_t)vocab * embed);
@@ -745,15 +643,10 @@ extern "C" int tn_gnmt_create(tn_ctx *ctx, const tn_param *params, int n_params,
   g->hl0 = g->pool.alloc<float>(2 * (size_t)max_batch * H); g->hl1 = g->pool.alloc<float>((size_t)max_batch * H);
   g->cl0 = g->pool.alloc<float>(2 * (size_t)max_batch * H); g->cl1 = g->pool.alloc<float>((size_t)max_batch * H);
   g->vl = g->pool.alloc<int32_t>(max_batch);
-  for (int i = 0; i < 2; ++i) {
-    g->h0[i] = g->pool.alloc<float>(R * H); g->h1[i] = g->pool.alloc<float>(R * H); g->att[i] = g->pool.alloc<float>(R * H);
-    g->c0[i] = g->pool.alloc<float>(R * H); g->c1[i] = g->pool.alloc<float>(R * H);
-    g->samples[i] = g->pool.alloc<int32_t>(R * g->maxL);
-  }
-  g->x0 = g->pool.alloc<float>(R * (embed + H)); g->x1 = g->pool.alloc<float>(R * 2 * H);
-  g->gi = g->pool.alloc<float>(R * G3); g->gh = g->pool.alloc<float>(R * G3); g->logits = g->pool.alloc<float>(R * vocab);
+  for (int i = 0; i < 2; ++i) g->samples[i] = g->pool.alloc<int32_t>(R * g->maxL);
   g->scores = g->pool.alloc<float>(R); g->alive = g->pool.alloc<int32_t>(R); g->vlen = g->pool.alloc<int32_t>(R);
-  g->tok = g->pool.alloc<int32_t>(R); g->gather = g->pool.alloc<int32_t>(R); g->flag = g->pool.alloc<int32_t>(1);
+  g->tok = g->pool.alloc<int32_t>(R); g->flag = g->pool.alloc<int32_t>(1);
+  g->h1n = g->pool.alloc<float>(R * H); g->c1n = g->pool.alloc<float>(R * H);
   g->sx0 = g->pool.alloc<float>(R * (embed + 2 * H)); g->sx1 = g->pool.alloc<float>(R * 3 * H);
   g->g0 = g->pool.alloc<float>(R * 4 * H); g->g1 = g->pool.alloc<float>(R * 4 * H);
   g->h0n = g->pool.alloc<float>(R * H); g->ctxn = g->pool.alloc<float>(R * H); g->c0n = g->pool.alloc<float>(R * H);
@@ -876,38 +769,28 @@ extern "C" int tn_gnmt_decode_seq(tn_gnmt *g, const int32_t *tgt, int ld, int st
   TN_REQUIRE(steps >= 1 && ld >= steps, "tn_gnmt_decode_seq: bad target length");
   TN_HIP_CHECK(hipSetDevice(g->ctx->device));
   hipStream_t s = g->ctx->stream;
-  const int B = g->B, T = g->T, H = g->H, E = g->E, V = g->V, G3 = g->G * H, R = B;
+  const int B = g->B, T = g->T, H = g->H, E = g->E, V = g->V, R = B, K0 = E + 2 * H, K1 = 3 * H;
   const bool lstm = g->G == 4;
   const int nb = (R * H + 255) / 256;
-  hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)(g->hl0 + (size_t)B * H), g->h0[0], B, 1, H);
-  hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)g->hl1, g->h1[0], B, 1, H);
-  hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)nullptr, g->att[0], B, 1, H);
-  if (lstm) {
-    hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)(g->cl0 + (size_t)B * H), g->c0[0], B, 1, H);
-    hipLaunchKernelGGL(expand_rows_kernel, dim3(nb), dim3(256), 0, s, (const float *)g->cl1, g->c1[0], B, 1, H);
-  }
-  const size_t att_lds = (size_t)(H + T + 256) * sizeof(float);
-  int cur = 0;
+  const size_t att_lds = ((size_t)(H + T) * 4 + (size_t)4 * (T > H ? T : H)) * sizeof(float);
+  TN_REQUIRE(att_lds <= 64 * 1024, "tn_gnmt_decode_seq: 8 * max(hidden, source length) exceeds the step kernel's 64 KiB of LDS");
   for (int i = 0; i < steps; ++i) {
-    const int nxt = cur ^ 1;
-    hipLaunchKernelGGL(take_column_kernel, dim3((B + 255) / 256), dim3(256), 0, s, tgt, ld, i, g->tok, B);
-    hipLaunchKernelGGL(embed_concat_kernel, dim3(R), dim3(128), 0, s, g->emb, g->tok, g->att[cur], g->x0, R, E, H);
-    int rc = launch_linear_f32(g->x0, E + H, g->wi0, E + H, g->bi0, g->gi, G3, R, G3, E + H, 0, s);
+    // decoder layer 0 starts from the encoder's BACKWARD layer-0 state, layer 1 from the uni layer (gnmt.py:146-150,224-252)
+    const float *h0p = i ? g->h0n : g->hl0 + (size_t)B * H, *h1p = i ? g->h1n : g->hl1;
+    const float *c0p = !lstm ? nullptr : i ? g->c0n : g->cl0 + (size_t)B * H, *c1p = !lstm ? nullptr : i ? g->c1n : g->cl1;
+    hipLaunchKernelGGL(dec_tf_prep_kernel, dim3(R), dim3(256), 0, s, (const float *)g->emb, tgt, ld, i,
+                       i ? (const float *)g->ctxn : (const float *)nullptr, h0p, h1p, c0p, c1p, g->sx0, g->sx1, g->c0cur, g->c1cur, H, E);
+    int rc = launch_linear_f32(g->sx0, K0, g->w0c, K0, g->b0c, g->g0, 4 * H, R, 4 * H, K0, 0, s);
     if (rc) return rc;
-    rc = launch_linear_f32(g->h0[cur], H, g->wh0, H, g->bh0, g->gh, G3, R, G3, H, 0, s);
+    hipLaunchKernelGGL(dec_attention_kernel<1>, dim3(R), dim3(kBeamThreads), att_lds, s, (const float *)g->g0,
+                       (const float *)(g->sx0 + E + H), K0, (const float *)g->c0cur, lstm ? 1 : 0, g->h0n, g->c0n, g->sx1, K1,
+                       (const float *)g->keyprojT, (const float *)g->mem, (const int32_t *)g->vl, g->ctxn, 1, 1, T, H);
+    rc = launch_linear_f32(g->sx1, K1, g->w1c, K1, g->b1c, g->g1, 4 * H, R, 4 * H, K1, 0, s);
     if (rc) return rc;
-    if (lstm) hipLaunchKernelGGL(lstm_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->c0[cur], g->h0[nxt], g->c0[nxt], g->x1, 2 * H, R, H);
-    else hipLaunchKernelGGL(gru_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->h0[cur], g->h0[nxt], g->x1, 2 * H, R, H);
-    hipLaunchKernelGGL(attention_kernel, dim3(R), dim3(256), att_lds, s, g->h0[nxt], g->keyproj, g->mem, g->vl, g->att[nxt], g->x1, 1, T, H);
-    rc = launch_linear_f32(g->x1, 2 * H, g->wi1, 2 * H, g->bi1, g->gi, G3, R, G3, 2 * H, 0, s);
+    hipLaunchKernelGGL(dec_tf_cell1_kernel, dim3(nb), dim3(256), 0, s, (const float *)g->g1, (const float *)g->sx1, lstm ? 1 : 0,
+                       (const float *)g->c1cur, g->h1n, g->c1n, R, H);
+    rc = launch_linear_f32(g->h1n, H, g->wp, H, g->bp, logits + (size_t)i * V, steps * V, R, V, H, 0, s);
     if (rc) return rc;
-    rc = launch_linear_f32(g->h1[cur], H, g->wh1, H, g->bh1, g->gh, G3, R, G3, H, 0, s);
-    if (rc) return rc;
-    if (lstm) hipLaunchKernelGGL(lstm_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->c1[cur], g->h1[nxt], g->c1[nxt], (float *)nullptr, 0, R, H);
-    else hipLaunchKernelGGL(gru_gate_kernel, dim3(nb), dim3(256), 0, s, g->gi, g->gh, g->h1[cur], g->h1[nxt], (float *)nullptr, 0, R, H);
-    rc = launch_linear_f32(g->h1[nxt], H, g->wp, H, g->bp, logits + (size_t)i * V, steps * V, R, V, H, 0, s);
-    if (rc) return rc;
-    cur = nxt;
   }
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;
