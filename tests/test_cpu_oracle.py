@@ -347,3 +347,39 @@ def test_train_oracle_matches_torch_autograd(cell):
         assert np.allclose(g[pre + d + "h2h_bias"], getattr(gru, "bias_hh_l0" + suf).grad.numpy(), atol=1e-9)
     assert np.allclose(g["cnnrnn0_dense0_weight"], fc.weight.grad.numpy(), atol=1e-9)
     assert np.allclose(g["cnnrnn0_dense0_bias"], fc.bias.grad.numpy(), atol=1e-9)
+
+
+def test_oracle_reproduces_its_committed_fixtures():
+    """tests/golden/oracle_*.npz (SURVEY §8c list: densenet121_224_b2, bigru / bilstm b2 t8 f1024, gnmt_step, beam_trace)
+    were produced by tests/golden/make_oracle_fixtures.py from seeded inputs: the oracle must keep reproducing them.
+    They pin the restatement to itself, not to MXNet (absent)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_oracle_fixtures", os.path.join(GOLD, "make_oracle_fixtures.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    from oracle import densenet_np as dn, gnmt_np as gn, rnn_np as rn
+    for mode in ("gru", "lstm"):
+        g = np.load(os.path.join(GOLD, f"oracle_bi{mode}_b2_t8_f1024.npz"))
+        p, x, vl = mk.rnn_inputs(mode)
+        seq, (fh, _), (bh, _) = rn.birnn_layer(x, p, "rnn_", mode, None)
+        assert np.abs(seq - g["seq"]).max() < 1e-6 and np.abs(fh - g["h_fwd"]).max() < 1e-6 and np.abs(bh - g["h_bwd"]).max() < 1e-6
+        rag, _, (rbh, _) = rn.birnn_layer(x, p, "rnn_", mode, vl)
+        assert np.abs(rag - g["seq_ragged"]).max() < 1e-6 and np.abs(rbh - g["h_bwd_ragged"]).max() < 1e-6
+        assert np.all(rag[1, 5:] == 0)                                  # steps past valid_length emit zeros
+    c = mk.GN
+    p, src, vl = mk.gnmt_inputs()
+    mem, states = gn.encoder(src, vl, p, "gru", c["H"])
+    dec = gn.Decoder(p, c["H"], cell="gru")
+    g = np.load(os.path.join(GOLD, "oracle_gnmt_step.npz"))
+    rnn_states, att = dec.init_state(mem, states, vl)
+    logp, ns, ctx = dec.step(g["tokens"], rnn_states, att, np.arange(c["B"]))
+    assert np.abs(mem - g["mem"]).max() < 1e-6 and np.abs(logp - g["logp"]).max() < 1e-5 and np.abs(ctx - g["ctx"]).max() < 1e-6
+    t = np.load(os.path.join(GOLD, "oracle_beam_trace.npz"))
+    s, sc, vlen = gn.beam_search(dec, mem, states, vl, 2, 3, c["beam"], 1.0, 5, c["max_length"])
+    assert np.array_equal(s, t["samples"]) and np.array_equal(vlen, t["valid_length"]) and np.abs(sc - t["scores"]).max() < 1e-5
+    d = np.load(os.path.join(GOLD, "oracle_densenet121_224_b2.npz"))
+    p, x = mk.densenet_inputs()
+    taps = {}
+    feats = dn.densenet121_features(x[:1], p, taps=taps)               # one of the two frames keeps the CPU suite short
+    assert np.abs(feats - d["feats"][:1]).max() < 1e-5
+    assert np.abs(dn.dense(feats, p, "framemodel0_dense0_") - d["logits"][:1]).max() < 1e-5
