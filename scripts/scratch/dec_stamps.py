@@ -1,7 +1,7 @@
 """Tuning: phase durations of the beam-search step kernels (alt build with -DTN_DEC_STAMPS)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-os.environ["TENNIS_HIP_LIB"] = os.path.abspath("tennis_amd/lib/alt/libtennis_stamps.so")
+os.environ["TENNIS_HIP_LIB"] = os.path.abspath("tennis_amd/lib/alt/libtennis_stamps.so")   # hipcc -DTN_DEC_STAMPS build of captioner.hip linked with the other objects
 import numpy as np, torch
 from tennis_amd import weights as W, _lib
 from tennis_amd.engine import GNMTCaptioner
