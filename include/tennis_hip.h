@@ -163,6 +163,30 @@ int tn_head_sgd_step(tn_head *h, float lr, float momentum, float wd, float resca
 int tn_head_read_param(tn_head *h, const char *name, int gradient, float *out_host, int64_t capacity, int64_t *numel);
 int tn_head_destroy(tn_head *h);
 
+/* ---- captioner training step ---------------------------------- */
+/* One step of reference train_gnmt.py::train (:328-337) for GRU cells, num_layers = 2, num_bi_layers = 1:
+ *   out, _ = model(src, tgt[:, :-1], src_valid_length, tgt_valid_length - 1)        teacher-forced NMTModel.forward
+ *   loss = MaskedSoftmaxCELoss(out, tgt[:, 1:], tgt_valid_length - 1).mean()
+ *          * (tgt.shape[1] - 1) / (tgt_valid_length - 1).mean()                      = summed NLL / number of valid tokens
+ *   loss.backward(); gluon.Trainer(params, 'adam', {'learning_rate': lr}).step(1)   MXNet Adam [EXT]
+ * Parameters use the names of tn_gnmt_create.  forward_backward takes DEVICE buffers: src (batch, steps, input_size)
+ * fp32, tgt (batch, ld) int32 of which tgt_len columns are used, valid lengths (batch,) int32 (tgt_valid_len counts BOS
+ * and EOS, as the reference's data loader gives it); loss is one device float, logits_out (batch, tgt_len-1, vocab)
+ * optional.  The gradient of the loss w.r.t. every parameter is left in the flat gradient buffer
+ * (tn_gnmt_trainer_buffers; all-reduce it over ranks for data parallelism) for tn_gnmt_trainer_adam_step. */
+typedef struct tn_gnmt_trainer tn_gnmt_trainer;
+int tn_gnmt_trainer_create(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix, int input_size,
+                           int hidden, int embed, int vocab, int max_batch, int max_src_len, int max_tgt_len,
+                           tn_gnmt_trainer **out);
+int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float *src, const int32_t *src_valid_len,
+                                     const int32_t *tgt, int ld, const int32_t *tgt_valid_len, int batch, int steps,
+                                     int tgt_len, float *loss, float *logits_out);
+int tn_gnmt_trainer_buffers(tn_gnmt_trainer *t, float **params_dev, float **grads_dev, int64_t *numel);
+int tn_gnmt_trainer_adam_step(tn_gnmt_trainer *t, float lr, float beta1, float beta2, float epsilon);
+int tn_gnmt_trainer_read_param(tn_gnmt_trainer *t, const char *name, int gradient, float *out_host, int64_t capacity,
+                               int64_t *numel);
+int tn_gnmt_trainer_destroy(tn_gnmt_trainer *t);
+
 /* ---- device PRF1 confusion histogram -------------------------------------- */
 /* Replaces the argmax + per-sample python loop of PRF1.update (reference
  * metrics/vision.py:41-49).  logits (rows,classes) fp32, labels (rows,) int32;

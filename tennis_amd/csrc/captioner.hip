@@ -20,6 +20,8 @@
 
 #include "common.h"
 #include "linear.h"
+#include "rnn.h"
+#include "train.h"
 
 namespace {
 
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(kBeamThreads) void dec_attention_kernel(
     const float *__restrict__ g0, const float *__restrict__ hprev, int ldh, const float *__restrict__ cprev, int lstm,
     float *__restrict__ hn, float *__restrict__ cn, float *__restrict__ x1, int ldx1,
     const float *__restrict__ kpT, const float *__restrict__ mem, const int32_t *__restrict__ valid_len,
-    float *__restrict__ ctx, int beam, int rows, int T, int H) {
+    float *__restrict__ ctx, int beam, int rows, int T, int H, float *__restrict__ wsave = nullptr) {
   constexpr int NP = (NBM + 3) & ~3;
   extern __shared__ float sm[];   // q[H][NP] | w[T][NP] | part[4][rows][max(T,H)]
   float *q = sm, *w = q + H * NP, *part = w + T * NP;
@@ -130,7 +132,11 @@ __global__ __launch_bounds__(kBeamThreads) void dec_attention_kernel(
     }
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     const float rs = 1.0f / sum;
-    for (int s = lane; s < T; s += 64) w[s * NP + wid] = s < vl ? w[s * NP + wid] * rs : 0.f;
+    for (int s = lane; s < T; s += 64) {
+      const float v = s < vl ? w[s * NP + wid] * rs : 0.f;
+      w[s * NP + wid] = v;
+      if (wsave) wsave[((long)r0 + wid) * T + s] = v;      // training keeps the attention weights
+    }
   } else if (wid < NP) {
     for (int s = lane; s < T; s += 64) w[s * NP + wid] = 0.f;      // padded rows feed unused accumulators
   }
@@ -505,6 +511,191 @@ __global__ __launch_bounds__(256) void masked_ce_kernel(const float *__restrict_
   if (t == 0) loss[b] = total / (float)L;
 }
 
+// ---- training step of the captioner (GRU cells) ------------------------------------------------------
+// Teacher-forced forward with everything the backward pass needs kept per step (step-major (L,B,.) arrays), the
+// gradient of the token-averaged masked cross-entropy, back-propagation through the decoder steps, the attention, the
+// key projection and the two encoder layers, Adam.  Reference: train_gnmt.py:310,328-337.
+
+// step inputs of teacher forcing, strided sources: x0 = [embed(tok), ctx_prev | 0, h0_prev], x1[:, 2H:3H] = h1_prev
+__global__ void trn_prep_kernel(const float *__restrict__ emb, const int32_t *__restrict__ tgt, int ld, int col,
+                                const float *__restrict__ ctx_prev, int ldc, const float *__restrict__ h0_prev, int ld0,
+                                const float *__restrict__ h1_prev, int ld1, float *__restrict__ x0, float *__restrict__ x1,
+                                int H, int E) {
+  const int r = blockIdx.x, K0 = E + 2 * H, K1 = 3 * H;
+  const int tok = tgt[(long)r * ld + col];
+  const float *e = emb + (long)(tok > 0 ? tok : 0) * E;
+  for (int i = threadIdx.x; i < K0; i += blockDim.x)
+    x0[(long)r * K0 + i] = i < E ? e[i] : i < E + H ? (ctx_prev ? ctx_prev[(long)r * ldc + i - E] : 0.f) : h0_prev[(long)r * ld0 + i - E - H];
+  for (int u = threadIdx.x; u < H; u += blockDim.x) x1[(long)r * K1 + 2 * H + u] = h1_prev[(long)r * ld1 + u];
+}
+
+// d loss / d logits for loss = sum over valid (b, t) of -log softmax(logits[b, t])[label] / (number of valid tokens);
+// logits (B, L, V) as decode_seq lays them out, dlogits STEP-major (L, B, V) like every other per-step array here
+__global__ __launch_bounds__(256) void trn_ce_bwd_kernel(const float *__restrict__ logits, const int32_t *__restrict__ labels,
+                                                         int ldl, const int32_t *__restrict__ valid_len, int B, int L, int V,
+                                                         float *__restrict__ dlogits, float *__restrict__ loss_rows) {
+  __shared__ float red[256];
+  const int i = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  int ntok = 0;
+  for (int q = 0; q < B; ++q) ntok += min(max(valid_len[q], 0), L);
+  const float *z = logits + ((long)b * L + i) * V;
+  float *d = dlogits + ((long)i * B + b) * V;
+  const bool valid = i < valid_len[b];
+  float mx = -INFINITY;
+  for (int v = t; v < V; v += 256) mx = fmaxf(mx, z[v]);
+  red[t] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] = fmaxf(red[t], red[t + o]); __syncthreads(); }
+  mx = red[0];
+  __syncthreads();
+  float sum = 0.f;
+  for (int v = t; v < V; v += 256) sum += expf(z[v] - mx);
+  red[t] = sum;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+  const float lse = mx + logf(red[0]);
+  const int lab = labels[(long)b * ldl + i];
+  const float sc = valid && ntok > 0 ? 1.0f / (float)ntok : 0.f;
+  for (int v = t; v < V; v += 256) d[v] = (expf(z[v] - lse) - (v == lab ? 1.f : 0.f)) * sc;
+  if (t == 0) loss_rows[(long)i * B + b] = valid ? (lse - z[lab]) * sc : 0.f;     // summed over (i, b) = the loss
+}
+
+// GRU cell backward on the stacked pre-activations g (R,4H) = [r, z, n_i2h, n_h2h]:
+//   dh = sum of up to four addends (each (R,H) with its own row stride, null = absent)
+//   dg (R,4H) = [d r, d z, d n, d n * r]   (the stacked weight matrix routes them to both branches)
+//   dhz (R,H) = dh * z                     (the direct path to h_prev; the rest comes back through dg x W)
+__global__ void trn_gru_bwd_kernel(const float *__restrict__ g, const float *__restrict__ hprev, int ldh,
+                                   const float *a0, int l0, const float *a1, int l1, const float *a2, int l2,
+                                   const float *a3, int l3, float *__restrict__ dg, float *dhz, int R, int H) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)R * H) return;
+  const long r = id / H;
+  const int u = (int)(id - r * H);
+  const float *q = g + r * 4 * H;
+  const float rg = sigm(q[u]), zg = sigm(q[H + u]), anh = q[3 * H + u];
+  const float ng = tanhf(q[2 * H + u] + rg * anh);
+  const float hp = hprev[r * ldh + u];
+  float dh = 0.f;
+  if (a0) dh += a0[r * l0 + u];
+  if (a1) dh += a1[r * l1 + u];
+  if (a2) dh += a2[r * l2 + u];
+  if (a3) dh += a3[r * l3 + u];
+  const float dn = dh * (1.f - zg) * (1.f - ng * ng);
+  float *o = dg + r * 4 * H;
+  o[u] = dn * anh * rg * (1.f - rg);
+  o[H + u] = dh * (hp - ng) * zg * (1.f - zg);
+  o[2 * H + u] = dn;
+  o[3 * H + u] = dn * rg;
+  dhz[id] = dh * zg;
+}
+
+// attention backward for one decoder row per workgroup (256 threads): ctx = sum_t w_t mem_t, w = masked softmax of
+// s_t = q . kp_t, q = h0 / sqrt(H).  dctx = up to two addends.  Accumulates into dmem, dkp (B,T,H); writes dq / sqrt(H).
+__global__ __launch_bounds__(256) void trn_att_bwd_kernel(const float *__restrict__ aw, const float *__restrict__ mem,
+                                                          const float *__restrict__ keyproj, const float *__restrict__ h0,
+                                                          int ldh, const float *c0, int lc0, const float *c1, int lc1,
+                                                          const int32_t *__restrict__ valid_len, float *__restrict__ dmem,
+                                                          float *__restrict__ dkp, float *__restrict__ dh0, int T, int H) {
+  extern __shared__ float sm[];    // dctx[H] | q[H] | ds[T] | red[256]
+  float *dctx = sm, *q = sm + H, *ds = q + H, *red = ds + T;
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int vl = min(max(valid_len[b], 0), T);
+  const float inv = 1.0f / sqrtf((float)H);
+  for (int u = t; u < H; u += 256) {
+    dctx[u] = (c0 ? c0[(long)b * lc0 + u] : 0.f) + (c1 ? c1[(long)b * lc1 + u] : 0.f);
+    q[u] = h0[(long)b * ldh + u] * inv;
+  }
+  __syncthreads();
+  const float *w = aw + (long)b * T;
+  const float *mv = mem + (long)b * T * H, *kp = keyproj + (long)b * T * H;
+  // dw_t = mem_t . dctx  (one wave per source step)
+  for (int s = wid; s < vl; s += 4) {
+    float a = 0.f;
+    for (int u = lane; u < H; u += 64) a = fmaf(mv[(long)s * H + u], dctx[u], a);
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (lane == 0) ds[s] = a;
+  }
+  __syncthreads();
+  float part = 0.f;
+  for (int s = t; s < vl; s += 256) part += w[s] * ds[s];
+  red[t] = part;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+  const float dot = red[0];
+  __syncthreads();
+  for (int s = t; s < vl; s += 256) ds[s] = w[s] * (ds[s] - dot);
+  __syncthreads();
+  // dmem_t += w_t dctx ; dkp_t += ds_t q ; dq = sum_t ds_t kp_t
+  for (int u = t; u < H; u += 256) {
+    float dq = 0.f;
+    const float dc = dctx[u], qu = q[u];
+    for (int s = 0; s < vl; ++s) {
+      const long o = ((long)b * T + s) * H + u;
+      dmem[o] += w[s] * dc;
+      dkp[o] += ds[s] * qu;
+      dq = fmaf(ds[s], kp[(long)s * H + u], dq);
+    }
+    dh0[(long)b * H + u] = dq * inv;
+  }
+}
+
+// d embedding: rows of the step-major input gradients summed per token, in (step, row) order (deterministic)
+__global__ void trn_emb_grad_kernel(const float *__restrict__ dx0, int K0, const int32_t *__restrict__ tgt, int ld, int B,
+                                    int L, int E, int V, float *__restrict__ demb) {
+  const int v = blockIdx.x;
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    float a = 0.f;
+    for (int i = 0; i < L; ++i)
+      for (int b = 0; b < B; ++b) {
+        const int tok = tgt[(long)b * ld + i];
+        if ((tok > 0 ? tok : 0) == v) a += dx0[((long)i * B + b) * K0 + e];
+      }
+    demb[(long)v * E + e] = a;
+  }
+}
+
+// Gluon cell parameters <-> the stacked (4H, in+H) matrix of the step GEMM (GRU: rows r, z = [Wi | Wh], bias bi + bh;
+// rows 2H..3H = [Wi_n | 0], bias bi_n; rows 3H..4H = [0 | Wh_n], bias bh_n)
+__global__ void trn_stack_kernel(const float *__restrict__ wi, const float *__restrict__ wh, const float *__restrict__ bi,
+                                 const float *__restrict__ bh, int in, int H, float *__restrict__ wc, float *__restrict__ bc) {
+  const int row = blockIdx.x, Kc = in + H;
+  const int src_i = row < 3 * H ? row : -1, src_h = row < 2 * H ? row : row >= 3 * H ? row - H : -1;
+  for (int k = threadIdx.x; k < Kc; k += blockDim.x)
+    wc[(long)row * Kc + k] = k < in ? (src_i >= 0 ? wi[(long)src_i * in + k] : 0.f) : (src_h >= 0 ? wh[(long)src_h * H + k - in] : 0.f);
+  if (threadIdx.x == 0) bc[row] = (src_i >= 0 ? bi[src_i] : 0.f) + (src_h >= 0 ? bh[src_h] : 0.f);
+}
+__global__ void trn_unstack_kernel(const float *__restrict__ dwc, const float *__restrict__ dbc, int in, int H,
+                                   float *__restrict__ dwi, float *__restrict__ dwh, float *__restrict__ dbi,
+                                   float *__restrict__ dbh) {
+  const int row = blockIdx.x, Kc = in + H;     // row of the Gluon (3H, .) matrices
+  const int ri = row, rh = row < 2 * H ? row : row + H;
+  for (int k = threadIdx.x; k < Kc; k += blockDim.x) {
+    if (k < in) dwi[(long)row * in + k] = dwc[(long)ri * Kc + k];
+    else dwh[(long)row * H + k - in] = dwc[(long)rh * Kc + k];
+  }
+  if (threadIdx.x == 0) { dbi[row] = dbc[ri]; dbh[row] = dbc[rh]; }
+}
+
+__global__ void trn_add2_kernel(const float *__restrict__ a, int la, const float *__restrict__ b, int lb,
+                                float *__restrict__ out, int R, int H) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)R * H) return;
+  const long r = id / H;
+  const int u = (int)(id - r * H);
+  out[id] = a[r * la + u] + b[r * lb + u];
+}
+
+// MXNet Adam [EXT]: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; w -= lr_t m / (sqrt(v) + eps), lr_t bias-corrected
+__global__ void trn_adam_kernel(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m,
+                                float *__restrict__ v, long n, float lr_t, float b1, float b2, float eps) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  const float mi = b1 * m[i] + (1.f - b1) * gi, vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi; v[i] = vi;
+  w[i] -= lr_t * mi / (sqrtf(vi) + eps);
+}
+
 struct DevBuf {
   std::vector<void *> ptrs;
   bool failed = false;
@@ -805,6 +996,312 @@ extern "C" int tn_masked_softmax_ce(tn_ctx *ctx, const float *logits, const int3
   TN_HIP_CHECK(hipSetDevice(ctx->device));
   hipLaunchKernelGGL(masked_ce_kernel, dim3(batch), dim3(256), 0, ctx->stream, logits, labels, ld_labels, valid_len, loss, steps, vocab);
   TN_HIP_CHECK(hipGetLastError());
+  return TN_OK;
+}
+
+// ---- captioner training handle ------------------------------------------------------------------------------------------
+struct tn_gnmt_trainer {
+  tn_ctx *ctx;
+  DevBuf pool;
+  int F, H, E, V, maxB, maxT, maxL;
+  std::string prefix;
+  // flat parameter / gradient / Adam-moment buffers; the two directions of the bi layer are adjacent per tensor kind so that
+  // one GEMM / one recurrent launch serves both
+  long n, step;
+  long o_e0wi, o_e0bi, o_e0wh, o_e0bh, o_e1wi, o_e1bi, o_e1wh, o_e1bh, o_d0wi, o_d0bi, o_d0wh, o_d0bh, o_d1wi, o_d1bi,
+      o_d1wh, o_d1bh, o_wk, o_wp, o_bp, o_emb;
+  float *w, *g, *am, *av;
+  // derived forms of the weights, refreshed after every update
+  float *e0whT, *e1whT, *e1wiT, *w0c, *b0c, *w1c, *b1c, *w0cT, *w1cT, *wpT, *wkT;
+  // forward state kept for the backward pass
+  float *gi0, *seq0, *sav0, *gi1, *mem, *sav1, *hl0, *hl1, *keyproj, *keyprojT;
+  float *X0, *G0, *X1, *G1, *H1, *AW, *h0tmp, *ctxtmp, *logits, *lossrows;
+  int32_t *vl, *tvl;
+  // backward workspace
+  float *dlog, *dH1, *dG0, *dG1, *dX0, *dX1, *dhz0, *dhz1, *dq, *dmem, *dkp, *dW0c, *db0c, *dW1c, *db1c;
+  float *dhl0, *dhl1, *dgi1, *dgh1, *hp1, *dseq0, *dgi0, *dgh0, *hp0;
+};
+
+static int trainer_refresh(tn_gnmt_trainer *t) {
+  hipStream_t s = t->ctx->stream;
+  const int H = t->H, E = t->E, V = t->V, GH = 3 * H, K0 = E + 2 * H, K1 = 3 * H;
+  int rc;
+#define TN_TRY(e) do { rc = (e); if (rc) return rc; } while (0)
+  for (int d = 0; d < 2; ++d)
+    TN_TRY(launch_transpose_f32(t->w + t->o_e0wh + (long)d * GH * H, GH, H, t->e0whT + (long)d * H * GH, s));
+  TN_TRY(launch_transpose_f32(t->w + t->o_e1wh, GH, H, t->e1whT, s));
+  TN_TRY(launch_transpose_f32(t->w + t->o_e1wi, GH, 2 * H, t->e1wiT, s));
+  hipLaunchKernelGGL(trn_stack_kernel, dim3(4 * H), dim3(256), 0, s, (const float *)(t->w + t->o_d0wi), (const float *)(t->w + t->o_d0wh),
+                     (const float *)(t->w + t->o_d0bi), (const float *)(t->w + t->o_d0bh), E + H, H, t->w0c, t->b0c);
+  hipLaunchKernelGGL(trn_stack_kernel, dim3(4 * H), dim3(256), 0, s, (const float *)(t->w + t->o_d1wi), (const float *)(t->w + t->o_d1wh),
+                     (const float *)(t->w + t->o_d1bi), (const float *)(t->w + t->o_d1bh), 2 * H, H, t->w1c, t->b1c);
+  TN_TRY(launch_transpose_f32(t->w0c, 4 * H, K0, t->w0cT, s));
+  TN_TRY(launch_transpose_f32(t->w1c, 4 * H, K1, t->w1cT, s));
+  TN_TRY(launch_transpose_f32(t->w + t->o_wp, V, H, t->wpT, s));
+  TN_TRY(launch_transpose_f32(t->w + t->o_wk, H, H, t->wkT, s));
+#undef TN_TRY
+  TN_HIP_CHECK(hipGetLastError());
+  return TN_OK;
+}
+
+extern "C" int tn_gnmt_trainer_create(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix_c, int input_size,
+                                      int hidden, int embed, int vocab, int max_batch, int max_src_len, int max_tgt_len,
+                                      tn_gnmt_trainer **out) {
+  TN_REQUIRE(ctx && params && prefix_c && out, "tn_gnmt_trainer_create: null argument");
+  TN_REQUIRE(input_size > 0 && hidden > 0 && hidden % 4 == 0 && 3 * hidden <= 1024 && embed > 0 && vocab > 1 && max_batch > 0 &&
+                 max_src_len > 0 && max_tgt_len > 1, "tn_gnmt_trainer_create: bad shape (3*hidden <= 1024, hidden % 4 == 0)");
+  TN_HIP_CHECK(hipSetDevice(ctx->device));
+  const std::string pre(prefix_c);
+  std::map<std::string, const tn_param *> pm;
+  for (int i = 0; i < n_params; ++i) pm[params[i].name] = &params[i];
+  tn_gnmt_trainer *t = new tn_gnmt_trainer();
+  t->ctx = ctx; t->F = input_size; t->H = hidden; t->E = embed; t->V = vocab; t->maxB = max_batch; t->maxT = max_src_len;
+  t->maxL = max_tgt_len - 1; t->prefix = pre; t->step = 0;
+  const long F = input_size, H = hidden, E = embed, V = vocab, GH = 3 * H;
+  long o = 0;
+  auto take = [&](long cnt) { const long r = o; o += cnt; return r; };
+  t->o_e0wi = take(2 * GH * F); t->o_e0bi = take(2 * GH); t->o_e0wh = take(2 * GH * H); t->o_e0bh = take(2 * GH);
+  t->o_e1wi = take(GH * 2 * H); t->o_e1bi = take(GH); t->o_e1wh = take(GH * H); t->o_e1bh = take(GH);
+  t->o_d0wi = take(GH * (E + H)); t->o_d0bi = take(GH); t->o_d0wh = take(GH * H); t->o_d0bh = take(GH);
+  t->o_d1wi = take(GH * 2 * H); t->o_d1bi = take(GH); t->o_d1wh = take(GH * H); t->o_d1bh = take(GH);
+  t->o_wk = take(H * H); t->o_wp = take(V * H); t->o_bp = take(V); t->o_emb = take(V * E);
+  t->n = o;
+  std::vector<float> w(t->n);
+  auto fail = [&](int code) { t->pool.release(); delete t; return code; };
+  bool ok = true;
+  auto put = [&](const std::string &name, long off, long cnt) {
+    auto it = pm.find(pre + name);
+    if (it == pm.end()) { tn_set_error("missing parameter: " + pre + name); ok = false; return; }
+    if (it->second->numel != cnt) { tn_set_error("parameter " + pre + name + " has the wrong size"); ok = false; return; }
+    memcpy(&w[off], it->second->data_host, sizeof(float) * cnt);
+  };
+  for (int d = 0; d < 2 && ok; ++d) {
+    const std::string c = std::string("enc_rnn0_") + (d ? "r_" : "l_");
+    put(c + "i2h_weight", t->o_e0wi + d * GH * F, GH * F); put(c + "i2h_bias", t->o_e0bi + d * GH, GH);
+    put(c + "h2h_weight", t->o_e0wh + d * GH * H, GH * H); put(c + "h2h_bias", t->o_e0bh + d * GH, GH);
+  }
+  put("enc_rnn1_i2h_weight", t->o_e1wi, GH * 2 * H); put("enc_rnn1_i2h_bias", t->o_e1bi, GH);
+  put("enc_rnn1_h2h_weight", t->o_e1wh, GH * H); put("enc_rnn1_h2h_bias", t->o_e1bh, GH);
+  put("dec_rnn0_i2h_weight", t->o_d0wi, GH * (E + H)); put("dec_rnn0_i2h_bias", t->o_d0bi, GH);
+  put("dec_rnn0_h2h_weight", t->o_d0wh, GH * H); put("dec_rnn0_h2h_bias", t->o_d0bh, GH);
+  put("dec_rnn1_i2h_weight", t->o_d1wi, GH * 2 * H); put("dec_rnn1_i2h_bias", t->o_d1bi, GH);
+  put("dec_rnn1_h2h_weight", t->o_d1wh, GH * H); put("dec_rnn1_h2h_bias", t->o_d1bh, GH);
+  put("dec_attention_key_weight", t->o_wk, H * H); put("tgt_proj_weight", t->o_wp, V * H); put("tgt_proj_bias", t->o_bp, V);
+  put("tgt_embed_weight", t->o_emb, V * E);
+  if (!ok) return fail(TN_ERR_MISSING);
+  t->w = t->pool.upload(w.data(), w.size());
+  auto fl = [&](size_t n) { return t->pool.alloc<float>(n); };
+  t->g = fl(t->n); t->am = fl(t->n); t->av = fl(t->n);
+  const size_t B = max_batch, T = max_src_len, L = t->maxL, BT = B * T, LB = L * B, K0 = E + 2 * H, K1 = 3 * H;
+  t->e0whT = fl(2 * H * GH); t->e1whT = fl(H * GH); t->e1wiT = fl(2 * H * GH);
+  t->w0c = fl(4 * H * K0); t->b0c = fl(4 * H); t->w1c = fl(4 * H * K1); t->b1c = fl(4 * H);
+  t->w0cT = fl(4 * H * K0); t->w1cT = fl(4 * H * K1); t->wpT = fl(V * H); t->wkT = fl(H * H);
+  t->gi0 = fl(BT * 2 * GH); t->seq0 = fl(BT * 2 * H); t->sav0 = fl(2 * BT * 4 * H); t->gi1 = fl(BT * GH); t->mem = fl(BT * H);
+  t->sav1 = fl(BT * 4 * H); t->hl0 = fl(2 * B * H); t->hl1 = fl(B * H); t->keyproj = fl(BT * H); t->keyprojT = fl(BT * H);
+  t->X0 = fl(LB * K0); t->G0 = fl(LB * 4 * H); t->X1 = fl(LB * K1); t->G1 = fl(LB * 4 * H); t->H1 = fl(LB * H); t->AW = fl(LB * T);
+  t->h0tmp = fl(B * H); t->ctxtmp = fl(B * H); t->logits = fl(LB * V); t->lossrows = fl(LB);
+  t->vl = t->pool.alloc<int32_t>(B); t->tvl = t->pool.alloc<int32_t>(B);
+  t->dlog = fl(LB * V); t->dH1 = fl(LB * H); t->dG0 = fl(LB * 4 * H); t->dG1 = fl(LB * 4 * H); t->dX0 = fl(LB * K0);
+  t->dX1 = fl(LB * K1); t->dhz0 = fl(B * H); t->dhz1 = fl(B * H); t->dq = fl(B * H); t->dmem = fl(BT * H); t->dkp = fl(BT * H);
+  t->dW0c = fl(4 * H * K0); t->db0c = fl(4 * H); t->dW1c = fl(4 * H * K1); t->db1c = fl(4 * H);
+  t->dhl0 = fl(2 * B * H); t->dhl1 = fl(B * H); t->dgi1 = fl(BT * GH); t->dgh1 = fl(BT * GH); t->hp1 = fl(BT * H);
+  t->dseq0 = fl(BT * 2 * H); t->dgi0 = fl(BT * 2 * GH); t->dgh0 = fl(BT * 2 * GH); t->hp0 = fl(2 * BT * H);
+  if (t->pool.failed) { tn_set_error("device allocation failed"); return fail(TN_ERR_NOMEM); }
+  TN_HIP_CHECK(hipMemsetAsync(t->g, 0, sizeof(float) * t->n, ctx->stream));
+  TN_HIP_CHECK(hipMemsetAsync(t->am, 0, sizeof(float) * t->n, ctx->stream));
+  TN_HIP_CHECK(hipMemsetAsync(t->av, 0, sizeof(float) * t->n, ctx->stream));
+  const int rc = trainer_refresh(t);
+  if (rc) return fail(rc);
+  *out = t;
+  return TN_OK;
+}
+
+__global__ void trn_dec_len_kernel(const int32_t *__restrict__ tgt_vl, int32_t *__restrict__ out, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) out[b] = tgt_vl[b] - 1;          // train_gnmt.py:331-332: the model and the loss see tgt_valid_length - 1
+}
+
+// One training step's forward + backward.  src (B,T,F) fp32, src_valid_len (B), tgt (B, ld) token ids with tgt_len >= 2
+// columns used (inputs tgt[:, :-1], labels tgt[:, 1:]), tgt_valid_len (B) as the data loader gives it (BOS and EOS
+// counted); all DEVICE buffers.  loss (1 float, device) = summed NLL of the valid target tokens / their number
+// (= the scalar of train_gnmt.py:332-333); logits_out (B, tgt_len-1, V) optional.  Gradients of that loss land in the
+// flat gradient buffer (tn_gnmt_trainer_buffers).
+extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float *src, const int32_t *src_valid_len,
+                                                const int32_t *tgt, int ld, const int32_t *tgt_valid_len, int batch, int steps,
+                                                int tgt_len, float *loss, float *logits_out) {
+  TN_REQUIRE(t && src && src_valid_len && tgt && tgt_valid_len && loss, "tn_gnmt_trainer_forward_backward: null argument");
+  TN_REQUIRE(batch > 0 && batch <= t->maxB && steps > 0 && steps <= t->maxT && tgt_len >= 2 && tgt_len - 1 <= t->maxL && ld >= tgt_len,
+             "tn_gnmt_trainer_forward_backward: batch / source steps / target length exceed the handle");
+  TN_HIP_CHECK(hipSetDevice(t->ctx->device));
+  hipStream_t s = t->ctx->stream;
+  const int B = batch, T = steps, L = tgt_len - 1, F = t->F, H = t->H, E = t->E, V = t->V, GH = 3 * H, K0 = E + 2 * H, K1 = 3 * H;
+  const int BT = B * T, LB = L * B;
+  const size_t att_lds = ((size_t)(H + T) * 4 + (size_t)4 * (T > H ? T : H)) * sizeof(float);
+  const size_t attb_lds = (size_t)(2 * H + T + 256) * sizeof(float);
+  TN_REQUIRE(att_lds <= 64 * 1024 && attb_lds <= 64 * 1024, "tn_gnmt_trainer: 8 * max(hidden, source length) exceeds 64 KiB of LDS");
+  float *w = t->w, *g = t->g;
+  int rc;
+#define TN_TRY(e) do { rc = (e); if (rc) return rc; } while (0)
+  const int nbH = (B * H + 255) / 256;
+  // ---------------- forward ----------------
+  TN_HIP_CHECK(hipMemcpyAsync(t->vl, src_valid_len, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(trn_dec_len_kernel, dim3((B + 255) / 256), dim3(256), 0, s, tgt_valid_len, t->tvl, B);
+  TN_TRY(launch_linear_f32(src, F, w + t->o_e0wi, F, w + t->o_e0bi, t->gi0, 2 * GH, BT, 2 * GH, F, 0, s));
+  TN_HIP_CHECK(hipMemsetAsync(t->seq0, 0, sizeof(float) * (size_t)BT * 2 * H, s));
+  TN_TRY(launch_rnn_recurrent(3, t->gi0, 2 * GH, t->e0whT, w + t->o_e0bh, t->vl, t->seq0, 2 * H, t->hl0, nullptr, B, T, H, 2, s, t->sav0));
+  TN_TRY(launch_linear_f32(t->seq0, 2 * H, w + t->o_e1wi, 2 * H, w + t->o_e1bi, t->gi1, GH, BT, GH, 2 * H, 0, s));
+  TN_HIP_CHECK(hipMemsetAsync(t->mem, 0, sizeof(float) * (size_t)BT * H, s));
+  TN_TRY(launch_rnn_recurrent(3, t->gi1, GH, t->e1whT, w + t->o_e1bh, t->vl, t->mem, H, t->hl1, nullptr, B, T, H, 1, s, t->sav1));
+  TN_TRY(launch_linear_f32(t->mem, H, w + t->o_wk, H, nullptr, t->keyproj, H, BT, H, H, 0, s));
+  hipLaunchKernelGGL(transpose_bth_kernel, dim3((H + 31) / 32, (T + 31) / 32, B), dim3(256), 0, s, (const float *)t->keyproj, t->keyprojT, T, H);
+  for (int i = 0; i < L; ++i) {
+    float *X0 = t->X0 + (size_t)i * B * K0, *X1 = t->X1 + (size_t)i * B * K1, *G0 = t->G0 + (size_t)i * B * 4 * H;
+    float *G1 = t->G1 + (size_t)i * B * 4 * H, *H1 = t->H1 + (size_t)i * B * H;
+    const float *X1p = t->X1 + (size_t)(i - 1) * B * K1, *H1p = t->H1 + (size_t)(i - 1) * B * H;
+    // decoder layer 0 starts from the encoder's BACKWARD layer-0 state, layer 1 from the uni layer (gnmt.py:146-150,224-252)
+    hipLaunchKernelGGL(trn_prep_kernel, dim3(B), dim3(256), 0, s, (const float *)(w + t->o_emb), tgt, ld, i,
+                       i ? X1p + H : (const float *)nullptr, K1, i ? X1p : (const float *)(t->hl0 + (size_t)B * H), i ? K1 : H,
+                       i ? H1p : (const float *)t->hl1, H, X0, X1, H, E);
+    TN_TRY(launch_linear_f32(X0, K0, t->w0c, K0, t->b0c, G0, 4 * H, B, 4 * H, K0, 0, s));
+    hipLaunchKernelGGL(dec_attention_kernel<1>, dim3(B), dim3(kBeamThreads), att_lds, s, (const float *)G0, (const float *)(X0 + E + H), K0,
+                       (const float *)nullptr, 0, t->h0tmp, (float *)nullptr, X1, K1, (const float *)t->keyprojT, (const float *)t->mem,
+                       (const int32_t *)t->vl, t->ctxtmp, 1, 1, T, H, t->AW + (size_t)i * B * T);
+    TN_TRY(launch_linear_f32(X1, K1, t->w1c, K1, t->b1c, G1, 4 * H, B, 4 * H, K1, 0, s));
+    hipLaunchKernelGGL(dec_tf_cell1_kernel, dim3(nbH), dim3(256), 0, s, (const float *)G1, (const float *)X1, 0, (const float *)nullptr, H1,
+                       (float *)nullptr, B, H);
+    TN_TRY(launch_linear_f32(H1, H, w + t->o_wp, H, w + t->o_bp, t->logits + (size_t)i * V, L * V, B, V, H, 0, s));
+  }
+  // ---------------- loss and its gradient ----------------
+  hipLaunchKernelGGL(trn_ce_bwd_kernel, dim3(L, B), dim3(256), 0, s, (const float *)t->logits, tgt + 1, ld, (const int32_t *)t->tvl, B, L, V,
+                     t->dlog, t->lossrows);
+  TN_TRY(launch_colsum_f32(t->lossrows, 1, LB, 1, loss, s));
+  if (logits_out) TN_HIP_CHECK(hipMemcpyAsync(logits_out, t->logits, sizeof(float) * (size_t)LB * V, hipMemcpyDeviceToDevice, s));
+  // ---------------- backward: projection ----------------
+  TN_TRY(launch_linear_f32(t->dlog, V, t->wpT, V, nullptr, t->dH1, H, LB, H, V, 0, s));
+  TN_TRY(launch_gemm_tn_f32(t->dlog, V, t->H1, H, g + t->o_wp, H, V, H, LB, s));
+  TN_TRY(launch_colsum_f32(t->dlog, V, LB, V, g + t->o_bp, s));
+  TN_HIP_CHECK(hipMemsetAsync(t->dmem, 0, sizeof(float) * (size_t)BT * H, s));
+  TN_HIP_CHECK(hipMemsetAsync(t->dkp, 0, sizeof(float) * (size_t)BT * H, s));
+  // ---------------- backward: decoder steps, last to first ----------------
+  for (int i = L - 1; i >= 0; --i) {
+    const bool last = i == L - 1;
+    float *X0 = t->X0 + (size_t)i * B * K0, *X1 = t->X1 + (size_t)i * B * K1, *G0 = t->G0 + (size_t)i * B * 4 * H;
+    float *G1 = t->G1 + (size_t)i * B * 4 * H;
+    float *dG0 = t->dG0 + (size_t)i * B * 4 * H, *dG1 = t->dG1 + (size_t)i * B * 4 * H;
+    float *dX0 = t->dX0 + (size_t)i * B * K0, *dX1 = t->dX1 + (size_t)i * B * K1;
+    const float *dX0n = t->dX0 + (size_t)(i + 1) * B * K0, *dX1n = t->dX1 + (size_t)(i + 1) * B * K1;   // step i+1 (valid unless last)
+    const float *nul = nullptr;
+    hipLaunchKernelGGL(trn_gru_bwd_kernel, dim3(nbH), dim3(256), 0, s, (const float *)G1, (const float *)(X1 + 2 * H), K1,
+                       (const float *)(t->dH1 + (size_t)i * B * H), H, last ? nul : (const float *)t->dhz1, H, last ? nul : dX1n + 2 * H, K1,
+                       nul, 0, dG1, t->dhz1, B, H);
+    TN_TRY(launch_linear_f32(dG1, 4 * H, t->w1cT, 4 * H, nullptr, dX1, K1, B, K1, 4 * H, 0, s));
+    hipLaunchKernelGGL(trn_att_bwd_kernel, dim3(B), dim3(256), attb_lds, s, (const float *)(t->AW + (size_t)i * B * T), (const float *)t->mem,
+                       (const float *)t->keyproj, (const float *)X1, K1, (const float *)(dX1 + H), K1, last ? nul : dX0n + E, K0,
+                       (const int32_t *)t->vl, t->dmem, t->dkp, t->dq, T, H);
+    hipLaunchKernelGGL(trn_gru_bwd_kernel, dim3(nbH), dim3(256), 0, s, (const float *)G0, (const float *)(X0 + E + H), K0,
+                       (const float *)dX1, K1, (const float *)t->dq, H, last ? nul : (const float *)t->dhz0, H, last ? nul : dX0n + E + H, K0,
+                       dG0, t->dhz0, B, H);
+    TN_TRY(launch_linear_f32(dG0, 4 * H, t->w0cT, 4 * H, nullptr, dX0, K0, B, K0, 4 * H, 0, s));
+  }
+  // gradients reaching the encoder's final states: layer 0 backward direction and the uni layer (forward direction of layer 0: none)
+  TN_HIP_CHECK(hipMemsetAsync(t->dhl0, 0, sizeof(float) * (size_t)B * H, s));
+  hipLaunchKernelGGL(trn_add2_kernel, dim3(nbH), dim3(256), 0, s, (const float *)t->dhz0, H, (const float *)(t->dX0 + E + H), K0,
+                     t->dhl0 + (size_t)B * H, B, H);
+  hipLaunchKernelGGL(trn_add2_kernel, dim3(nbH), dim3(256), 0, s, (const float *)t->dhz1, H, (const float *)(t->dX1 + 2 * H), K1, t->dhl1, B, H);
+  // ---------------- backward: decoder weights, attention key projection, embedding ----------------
+  TN_TRY(launch_gemm_tn_f32(t->dG0, 4 * H, t->X0, K0, t->dW0c, K0, 4 * H, K0, LB, s));
+  TN_TRY(launch_colsum_f32(t->dG0, 4 * H, LB, 4 * H, t->db0c, s));
+  hipLaunchKernelGGL(trn_unstack_kernel, dim3(GH), dim3(256), 0, s, (const float *)t->dW0c, (const float *)t->db0c, E + H, H, g + t->o_d0wi,
+                     g + t->o_d0wh, g + t->o_d0bi, g + t->o_d0bh);
+  TN_TRY(launch_gemm_tn_f32(t->dG1, 4 * H, t->X1, K1, t->dW1c, K1, 4 * H, K1, LB, s));
+  TN_TRY(launch_colsum_f32(t->dG1, 4 * H, LB, 4 * H, t->db1c, s));
+  hipLaunchKernelGGL(trn_unstack_kernel, dim3(GH), dim3(256), 0, s, (const float *)t->dW1c, (const float *)t->db1c, 2 * H, H, g + t->o_d1wi,
+                     g + t->o_d1wh, g + t->o_d1bi, g + t->o_d1bh);
+  TN_TRY(launch_gemm_tn_f32(t->dkp, H, t->mem, H, g + t->o_wk, H, H, H, BT, s));
+  TN_TRY(launch_linear_f32(t->dkp, H, t->wkT, H, nullptr, t->dmem, H, BT, H, H, 1, s));
+  hipLaunchKernelGGL(trn_emb_grad_kernel, dim3(V), dim3(64), 0, s, (const float *)t->dX0, K0, tgt, ld, B, L, E, V, g + t->o_emb);
+  // ---------------- backward: encoder ----------------
+  TN_HIP_CHECK(hipMemsetAsync(t->dgi1, 0, sizeof(float) * (size_t)BT * GH, s));
+  TN_HIP_CHECK(hipMemsetAsync(t->dgh1, 0, sizeof(float) * (size_t)BT * GH, s));
+  TN_HIP_CHECK(hipMemsetAsync(t->hp1, 0, sizeof(float) * (size_t)BT * H, s));
+  TN_TRY(launch_gru_train_bwd(t->mem, t->sav1, t->dmem, w + t->o_e1wh, t->dgi1, t->dgh1, t->hp1, B, T, H, s, 1, t->vl, t->dhl1));
+  TN_TRY(launch_gemm_tn_f32(t->dgi1, GH, t->seq0, 2 * H, g + t->o_e1wi, 2 * H, GH, 2 * H, BT, s));
+  TN_TRY(launch_colsum_f32(t->dgi1, GH, BT, GH, g + t->o_e1bi, s));
+  TN_TRY(launch_gemm_tn_f32(t->dgh1, GH, t->hp1, H, g + t->o_e1wh, H, GH, H, BT, s));
+  TN_TRY(launch_colsum_f32(t->dgh1, GH, BT, GH, g + t->o_e1bh, s));
+  TN_TRY(launch_linear_f32(t->dgi1, GH, t->e1wiT, GH, nullptr, t->dseq0, 2 * H, BT, 2 * H, GH, 0, s));
+  TN_HIP_CHECK(hipMemsetAsync(t->dgi0, 0, sizeof(float) * (size_t)BT * 2 * GH, s));
+  TN_HIP_CHECK(hipMemsetAsync(t->dgh0, 0, sizeof(float) * (size_t)BT * 2 * GH, s));
+  TN_HIP_CHECK(hipMemsetAsync(t->hp0, 0, sizeof(float) * (size_t)2 * BT * H, s));
+  TN_TRY(launch_gru_train_bwd(t->seq0, t->sav0, t->dseq0, w + t->o_e0wh, t->dgi0, t->dgh0, t->hp0, B, T, H, s, 2, t->vl, t->dhl0));
+  TN_TRY(launch_gemm_tn_f32(t->dgi0, 2 * GH, src, F, g + t->o_e0wi, F, 2 * GH, F, BT, s));
+  TN_TRY(launch_colsum_f32(t->dgi0, 2 * GH, BT, 2 * GH, g + t->o_e0bi, s));
+  for (int d = 0; d < 2; ++d)
+    TN_TRY(launch_gemm_tn_f32(t->dgh0 + d * GH, 2 * GH, t->hp0 + (size_t)d * BT * H, H, g + t->o_e0wh + (long)d * GH * H, H, GH, H, BT, s));
+  TN_TRY(launch_colsum_f32(t->dgh0, 2 * GH, BT, 2 * GH, g + t->o_e0bh, s));
+#undef TN_TRY
+  TN_HIP_CHECK(hipGetLastError());
+  return TN_OK;
+}
+
+extern "C" int tn_gnmt_trainer_buffers(tn_gnmt_trainer *t, float **params_dev, float **grads_dev, int64_t *numel) {
+  TN_REQUIRE(t, "tn_gnmt_trainer_buffers: null handle");
+  if (params_dev) *params_dev = t->w;
+  if (grads_dev) *grads_dev = t->g;
+  if (numel) *numel = t->n;
+  return TN_OK;
+}
+
+// gluon.Trainer(params, 'adam', {'learning_rate': lr}).step(1) (train_gnmt.py:310,337): MXNet Adam, beta1 0.9, beta2 0.999,
+// epsilon 1e-8, no weight decay, no clipping, rescale_grad 1
+extern "C" int tn_gnmt_trainer_adam_step(tn_gnmt_trainer *t, float lr, float beta1, float beta2, float epsilon) {
+  TN_REQUIRE(t, "tn_gnmt_trainer_adam_step: null handle");
+  TN_HIP_CHECK(hipSetDevice(t->ctx->device));
+  t->step += 1;
+  const double c1 = 1.0 - pow((double)beta1, (double)t->step), c2 = 1.0 - pow((double)beta2, (double)t->step);
+  const float lr_t = (float)((double)lr * sqrt(c2) / c1);
+  hipLaunchKernelGGL(trn_adam_kernel, dim3((t->n + 255) / 256), dim3(256), 0, t->ctx->stream, t->w, (const float *)t->g, t->am, t->av, t->n,
+                     lr_t, beta1, beta2, epsilon);
+  TN_HIP_CHECK(hipGetLastError());
+  return trainer_refresh(t);
+}
+
+extern "C" int tn_gnmt_trainer_read_param(tn_gnmt_trainer *t, const char *name_c, int gradient, float *out_host, int64_t capacity,
+                                          int64_t *numel) {
+  TN_REQUIRE(t && name_c && out_host && numel, "tn_gnmt_trainer_read_param: null argument");
+  const std::string name(name_c), pre = t->prefix;
+  const long F = t->F, H = t->H, E = t->E, V = t->V, GH = 3 * H;
+  long off = -1, cnt = 0;
+  auto cell = [&](const std::string &c, long owi, long obi, long owh, long obh, long in) {
+    if (name == pre + c + "i2h_weight") { off = owi; cnt = GH * in; }
+    if (name == pre + c + "i2h_bias") { off = obi; cnt = GH; }
+    if (name == pre + c + "h2h_weight") { off = owh; cnt = GH * H; }
+    if (name == pre + c + "h2h_bias") { off = obh; cnt = GH; }
+  };
+  for (int d = 0; d < 2; ++d)
+    cell(std::string("enc_rnn0_") + (d ? "r_" : "l_"), t->o_e0wi + d * GH * F, t->o_e0bi + d * GH, t->o_e0wh + d * GH * H, t->o_e0bh + d * GH, F);
+  cell("enc_rnn1_", t->o_e1wi, t->o_e1bi, t->o_e1wh, t->o_e1bh, 2 * H);
+  cell("dec_rnn0_", t->o_d0wi, t->o_d0bi, t->o_d0wh, t->o_d0bh, E + H);
+  cell("dec_rnn1_", t->o_d1wi, t->o_d1bi, t->o_d1wh, t->o_d1bh, 2 * H);
+  if (name == pre + "dec_attention_key_weight") { off = t->o_wk; cnt = H * H; }
+  if (name == pre + "tgt_proj_weight") { off = t->o_wp; cnt = V * H; }
+  if (name == pre + "tgt_proj_bias") { off = t->o_bp; cnt = V; }
+  if (name == pre + "tgt_embed_weight") { off = t->o_emb; cnt = V * E; }
+  TN_REQUIRE(off >= 0, "tn_gnmt_trainer_read_param: unknown parameter name");
+  TN_REQUIRE(capacity >= cnt, "tn_gnmt_trainer_read_param: host buffer too small");
+  TN_HIP_CHECK(hipSetDevice(t->ctx->device));
+  TN_HIP_CHECK(hipStreamSynchronize(t->ctx->stream));
+  TN_HIP_CHECK(hipMemcpy(out_host, (gradient ? t->g : t->w) + off, sizeof(float) * cnt, hipMemcpyDeviceToHost));
+  *numel = cnt;
+  return TN_OK;
+}
+
+extern "C" int tn_gnmt_trainer_destroy(tn_gnmt_trainer *t) {
+  if (!t) return TN_OK;
+  (void)hipSetDevice(t->ctx->device);
+  (void)hipStreamSynchronize(t->ctx->stream);
+  t->pool.release();
+  delete t;
   return TN_OK;
 }
 

@@ -10,7 +10,8 @@ int launch_dense_bwd(const float *dlogits, const float *pooled, const float *wd,
                      float *dbd, float *dpooled, hipStream_t s);
 int launch_scatter_pool_grad(const float *dpooled, const int32_t *arg, int B, int T, int F, float *dseq, hipStream_t s);
 int launch_gru_train_bwd(const float *seq, const float *gates, const float *dseq, const float *wh, float *dgi,
-                         float *dgh, float *hprev, int B, int T, int H, hipStream_t s);
+                         float *dgh, float *hprev, int B, int T, int H, hipStream_t s, int dirs = 2,
+                         const int32_t *valid_len = nullptr, const float *dh_last = nullptr);
 int launch_lstm_train_bwd(const float *seq, const float *gates, const float *dseq, const float *wh, float *dgi,
                           float *hprev, int B, int T, int H, hipStream_t s);
 int launch_gemm_tn_f32(const float *A, int lda, const float *Bm, int ldb, float *Cm, int ldc, int M, int N, int K,

@@ -86,10 +86,12 @@ __global__ void scatter_pool_grad_kernel(const float *__restrict__ dpooled, cons
 // 16 loads at a time, and small batches run one row per workgroup.
 template <int NB, int KR, int MAXT>
 __global__ __launch_bounds__(MAXT) void gru_train_bwd_kernel(const float *__restrict__ seq, const float *__restrict__ gates,
-                                     const float *__restrict__ dseq, const float *__restrict__ wh,   // [2][3H][H]
-                                     float *__restrict__ dgi, float *__restrict__ dgh,               // [B*T][2*3H]
-                                     float *__restrict__ hprev,                                      // [2][B*T][H]
-                                     int B, int T, int H) {
+                                     const float *__restrict__ dseq, const float *__restrict__ wh,   // [dirs][3H][H]
+                                     float *__restrict__ dgi, float *__restrict__ dgh,               // [B*T][dirs*3H]
+                                     float *__restrict__ hprev,                                      // [dirs][B*T][H]
+                                     int B, int T, int H, int dirs,
+                                     const int32_t *__restrict__ valid_len,    // [B] or null: steps >= valid_len never ran
+                                     const float *__restrict__ dh_last) {      // [dirs][B][H] or null: d loss / d final state
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int GH = 3 * H;
   float *dh = lds;                  // [NB][H]   gradient flowing into h_t from the later step
@@ -104,24 +106,26 @@ __global__ __launch_bounds__(MAXT) void gru_train_bwd_kernel(const float *__rest
   for (int i = j; i < NB * H; i += GH) dh[i] = 0.f;
   __syncthreads();
   for (int s = T - 1; s >= 0; --s) {          // reverse of the direction's own walking order
-    const int t = dir ? T - 1 - s : s;
-    const int tp = dir ? t + 1 : t - 1;       // where h_prev of this step was emitted
     for (int idx = j; idx < NB * H; idx += GH) {
       const int b = idx / H, uu = idx - b * H, bg = b0 + b;
       float d_r = 0.f, d_z = 0.f, d_n = 0.f, d_nr = 0.f, dhp = 0.f, hp = 0.f;
-      if (bg < B) {
+      const int vlen = bg < B ? (valid_len ? valid_len[bg] : T) : 0;
+      if (s < vlen) {
+        const int t = dir ? vlen - 1 - s : s;       // the reverse direction starts at the row's last valid step
+        const int tp = dir ? t + 1 : t - 1;         // where h_prev of this step was emitted
         const long row = (long)bg * T + t;
         const float *sv = gates + ((long)dir * B * T + row) * (4 * H);
         const float r = sv[uu], z = sv[H + uu], n = sv[2 * H + uu], ghn = sv[3 * H + uu];
-        hp = s > 0 ? seq[((long)bg * T + tp) * (2 * H) + dir * H + uu] : 0.f;
-        const float dht = dh[idx] + dseq[row * (2 * H) + dir * H + uu];
+        hp = s > 0 ? seq[((long)bg * T + tp) * (dirs * H) + dir * H + uu] : 0.f;
+        const float carry = (s == vlen - 1 && dh_last) ? dh_last[((long)dir * B + bg) * H + uu] : dh[idx];
+        const float dht = carry + dseq[row * (dirs * H) + dir * H + uu];
         const float dn = dht * (1.f - z), dz = dht * (hp - n);
         dhp = dht * z;
         d_n = dn * (1.f - n * n);
         d_z = dz * z * (1.f - z);
         d_r = d_n * ghn * r * (1.f - r);
         d_nr = d_n * r;
-        float *o1 = dgi + row * (2 * GH) + dir * GH, *o2 = dgh + row * (2 * GH) + dir * GH;
+        float *o1 = dgi + row * (dirs * GH) + dir * GH, *o2 = dgh + row * (dirs * GH) + dir * GH;
         o1[uu] = d_r; o1[H + uu] = d_z; o1[2 * H + uu] = d_n;
         o2[uu] = d_r; o2[H + uu] = d_z; o2[2 * H + uu] = d_nr;
         hprev[((long)dir * B * T + row) * H + uu] = hp;
@@ -446,13 +450,13 @@ int launch_scatter_pool_grad(const float *dpooled, const int32_t *arg, int B, in
   TN_LAUNCH_CHECK();
 }
 // rows per workgroup / register-resident prefix: the same policy as launch_rnn_recurrent (rnn.hip)
-#define TN_BPTT_DISPATCH(KERNEL, GATES, ...)                                                                      \
+#define TN_BPTT_DISPATCH(KERNEL, GATES, DIRS, ...)                                                                      \
   do {                                                                                                            \
     const int threads = GATES * H;                                                                                \
     TN_REQUIRE(threads <= 1024 && H % 4 == 0, "train: gates*hidden must be <= 1024 and hidden % 4 == 0");        \
-    const int nb = ((B + 3) / 4) * 2 >= 256 ? 4 : 1;                                                              \
+    const int nb = ((B + 3) / 4) * (DIRS) >= 256 ? 4 : 1;                                                              \
     const int kr = (threads <= 512 && H >= 128) ? 128 : (threads <= 768 && H >= 96) ? 96 : H >= 64 ? 64 : 0;      \
-    const dim3 grid((B + nb - 1) / nb, 2), block(threads);                                                        \
+    const dim3 grid((B + nb - 1) / nb, DIRS), block(threads);                                                     \
     const size_t lds = (size_t)(nb * H * (GATES == 4 ? 2 : 1) + 2 * nb * GATES * H) * sizeof(float);              \
     if (nb == 4) hipLaunchKernelGGL((KERNEL<4, 0, 1024>), grid, block, lds, s, __VA_ARGS__);                      \
     else if (kr == 128) hipLaunchKernelGGL((KERNEL<1, 128, 512>), grid, block, lds, s, __VA_ARGS__);              \
@@ -461,13 +465,14 @@ int launch_scatter_pool_grad(const float *dpooled, const int32_t *arg, int B, in
     else hipLaunchKernelGGL((KERNEL<1, 0, 1024>), grid, block, lds, s, __VA_ARGS__);                              \
   } while (0)
 int launch_gru_train_bwd(const float *seq, const float *gates, const float *dseq, const float *wh, float *dgi,
-                         float *dgh, float *hprev, int B, int T, int H, hipStream_t s) {
-  TN_BPTT_DISPATCH(gru_train_bwd_kernel, 3, seq, gates, dseq, wh, dgi, dgh, hprev, B, T, H);
+                         float *dgh, float *hprev, int B, int T, int H, hipStream_t s, int dirs, const int32_t *valid_len,
+                         const float *dh_last) {
+  TN_BPTT_DISPATCH(gru_train_bwd_kernel, 3, dirs, seq, gates, dseq, wh, dgi, dgh, hprev, B, T, H, dirs, valid_len, dh_last);
   TN_LAUNCH_CHECK();
 }
 int launch_lstm_train_bwd(const float *seq, const float *gates, const float *dseq, const float *wh, float *dgi,
                           float *hprev, int B, int T, int H, hipStream_t s) {
-  TN_BPTT_DISPATCH(lstm_train_bwd_kernel, 4, seq, gates, dseq, wh, dgi, hprev, B, T, H);
+  TN_BPTT_DISPATCH(lstm_train_bwd_kernel, 4, 2, seq, gates, dseq, wh, dgi, hprev, B, T, H);
   TN_LAUNCH_CHECK();
 }
 int launch_gemm_tn_f32(const float *A, int lda, const float *Bm, int ldb, float *Cm, int ldc, int M, int N, int K,

@@ -335,3 +335,78 @@ class TemporalHeadTrainer:
                 self.handle = None
         except Exception:
             pass
+
+
+class GNMTTrainer:
+    """One training step of the captioner the way reference train_gnmt.py::train drives it (:328-337): teacher-forced
+    ``NMTModel`` forward, token-averaged ``MaskedSoftmaxCELoss``, ``loss.backward()``, ``gluon.Trainer('adam').step(1)``.
+    GRU cells (the reference's flag default), ``num_layers=2, num_bi_layers=1``.  ``grads`` / ``params`` are flat device
+    views for a data-parallel all-reduce between ``forward_backward`` and ``step``."""
+
+    def __init__(self, params: dict, input_size: int, hidden: int, embed: int, vocab: int, max_batch: int = 32,
+                 max_src_len: int = 256, max_tgt_len: int = 64, prefix: str = "gnmt_", ctx: _lib.Context | None = None):
+        self.ctx = ctx or _lib.default_context()
+        self.lib = self.ctx.lib
+        self.input_size, self.hidden, self.embed, self.vocab, self.prefix = input_size, hidden, embed, vocab, prefix
+        self.names = [k for k in params if k.startswith(prefix)]
+        self.shapes = {k: tuple(np.asarray(params[k]).shape) for k in self.names}
+        arr, keep = _lib.make_params({k: params[k] for k in self.names})
+        h = C.c_void_p()
+        check(self.lib.tn_gnmt_trainer_create(self.ctx.handle, arr, len(arr), prefix.encode(), input_size, hidden, embed, vocab,
+                                              max_batch, max_src_len, max_tgt_len, C.byref(h)), "tn_gnmt_trainer_create")
+        del keep
+        self.handle = h
+        pw, pg, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(self.lib.tn_gnmt_trainer_buffers(h, C.byref(pw), C.byref(pg), C.byref(n)), "tn_gnmt_trainer_buffers")
+        self.numel, self._pw, self._pg = n.value, pw.value, pg.value
+
+    def _view(self, addr):
+        class _Arr:
+            __cuda_array_interface__ = {"shape": (self.numel,), "typestr": "<f4", "data": (addr, False), "version": 3}
+        return torch.as_tensor(_Arr(), device=f"cuda:{self.ctx.device}")
+
+    @property
+    def grads(self) -> torch.Tensor:
+        return self._view(self._pg)
+
+    @property
+    def params(self) -> torch.Tensor:
+        return self._view(self._pw)
+
+    def forward_backward(self, src: torch.Tensor, src_valid_length: torch.Tensor, tgt: torch.Tensor,
+                         tgt_valid_length: torch.Tensor, return_logits: bool = False):
+        """src (B,T,F) fp32, tgt (B,L) token ids incl. BOS / EOS, valid lengths (B,) -> loss (0-d tensor) [, logits (B,L-1,V)]"""
+        src = src.contiguous().float()
+        b, t, _ = src.shape
+        dev = src.device
+        tgt = tgt.to(device=dev, dtype=torch.int32).contiguous()
+        svl = src_valid_length.to(device=dev, dtype=torch.int32).contiguous()
+        tvl = tgt_valid_length.to(device=dev, dtype=torch.int32).contiguous()
+        loss = torch.empty((1,), dtype=torch.float32, device=dev)
+        logits = torch.empty((b, tgt.shape[1] - 1, self.vocab), dtype=torch.float32, device=dev) if return_logits else None
+        check(self.lib.tn_gnmt_trainer_forward_backward(self.handle, ptr(src), ptr(svl), ptr(tgt), tgt.shape[1], ptr(tvl), b, t,
+                                                        tgt.shape[1], ptr(loss), ptr(logits)), "tn_gnmt_trainer_forward_backward")
+        return (loss[0], logits) if return_logits else loss[0]
+
+    def step(self, lr: float, beta1: float = 0.9, beta2: float = 0.999, epsilon: float = 1e-8):
+        check(self.lib.tn_gnmt_trainer_adam_step(self.handle, lr, beta1, beta2, epsilon), "tn_gnmt_trainer_adam_step")
+
+    def get(self, name: str, gradient: bool = False) -> np.ndarray:
+        shape = self.shapes[name]
+        out = np.empty(int(np.prod(shape)), np.float32)
+        n = C.c_int64()
+        check(self.lib.tn_gnmt_trainer_read_param(self.handle, name.encode(), 1 if gradient else 0,
+                                                  out.ctypes.data_as(C.POINTER(C.c_float)), out.size, C.byref(n)),
+              "tn_gnmt_trainer_read_param")
+        return out[:n.value].reshape(shape).copy()
+
+    def state_dict(self) -> dict:
+        return {k: self.get(k) for k in self.names}
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.tn_gnmt_trainer_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass

@@ -1,0 +1,75 @@
+"""-m gpu: the captioner's training step (teacher-forced forward, token-averaged masked CE, backward through decoder,
+attention and encoder, Adam) through the C ABI vs oracle/gnmt_train_torch.py (torch autograd on the CPU, float64)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gnmt_train_torch as gt
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed, B, T, F, H, E, V, L):
+    from tennis_amd import weights as W
+    p = W.make_gnmt_weights(seed, "gru", F, H, E, V)
+    rng = np.random.default_rng(seed)
+    p["gnmt_tgt_embed_weight"] = rng.normal(0, 0.5, (V, E)).astype(np.float32)      # every row trainable, none zeroed
+    src = (np.abs(rng.normal(0, 1, (B, T, F))) * 0.5).astype(np.float32)
+    svl = rng.integers(max(1, T // 2), T + 1, B).astype(np.int32)
+    svl[0] = T
+    tgt = rng.integers(4, V, (B, L)).astype(np.int32)
+    tgt[:, 0] = 2
+    tvl = rng.integers(3, L + 1, B).astype(np.int32)
+    tvl[0] = L
+    for b in range(B):
+        tgt[b, tvl[b] - 1] = 3
+        tgt[b, tvl[b]:] = 1                                                         # <pad>
+    return p, src, svl, tgt, tvl
+
+
+@pytest.mark.parametrize("cfg", [dict(seed=1, B=3, T=9, F=16, H=8, E=6, V=14, L=6),
+                                 dict(seed=2, B=5, T=23, F=64, H=32, E=20, V=40, L=11),
+                                 dict(seed=3, B=4, T=40, F=128, H=128, E=100, V=254, L=9)])   # config-C5 widths
+def test_loss_and_gradients_match_autograd(cfg, report):
+    from tennis_amd.engine import GNMTTrainer
+    p, src, svl, tgt, tvl = _case(**cfg)
+    tr = GNMTTrainer(p, cfg["F"], cfg["H"], cfg["E"], cfg["V"], max_batch=cfg["B"], max_src_len=cfg["T"], max_tgt_len=cfg["L"])
+    loss, logits = tr.forward_backward(torch.from_numpy(src).cuda(), torch.from_numpy(svl).cuda(), torch.from_numpy(tgt).cuda(),
+                                       torch.from_numpy(tvl).cuda(), return_logits=True)
+    rl, rlog, rg = gt.loss_and_grads(p, src, svl, tgt, tvl, cfg["H"])
+    assert abs(float(loss) - rl) < 1e-4 * max(1.0, abs(rl)), (float(loss), rl)
+    assert np.abs(logits.cpu().numpy() - rlog).max() < 1e-4
+    worst = 0.0
+    for k, g in rg.items():
+        got = tr.get(k, gradient=True)
+        err = np.abs(got - g).max() / max(1e-7, np.abs(g).max())
+        worst = max(worst, err)
+        assert err < 2e-3, (k, err, np.abs(g).max())
+    report[f"gnmt_train_grad_rel_err_H{cfg['H']}_T{cfg['T']}"] = float(worst)
+
+
+def test_adam_steps_follow_the_oracle_and_reduce_the_loss():
+    from tennis_amd.engine import GNMTTrainer
+    cfg = dict(seed=4, B=4, T=12, F=24, H=16, E=10, V=20, L=7)
+    p, src, svl, tgt, tvl = _case(**cfg)
+    tr = GNMTTrainer(p, cfg["F"], cfg["H"], cfg["E"], cfg["V"], max_batch=cfg["B"], max_src_len=cfg["T"], max_tgt_len=cfg["L"])
+    args = [torch.from_numpy(a).cuda() for a in (src, svl, tgt, tvl)]
+    q = {k: v.astype(np.float64) for k, v in p.items()}
+    m, v = {}, {}
+    lr = 1e-3                                                   # train_gnmt.py flag default
+    for step in range(1, 4):
+        loss = tr.forward_backward(*args)
+        rl, _, rg = gt.loss_and_grads({k: a.astype(np.float32) for k, a in q.items()}, src, svl, tgt, tvl, cfg["H"])
+        assert abs(float(loss) - rl) < 2e-4 * max(1.0, abs(rl))
+        tr.step(lr)
+        q, m, v = gt.adam_step(q, rg, m, v, step, lr)
+        st = tr.state_dict()
+        for k in q:
+            assert np.abs(st[k] - q[k]).max() < 2e-4 * max(1.0, np.abs(q[k]).max()), (step, k)
+    first = float(tr.forward_backward(*args))
+    for _ in range(150):
+        tr.forward_backward(*args)
+        tr.step(1e-2)
+    assert float(tr.forward_backward(*args)) < 0.5 * first
+    g = tr.grads
+    assert g.shape == (tr.numel,) and bool(torch.isfinite(g).all())
