@@ -182,6 +182,10 @@ int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float *src, const
                                      const int32_t *tgt, int ld, const int32_t *tgt_valid_len, int batch, int steps,
                                      int tgt_len, float *loss, float *logits_out);
 int tn_gnmt_trainer_buffers(tn_gnmt_trainer *t, float **params_dev, float **grads_dev, int64_t *numel);
+/* --dropout of train_gnmt.py (gnmt.py:152,395: after each encoder layer and on the top decoder cell's output), inverted
+ * dropout from a counter-based generator; 0 until set.  tn_gnmt_trainer_dropout_masks: the last step's masks (test hook). */
+int tn_gnmt_trainer_set_dropout(tn_gnmt_trainer *t, float p, uint64_t seed);
+int tn_gnmt_trainer_dropout_masks(tn_gnmt_trainer *t, float **m_enc0, float **m_enc1, float **m_dec);
 int tn_gnmt_trainer_adam_step(tn_gnmt_trainer *t, float lr, float beta1, float beta2, float epsilon);
 int tn_gnmt_trainer_read_param(tn_gnmt_trainer *t, const char *name, int gradient, float *out_host, int64_t capacity,
                                int64_t *numel);

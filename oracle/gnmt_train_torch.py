@@ -53,8 +53,9 @@ def _direction(x, w, pref, reverse, vl):
     return torch.stack(outs, dim=1), h
 
 
-def forward_loss(params: dict, src, src_vl, tgt, tgt_vl, hidden, prefix="gnmt_", dtype=torch.float64):
-    """-> (loss scalar tensor, logits (B, L-1, V), leaf tensors dict)."""
+def forward_loss(params: dict, src, src_vl, tgt, tgt_vl, hidden, prefix="gnmt_", dtype=torch.float64, masks=None):
+    """-> (loss scalar tensor, logits (B, L-1, V), leaf tensors dict).  masks = (m_enc0 (B,T,2H), m_enc1 (B,T,H), m_dec (L,B,H))
+    are the dropout masks (already scaled by 1/(1-p)) of gnmt.py:152,395; None = no dropout."""
     w = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True) for k, v in params.items()}
     x = torch.tensor(np.asarray(src), dtype=dtype)
     vl = torch.tensor(np.asarray(src_vl), dtype=torch.long)
@@ -64,7 +65,11 @@ def forward_loss(params: dict, src, src_vl, tgt, tgt_vl, hidden, prefix="gnmt_",
     fo, _ = _direction(x, w, pe + "rnn0_l_", False, vl)
     bo, bh0 = _direction(x, w, pe + "rnn0_r_", True, vl)
     seq0 = torch.cat([fo, bo], dim=2)
+    if masks is not None:
+        seq0 = seq0 * torch.tensor(np.asarray(masks[0]), dtype=dtype)      # dropout on the layer output (states are not dropped)
     mem, h1 = _direction(seq0, w, pe + "rnn1_", False, vl)
+    if masks is not None:
+        mem = mem * torch.tensor(np.asarray(masks[1]), dtype=dtype)
     keyproj = mem @ w[prefix + "dec_attention_key_weight"].T
     mask = (torch.arange(T)[None, :] < vl[:, None])
     tg = torch.tensor(np.asarray(tgt), dtype=torch.long)
@@ -84,7 +89,8 @@ def forward_loss(params: dict, src, src_vl, tgt, tgt_vl, hidden, prefix="gnmt_",
         att = torch.einsum("bt,bth->bh", wts, mem)
         h1s = _gru_cell(torch.cat([h0s, att], dim=1), h1s, w[pd + "rnn1_i2h_weight"], w[pd + "rnn1_h2h_weight"],
                         w[pd + "rnn1_i2h_bias"], w[pd + "rnn1_h2h_bias"])
-        logits.append(h1s @ w[prefix + "tgt_proj_weight"].T + w[prefix + "tgt_proj_bias"])
+        top = h1s if masks is None else h1s * torch.tensor(np.asarray(masks[2][i]), dtype=dtype)
+        logits.append(top @ w[prefix + "tgt_proj_weight"].T + w[prefix + "tgt_proj_bias"])
     logits = torch.stack(logits, dim=1)                                       # (B, L, V)
     logp = torch.log_softmax(logits, dim=2)
     nll = -torch.gather(logp, 2, tg[:, 1:, None]).squeeze(2)
@@ -94,8 +100,8 @@ def forward_loss(params: dict, src, src_vl, tgt, tgt_vl, hidden, prefix="gnmt_",
     return loss, logits, w
 
 
-def loss_and_grads(params, src, src_vl, tgt, tgt_vl, hidden, prefix="gnmt_"):
-    loss, logits, w = forward_loss(params, src, src_vl, tgt, tgt_vl, hidden, prefix)
+def loss_and_grads(params, src, src_vl, tgt, tgt_vl, hidden, prefix="gnmt_", masks=None):
+    loss, logits, w = forward_loss(params, src, src_vl, tgt, tgt_vl, hidden, prefix, masks=masks)
     loss.backward()
     return float(loss.detach()), logits.detach().numpy(), {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape)) for k, v in w.items()}
 

@@ -685,6 +685,23 @@ __global__ void trn_add2_kernel(const float *__restrict__ a, int la, const float
   out[id] = a[r * la + u] + b[r * lb + u];
 }
 
+// inverted dropout (gluon nn.Dropout in training mode): mask = keep ? 1/(1-p) : 0 from a counter-based hash (splitmix64),
+// so a step's masks depend only on (seed, step counter, element index); y = x * mask
+__global__ void trn_dropout_mask_kernel(float *__restrict__ mask, long n, float p, unsigned long long key) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long z = key + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const float u = (float)(z >> 40) * (1.0f / 16777216.0f);      // uniform [0, 1)
+  mask[i] = u < p ? 0.f : 1.0f / (1.0f - p);
+}
+__global__ void trn_mul_kernel(const float *__restrict__ x, const float *__restrict__ m, float *__restrict__ y, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = x[i] * m[i];
+}
+
 // MXNet Adam [EXT]: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; w -= lr_t m / (sqrt(v) + eps), lr_t bias-corrected
 __global__ void trn_adam_kernel(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m,
                                 float *__restrict__ v, long n, float lr_t, float b1, float b2, float eps) {
@@ -1020,6 +1037,10 @@ struct tn_gnmt_trainer {
   // backward workspace
   float *dlog, *dH1, *dG0, *dG1, *dX0, *dX1, *dhz0, *dhz1, *dq, *dmem, *dkp, *dW0c, *db0c, *dW1c, *db1c;
   float *dhl0, *dhl1, *dgi1, *dgh1, *hp1, *dseq0, *dgi0, *dgh0, *hp0;
+  // dropout (gnmt.py:152,395: after each encoder layer and on the top decoder cell's output): masks and dropped copies
+  float drop_p;
+  unsigned long long drop_seed, drop_count;
+  float *M0, *M1, *M2, *seq0d, *memd, *H1d;
 };
 
 static int trainer_refresh(tn_gnmt_trainer *t) {
@@ -1106,6 +1127,8 @@ extern "C" int tn_gnmt_trainer_create(tn_ctx *ctx, const tn_param *params, int n
   t->dW0c = fl(4 * H * K0); t->db0c = fl(4 * H); t->dW1c = fl(4 * H * K1); t->db1c = fl(4 * H);
   t->dhl0 = fl(2 * B * H); t->dhl1 = fl(B * H); t->dgi1 = fl(BT * GH); t->dgh1 = fl(BT * GH); t->hp1 = fl(BT * H);
   t->dseq0 = fl(BT * 2 * H); t->dgi0 = fl(BT * 2 * GH); t->dgh0 = fl(BT * 2 * GH); t->hp0 = fl(2 * BT * H);
+  t->M0 = fl(BT * 2 * H); t->M1 = fl(BT * H); t->M2 = fl(LB * H); t->seq0d = fl(BT * 2 * H); t->memd = fl(BT * H); t->H1d = fl(LB * H);
+  t->drop_p = 0.f; t->drop_seed = 0; t->drop_count = 0;
   if (t->pool.failed) { tn_set_error("device allocation failed"); return fail(TN_ERR_NOMEM); }
   TN_HIP_CHECK(hipMemsetAsync(t->g, 0, sizeof(float) * t->n, ctx->stream));
   TN_HIP_CHECK(hipMemsetAsync(t->am, 0, sizeof(float) * t->n, ctx->stream));
@@ -1149,10 +1172,23 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
   TN_TRY(launch_linear_f32(src, F, w + t->o_e0wi, F, w + t->o_e0bi, t->gi0, 2 * GH, BT, 2 * GH, F, 0, s));
   TN_HIP_CHECK(hipMemsetAsync(t->seq0, 0, sizeof(float) * (size_t)BT * 2 * H, s));
   TN_TRY(launch_rnn_recurrent(3, t->gi0, 2 * GH, t->e0whT, w + t->o_e0bh, t->vl, t->seq0, 2 * H, t->hl0, nullptr, B, T, H, 2, s, t->sav0));
-  TN_TRY(launch_linear_f32(t->seq0, 2 * H, w + t->o_e1wi, 2 * H, w + t->o_e1bi, t->gi1, GH, BT, GH, 2 * H, 0, s));
+  // dropout points of the reference (gnmt.py:152,395); the recurrences themselves keep the un-dropped outputs
+  const bool drop = t->drop_p > 0.f;
+  const float *seq0d = t->seq0, *memd = t->mem, *H1d = t->H1;
+  if (drop) {
+    const unsigned long long key = t->drop_seed * 0x2545F4914F6CDD1Dull + (++t->drop_count) * 0xD1342543DE82EF95ull;
+    const long n0 = (long)BT * 2 * H, n1 = (long)BT * H, n2 = (long)LB * H;
+    hipLaunchKernelGGL(trn_dropout_mask_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, t->M0, n0, t->drop_p, key ^ 0x1111ull);
+    hipLaunchKernelGGL(trn_dropout_mask_kernel, dim3((n1 + 255) / 256), dim3(256), 0, s, t->M1, n1, t->drop_p, key ^ 0x2222ull);
+    hipLaunchKernelGGL(trn_dropout_mask_kernel, dim3((n2 + 255) / 256), dim3(256), 0, s, t->M2, n2, t->drop_p, key ^ 0x3333ull);
+    hipLaunchKernelGGL(trn_mul_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, (const float *)t->seq0, (const float *)t->M0, t->seq0d, n0);
+    seq0d = t->seq0d; memd = t->memd; H1d = t->H1d;
+  }
+  TN_TRY(launch_linear_f32(seq0d, 2 * H, w + t->o_e1wi, 2 * H, w + t->o_e1bi, t->gi1, GH, BT, GH, 2 * H, 0, s));
   TN_HIP_CHECK(hipMemsetAsync(t->mem, 0, sizeof(float) * (size_t)BT * H, s));
   TN_TRY(launch_rnn_recurrent(3, t->gi1, GH, t->e1whT, w + t->o_e1bh, t->vl, t->mem, H, t->hl1, nullptr, B, T, H, 1, s, t->sav1));
-  TN_TRY(launch_linear_f32(t->mem, H, w + t->o_wk, H, nullptr, t->keyproj, H, BT, H, H, 0, s));
+  if (drop) hipLaunchKernelGGL(trn_mul_kernel, dim3(((long)BT * H + 255) / 256), dim3(256), 0, s, (const float *)t->mem, (const float *)t->M1, t->memd, (long)BT * H);
+  TN_TRY(launch_linear_f32(memd, H, w + t->o_wk, H, nullptr, t->keyproj, H, BT, H, H, 0, s));
   hipLaunchKernelGGL(transpose_bth_kernel, dim3((H + 31) / 32, (T + 31) / 32, B), dim3(256), 0, s, (const float *)t->keyproj, t->keyprojT, T, H);
   for (int i = 0; i < L; ++i) {
     float *X0 = t->X0 + (size_t)i * B * K0, *X1 = t->X1 + (size_t)i * B * K1, *G0 = t->G0 + (size_t)i * B * 4 * H;
@@ -1164,12 +1200,17 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
                        i ? H1p : (const float *)t->hl1, H, X0, X1, H, E);
     TN_TRY(launch_linear_f32(X0, K0, t->w0c, K0, t->b0c, G0, 4 * H, B, 4 * H, K0, 0, s));
     hipLaunchKernelGGL(dec_attention_kernel<1>, dim3(B), dim3(kBeamThreads), att_lds, s, (const float *)G0, (const float *)(X0 + E + H), K0,
-                       (const float *)nullptr, 0, t->h0tmp, (float *)nullptr, X1, K1, (const float *)t->keyprojT, (const float *)t->mem,
+                       (const float *)nullptr, 0, t->h0tmp, (float *)nullptr, X1, K1, (const float *)t->keyprojT, memd,
                        (const int32_t *)t->vl, t->ctxtmp, 1, 1, T, H, t->AW + (size_t)i * B * T);
     TN_TRY(launch_linear_f32(X1, K1, t->w1c, K1, t->b1c, G1, 4 * H, B, 4 * H, K1, 0, s));
     hipLaunchKernelGGL(dec_tf_cell1_kernel, dim3(nbH), dim3(256), 0, s, (const float *)G1, (const float *)X1, 0, (const float *)nullptr, H1,
                        (float *)nullptr, B, H);
-    TN_TRY(launch_linear_f32(H1, H, w + t->o_wp, H, w + t->o_bp, t->logits + (size_t)i * V, L * V, B, V, H, 0, s));
+    const float *H1p_ = H1;
+    if (drop) {
+      hipLaunchKernelGGL(trn_mul_kernel, dim3(nbH), dim3(256), 0, s, (const float *)H1, (const float *)(t->M2 + (size_t)i * B * H), t->H1d + (size_t)i * B * H, (long)B * H);
+      H1p_ = t->H1d + (size_t)i * B * H;
+    }
+    TN_TRY(launch_linear_f32(H1p_, H, w + t->o_wp, H, w + t->o_bp, t->logits + (size_t)i * V, L * V, B, V, H, 0, s));
   }
   // ---------------- loss and its gradient ----------------
   hipLaunchKernelGGL(trn_ce_bwd_kernel, dim3(L, B), dim3(256), 0, s, (const float *)t->logits, tgt + 1, ld, (const int32_t *)t->tvl, B, L, V,
@@ -1178,7 +1219,8 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
   if (logits_out) TN_HIP_CHECK(hipMemcpyAsync(logits_out, t->logits, sizeof(float) * (size_t)LB * V, hipMemcpyDeviceToDevice, s));
   // ---------------- backward: projection ----------------
   TN_TRY(launch_linear_f32(t->dlog, V, t->wpT, V, nullptr, t->dH1, H, LB, H, V, 0, s));
-  TN_TRY(launch_gemm_tn_f32(t->dlog, V, t->H1, H, g + t->o_wp, H, V, H, LB, s));
+  if (drop) hipLaunchKernelGGL(trn_mul_kernel, dim3(((long)LB * H + 255) / 256), dim3(256), 0, s, (const float *)t->dH1, (const float *)t->M2, t->dH1, (long)LB * H);
+  TN_TRY(launch_gemm_tn_f32(t->dlog, V, H1d, H, g + t->o_wp, H, V, H, LB, s));
   TN_TRY(launch_colsum_f32(t->dlog, V, LB, V, g + t->o_bp, s));
   TN_HIP_CHECK(hipMemsetAsync(t->dmem, 0, sizeof(float) * (size_t)BT * H, s));
   TN_HIP_CHECK(hipMemsetAsync(t->dkp, 0, sizeof(float) * (size_t)BT * H, s));
@@ -1195,7 +1237,7 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
                        (const float *)(t->dH1 + (size_t)i * B * H), H, last ? nul : (const float *)t->dhz1, H, last ? nul : dX1n + 2 * H, K1,
                        nul, 0, dG1, t->dhz1, B, H);
     TN_TRY(launch_linear_f32(dG1, 4 * H, t->w1cT, 4 * H, nullptr, dX1, K1, B, K1, 4 * H, 0, s));
-    hipLaunchKernelGGL(trn_att_bwd_kernel, dim3(B), dim3(256), attb_lds, s, (const float *)(t->AW + (size_t)i * B * T), (const float *)t->mem,
+    hipLaunchKernelGGL(trn_att_bwd_kernel, dim3(B), dim3(256), attb_lds, s, (const float *)(t->AW + (size_t)i * B * T), memd,
                        (const float *)t->keyproj, (const float *)X1, K1, (const float *)(dX1 + H), K1, last ? nul : dX0n + E, K0,
                        (const int32_t *)t->vl, t->dmem, t->dkp, t->dq, T, H);
     hipLaunchKernelGGL(trn_gru_bwd_kernel, dim3(nbH), dim3(256), 0, s, (const float *)G0, (const float *)(X0 + E + H), K0,
@@ -1217,19 +1259,21 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
   TN_TRY(launch_colsum_f32(t->dG1, 4 * H, LB, 4 * H, t->db1c, s));
   hipLaunchKernelGGL(trn_unstack_kernel, dim3(GH), dim3(256), 0, s, (const float *)t->dW1c, (const float *)t->db1c, 2 * H, H, g + t->o_d1wi,
                      g + t->o_d1wh, g + t->o_d1bi, g + t->o_d1bh);
-  TN_TRY(launch_gemm_tn_f32(t->dkp, H, t->mem, H, g + t->o_wk, H, H, H, BT, s));
+  TN_TRY(launch_gemm_tn_f32(t->dkp, H, memd, H, g + t->o_wk, H, H, H, BT, s));
   TN_TRY(launch_linear_f32(t->dkp, H, t->wkT, H, nullptr, t->dmem, H, BT, H, H, 1, s));
+  if (drop) hipLaunchKernelGGL(trn_mul_kernel, dim3(((long)BT * H + 255) / 256), dim3(256), 0, s, (const float *)t->dmem, (const float *)t->M1, t->dmem, (long)BT * H);
   hipLaunchKernelGGL(trn_emb_grad_kernel, dim3(V), dim3(64), 0, s, (const float *)t->dX0, K0, tgt, ld, B, L, E, V, g + t->o_emb);
   // ---------------- backward: encoder ----------------
   TN_HIP_CHECK(hipMemsetAsync(t->dgi1, 0, sizeof(float) * (size_t)BT * GH, s));
   TN_HIP_CHECK(hipMemsetAsync(t->dgh1, 0, sizeof(float) * (size_t)BT * GH, s));
   TN_HIP_CHECK(hipMemsetAsync(t->hp1, 0, sizeof(float) * (size_t)BT * H, s));
   TN_TRY(launch_gru_train_bwd(t->mem, t->sav1, t->dmem, w + t->o_e1wh, t->dgi1, t->dgh1, t->hp1, B, T, H, s, 1, t->vl, t->dhl1));
-  TN_TRY(launch_gemm_tn_f32(t->dgi1, GH, t->seq0, 2 * H, g + t->o_e1wi, 2 * H, GH, 2 * H, BT, s));
+  TN_TRY(launch_gemm_tn_f32(t->dgi1, GH, seq0d, 2 * H, g + t->o_e1wi, 2 * H, GH, 2 * H, BT, s));
   TN_TRY(launch_colsum_f32(t->dgi1, GH, BT, GH, g + t->o_e1bi, s));
   TN_TRY(launch_gemm_tn_f32(t->dgh1, GH, t->hp1, H, g + t->o_e1wh, H, GH, H, BT, s));
   TN_TRY(launch_colsum_f32(t->dgh1, GH, BT, GH, g + t->o_e1bh, s));
   TN_TRY(launch_linear_f32(t->dgi1, GH, t->e1wiT, GH, nullptr, t->dseq0, 2 * H, BT, 2 * H, GH, 0, s));
+  if (drop) hipLaunchKernelGGL(trn_mul_kernel, dim3(((long)BT * 2 * H + 255) / 256), dim3(256), 0, s, (const float *)t->dseq0, (const float *)t->M0, t->dseq0, (long)BT * 2 * H);
   TN_HIP_CHECK(hipMemsetAsync(t->dgi0, 0, sizeof(float) * (size_t)BT * 2 * GH, s));
   TN_HIP_CHECK(hipMemsetAsync(t->dgh0, 0, sizeof(float) * (size_t)BT * 2 * GH, s));
   TN_HIP_CHECK(hipMemsetAsync(t->hp0, 0, sizeof(float) * (size_t)2 * BT * H, s));
@@ -1241,6 +1285,22 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
   TN_TRY(launch_colsum_f32(t->dgh0, 2 * GH, BT, 2 * GH, g + t->o_e0bh, s));
 #undef TN_TRY
   TN_HIP_CHECK(hipGetLastError());
+  return TN_OK;
+}
+
+// dropout rate of the encoder / decoder layers (train_gnmt.py --dropout, default 0.2 there; 0 here until set) and the
+// seed of the counter-based mask generator.  MXNet's own random stream cannot be reproduced: masks differ from the
+// reference's, their distribution and placement do not.
+extern "C" int tn_gnmt_trainer_set_dropout(tn_gnmt_trainer *t, float p, uint64_t seed) {
+  TN_REQUIRE(t, "tn_gnmt_trainer_set_dropout: null handle");
+  TN_REQUIRE(p >= 0.f && p < 1.f, "tn_gnmt_trainer_set_dropout: rate must be in [0, 1)");
+  t->drop_p = p; t->drop_seed = seed; t->drop_count = 0;
+  return TN_OK;
+}
+// the masks of the last forward_backward (device pointers; (B*T, 2H), (B*T, H), (L*B, H) step-major) - test hook
+extern "C" int tn_gnmt_trainer_dropout_masks(tn_gnmt_trainer *t, float **m_enc0, float **m_enc1, float **m_dec) {
+  TN_REQUIRE(t && m_enc0 && m_enc1 && m_dec, "tn_gnmt_trainer_dropout_masks: null argument");
+  *m_enc0 = t->M0; *m_enc1 = t->M1; *m_dec = t->M2;
   return TN_OK;
 }
 

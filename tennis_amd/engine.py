@@ -388,6 +388,22 @@ class GNMTTrainer:
                                                         tgt.shape[1], ptr(loss), ptr(logits)), "tn_gnmt_trainer_forward_backward")
         return (loss[0], logits) if return_logits else loss[0]
 
+    def set_dropout(self, p: float, seed: int = 0):
+        """``--dropout`` of train_gnmt.py (default 0.2 there): after each encoder layer and on the top decoder cell's output."""
+        check(self.lib.tn_gnmt_trainer_set_dropout(self.handle, p, seed), "tn_gnmt_trainer_set_dropout")
+
+    def dropout_masks(self, batch: int, src_steps: int, tgt_steps: int):
+        """The last step's masks as tensors: (B,T,2H), (B,T,H), (L,B,H) (step-major) - for tests against the oracle."""
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(self.lib.tn_gnmt_trainer_dropout_masks(self.handle, C.byref(a), C.byref(b), C.byref(c)), "tn_gnmt_trainer_dropout_masks")
+        h = self.hidden
+
+        def view(addr, shape):
+            class _Arr:
+                __cuda_array_interface__ = {"shape": shape, "typestr": "<f4", "data": (addr, False), "version": 3}
+            return torch.as_tensor(_Arr(), device=f"cuda:{self.ctx.device}")
+        return (view(a.value, (batch, src_steps, 2 * h)), view(b.value, (batch, src_steps, h)), view(c.value, (tgt_steps, batch, h)))
+
     def step(self, lr: float, beta1: float = 0.9, beta2: float = 0.999, epsilon: float = 1e-8):
         check(self.lib.tn_gnmt_trainer_adam_step(self.handle, lr, beta1, beta2, epsilon), "tn_gnmt_trainer_adam_step")
 

@@ -73,3 +73,28 @@ def test_adam_steps_follow_the_oracle_and_reduce_the_loss():
     assert float(tr.forward_backward(*args)) < 0.5 * first
     g = tr.grads
     assert g.shape == (tr.numel,) and bool(torch.isfinite(g).all())
+
+
+def test_dropout_gradients_match_autograd_with_the_same_masks():
+    """--dropout (train_gnmt.py default 0.2): the masks come from the library's counter-based generator; given the same masks
+    the oracle must produce the same loss and gradients, and the masks must have the right rate and scale."""
+    from tennis_amd.engine import GNMTTrainer
+    cfg = dict(seed=5, B=4, T=15, F=32, H=16, E=12, V=24, L=8)
+    p, src, svl, tgt, tvl = _case(**cfg)
+    tr = GNMTTrainer(p, cfg["F"], cfg["H"], cfg["E"], cfg["V"], max_batch=cfg["B"], max_src_len=cfg["T"], max_tgt_len=cfg["L"])
+    tr.set_dropout(0.2, seed=7)
+    args = [torch.from_numpy(a).cuda() for a in (src, svl, tgt, tvl)]
+    loss = tr.forward_backward(*args)
+    masks = [m.cpu().numpy() for m in tr.dropout_masks(cfg["B"], cfg["T"], cfg["L"] - 1)]
+    for m in masks:
+        vals = np.unique(m)
+        assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1.25) < 1e-6
+        assert 0.1 < float((m == 0).mean()) < 0.3
+    rl, _, rg = gt.loss_and_grads(p, src, svl, tgt, tvl, cfg["H"], masks=masks)
+    assert abs(float(loss) - rl) < 1e-4 * max(1.0, abs(rl))
+    for k, g in rg.items():
+        err = np.abs(tr.get(k, gradient=True) - g).max() / max(1e-7, np.abs(g).max())
+        assert err < 2e-3, (k, err)
+    loss2 = tr.forward_backward(*args)                      # next step: new masks
+    m2 = tr.dropout_masks(cfg["B"], cfg["T"], cfg["L"] - 1)[2].cpu().numpy()
+    assert not np.array_equal(m2, masks[2]) and abs(float(loss2) - float(loss)) > 0
