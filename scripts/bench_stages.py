@@ -58,6 +58,18 @@ smp, sc, svl = c5()
 out["C5_gnmt"] = {"encode_ms": round(s_enc * 1e3, 2), "encode_plus_beam_ms": round(s_all * 1e3, 2),
                   "clips_per_s": round(B / s_all, 1), "steps_run": int(svl.max().item()) - 1,
                   "note": "random-init weights: beams rarely emit EOS, so this is the max_length=150 worst case"}
+# ---- C5 training step: 32 clips x T=214 x F=1024, captions of 20 tokens ---------------------------------------------
+from tennis_amd.engine import GNMTTrainer
+gtr = GNMTTrainer(p, F, H, E, V, max_batch=B, max_src_len=T, max_tgt_len=20)
+tg = torch.from_numpy(rng.integers(4, V, (B, 20)).astype(np.int32)).to(dev)
+tg[:, 0] = 2
+tv = torch.full((B,), 20, dtype=torch.int32, device=dev)
+def c5t():
+    gtr.forward_backward(src, vl, tg, tv)
+    gtr.step(1e-3)
+s = timed(c5t, 10)
+out["C5_train_step"] = {"ms_per_clip_batch": round(s * 1e3, 2), "clips_per_s": round(B / s, 1),
+                        "note": "teacher-forced forward (19 decoder steps) + backward through decoder, attention and both encoder layers + Adam, fp32"}
 # ---- input side: Resize(256) + CenterCrop(224) of 256 decoded 720p frames, resident in HBM ---------------------------
 from tennis_amd import transforms as TT
 tf = TT.Compose([TT.Resize(256), TT.CenterCrop(224), TT.ToTensor(), TT.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])

@@ -98,3 +98,33 @@ def test_dropout_gradients_match_autograd_with_the_same_masks():
     loss2 = tr.forward_backward(*args)                      # next step: new masks
     m2 = tr.dropout_masks(cfg["B"], cfg["T"], cfg["L"] - 1)[2].cpu().numpy()
     assert not np.array_equal(m2, masks[2]) and abs(float(loss2) - float(loss)) > 0
+
+
+def test_train_driver(tmp_path):
+    """tennis_amd.train_gnmt.train (reference train_gnmt.py:305-461): bucketed batches, Adam steps, per-epoch evaluation
+    (loss + BLEU of the beam-search output), learning-rate halving from 2/3 of the epochs, parameter files."""
+    from tennis_amd.captions import CaptionSet
+    from tennis_amd.models.captioning.gnmt import NMTModel, get_gnmt_encoder_decoder
+    from tennis_amd.train_gnmt import train
+    from tennis_amd.utils.translation import BeamSearchScorer, BeamSearchTranslator
+    tr_set = CaptionSet(split="train", n_points=16, feature_dim=48, mean_frames=10, max_cap_len=50)
+    va_set = CaptionSet(split="val", n_points=6, feature_dim=48, mean_frames=10, vocab=tr_set.vocab, inference=True)
+    enc, dec = get_gnmt_encoder_decoder(cell_type="gru", hidden_size=24, num_layers=2, num_bi_layers=1)
+    model = NMTModel(src_vocab=None, tgt_vocab=tr_set.vocab, encoder=enc, decoder=dec, embed_size=12, prefix="gnmt_", input_size=48)
+    model.initialize()
+    translator = BeamSearchTranslator(model=model, beam_size=4, scorer=BeamSearchScorer(alpha=1.0, K=5), max_length=20)
+    logs = []
+    hist = train(tr_set, va_set, None, model, translator, epochs=9, batch_size=8, lr=2e-2, dropout=0.1, save_dir=str(tmp_path),
+                 log=logs.append)
+    assert len(hist) == 9 and hist[-1]["train_loss"] < 0.9 * hist[0]["train_loss"]      # random captions: memorisation only
+    assert all(np.isfinite(h["valid_loss"]) and 0.0 <= h["valid_bleu"] <= 1.0 for h in hist)
+    assert np.allclose([h["lr"] for h in hist], [2e-2] * 6 + [1e-2, 5e-3, 2.5e-3])       # halved after every epoch from epoch + 1 >= 6
+    assert (tmp_path / "0008.params").exists() and (tmp_path / "epoch8_valid_out.txt").exists()
+    assert any("valid Loss" in l for l in logs)
+    # the saved parameters load back into a fresh model and reproduce the last evaluation
+    enc2, dec2 = get_gnmt_encoder_decoder(cell_type="gru", hidden_size=24, num_layers=2, num_bi_layers=1)
+    m2 = NMTModel(src_vocab=None, tgt_vocab=tr_set.vocab, encoder=enc2, decoder=dec2, embed_size=12, prefix="gnmt_", input_size=48)
+    m2.initialize()
+    m2.load_parameters(str(tmp_path / "0008.params"))
+    a, b = model.collect_params(), m2.collect_params()
+    assert all(np.array_equal(a[k].data, b[k].data) for k in a)
