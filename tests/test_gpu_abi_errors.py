@@ -61,3 +61,36 @@ def test_two_stream_model_is_refused():
     from tennis_amd.models.vision.definitions import TwoStreamModel
     with pytest.raises(NotImplementedError):
         TwoStreamModel(None, None, 11)
+
+
+def test_gnmt_trainer_errors():
+    """The captioner training handle: missing / mis-sized parameters, shapes beyond the handle, bad dropout rate and
+    unknown names raise with the library's message; an LSTM model is refused by the driver."""
+    import ctypes as C
+    from tennis_amd import _lib, weights as W
+    from tennis_amd.engine import GNMTTrainer
+    p = W.make_gnmt_weights(0, "gru", 16, 8, 6, 12)
+    tr = GNMTTrainer(p, 16, 8, 6, 12, max_batch=2, max_src_len=5, max_tgt_len=4)
+    z = lambda *s: torch.zeros(s, dtype=torch.int32, device="cuda")
+    src = torch.zeros((3, 5, 16), device="cuda")
+    with pytest.raises(RuntimeError, match="exceed"):
+        tr.forward_backward(src, z(3) + 5, z(3, 4), z(3) + 4)                     # batch 3 > 2
+    with pytest.raises(RuntimeError, match="exceed"):
+        tr.forward_backward(src[:2], z(2) + 5, z(2, 6), z(2) + 6)                # 6 target columns > 4
+    with pytest.raises(RuntimeError, match="rate"):
+        tr.set_dropout(1.0)
+    with pytest.raises(KeyError):
+        tr.get("gnmt_no_such_weight")
+    lib = _lib.load()
+    n, buf = C.c_int64(), (C.c_float * 4)()
+    assert lib.tn_gnmt_trainer_read_param(tr.handle, b"gnmt_nope", 0, buf, 4, C.byref(n)) != 0
+    assert b"unknown parameter" in lib.tn_last_error()
+    assert lib.tn_gnmt_trainer_read_param(tr.handle, b"gnmt_tgt_proj_bias", 0, buf, 4, C.byref(n)) != 0     # 12 floats > 4
+    assert b"too small" in lib.tn_last_error()
+    q = dict(p)
+    del q["gnmt_dec_attention_key_weight"]
+    with pytest.raises(RuntimeError, match="dec_attention_key_weight"):
+        GNMTTrainer(q, 16, 8, 6, 12)
+    with pytest.raises(RuntimeError, match="wrong size"):
+        GNMTTrainer(W.make_gnmt_weights(0, "lstm", 16, 8, 6, 12), 16, 8, 6, 12)   # 4-gate weights into the GRU trainer
+    assert lib.tn_gnmt_trainer_destroy(None) == 0
