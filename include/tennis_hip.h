@@ -164,7 +164,8 @@ int tn_head_read_param(tn_head *h, const char *name, int gradient, float *out_ho
 int tn_head_destroy(tn_head *h);
 
 /* ---- captioner training step ---------------------------------- */
-/* One step of reference train_gnmt.py::train (:328-337) for GRU cells, num_layers = 2, num_bi_layers = 1:
+/* One step of reference train_gnmt.py::train (:328-337) for GRU or LSTM cells (--cell_type), num_layers = 2,
+ * num_bi_layers = 1:
  *   out, _ = model(src, tgt[:, :-1], src_valid_length, tgt_valid_length - 1)        teacher-forced NMTModel.forward
  *   loss = MaskedSoftmaxCELoss(out, tgt[:, 1:], tgt_valid_length - 1).mean()
  *          * (tgt.shape[1] - 1) / (tgt_valid_length - 1).mean()                      = summed NLL / number of valid tokens
@@ -175,9 +176,9 @@ int tn_head_destroy(tn_head *h);
  * optional.  The gradient of the loss w.r.t. every parameter is left in the flat gradient buffer
  * (tn_gnmt_trainer_buffers; all-reduce it over ranks for data parallelism) for tn_gnmt_trainer_adam_step. */
 typedef struct tn_gnmt_trainer tn_gnmt_trainer;
-int tn_gnmt_trainer_create(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix, int input_size,
-                           int hidden, int embed, int vocab, int max_batch, int max_src_len, int max_tgt_len,
-                           tn_gnmt_trainer **out);
+int tn_gnmt_trainer_create(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix, tn_rnn_kind cell_kind,
+                           int input_size, int hidden, int embed, int vocab, int max_batch, int max_src_len,
+                           int max_tgt_len, tn_gnmt_trainer **out);
 int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float *src, const int32_t *src_valid_len,
                                      const int32_t *tgt, int ld, const int32_t *tgt_valid_len, int batch, int steps,
                                      int tgt_len, float *loss, float *logits_out);

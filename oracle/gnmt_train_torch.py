@@ -11,7 +11,7 @@ gives the gradients:
   update   gluon.Trainer(params, 'adam', {'learning_rate': lr}).step(1)                 train_gnmt.py:310,337
            MXNet Adam [EXT]: lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t); m, v moments; w -= lr_t * m / (sqrt(v) + eps)
 
-GRU cells only (the reference's flag default).  PARITY UNPINNED against MXNet / gluonnlp (absent); the backward pass is
+GRU (the reference's flag default) and LSTM cells.  PARITY UNPINNED against MXNet / gluonnlp (absent); the backward pass is
 torch autograd's.  Only tests/ may import this module.
 """
 from __future__ import annotations
@@ -30,30 +30,46 @@ def _gru_cell(x, h, wi, wh, bi, bh):
     return (1 - z) * n + z * h
 
 
-def _direction(x, w, pref, reverse, vl):
+def _lstm_cell(x, h, c, wi, wh, bi, bh):
+    H = h.shape[-1]
+    g = x @ wi.T + bi + h @ wh.T + bh
+    i, f, gg, o = torch.sigmoid(g[:, :H]), torch.sigmoid(g[:, H:2 * H]), torch.tanh(g[:, 2 * H:3 * H]), torch.sigmoid(g[:, 3 * H:])
+    c2 = f * c + i * gg
+    return o * torch.tanh(c2), c2
+
+
+def _cell(cell, x, h, c, wi, wh, bi, bh):
+    if cell == "lstm":
+        return _lstm_cell(x, h, c, wi, wh, bi, bh)
+    return _gru_cell(x, h, wi, wh, bi, bh), c
+
+
+def _direction(x, w, pref, reverse, vl, cell="gru"):
     """gluon unroll(valid_length=...): steps past the valid length neither update the state nor emit output; the
     reverse direction starts at each row's last valid step (oracle/rnn_np.py::rnn_direction)."""
     B, T, _ = x.shape
     wi, wh, bi, bh = (w[pref + k] for k in ("i2h_weight", "h2h_weight", "i2h_bias", "h2h_bias"))
     H = wh.shape[1]
     h = torch.zeros((B, H), dtype=x.dtype)
+    c = torch.zeros((B, H), dtype=x.dtype)
     outs = [torch.zeros((B, H), dtype=x.dtype) for _ in range(T)]
     ar = torch.arange(B)
     for s in range(T):
         idx = (vl - 1 - s) if reverse else torch.full((B,), s, dtype=torch.long)
         act = (s < vl) if reverse else (idx < vl)
         idc = idx.clamp(0, T - 1)
-        hn = _gru_cell(x[ar, idc], h, wi, wh, bi, bh)
+        hn, cn = _cell(cell, x[ar, idc], h, c, wi, wh, bi, bh)
         m = act[:, None].to(x.dtype)
         h = m * hn + (1 - m) * h
+        c = m * cn + (1 - m) * c
         for b in range(B):
             if bool(act[b]):
                 outs[int(idc[b])] = outs[int(idc[b])].clone()
                 outs[int(idc[b])][b] = hn[b]
-    return torch.stack(outs, dim=1), h
+    return torch.stack(outs, dim=1), h, c
 
 
-def forward_loss(params: dict, src, src_vl, tgt, tgt_vl, hidden, prefix="gnmt_", dtype=torch.float64, masks=None):
+def forward_loss(params: dict, src, src_vl, tgt, tgt_vl, hidden, prefix="gnmt_", dtype=torch.float64, masks=None, cell="gru"):
     """-> (loss scalar tensor, logits (B, L-1, V), leaf tensors dict).  masks = (m_enc0 (B,T,2H), m_enc1 (B,T,H), m_dec (L,B,H))
     are the dropout masks (already scaled by 1/(1-p)) of gnmt.py:152,395; None = no dropout."""
     w = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True) for k, v in params.items()}
@@ -62,12 +78,12 @@ def forward_loss(params: dict, src, src_vl, tgt, tgt_vl, hidden, prefix="gnmt_",
     B, T, _ = x.shape
     H = hidden
     pe = prefix + "enc_"
-    fo, _ = _direction(x, w, pe + "rnn0_l_", False, vl)
-    bo, bh0 = _direction(x, w, pe + "rnn0_r_", True, vl)
+    fo, _, _ = _direction(x, w, pe + "rnn0_l_", False, vl, cell)
+    bo, bh0, bc0 = _direction(x, w, pe + "rnn0_r_", True, vl, cell)
     seq0 = torch.cat([fo, bo], dim=2)
     if masks is not None:
         seq0 = seq0 * torch.tensor(np.asarray(masks[0]), dtype=dtype)      # dropout on the layer output (states are not dropped)
-    mem, h1 = _direction(seq0, w, pe + "rnn1_", False, vl)
+    mem, h1, c1 = _direction(seq0, w, pe + "rnn1_", False, vl, cell)
     if masks is not None:
         mem = mem * torch.tensor(np.asarray(masks[1]), dtype=dtype)
     keyproj = mem @ w[prefix + "dec_attention_key_weight"].T
@@ -76,19 +92,20 @@ def forward_loss(params: dict, src, src_vl, tgt, tgt_vl, hidden, prefix="gnmt_",
     tvl = torch.tensor(np.asarray(tgt_vl), dtype=torch.long) - 1
     L = tg.shape[1] - 1
     h0s, h1s, att = bh0, h1, torch.zeros((B, H), dtype=dtype)
+    c0s, c1s = bc0, c1
     pd = prefix + "dec_"
     logits = []
     for i in range(L):
         emb = w[prefix + "tgt_embed_weight"][tg[:, i].clamp(min=0)]
-        h0s = _gru_cell(torch.cat([emb, att], dim=1), h0s, w[pd + "rnn0_i2h_weight"], w[pd + "rnn0_h2h_weight"],
-                        w[pd + "rnn0_i2h_bias"], w[pd + "rnn0_h2h_bias"])
+        h0s, c0s = _cell(cell, torch.cat([emb, att], dim=1), h0s, c0s, w[pd + "rnn0_i2h_weight"], w[pd + "rnn0_h2h_weight"],
+                         w[pd + "rnn0_i2h_bias"], w[pd + "rnn0_h2h_bias"])
         q = h0s / np.sqrt(H)
         score = torch.einsum("bh,bth->bt", q, keyproj)
         score = torch.where(mask, score, torch.full_like(score, -1e18))
         wts = torch.softmax(score, dim=1) * mask.to(dtype)
         att = torch.einsum("bt,bth->bh", wts, mem)
-        h1s = _gru_cell(torch.cat([h0s, att], dim=1), h1s, w[pd + "rnn1_i2h_weight"], w[pd + "rnn1_h2h_weight"],
-                        w[pd + "rnn1_i2h_bias"], w[pd + "rnn1_h2h_bias"])
+        h1s, c1s = _cell(cell, torch.cat([h0s, att], dim=1), h1s, c1s, w[pd + "rnn1_i2h_weight"], w[pd + "rnn1_h2h_weight"],
+                         w[pd + "rnn1_i2h_bias"], w[pd + "rnn1_h2h_bias"])
         top = h1s if masks is None else h1s * torch.tensor(np.asarray(masks[2][i]), dtype=dtype)
         logits.append(top @ w[prefix + "tgt_proj_weight"].T + w[prefix + "tgt_proj_bias"])
     logits = torch.stack(logits, dim=1)                                       # (B, L, V)
@@ -100,8 +117,8 @@ def forward_loss(params: dict, src, src_vl, tgt, tgt_vl, hidden, prefix="gnmt_",
     return loss, logits, w
 
 
-def loss_and_grads(params, src, src_vl, tgt, tgt_vl, hidden, prefix="gnmt_", masks=None):
-    loss, logits, w = forward_loss(params, src, src_vl, tgt, tgt_vl, hidden, prefix, masks=masks)
+def loss_and_grads(params, src, src_vl, tgt, tgt_vl, hidden, prefix="gnmt_", masks=None, cell="gru"):
+    loss, logits, w = forward_loss(params, src, src_vl, tgt, tgt_vl, hidden, prefix, masks=masks, cell=cell)
     loss.backward()
     return float(loss.detach()), logits.detach().numpy(), {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape)) for k, v in w.items()}
 

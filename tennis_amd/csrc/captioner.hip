@@ -589,6 +589,34 @@ __global__ void trn_gru_bwd_kernel(const float *__restrict__ g, const float *__r
   dhz[id] = dh * zg;
 }
 
+// LSTM cell backward on the stacked pre-activations g (R,4H) = [i, f, g, o]: dc = dc_carry + dh o (1 - tanh^2 c);
+// dg (R,4H); dcz = dc f (to c_prev); there is no direct path to h_prev (dhz = 0)
+__global__ void trn_lstm_bwd_kernel(const float *__restrict__ g, const float *__restrict__ cprev, const float *__restrict__ cnew,
+                                    const float *a0, int l0, const float *a1, int l1, const float *a2, int l2,
+                                    const float *a3, int l3, const float *dcc, float *__restrict__ dg, float *dhz, float *dcz,
+                                    int R, int H) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)R * H) return;
+  const long r = id / H;
+  const int u = (int)(id - r * H);
+  const float *q = g + r * 4 * H;
+  const float ig = sigm(q[u]), fg = sigm(q[H + u]), gg = tanhf(q[2 * H + u]), og = sigm(q[3 * H + u]);
+  const float tc = tanhf(cnew[id]);
+  float dh = 0.f;
+  if (a0) dh += a0[r * l0 + u];
+  if (a1) dh += a1[r * l1 + u];
+  if (a2) dh += a2[r * l2 + u];
+  if (a3) dh += a3[r * l3 + u];
+  const float dct = (dcc ? dcc[id] : 0.f) + dh * og * (1.f - tc * tc);
+  float *o = dg + r * 4 * H;
+  o[u] = dct * gg * ig * (1.f - ig);
+  o[H + u] = dct * cprev[id] * fg * (1.f - fg);
+  o[2 * H + u] = dct * ig * (1.f - gg * gg);
+  o[3 * H + u] = dh * tc * og * (1.f - og);
+  dhz[id] = 0.f;
+  dcz[id] = dct * fg;
+}
+
 // attention backward for one decoder row per workgroup (256 threads): ctx = sum_t w_t mem_t, w = masked softmax of
 // s_t = q . kp_t, q = h0 / sqrt(H).  dctx = up to two addends.  Accumulates into dmem, dkp (B,T,H); writes dq / sqrt(H).
 __global__ __launch_bounds__(256) void trn_att_bwd_kernel(const float *__restrict__ aw, const float *__restrict__ mem,
@@ -656,19 +684,21 @@ __global__ void trn_emb_grad_kernel(const float *__restrict__ dx0, int K0, const
 
 // Gluon cell parameters <-> the stacked (4H, in+H) matrix of the step GEMM (GRU: rows r, z = [Wi | Wh], bias bi + bh;
 // rows 2H..3H = [Wi_n | 0], bias bi_n; rows 3H..4H = [0 | Wh_n], bias bh_n)
+// (LSTM: every row = [Wi | Wh], bias bi + bh)
 __global__ void trn_stack_kernel(const float *__restrict__ wi, const float *__restrict__ wh, const float *__restrict__ bi,
-                                 const float *__restrict__ bh, int in, int H, float *__restrict__ wc, float *__restrict__ bc) {
+                                 const float *__restrict__ bh, int in, int H, int lstm, float *__restrict__ wc,
+                                 float *__restrict__ bc) {
   const int row = blockIdx.x, Kc = in + H;
-  const int src_i = row < 3 * H ? row : -1, src_h = row < 2 * H ? row : row >= 3 * H ? row - H : -1;
+  const int src_i = (lstm || row < 3 * H) ? row : -1, src_h = (lstm || row < 2 * H) ? row : row >= 3 * H ? row - H : -1;
   for (int k = threadIdx.x; k < Kc; k += blockDim.x)
     wc[(long)row * Kc + k] = k < in ? (src_i >= 0 ? wi[(long)src_i * in + k] : 0.f) : (src_h >= 0 ? wh[(long)src_h * H + k - in] : 0.f);
   if (threadIdx.x == 0) bc[row] = (src_i >= 0 ? bi[src_i] : 0.f) + (src_h >= 0 ? bh[src_h] : 0.f);
 }
-__global__ void trn_unstack_kernel(const float *__restrict__ dwc, const float *__restrict__ dbc, int in, int H,
+__global__ void trn_unstack_kernel(const float *__restrict__ dwc, const float *__restrict__ dbc, int in, int H, int lstm,
                                    float *__restrict__ dwi, float *__restrict__ dwh, float *__restrict__ dbi,
                                    float *__restrict__ dbh) {
-  const int row = blockIdx.x, Kc = in + H;     // row of the Gluon (3H, .) matrices
-  const int ri = row, rh = row < 2 * H ? row : row + H;
+  const int row = blockIdx.x, Kc = in + H;     // row of the Gluon (G*H, .) matrices
+  const int ri = row, rh = (lstm || row < 2 * H) ? row : row + H;
   for (int k = threadIdx.x; k < Kc; k += blockDim.x) {
     if (k < in) dwi[(long)row * in + k] = dwc[(long)ri * Kc + k];
     else dwh[(long)row * H + k - in] = dwc[(long)rh * Kc + k];
@@ -1021,6 +1051,7 @@ struct tn_gnmt_trainer {
   tn_ctx *ctx;
   DevBuf pool;
   int F, H, E, V, maxB, maxT, maxL;
+  int G;                          // gates per cell: 3 GRU, 4 LSTM
   std::string prefix;
   // flat parameter / gradient / Adam-moment buffers; the two directions of the bi layer are adjacent per tensor kind so that
   // one GEMM / one recurrent launch serves both
@@ -1041,11 +1072,13 @@ struct tn_gnmt_trainer {
   float drop_p;
   unsigned long long drop_seed, drop_count;
   float *M0, *M1, *M2, *seq0d, *memd, *H1d;
+  // LSTM cell states: encoder finals, decoder per step, and their gradients
+  float *cl0, *cl1, *C0, *C1, *dcz0, *dcz1, *dcl0, *dcl1;
 };
 
 static int trainer_refresh(tn_gnmt_trainer *t) {
   hipStream_t s = t->ctx->stream;
-  const int H = t->H, E = t->E, V = t->V, GH = 3 * H, K0 = E + 2 * H, K1 = 3 * H;
+  const int H = t->H, E = t->E, V = t->V, GH = t->G * H, K0 = E + 2 * H, K1 = 3 * H, lstm = t->G == 4;
   int rc;
 #define TN_TRY(e) do { rc = (e); if (rc) return rc; } while (0)
   for (int d = 0; d < 2; ++d)
@@ -1053,9 +1086,9 @@ static int trainer_refresh(tn_gnmt_trainer *t) {
   TN_TRY(launch_transpose_f32(t->w + t->o_e1wh, GH, H, t->e1whT, s));
   TN_TRY(launch_transpose_f32(t->w + t->o_e1wi, GH, 2 * H, t->e1wiT, s));
   hipLaunchKernelGGL(trn_stack_kernel, dim3(4 * H), dim3(256), 0, s, (const float *)(t->w + t->o_d0wi), (const float *)(t->w + t->o_d0wh),
-                     (const float *)(t->w + t->o_d0bi), (const float *)(t->w + t->o_d0bh), E + H, H, t->w0c, t->b0c);
+                     (const float *)(t->w + t->o_d0bi), (const float *)(t->w + t->o_d0bh), E + H, H, lstm, t->w0c, t->b0c);
   hipLaunchKernelGGL(trn_stack_kernel, dim3(4 * H), dim3(256), 0, s, (const float *)(t->w + t->o_d1wi), (const float *)(t->w + t->o_d1wh),
-                     (const float *)(t->w + t->o_d1bi), (const float *)(t->w + t->o_d1bh), 2 * H, H, t->w1c, t->b1c);
+                     (const float *)(t->w + t->o_d1bi), (const float *)(t->w + t->o_d1bh), 2 * H, H, lstm, t->w1c, t->b1c);
   TN_TRY(launch_transpose_f32(t->w0c, 4 * H, K0, t->w0cT, s));
   TN_TRY(launch_transpose_f32(t->w1c, 4 * H, K1, t->w1cT, s));
   TN_TRY(launch_transpose_f32(t->w + t->o_wp, V, H, t->wpT, s));
@@ -1065,20 +1098,22 @@ static int trainer_refresh(tn_gnmt_trainer *t) {
   return TN_OK;
 }
 
-extern "C" int tn_gnmt_trainer_create(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix_c, int input_size,
-                                      int hidden, int embed, int vocab, int max_batch, int max_src_len, int max_tgt_len,
-                                      tn_gnmt_trainer **out) {
+extern "C" int tn_gnmt_trainer_create(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix_c, tn_rnn_kind cell_kind,
+                                      int input_size, int hidden, int embed, int vocab, int max_batch, int max_src_len,
+                                      int max_tgt_len, tn_gnmt_trainer **out) {
   TN_REQUIRE(ctx && params && prefix_c && out, "tn_gnmt_trainer_create: null argument");
-  TN_REQUIRE(input_size > 0 && hidden > 0 && hidden % 4 == 0 && 3 * hidden <= 1024 && embed > 0 && vocab > 1 && max_batch > 0 &&
-                 max_src_len > 0 && max_tgt_len > 1, "tn_gnmt_trainer_create: bad shape (3*hidden <= 1024, hidden % 4 == 0)");
+  TN_REQUIRE(cell_kind == TN_RNN_GRU || cell_kind == TN_RNN_LSTM, "tn_gnmt_trainer_create: cell_type must be 'gru' or 'lstm'");
+  const int G_ = cell_kind == TN_RNN_GRU ? 3 : 4;
+  TN_REQUIRE(input_size > 0 && hidden > 0 && hidden % 4 == 0 && G_ * hidden <= 1024 && embed > 0 && vocab > 1 && max_batch > 0 &&
+                 max_src_len > 0 && max_tgt_len > 1, "tn_gnmt_trainer_create: bad shape (gates*hidden <= 1024, hidden % 4 == 0)");
   TN_HIP_CHECK(hipSetDevice(ctx->device));
   const std::string pre(prefix_c);
   std::map<std::string, const tn_param *> pm;
   for (int i = 0; i < n_params; ++i) pm[params[i].name] = &params[i];
   tn_gnmt_trainer *t = new tn_gnmt_trainer();
   t->ctx = ctx; t->F = input_size; t->H = hidden; t->E = embed; t->V = vocab; t->maxB = max_batch; t->maxT = max_src_len;
-  t->maxL = max_tgt_len - 1; t->prefix = pre; t->step = 0;
-  const long F = input_size, H = hidden, E = embed, V = vocab, GH = 3 * H;
+  t->maxL = max_tgt_len - 1; t->prefix = pre; t->step = 0; t->G = G_;
+  const long F = input_size, H = hidden, E = embed, V = vocab, GH = (long)G_ * H;
   long o = 0;
   auto take = [&](long cnt) { const long r = o; o += cnt; return r; };
   t->o_e0wi = take(2 * GH * F); t->o_e0bi = take(2 * GH); t->o_e0wh = take(2 * GH * H); t->o_e0bh = take(2 * GH);
@@ -1117,8 +1152,8 @@ extern "C" int tn_gnmt_trainer_create(tn_ctx *ctx, const tn_param *params, int n
   t->e0whT = fl(2 * H * GH); t->e1whT = fl(H * GH); t->e1wiT = fl(2 * H * GH);
   t->w0c = fl(4 * H * K0); t->b0c = fl(4 * H); t->w1c = fl(4 * H * K1); t->b1c = fl(4 * H);
   t->w0cT = fl(4 * H * K0); t->w1cT = fl(4 * H * K1); t->wpT = fl(V * H); t->wkT = fl(H * H);
-  t->gi0 = fl(BT * 2 * GH); t->seq0 = fl(BT * 2 * H); t->sav0 = fl(2 * BT * 4 * H); t->gi1 = fl(BT * GH); t->mem = fl(BT * H);
-  t->sav1 = fl(BT * 4 * H); t->hl0 = fl(2 * B * H); t->hl1 = fl(B * H); t->keyproj = fl(BT * H); t->keyprojT = fl(BT * H);
+  t->gi0 = fl(BT * 2 * GH); t->seq0 = fl(BT * 2 * H); t->sav0 = fl(2 * BT * (G_ + 1) * H); t->gi1 = fl(BT * GH); t->mem = fl(BT * H);
+  t->sav1 = fl(BT * (G_ + 1) * H); t->hl0 = fl(2 * B * H); t->hl1 = fl(B * H); t->keyproj = fl(BT * H); t->keyprojT = fl(BT * H);
   t->X0 = fl(LB * K0); t->G0 = fl(LB * 4 * H); t->X1 = fl(LB * K1); t->G1 = fl(LB * 4 * H); t->H1 = fl(LB * H); t->AW = fl(LB * T);
   t->h0tmp = fl(B * H); t->ctxtmp = fl(B * H); t->logits = fl(LB * V); t->lossrows = fl(LB);
   t->vl = t->pool.alloc<int32_t>(B); t->tvl = t->pool.alloc<int32_t>(B);
@@ -1129,6 +1164,8 @@ extern "C" int tn_gnmt_trainer_create(tn_ctx *ctx, const tn_param *params, int n
   t->dseq0 = fl(BT * 2 * H); t->dgi0 = fl(BT * 2 * GH); t->dgh0 = fl(BT * 2 * GH); t->hp0 = fl(2 * BT * H);
   t->M0 = fl(BT * 2 * H); t->M1 = fl(BT * H); t->M2 = fl(LB * H); t->seq0d = fl(BT * 2 * H); t->memd = fl(BT * H); t->H1d = fl(LB * H);
   t->drop_p = 0.f; t->drop_seed = 0; t->drop_count = 0;
+  t->cl0 = fl(2 * B * H); t->cl1 = fl(B * H); t->C0 = fl(LB * H); t->C1 = fl(LB * H); t->dcz0 = fl(B * H); t->dcz1 = fl(B * H);
+  t->dcl0 = fl(2 * B * H); t->dcl1 = fl(B * H);
   if (t->pool.failed) { tn_set_error("device allocation failed"); return fail(TN_ERR_NOMEM); }
   TN_HIP_CHECK(hipMemsetAsync(t->g, 0, sizeof(float) * t->n, ctx->stream));
   TN_HIP_CHECK(hipMemsetAsync(t->am, 0, sizeof(float) * t->n, ctx->stream));
@@ -1157,8 +1194,9 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
              "tn_gnmt_trainer_forward_backward: batch / source steps / target length exceed the handle");
   TN_HIP_CHECK(hipSetDevice(t->ctx->device));
   hipStream_t s = t->ctx->stream;
-  const int B = batch, T = steps, L = tgt_len - 1, F = t->F, H = t->H, E = t->E, V = t->V, GH = 3 * H, K0 = E + 2 * H, K1 = 3 * H;
+  const int B = batch, T = steps, L = tgt_len - 1, F = t->F, H = t->H, E = t->E, V = t->V, G = t->G, GH = G * H, K0 = E + 2 * H, K1 = 3 * H;
   const int BT = B * T, LB = L * B;
+  const bool lstm = G == 4;
   const size_t att_lds = ((size_t)(H + T) * 4 + (size_t)4 * (T > H ? T : H)) * sizeof(float);
   const size_t attb_lds = (size_t)(2 * H + T + 256) * sizeof(float);
   TN_REQUIRE(att_lds <= 64 * 1024 && attb_lds <= 64 * 1024, "tn_gnmt_trainer: 8 * max(hidden, source length) exceeds 64 KiB of LDS");
@@ -1171,7 +1209,7 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
   hipLaunchKernelGGL(trn_dec_len_kernel, dim3((B + 255) / 256), dim3(256), 0, s, tgt_valid_len, t->tvl, B);
   TN_TRY(launch_linear_f32(src, F, w + t->o_e0wi, F, w + t->o_e0bi, t->gi0, 2 * GH, BT, 2 * GH, F, 0, s));
   TN_HIP_CHECK(hipMemsetAsync(t->seq0, 0, sizeof(float) * (size_t)BT * 2 * H, s));
-  TN_TRY(launch_rnn_recurrent(3, t->gi0, 2 * GH, t->e0whT, w + t->o_e0bh, t->vl, t->seq0, 2 * H, t->hl0, nullptr, B, T, H, 2, s, t->sav0));
+  TN_TRY(launch_rnn_recurrent(G, t->gi0, 2 * GH, t->e0whT, w + t->o_e0bh, t->vl, t->seq0, 2 * H, t->hl0, lstm ? t->cl0 : nullptr, B, T, H, 2, s, t->sav0));
   // dropout points of the reference (gnmt.py:152,395); the recurrences themselves keep the un-dropped outputs
   const bool drop = t->drop_p > 0.f;
   const float *seq0d = t->seq0, *memd = t->mem, *H1d = t->H1;
@@ -1186,7 +1224,7 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
   }
   TN_TRY(launch_linear_f32(seq0d, 2 * H, w + t->o_e1wi, 2 * H, w + t->o_e1bi, t->gi1, GH, BT, GH, 2 * H, 0, s));
   TN_HIP_CHECK(hipMemsetAsync(t->mem, 0, sizeof(float) * (size_t)BT * H, s));
-  TN_TRY(launch_rnn_recurrent(3, t->gi1, GH, t->e1whT, w + t->o_e1bh, t->vl, t->mem, H, t->hl1, nullptr, B, T, H, 1, s, t->sav1));
+  TN_TRY(launch_rnn_recurrent(G, t->gi1, GH, t->e1whT, w + t->o_e1bh, t->vl, t->mem, H, t->hl1, lstm ? t->cl1 : nullptr, B, T, H, 1, s, t->sav1));
   if (drop) hipLaunchKernelGGL(trn_mul_kernel, dim3(((long)BT * H + 255) / 256), dim3(256), 0, s, (const float *)t->mem, (const float *)t->M1, t->memd, (long)BT * H);
   TN_TRY(launch_linear_f32(memd, H, w + t->o_wk, H, nullptr, t->keyproj, H, BT, H, H, 0, s));
   hipLaunchKernelGGL(transpose_bth_kernel, dim3((H + 31) / 32, (T + 31) / 32, B), dim3(256), 0, s, (const float *)t->keyproj, t->keyprojT, T, H);
@@ -1199,12 +1237,14 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
                        i ? X1p + H : (const float *)nullptr, K1, i ? X1p : (const float *)(t->hl0 + (size_t)B * H), i ? K1 : H,
                        i ? H1p : (const float *)t->hl1, H, X0, X1, H, E);
     TN_TRY(launch_linear_f32(X0, K0, t->w0c, K0, t->b0c, G0, 4 * H, B, 4 * H, K0, 0, s));
+    const float *c0p = !lstm ? nullptr : i ? t->C0 + (size_t)(i - 1) * B * H : t->cl0 + (size_t)B * H;
+    const float *c1p = !lstm ? nullptr : i ? t->C1 + (size_t)(i - 1) * B * H : t->cl1;
     hipLaunchKernelGGL(dec_attention_kernel<1>, dim3(B), dim3(kBeamThreads), att_lds, s, (const float *)G0, (const float *)(X0 + E + H), K0,
-                       (const float *)nullptr, 0, t->h0tmp, (float *)nullptr, X1, K1, (const float *)t->keyprojT, memd,
+                       c0p, lstm ? 1 : 0, t->h0tmp, lstm ? t->C0 + (size_t)i * B * H : (float *)nullptr, X1, K1, (const float *)t->keyprojT, memd,
                        (const int32_t *)t->vl, t->ctxtmp, 1, 1, T, H, t->AW + (size_t)i * B * T);
     TN_TRY(launch_linear_f32(X1, K1, t->w1c, K1, t->b1c, G1, 4 * H, B, 4 * H, K1, 0, s));
-    hipLaunchKernelGGL(dec_tf_cell1_kernel, dim3(nbH), dim3(256), 0, s, (const float *)G1, (const float *)X1, 0, (const float *)nullptr, H1,
-                       (float *)nullptr, B, H);
+    hipLaunchKernelGGL(dec_tf_cell1_kernel, dim3(nbH), dim3(256), 0, s, (const float *)G1, (const float *)X1, lstm ? 1 : 0, c1p, H1,
+                       lstm ? t->C1 + (size_t)i * B * H : (float *)nullptr, B, H);
     const float *H1p_ = H1;
     if (drop) {
       hipLaunchKernelGGL(trn_mul_kernel, dim3(nbH), dim3(256), 0, s, (const float *)H1, (const float *)(t->M2 + (size_t)i * B * H), t->H1d + (size_t)i * B * H, (long)B * H);
@@ -1233,16 +1273,27 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
     float *dX0 = t->dX0 + (size_t)i * B * K0, *dX1 = t->dX1 + (size_t)i * B * K1;
     const float *dX0n = t->dX0 + (size_t)(i + 1) * B * K0, *dX1n = t->dX1 + (size_t)(i + 1) * B * K1;   // step i+1 (valid unless last)
     const float *nul = nullptr;
-    hipLaunchKernelGGL(trn_gru_bwd_kernel, dim3(nbH), dim3(256), 0, s, (const float *)G1, (const float *)(X1 + 2 * H), K1,
-                       (const float *)(t->dH1 + (size_t)i * B * H), H, last ? nul : (const float *)t->dhz1, H, last ? nul : dX1n + 2 * H, K1,
-                       nul, 0, dG1, t->dhz1, B, H);
+    const float *a1b = last ? nul : (const float *)t->dhz1, *a1c = last ? nul : dX1n + 2 * H;
+    if (lstm)
+      hipLaunchKernelGGL(trn_lstm_bwd_kernel, dim3(nbH), dim3(256), 0, s, (const float *)G1, i ? (const float *)(t->C1 + (size_t)(i - 1) * B * H) : (const float *)t->cl1,
+                         (const float *)(t->C1 + (size_t)i * B * H), (const float *)(t->dH1 + (size_t)i * B * H), H, a1b, H, a1c, K1, nul, 0,
+                         last ? nul : (const float *)t->dcz1, dG1, t->dhz1, t->dcz1, B, H);
+    else
+      hipLaunchKernelGGL(trn_gru_bwd_kernel, dim3(nbH), dim3(256), 0, s, (const float *)G1, (const float *)(X1 + 2 * H), K1,
+                         (const float *)(t->dH1 + (size_t)i * B * H), H, a1b, H, a1c, K1, nul, 0, dG1, t->dhz1, B, H);
     TN_TRY(launch_linear_f32(dG1, 4 * H, t->w1cT, 4 * H, nullptr, dX1, K1, B, K1, 4 * H, 0, s));
     hipLaunchKernelGGL(trn_att_bwd_kernel, dim3(B), dim3(256), attb_lds, s, (const float *)(t->AW + (size_t)i * B * T), memd,
                        (const float *)t->keyproj, (const float *)X1, K1, (const float *)(dX1 + H), K1, last ? nul : dX0n + E, K0,
                        (const int32_t *)t->vl, t->dmem, t->dkp, t->dq, T, H);
-    hipLaunchKernelGGL(trn_gru_bwd_kernel, dim3(nbH), dim3(256), 0, s, (const float *)G0, (const float *)(X0 + E + H), K0,
-                       (const float *)dX1, K1, (const float *)t->dq, H, last ? nul : (const float *)t->dhz0, H, last ? nul : dX0n + E + H, K0,
-                       dG0, t->dhz0, B, H);
+    const float *a0c = last ? nul : (const float *)t->dhz0, *a0d = last ? nul : dX0n + E + H;
+    if (lstm)
+      hipLaunchKernelGGL(trn_lstm_bwd_kernel, dim3(nbH), dim3(256), 0, s, (const float *)G0,
+                         i ? (const float *)(t->C0 + (size_t)(i - 1) * B * H) : (const float *)(t->cl0 + (size_t)B * H),
+                         (const float *)(t->C0 + (size_t)i * B * H), (const float *)dX1, K1, (const float *)t->dq, H, a0c, H, a0d, K0,
+                         last ? nul : (const float *)t->dcz0, dG0, t->dhz0, t->dcz0, B, H);
+    else
+      hipLaunchKernelGGL(trn_gru_bwd_kernel, dim3(nbH), dim3(256), 0, s, (const float *)G0, (const float *)(X0 + E + H), K0,
+                         (const float *)dX1, K1, (const float *)t->dq, H, a0c, H, a0d, K0, dG0, t->dhz0, B, H);
     TN_TRY(launch_linear_f32(dG0, 4 * H, t->w0cT, 4 * H, nullptr, dX0, K0, B, K0, 4 * H, 0, s));
   }
   // gradients reaching the encoder's final states: layer 0 backward direction and the uni layer (forward direction of layer 0: none)
@@ -1250,14 +1301,19 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
   hipLaunchKernelGGL(trn_add2_kernel, dim3(nbH), dim3(256), 0, s, (const float *)t->dhz0, H, (const float *)(t->dX0 + E + H), K0,
                      t->dhl0 + (size_t)B * H, B, H);
   hipLaunchKernelGGL(trn_add2_kernel, dim3(nbH), dim3(256), 0, s, (const float *)t->dhz1, H, (const float *)(t->dX1 + 2 * H), K1, t->dhl1, B, H);
+  if (lstm) {   // gradients reaching the encoder's final cell states
+    TN_HIP_CHECK(hipMemsetAsync(t->dcl0, 0, sizeof(float) * (size_t)B * H, s));
+    TN_HIP_CHECK(hipMemcpyAsync(t->dcl0 + (size_t)B * H, t->dcz0, sizeof(float) * (size_t)B * H, hipMemcpyDeviceToDevice, s));
+    TN_HIP_CHECK(hipMemcpyAsync(t->dcl1, t->dcz1, sizeof(float) * (size_t)B * H, hipMemcpyDeviceToDevice, s));
+  }
   // ---------------- backward: decoder weights, attention key projection, embedding ----------------
   TN_TRY(launch_gemm_tn_f32(t->dG0, 4 * H, t->X0, K0, t->dW0c, K0, 4 * H, K0, LB, s));
   TN_TRY(launch_colsum_f32(t->dG0, 4 * H, LB, 4 * H, t->db0c, s));
-  hipLaunchKernelGGL(trn_unstack_kernel, dim3(GH), dim3(256), 0, s, (const float *)t->dW0c, (const float *)t->db0c, E + H, H, g + t->o_d0wi,
+  hipLaunchKernelGGL(trn_unstack_kernel, dim3(GH), dim3(256), 0, s, (const float *)t->dW0c, (const float *)t->db0c, E + H, H, lstm ? 1 : 0, g + t->o_d0wi,
                      g + t->o_d0wh, g + t->o_d0bi, g + t->o_d0bh);
   TN_TRY(launch_gemm_tn_f32(t->dG1, 4 * H, t->X1, K1, t->dW1c, K1, 4 * H, K1, LB, s));
   TN_TRY(launch_colsum_f32(t->dG1, 4 * H, LB, 4 * H, t->db1c, s));
-  hipLaunchKernelGGL(trn_unstack_kernel, dim3(GH), dim3(256), 0, s, (const float *)t->dW1c, (const float *)t->db1c, 2 * H, H, g + t->o_d1wi,
+  hipLaunchKernelGGL(trn_unstack_kernel, dim3(GH), dim3(256), 0, s, (const float *)t->dW1c, (const float *)t->db1c, 2 * H, H, lstm ? 1 : 0, g + t->o_d1wi,
                      g + t->o_d1wh, g + t->o_d1bi, g + t->o_d1bh);
   TN_TRY(launch_gemm_tn_f32(t->dkp, H, memd, H, g + t->o_wk, H, H, H, BT, s));
   TN_TRY(launch_linear_f32(t->dkp, H, t->wkT, H, nullptr, t->dmem, H, BT, H, H, 1, s));
@@ -1267,22 +1323,26 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
   TN_HIP_CHECK(hipMemsetAsync(t->dgi1, 0, sizeof(float) * (size_t)BT * GH, s));
   TN_HIP_CHECK(hipMemsetAsync(t->dgh1, 0, sizeof(float) * (size_t)BT * GH, s));
   TN_HIP_CHECK(hipMemsetAsync(t->hp1, 0, sizeof(float) * (size_t)BT * H, s));
-  TN_TRY(launch_gru_train_bwd(t->mem, t->sav1, t->dmem, w + t->o_e1wh, t->dgi1, t->dgh1, t->hp1, B, T, H, s, 1, t->vl, t->dhl1));
+  if (lstm) TN_TRY(launch_lstm_train_bwd(t->mem, t->sav1, t->dmem, w + t->o_e1wh, t->dgi1, t->hp1, B, T, H, s, 1, t->vl, t->dhl1, t->dcl1));
+  else TN_TRY(launch_gru_train_bwd(t->mem, t->sav1, t->dmem, w + t->o_e1wh, t->dgi1, t->dgh1, t->hp1, B, T, H, s, 1, t->vl, t->dhl1));
+  const float *dgh1 = lstm ? t->dgi1 : t->dgh1;      // LSTM: one pre-activation gradient feeds both branches
   TN_TRY(launch_gemm_tn_f32(t->dgi1, GH, seq0d, 2 * H, g + t->o_e1wi, 2 * H, GH, 2 * H, BT, s));
   TN_TRY(launch_colsum_f32(t->dgi1, GH, BT, GH, g + t->o_e1bi, s));
-  TN_TRY(launch_gemm_tn_f32(t->dgh1, GH, t->hp1, H, g + t->o_e1wh, H, GH, H, BT, s));
-  TN_TRY(launch_colsum_f32(t->dgh1, GH, BT, GH, g + t->o_e1bh, s));
+  TN_TRY(launch_gemm_tn_f32(dgh1, GH, t->hp1, H, g + t->o_e1wh, H, GH, H, BT, s));
+  TN_TRY(launch_colsum_f32(dgh1, GH, BT, GH, g + t->o_e1bh, s));
   TN_TRY(launch_linear_f32(t->dgi1, GH, t->e1wiT, GH, nullptr, t->dseq0, 2 * H, BT, 2 * H, GH, 0, s));
   if (drop) hipLaunchKernelGGL(trn_mul_kernel, dim3(((long)BT * 2 * H + 255) / 256), dim3(256), 0, s, (const float *)t->dseq0, (const float *)t->M0, t->dseq0, (long)BT * 2 * H);
   TN_HIP_CHECK(hipMemsetAsync(t->dgi0, 0, sizeof(float) * (size_t)BT * 2 * GH, s));
   TN_HIP_CHECK(hipMemsetAsync(t->dgh0, 0, sizeof(float) * (size_t)BT * 2 * GH, s));
   TN_HIP_CHECK(hipMemsetAsync(t->hp0, 0, sizeof(float) * (size_t)2 * BT * H, s));
-  TN_TRY(launch_gru_train_bwd(t->seq0, t->sav0, t->dseq0, w + t->o_e0wh, t->dgi0, t->dgh0, t->hp0, B, T, H, s, 2, t->vl, t->dhl0));
+  if (lstm) TN_TRY(launch_lstm_train_bwd(t->seq0, t->sav0, t->dseq0, w + t->o_e0wh, t->dgi0, t->hp0, B, T, H, s, 2, t->vl, t->dhl0, t->dcl0));
+  else TN_TRY(launch_gru_train_bwd(t->seq0, t->sav0, t->dseq0, w + t->o_e0wh, t->dgi0, t->dgh0, t->hp0, B, T, H, s, 2, t->vl, t->dhl0));
+  const float *dgh0 = lstm ? t->dgi0 : t->dgh0;
   TN_TRY(launch_gemm_tn_f32(t->dgi0, 2 * GH, src, F, g + t->o_e0wi, F, 2 * GH, F, BT, s));
   TN_TRY(launch_colsum_f32(t->dgi0, 2 * GH, BT, 2 * GH, g + t->o_e0bi, s));
   for (int d = 0; d < 2; ++d)
-    TN_TRY(launch_gemm_tn_f32(t->dgh0 + d * GH, 2 * GH, t->hp0 + (size_t)d * BT * H, H, g + t->o_e0wh + (long)d * GH * H, H, GH, H, BT, s));
-  TN_TRY(launch_colsum_f32(t->dgh0, 2 * GH, BT, 2 * GH, g + t->o_e0bh, s));
+    TN_TRY(launch_gemm_tn_f32(dgh0 + d * GH, 2 * GH, t->hp0 + (size_t)d * BT * H, H, g + t->o_e0wh + (long)d * GH * H, H, GH, H, BT, s));
+  TN_TRY(launch_colsum_f32(dgh0, 2 * GH, BT, 2 * GH, g + t->o_e0bh, s));
 #undef TN_TRY
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;
@@ -1330,7 +1390,7 @@ extern "C" int tn_gnmt_trainer_read_param(tn_gnmt_trainer *t, const char *name_c
                                           int64_t *numel) {
   TN_REQUIRE(t && name_c && out_host && numel, "tn_gnmt_trainer_read_param: null argument");
   const std::string name(name_c), pre = t->prefix;
-  const long F = t->F, H = t->H, E = t->E, V = t->V, GH = 3 * H;
+  const long F = t->F, H = t->H, E = t->E, V = t->V, GH = (long)t->G * H;
   long off = -1, cnt = 0;
   auto cell = [&](const std::string &c, long owi, long obi, long owh, long obh, long in) {
     if (name == pre + c + "i2h_weight") { off = owi; cnt = GH * in; }

@@ -193,10 +193,13 @@ __global__ __launch_bounds__(MAXT) void gru_train_bwd_kernel(const float *__rest
 // gradient is the same for the i2h and the h2h branch, so only dgi is written (the caller uses it for both).
 template <int NB, int KR, int MAXT>
 __global__ __launch_bounds__(MAXT) void lstm_train_bwd_kernel(const float *__restrict__ seq, const float *__restrict__ gates,
-                                      const float *__restrict__ dseq, const float *__restrict__ wh,   // [2][4H][H]
-                                      float *__restrict__ dgi,                                        // [B*T][2*4H]
-                                      float *__restrict__ hprev,                                      // [2][B*T][H]
-                                      int B, int T, int H) {
+                                      const float *__restrict__ dseq, const float *__restrict__ wh,   // [dirs][4H][H]
+                                      float *__restrict__ dgi,                                        // [B*T][dirs*4H]
+                                      float *__restrict__ hprev,                                      // [dirs][B*T][H]
+                                      int B, int T, int H, int dirs,
+                                      const int32_t *__restrict__ valid_len,     // [B] or null: steps >= valid_len never ran
+                                      const float *__restrict__ dh_last,         // [dirs][B][H] or null: d loss / d final h
+                                      const float *__restrict__ dc_last) {       // ... / d final c
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int GH = 4 * H;
   float *dh = lds;                  // [NB][H]   gradient flowing into h_t from the later step
@@ -212,30 +215,32 @@ __global__ __launch_bounds__(MAXT) void lstm_train_bwd_kernel(const float *__res
   for (int i = j; i < NB * H; i += GH) { dh[i] = 0.f; dc[i] = 0.f; }
   __syncthreads();
   for (int s = T - 1; s >= 0; --s) {
-    const int t = dir ? T - 1 - s : s;
-    const int tp = dir ? t + 1 : t - 1;
     for (int idx = j; idx < NB * H; idx += GH) {
       const int b = idx / H, uu = idx - b * H, bg = b0 + b;
       float d_i = 0.f, d_f = 0.f, d_g = 0.f, d_o = 0.f, dcp = 0.f;
-      if (bg < B) {
+      const int vlen = bg < B ? (valid_len ? valid_len[bg] : T) : 0;
+      if (s < vlen) {
+        const int t = dir ? vlen - 1 - s : s;
+        const int tp = dir ? t + 1 : t - 1;
         const long row = (long)bg * T + t;
         const float *sv = gates + ((long)dir * B * T + row) * (5 * H);
         const float ig = sv[uu], fg = sv[H + uu], gg = sv[2 * H + uu], og = sv[3 * H + uu], c2 = sv[4 * H + uu];
         float hp = 0.f, cp = 0.f;
         if (s > 0) {
           const long rp = (long)bg * T + tp;
-          hp = seq[rp * (2 * H) + dir * H + uu];
+          hp = seq[rp * (dirs * H) + dir * H + uu];
           cp = gates[((long)dir * B * T + rp) * (5 * H) + 4 * H + uu];
         }
+        const bool lastp = s == vlen - 1;
         const float tc = tanhf(c2);
-        const float dht = dh[idx] + dseq[row * (2 * H) + dir * H + uu];
-        const float dct = dc[idx] + dht * og * (1.f - tc * tc);
+        const float dht = ((lastp && dh_last) ? dh_last[((long)dir * B + bg) * H + uu] : dh[idx]) + dseq[row * (dirs * H) + dir * H + uu];
+        const float dct = ((lastp && dc_last) ? dc_last[((long)dir * B + bg) * H + uu] : dc[idx]) + dht * og * (1.f - tc * tc);
         d_o = dht * tc * og * (1.f - og);
         d_i = dct * gg * ig * (1.f - ig);
         d_f = dct * cp * fg * (1.f - fg);
         d_g = dct * ig * (1.f - gg * gg);
         dcp = dct * fg;
-        float *o1 = dgi + row * (2 * GH) + dir * GH;
+        float *o1 = dgi + row * (dirs * GH) + dir * GH;
         o1[uu] = d_i; o1[H + uu] = d_f; o1[2 * H + uu] = d_g; o1[3 * H + uu] = d_o;
         hprev[((long)dir * B * T + row) * H + uu] = hp;
       }
@@ -471,8 +476,9 @@ int launch_gru_train_bwd(const float *seq, const float *gates, const float *dseq
   TN_LAUNCH_CHECK();
 }
 int launch_lstm_train_bwd(const float *seq, const float *gates, const float *dseq, const float *wh, float *dgi,
-                          float *hprev, int B, int T, int H, hipStream_t s) {
-  TN_BPTT_DISPATCH(lstm_train_bwd_kernel, 4, 2, seq, gates, dseq, wh, dgi, hprev, B, T, H);
+                          float *hprev, int B, int T, int H, hipStream_t s, int dirs, const int32_t *valid_len,
+                          const float *dh_last, const float *dc_last) {
+  TN_BPTT_DISPATCH(lstm_train_bwd_kernel, 4, dirs, seq, gates, dseq, wh, dgi, hprev, B, T, H, dirs, valid_len, dh_last, dc_last);
   TN_LAUNCH_CHECK();
 }
 int launch_gemm_tn_f32(const float *A, int lda, const float *Bm, int ldb, float *Cm, int ldc, int M, int N, int K,

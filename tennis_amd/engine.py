@@ -340,19 +340,24 @@ class TemporalHeadTrainer:
 class GNMTTrainer:
     """One training step of the captioner the way reference train_gnmt.py::train drives it (:328-337): teacher-forced
     ``NMTModel`` forward, token-averaged ``MaskedSoftmaxCELoss``, ``loss.backward()``, ``gluon.Trainer('adam').step(1)``.
-    GRU cells (the reference's flag default), ``num_layers=2, num_bi_layers=1``.  ``grads`` / ``params`` are flat device
+    GRU (the reference's flag default) or LSTM cells, ``num_layers=2, num_bi_layers=1``.  ``grads`` / ``params`` are flat device
     views for a data-parallel all-reduce between ``forward_backward`` and ``step``."""
 
     def __init__(self, params: dict, input_size: int, hidden: int, embed: int, vocab: int, max_batch: int = 32,
-                 max_src_len: int = 256, max_tgt_len: int = 64, prefix: str = "gnmt_", ctx: _lib.Context | None = None):
+                 max_src_len: int = 256, max_tgt_len: int = 64, prefix: str = "gnmt_", ctx: _lib.Context | None = None,
+                 cell_type: str = "gru"):
+        if cell_type not in ("gru", "lstm"):
+            raise ValueError(f"cell_type must be 'gru' or 'lstm', got {cell_type!r}")
         self.ctx = ctx or _lib.default_context()
         self.lib = self.ctx.lib
         self.input_size, self.hidden, self.embed, self.vocab, self.prefix = input_size, hidden, embed, vocab, prefix
+        self.cell_type = cell_type
         self.names = [k for k in params if k.startswith(prefix)]
         self.shapes = {k: tuple(np.asarray(params[k]).shape) for k in self.names}
         arr, keep = _lib.make_params({k: params[k] for k in self.names})
         h = C.c_void_p()
-        check(self.lib.tn_gnmt_trainer_create(self.ctx.handle, arr, len(arr), prefix.encode(), input_size, hidden, embed, vocab,
+        check(self.lib.tn_gnmt_trainer_create(self.ctx.handle, arr, len(arr), prefix.encode(),
+                                              _lib.RNN_GRU if cell_type == "gru" else _lib.RNN_LSTM, input_size, hidden, embed, vocab,
                                               max_batch, max_src_len, max_tgt_len, C.byref(h)), "tn_gnmt_trainer_create")
         del keep
         self.handle = h

@@ -1,5 +1,5 @@
 """Host side of the captioner's training path — counterpart of reference train_gnmt.py::train (:305-470) for the
-GRU configuration it ships as default (``--cell_type gru --num_layers 2 --num_bi_layers 1``):
+configuration it ships as default (``--num_layers 2 --num_bi_layers 1``, ``--cell_type gru`` or ``lstm``):
 
     trainer = gluon.Trainer(model.collect_params(), 'adam', {'learning_rate': lr})                      :310
     for epoch: for batch in train loader (FixedBucketSampler over target lengths):                      :318
@@ -41,14 +41,14 @@ def train(data_train, data_val, data_test, model, translator, epochs: int, batch
           start_epoch: int = 0, save_dir: str | None = None, seed: int = 0, log=print):
     """-> history: one dict per epoch (train loss, valid / test loss and BLEU, learning rate)."""
     enc = model.encoder
-    if enc._cell_type != "gru" or enc._num_layers != 2 or enc._num_bi_layers != 1:
-        raise NotImplementedError("the training step is built for cell_type='gru', num_layers=2, num_bi_layers=1 "
-                                  "(the reference's flag defaults)")
+    if enc._cell_type not in ("gru", "lstm") or enc._num_layers != 2 or enc._num_bi_layers != 1:
+        raise NotImplementedError("the training step is built for num_layers=2, num_bi_layers=1 (the reference's flag defaults)")
     params = {k: v.data for k, v in model.collect_params().items()}
     max_t = max(l[0] for l in data_train.get_data_lens())
     max_l = max(l[-1] for l in data_train.get_data_lens())
     trainer = GNMTTrainer(params, model._input_size, enc._hidden_size, model._embed_size, len(model.tgt_vocab),
-                          max_batch=batch_size, max_src_len=max_t, max_tgt_len=max_l, prefix=model.prefix)
+                          max_batch=batch_size, max_src_len=max_t, max_tgt_len=max_l, prefix=model.prefix,
+                          cell_type=enc._cell_type)
     if dropout > 0:
         trainer.set_dropout(dropout, seed)
     val_tgt = data_val.get_captions(split=True) if data_val is not None else None

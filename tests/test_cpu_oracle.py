@@ -385,22 +385,23 @@ def test_oracle_reproduces_its_committed_fixtures():
     assert np.abs(dn.dense(feats, p, "framemodel0_dense0_") - d["logits"][:1]).max() < 1e-5
 
 
-def test_gnmt_train_oracle_forward_matches_numpy_oracle():
+@pytest.mark.parametrize("cell", ["gru", "lstm"])
+def test_gnmt_train_oracle_forward_matches_numpy_oracle(cell):
     """oracle/gnmt_train_torch.py (torch, for autograd) computes the same teacher-forced logits and loss as the numpy
     restatement oracle/gnmt_np.py it is written from; MXNet Adam's first step moves every weight by ~lr."""
     from oracle import gnmt_np as gn, gnmt_train_torch as gt
     from tennis_amd import weights as W
     B, T, F, H, E, V, L = 3, 9, 16, 8, 6, 14, 6
-    p = W.make_gnmt_weights(1, "gru", F, H, E, V)
+    p = W.make_gnmt_weights(1, cell, F, H, E, V)
     rng = np.random.default_rng(0)
     src = (np.abs(rng.normal(0, 1, (B, T, F))) * 0.5).astype(np.float32)
     vl = np.array([9, 5, 7], np.int32)
     tgt = rng.integers(4, V, (B, L)).astype(np.int32)
     tgt[:, 0] = 2
     tvl = np.array([6, 4, 5], np.int32)
-    loss, logits, g = gt.loss_and_grads(p, src, vl, tgt, tvl, H)
-    mem, states = gn.encoder(src, vl, p, "gru", H)
-    ref = gn.decode_seq(gn.Decoder(p, H, cell="gru"), mem, states, vl, tgt[:, :-1])
+    loss, logits, g = gt.loss_and_grads(p, src, vl, tgt, tvl, H, cell=cell)
+    mem, states = gn.encoder(src, vl, p, cell, H)
+    ref = gn.decode_seq(gn.Decoder(p, H, cell=cell), mem, states, vl, tgt[:, :-1])
     assert np.abs(logits - ref).max() < 1e-6
     rl = gn.masked_softmax_ce(ref, tgt[:, 1:], tvl - 1)
     assert abs(loss - float(rl.mean() * (L - 1) / np.mean(tvl - 1))) < 1e-5          # train_gnmt.py:332-333

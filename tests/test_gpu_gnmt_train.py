@@ -9,9 +9,9 @@ from oracle import gnmt_train_torch as gt
 pytestmark = pytest.mark.gpu
 
 
-def _case(seed, B, T, F, H, E, V, L):
+def _case(seed, B, T, F, H, E, V, L, cell="gru"):
     from tennis_amd import weights as W
-    p = W.make_gnmt_weights(seed, "gru", F, H, E, V)
+    p = W.make_gnmt_weights(seed, cell, F, H, E, V)
     rng = np.random.default_rng(seed)
     p["gnmt_tgt_embed_weight"] = rng.normal(0, 0.5, (V, E)).astype(np.float32)      # every row trainable, none zeroed
     src = (np.abs(rng.normal(0, 1, (B, T, F))) * 0.5).astype(np.float32)
@@ -29,14 +29,19 @@ def _case(seed, B, T, F, H, E, V, L):
 
 @pytest.mark.parametrize("cfg", [dict(seed=1, B=3, T=9, F=16, H=8, E=6, V=14, L=6),
                                  dict(seed=2, B=5, T=23, F=64, H=32, E=20, V=40, L=11),
-                                 dict(seed=3, B=4, T=40, F=128, H=128, E=100, V=254, L=9)])   # config-C5 widths
+                                 dict(seed=3, B=4, T=40, F=128, H=128, E=100, V=254, L=9),    # config-C5 widths
+                                 dict(seed=6, B=3, T=9, F=16, H=8, E=6, V=14, L=6, cell="lstm"),
+                                 dict(seed=7, B=5, T=23, F=64, H=32, E=20, V=40, L=11, cell="lstm"),
+                                 dict(seed=8, B=4, T=40, F=128, H=128, E=100, V=254, L=9, cell="lstm")])
 def test_loss_and_gradients_match_autograd(cfg, report):
     from tennis_amd.engine import GNMTTrainer
     p, src, svl, tgt, tvl = _case(**cfg)
-    tr = GNMTTrainer(p, cfg["F"], cfg["H"], cfg["E"], cfg["V"], max_batch=cfg["B"], max_src_len=cfg["T"], max_tgt_len=cfg["L"])
+    cell = cfg.get("cell", "gru")
+    tr = GNMTTrainer(p, cfg["F"], cfg["H"], cfg["E"], cfg["V"], max_batch=cfg["B"], max_src_len=cfg["T"], max_tgt_len=cfg["L"],
+                     cell_type=cell)
     loss, logits = tr.forward_backward(torch.from_numpy(src).cuda(), torch.from_numpy(svl).cuda(), torch.from_numpy(tgt).cuda(),
                                        torch.from_numpy(tvl).cuda(), return_logits=True)
-    rl, rlog, rg = gt.loss_and_grads(p, src, svl, tgt, tvl, cfg["H"])
+    rl, rlog, rg = gt.loss_and_grads(p, src, svl, tgt, tvl, cfg["H"], cell=cell)
     assert abs(float(loss) - rl) < 1e-4 * max(1.0, abs(rl)), (float(loss), rl)
     assert np.abs(logits.cpu().numpy() - rlog).max() < 1e-4
     worst = 0.0
@@ -45,21 +50,23 @@ def test_loss_and_gradients_match_autograd(cfg, report):
         err = np.abs(got - g).max() / max(1e-7, np.abs(g).max())
         worst = max(worst, err)
         assert err < 2e-3, (k, err, np.abs(g).max())
-    report[f"gnmt_train_grad_rel_err_H{cfg['H']}_T{cfg['T']}"] = float(worst)
+    report[f"gnmt_train_{cell}_grad_rel_err_H{cfg['H']}_T{cfg['T']}"] = float(worst)
 
 
-def test_adam_steps_follow_the_oracle_and_reduce_the_loss():
+@pytest.mark.parametrize("cell", ["gru", "lstm"])
+def test_adam_steps_follow_the_oracle_and_reduce_the_loss(cell):
     from tennis_amd.engine import GNMTTrainer
-    cfg = dict(seed=4, B=4, T=12, F=24, H=16, E=10, V=20, L=7)
+    cfg = dict(seed=4, B=4, T=12, F=24, H=16, E=10, V=20, L=7, cell=cell)
     p, src, svl, tgt, tvl = _case(**cfg)
-    tr = GNMTTrainer(p, cfg["F"], cfg["H"], cfg["E"], cfg["V"], max_batch=cfg["B"], max_src_len=cfg["T"], max_tgt_len=cfg["L"])
+    tr = GNMTTrainer(p, cfg["F"], cfg["H"], cfg["E"], cfg["V"], max_batch=cfg["B"], max_src_len=cfg["T"], max_tgt_len=cfg["L"],
+                     cell_type=cell)
     args = [torch.from_numpy(a).cuda() for a in (src, svl, tgt, tvl)]
     q = {k: v.astype(np.float64) for k, v in p.items()}
     m, v = {}, {}
     lr = 1e-3                                                   # train_gnmt.py flag default
     for step in range(1, 4):
         loss = tr.forward_backward(*args)
-        rl, _, rg = gt.loss_and_grads({k: a.astype(np.float32) for k, a in q.items()}, src, svl, tgt, tvl, cfg["H"])
+        rl, _, rg = gt.loss_and_grads({k: a.astype(np.float32) for k, a in q.items()}, src, svl, tgt, tvl, cfg["H"], cell=cell)
         assert abs(float(loss) - rl) < 2e-4 * max(1.0, abs(rl))
         tr.step(lr)
         q, m, v = gt.adam_step(q, rg, m, v, step, lr)
