@@ -163,6 +163,25 @@ int tn_head_sgd_step(tn_head *h, float lr, float momentum, float wd, float resca
 int tn_head_read_param(tn_head *h, const char *name, int gradient, float *out_host, int64_t capacity, int64_t *numel);
 int tn_head_destroy(tn_head *h);
 
+/* ---- fine-tuning step of the frame classifier (second half) ------ */
+/* FrameModel(DenseNet-121 .features, Dense(classes)) trained end to end as reference train.py does when the backbone is
+ * not frozen: BatchNorm in training mode (batch statistics; running statistics updated with momentum 0.9),
+ * SoftmaxCrossEntropyLoss per sample (train.py:324), backward of the summed losses (:419-421), SGD with momentum and
+ * weight decay, rescale_grad = 1/batch_size (:298-299,424).  fp32.  Parameters by their Gluon names (as
+ * tn_densenet121_create + the Dense).  x (batch, H, W, 3) fp32 normalised NHWC frames and labels (batch,) int32 are
+ * DEVICE buffers; batch must equal the handle's.  read_param returns Gluon-ordered weights / gradients, running
+ * statistics, or "<bn>_batch_mean" / "<bn>_batch_var" of the last step. */
+typedef struct tn_finetune tn_finetune;
+int tn_finetune_create(tn_ctx *ctx, const tn_param *params, int n_params, const char *backbone_prefix,
+                       const char *dense_prefix, int height, int width, int classes, int batch, tn_finetune **out);
+int tn_finetune_forward_backward(tn_finetune *f, const float *x, const int32_t *labels, int batch, float *loss,
+                                 float *logits);
+int tn_finetune_buffers(tn_finetune *f, float **params_dev, float **grads_dev, int64_t *numel);
+int tn_finetune_sgd_step(tn_finetune *f, float lr, float momentum, float wd, float rescale_grad);
+int tn_finetune_read_param(tn_finetune *f, const char *name, int gradient, float *out_host, int64_t capacity,
+                           int64_t *numel);
+int tn_finetune_destroy(tn_finetune *f);
+
 /* ---- captioner training step ---------------------------------- */
 /* One step of reference train_gnmt.py::train (:328-337) for GRU or LSTM cells (--cell_type), num_layers = 2,
  * num_bi_layers = 1:

@@ -67,6 +67,13 @@ _SIGS = {
     "tn_head_sgd_step": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float]),
     "tn_head_read_param": (C.c_int, [_P, C.c_char_p, C.c_int, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64)]),
     "tn_head_destroy": (C.c_int, [_P]),
+    "tn_finetune_create": (C.c_int, [_P, C.POINTER(TnParam), C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.POINTER(_P)]),
+    "tn_finetune_forward_backward": (C.c_int, [_P, _P, _P, C.c_int, _P, _P]),
+    "tn_finetune_buffers": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64)]),
+    "tn_finetune_sgd_step": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "tn_finetune_read_param": (C.c_int, [_P, C.c_char_p, C.c_int, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64)]),
+    "tn_finetune_destroy": (C.c_int, [_P]),
     "tn_gnmt_trainer_create": (C.c_int, [_P, C.POINTER(TnParam), C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "tn_gnmt_trainer_forward_backward": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),

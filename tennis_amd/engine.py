@@ -431,3 +431,71 @@ class GNMTTrainer:
                 self.handle = None
         except Exception:
             pass
+
+
+class FrameModelTrainer:
+    """End-to-end fine-tuning step of ``FrameModel(DenseNet121.features, classes)`` the way reference train.py drives it
+    with an un-frozen backbone: BatchNorm in training mode, ``SoftmaxCrossEntropyLoss`` per sample (:324), backward of the
+    summed losses (:419-421), ``gluon.Trainer('sgd', {lr, momentum, wd}).step(batch_size)`` (:298-299,424).  fp32.  The batch
+    size is fixed at construction (BatchNorm statistics are per batch)."""
+
+    def __init__(self, params: dict, size: int = 224, classes: int = 11, batch: int = 8, prefix: str = "densenet0_",
+                 dense_prefix: str = "framemodel0_dense0_", ctx: _lib.Context | None = None):
+        self.ctx = ctx or _lib.default_context()
+        self.lib = self.ctx.lib
+        self.size, self.classes, self.batch = size, classes, batch
+        self.names = [k for k in params if k.startswith(prefix) or k.startswith(dense_prefix)]
+        self.shapes = {k: tuple(np.asarray(params[k]).shape) for k in self.names}
+        arr, keep = _lib.make_params({k: params[k] for k in self.names})
+        h = C.c_void_p()
+        check(self.lib.tn_finetune_create(self.ctx.handle, arr, len(arr), prefix.encode(), dense_prefix.encode(), size, size, classes,
+                                          batch, C.byref(h)), "tn_finetune_create")
+        del keep
+        self.handle = h
+        pw, pg, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(self.lib.tn_finetune_buffers(h, C.byref(pw), C.byref(pg), C.byref(n)), "tn_finetune_buffers")
+        self.numel, self._pw, self._pg = n.value, pw.value, pg.value
+
+    def _view(self, addr):
+        class _Arr:
+            __cuda_array_interface__ = {"shape": (self.numel,), "typestr": "<f4", "data": (addr, False), "version": 3}
+        return torch.as_tensor(_Arr(), device=f"cuda:{self.ctx.device}")
+
+    @property
+    def grads(self) -> torch.Tensor:
+        return self._view(self._pg)
+
+    def forward_backward(self, x: torch.Tensor, labels: torch.Tensor):
+        """x: frames as NCHW fp32 (the reference layout) or NHWC fp32, normalised; labels (B,) -> (loss (B,), logits (B, classes))"""
+        if x.dim() == 4 and x.shape[1] == 3 and x.shape[3] != 3:
+            x = x.permute(0, 2, 3, 1)
+        x = x.contiguous().float()
+        b = x.shape[0]
+        labels = labels.to(device=x.device, dtype=torch.int32).contiguous()
+        loss = torch.empty((b,), dtype=torch.float32, device=x.device)
+        logits = torch.empty((b, self.classes), dtype=torch.float32, device=x.device)
+        check(self.lib.tn_finetune_forward_backward(self.handle, ptr(x), ptr(labels), b, ptr(loss), ptr(logits)),
+              "tn_finetune_forward_backward")
+        return loss, logits
+
+    def step(self, batch_size: int, lr: float, momentum: float = 0.9, wd: float = 1e-4):
+        check(self.lib.tn_finetune_sgd_step(self.handle, lr, momentum, wd, 1.0 / batch_size), "tn_finetune_sgd_step")
+
+    def get(self, name: str, gradient: bool = False, shape=None) -> np.ndarray:
+        shape = shape or self.shapes[name]
+        out = np.empty(int(np.prod(shape)), np.float32)
+        n = C.c_int64()
+        check(self.lib.tn_finetune_read_param(self.handle, name.encode(), 1 if gradient else 0,
+                                              out.ctypes.data_as(C.POINTER(C.c_float)), out.size, C.byref(n)), "tn_finetune_read_param")
+        return out[:n.value].reshape(shape).copy()
+
+    def state_dict(self) -> dict:
+        return {k: self.get(k) for k in self.names}
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.tn_finetune_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
