@@ -70,6 +70,21 @@ def c5t():
 s = timed(c5t, 10)
 out["C5_train_step"] = {"ms_per_clip_batch": round(s * 1e3, 2), "clips_per_s": round(B / s, 1),
                         "note": "teacher-forced forward (19 decoder steps) + backward through decoder, attention and both encoder layers + Adam, fp32"}
+# ---- end-to-end fine-tuning step of the frame classifier (fp32, training-mode BatchNorm) ---------------------------
+from tennis_amd.engine import FrameModelTrainer
+pf = W.make_densenet121_weights(0)
+pf.update(W.make_dense_weights(1, 11, 1024, "framemodel0_dense0_"))
+BF = 16
+ftr = FrameModelTrainer(pf, 224, 11, batch=BF)
+xf = torch.randn((BF, 224, 224, 3), device=dev)
+yf = torch.randint(0, 11, (BF,), dtype=torch.int32, device=dev)
+def ftstep():
+    ftr.forward_backward(xf, yf)
+    ftr.step(BF, 1e-3, 0.9, 1e-4)
+s = timed(ftstep, 5)
+out["finetune_step_b16"] = {"ms_per_batch": round(s * 1e3, 1), "frames_per_s": round(BF / s, 1), "tflops": round(3 * 5.666e9 * BF / s / 1e12, 2),
+                            "note": "correct-first path: every convolution an exact-f32 MFMA GEMM (3x3 via im2col), 3 x forward FLOPs counted"}
+del ftr
 # ---- input side: Resize(256) + CenterCrop(224) of 256 decoded 720p frames, resident in HBM ---------------------------
 from tennis_amd import transforms as TT
 tf = TT.Compose([TT.Resize(256), TT.CenterCrop(224), TT.ToTensor(), TT.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])

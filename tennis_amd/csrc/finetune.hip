@@ -81,56 +81,46 @@ __global__ void ft_col2im3_kernel(const float *__restrict__ dcol, int B, int H, 
 }
 
 // ---- BatchNorm (training mode) + ReLU ---------------------------------------------------------------------------------
-// batch mean and biased variance of columns [0,C) of x (row stride ld): 64 columns per workgroup, 16 row groups
+// batch mean and biased variance of columns [0,C) of x (row stride ld).  Grid (C/64, RS): 64 columns x one of RS row slices
+// per workgroup; one pass over the data with the column's first element as the shift (sums of (x - x0) and (x - x0)^2:
+// no cancellation worth speaking of since x0 lies inside the data), slices added in order by the finish kernel.
 __global__ __launch_bounds__(1024) void ft_bn_stats_kernel(const float *__restrict__ x, int ld, long M, int C,
-                                                           float *__restrict__ mean, float *__restrict__ var) {
-  __shared__ float part[16][64];
-  __shared__ float mu[64];
+                                                           float *__restrict__ part) {
+  __shared__ float p1[16][64], p2[16][64];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
-  float a = 0.f;
+  const long stride = 16L * gridDim.y;
+  float a1 = 0.f, a2 = 0.f;
   if (c < C) {
-    long r = rg;
-    for (; r + 15 * 16 < M; r += 256) {
+    const float x0 = x[c];
+    long r = (long)blockIdx.y * 16 + rg;
+    for (; r + 15 * stride < M; r += 16 * stride) {
       float v[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = x[(r + i * 16) * ld + c];
+      for (int i = 0; i < 16; ++i) v[i] = x[(r + i * stride) * ld + c] - x0;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) a += v[i];
+      for (int i = 0; i < 16; ++i) { a1 += v[i]; a2 = fmaf(v[i], v[i], a2); }
     }
-    for (; r < M; r += 16) a += x[r * ld + c];
+    for (; r < M; r += stride) { const float d = x[r * ld + c] - x0; a1 += d; a2 = fmaf(d, d, a2); }
   }
-  part[rg][cl] = a;
-  __syncthreads();
-  if (rg == 0) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s += part[i][cl];
-    mu[cl] = s / (float)M;
-  }
-  __syncthreads();
-  const float m = mu[cl];
-  a = 0.f;
-  if (c < C) {
-    long r = rg;
-    for (; r + 15 * 16 < M; r += 256) {
-      float v[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = x[(r + i * 16) * ld + c] - m;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) a = fmaf(v[i], v[i], a);
-    }
-    for (; r < M; r += 16) { const float d = x[r * ld + c] - m; a = fmaf(d, d, a); }
-  }
-  __syncthreads();
-  part[rg][cl] = a;
+  p1[rg][cl] = a1; p2[rg][cl] = a2;
   __syncthreads();
   if (rg == 0 && c < C) {
-    float s = 0.f;
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s += part[i][cl];
-    mean[c] = m;
-    var[c] = s / (float)M;
+    for (int i = 0; i < 16; ++i) { s1 += p1[i][cl]; s2 += p2[i][cl]; }
+    part[((long)blockIdx.y * 2 + 0) * C + c] = s1;
+    part[((long)blockIdx.y * 2 + 1) * C + c] = s2;
   }
+}
+__global__ void ft_bn_stats_finish_kernel(const float *__restrict__ part, int RS, int C, const float *__restrict__ x, long M,
+                                          float *__restrict__ mean, float *__restrict__ var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int z = 0; z < RS; ++z) { s1 += part[((long)z * 2 + 0) * C + c]; s2 += part[((long)z * 2 + 1) * C + c]; }
+  const float d = s1 / (float)M;
+  mean[c] = x[c] + d;
+  var[c] = fmaxf(s2 / (float)M - d * d, 0.f);
 }
 // y (M,C contiguous) = relu(gamma * (x - mean) / sqrt(var + eps) + beta)
 __global__ void ft_bn_relu_kernel(const float *__restrict__ x, int ld, long M, int C, const float *__restrict__ mean,
@@ -143,19 +133,34 @@ __global__ void ft_bn_relu_kernel(const float *__restrict__ x, int ld, long M, i
   const float v = gamma[c] * (x[r * ld + c] - mean[c]) * rsqrtf(var[c] + kEps) + beta[c];
   y[id] = v > 0.f ? v : 0.f;
 }
-// column sums the BN backward needs: s1 = sum g, s2 = sum g * xhat with g = dy * [bn output > 0]
+// column sums the BN backward needs: s1 = sum g, s2 = sum g * xhat with g = dy * [bn output > 0].  Grid (C/64, RS): 64
+// columns x one of RS row slices per workgroup (16 row groups inside), partial sums to part[(slice*2 + {0,1})*C + c];
+// ft_bn_bwd_finish_kernel adds the slices in order.
 __global__ __launch_bounds__(1024) void ft_bn_bwd_reduce_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                                 int ld, long M, int C, const float *__restrict__ mean,
                                                                 const float *__restrict__ var,
                                                                 const float *__restrict__ gamma,
-                                                                const float *__restrict__ beta, float *__restrict__ dgamma,
-                                                                float *__restrict__ dbeta) {
+                                                                const float *__restrict__ beta, float *__restrict__ part) {
   __shared__ float p1[16][64], p2[16][64];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  const long stride = 16L * gridDim.y;
   float a1 = 0.f, a2 = 0.f;
   if (c < C) {
     const float m = mean[c], is = rsqrtf(var[c] + kEps), ga = gamma[c], be = beta[c];
-    for (long r = rg; r < M; r += 16) {
+    long r = (long)blockIdx.y * 16 + rg;
+    for (; r + 7 * stride < M; r += 8 * stride) {
+      float xv[8], dv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { xv[i] = x[(r + i * stride) * ld + c]; dv[i] = dy[(r + i * stride) * C + c]; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float xh = (xv[i] - m) * is;
+        const float g = ga * xh + be > 0.f ? dv[i] : 0.f;
+        a1 += g;
+        a2 = fmaf(g, xh, a2);
+      }
+    }
+    for (; r < M; r += stride) {
       const float xh = (x[r * ld + c] - m) * is;
       const float g = ga * xh + be > 0.f ? dy[r * C + c] : 0.f;
       a1 += g;
@@ -168,9 +173,18 @@ __global__ __launch_bounds__(1024) void ft_bn_bwd_reduce_kernel(const float *__r
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { s1 += p1[i][cl]; s2 += p2[i][cl]; }
-    dbeta[c] = s1;
-    dgamma[c] = s2;
+    part[((long)blockIdx.y * 2 + 0) * C + c] = s1;
+    part[((long)blockIdx.y * 2 + 1) * C + c] = s2;
   }
+}
+__global__ void ft_bn_bwd_finish_kernel(const float *__restrict__ part, int RS, int C, float *__restrict__ dgamma,
+                                        float *__restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int z = 0; z < RS; ++z) { s1 += part[((long)z * 2 + 0) * C + c]; s2 += part[((long)z * 2 + 1) * C + c]; }
+  dbeta[c] = s1;
+  dgamma[c] = s2;
 }
 // dx = gamma / sqrt(var + eps) * (g - dbeta / M - xhat * dgamma / M); assigned or accumulated into dx (row stride ldd)
 __global__ void ft_bn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x, int ld, long M, int C,
@@ -314,12 +328,22 @@ struct tn_finetune {
   // activations kept for backward
   float *x_in, *col7, *z0, *a0, *X[4], *dX[4], *feat, *logits, *loss, *dlog, *dfeat;
   // temporaries
-  float *ta, *tb, *col, *dcol, *tg, *tw, *dgam, *dbet;
+  float *ta, *tb, *col, *dcol, *tg, *tw, *ws;      // ws: split-K partial results / BatchNorm reduction slices
+  long ws_floats;
   int32_t *labels;
 };
 
+static int ft_slices(long M, int C) {
+  const int cb = (C + 63) / 64;
+  int RS = (int)((M + 2047) / 2048);                 // >= 2048 rows per slice, <= 512 workgroups
+  if (RS > 512 / cb) RS = 512 / cb;
+  return RS < 1 ? 1 : RS;
+}
 static void ft_bn_forward(tn_finetune *f, const FtBn &bn, const float *x, int ld, long M, float *y, hipStream_t s) {
-  hipLaunchKernelGGL(ft_bn_stats_kernel, dim3((bn.C + 63) / 64), dim3(1024), 0, s, x, ld, M, bn.C, bn.mean, bn.var);
+  const int RS = ft_slices(M, bn.C);
+  hipLaunchKernelGGL(ft_bn_stats_kernel, dim3((bn.C + 63) / 64, RS), dim3(1024), 0, s, x, ld, M, bn.C, f->ws);
+  hipLaunchKernelGGL(ft_bn_stats_finish_kernel, dim3((bn.C + 255) / 256), dim3(256), 0, s, (const float *)f->ws, RS, bn.C, x, M, bn.mean,
+                     bn.var);
   hipLaunchKernelGGL(ft_bn_relu_kernel, dim3(nblk(M * bn.C)), dim3(256), 0, s, x, ld, M, bn.C, (const float *)bn.mean,
                      (const float *)bn.var, (const float *)(f->w + bn.o_gamma), (const float *)(f->w + bn.o_beta), y);
 }
@@ -330,8 +354,10 @@ static void ft_bn_recompute(tn_finetune *f, const FtBn &bn, const float *x, int 
 // dy (M,C) contiguous -> gradients of gamma / beta into f->g and dx (stride ldd), assigned or accumulated
 static void ft_bn_backward(tn_finetune *f, const FtBn &bn, const float *dy, const float *x, int ld, long M, float *dx, int ldd,
                            int accumulate, hipStream_t s) {
-  hipLaunchKernelGGL(ft_bn_bwd_reduce_kernel, dim3((bn.C + 63) / 64), dim3(1024), 0, s, dy, x, ld, M, bn.C, (const float *)bn.mean,
-                     (const float *)bn.var, (const float *)(f->w + bn.o_gamma), (const float *)(f->w + bn.o_beta),
+  const int cb = (bn.C + 63) / 64, RS = ft_slices(M, bn.C);
+  hipLaunchKernelGGL(ft_bn_bwd_reduce_kernel, dim3(cb, RS), dim3(1024), 0, s, dy, x, ld, M, bn.C, (const float *)bn.mean,
+                     (const float *)bn.var, (const float *)(f->w + bn.o_gamma), (const float *)(f->w + bn.o_beta), f->ws);
+  hipLaunchKernelGGL(ft_bn_bwd_finish_kernel, dim3((bn.C + 255) / 256), dim3(256), 0, s, (const float *)f->ws, RS, bn.C,
                      f->g + bn.o_gamma, f->g + bn.o_beta);
   hipLaunchKernelGGL(ft_bn_bwd_apply_kernel, dim3(nblk(M * bn.C)), dim3(256), 0, s, dy, x, ld, M, bn.C, (const float *)bn.mean,
                      (const float *)bn.var, (const float *)(f->w + bn.o_gamma), (const float *)(f->w + bn.o_beta),
@@ -454,6 +480,7 @@ extern "C" int tn_finetune_create(tn_ctx *ctx, const tn_param *params, int n_par
   const long Mb0 = B * f->Hb[0] * f->Hb[0];
   f->ta = P.fl(maxMK); f->tb = P.fl(maxMK > maxM128 ? maxMK : maxM128); f->col = P.fl(Mb0 * 1152); f->dcol = P.fl(Mb0 * 1152);
   f->tg = P.fl(maxMK); f->tw = P.fl(1024L * 1024);
+  f->ws_floats = 16L << 20; f->ws = P.fl(f->ws_floats);
   f->feat = P.fl(B * c); f->dfeat = P.fl(B * c); f->logits = P.fl(B * classes); f->loss = P.fl(B); f->dlog = P.fl(B * classes);
   {
     void *lp = nullptr;
@@ -535,14 +562,14 @@ extern "C" int tn_finetune_forward_backward(tn_finetune *f, const float *x, cons
       // 3x3: dW3 = dy^T col ; dcol = dy W3 ; col2im
       ft_bn_recompute(f, L.bn2, L.z1, 128, M, f->tb, s);
       hipLaunchKernelGGL(ft_im2col3_kernel, dim3(nblk(M * 9 * 32)), dim3(256), 0, s, (const float *)f->tb, B, Hh, Hh, 128, f->col);
-      TN_TRY(launch_gemm_tn_f32(dy, Ct, f->col, 1152, g + L.o_w3, 1152, 32, 1152, (int)M, s));
+      TN_TRY(launch_gemm_tn_f32(dy, Ct, f->col, 1152, g + L.o_w3, 1152, 32, 1152, (int)M, s, f->ws, f->ws_floats));
       TN_TRY(launch_transpose_f32(w + L.o_w3, 32, 1152, f->tw, s));                      // (1152, 32)
       TN_TRY(launch_linear_f32(dy, Ct, f->tw, 32, nullptr, f->dcol, 1152, (int)M, 1152, 32, 0, s));
       hipLaunchKernelGGL(ft_col2im3_kernel, dim3(nblk(M * 32)), dim3(256), 0, s, (const float *)f->dcol, B, Hh, Hh, 128, f->tg);
       ft_bn_backward(f, L.bn2, f->tg, L.z1, 128, M, f->tb, 128, 0, s);                  // tb = d z1
       // 1x1: dW1 = dz1^T a ; da = dz1 W1
       ft_bn_recompute(f, L.bn1, f->X[b], Ct, M, f->ta, s);
-      TN_TRY(launch_gemm_tn_f32(f->tb, 128, f->ta, L.K, g + L.o_w1, L.K, 128, L.K, (int)M, s));
+      TN_TRY(launch_gemm_tn_f32(f->tb, 128, f->ta, L.K, g + L.o_w1, L.K, 128, L.K, (int)M, s, f->ws, f->ws_floats));
       TN_TRY(launch_transpose_f32(w + L.o_w1, 128, L.K, f->tw, s));                     // (K, 128)
       TN_TRY(launch_linear_f32(f->tb, 128, f->tw, 128, nullptr, f->tg, L.K, (int)M, L.K, 128, 0, s));
       ft_bn_backward(f, L.bn1, f->tg, f->X[b], Ct, M, f->dX[b], Ct, 1, s);               // accumulate into channels [0, K)
@@ -553,7 +580,7 @@ extern "C" int tn_finetune_forward_backward(tn_finetune *f, const float *x, cons
       const long Mp = (long)B * Hp * Hp;
       hipLaunchKernelGGL(ft_avgpool2_bwd_kernel, dim3(nblk(Mp * T.Cout)), dim3(256), 0, s, (const float *)f->dX[b], Ct, B, Hp, Hp, T.Cout, f->tb);
       ft_bn_recompute(f, T.bn, f->X[b - 1], Cp, Mp, f->ta, s);
-      TN_TRY(launch_gemm_tn_f32(f->tb, T.Cout, f->ta, T.Cin, g + T.o_w, T.Cin, T.Cout, T.Cin, (int)Mp, s));
+      TN_TRY(launch_gemm_tn_f32(f->tb, T.Cout, f->ta, T.Cin, g + T.o_w, T.Cin, T.Cout, T.Cin, (int)Mp, s, f->ws, f->ws_floats));
       TN_TRY(launch_transpose_f32(w + T.o_w, T.Cout, T.Cin, f->tw, s));                  // (Cin, Cout)
       TN_TRY(launch_linear_f32(f->tb, T.Cout, f->tw, T.Cout, nullptr, f->tg, T.Cin, (int)Mp, T.Cin, T.Cout, 0, s));
       ft_bn_backward(f, T.bn, f->tg, f->X[b - 1], Cp, Mp, f->dX[b - 1], Cp, 0, s);
@@ -563,7 +590,7 @@ extern "C" int tn_finetune_forward_backward(tn_finetune *f, const float *x, cons
       hipLaunchKernelGGL(ft_maxpool_bwd_kernel, dim3(nblk(M0 * 64)), dim3(256), 0, s, (const float *)f->a0, (const float *)f->dX[0], Ct, B, H / 2,
                          W / 2, 64, f->tg);
       ft_bn_backward(f, f->bn0, f->tg, f->z0, 64, M0, f->tb, 64, 0, s);
-      TN_TRY(launch_gemm_tn_f32(f->tb, 64, f->col7, 147, g + f->o_w0, 147, 64, 147, (int)M0, s));
+      TN_TRY(launch_gemm_tn_f32(f->tb, 64, f->col7, 147, g + f->o_w0, 147, 64, 147, (int)M0, s, f->ws, f->ws_floats));
     }
   }
   // ---------------- BatchNorm running statistics ----------------

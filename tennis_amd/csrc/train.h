@@ -16,7 +16,7 @@ int launch_lstm_train_bwd(const float *seq, const float *gates, const float *dse
                           float *hprev, int B, int T, int H, hipStream_t s, int dirs = 2,
                           const int32_t *valid_len = nullptr, const float *dh_last = nullptr, const float *dc_last = nullptr);
 int launch_gemm_tn_f32(const float *A, int lda, const float *Bm, int ldb, float *Cm, int ldc, int M, int N, int K,
-                       hipStream_t s);
+                       hipStream_t s, float *workspace = nullptr, long workspace_floats = 0);   // workspace: enables split-K
 int launch_colsum_f32(const float *A, int lda, int rows, int cols, float *out, hipStream_t s);
 int launch_sgd_momentum(float *w, const float *g, float *mom, long n, float lr, float momentum, float wd,
                         float rescale, hipStream_t s);

@@ -310,7 +310,12 @@ __global__ __launch_bounds__(MAXT) void lstm_train_bwd_kernel(const float *__res
 constexpr int kTnPD = 4;
 __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const float *__restrict__ A, int lda,
                                                           const float *__restrict__ Bm, int ldb,
-                                                          float *__restrict__ Cm, int ldc, int M, int N, int K) {
+                                                          float *__restrict__ Cm, int ldc, int M, int N, int K, int kchunk) {
+  // split-K: slice blockIdx.z covers rows [z*kchunk, (z+1)*kchunk) and writes its own (M, N) partial result
+  A += (long)blockIdx.z * kchunk * lda;
+  Bm += (long)blockIdx.z * kchunk * ldb;
+  Cm += (long)blockIdx.z * M * ldc;
+  K = min(kchunk, K - (int)blockIdx.z * kchunk);
   __shared__ float As[2][16][64 + 4], Bs[2][16][64 + 4];
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6, wm = wid >> 1, wn = wid & 1;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
@@ -382,6 +387,15 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const float *__restric
         if (m < M) Cm[(long)m * ldc + n] = acc[i][q][r];
       }
     }
+}
+
+// sum of S (M, N) partial results (row stride N) into C (row stride ldc), slices added in order
+__global__ void splitk_reduce_kernel(const float *__restrict__ ws, int S, int M, int N, float *__restrict__ Cm, int ldc) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)M * N) return;
+  float a = 0.f;
+  for (int z = 0; z < S; ++z) a += ws[(long)z * M * N + id];
+  Cm[(id / N) * ldc + id % N] = a;
 }
 
 // column sums of A [rows][lda] (the bias gradients): 64 columns per workgroup, 16 row groups, 16 loads in flight,
@@ -482,9 +496,26 @@ int launch_lstm_train_bwd(const float *seq, const float *gates, const float *dse
   TN_LAUNCH_CHECK();
 }
 int launch_gemm_tn_f32(const float *A, int lda, const float *Bm, int ldb, float *Cm, int ldc, int M, int N, int K,
-                       hipStream_t s) {
-  hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, s, A, lda, Bm, ldb, Cm, ldc,
-                     M, N, K);
+                       hipStream_t s, float *workspace, long workspace_floats) {
+  const int tiles = ((N + 63) / 64) * ((M + 63) / 64);
+  // few output tiles and a long reduction (weight gradients over all pixels): split K over workgroups, partial results
+  // in the caller's workspace, summed in slice order (deterministic)
+  int S = 1;
+  if (workspace && tiles < 256 && K >= 2048) {
+    S = (512 + tiles - 1) / tiles;
+    if (S > K / 512) S = K / 512;
+    while (S > 1 && (long)S * M * N > workspace_floats) --S;
+  }
+  if (S <= 1) {
+    hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64, 1), dim3(256), 0, s, A, lda, Bm, ldb, Cm, ldc,
+                       M, N, K, K);
+    TN_LAUNCH_CHECK();
+  }
+  const int kchunk = (((K + S - 1) / S) + 15) / 16 * 16;
+  S = (K + kchunk - 1) / kchunk;
+  hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64, S), dim3(256), 0, s, A, lda, Bm, ldb, workspace, N,
+                     M, N, K, kchunk);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(((long)M * N + 255) / 256), dim3(256), 0, s, (const float *)workspace, S, M, N, Cm, ldc);
   TN_LAUNCH_CHECK();
 }
 int launch_colsum_f32(const float *A, int lda, int rows, int cols, float *out, hipStream_t s) {

@@ -1,7 +1,10 @@
 """Host side of the temporal-head training path — counterparts of reference train.py:
 ``gluon.Trainer(params, 'sgd', {...})`` (:298-299), ``gluon.loss.SoftmaxCrossEntropyLoss`` (:324) and
-``train_model`` (:388-499) for ``CNNRNN(model=None, type='gru')`` on pre-extracted features (the frozen-backbone
-recipe, e.g. model 0042 of models/README.md:57-59).  All arithmetic runs in libtennis_hip (tn_head_*); torch is the
+``train_model`` (:388-499) for ``CNNRNN(model=None, type='gru'|'lstm')`` on pre-extracted features (the frozen-backbone
+recipe, e.g. model 0042 of models/README.md:57-59; ``engine.TemporalHeadTrainer``) and for the end-to-end frame classifier
+``FrameModel(DenseNet121.features, classes)`` with BatchNorm in training mode (model 0006; ``engine.FrameModelTrainer``) — both
+expose ``forward_backward(x, labels) -> (loss, logits)``, ``step(batch_size, lr, momentum, wd)``, ``grads`` and ``state_dict()``.
+All arithmetic runs in libtennis_hip (tn_head_* / tn_finetune_*); torch is the
 buffer / collective plumbing: with ``torch.distributed`` initialised (backend nccl = RCCL) every rank trains on its
 shard of the batch and the flat gradient buffer is all-reduced before the update.
 """

@@ -94,3 +94,28 @@ def test_gnmt_trainer_errors():
     with pytest.raises(RuntimeError, match="wrong size"):
         GNMTTrainer(W.make_gnmt_weights(0, "lstm", 16, 8, 6, 12), 16, 8, 6, 12)   # 4-gate weights into the GRU trainer
     assert lib.tn_gnmt_trainer_destroy(None) == 0
+
+
+def test_finetune_errors():
+    import ctypes as C
+    from tennis_amd import _lib, weights as W
+    from tennis_amd.engine import FrameModelTrainer
+    p = W.make_densenet121_weights(0)
+    p.update(W.make_dense_weights(1, 11, 1024, "framemodel0_dense0_"))
+    with pytest.raises(RuntimeError, match="divisible by 32"):
+        FrameModelTrainer(p, 200, 11, batch=2)
+    tr = FrameModelTrainer(p, 64, 11, batch=2)                    # any side divisible by 32 works
+    x = torch.zeros((3, 64, 64, 3), device="cuda")
+    with pytest.raises(RuntimeError, match="batch must equal"):
+        tr.forward_backward(x, torch.zeros(3, dtype=torch.int32, device="cuda"))
+    loss, logits = tr.forward_backward(torch.randn((2, 64, 64, 3), device="cuda"), torch.tensor([1, 5], dtype=torch.int32, device="cuda"))
+    assert bool(torch.isfinite(loss).all()) and logits.shape == (2, 11)
+    lib = _lib.load()
+    n, buf = C.c_int64(), (C.c_float * 4)()
+    assert lib.tn_finetune_read_param(tr.handle, b"densenet0_nope", 0, buf, 4, C.byref(n)) != 0
+    assert b"unknown parameter" in lib.tn_last_error()
+    q = dict(p)
+    del q["densenet0_stage2_batchnorm5_running_var"]
+    with pytest.raises(RuntimeError, match="stage2_batchnorm5_running_var"):
+        FrameModelTrainer(q, 64, 11, batch=2)
+    assert lib.tn_finetune_destroy(None) == 0

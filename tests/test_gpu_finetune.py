@@ -102,3 +102,33 @@ def test_sgd_steps_reduce_the_loss():
         loss, _ = tr.forward_backward(xd, yd)
         tr.step(B, 0.01, 0.9, 1e-4)
     assert float(loss.mean()) < 0.7 * first and bool(torch.isfinite(tr.grads).all())
+
+
+def test_train_model_driver_with_the_frame_classifier(tmp_path):
+    """tennis_amd.train.train_model (reference train.py:388-499) drives the end-to-end classifier exactly as it drives the
+    temporal head: LR schedule, metric updates, per-epoch parameter files that load back into a FrameModel."""
+    from tennis_amd.engine import FrameModelTrainer
+    from tennis_amd.metrics.vision import PRF1
+    from tennis_amd.model_zoo import get_model
+    from tennis_amd.models.vision.definitions import FrameModel
+    from tennis_amd.train import Trainer, train_model
+    B = 4
+    p, x, y = _setup(B, seed=11)
+    head = FrameModelTrainer(p, 224, 11, batch=B)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    tr = Trainer(head, "sgd", {"learning_rate": 0.01, "momentum": 0.9, "wd": 1e-4})
+    metric = PRF1(label_names=[str(i) for i in range(11)])
+    hist = train_model(head, lambda: [(xd, yd)] * 3, [metric], tr, epochs=3, batch_size=B, lr_steps=(1, 2), lr_factor=0.75,
+                       save_dir=str(tmp_path), log=lambda *_: None)
+    assert len(hist) == 3 and hist[-1]["loss"] < hist[0]["loss"] and abs(hist[-1]["lr"] - 0.01 * 0.75 ** 2) < 1e-9
+    fm = FrameModel(get_model("DenseNet121", pretrained=True, seed=3).features, 11, prefix="framemodel0_")
+    fm.initialize()
+    fm.classes._materialize(1024)
+    fm.load_parameters(str(tmp_path / "0002.params"))
+    st = head.state_dict()
+    for k in ("densenet0_stage3_conv7_weight", "densenet0_batchnorm2_running_var", "framemodel0_dense0_bias"):
+        got = fm.collect_params()[k].data
+        ref = st[k].astype(np.float16).astype(np.float32) if k.endswith("conv7_weight") else st[k]   # the served model rounds conv weights to fp16
+        assert np.allclose(got, ref, atol=1e-6), k
+    logits = fm(xd).cpu().numpy()                            # inference with the running statistics just trained
+    assert logits.shape == (B, 11) and np.isfinite(logits).all()
