@@ -87,3 +87,67 @@ def train(data_train, data_val, data_test, model, translator, epochs: int, batch
             model.save_parameters(os.path.join(save_dir, "{:04d}.params".format(epoch_id)), structural=False)
         history.append(rec)
     return history
+
+
+def build_parser():
+    import argparse
+    p = argparse.ArgumentParser(description="tennis_amd train_gnmt (flags of reference train_gnmt.py:48-118)")
+    p.add_argument("--model_id", default="0000")
+    p.add_argument("--epochs", type=int, default=40)
+    p.add_argument("--num_hidden", type=int, default=128)
+    p.add_argument("--emb_size", type=int, default=100)
+    p.add_argument("--dropout", type=float, default=0.2)
+    p.add_argument("--num_layers", type=int, default=2)
+    p.add_argument("--num_bi_layers", type=int, default=1)
+    p.add_argument("--cell_type", default="gru")
+    p.add_argument("--batch_size", type=int, default=128)
+    p.add_argument("--beam_size", type=int, default=4)
+    p.add_argument("--lp_alpha", type=float, default=1.0)
+    p.add_argument("--lp_k", type=int, default=5)
+    p.add_argument("--test_batch_size", type=int, default=32)
+    p.add_argument("--num_buckets", type=int, default=5)
+    p.add_argument("--tgt_max_len", type=int, default=50)
+    p.add_argument("--lr", type=float, default=1e-3)
+    p.add_argument("--lr_update_factor", type=float, default=0.5)
+    p.add_argument("--every", type=int, default=1)
+    p.add_argument("--feature_dim", type=int, default=1024, help="width of the pre-extracted frame features (feats_model)")
+    p.add_argument("--n_points", type=int, default=64, help="synthetic source: points per split")
+    p.add_argument("--root", default="models/captioning/experiments")
+    return p
+
+
+def build(flags):
+    """Datasets, model and translator as reference train_gnmt.py:120-256 assembles them (feature mode)."""
+    from .captions import CaptionSet
+    from .models.captioning.gnmt import NMTModel, get_gnmt_encoder_decoder
+    from .utils.translation import BeamSearchScorer, BeamSearchTranslator
+    data_train = CaptionSet(split="train", every=flags.every, max_cap_len=flags.tgt_max_len, n_points=flags.n_points,
+                            feature_dim=flags.feature_dim)
+    data_val = CaptionSet(split="val", every=flags.every, vocab=data_train.vocab, inference=True,
+                          n_points=max(4, flags.n_points // 4), feature_dim=flags.feature_dim)
+    data_test = CaptionSet(split="test", every=flags.every, vocab=data_train.vocab, inference=True,
+                           n_points=max(4, flags.n_points // 4), feature_dim=flags.feature_dim)
+    enc, dec = get_gnmt_encoder_decoder(cell_type=flags.cell_type, hidden_size=flags.num_hidden, dropout=flags.dropout,
+                                        num_layers=flags.num_layers, num_bi_layers=flags.num_bi_layers)
+    model = NMTModel(src_vocab=None, tgt_vocab=data_train.vocab, encoder=enc, decoder=dec, embed_size=flags.emb_size,
+                     prefix="gnmt_", input_size=flags.feature_dim)
+    model.initialize()
+    translator = BeamSearchTranslator(model=model, beam_size=flags.beam_size,
+                                      scorer=BeamSearchScorer(alpha=flags.lp_alpha, K=flags.lp_k),
+                                      max_length=flags.tgt_max_len + 100)                     # train_gnmt.py:250-252
+    return data_train, data_val, data_test, model, translator
+
+
+def main(argv=None):
+    flags = build_parser().parse_args(argv)
+    data_train, data_val, data_test, model, translator = build(flags)
+    save_dir = os.path.join(flags.root, flags.model_id)
+    hist = train(data_train, data_val, data_test, model, translator, flags.epochs, flags.batch_size, lr=flags.lr,
+                 lr_update_factor=flags.lr_update_factor, dropout=flags.dropout, num_buckets=flags.num_buckets,
+                 test_batch_size=flags.test_batch_size, save_dir=save_dir)
+    print("[Finished] best valid bleu={:.2f}".format(100 * max(h.get("valid_bleu", 0.0) for h in hist)))
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

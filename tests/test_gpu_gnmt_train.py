@@ -135,3 +135,17 @@ def test_train_driver(tmp_path):
     m2.load_parameters(str(tmp_path / "0008.params"))
     a, b = model.collect_params(), m2.collect_params()
     assert all(np.array_equal(a[k].data, b[k].data) for k in a)
+
+
+def test_train_and_evaluate_mains(tmp_path, capsys):
+    """python -m tennis_amd.train_gnmt / evaluate_gnmt with the reference's flag names: train two epochs, then the
+    evaluation driver loads valid_best / the newest epoch file and reports loss and BLEU for both splits."""
+    from tennis_amd import evaluate_gnmt, train_gnmt
+    args = ["--model_id", "t001", "--root", str(tmp_path), "--epochs", "2", "--num_hidden", "16", "--emb_size", "8", "--batch_size", "8",
+            "--n_points", "16", "--feature_dim", "32", "--tgt_max_len", "12", "--beam_size", "3", "--dropout", "0.1", "--test_batch_size", "4"]
+    assert train_gnmt.main(args) == 0
+    assert (tmp_path / "t001" / "0001.params").exists()
+    out = evaluate_gnmt.main(args)
+    assert set(out) == {"valid", "test"} and all(np.isfinite(v[0]) and 0.0 <= v[1] <= 1.0 for v in out.values())
+    assert (tmp_path / "t001" / "best_test_out.txt").exists()
+    assert "Best model valid Loss" in capsys.readouterr().out
