@@ -281,17 +281,24 @@ class DataLoader:
     """``gluon.data.DataLoader(dataset, batch_size, shuffle=False)`` stand-in: yields
     (data, labels, idxs) numpy batches in order, last batch kept (evaluate.py:113)."""
 
-    def __init__(self, dataset, batch_size, shuffle=False, num_workers=0, last_batch="keep"):
-        assert not shuffle, "the accelerated inference path is deterministic and un-shuffled"
-        self.dataset, self.batch_size = dataset, batch_size
+    def __init__(self, dataset, batch_size, shuffle=False, num_workers=0, last_batch="keep", seed=0):
+        """``shuffle=True`` (training, train.py:189): a fresh seeded permutation per epoch; ``last_batch='discard'`` drops a
+        ragged final batch (the fine-tuning step needs a fixed batch for its BatchNorm statistics)."""
+        self.dataset, self.batch_size, self.shuffle, self.last_batch = dataset, batch_size, shuffle, last_batch
+        self._rng = np.random.default_rng(seed)
 
     def __len__(self):
-        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+        n = len(self.dataset)
+        return n // self.batch_size if self.last_batch == "discard" else (n + self.batch_size - 1) // self.batch_size
 
     def __iter__(self):
         n = len(self.dataset)
+        order = self._rng.permutation(n) if self.shuffle else np.arange(n)
         for s in range(0, n, self.batch_size):
-            items = [self.dataset[i] for i in range(s, min(n, s + self.batch_size))]
+            ids = order[s:s + self.batch_size]
+            if self.last_batch == "discard" and len(ids) < self.batch_size:
+                break
+            items = [self.dataset[int(i)] for i in ids]
             tf = getattr(self.dataset, "_transform", None)
             if getattr(tf, "device_batched", False) and not self.dataset._load_feats:
                 data = tf(np.stack([it[0] for it in items]))               # one Resize+CenterCrop launch per batch

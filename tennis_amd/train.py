@@ -79,3 +79,104 @@ def train_model(head: TemporalHeadTrainer, train_batches, metrics, trainer: Trai
             with open(os.path.join(save_dir, "{:04d}.params".format(epoch)), "wb") as f:
                 np.savez(f, **head.state_dict())
     return history
+
+
+def build_parser():
+    import argparse
+    p = argparse.ArgumentParser(description="tennis_amd train (flags of reference train.py:30-95)")
+    p.add_argument("--backbone", default="DenseNet121")
+    p.add_argument("--freeze_backbone", action="store_true")
+    p.add_argument("--model_id", default="0000")
+    p.add_argument("--split_id", default="02")
+    p.add_argument("--data_shape", type=int, default=224)
+    p.add_argument("--every", default="1, 1, 1")
+    p.add_argument("--balance", default="True, False, False")
+    p.add_argument("--window", type=int, default=1)
+    p.add_argument("--padding", type=int, default=1)
+    p.add_argument("--stride", type=int, default=1)
+    p.add_argument("--batch_size", type=int, default=64)
+    p.add_argument("--epochs", type=int, default=20)
+    p.add_argument("--lr", type=float, default=0.001)
+    p.add_argument("--lr_factor", type=float, default=0.75)
+    p.add_argument("--lr_steps", default="10, 20")
+    p.add_argument("--momentum", type=float, default=0.9)
+    p.add_argument("--wd", type=float, default=0.0001)
+    p.add_argument("--feats_model", default=None)
+    p.add_argument("--temp_pool", default=None, help="gru or lstm (trained); mean / max need no training")
+    p.add_argument("--root", default="data")
+    p.add_argument("--frames_per_video", type=int, default=16)
+    p.add_argument("--exp_root", default=os.path.join("models", "vision", "experiments"))
+    return p
+
+
+def main(argv=None):
+    """reference train.py::main (:98-386) for the two trainable configurations on the hot path:
+      * ``--feats_model <id> --window W --temp_pool gru|lstm``: the temporal head on pre-extracted features (backbone frozen);
+      * ``--window 1`` without ``--feats_model``: the frame classifier end to end (BatchNorm in training mode).
+    Frames go through the TEST transform: the reference's train-time augmentation (RandomResizedCrop, flips, colour jitter,
+    lighting; train.py:127-136) is host-side image processing outside this path and is not mirrored."""
+    from .dataset import DataLoader, TennisSet
+    from .engine import FrameModelTrainer, TemporalHeadTrainer
+    from .evaluate import evaluate_model
+    from .metrics.vision import PRF1
+    from .model_zoo import get_model
+    from .models.vision.definitions import CNNRNN, FrameModel
+    from . import weights as W
+    flags = build_parser().parse_args(argv)
+    every = [int(s) for s in flags.every.split(",")]
+    balance = [s.strip().lower() in ("true", "t") for s in flags.balance.split(",")]
+    lr_steps = [int(s) for s in flags.lr_steps.split(",")]
+    mk = lambda split, ev, bal: TennisSet(root=flags.root, split=split, every=ev, padding=flags.padding, stride=flags.stride,
+                                          window=flags.window, model_id=flags.model_id, split_id=flags.split_id, balance=bal,
+                                          feats_model=flags.feats_model, data_shape=flags.data_shape,
+                                          frames_per_video=flags.frames_per_video)
+    train_set, val_set = mk("train", every[0], balance[0]), mk("val", every[1], balance[1])
+    n_cls = len(train_set.classes)
+    save_dir = os.path.join(flags.exp_root, flags.model_id)
+    if flags.feats_model is not None:
+        if flags.window <= 1 or flags.temp_pool not in ("gru", "lstm"):
+            raise SystemExit("training on features needs --window > 1 and --temp_pool gru|lstm (definitions.py:94-96)")
+        feat_dim = int(np.asarray(train_set[0][0]).shape[-1])
+        model = CNNRNN(None, num_classes=n_cls, type=flags.temp_pool, hidden_size=128)
+        model.rnn._materialize(feat_dim)
+        model.classes._materialize(256)
+        params = {k: v.data for k, v in model.collect_params().items()}
+        head = TemporalHeadTrainer(params, feat_dim, 128, n_cls, max_batch=flags.batch_size, max_steps=flags.window,
+                                   rnn_prefix=model.rnn.prefix, dense_prefix=model.classes.prefix, type=flags.temp_pool)
+        last = "keep"
+    else:
+        if flags.window != 1 or flags.freeze_backbone:
+            raise SystemExit("end-to-end training is built for --window 1 with a trainable backbone; a frozen backbone "
+                             "trains on features (--feats_model after evaluate --save_feats)")
+        model = FrameModel(get_model(flags.backbone, pretrained=True).features, n_cls)
+        model.initialize()
+        model.classes._materialize(1024)
+        params = {k: v.data for k, v in model.collect_params().items()}
+        head = FrameModelTrainer(params, flags.data_shape, n_cls, batch=flags.batch_size, prefix=model.backbone.prefix,
+                                 dense_prefix=model.classes.prefix)
+        last = "discard"
+    train_data = DataLoader(train_set, flags.batch_size, shuffle=True, last_batch=last)
+    val_data = DataLoader(val_set, flags.batch_size, shuffle=False)
+    trainer = Trainer(head, "sgd", {"learning_rate": flags.lr, "momentum": flags.momentum, "wd": flags.wd})
+    metrics = [PRF1(label_names=train_set.classes)]
+
+    def batches():
+        for data, labels, _ in train_data:
+            x = data if isinstance(data, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(data))
+            yield x.cuda(), torch.from_numpy(labels.astype(np.int32)).cuda()
+
+    def validate(h):                                     # train.py:445-470: the validation metrics of the updated model
+        model.set_params(h.state_dict())
+        vm = [PRF1(label_names=val_set.classes)]
+        evaluate_model(model, val_data, val_set, vm)
+        return dict(vm[0].get())
+
+    hist = train_model(head, batches, metrics, trainer, flags.epochs, flags.batch_size, lr_steps=lr_steps,
+                       lr_factor=flags.lr_factor, val_fn=validate, save_dir=save_dir)
+    best = max(hist, key=lambda r: r["val"].get("AVG_f1", 0.0))
+    print("[Finished] best epoch {} val AVG_f1={:.3f}".format(best["epoch"], best["val"].get("AVG_f1", 0.0)))
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

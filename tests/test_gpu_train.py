@@ -99,3 +99,25 @@ def test_train_model_driver(tmp_path):
     assert metric.mat.sum() == 6 * B                                  # the last epoch's samples
     z = np.load(str(tmp_path / "0004.params"))
     assert set(z.files) == set(p) and z["cnnrnn0_dense0_weight"].shape == (C_, 2 * H)
+
+
+def test_train_main_pipeline(tmp_path, capsys):
+    """The reference's workflow for the temporal model end to end on the synthetic source: evaluate --save_feats writes the
+    per-frame .npy features, train --feats_model --window --temp_pool gru trains the head on windows of them, and the saved
+    parameters load back; then one epoch of the end-to-end frame classifier (train --window 1)."""
+    from tennis_amd import evaluate as ev, train as tr
+    root = str(tmp_path / "data")
+    common = ["--root", root, "--frames_per_video", "12", "--data_shape", "224", "--model_id", "0001"]
+    for split in ("train", "val"):
+        assert ev.main(common + ["--split", split, "--save_feats", "--batch_size", "8"]) == 0
+    exp = str(tmp_path / "exp")
+    args = ["--root", root, "--frames_per_video", "12", "--data_shape", "224", "--model_id", "0002", "--feats_model", "0001", "--window", "4",
+            "--temp_pool", "gru", "--epochs", "3", "--batch_size", "8", "--lr", "0.01", "--lr_steps", "1, 2", "--exp_root", exp]
+    assert tr.main(args) == 0
+    out = capsys.readouterr().out
+    assert "[Finished] best epoch" in out and (tmp_path / "exp" / "0002" / "0002.params").exists()
+    # end-to-end frame classifier, one epoch
+    args = ["--root", root, "--frames_per_video", "8", "--data_shape", "224", "--model_id", "0003", "--window", "1", "--epochs", "1",
+            "--batch_size", "4", "--exp_root", exp]
+    assert tr.main(args) == 0
+    assert (tmp_path / "exp" / "0003" / "0000.params").exists()
