@@ -1,8 +1,10 @@
 """Caption-mode dataset, batching and the captioning evaluate() driver — mirrors of the
 caption branch of reference dataset.py::TennisSet (dataset.py:52-74,154-183,235-247),
 utils/captioning.py::get_dataloaders/write_sentences (:28-95) and
-train_gnmt.py::evaluate (:264-302), over a SYNTHETIC source (the TenniSet features and
-captions are not available).
+train_gnmt.py::evaluate (:264-302).  Two sources: ON DISK when ``root`` holds the reference's layout
+(``splits/<split_id>/<split>.txt``, ``annotations/points.txt`` + ``captions.txt``, per-frame ``.npy`` features under
+``features/<feats_model>/`` as ``evaluate --save_feats`` writes them; parsed by ``TennisSet.load_data``), else SYNTHETIC
+(the TenniSet features and captions are not available).
 
 One sample = one *point*: every `every`-th frame feature in [start, end), stacked (T,F), plus
 the caption ids ``[<bos>] + vocab[tokens][:max_cap_len] + [<eos>]`` as int32 (dataset.py:67-73);
@@ -28,17 +30,30 @@ class CaptionSet:
     """``TennisSet(captions=True, feats_model=...)`` counterpart."""
 
     def __init__(self, split="train", every=1, max_cap_len=-1, vocab=None, inference=False, n_points=24,
-                 feature_dim=1024, mean_frames=40, seed=7):
+                 feature_dim=1024, mean_frames=40, seed=7, root=None, split_id="02", feats_model=None):
         self._captions, self._split, self._every, self._inference = True, split, every, inference
-        rng = np.random.default_rng(zlib.crc32(f"{split}:{seed}".encode()))
         self._points, self._samples = {}, []
-        for i in range(n_points):
-            start = int(rng.integers(0, 1000))
-            n = int(np.clip(rng.normal(mean_frames, mean_frames / 3), 4, 3 * mean_frames))
-            cap = " ".join(rng.choice(WORDS, size=int(rng.integers(4, 14))))
-            pid = f"P{split}{i:04d}"
-            self._points[pid] = ["V006", start, start + n, 0, cap]
-            self._samples.append(pid)
+        self._feat_dir = None
+        import os
+        if root is not None and os.path.exists(os.path.join(root, "splits", split_id, split + ".txt")):
+            # dataset.py:35-52: the points of this split from annotations/points.txt + captions.txt; frames as features
+            from .dataset import TennisSet
+            if feats_model is None:
+                raise ValueError("the caption source on disk reads pre-extracted features: pass feats_model (dataset.py:42-44)")
+            ts = TennisSet(root=root, split=split, split_id=split_id, every=1, balance=False, feats_model=feats_model)
+            for pid, pt in ts._points.items():
+                self._points[pid] = [pt[0], int(pt[1]), int(pt[2]), 0, pt[-1]]
+            self._samples = list(self._points.keys())
+            self._feat_dir, self._feat_path = ts.feat_dir, ts.get_feature_path
+        else:
+            rng = np.random.default_rng(zlib.crc32(f"{split}:{seed}".encode()))
+            for i in range(n_points):
+                start = int(rng.integers(0, 1000))
+                n = int(np.clip(rng.normal(mean_frames, mean_frames / 3), 4, 3 * mean_frames))
+                cap = " ".join(rng.choice(WORDS, size=int(rng.integers(4, 14))))
+                pid = f"P{split}{i:04d}"
+                self._points[pid] = ["V006", start, start + n, 0, cap]
+                self._samples.append(pid)
         self._fdim, self._seed = feature_dim, seed
         if vocab is None:                                              # dataset.py:55-58
             counter = {}
@@ -62,6 +77,8 @@ class CaptionSet:
         return [c.split() for c in caps] if split and not ids else caps
 
     def _feature(self, vid, frame):
+        if self._feat_dir is not None:                                  # dataset.py:169-171
+            return np.load(self._feat_path(self._feat_dir, vid, frame)).astype(np.float32)
         s = zlib.crc32(f"{vid}:{frame}:{self._seed}".encode())
         return np.abs(np.random.default_rng(s).normal(0, 1, self._fdim)).astype(np.float32) * 0.5
 

@@ -174,3 +174,32 @@ def test_structural_parameter_names_and_params_round_trip(tmp_path):
     cr.classes._materialize(32)
     names = set(cr._structural_params())
     assert {"rnn.l0_i2h_weight", "rnn.r0_h2h_bias", "classes.weight", "classes.bias"} <= names and len(names) == 10
+
+
+def test_caption_set_on_disk(tmp_path):
+    """CaptionSet over the reference's directory layout: points / captions of the split, per-frame .npy features at the
+    save_feats path scheme (dataset.py:154-183), vocabulary built from the training captions and reused."""
+    from tennis_amd.captions import CaptionSet, pad_batchify
+    from tennis_amd.dataset import TennisSet
+    root = str(tmp_path / "data")
+    _write_dataset(root, np.random.default_rng(6))
+    rng = np.random.default_rng(0)
+    feats = {}
+    for v, n in (("V010", 14), ("V011", 9)):
+        for fr in range(n):
+            path = TennisSet.get_feature_path(os.path.join(root, "features", "0042"), v, fr)
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            feats[(v, fr)] = rng.normal(0, 1, 24).astype(np.float32)
+            np.save(path, feats[(v, fr)])
+    cs = CaptionSet(root=root, split="test", split_id="02", feats_model="0042", inference=True)
+    assert len(cs) == 2 and cs.get_captions() == ["serve in", "serve far"]
+    x, cap, tl, cl, idx = cs[1]
+    assert x.shape == (2, 24) and tl == 2 and idx == 1
+    assert np.array_equal(x[0], feats[("V011", 4)]) and np.array_equal(x[1], feats[("V011", 5)])       # frames [start, end)
+    assert cap[0] == 2 and cap[-1] == 3 and cl == 4 and cs.vocab.idx_to_token[cap[1]] == "serve"
+    ev = CaptionSet(root=root, split="test", split_id="02", feats_model="0042", vocab=cs.vocab, every=2)
+    assert ev.vocab is cs.vocab and ev[0][0].shape == (1, 24)
+    src, tgt, svl, tvl = pad_batchify([cs[0][:4], cs[1][:4]])
+    assert src.shape == (2, 2, 24) and tgt.shape == (2, 4)
+    with pytest.raises(ValueError):
+        CaptionSet(root=root, split="test", split_id="02")
