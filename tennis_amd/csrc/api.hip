@@ -383,11 +383,11 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
     const int Hh = e->Hb[b], Ww = e->Wb[b];
     const int M = B * Hh * Ww;
     const bool fused = e->fuse && dense_layer_supported(Hh, Ww);
-    if (fused && e->chain && e->dl_variant == 0 && Hh == Ww && (Hh == 14 || Hh == 7)) {
+    if (fused && e->chain && (e->dl_variant & ~32) == 0 && Hh == Ww && (Hh == 14 || Hh == 7)) {
       // one workgroup per frame walks the whole block: no launch gaps, no cold prologue per layer
       auto &L0 = e->layers[b][0];
       const int nl = (int)e->layers[b].size();
-      DenseLayerArgs af{bbuf[b], e->Cb[b], L0.cin, L0.s1, L0.t1, L0.w1, L0.s2, L0.t2, L0.w3p, B, Hh, Ww, nullptr, 0, e->chain_dev[b], nl};
+      DenseLayerArgs af{bbuf[b], e->Cb[b], L0.cin, L0.s1, L0.t1, L0.w1, L0.s2, L0.t2, L0.w3p, B, Hh, Ww, nullptr, e->dl_variant, e->chain_dev[b], nl};
       double fl = 0, by = 0;
       for (auto &L : e->layers[b]) {
         fl += 2.0 * M * (128.0 * L.cin + 32.0 * 1152);

@@ -64,11 +64,15 @@ struct DLGeom {
   static constexpr int TAB2 = TAB;                           // s2[128], t2[128]
   static constexpr int TAB1 = TAB + 1024;                    // s1[K], t1[K]  (K <= 1024)
   static constexpr int LDS_BYTES = TAB + 1024 + 8192;
-  static constexpr int MIW = BM / 128;                       // 16-row pixel fragments per wave
+  // BM = 64 (7x7 frames, 63 tile rows): the waves split the tile 4 (pixel rows) x 2 (bottleneck channel halves)
+  // instead of 8 x 1, so no wave spends MFMAs and weight-fragment reads on rows past the frame
+  static constexpr bool NSPLIT = (BM == 64);
+  static constexpr int NI = NSPLIT ? 4 : 8;                  // 16-channel weight fragments per wave
+  static constexpr int MIW = NSPLIT ? 1 : BM / 128;          // 16-row pixel fragments per wave
   static_assert(PIECES % 8 == 0, "DMA pieces must divide over 8 waves");
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
   static_assert(16 * NF16 * 80 <= TILE_BYTES, "output row buffer does not fit");
-  static_assert(BM >= TR * W && BM % 128 == 0, "phase A tile too small");
+  static_assert(BM >= TR * W && (BM % 128 == 0 || BM == 64), "phase A tile too small");
   static_assert(BK == 32 || BK == 64, "BK");
 };
 
@@ -110,7 +114,8 @@ __device__ __forceinline__ void pp_barrier() {
 template <int W, int ROUT, int BM, int BK, int PP, bool CHAIN>
 __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   using G = DLGeom<W, ROUT, BM, BK>;
-  constexpr int WP = G::WP, TR = G::TR, MIW = G::MIW;
+  constexpr int WP = G::WP, TR = G::TR, MIW = G::MIW, NI = G::NI;
+  static_assert(!G::NSPLIT || PP == 2, "the 4 x 2 wave split exists for the flat K loop only");
   constexpr int ROWB = G::ROWB, PPW = G::PPW, RPP = G::RPP, CPR = ROWB / 16;  // chunks per row
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *tile = smem;                   // bottleneck tile (aliases the DMA ring)
@@ -175,9 +180,11 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   const int K = a.K;
   // ======================= phase A: bottleneck = conv1x1(relu(bn1(x))) =======================
   const int frow = lane & 15, fch = lane >> 4;
-  f32x4 acc[8][MIW];
+  const int mrow0 = G::NSPLIT ? (wid & 3) * 16 : wid * (BM / 8);   // first tile row of this wave
+  const int nch0 = G::NSPLIT ? (wid >> 2) * 64 : 0;                // first bottleneck channel of this wave
+  f32x4 acc[NI][MIW];
 #pragma unroll
-  for (int ni = 0; ni < 8; ++ni)
+  for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
     for (int mi = 0; mi < MIW; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)smem);   // LDS byte address of smem
@@ -402,19 +409,19 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
         const float4 t0 = *(const float4 *)(tab1 + 1024 + kb), t1 = *(const float4 *)(tab1 + 1024 + kb + 4);
         const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
         const float sh[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-        f16x8 wa[8];
+        f16x8 wa[NI];
 #pragma unroll
-        for (int ni = 0; ni < 8; ++ni) {
-          const int row = ni * 16 + frow;
+        for (int ni = 0; ni < NI; ++ni) {
+          const int row = nch0 + ni * 16 + frow;
           wa[ni] = *(const f16x8 *)(Ws + row * ROWB + (stage_swz<BK>(row, ks * 4 + fch) << 4));
         }
 #pragma unroll
         for (int mi = 0; mi < MIW; ++mi) {
-          const int row = wid * (BM / 8) + mi * 16 + frow;
+          const int row = mrow0 + mi * 16 + frow;
           const f16x8 xraw = *(const f16x8 *)(Xs + row * ROWB + (stage_swz<BK>(row, ks * 4 + fch) << 4));
           const f16x8 xb = bn_relu8_mix(xraw, sc, sh);
 #pragma unroll
-          for (int ni = 0; ni < 8; ++ni)
+          for (int ni = 0; ni < NI; ++ni)
             acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ni], xb, acc[ni][mi], 0, 0, 0);
           if constexpr (SPREAD) {
             constexpr int NG = (BK / 32) * MIW;
@@ -466,7 +473,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     bool ok[MIW];
 #pragma unroll
     for (int mi = 0; mi < MIW; ++mi) {
-      const int m = wid * (BM / 8) + mi * 16 + frow;
+      const int m = mrow0 + mi * 16 + frow;
       const int rr = m / W, x = m - rr * W;
       const int slot = (rr + top_pad) * WP + x + 1;
       dst[mi] = tile + slot * 256 + (fch & 1) * 8;
@@ -474,10 +481,10 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
       ok[mi] = m < MA;
     }
 #pragma unroll
-    for (int ni = 0; ni < ((TN_EXP & 4) ? 0 : 8); ++ni) {
-      const float4 sv = *(const float4 *)(tab2 + ni * 16 + fch * 4);
-      const float4 tv = *(const float4 *)(tab2 + 128 + ni * 16 + fch * 4);
-      const int chunk = ni * 2 + (fch >> 1);              // channels n>>3
+    for (int ni = 0; ni < ((TN_EXP & 4) ? 0 : NI); ++ni) {
+      const float4 sv = *(const float4 *)(tab2 + nch0 + ni * 16 + fch * 4);
+      const float4 tv = *(const float4 *)(tab2 + 128 + nch0 + ni * 16 + fch * 4);
+      const int chunk = (nch0 >> 3) + ni * 2 + (fch >> 1);   // channels n>>3
 #pragma unroll
       for (int mi = 0; mi < MIW; ++mi) {
         const f16x4 hv = bn_relu4_from_f32(acc[ni][mi], sv, tv);
@@ -656,7 +663,9 @@ int launch_dense_layer_big(const DenseLayerArgs &a, hipStream_t s) {
   TN_REQUIRE(a.K % 32 == 0 && klast <= 1024 && a.ldc % 8 == 0 && klast + 32 <= a.ldc, "dense_layer: bad channel geometry");
   if (a.nchain > 0) {
     TN_REQUIRE(a.H == a.W && (a.H == 14 || a.H == 7) && a.chain, "dense_layer: layer chaining needs whole-frame tiles (14x14, 7x7)");
-    return a.H == 14 ? launch_geom<14, 14, 256, 64, 2, true>(a, s) : launch_geom<7, 7, 128, 64, 2, true>(a, s);
+    if (a.H == 14) return launch_geom<14, 14, 256, 64, 2, true>(a, s);
+    // 7x7: 4 x 2 wave split over a 64-row tile (variant bit 5: the 8 x 1 split over 128 rows, for A/B runs)
+    return (a.variant & 32) ? launch_geom<7, 7, 128, 64, 2, true>(a, s) : launch_geom<7, 7, 64, 64, 2, true>(a, s);
   }
   // K-loop flavour (tuning hook, variant bits 2-3): default 0 -> flat loop with the refill spread over the MFMA
   // groups (measured best); 1 -> ping-pong halves, 2 -> flat with the refill up front, 3 -> ping-pong with the
