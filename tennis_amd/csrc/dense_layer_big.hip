@@ -418,11 +418,13 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
 #pragma unroll
         for (int mi = 0; mi < MIW; ++mi) {
           const int row = mrow0 + mi * 16 + frow;
+          if ((a.variant & 64) || mrow0 + mi * 16 < MA) {   // wave-uniform: fragments past the tile's rows are skipped (bit 6: not)
           const f16x8 xraw = *(const f16x8 *)(Xs + row * ROWB + (stage_swz<BK>(row, ks * 4 + fch) << 4));
           const f16x8 xb = bn_relu8_mix(xraw, sc, sh);
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
             acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ni], xb, acc[ni][mi], 0, 0, 0);
+          }
           if constexpr (SPREAD) {
             constexpr int NG = (BK / 32) * MIW;
             const int gi = ks * MIW + mi;           // compile-time after unrolling
