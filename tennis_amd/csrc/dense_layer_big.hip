@@ -180,7 +180,11 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   const int K = a.K;
   // ======================= phase A: bottleneck = conv1x1(relu(bn1(x))) =======================
   const int frow = lane & 15, fch = lane >> 4;
-  const int mrow0 = G::NSPLIT ? (wid & 3) * 16 : wid * (BM / 8);   // first tile row of this wave
+  // REBAL (28x28: 28 real fragments in a 32-fragment tile): waves 0-3 own 4 fragments, waves 4-7 own 3, so every
+  // SIMD (waves w, w+4) carries 7 instead of 8 / 8 / 8 / 4
+  const bool REBAL = !G::NSPLIT && (PP == 0 || PP == 2) && MIW == 4 && (TR * W + 15) / 16 == 28 && !(a.variant & 128);   // bit 7: off, for A/B runs
+  const int mrow0 = G::NSPLIT ? (wid & 3) * 16 : REBAL ? (wid < 4 ? wid * 64 : 256 + (wid - 4) * 48) : wid * (BM / 8);   // first tile row of this wave
+  const int nfw = (REBAL && wid >= 4) ? 3 : MIW;                    // fragments this wave owns
   const int nch0 = G::NSPLIT ? (wid >> 2) * 64 : 0;                // first bottleneck channel of this wave
   f32x4 acc[NI][MIW];
 #pragma unroll
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
 #pragma unroll
         for (int mi = 0; mi < MIW; ++mi) {
           const int row = mrow0 + mi * 16 + frow;
-          if ((a.variant & 64) || mrow0 + mi * 16 < MA) {   // wave-uniform: fragments past the tile's rows are skipped (bit 6: not)
+          if ((a.variant & 64) || (mrow0 + mi * 16 < MA && mi < nfw)) {   // wave-uniform: fragments past the tile's rows are skipped (bit 6: not)
           const f16x8 xraw = *(const f16x8 *)(Xs + row * ROWB + (stage_swz<BK>(row, ks * 4 + fch) << 4));
           const f16x8 xb = bn_relu8_mix(xraw, sc, sh);
 #pragma unroll
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
       const int slot = (rr + top_pad) * WP + x + 1;
       dst[mi] = tile + slot * 256 + (fch & 1) * 8;
       sl15[mi] = slot & 15;
-      ok[mi] = m < MA;
+      ok[mi] = m < MA && mi < nfw;
     }
 #pragma unroll
     for (int ni = 0; ni < ((TN_EXP & 4) ? 0 : NI); ++ni) {
