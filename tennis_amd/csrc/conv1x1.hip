@@ -17,26 +17,31 @@
 // 256-byte store.  With POOL the four BN+ReLU'd input pixels of each pooled
 // pixel are averaged before the GEMM (avgpool and 1x1 conv commute), which also
 // cuts the transition GEMMs' work by 4x.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
 
 constexpr int BN_TILE = 128;
 constexpr int BK = 64;
-constexpr int CPITCH = 272;  // bytes per epilogue row: 128 halfs + 8 pad
 
-template <int MI>
+template <int MI, int NB>
 constexpr int smem_bytes() {
-  constexpr int tiles = 32 * MI * 128 + BN_TILE * 128;
-  constexpr int epi = 32 * MI * CPITCH;
+  constexpr int tiles = 32 * MI * 128 + NB * 128;
+  constexpr int epi = 32 * MI * (NB * 2 + 16);
   return tiles > epi ? tiles : epi;
 }
 
-template <int MI, bool POOL>
+// NB = output channels per workgroup (128, or 256 for the transitions with N >= 256: every column tile streams
+// the pixel tile again and repeats its BN+ReLU+average, so wider tiles cut both)
+template <int MI, bool POOL, int NB>
 __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
   constexpr int BM = 32 * MI;
   constexpr int NSRC = POOL ? 4 : 1;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[smem_bytes<MI>()];
+  constexpr int NI = NB / 32;          // 16-channel fragments per wave (a wave owns NB / 2 channels)
+  constexpr int CPITCH = NB * 2 + 16;  // bytes per epilogue row: NB halfs + 8 pad
+  __shared__ __attribute__((aligned(16))) unsigned char smem[smem_bytes<MI, NB>()];
   unsigned char *Xs = smem;
   unsigned char *Ws = smem + BM * 128;
 
@@ -49,14 +54,14 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
   // L2 for the others (the transitions read every input N/128 times otherwise)
   int mt = blockIdx.x, nt = blockIdx.y;
   if constexpr (POOL) {
-    const int NT = a.N / BN_TILE, L = blockIdx.x;
+    const int NT = a.N / NB, L = blockIdx.x;
     const int grp = L / (8 * NT), rem = L - grp * 8 * NT;
     mt = grp * 8 + (rem & 7);
     nt = rem >> 3;
     if (mt * BM >= a.M) return;      // padding of the last group of 8 pixel tiles
   }
   const int m0 = mt * BM;
-  const int n0 = nt * BN_TILE;
+  const int n0 = nt * NB;
   const int K = a.K;
 
   // staging assignment: chunk column c (8 halfs) is fixed per thread
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
   const f16 *wsrc = a.w + (long)(n0 + r0) * K;
 
   f16x8 xr[MI][NSRC];
-  f16x8 wr[4];
+  f16x8 wr[NI];
   float sc[8], sh[8];
 
   auto load_tile = [&](int kt) {
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
 #pragma unroll
         for (int s = 0; s < NSRC; ++s) xr[i][s] = *(const f16x8 *)(xsrc[i][s] + kc);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) wr[i] = *(const f16x8 *)(wsrc + (long)(32 * i) * K + kc);
+      for (int i = 0; i < NI; ++i) wr[i] = *(const f16x8 *)(wsrc + (long)(32 * i) * K + kc);
     }
   };
 
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
       *(f16x8 *)(Xs + swz<128>(r0 + 32 * i, c)) = v;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
       f16x8 v = wr[i];
       if (!kv) {
 #pragma unroll
@@ -145,9 +150,9 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
     }
   };
 
-  f32x4 acc[4][MI];
+  f32x4 acc[NI][MI];
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni)
+  for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -163,15 +168,15 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       if (kt * BK + ks * 32 < K) {
-        f16x8 xb[MI], wa[4];
+        f16x8 xb[MI], wa[NI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
           xb[mi] = *(const f16x8 *)(Xs + swz<128>(wm * 16 * MI + mi * 16 + frow, ks * 4 + fch));
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          wa[ni] = *(const f16x8 *)(Ws + swz<128>(wn * 64 + ni * 16 + frow, ks * 4 + fch));
+        for (int ni = 0; ni < NI; ++ni)
+          wa[ni] = *(const f16x8 *)(Ws + swz<128>(wn * (NB / 2) + ni * 16 + frow, ks * 4 + fch));
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
             acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ni], xb[mi], acc[ni][mi], 0, 0, 0);
@@ -182,11 +187,11 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
 
   // epilogue: D[i=n][j=m]; lane holds n = (lane>>4)*4 + r, m = lane&15
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni)
+  for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int m = wm * 16 * MI + mi * 16 + frow;
-      const int n = wn * 64 + ni * 16 + fch * 4;
+      const int n = wn * (NB / 2) + ni * 16 + fch * 4;
       f16x4 h;
 #pragma unroll
       for (int r = 0; r < 4; ++r) h[r] = (f16)acc[ni][mi][r];
@@ -194,9 +199,9 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
     }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < MI * 2; ++i) {
+  for (int i = 0; i < MI * NB / 64; ++i) {
     const int id = t + 256 * i;
-    const int row = id >> 4, ch = id & 15;
+    const int row = id / (NB / 8), ch = id % (NB / 8);
     const int m = m0 + row;
     if (m < a.M) {
       const uint4 v = *(const uint4 *)(smem + row * CPITCH + ch * 16);
@@ -212,18 +217,21 @@ int launch_conv1x1(const Conv1x1Args &a, hipStream_t s) {
   TN_REQUIRE(a.ldx % 8 == 0 && a.ldy % 8 == 0 && a.yoff % 8 == 0, "conv1x1: strides must be multiples of 8");
   const dim3 block(256);
   if (a.pool) {
-    const int mtiles = (a.M + 63) / 64, NT = a.N / BN_TILE;
+    static const bool narrow = getenv("TN_TRANS_NARROW") != nullptr;   // A/B runs: 128-channel tiles everywhere
+    const bool wide = a.N % 256 == 0 && !narrow;
+    const int mtiles = (a.M + 63) / 64, NT = a.N / (wide ? 256 : BN_TILE);
     const dim3 grid(((mtiles + 7) / 8) * 8 * NT);
-    hipLaunchKernelGGL((conv1x1_kernel<2, true>), grid, block, 0, s, a);
+    if (wide) hipLaunchKernelGGL((conv1x1_kernel<2, true, 256>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv1x1_kernel<2, true, 128>), grid, block, 0, s, a);
   } else if (a.M >= 128 * 512) {
     const dim3 grid((a.M + 127) / 128, a.N / BN_TILE);
-    hipLaunchKernelGGL((conv1x1_kernel<4, false>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((conv1x1_kernel<4, false, 128>), grid, block, 0, s, a);
   } else if (a.M >= 64 * 512) {
     const dim3 grid((a.M + 63) / 64, a.N / BN_TILE);
-    hipLaunchKernelGGL((conv1x1_kernel<2, false>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((conv1x1_kernel<2, false, 128>), grid, block, 0, s, a);
   } else {
     const dim3 grid((a.M + 31) / 32, a.N / BN_TILE);
-    hipLaunchKernelGGL((conv1x1_kernel<1, false>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((conv1x1_kernel<1, false, 128>), grid, block, 0, s, a);
   }
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;
