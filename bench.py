@@ -3,13 +3,18 @@
 (BASELINE.json configs[1]: batch 256 synthetic frames, fp16, one MI355X per rank).
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = one pass of the hot path over one batch of 256 synthetic frames per rank
-(inputs resident in HBM): stem -> 58 dense layers -> 3 transitions -> head ->
-(B,1024) fp32 features, then for N>1 the RCCL all-gather of the feature rows that
-the temporal/caption stage consumes.  Frames shard across ranks with
-no other exchange: weak scaling.  Rank 0 prints ONE JSON line.
+N > 1 runs one process per GPU over RCCL: under ``python -m torch.distributed.run --nproc-per-node N ...`` the ranks
+exist already (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* are read from the environment); started as plain
+``python bench.py --gpus N`` the script spawns the N ranks itself (tennis_amd.sharding.launch).  Rank 0 prints ONE
+JSON line.
+
+A step = one pass of the hot path over one batch of 256 synthetic frames per rank (inputs resident in HBM):
+stem -> 58 dense layers -> 3 transitions -> head -> (B,1024) fp32 features, then for N > 1 the RCCL all-gather of
+the feature rows that the temporal / caption stage consumes.  Frames shard across ranks with no other
+exchange: weak scaling.  The timed region is EXACTLY K steps between two fences (barrier + device synchronise); when
+K is small the region is repeated (each repetition again exactly K fenced steps, at least 200 steps in total) and
+the MEDIAN repetition is reported, so that a 20-step run is not a single 48-ms sample.
 """
 import argparse
 import json
@@ -28,6 +33,18 @@ SIZE = 224
 FLOP_PER_FRAME = 5.666e9          # 2 x 2.8331 GMAC over the 120 convolutions
 MFMA_PEAK_TFLOPS = 2500.0         # MI355X dense fp16 MFMA (MI355X_MICROARCH.md)
 HBM_PEAK_TBS = 8.0                # MI355X HBM3E (MI355X_MICROARCH.md)
+MIN_TOTAL_STEPS = 200
+# compulsory HBM bytes per frame if every intermediate stayed on chip: fp16 NHWC frame in, fp32
+# features out (+ 13.7 MB of fp16 weights per batch)
+COMPULSORY_BYTES_PER_FRAME = 301056 + 4096
+WEIGHT_BYTES = 13.7e6
+# profile family (tn_densenet121_profile) -> kernel family key of profiles/*_pmc_traffic.json
+PMC_KEYS = {"dense_layer_fused_56x56": ("dense_layer_56x56", "dense_layer_kernel<56"),
+            "dense_layer_fused_28x28": ("dense_layer_28x28", "dense_layer_kernel<28"),
+            "dense_block_chained_14x14": ("dense_block_14x14", "dense_layer_kernel<14"),
+            "dense_block_chained_7x7": ("dense_block_7x7", "dense_layer_kernel<7"),
+            "stem_conv_bn_relu_maxpool": ("stem_pool_kernel",), "transition_conv1x1_avgpool": ("conv1x1_kernel",),
+            "head_bnrelu_avgpool7": ("head_kernel",)}
 
 
 def make_frames(batch, size, seed, device):
@@ -41,68 +58,90 @@ def make_frames(batch, size, seed, device):
 
 
 def pmc_traffic(kernel_family):
-    """HBM bytes per launch of the dominant kernel family from the newest committed rocprofv3 PMC
-    summary (profiles/*_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2
-    FETCH correction).  PMC counters cannot be read from inside the timed process."""
+    """(HBM bytes per launch, file) of a kernel family from the newest committed rocprofv3 PMC summary
+    (profiles/*_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 FETCH correction).  PMC counters
+    cannot be read from inside the timed process: this is a figure from a file, labelled as such in the line."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not files:
-        return None
+        return None, None
     fam = json.load(open(files[-1])).get("families", {})
-    return fam.get(kernel_family, {}).get("hbm_bytes_per_dispatch_corrected")
+    for key in PMC_KEYS.get(kernel_family, ()) + (kernel_family,):
+        if key in fam:
+            return fam[key].get("hbm_bytes_per_dispatch_corrected"), os.path.relpath(files[-1], ROOT)
+    return None, os.path.relpath(files[-1], ROOT)
 
 
-def cpu_baseline(params, frames_nhwc_f16, seconds_target=12.0):
-    """Reference CPU path stand-in (oracle/torch_ref.py, fp32, oneDNN) on a bounded sample."""
+def _median_rate(fn, n, runs):
+    """frames/s of fn() over n frames: warm-up + median of `runs` timed calls."""
+    fn()
+    ts = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return n / float(np.median(ts)), ts
+
+
+def cpu_baseline(params, frames_nhwc_f16, full=False):
+    """The reference CPU path stand-ins of SURVEY §8(d) on this box's host cores, on bounded samples (MXNet's CPU
+    path cannot be installed: both are restatements, kind "port"):
+      (i)  oracle/torch_ref.py — the same graph through torch-CPU / oneDNN, fp32, all cores: config C1's 32 frames,
+           median of 5 runs (`value`); the 256-frame batch once more with --cpu-baseline-full;
+      (ii) oracle/densenet_np.py — the numpy fp32 oracle, 2 frames, median of 3 runs (`numpy_oracle`)."""
+    from oracle import densenet_np as dn
     from oracle.torch_ref import TorchDenseNet121
-    net = TorchDenseNet121(params)
-    n = 16
-    x = frames_nhwc_f16[:n].float().permute(0, 3, 1, 2).contiguous().cpu()
     threads = torch.get_num_threads()
-    net(x[:2])  # warm-up
-    t0 = time.time()
-    reps = 0
-    while True:
-        net(x)
-        reps += 1
-        if time.time() - t0 > seconds_target or reps >= 8:
-            break
-    dt = time.time() - t0
-    return {"value": round(n * reps / dt, 2), "unit": "frames/sec", "cores": threads, "kind": "port",
-            "sample": f"{reps} x {n} frames 224x224 fp32, torch-CPU(oneDNN) restatement oracle/torch_ref.py "
-                      f"(MXNet CPU path not installable), host has {os.cpu_count()} logical cpus"}
+    net = TorchDenseNet121(params)
+    x32 = frames_nhwc_f16[:32].float().permute(0, 3, 1, 2).contiguous().cpu()
+    net(x32[:2])
+    fps32, ts32 = _median_rate(lambda: net(x32), 32, 5)
+    out = {"value": round(fps32, 2), "unit": "frames/sec", "cores": threads, "kind": "port",
+           "sample": f"config C1: 32 frames 224x224 fp32 through oracle/torch_ref.py (torch-CPU/oneDNN restatement; MXNet CPU "
+                     f"path not installable), median of 5 runs, {threads} threads of {os.cpu_count()} logical cpus",
+           "runs_s": [round(t, 3) for t in ts32]}
+    x2 = x32[:2].numpy()
+    fps_np, ts_np = _median_rate(lambda: dn.densenet121_features(x2, params), 2, 3)
+    out["numpy_oracle"] = {"value": round(fps_np, 3), "unit": "frames/sec", "cores": "numpy/BLAS default threads",
+                           "sample": "2 frames 224x224 fp32 through oracle/densenet_np.py, median of 3 runs",
+                           "runs_s": [round(t, 3) for t in ts_np]}
+    if full:
+        n = min(256, frames_nhwc_f16.shape[0])
+        x256 = frames_nhwc_f16[:n].float().permute(0, 3, 1, 2).contiguous().cpu()
+        fps256, ts256 = _median_rate(lambda: net(x256), n, 5)
+        out["batch256"] = {"value": round(fps256, 2), "unit": "frames/sec", "cores": threads,
+                           "sample": f"{n}-frame batch through oracle/torch_ref.py, median of 5 runs",
+                           "runs_s": [round(t, 3) for t in ts256]}
+    return out
 
 
-def main():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the 256-frame batch on the CPU (minutes)")
+    ap.add_argument("--single-region", action="store_true", help="one timed region of K steps only (no repetitions)")
+    return ap
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
-        args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+
+def run(argv):
+    args = build_parser().parse_args(argv)
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+    from tennis_amd import sharding
+    rank, world, dev = sharding.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: tennis_amd has no CPU path")
 
     from tennis_amd import _lib
     from tennis_amd import weights as W
     from tennis_amd.engine import DenseNet121Features
 
-    ctx = _lib.Context(local_rank)
+    ctx = _lib.Context(dev.index)
     params = W.make_densenet121_weights(0)
     enc = DenseNet121Features(params, SIZE, max_batch=args.batch, ctx=ctx)
     x = make_frames(args.batch, SIZE, 1234 + rank, dev)
@@ -121,55 +160,64 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_region(k):
+        """exactly k steps between two fences; max over ranks"""
+        fence()
+        t0 = time.perf_counter()
+        for i in range(k):
+            step(i)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
+
     for i in range(args.warmup):
         step(i)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    repeats = 1 if args.single_region else max(1, -(-MIN_TOTAL_STEPS // args.steps))
+    times = [timed_region(args.steps) for _ in range(repeats)]
+    dt = float(np.median(times))
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         fps = world * args.batch * args.steps / dt
-        # ---- roofline of the dominant kernel family: HIP events around every launch
-        # (separate instrumented passes, so the timed region above carries no events)
+        # ---- roofline of the dominant kernel family: HIP events around every launch on the stream the kernels run
+        # on (separate instrumented passes, so the timed region above carries no events)
         fams = {}
-        for _ in range(3):
+        NPROF = 3
+        for _ in range(NPROF):
             stats, _ = enc.profile(x)
             for s in stats:
                 a = fams.setdefault(s["name"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
                 a["ms"] += s["ms"]; a["flops"] += s["flops"]; a["bytes"] += s["bytes"]; a["launches"] += s["launches"]
         dom = max(fams, key=lambda k: fams[k]["ms"])
         d = fams[dom]
-        # which roofline binds the dominant kernel: time at HBM peak for its algorithmic bytes vs time at the
-        # dense-fp16 MFMA peak for its algorithmic flops (DenseNet's concatenated inputs make the dense layers
-        # byte-heavy: 128K+36864 flop per K+32 fp16 values read/written is below the 312 flop/B ridge from K=160 on)
         secs = d["ms"] * 1e-3
         tf, tbs = d["flops"] / secs / 1e12, d["bytes"] / secs / 1e12
-        hbm_bound = d["bytes"] / (HBM_PEAK_TBS * 1e12) >= d["flops"] / (MFMA_PEAK_TFLOPS * 1e12)
-        roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": dom,
-                    "achieved": round(tbs * 1e3 if hbm_bound else tf, 2),
-                    "peak": HBM_PEAK_TBS * 1e3 if hbm_bound else MFMA_PEAK_TFLOPS,
-                    "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                    "frac": round(tbs / HBM_PEAK_TBS if hbm_bound else tf / MFMA_PEAK_TFLOPS, 4),
-                    "traffic": pmc_traffic(dom),
-                    "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
+        traffic, traffic_file = pmc_traffic(dom)
+        enc_tf = FLOP_PER_FRAME * fps / world / 1e12
+        # SURVEY §8(d): the encoder is a dense contraction -> the MFMA roofline is the graded bound (target 40 % of the
+        # 2.5 PFLOP/s dense fp16 peak); the HBM figure (layer-wise algorithmic bytes) is reported next to it
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(tf, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
+                    "traffic": traffic,
+                    "traffic_source": (f"from {traffic_file} (rocprofv3 PMC passes of an earlier run of this command, "
+                                       "not measured in this process)") if traffic_file else None,
                     "algorithmic_flops_per_launch": round(d["flops"] / d["launches"]),
-                    "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2), "launches_per_step": d["launches"] // 3,
-                    "other_roofline": {"bound": "mfma" if hbm_bound else "hbm",
-                                       "achieved": round(tf if hbm_bound else tbs * 1e3, 2),
-                                       "peak": MFMA_PEAK_TFLOPS if hbm_bound else HBM_PEAK_TBS * 1e3,
-                                       "unit": "TFLOP/s" if hbm_bound else "GB/s",
-                                       "frac": round(tf / MFMA_PEAK_TFLOPS if hbm_bound else tbs / HBM_PEAK_TBS, 4)},
-                    "families_ms_per_step": {k: round(v["ms"] / 3, 3) for k, v in fams.items()},
-                    "encoder_tflops": round(FLOP_PER_FRAME * fps / world / 1e12, 2),
-                    "encoder_frac_of_mfma_peak": round(FLOP_PER_FRAME * fps / world / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+                    "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
+                    "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2), "launches_per_step": d["launches"] // NPROF,
+                    "other_roofline": {"bound": "hbm", "achieved": round(tbs * 1e3, 2), "peak": HBM_PEAK_TBS * 1e3,
+                                       "unit": "GB/s", "frac": round(tbs / HBM_PEAK_TBS, 4),
+                                       "bytes": "layer-wise algorithmic (every layer reads its inputs from HBM once)"},
+                    "families_ms_per_step": {k: round(v["ms"] / NPROF, 3) for k, v in fams.items()},
+                    "families_mfma_frac": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)
+                                           for k, v in fams.items() if v["flops"] > 0},
+                    "encoder_tflops": round(enc_tf, 2),
+                    "encoder_frac_of_mfma_peak": round(enc_tf / MFMA_PEAK_TFLOPS, 4),
+                    "compulsory_bytes_per_step": int(COMPULSORY_BYTES_PER_FRAME * args.batch + WEIGHT_BYTES),
+                    "layerwise_bytes_per_step": round(sum(v["bytes"] for v in fams.values()) / NPROF)}
         out = {"metric": "frames/sec DenseNet-121 224x224 feature-extract", "value": round(fps, 1),
                "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
@@ -178,14 +226,29 @@ def main():
                                       "(BASELINE.json configs[1])",
                           "frames_per_step_per_gpu": args.batch, "input": "NHWC fp16 normalised, HBM-resident",
                           "output": "fp32 features (B,1024)" + ("; RCCL all-gather of feature rows" if world > 1 else ""),
-                          "weights": "seeded random-init, conv weights fp16"},
+                          "weights": "seeded random-init, conv weights fp16",
+                          "timing": f"median of {repeats} fenced regions of exactly {args.steps} steps",
+                          "region_ms": [round(t * 1e3, 2) for t in times]},
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(params, x)
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline(params, x, full=args.cpu_baseline_full)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = build_parser().parse_args(argv)
+    from tennis_amd import sharding
+    if args.gpus > 1 and not sharding.under_launcher():
+        n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but {n} GPUs are visible")
+        sharding.launch(run, args.gpus, (argv,))
+        return
+    run(argv)
 
 
 if __name__ == "__main__":

@@ -137,6 +137,10 @@ typedef struct tn_preproc tn_preproc;
 int tn_preproc_create(tn_ctx *ctx, int src_h, int src_w, int resize, int crop, tn_preproc **out);
 int tn_preproc_forward(tn_preproc *p, const uint8_t *src, int batch, uint8_t *dst);
 int tn_preproc_destroy(tn_preproc *p);
+/* ToTensor + Normalize (reference evaluate.py:96-97, train.py:138-139) for consumers of fp32 frames (the fine-tuning
+ * step; the inference encoder fuses it into its stem load): dst[p][c] = (src[p][c] / 255 - mean[c]) / std[c],
+ * src (pixels, 3) uint8 NHWC, dst (pixels, 3) float NHWC, both DEVICE; mean3 / std3 HOST arrays of 3 floats. */
+int tn_to_tensor_normalize(tn_ctx *ctx, const uint8_t *src, long pixels, const float *mean3, const float *std3, float *dst);
 
 /* ---- F.max / F.mean over axis 1 ------------------------------------------ */
 /* Replaces reference models/vision/definitions.py:66-69,107.  x (B,T,F) -> y (B,F). */
@@ -169,12 +173,12 @@ int tn_head_destroy(tn_head *h);
  * SoftmaxCrossEntropyLoss per sample (train.py:324), backward of the summed losses (:419-421), SGD with momentum and
  * weight decay, rescale_grad = 1/batch_size (:298-299,424).  fp32.  Parameters by their Gluon names (as
  * tn_densenet121_create + the Dense).  x (batch, H, W, 3) fp32 normalised NHWC frames and labels (batch,) int32 are
- * DEVICE buffers; batch must equal the handle's.  read_param returns Gluon-ordered weights / gradients, running
+ * DEVICE buffers; batch, height and width must equal the handle's (the frame buffer is read as batch x height x width x 3).  read_param returns Gluon-ordered weights / gradients, running
  * statistics, or "<bn>_batch_mean" / "<bn>_batch_var" of the last step. */
 typedef struct tn_finetune tn_finetune;
 int tn_finetune_create(tn_ctx *ctx, const tn_param *params, int n_params, const char *backbone_prefix,
                        const char *dense_prefix, int height, int width, int classes, int batch, tn_finetune **out);
-int tn_finetune_forward_backward(tn_finetune *f, const float *x, const int32_t *labels, int batch, float *loss,
+int tn_finetune_forward_backward(tn_finetune *f, const float *x, const int32_t *labels, int batch, int height, int width, float *loss,
                                  float *logits);
 int tn_finetune_buffers(tn_finetune *f, float **params_dev, float **grads_dev, int64_t *numel);
 int tn_finetune_sgd_step(tn_finetune *f, float lr, float momentum, float wd, float rescale_grad);

@@ -58,6 +58,7 @@ _SIGS = {
     "tn_preproc_create": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "tn_preproc_forward": (C.c_int, [_P, _P, C.c_int, _P]),
     "tn_preproc_destroy": (C.c_int, [_P]),
+    "tn_to_tensor_normalize": (C.c_int, [_P, _P, C.c_long, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "tn_temporal_pool": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "tn_prf1_update": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
     "tn_head_create": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(TnParam), C.c_int, C.c_char_p, C.c_char_p, C.c_int,
@@ -69,7 +70,7 @@ _SIGS = {
     "tn_head_destroy": (C.c_int, [_P]),
     "tn_finetune_create": (C.c_int, [_P, C.POINTER(TnParam), C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.POINTER(_P)]),
-    "tn_finetune_forward_backward": (C.c_int, [_P, _P, _P, C.c_int, _P, _P]),
+    "tn_finetune_forward_backward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "tn_finetune_buffers": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64)]),
     "tn_finetune_sgd_step": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float]),
     "tn_finetune_read_param": (C.c_int, [_P, C.c_char_p, C.c_int, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64)]),
@@ -149,13 +150,15 @@ def make_params(params: dict):
 class Context:
     """One tn_ctx bound to a torch device and (by default) torch's current stream."""
 
-    def __init__(self, device: int = 0, stream=None):
+    def __init__(self, device: int | None = None, stream=None):
         if not torch.cuda.is_available():
             raise RuntimeError("tennis_amd needs a ROCm GPU: torch.cuda.is_available() is False and there is no "
                                "CPU fallback")
         self.lib = load()
+        device = default_device() if device is None else int(device)
         self.device = device
-        torch.cuda.set_device(device)
+        # the process's current device is left alone: the library switches to `device` for the duration of each
+        # call (TnDeviceGuard) and torch tensors carry their own device
         if stream is None:
             stream = torch.cuda.current_stream(device)
         self.torch_stream = stream
@@ -178,7 +181,20 @@ class Context:
 _default_ctx = {}
 
 
-def default_context(device: int = 0) -> Context:
+def default_device() -> int:
+    """The GPU of this process: torch's current device — one process per GPU, so under torchrun that is
+    LOCAL_RANK once the launcher (or init_distributed) has called torch.cuda.set_device — else LOCAL_RANK, else 0."""
+    if torch.cuda.is_available():
+        cur = torch.cuda.current_device()
+        if cur != 0 or "LOCAL_RANK" not in os.environ:
+            return cur
+        lr = int(os.environ["LOCAL_RANK"])
+        return lr if lr < torch.cuda.device_count() else cur
+    return 0
+
+
+def default_context(device: int | None = None) -> Context:
+    device = default_device() if device is None else int(device)
     if device not in _default_ctx:
         _default_ctx[device] = Context(device)
     return _default_ctx[device]

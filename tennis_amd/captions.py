@@ -110,20 +110,34 @@ def pad_batchify(samples):
     return tuple(out)
 
 
-def bucketed_batches(dataset, batch_size, num_buckets=5):
-    """Stand-in for ``FixedBucketSampler(lengths=target_lengths, shuffle=False)`` with constant-width
-    buckets (utils/captioning.py:62-86): samples are grouped by target length so padding stays small;
-    instance ids travel with the batch, evaluate() restores the dataset order."""
+def bucketed_batches(dataset, batch_size, num_buckets=5, shuffle=False, seed=0, epoch=0, rank=0, world=1):
+    """Stand-in for ``FixedBucketSampler(lengths, batch_size, num_buckets, shuffle)`` with constant-width buckets:
+    samples are grouped by target length so padding stays small; instance ids travel with the batch, evaluate()
+    restores the dataset order.  ``shuffle=False`` is the reference's validation / test sampler
+    (utils/captioning.py:62-86); ``shuffle=True`` its TRAINING sampler (:48-55): the samples of a bucket are permuted
+    before they are cut into batches and the batches are visited in random order, afresh every epoch
+    (``default_rng(seed + epoch)``).  ``rank`` / ``world``: a data-parallel rank takes batches rank::world of that
+    (identically seeded) list, padded by wrapping so that every rank runs the same number of steps."""
     lens = [l[-1] for l in dataset.get_data_lens()]
     lo, hi = min(lens), max(lens)
     width = max(1, math.ceil((hi - lo + 1) / num_buckets))
     buckets = {}
     for i, l in enumerate(lens):
         buckets.setdefault((l - lo) // width, []).append(i)
+    rng = np.random.default_rng(seed + epoch) if shuffle else None
+    batches = []
     for k in sorted(buckets):
         idxs = buckets[k]
-        for s in range(0, len(idxs), batch_size):
-            yield pad_batchify([dataset[i] for i in idxs[s:s + batch_size]])
+        if shuffle:
+            idxs = [idxs[j] for j in rng.permutation(len(idxs))]
+        batches += [idxs[s:s + batch_size] for s in range(0, len(idxs), batch_size)]
+    if shuffle:
+        batches = [batches[j] for j in rng.permutation(len(batches))]
+    if world > 1:
+        n = -(-len(batches) // world) * world
+        batches = [batches[j % len(batches)] for j in range(n)][rank::world]
+    for ids in batches:
+        yield pad_batchify([dataset[i] for i in ids])
 
 
 def write_sentences(sentences, file_path):                             # utils/captioning.py:89-95

@@ -25,7 +25,7 @@ extern "C" int tn_ctx_create(int device, void *stream, int own_stream, tn_ctx **
   int n = 0;
   TN_HIP_CHECK(hipGetDeviceCount(&n));
   TN_REQUIRE(device >= 0 && device < n, "tn_ctx_create: no such device");
-  TN_HIP_CHECK(hipSetDevice(device));
+  TN_ON_DEVICE(device);
   tn_ctx *c = new tn_ctx();
   c->device = device;
   c->own_stream = own_stream != 0;
@@ -256,7 +256,7 @@ extern "C" int tn_densenet121_create(tn_ctx *ctx, const tn_param *params, int n_
   TN_REQUIRE(max_batch > 0, "tn_densenet121_create: max_batch must be positive");
   TN_REQUIRE(height >= 224 && width >= 224 && height <= 1024 && width <= 1024,
              "tn_densenet121_create: input size must be in [224,1024] (AvgPool2D(7) needs a >=7x7 final map)");
-  TN_HIP_CHECK(hipSetDevice(ctx->device));
+  TN_ON_DEVICE(ctx->device);
   const std::string pre(prefix_c);
   ParamMap pm(params, n_params);
   tn_encoder *e = new tn_encoder();
@@ -393,7 +393,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
         fl += 2.0 * M * (128.0 * L.cin + 32.0 * 1152);
         by += (double)M * (L.cin + 32) * 2 + 128.0 * L.cin * 2 + 32.0 * 1152 * 2;
       }
-      tm.begin("dense_block_chained", fl, by);
+      tm.begin(Hh == 14 ? "dense_block_chained_14x14" : "dense_block_chained_7x7", fl, by);
       rc = launch_dense_layer(af, s);
       tm.end();
       if (rc) return rc;
@@ -401,7 +401,8 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
     for (auto &L : e->layers[b]) {
       if (fused) {
         DenseLayerArgs af{bbuf[b], e->Cb[b], L.cin, L.s1, L.t1, L.w1, L.s2, L.t2, L.w3p, B, Hh, Ww, nullptr, e->dl_variant};
-        tm.begin("dense_layer_fused", 2.0 * M * (128.0 * L.cin + 32.0 * 1152),
+        const std::string fam = "dense_layer_fused_" + std::to_string(Hh) + "x" + std::to_string(Ww);
+        tm.begin(fam.c_str(), 2.0 * M * (128.0 * L.cin + 32.0 * 1152),
                  (double)M * (L.cin + 32) * 2 + 128.0 * L.cin * 2 + 32.0 * 1152 * 2);
         rc = launch_dense_layer(af, s);
         tm.end();
@@ -439,7 +440,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
 static int encoder_run(tn_encoder *e, const void *x, tn_layout layout, int B, float *feat, EventTimer &tm) {
   TN_REQUIRE(e && x && feat, "tn_densenet121_forward: null argument");
   TN_REQUIRE(B > 0 && B <= e->maxB, "tn_densenet121_forward: batch exceeds max_batch");
-  TN_HIP_CHECK(hipSetDevice(e->ctx->device));
+  TN_ON_DEVICE(e->ctx->device);
   hipStream_t s = e->ctx->stream;
   e->last_batch = B;
   // Large batches run as two half-batches on two side streams: the halves drift apart, so one
@@ -516,7 +517,7 @@ extern "C" int tn_densenet121_read_tap(tn_encoder *e, const char *tap_c, int bat
 
 extern "C" int tn_densenet121_destroy(tn_encoder *enc) {
   if (!enc) return TN_OK;
-  (void)hipSetDevice(enc->ctx->device);
+  TnDeviceGuard tn_dg_(enc->ctx->device);
   for (int i = 0; i < 4; ++i) { (void)hipStreamSynchronize(enc->side[i]); (void)hipStreamDestroy(enc->side[i]); (void)hipEventDestroy(enc->ev_done[i]); }
   (void)hipEventDestroy(enc->ev_in);
   enc->pool.release();
@@ -536,7 +537,7 @@ extern "C" int tn_dense_create(tn_ctx *ctx, const float *weight_host, const floa
                                int in_units, tn_dense **out) {
   TN_REQUIRE(ctx && weight_host && out, "tn_dense_create: null argument");
   TN_REQUIRE(units > 0 && in_units > 0, "tn_dense_create: bad shape");
-  TN_HIP_CHECK(hipSetDevice(ctx->device));
+  TN_ON_DEVICE(ctx->device);
   tn_dense *d = new tn_dense();
   d->ctx = ctx; d->units = units; d->in_units = in_units;
   d->w = d->pool.upload(std::vector<float>(weight_host, weight_host + (size_t)units * in_units));
@@ -548,13 +549,13 @@ extern "C" int tn_dense_create(tn_ctx *ctx, const float *weight_host, const floa
 extern "C" int tn_dense_forward(tn_dense *d, const float *x, int rows, float *y) {
   TN_REQUIRE(d && x && y, "tn_dense_forward: null argument");
   TN_REQUIRE(rows >= 0, "tn_dense_forward: negative rows");
-  TN_HIP_CHECK(hipSetDevice(d->ctx->device));
+  TN_ON_DEVICE(d->ctx->device);
   return launch_linear_f32(x, d->in_units, d->w, d->in_units, d->b, y, d->units, rows, d->units, d->in_units, 0,
                            d->ctx->stream);
 }
 extern "C" int tn_dense_destroy(tn_dense *d) {
   if (!d) return TN_OK;
-  (void)hipSetDevice(d->ctx->device);
+  TnDeviceGuard tn_dg_(d->ctx->device);
   d->pool.release();
   delete d;
   return TN_OK;
@@ -579,7 +580,7 @@ extern "C" int tn_birnn_create(tn_ctx *ctx, tn_rnn_kind kind, int input_size, in
   TN_REQUIRE(input_size > 0 && hidden > 0 && hidden % 4 == 0 && max_rows > 0, "tn_birnn_create: bad shape");
   const int G = kind == TN_RNN_GRU ? 3 : 4;
   TN_REQUIRE(G * hidden <= 1024, "tn_birnn_create: gates*hidden must be <= 1024");
-  TN_HIP_CHECK(hipSetDevice(ctx->device));
+  TN_ON_DEVICE(ctx->device);
   const std::string pre(prefix_c);
   ParamMap pm(params, n_params);
   const int dirs = bidirectional ? 2 : 1, GH = G * hidden;
@@ -613,7 +614,7 @@ extern "C" int tn_birnn_forward(tn_birnn *r, const float *x, int batch, int step
                                 float *seq, float *h_last, float *c_last) {
   TN_REQUIRE(r && x && seq, "tn_birnn_forward: null argument");
   TN_REQUIRE(batch > 0 && steps > 0 && (long)batch * steps <= r->max_rows, "tn_birnn_forward: B*T exceeds max_rows");
-  TN_HIP_CHECK(hipSetDevice(r->ctx->device));
+  TN_ON_DEVICE(r->ctx->device);
   hipStream_t s = r->ctx->stream;
   const int GH = r->gates * r->H, N = r->dirs * GH, rows = batch * steps;
   int rc = launch_linear_f32(x, r->F, r->wi, r->F, r->bi, r->gi, N, rows, N, r->F, 0, s);
@@ -624,7 +625,7 @@ extern "C" int tn_birnn_forward(tn_birnn *r, const float *x, int batch, int step
 }
 extern "C" int tn_birnn_destroy(tn_birnn *r) {
   if (!r) return TN_OK;
-  (void)hipSetDevice(r->ctx->device);
+  TnDeviceGuard tn_dg_(r->ctx->device);
   r->pool.release();
   delete r;
   return TN_OK;
@@ -662,7 +663,7 @@ extern "C" int tn_head_create(tn_ctx *ctx, tn_rnn_kind kind, int input_size, int
   const int G = kind == TN_RNN_GRU ? 3 : 4;
   TN_REQUIRE(input_size > 0 && hidden > 0 && hidden % 4 == 0 && G * hidden <= 1024 && classes > 0 && max_batch > 0 &&
                  max_steps > 0, "tn_head_create: bad shape (gates*hidden must be <= 1024, hidden % 4 == 0)");
-  TN_HIP_CHECK(hipSetDevice(ctx->device));
+  TN_ON_DEVICE(ctx->device);
   ParamMap pm(params, n_params);
   const int F = input_size, H = hidden, C = classes, GH = G * hidden;
   tn_head *h = new tn_head();
@@ -708,7 +709,7 @@ extern "C" int tn_head_forward_backward(tn_head *h, const float *x, const int32_
                                         float *logits) {
   TN_REQUIRE(h && x && labels, "tn_head_forward_backward: null argument");
   TN_REQUIRE(B > 0 && B <= h->maxB && T > 0 && T <= h->maxT, "tn_head_forward_backward: batch / steps exceed the maxima");
-  TN_HIP_CHECK(hipSetDevice(h->ctx->device));
+  TN_ON_DEVICE(h->ctx->device);
   hipStream_t s = h->ctx->stream;
   const int F = h->F, H = h->H, C = h->C, GH = h->G * h->H, M = B * T;
   const bool lstm = h->G == 4;
@@ -750,7 +751,7 @@ extern "C" int tn_head_buffers(tn_head *h, float **params_dev, float **grads_dev
 
 extern "C" int tn_head_sgd_step(tn_head *h, float lr, float momentum, float wd, float rescale_grad) {
   TN_REQUIRE(h, "tn_head_sgd_step: null handle");
-  TN_HIP_CHECK(hipSetDevice(h->ctx->device));
+  TN_ON_DEVICE(h->ctx->device);
   int rc = launch_sgd_momentum(h->w, h->g, h->mom, h->n, lr, momentum, wd, rescale_grad, h->ctx->stream);
   if (rc) return rc;
   return head_refresh_whT(h);
@@ -773,7 +774,7 @@ extern "C" int tn_head_read_param(tn_head *h, const char *name_c, int gradient, 
   if (name == h->dense_prefix + "bias") { off = h->o_bd; cnt = h->C; }
   TN_REQUIRE(off >= 0, "tn_head_read_param: unknown parameter name");
   TN_REQUIRE(capacity >= cnt, "tn_head_read_param: host buffer too small");
-  TN_HIP_CHECK(hipSetDevice(h->ctx->device));
+  TN_ON_DEVICE(h->ctx->device);
   TN_HIP_CHECK(hipStreamSynchronize(h->ctx->stream));
   TN_HIP_CHECK(hipMemcpy(out_host, (gradient ? h->g : h->w) + off, sizeof(float) * cnt, hipMemcpyDeviceToHost));
   *numel = cnt;
@@ -782,7 +783,7 @@ extern "C" int tn_head_read_param(tn_head *h, const char *name_c, int gradient, 
 
 extern "C" int tn_head_destroy(tn_head *h) {
   if (!h) return TN_OK;
-  (void)hipSetDevice(h->ctx->device);
+  TnDeviceGuard tn_dg_(h->ctx->device);
   (void)hipStreamSynchronize(h->ctx->stream);
   h->pool.release();
   delete h;
@@ -795,7 +796,7 @@ extern "C" int tn_temporal_pool(tn_ctx *ctx, const float *x, int batch, int step
   TN_REQUIRE(ctx && x && y, "tn_temporal_pool: null argument");
   TN_REQUIRE(batch > 0 && steps > 0 && feat > 0, "tn_temporal_pool: bad shape");
   TN_REQUIRE(kind == TN_POOL_MAX || kind == TN_POOL_MEAN, "tn_temporal_pool: unknown pool kind");
-  TN_HIP_CHECK(hipSetDevice(ctx->device));
+  TN_ON_DEVICE(ctx->device);
   return launch_temporal_pool(x, batch, steps, feat, (int)kind, y, ctx->stream);
 }
 
@@ -804,6 +805,6 @@ extern "C" int tn_prf1_update(tn_ctx *ctx, const float *logits, const int32_t *l
   TN_REQUIRE(ctx && logits && labels && mat, "tn_prf1_update: null argument");
   TN_REQUIRE(rows >= 0 && classes > 0, "tn_prf1_update: bad shape");
   if (rows == 0) return TN_OK;
-  TN_HIP_CHECK(hipSetDevice(ctx->device));
+  TN_ON_DEVICE(ctx->device);
   return launch_prf1(logits, labels, rows, classes, mat, ctx->stream);
 }

@@ -790,7 +790,7 @@ extern "C" int tn_gnmt_create(tn_ctx *ctx, const tn_param *params, int n_params,
   TN_REQUIRE(beam >= 1 && beam <= 16 && vocab >= beam && max_length >= 1, "tn_gnmt_create: bad beam/vocab/max_length");
   TN_REQUIRE(input_size > 0 && hidden > 0 && hidden % 4 == 0 && embed > 0 && max_batch > 0 && max_src_len > 0,
              "tn_gnmt_create: bad shape");
-  TN_HIP_CHECK(hipSetDevice(ctx->device));
+  TN_ON_DEVICE(ctx->device);
   const std::string pre(prefix_c);
   std::map<std::string, const tn_param *> pm;
   for (int i = 0; i < n_params; ++i) pm[params[i].name] = &params[i];
@@ -899,7 +899,7 @@ extern "C" int tn_gnmt_create(tn_ctx *ctx, const tn_param *params, int n_params,
 extern "C" int tn_gnmt_encode(tn_gnmt *g, const float *src, const int32_t *valid_len, int batch, int steps, float *mem_out) {
   TN_REQUIRE(g && src && valid_len, "tn_gnmt_encode: null argument");
   TN_REQUIRE(batch > 0 && batch <= g->maxB && steps > 0 && steps <= g->maxT, "tn_gnmt_encode: batch/steps exceed the handle");
-  TN_HIP_CHECK(hipSetDevice(g->ctx->device));
+  TN_ON_DEVICE(g->ctx->device);
   hipStream_t s = g->ctx->stream;
   const int H = g->H;
   TN_HIP_CHECK(hipMemcpyAsync(g->vl, valid_len, sizeof(int32_t) * batch, hipMemcpyDeviceToDevice, s));
@@ -926,7 +926,7 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
   TN_REQUIRE(g->B > 0, "tn_gnmt_beam_search: call tn_gnmt_encode first");
   TN_REQUIRE(max_length >= 1 && max_length + 2 <= g->maxL, "tn_gnmt_beam_search: max_length exceeds the handle");
   TN_REQUIRE(bos >= 0 && bos < g->V && eos >= 0 && eos < g->V, "tn_gnmt_beam_search: bos/eos outside the vocabulary");
-  TN_HIP_CHECK(hipSetDevice(g->ctx->device));
+  TN_ON_DEVICE(g->ctx->device);
   hipStream_t s = g->ctx->stream;
   const int B = g->B, T = g->T, H = g->H, E = g->E, V = g->V, beam = g->beam, R = B * beam, L = g->maxL;
   const int K0 = E + 2 * H, K1 = 3 * H;
@@ -1005,7 +1005,7 @@ extern "C" int tn_gnmt_decode_seq(tn_gnmt *g, const int32_t *tgt, int ld, int st
   TN_REQUIRE(g && tgt && logits, "tn_gnmt_decode_seq: null argument");
   TN_REQUIRE(g->B > 0, "tn_gnmt_decode_seq: call tn_gnmt_encode first");
   TN_REQUIRE(steps >= 1 && ld >= steps, "tn_gnmt_decode_seq: bad target length");
-  TN_HIP_CHECK(hipSetDevice(g->ctx->device));
+  TN_ON_DEVICE(g->ctx->device);
   hipStream_t s = g->ctx->stream;
   const int B = g->B, T = g->T, H = g->H, E = g->E, V = g->V, R = B, K0 = E + 2 * H, K1 = 3 * H;
   const bool lstm = g->G == 4;
@@ -1040,7 +1040,7 @@ extern "C" int tn_masked_softmax_ce(tn_ctx *ctx, const float *logits, const int3
                                     const int32_t *valid_len, int batch, int steps, int vocab, float *loss) {
   TN_REQUIRE(ctx && logits && labels && valid_len && loss, "tn_masked_softmax_ce: null argument");
   TN_REQUIRE(batch > 0 && steps > 0 && vocab > 0 && ld_labels >= steps, "tn_masked_softmax_ce: bad shape");
-  TN_HIP_CHECK(hipSetDevice(ctx->device));
+  TN_ON_DEVICE(ctx->device);
   hipLaunchKernelGGL(masked_ce_kernel, dim3(batch), dim3(256), 0, ctx->stream, logits, labels, ld_labels, valid_len, loss, steps, vocab);
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;
@@ -1106,7 +1106,7 @@ extern "C" int tn_gnmt_trainer_create(tn_ctx *ctx, const tn_param *params, int n
   const int G_ = cell_kind == TN_RNN_GRU ? 3 : 4;
   TN_REQUIRE(input_size > 0 && hidden > 0 && hidden % 4 == 0 && G_ * hidden <= 1024 && embed > 0 && vocab > 1 && max_batch > 0 &&
                  max_src_len > 0 && max_tgt_len > 1, "tn_gnmt_trainer_create: bad shape (gates*hidden <= 1024, hidden % 4 == 0)");
-  TN_HIP_CHECK(hipSetDevice(ctx->device));
+  TN_ON_DEVICE(ctx->device);
   const std::string pre(prefix_c);
   std::map<std::string, const tn_param *> pm;
   for (int i = 0; i < n_params; ++i) pm[params[i].name] = &params[i];
@@ -1192,7 +1192,7 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
   TN_REQUIRE(t && src && src_valid_len && tgt && tgt_valid_len && loss, "tn_gnmt_trainer_forward_backward: null argument");
   TN_REQUIRE(batch > 0 && batch <= t->maxB && steps > 0 && steps <= t->maxT && tgt_len >= 2 && tgt_len - 1 <= t->maxL && ld >= tgt_len,
              "tn_gnmt_trainer_forward_backward: batch / source steps / target length exceed the handle");
-  TN_HIP_CHECK(hipSetDevice(t->ctx->device));
+  TN_ON_DEVICE(t->ctx->device);
   hipStream_t s = t->ctx->stream;
   const int B = batch, T = steps, L = tgt_len - 1, F = t->F, H = t->H, E = t->E, V = t->V, G = t->G, GH = G * H, K0 = E + 2 * H, K1 = 3 * H;
   const int BT = B * T, LB = L * B;
@@ -1376,7 +1376,7 @@ extern "C" int tn_gnmt_trainer_buffers(tn_gnmt_trainer *t, float **params_dev, f
 // epsilon 1e-8, no weight decay, no clipping, rescale_grad 1
 extern "C" int tn_gnmt_trainer_adam_step(tn_gnmt_trainer *t, float lr, float beta1, float beta2, float epsilon) {
   TN_REQUIRE(t, "tn_gnmt_trainer_adam_step: null handle");
-  TN_HIP_CHECK(hipSetDevice(t->ctx->device));
+  TN_ON_DEVICE(t->ctx->device);
   t->step += 1;
   const double c1 = 1.0 - pow((double)beta1, (double)t->step), c2 = 1.0 - pow((double)beta2, (double)t->step);
   const float lr_t = (float)((double)lr * sqrt(c2) / c1);
@@ -1409,7 +1409,7 @@ extern "C" int tn_gnmt_trainer_read_param(tn_gnmt_trainer *t, const char *name_c
   if (name == pre + "tgt_embed_weight") { off = t->o_emb; cnt = V * E; }
   TN_REQUIRE(off >= 0, "tn_gnmt_trainer_read_param: unknown parameter name");
   TN_REQUIRE(capacity >= cnt, "tn_gnmt_trainer_read_param: host buffer too small");
-  TN_HIP_CHECK(hipSetDevice(t->ctx->device));
+  TN_ON_DEVICE(t->ctx->device);
   TN_HIP_CHECK(hipStreamSynchronize(t->ctx->stream));
   TN_HIP_CHECK(hipMemcpy(out_host, (gradient ? t->g : t->w) + off, sizeof(float) * cnt, hipMemcpyDeviceToHost));
   *numel = cnt;
@@ -1418,7 +1418,7 @@ extern "C" int tn_gnmt_trainer_read_param(tn_gnmt_trainer *t, const char *name_c
 
 extern "C" int tn_gnmt_trainer_destroy(tn_gnmt_trainer *t) {
   if (!t) return TN_OK;
-  (void)hipSetDevice(t->ctx->device);
+  TnDeviceGuard tn_dg_(t->ctx->device);
   (void)hipStreamSynchronize(t->ctx->stream);
   t->pool.release();
   delete t;
@@ -1435,7 +1435,7 @@ extern "C" int tn_dbg_dec_stamps(long long *out) {
 
 extern "C" int tn_gnmt_destroy(tn_gnmt *g) {
   if (!g) return TN_OK;
-  (void)hipSetDevice(g->ctx->device);
+  TnDeviceGuard tn_dg_(g->ctx->device);
   tn_birnn_destroy(g->enc0);
   tn_birnn_destroy(g->enc1);
   g->pool.release();

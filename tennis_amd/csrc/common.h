@@ -31,6 +31,31 @@ void tn_set_error(const std::string &msg);
     }                                                                                  \
   } while (0)
 
+// Makes `dev` the calling thread's current HIP device for the rest of the scope and puts the previous one back
+// on exit: the library never leaves the caller's (torch's) current device changed behind its back.
+struct TnDeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit TnDeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev == dev) prev = -1;
+    else ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~TnDeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  TnDeviceGuard(const TnDeviceGuard &) = delete;
+  TnDeviceGuard &operator=(const TnDeviceGuard &) = delete;
+};
+#define TN_DG_CAT2(a, b) a##b
+#define TN_DG_CAT(a, b) TN_DG_CAT2(a, b)
+#define TN_ON_DEVICE(dev)                                                              \
+  TnDeviceGuard TN_DG_CAT(tn_dg_, __LINE__)(dev);                                      \
+  if (!TN_DG_CAT(tn_dg_, __LINE__).ok) {                                               \
+    tn_set_error("hipSetDevice failed");                                               \
+    return TN_ERR_HIP;                                                                 \
+  }
+
 struct tn_ctx {
   int device;
   hipStream_t stream;

@@ -53,7 +53,7 @@ extern "C" int tn_dbg_conv1x1(tn_ctx *ctx, const void *x_f16, int ldx, int K, co
                               const float *shift_host, const float *w_host /*[N][K]*/, int N, void *y_f16, int ldy,
                               int yoff, int M, int pool, int H, int W) {
   TN_REQUIRE(ctx && x_f16 && y_f16 && scale_host && shift_host && w_host, "tn_dbg_conv1x1: null argument");
-  TN_HIP_CHECK(hipSetDevice(ctx->device));
+  TN_ON_DEVICE(ctx->device);
   std::vector<f16> wh((size_t)N * K);
   for (size_t i = 0; i < wh.size(); ++i) wh[i] = (f16)w_host[i];
   f16 *w = up(wh);
@@ -72,7 +72,7 @@ extern "C" int tn_dbg_conv1x1(tn_ctx *ctx, const void *x_f16, int ldx, int K, co
 extern "C" int tn_dbg_conv3x3(tn_ctx *ctx, const void *x_f16, const float *scale_host, const float *shift_host,
                               const float *w_host, void *y_f16, int ldy, int yoff, int B, int H, int W) {
   TN_REQUIRE(ctx && x_f16 && y_f16 && scale_host && shift_host && w_host, "tn_dbg_conv3x3: null argument");
-  TN_HIP_CHECK(hipSetDevice(ctx->device));
+  TN_ON_DEVICE(ctx->device);
   f16 *w = up(pack_conv3x3(w_host));
   float *s = up(std::vector<float>(scale_host, scale_host + 128));
   float *t = up(std::vector<float>(shift_host, shift_host + 128));
@@ -100,6 +100,6 @@ extern "C" int tn_dbg_dense_layer_dev(tn_ctx *ctx, void *buf_f16, int ldc, int K
 extern "C" int tn_dbg_linear(tn_ctx *ctx, const float *x, const float *w, const float *bias, float *y, int M, int N,
                              int K) {
   TN_REQUIRE(ctx && x && w && y, "tn_dbg_linear: null argument");
-  TN_HIP_CHECK(hipSetDevice(ctx->device));
+  TN_ON_DEVICE(ctx->device);
   return launch_linear_f32(x, K, w, K, bias, y, N, M, N, K, 0, ctx->stream);
 }

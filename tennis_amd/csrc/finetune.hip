@@ -383,7 +383,7 @@ extern "C" int tn_finetune_create(tn_ctx *ctx, const tn_param *params, int n_par
   TN_REQUIRE(ctx && params && backbone_prefix && dense_prefix && out, "tn_finetune_create: null argument");
   TN_REQUIRE(height > 0 && width > 0 && height % 32 == 0 && width % 32 == 0 && height == width && classes > 0 && batch > 0,
              "tn_finetune_create: frames must be square with a side divisible by 32");
-  TN_HIP_CHECK(hipSetDevice(ctx->device));
+  TN_ON_DEVICE(ctx->device);
   std::map<std::string, const tn_param *> pm;
   for (int i = 0; i < n_params; ++i) pm[params[i].name] = &params[i];
   tn_finetune *f = new tn_finetune();
@@ -505,11 +505,12 @@ extern "C" int tn_finetune_create(tn_ctx *ctx, const tn_param *params, int n_par
 // x (batch, H, W, 3) fp32 normalised frames (NHWC), labels (batch,) int32, both DEVICE.  Runs the training-mode forward,
 // the per-sample softmax cross-entropy and the backward of their SUM; loss (batch,) / logits (batch, classes) optional
 // device outputs.  Gradients land in the flat buffer (tn_finetune_buffers); BatchNorm running statistics are updated.
-extern "C" int tn_finetune_forward_backward(tn_finetune *f, const float *x, const int32_t *labels, int batch, float *loss,
-                                            float *logits) {
+extern "C" int tn_finetune_forward_backward(tn_finetune *f, const float *x, const int32_t *labels, int batch, int height, int width,
+                                            float *loss, float *logits) {
   TN_REQUIRE(f && x && labels, "tn_finetune_forward_backward: null argument");
+  TN_REQUIRE(height == f->H && width == f->W, "tn_finetune_forward_backward: the frame size must equal the handle's");
   TN_REQUIRE(batch == f->B, "tn_finetune_forward_backward: the batch must equal the handle's (BatchNorm statistics are per batch)");
-  TN_HIP_CHECK(hipSetDevice(f->ctx->device));
+  TN_ON_DEVICE(f->ctx->device);
   hipStream_t s = f->ctx->stream;
   const int B = f->B, H = f->H, W = f->W, NC = f->classes;
   const long M0 = (long)B * (H / 2) * (W / 2);
@@ -618,7 +619,7 @@ extern "C" int tn_finetune_buffers(tn_finetune *f, float **params_dev, float **g
 
 extern "C" int tn_finetune_sgd_step(tn_finetune *f, float lr, float momentum, float wd, float rescale_grad) {
   TN_REQUIRE(f, "tn_finetune_sgd_step: null handle");
-  TN_HIP_CHECK(hipSetDevice(f->ctx->device));
+  TN_ON_DEVICE(f->ctx->device);
   return launch_sgd_momentum(f->w, f->g, f->mom, f->n, lr, momentum, wd, rescale_grad, f->ctx->stream);
 }
 
@@ -628,7 +629,7 @@ extern "C" int tn_finetune_read_param(tn_finetune *f, const char *name_c, int gr
                                       int64_t *numel) {
   TN_REQUIRE(f && name_c && out_host && numel, "tn_finetune_read_param: null argument");
   const std::string name(name_c);
-  TN_HIP_CHECK(hipSetDevice(f->ctx->device));
+  TN_ON_DEVICE(f->ctx->device);
   TN_HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
   const float *base = gradient ? f->g : f->w;
   auto copy = [&](const float *dev, long cnt) -> int {
@@ -676,7 +677,7 @@ extern "C" int tn_finetune_read_param(tn_finetune *f, const char *name_c, int gr
 
 extern "C" int tn_finetune_destroy(tn_finetune *f) {
   if (!f) return TN_OK;
-  (void)hipSetDevice(f->ctx->device);
+  TnDeviceGuard tn_dg_(f->ctx->device);
   (void)hipStreamSynchronize(f->ctx->stream);
   f->pool.release();
   delete f;

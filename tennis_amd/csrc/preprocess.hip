@@ -78,7 +78,7 @@ extern "C" int tn_preproc_create(tn_ctx *ctx, int src_h, int src_w, int resize, 
   TN_REQUIRE(ctx && out, "tn_preproc_create: null argument");
   TN_REQUIRE(src_h > 0 && src_w > 0 && resize > 0 && crop > 0, "tn_preproc_create: bad shape");
   TN_REQUIRE(crop <= resize, "tn_preproc_create: crop larger than the resized frame (CenterCrop would rescale: unsupported)");
-  TN_HIP_CHECK(hipSetDevice(ctx->device));
+  TN_ON_DEVICE(ctx->device);
   std::vector<Tap> xt, yt;
   make_taps(src_w, resize, true, xt);
   make_taps(src_h, resize, false, yt);
@@ -101,16 +101,54 @@ extern "C" int tn_preproc_create(tn_ctx *ctx, int src_h, int src_w, int resize, 
 extern "C" int tn_preproc_forward(tn_preproc *p, const uint8_t *src, int batch, uint8_t *dst) {
   TN_REQUIRE(p && src && dst, "tn_preproc_forward: null argument");
   TN_REQUIRE(batch > 0 && batch <= 65535, "tn_preproc_forward: batch must be in 1..65535");
-  TN_HIP_CHECK(hipSetDevice(p->ctx->device));
+  TN_ON_DEVICE(p->ctx->device);
   hipLaunchKernelGGL(resize_crop_u8_kernel, dim3((p->crop + 255) / 256, p->crop, batch), dim3(256), 0, p->ctx->stream, src,
                      p->Hs, p->Ws, (const Tap *)p->xt, (const Tap *)p->yt, p->x0, p->y0, p->crop, p->box2, dst);
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;
 }
 
+// ToTensor + Normalize of the transform (evaluate.py:96-97, train.py:138) for consumers that want fp32 frames (the
+// fine-tuning step): y = (x / 255 - mean[c]) / std[c], NHWC in, NHWC out.  4 pixels (12 bytes) per thread.
+__global__ __launch_bounds__(256) void to_tensor_normalize_kernel(const uint8_t *__restrict__ src, long npix, float m0, float m1, float m2,
+                                                                   float i0, float i1, float i2, float *__restrict__ dst) {
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;     // group of 4 pixels
+  const long p0 = q * 4;
+  if (p0 >= npix) return;
+  const float mean[3] = {m0, m1, m2}, inv[3] = {i0, i1, i2};
+  if (p0 + 4 <= npix) {
+    const uint32_t *s32 = (const uint32_t *)(src + p0 * 3);
+    const uint32_t a = s32[0], b = s32[1], c = s32[2];
+    const uint8_t v[12] = {(uint8_t)a, (uint8_t)(a >> 8), (uint8_t)(a >> 16), (uint8_t)(a >> 24), (uint8_t)b, (uint8_t)(b >> 8),
+                           (uint8_t)(b >> 16), (uint8_t)(b >> 24), (uint8_t)c, (uint8_t)(c >> 8), (uint8_t)(c >> 16), (uint8_t)(c >> 24)};
+    float o[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) o[j] = ((float)v[j] / 255.0f - mean[j % 3]) * inv[j % 3];
+    float4 *d4 = (float4 *)(dst + p0 * 3);
+    d4[0] = make_float4(o[0], o[1], o[2], o[3]);
+    d4[1] = make_float4(o[4], o[5], o[6], o[7]);
+    d4[2] = make_float4(o[8], o[9], o[10], o[11]);
+  } else {
+    for (long p = p0; p < npix; ++p)
+      for (int c = 0; c < 3; ++c) dst[p * 3 + c] = ((float)src[p * 3 + c] / 255.0f - mean[c]) * inv[c];
+  }
+}
+
+extern "C" int tn_to_tensor_normalize(tn_ctx *ctx, const uint8_t *src, long pixels, const float *mean3, const float *std3, float *dst) {
+  TN_REQUIRE(ctx && src && dst && mean3 && std3, "tn_to_tensor_normalize: null argument");
+  TN_REQUIRE(pixels > 0, "tn_to_tensor_normalize: no pixels");
+  TN_REQUIRE(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "tn_to_tensor_normalize: zero std");
+  TN_ON_DEVICE(ctx->device);
+  const long groups = (pixels + 3) / 4;
+  hipLaunchKernelGGL(to_tensor_normalize_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, ctx->stream, src, pixels, mean3[0],
+                     mean3[1], mean3[2], 1.0f / std3[0], 1.0f / std3[1], 1.0f / std3[2], dst);
+  TN_HIP_CHECK(hipGetLastError());
+  return TN_OK;
+}
+
 extern "C" int tn_preproc_destroy(tn_preproc *p) {
   if (!p) return TN_OK;
-  (void)hipSetDevice(p->ctx->device);
+  TnDeviceGuard tn_dg_(p->ctx->device);
   (void)hipStreamSynchronize(p->ctx->stream);
   (void)hipFree(p->xt);
   (void)hipFree(p->yt);

@@ -54,7 +54,7 @@ class TennisSet:
                  data_shape=224, videos=("V006", "V007"), frames_per_video=16, seed=1234, split_first=0,
                  video_length=None):
         if captions:
-            raise NotImplementedError("caption mode (dataset.py:154-183) is served by tennis_amd.captioning")
+            raise NotImplementedError("caption mode (dataset.py:154-183) is served by tennis_amd.captions.CaptionSet")
         if flow:
             raise NotImplementedError("optical-flow input is outside the accelerated hot path (SURVEY §2a)")
         self._root = root
@@ -291,6 +291,16 @@ class DataLoader:
         n = len(self.dataset)
         return n // self.batch_size if self.last_batch == "discard" else (n + self.batch_size - 1) // self.batch_size
 
+    def collate(self, ids):
+        """(data, labels, idxs) for the dataset items ``ids`` (what one iteration step yields)."""
+        items = [self.dataset[int(i)] for i in ids]
+        data = np.stack([it[0] for it in items])
+        tf = getattr(self.dataset, "_transform", None)
+        if getattr(tf, "device_batched", False) and not self.dataset._load_feats:
+            data = tf(data)                                                # one Resize+CenterCrop launch per batch
+        return (data, np.array([it[1] for it in items], dtype=np.float32),
+                np.array([it[2] for it in items], dtype=np.int64))
+
     def __iter__(self):
         n = len(self.dataset)
         order = self._rng.permutation(n) if self.shuffle else np.arange(n)
@@ -298,12 +308,4 @@ class DataLoader:
             ids = order[s:s + self.batch_size]
             if self.last_batch == "discard" and len(ids) < self.batch_size:
                 break
-            items = [self.dataset[int(i)] for i in ids]
-            tf = getattr(self.dataset, "_transform", None)
-            if getattr(tf, "device_batched", False) and not self.dataset._load_feats:
-                data = tf(np.stack([it[0] for it in items]))               # one Resize+CenterCrop launch per batch
-                yield (data, np.array([it[1] for it in items], dtype=np.float32),
-                       np.array([it[2] for it in items], dtype=np.int64))
-                continue
-            yield (np.stack([it[0] for it in items]), np.array([it[1] for it in items], dtype=np.float32),
-                   np.array([it[2] for it in items], dtype=np.int64))
+            yield self.collate(ids)

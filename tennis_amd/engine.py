@@ -15,6 +15,14 @@ from . import _lib
 from ._lib import check, ptr
 
 
+def _on_ctx_device(ctx, x: torch.Tensor, what: str):
+    """A handle's weights and workspace live on its context's GPU: inputs must be there too (one process per GPU)."""
+    if not x.is_cuda:
+        raise ValueError(f"{what}: input must already be on the GPU")
+    if x.device.index != ctx.device:
+        raise ValueError(f"{what}: input is on cuda:{x.device.index} but this handle was built on cuda:{ctx.device}")
+
+
 def _layout_of(x: torch.Tensor, size_hw):
     """Pick the tn_layout of a frame batch from dtype/shape (reference frames are
     NCHW float32 after ToTensor+Normalize, evaluate.py:96-97)."""
@@ -48,8 +56,7 @@ class DenseNet121Features:
         self.workspace_bytes = self.lib.tn_densenet121_workspace_bytes(h)
 
     def __call__(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
-        if not x.is_cuda:
-            raise ValueError("frames must already be on the GPU")
+        _on_ctx_device(self.ctx, x, "DenseNet121Features")
         x = x.contiguous()
         layout = _layout_of(x, self.size)
         b = x.shape[0]
@@ -109,6 +116,7 @@ class Dense:
         self.handle = h
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        _on_ctx_device(self.ctx, x, "Dense")
         x = x.reshape(x.shape[0], -1).contiguous().float()
         if x.shape[1] != self.in_units:
             raise ValueError(f"Dense expects {self.in_units} input units, got {x.shape[1]}")
@@ -144,6 +152,7 @@ class BiRNN:
         self.handle = h
 
     def __call__(self, x: torch.Tensor, valid_length: torch.Tensor | None = None, return_state: bool = False):
+        _on_ctx_device(self.ctx, x, "BiRNN")
         x = x.contiguous().float()
         b, t, f = x.shape
         if f != self.input_size:
@@ -167,13 +176,29 @@ class BiRNN:
 
 def temporal_pool(x: torch.Tensor, kind: str, ctx: _lib.Context | None = None) -> torch.Tensor:
     """``F.max(x, axis=1)`` / ``F.mean(x, axis=1)`` (definitions.py:66-69,107)."""
-    ctx = ctx or _lib.default_context()
+    ctx = ctx or _lib.default_context(x.device.index)
     x = x.contiguous().float()
     b, t = x.shape[:2]
     f = int(np.prod(x.shape[2:]))
     y = torch.empty((b,) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
     check(ctx.lib.tn_temporal_pool(ctx.handle, ptr(x), b, t, f, _lib.POOL_MEAN if kind == "mean" else _lib.POOL_MAX,
                                    ptr(y)), "tn_temporal_pool")
+    return y
+
+
+def to_tensor_normalize(x: torch.Tensor, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225),
+                        ctx: _lib.Context | None = None) -> torch.Tensor:
+    """``transforms.ToTensor()`` + ``transforms.Normalize(mean, std)`` (reference evaluate.py:96-97) on a uint8
+    (..., H, W, 3) device batch -> float32 of the same (NHWC) shape."""
+    ctx = ctx or _lib.default_context(x.device.index)
+    _on_ctx_device(ctx, x, "to_tensor_normalize")
+    if x.dtype != torch.uint8 or x.shape[-1] != 3:
+        raise ValueError(f"expected uint8 (..., H, W, 3) frames, got {tuple(x.shape)} {x.dtype}")
+    x = x.contiguous()
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    sd = (C.c_float * 3)(*[float(v) for v in std])
+    check(ctx.lib.tn_to_tensor_normalize(ctx.handle, ptr(x), x.numel() // 3, m, sd, ptr(y)), "tn_to_tensor_normalize")
     return y
 
 
@@ -238,7 +263,7 @@ class GNMTCaptioner:
 def masked_softmax_ce(logits: torch.Tensor, labels: torch.Tensor, valid_length: torch.Tensor,
                       ctx: _lib.Context | None = None) -> torch.Tensor:
     """``gluonnlp.loss.MaskedSoftmaxCELoss`` (reference train_gnmt.py:256,281): (B,) losses."""
-    ctx = ctx or _lib.default_context()
+    ctx = ctx or _lib.default_context(logits.device.index)
     logits = logits.contiguous().float()
     b, l, v = logits.shape
     lab = labels.to(logits.device).round().to(torch.int32).contiguous()
@@ -467,14 +492,21 @@ class FrameModelTrainer:
 
     def forward_backward(self, x: torch.Tensor, labels: torch.Tensor):
         """x: frames as NCHW fp32 (the reference layout) or NHWC fp32, normalised; labels (B,) -> (loss (B,), logits (B, classes))"""
-        if x.dim() == 4 and x.shape[1] == 3 and x.shape[3] != 3:
+        _on_ctx_device(self.ctx, x, "FrameModelTrainer")
+        sz = self.size
+        if x.dtype == torch.uint8:        # decoded frames out of transforms.Compose: ToTensor + Normalize here
+            x = to_tensor_normalize(x, ctx=self.ctx)
+        if x.dim() == 4 and tuple(x.shape[1:]) == (3, sz, sz):
             x = x.permute(0, 2, 3, 1)
+        if x.dim() != 4 or tuple(x.shape) != (self.batch, sz, sz, 3):
+            raise ValueError(f"FrameModelTrainer expects ({self.batch}, 3, {sz}, {sz}) or ({self.batch}, {sz}, {sz}, 3) frames "
+                             f"(apply the Resize/CenterCrop transform first), got {tuple(x.shape)}")
         x = x.contiguous().float()
         b = x.shape[0]
         labels = labels.to(device=x.device, dtype=torch.int32).contiguous()
         loss = torch.empty((b,), dtype=torch.float32, device=x.device)
         logits = torch.empty((b, self.classes), dtype=torch.float32, device=x.device)
-        check(self.lib.tn_finetune_forward_backward(self.handle, ptr(x), ptr(labels), b, ptr(loss), ptr(logits)),
+        check(self.lib.tn_finetune_forward_backward(self.handle, ptr(x), ptr(labels), b, sz, sz, ptr(loss), ptr(logits)),
               "tn_finetune_forward_backward")
         return loss, logits
 

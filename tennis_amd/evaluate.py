@@ -5,17 +5,27 @@ hot path: same flag names, ``save_features`` (evaluate.py:306-321) and
 Differences that are deliberate: one device per rank
 (no serialised per-device inner loop, no ``idxs`` rebinding bug), one D2H copy per
 batch instead of one per row, frames sharded by batch across ranks.
+
+``--num_gpus N`` (reference evaluate.py:101-102: the ``ctx`` list each batch is split over) starts N processes of
+this script, one per GPU (``sharding.launch``; under ``torch.distributed.run`` the ranks exist already):
+``--save_feats`` then goes through ``save_features_sharded`` — every rank encodes its batches, writes their
+``.npy`` files and the feature rows are all-gathered over RCCL so that each rank ends with the whole (N, F)
+matrix; testing shards the batches and sums the confusion matrices.  ``--corpus_frames N`` runs BASELINE config
+C4 — a synthetic N-frame corpus (786 455 = the 5-match corpus) through the same sharded encode +
+chunked, overlapped all-gather — and prints one JSON line with the rates.
 """
 from __future__ import annotations
 
 import argparse
+import json
 import os
+import sys
 import time
 
 import numpy as np
 import torch
 
-from . import transforms
+from . import sharding, transforms
 from .dataset import DataLoader, TennisSet
 from .metrics.vision import PRF1
 from .model_zoo import get_model
@@ -57,6 +67,112 @@ def save_features(net, loader, dataset, ctx=None, verbose=True):
     return written
 
 
+def _backbone_dim(net, loader):
+    """Feature width F of ``net.backbone`` (1024 at 224x224, 4096 at 512x512): asked of the engine when it exists,
+    else measured on the first sample."""
+    eng = getattr(net.backbone, "_engine", None)
+    if eng is not None and hasattr(eng, "feature_dim"):
+        return int(eng.feature_dim)
+    data, _, _ = loader.collate([0])
+    return int(net.backbone(data).shape[-1])
+
+
+def save_features_sharded(net, loader, dataset, device=None, rank=None, world=None, group=None, block=1, verbose=False,
+                          write=True, stats=None):
+    """``save_features`` (evaluate.py:306-321) for N ranks: rank r encodes the batches ``sharding.rank_batches`` gives
+    it (dataset order, no shuffle), writes their ``.npy`` files (skip-if-exists, as the reference) and the rows are
+    all-gathered round by round behind the compute.  Returns (features (len(dataset), F) in dataset order — identical
+    on every rank —, files written by this rank)."""
+    if rank is None or world is None:
+        rank, world = sharding._rank(group), sharding._world(group)
+    fdim = _backbone_dim(net, loader)
+    written = [0]
+
+    def encode(s, e):
+        data, _labels, idxs = loader.collate(range(s, e))
+        feat = net.backbone(data)
+        if write:
+            host = feat.detach().cpu().numpy()
+            for i, idx in enumerate(int(j) for j in idxs):
+                feat_path = dataset.save_feature_path(idx)
+                if not os.path.exists(feat_path):
+                    os.makedirs(os.path.dirname(feat_path), exist_ok=True)
+                    np.save(feat_path, host[i])
+                    written[0] += 1
+                    if verbose:
+                        print("Saving %s" % feat_path)
+        return feat
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    full = sharding.extract_features_sharded(encode, len(dataset), loader.batch_size, fdim, device, rank=rank, world=world,
+                                             group=group, block=block, stats=stats)
+    return full, written[0]
+
+
+class SyntheticCorpus:
+    """A corpus of ``n_frames`` synthetic decoded frames generated ON the device batch by batch (uint8 NHWC, seeded by
+    the global frame index range, so every rank produces the same frame for the same index): stands in for the
+    786 455 frames of the 5-match corpus, which cannot be shipped."""
+
+    def __init__(self, n_frames, size, device, seed=1234):
+        self.n, self.size, self.device, self.seed = int(n_frames), int(size), device, seed
+
+    def __len__(self):
+        return self.n
+
+    def frames(self, s, e):
+        g = torch.Generator(device=self.device)
+        g.manual_seed(self.seed + s)
+        return torch.randint(0, 256, (e - s, self.size, self.size, 3), generator=g, device=self.device, dtype=torch.uint8)
+
+
+def extract_corpus(backbone, n_frames, batch, size, device, rank, world, block=4, seed=1234, reuse_frames=False):
+    """BASELINE config C4: feature-extract over an ``n_frames`` corpus sharded over the ranks with the RCCL all-gather
+    of the rows (chunked: one collective per round of ``block`` batches per rank, in flight behind the next round).
+    Every batch of frames is generated on the device from its frame indices inside the loop (the result is then the
+    same for any number of ranks: the checksum of the gathered matrix is a parity check); ``reuse_frames`` generates
+    a rank's first batch once and re-uses it (frame synthesis is not part of the path).
+    -> (features (n_frames, F) on every rank, dict of timings)."""
+    corpus = SyntheticCorpus(n_frames, size, device, seed)
+    cached = {}
+
+    def encode(s, e):
+        if reuse_frames:
+            if (e - s) not in cached:
+                cached[e - s] = corpus.frames(s, e)
+            x = cached[e - s]
+        else:
+            x = corpus.frames(s, e)
+        return backbone(x)
+    fdim = int(backbone(corpus.frames(0, min(batch, n_frames))).shape[-1])      # also builds the engine (untimed)
+    fence = (lambda: (torch.distributed.barrier() if world > 1 else None, torch.cuda.synchronize() if device.type == "cuda" else None))
+    stats = {}
+    fence()
+    t0 = time.perf_counter()
+    full = sharding.extract_features_sharded(encode, n_frames, batch, fdim, device, rank=rank, world=world, block=block, stats=stats)
+    fence()
+    dt = time.perf_counter() - t0
+    stats.update(seconds=dt, frames_per_sec=n_frames / dt, feature_dim=fdim,
+                 gather_GBps_per_rank=(stats["gather_bytes_per_rank"] * max(world - 1, 0) / dt / 1e9))
+    return full, stats
+
+
+def best_or_newest_params(mod_path, need_scores):
+    """The parameter file the reference would load (evaluate.py:186-200,206-212,223-240): epoch with the best
+    ``scores.txt`` line; without a scores file the newest ``NNNN.params`` (None when the directory holds neither and
+    ``need_scores`` is False)."""
+    from .train import best_epoch_from_scores, newest_params
+    scores = os.path.join(mod_path, "scores.txt")
+    if os.path.exists(scores):
+        ep, sc = best_epoch_from_scores(scores)
+        if ep >= 0:
+            print("Testing best model from Epoch %d with score of %f" % (ep, sc))
+            return os.path.join(mod_path, "{:04d}.params".format(ep))
+    if need_scores and not os.path.isdir(mod_path):
+        return None
+    return newest_params(mod_path)
+
+
 def build_parser():
     p = argparse.ArgumentParser(description="tennis_amd evaluate (flags of reference evaluate.py:30-75)")
     p.add_argument("--backbone", default="DenseNet121")
@@ -75,12 +191,46 @@ def build_parser():
     p.add_argument("--temp_pool", default=None, help="mean, max, gru or lstm")
     p.add_argument("--root", default="data")
     p.add_argument("--frames_per_video", type=int, default=16)
+    p.add_argument("--exp_root", default=os.path.join("models", "vision", "experiments"))
+    p.add_argument("--corpus_frames", type=int, default=0,
+                   help="config C4: encode a synthetic corpus of this many frames sharded over --num_gpus ranks with "
+                        "the all-gather of the feature rows (786455 = the 5-match corpus); prints one JSON line")
+    p.add_argument("--gather_block", type=int, default=4, help="batches per rank per all-gather round")
+    p.add_argument("--corpus_reuse_frames", action="store_true", help="C4: generate one synthetic batch per rank and re-use it")
     return p
 
 
 def main(argv=None):
     flags = build_parser().parse_args(argv)
+    if flags.num_gpus > 1 and not sharding.under_launcher():
+        # evaluate.py:101-102 builds ctx = [gpu(0) .. gpu(N-1)] in one process; here: one process per GPU
+        if torch.cuda.is_available() and flags.num_gpus > torch.cuda.device_count():
+            raise SystemExit(f"--num_gpus {flags.num_gpus} but only {torch.cuda.device_count()} GPUs are visible")
+        sharding.launch(main, flags.num_gpus, (list(sys.argv[1:] if argv is None else argv),))
+        return 0
+    rank, world, dev = sharding.init_distributed()
+    try:
+        return _main_rank(flags, rank, world, dev)
+    finally:
+        if world > 1 and torch.distributed.is_initialized():
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+
+
+def _main_rank(flags, rank, world, dev):
     every = [int(s) for s in flags.every.split(",")]
+    if flags.corpus_frames > 0:                                             # BASELINE config C4
+        backbone = get_model(flags.backbone, pretrained=True, max_batch=flags.batch_size).features
+        full, st = extract_corpus(backbone, flags.corpus_frames, flags.batch_size, flags.data_shape, dev, rank, world,
+                                  block=flags.gather_block, reuse_frames=flags.corpus_reuse_frames)
+        if rank == 0:
+            print(json.dumps({"config": "C4 corpus feature-extract + all-gather", "frames": flags.corpus_frames,
+                              "n_gpus": world, "batch": flags.batch_size, "rounds": st["rounds"],
+                              "frames_per_sec": round(st["frames_per_sec"], 1), "seconds": round(st["seconds"], 3),
+                              "feature_matrix_MB": round(full.numel() * 4 / 1e6, 1),
+                              "gather_GBps_per_rank": round(st["gather_GBps_per_rank"], 3),
+                              "checksum": float(full.double().sum().item())}))
+        return 0
     # evaluate.py:91-98: Resize(s + 32) / CenterCrop(s) / ToTensor / Normalize, here one GPU launch per batch; the
     # synthetic source already produces data_shape frames, so only data on disk goes through it
     transform_test = None
@@ -111,16 +261,42 @@ def main(argv=None):
     model.initialize()
     model.hybridize()
 
+    # trained parameters: the best epoch of scores.txt (evaluate.py:186-200,223-240), else the newest NNNN.params
+    # (:206-212); an experiment directory without either leaves the (seeded) initial parameters, with a notice
+    mod_path = os.path.join(flags.exp_root, flags.model_id)
+    if flags.temp_pool in ["max", "mean"] and flags.feats_model is not None and not flags.save_feats:
+        mod_path = os.path.join(flags.exp_root, flags.feats_model)          # evaluate.py:219-222
+    params_file = best_or_newest_params(mod_path, need_scores=False)
+    if params_file is not None:
+        model.load_parameters(params_file)
+        print("Loaded model params: {}".format(params_file))
+    elif rank == 0:
+        print("no trained parameters under %s: evaluating the initial parameters" % mod_path)
+
     if flags.save_feats:                                                    # evaluate.py:186-204
-        n = save_features(model, test_data, test_set)
-        print("wrote %d feature files under %s" % (n, test_set.feat_dir))
+        # one code path for any number of ranks (world 1: no collective, the shard IS the matrix)
+        full, n = save_features_sharded(model, test_data, test_set, device=dev, rank=rank, world=world,
+                                        block=flags.gather_block, verbose=(world == 1))
+        print("[rank %d of %d] wrote %d feature files under %s; feature matrix %s on every rank" %
+              (rank, world, n, test_set.feat_dir, tuple(full.shape)))
         return 0
 
     if flags.temp_pool in ["max", "mean"]:                                  # evaluate.py:242-244
         model = TemporalPooling(model, pool=flags.temp_pool, num_classes=0, feats=flags.feats_model is not None)
     test_metrics = [PRF1(label_names=test_set.classes)]
     tic = time.time()
-    results, gts = evaluate_model(model, test_data, test_set, test_metrics)
+    if world > 1:                                                           # each rank tests batches rank::world
+        results, gts = evaluate_model(model, _RankBatches(test_data, rank, world), test_set, test_metrics)
+        for m in test_metrics:                                              # confusion counts add up over the ranks
+            packed = torch.from_numpy(np.concatenate([m.mat.ravel(), m.scores.ravel()])).to(dev)
+            torch.distributed.all_reduce(packed)
+            packed = packed.cpu().numpy()
+            m.mat = packed[:m.mat.size].reshape(m.mat.shape)
+            m.scores = packed[m.mat.size:].reshape(m.scores.shape)
+        if rank != 0:
+            return 0
+    else:
+        results, gts = evaluate_model(model, test_data, test_set, test_metrics)
     str_ = "Test set:"                                                       # evaluate.py:250-255
     for i in range(len(test_set.classes)):
         str_ += "\n"
@@ -133,6 +309,18 @@ def main(argv=None):
     str_ += "  # Samples: {}, Time Taken: {:.1f}".format(len(test_set), time.time() - tic)
     print(str_)
     return 0
+
+
+class _RankBatches:
+    """The batches b with b mod world == rank of a loader (dataset order)."""
+
+    def __init__(self, loader, rank, world):
+        self.loader, self.rank, self.world = loader, rank, world
+
+    def __iter__(self):
+        for b, batch in enumerate(self.loader):
+            if b % self.world == self.rank:
+                yield batch
 
 
 if __name__ == "__main__":

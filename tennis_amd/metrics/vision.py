@@ -31,7 +31,7 @@ class PRF1:
         n = len(self.label_names)
         for label, pred in zip(labels, preds):
             if isinstance(pred, torch.Tensor) and pred.is_cuda and pred.dim() == 2:
-                ctx = _lib.default_context(pred.device.index or 0)
+                ctx = _lib.default_context(pred.device.index)
                 lab = (label if isinstance(label, torch.Tensor) else torch.as_tensor(np.asarray(label)))
                 lab = lab.to(device=pred.device, dtype=torch.int32).contiguous()
                 pr = pred.contiguous().float()

@@ -47,14 +47,49 @@ class Trainer:
         allreduce_and_step(self.head, batch_size, self.learning_rate, self.momentum, self.wd)
 
 
+def best_epoch_from_scores(scores_path: str):
+    """(epoch, score) of the best line of ``scores.txt`` ("epoch<TAB>AVG_NB_f1" per validated epoch, written by
+    ``train_model``; read back the way reference evaluate.py:186-195 / train.py:334-342 do: first strict maximum)."""
+    best_epoch, best_score = -1, -1.0
+    with open(scores_path, "r") as f:
+        for line in f:
+            parts = line.rstrip().split()
+            if len(parts) != 2:
+                continue
+            if float(parts[1]) > best_score:
+                best_epoch, best_score = int(parts[0]), float(parts[1])
+    return best_epoch, best_score
+
+
+def newest_params(save_dir: str):
+    """Newest ``NNNN.params`` of an experiment directory or None (reference train.py:287-293, evaluate.py:206-212)."""
+    if not os.path.isdir(save_dir):
+        return None
+    files = sorted((f for f in os.listdir(save_dir) if f.endswith(".params")), reverse=True)
+    return os.path.join(save_dir, files[0]) if files else None
+
+
+def is_main_rank() -> bool:
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+
 def train_model(head: TemporalHeadTrainer, train_batches, metrics, trainer: Trainer, epochs: int, batch_size: int,
                 lr_steps=(10, 20), lr_factor: float = 0.75, start_epoch: int = 0, val_fn=None, save_dir: str | None = None,
-                log=print):
+                log=print, model=None, score_key: str = "AVG_NB_f1"):
     """reference train.py:388-499 with the model call, loss and backward fused into ``head.forward_backward``.
-    ``train_batches``: callable -> iterable of (features (B,T,F) tensor, labels (B,) tensor) per epoch."""
+    ``train_batches``: callable -> iterable of (features (B,T,F) tensor, labels (B,) tensor) per epoch.
+    Per epoch (rank 0 only): the validation ``AVG_NB_f1`` is appended to ``<save_dir>/scores.txt`` (:487-489) and the
+    parameters go to ``<save_dir>/NNNN.params`` (:497) — through ``model.save_parameters`` (the MXNet container with
+    Gluon's structural names, what the reference's ``load_parameters`` reads) when the mirror ``model`` is given,
+    else an ``.npz`` of the trainer's prefixed names under ``NNNN.npz``."""
     lr_counter = 0
     lr_steps = list(lr_steps) + [1 << 30]
     history = []
+    for epoch in range(0, start_epoch):                                     # a resumed run keeps the schedule it had
+        if epoch == lr_steps[lr_counter]:
+            trainer.set_learning_rate(trainer.learning_rate * lr_factor)
+            lr_counter += 1
     for epoch in range(start_epoch, epochs):
         if epoch == lr_steps[lr_counter]:                                   # :395-397
             trainer.set_learning_rate(trainer.learning_rate * lr_factor)
@@ -74,10 +109,17 @@ def train_model(head: TemporalHeadTrainer, train_batches, metrics, trainer: Trai
             row["val"] = val_fn(head)
         history.append(row)
         log("[Epoch {}] loss: {:.3f} lr: {:.2E}".format(epoch, row["loss"], trainer.learning_rate))
-        if save_dir:                                                        # :497
+        if save_dir and is_main_rank():
             os.makedirs(save_dir, exist_ok=True)
-            with open(os.path.join(save_dir, "{:04d}.params".format(epoch)), "wb") as f:
-                np.savez(f, **head.state_dict())
+            if isinstance(row.get("val"), dict) and score_key in row["val"]:   # :487-489
+                with open(os.path.join(save_dir, "scores.txt"), "a") as f:
+                    f.write(str(epoch) + "\t" + str(float(row["val"][score_key])) + "\n")
+            if model is not None:                                           # :497
+                model.set_params(head.state_dict())
+                model.save_parameters(os.path.join(save_dir, "{:04d}.params".format(epoch)))
+            else:
+                with open(os.path.join(save_dir, "{:04d}.npz".format(epoch)), "wb") as f:
+                    np.savez(f, **head.state_dict())
     return history
 
 
@@ -115,8 +157,10 @@ def main(argv=None):
       * ``--window 1`` without ``--feats_model``: the frame classifier end to end (BatchNorm in training mode).
     Frames go through the TEST transform: the reference's train-time augmentation (RandomResizedCrop, flips, colour jitter,
     lighting; train.py:127-136) is host-side image processing outside this path and is not mirrored."""
+    from . import transforms
     from .dataset import DataLoader, TennisSet
     from .engine import FrameModelTrainer, TemporalHeadTrainer
+    from .sharding import init_distributed
     from .evaluate import evaluate_model
     from .metrics.vision import PRF1
     from .model_zoo import get_model
@@ -126,10 +170,20 @@ def main(argv=None):
     every = [int(s) for s in flags.every.split(",")]
     balance = [s.strip().lower() in ("true", "t") for s in flags.balance.split(",")]
     lr_steps = [int(s) for s in flags.lr_steps.split(",")]
-    mk = lambda split, ev, bal: TennisSet(root=flags.root, split=split, every=ev, padding=flags.padding, stride=flags.stride,
-                                          window=flags.window, model_id=flags.model_id, split_id=flags.split_id, balance=bal,
-                                          feats_model=flags.feats_model, data_shape=flags.data_shape,
-                                          frames_per_video=flags.frames_per_video)
+    rank, world, dev = init_distributed()              # one process per GPU under torchrun, (0, 1, cuda:current) otherwise
+    if flags.batch_size % world:
+        raise SystemExit(f"--batch_size {flags.batch_size} must be a multiple of the {world} ranks")
+    local_bs = flags.batch_size // world
+    # frames on disk come at their native size: Resize(s + 32) / CenterCrop(s) / ToTensor / Normalize as evaluate.py:93-98
+    # (one GPU launch per batch); the synthetic source already produces data_shape frames
+    on_disk = flags.feats_model is None and os.path.exists(os.path.join(flags.root, "splits", flags.split_id, "train.txt"))
+    tf = transforms.Compose([transforms.Resize(flags.data_shape + 32), transforms.CenterCrop(flags.data_shape),
+                             transforms.ToTensor(),
+                             transforms.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])]) if on_disk else None
+    mk = lambda split, ev, bal: TennisSet(root=flags.root, transform=tf, split=split, every=ev, padding=flags.padding,
+                                          stride=flags.stride, window=flags.window, model_id=flags.model_id,
+                                          split_id=flags.split_id, balance=bal, feats_model=flags.feats_model,
+                                          data_shape=flags.data_shape, frames_per_video=flags.frames_per_video)
     train_set, val_set = mk("train", every[0], balance[0]), mk("val", every[1], balance[1])
     n_cls = len(train_set.classes)
     save_dir = os.path.join(flags.exp_root, flags.model_id)
@@ -140,10 +194,10 @@ def main(argv=None):
         model = CNNRNN(None, num_classes=n_cls, type=flags.temp_pool, hidden_size=128)
         model.rnn._materialize(feat_dim)
         model.classes._materialize(256)
-        params = {k: v.data for k, v in model.collect_params().items()}
-        head = TemporalHeadTrainer(params, feat_dim, 128, n_cls, max_batch=flags.batch_size, max_steps=flags.window,
-                                   rnn_prefix=model.rnn.prefix, dense_prefix=model.classes.prefix, type=flags.temp_pool)
         last = "keep"
+        mk_head = lambda p: TemporalHeadTrainer(p, feat_dim, 128, n_cls, max_batch=local_bs, max_steps=flags.window,
+                                                rnn_prefix=model.rnn.prefix, dense_prefix=model.classes.prefix,
+                                                type=flags.temp_pool)
     else:
         if flags.window != 1 or flags.freeze_backbone:
             raise SystemExit("end-to-end training is built for --window 1 with a trainable backbone; a frozen backbone "
@@ -151,19 +205,31 @@ def main(argv=None):
         model = FrameModel(get_model(flags.backbone, pretrained=True).features, n_cls)
         model.initialize()
         model.classes._materialize(1024)
-        params = {k: v.data for k, v in model.collect_params().items()}
-        head = FrameModelTrainer(params, flags.data_shape, n_cls, batch=flags.batch_size, prefix=model.backbone.prefix,
-                                 dense_prefix=model.classes.prefix)
         last = "discard"
+        mk_head = lambda p: FrameModelTrainer(p, flags.data_shape, n_cls, batch=local_bs, prefix=model.backbone.prefix,
+                                              dense_prefix=model.classes.prefix)
+    # resume from the newest NNNN.params of the experiment (train.py:286-295)
+    start_epoch = 0
+    newest = newest_params(save_dir)
+    if newest is not None:
+        model.load_parameters(newest)
+        start_epoch = int(os.path.basename(newest).split(".")[0]) + 1
+        print("Loaded model params: {}".format(newest))
+    head = mk_head({k: v.data for k, v in model.collect_params().items()})
     train_data = DataLoader(train_set, flags.batch_size, shuffle=True, last_batch=last)
     val_data = DataLoader(val_set, flags.batch_size, shuffle=False)
     trainer = Trainer(head, "sgd", {"learning_rate": flags.lr, "momentum": flags.momentum, "wd": flags.wd})
     metrics = [PRF1(label_names=train_set.classes)]
 
-    def batches():
+    def batches():          # every rank walks the same (seeded) batches and trains on its rows rank::world of each
         for data, labels, _ in train_data:
             x = data if isinstance(data, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(data))
-            yield x.cuda(), torch.from_numpy(labels.astype(np.int32)).cuda()
+            y = torch.from_numpy(labels.astype(np.int32))
+            if world > 1:
+                if x.shape[0] % world:
+                    continue        # a ragged last batch cannot be split evenly: dropped in data-parallel runs
+                x, y = x[rank::world], y[rank::world]
+            yield x.to(dev), y.to(dev)
 
     def validate(h):                                     # train.py:445-470: the validation metrics of the updated model
         model.set_params(h.state_dict())
@@ -172,9 +238,10 @@ def main(argv=None):
         return dict(vm[0].get())
 
     hist = train_model(head, batches, metrics, trainer, flags.epochs, flags.batch_size, lr_steps=lr_steps,
-                       lr_factor=flags.lr_factor, val_fn=validate, save_dir=save_dir)
-    best = max(hist, key=lambda r: r["val"].get("AVG_f1", 0.0))
-    print("[Finished] best epoch {} val AVG_f1={:.3f}".format(best["epoch"], best["val"].get("AVG_f1", 0.0)))
+                       lr_factor=flags.lr_factor, start_epoch=start_epoch, val_fn=validate, save_dir=save_dir, model=model)
+    if hist and is_main_rank():
+        best = max(hist, key=lambda r: r["val"].get("AVG_NB_f1", 0.0))
+        print("[Finished] best epoch {} val AVG_NB_f1={:.3f}".format(best["epoch"], best["val"].get("AVG_NB_f1", 0.0)))
     return 0
 
 

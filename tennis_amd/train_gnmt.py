@@ -27,13 +27,18 @@ from .engine import GNMTTrainer
 from .metrics.bleu import compute_bleu
 
 
-def allreduce_grads(trainer: GNMTTrainer):
-    """Data parallelism: every rank's loss is already a per-token average, so the ranks' gradients are averaged."""
+def allreduce_grads(trainer, n_tokens: int):
+    """Data parallelism.  A rank's gradient is that of ITS per-token average loss over ``n_tokens`` target tokens; the
+    global per-token average over all ranks' batches is sum_r(n_r * mean_r) / sum_r(n_r), so the gradients are
+    weighted by the token counts: all-reduce n_r * g_r and n_r, then divide (reference loss: train_gnmt.py:332-333)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         g = trainer.grads
+        cnt = torch.tensor([float(n_tokens)], dtype=torch.float32, device=g.device)
+        g *= float(n_tokens)
         dist.all_reduce(g, op=dist.ReduceOp.SUM)
-        g /= dist.get_world_size()
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        g /= cnt
 
 
 def train(data_train, data_val, data_test, model, translator, epochs: int, batch_size: int, lr: float = 1e-3,
@@ -56,12 +61,17 @@ def train(data_train, data_val, data_test, model, translator, epochs: int, batch
     best_valid_bleu, history = 0.0, []
     if save_dir:
         os.makedirs(save_dir, exist_ok=True)
+    import torch.distributed as dist
+    ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank, world = (dist.get_rank(), dist.get_world_size()) if ddp else (0, 1)
     for epoch_id in range(start_epoch, epochs):
         tot, nb = 0.0, 0
-        for src, tgt, svl, tvl, *_ in bucketed_batches(data_train, batch_size, num_buckets):
+        # FixedBucketSampler(..., shuffle=True) of the training loader (utils/captioning.py:48-55)
+        for src, tgt, svl, tvl, *_ in bucketed_batches(data_train, batch_size, num_buckets, shuffle=True, seed=seed,
+                                                       epoch=epoch_id, rank=rank, world=world):
             loss = trainer.forward_backward(torch.from_numpy(src).cuda(), torch.from_numpy(svl.astype(np.int32)).cuda(),
                                             torch.from_numpy(tgt).cuda(), torch.from_numpy(tvl.astype(np.int32)).cuda())
-            allreduce_grads(trainer)
+            allreduce_grads(trainer, int((tvl.astype(np.int64) - 1).sum()))
             trainer.step(lr)                                                     # trainer.step(1)
             tot += float(loss)
             nb += 1

@@ -85,7 +85,7 @@ class Compose:
         lead = tuple(x.shape[:-3])
         h, w = int(x.shape[-3]), int(x.shape[-2])
         plan = self._plan(h, w)
-        x = (x if x.is_cuda else x.cuda()).contiguous().reshape(-1, h, w, 3)
+        x = x.to(torch.device('cuda', self._ctx.device)).contiguous().reshape(-1, h, w, 3)
         out = torch.empty((x.shape[0], self.crop, self.crop, 3), dtype=torch.uint8, device=x.device)
         for s in range(0, x.shape[0], 65535):
             n = min(65535, x.shape[0] - s)

@@ -34,14 +34,77 @@ def test_sharded_extract_allgather_world2():
 
 
 def test_rank_batches_partition():
-    for n, b, w in [(786455, 256, 8), (37, 8, 2), (5, 8, 4), (256, 256, 1)]:
+    for n, b, w, blk in [(786455, 256, 8, 1), (786455, 256, 8, 4), (37, 8, 2, 1), (37, 8, 2, 3), (5, 8, 4, 2), (256, 256, 1, 1)]:
         seen = []
         for r in range(w):
-            seen += sharding.rank_batches(n, b, r, w)
+            mine = sharding.rank_batches(n, b, r, w, blk)
+            assert sum(e - s for s, e in mine) <= sharding.local_rows(n, b, w, blk)
+            seen += mine
         seen.sort()
         assert seen[0][0] == 0 and seen[-1][1] == n
         assert all(a[1] == c[0] for a, c in zip(seen, seen[1:]))
-        assert sharding.local_rows(n, b, w) * w >= n
+        assert sharding.local_rows(n, b, w, blk) * w >= n
+
+
+class _CpuBackbone:
+    """Stands in for the HIP encoder (no GPU in the CPU suite): features are a fixed function of the frame bytes."""
+    def __call__(self, data):
+        x = torch.from_numpy(np.ascontiguousarray(data)).float()
+        x = x.reshape(x.shape[0], -1)
+        return torch.stack([x.mean(1), x.std(1), x[:, 0], x[:, -1], x.abs().max(1).values], 1)
+
+
+class _CpuNet:
+    backbone = _CpuBackbone()
+
+
+def _eval_worker(root, n_expected, q):
+    """config C4's code path on gloo: tennis_amd.evaluate.save_features_sharded (the function evaluate.main drives for
+    --save_feats --num_gpus N) -> per-rank .npy files + all-gathered (N, F) matrix; ranks formed by sharding.launch."""
+    import numpy as np
+    import torch.distributed as dist
+    from tennis_amd import evaluate as ev, sharding
+    from tennis_amd.dataset import DataLoader, TennisSet
+    rank, world, dev = sharding.init_distributed()
+    assert world == 2 and dev.type == "cpu"
+    ds = TennisSet(root=root, split="test", model_id="c4", save_feats=True, frames_per_video=7, data_shape=16, split_first=2,
+                   video_length=12)
+    assert len(ds) == n_expected
+    loader = DataLoader(ds, batch_size=4)
+    stats = {}
+    full, written = ev.save_features_sharded(_CpuNet(), loader, ds, device=dev, rank=rank, world=world, block=2, stats=stats)
+    ref = torch.cat([_CpuNet.backbone(loader.collate(range(s, min(s + 4, len(ds))))[0]) for s in range(0, len(ds), 4)])
+    ok = bool(torch.equal(full, ref))
+    dist.barrier()
+    on_disk = all(np.array_equal(np.load(ds.save_feature_path(i)), ref[i].numpy()) for i in range(len(ds)))
+    q.put((rank, ok, on_disk, written, stats["frames_local"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_evaluate_save_features_sharded_world2(tmp_path):
+    from tennis_amd.dataset import TennisSet
+    root = str(tmp_path)
+    n = len(TennisSet(root=root, split="test", model_id="c4", save_feats=True, frames_per_video=7, data_shape=16, split_first=2,
+                      video_length=12))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    sharding.launch(_eval_worker, 2, (root, n, q))
+    res = sorted(q.get(timeout=60) for _ in range(2))
+    assert all(ok and disk for _, ok, disk, _, _ in res), res
+    assert sum(w for *_, w, _ in res) == n                  # every frame written exactly once, by its owner
+    assert sum(f for *_, f in res) == n and all(f > 0 for *_, f in res)
+
+
+def test_bench_and_evaluate_self_launch_are_wired():
+    """bench.py --gpus N / evaluate.py --num_gpus N started as plain python spawn their ranks (sharding.launch)
+    instead of silently running one: the launch branch is taken when no launcher environment is present."""
+    import inspect
+    import bench
+    from tennis_amd import evaluate as ev
+    assert "sharding.launch(run, args.gpus" in inspect.getsource(bench.main)
+    assert "sharding.launch(main, flags.num_gpus" in inspect.getsource(ev.main)
+    assert not sharding.under_launcher()
 
 
 def _dp_train_worker(rank, world, port, q):

@@ -219,6 +219,59 @@ def test_caption_set_batching_and_sentences(tmp_path):
     assert f.read_text() == "a b\nc d\n"
 
 
+def test_bucketed_batches_training_sampler():
+    """FixedBucketSampler(shuffle=True) stand-in (utils/captioning.py:48-55): every sample exactly once per epoch, the
+    order changes from epoch to epoch and is reproducible; data-parallel ranks split the same batch list evenly."""
+    from tennis_amd.captions import CaptionSet, bucketed_batches
+    ds = CaptionSet(split="train", n_points=23, feature_dim=4, mean_frames=5, max_cap_len=9, inference=True)   # ids travel with the batch
+    ids = lambda **kw: [b[-1].astype(int).tolist() for b in bucketed_batches(ds, 4, 3, **kw)]
+    plain = ids()
+    e0, e0b, e1 = ids(shuffle=True, seed=5, epoch=0), ids(shuffle=True, seed=5, epoch=0), ids(shuffle=True, seed=5, epoch=1)
+    for ep in (plain, e0, e1):
+        assert sorted(i for b in ep for i in b) == list(range(23))
+    assert e0 == e0b and e0 != e1 and e0 != plain
+    lens = [l[-1] for l in ds.get_data_lens()]
+    width = -(-(max(lens) - min(lens) + 1) // 3)
+    for b in e0:                                        # a batch never mixes buckets
+        assert len({(lens[i] - min(lens)) // width for i in b}) == 1
+    r0, r1 = ids(shuffle=True, seed=5, epoch=0, rank=0, world=2), ids(shuffle=True, seed=5, epoch=0, rank=1, world=2)
+    assert len(r0) == len(r1) == -(-len(e0) // 2)
+    assert sorted(i for b in e0 for i in b) == sorted(set(i for b in r0 + r1 for i in b))
+
+
+def _wavg_worker(rank, world, port, q):
+    import os
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch
+    import torch.distributed as dist
+    from tennis_amd.train_gnmt import allreduce_grads
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class T:                                            # the surface allreduce_grads uses: a flat gradient tensor
+        grads = torch.tensor([1.0, 2.0]) if rank == 0 else torch.tensor([5.0, -2.0])
+    t = T()
+    allreduce_grads(t, 30 if rank == 0 else 10)
+    q.put((rank, t.grads.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_captioner_ddp_gradients_are_token_weighted():
+    """Ranks average per-TOKEN: (30*g0 + 10*g1) / 40, not (g0 + g1) / 2 (reference loss: train_gnmt.py:332-333)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400) + 17
+    procs = [ctx.Process(target=_wavg_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for pr in procs:
+        pr.join(timeout=60)
+    for _, g in res:
+        assert np.allclose(g, [(30 * 1 + 10 * 5) / 40, (30 * 2 - 10 * 2) / 40])
+
+
 def test_gnmt_oracle_properties():
     """Beam 1 == greedy argmax decoding; padding the source does not change the result;
     BOS first / EOS at valid_len-1; teacher-forced log-softmax row equals the step's logp."""

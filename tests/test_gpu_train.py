@@ -97,7 +97,7 @@ def test_train_model_driver(tmp_path):
     assert [round(h["lr"], 6) for h in hist] == [0.1, 0.1, 0.05, 0.05, 0.025]
     assert hist[-1]["loss"] < 0.5 * hist[0]["loss"]
     assert metric.mat.sum() == 6 * B                                  # the last epoch's samples
-    z = np.load(str(tmp_path / "0004.params"))
+    z = np.load(str(tmp_path / "0004.npz"))          # no mirror model handed over: prefixed names in an .npz
     assert set(z.files) == set(p) and z["cnnrnn0_dense0_weight"].shape == (C_, 2 * H)
 
 
@@ -116,6 +116,26 @@ def test_train_main_pipeline(tmp_path, capsys):
     assert tr.main(args) == 0
     out = capsys.readouterr().out
     assert "[Finished] best epoch" in out and (tmp_path / "exp" / "0002" / "0002.params").exists()
+    # train.py:487-489,497: one "epoch<TAB>AVG_NB_f1" line per epoch, NNNN.params in the MXNet container with Gluon's
+    # structural names (what the reference's load_parameters reads)
+    from tennis_amd.params_io import is_mxnet_params, load_mxnet_params
+    from tennis_amd.train import best_epoch_from_scores
+    lines = (tmp_path / "exp" / "0002" / "scores.txt").read_text().splitlines()
+    assert [ln.split("\t")[0] for ln in lines] == ["0", "1", "2"]
+    f2 = str(tmp_path / "exp" / "0002" / "0002.params")
+    assert is_mxnet_params(f2) and "rnn.l0_i2h_weight" in load_mxnet_params(f2) and "classes.weight" in load_mxnet_params(f2)
+    best_ep, best_sc = best_epoch_from_scores(str(tmp_path / "exp" / "0002" / "scores.txt"))
+    # evaluate.py:223-240: testing loads the best epoch of scores.txt
+    assert ev.main(["--root", root, "--frames_per_video", "12", "--data_shape", "224", "--model_id", "0002", "--feats_model", "0001",
+                    "--window", "4", "--temp_pool", "gru", "--split", "val", "--batch_size", "8", "--exp_root", exp]) == 0
+    out = capsys.readouterr().out
+    assert "Testing best model from Epoch %d" % best_ep in out and "%04d.params" % best_ep in out
+    assert "Test_AVG_NB_f1={:.3f}".format(best_sc) in out          # the validation score of that epoch, reproduced
+    # train.py:286-295: a second run resumes after the newest NNNN.params
+    assert tr.main(args[:args.index("--epochs")] + ["--epochs", "4"] + args[args.index("--epochs") + 2:]) == 0
+    out = capsys.readouterr().out
+    assert "Loaded model params" in out and "0002.params" in out and (tmp_path / "exp" / "0002" / "0003.params").exists()
+    assert len((tmp_path / "exp" / "0002" / "scores.txt").read_text().splitlines()) == 4
     # end-to-end frame classifier, one epoch
     args = ["--root", root, "--frames_per_video", "8", "--data_shape", "224", "--model_id", "0003", "--window", "1", "--epochs", "1",
             "--batch_size", "4", "--exp_root", exp]
