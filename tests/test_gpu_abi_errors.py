@@ -106,8 +106,20 @@ def test_finetune_errors():
         FrameModelTrainer(p, 200, 11, batch=2)
     tr = FrameModelTrainer(p, 64, 11, batch=2)                    # any side divisible by 32 works
     x = torch.zeros((3, 64, 64, 3), device="cuda")
-    with pytest.raises(RuntimeError, match="batch must equal"):
+    with pytest.raises(ValueError, match="FrameModelTrainer expects"):          # the host mirror checks batch and frame size ...
         tr.forward_backward(x, torch.zeros(3, dtype=torch.int32, device="cuda"))
+    with pytest.raises(ValueError, match="FrameModelTrainer expects"):          # ... e.g. un-cropped frames (train.py transform)
+        tr.forward_backward(torch.zeros((2, 96, 96, 3), device="cuda"), torch.zeros(2, dtype=torch.int32, device="cuda"))
+    lib0 = _lib.load()                                                           # ... and so does the C ABI underneath it
+    lab = torch.zeros(3, dtype=torch.int32, device="cuda")
+    assert lib0.tn_finetune_forward_backward(tr.handle, _lib.ptr(x), _lib.ptr(lab), 3, 64, 64, None, None) != 0
+    assert b"batch must equal" in lib0.tn_last_error()
+    assert lib0.tn_finetune_forward_backward(tr.handle, _lib.ptr(x), _lib.ptr(lab), 2, 96, 96, None, None) != 0
+    assert b"frame size must equal" in lib0.tn_last_error()
+    u8 = torch.randint(0, 256, (2, 64, 64, 3), device="cuda", dtype=torch.uint8)   # decoded frames: ToTensor + Normalize in the library
+    from tennis_amd.engine import to_tensor_normalize
+    ref = ((u8.float() / 255.0 - torch.tensor([0.485, 0.456, 0.406], device="cuda")) / torch.tensor([0.229, 0.224, 0.225], device="cuda"))
+    assert float((to_tensor_normalize(u8) - ref).abs().max()) < 1e-6
     loss, logits = tr.forward_backward(torch.randn((2, 64, 64, 3), device="cuda"), torch.tensor([1, 5], dtype=torch.int32, device="cuda"))
     assert bool(torch.isfinite(loss).all()) and logits.shape == (2, 11)
     lib = _lib.load()

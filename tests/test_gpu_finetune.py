@@ -118,9 +118,14 @@ def test_train_model_driver_with_the_frame_classifier(tmp_path):
     xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
     tr = Trainer(head, "sgd", {"learning_rate": 0.01, "momentum": 0.9, "wd": 1e-4})
     metric = PRF1(label_names=[str(i) for i in range(11)])
+    mirror = FrameModel(get_model("DenseNet121", pretrained=True, seed=5).features, 11, prefix="framemodel0_")
+    mirror.initialize()
+    mirror.classes._materialize(1024)
     hist = train_model(head, lambda: [(xd, yd)] * 3, [metric], tr, epochs=3, batch_size=B, lr_steps=(1, 2), lr_factor=0.75,
-                       save_dir=str(tmp_path), log=lambda *_: None)
+                       save_dir=str(tmp_path), log=lambda *_: None, model=mirror)
     assert len(hist) == 3 and hist[-1]["loss"] < hist[0]["loss"] and abs(hist[-1]["lr"] - 0.01 * 0.75 ** 2) < 1e-9
+    from tennis_amd.params_io import is_mxnet_params
+    assert is_mxnet_params(str(tmp_path / "0002.params"))    # train.py:497: the MXNet container with Gluon's structural names
     fm = FrameModel(get_model("DenseNet121", pretrained=True, seed=3).features, 11, prefix="framemodel0_")
     fm.initialize()
     fm.classes._materialize(1024)
