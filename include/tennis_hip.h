@@ -263,7 +263,7 @@ int tn_dbg_conv3x3(tn_ctx *ctx, const void *x_f16, const float *scale_host, cons
                    const float *w_host, void *y_f16, int ldy, int yoff, int B, int H, int W);
 /* Tuning hooks: asynchronous single launches on device-resident, pre-converted
  * operands (fp16 [N][K] 1x1 weights; tn_dbg_pack_conv3x3 image for the 3x3:
- * 3 x 72*64*8 halves: the 32x32x16 layout and the two 16x16x32 MFMA operand layouts). */
+ * 2 x 72*64*8 halves, the 32x32x16 and the 16x16x32 MFMA operand layouts). */
 int tn_dbg_pack_conv3x3(const float *w_host, uint16_t *out_host);
 int tn_dbg_conv1x1_dev(tn_ctx *ctx, const void *x_f16, int ldx, int K, const float *scale, const float *shift,
                        const void *w_f16, int N, void *y_f16, int ldy, int yoff, int M, int pool, int H, int W,

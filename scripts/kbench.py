@@ -38,7 +38,7 @@ res = []
 for v in [int(s) for s in args.variants.split(",")]:
     if "c3" in args.kernels:
         w = rng.normal(0, 0.03, (32, 128, 3, 3)).astype(np.float32)
-        wp = np.empty(3 * 72 * 64 * 8, np.uint16)   # the three MFMA operand layouts
+        wp = np.empty(2 * 72 * 64 * 8, np.uint16)   # both MFMA operand layouts
         lib.tn_dbg_pack_conv3x3(w.ctypes.data_as(C.c_void_p), wp.ctypes.data_as(C.c_void_p))
         wpd = torch.from_numpy(wp.view(np.int16)).cuda()
         sc = torch.rand(128, device="cuda") + 0.5; sh = torch.randn(128, device="cuda") * 0.3
@@ -91,7 +91,7 @@ for v in [int(s) for s in args.variants.split(",")]:
             del x, y
     if "dl" in args.kernels:
         w = rng.normal(0, 0.03, (32, 128, 3, 3)).astype(np.float32)
-        wp = np.empty(3 * 72 * 64 * 8, np.uint16)   # the three MFMA operand layouts
+        wp = np.empty(2 * 72 * 64 * 8, np.uint16)   # both MFMA operand layouts
         lib.tn_dbg_pack_conv3x3(w.ctypes.data_as(C.c_void_p), wp.ctypes.data_as(C.c_void_p))
         wpd = torch.from_numpy(wp.view(np.int16)).cuda()
         s2 = torch.rand(128, device="cuda") + 0.5; t2 = torch.randn(128, device="cuda") * 0.3

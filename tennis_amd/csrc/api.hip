@@ -134,10 +134,7 @@ std::vector<f16> pack_conv3x3(const float *w) {
   //  [0]     v_mfma_f32_32x32x16_f16 A fragments [9 taps x 8 k16-steps][64 lanes][8]   (conv3x3.hip, dense_layer_small.hip)
   //  [36864] v_mfma_f32_16x16x32_f16 A fragments [9 taps][4 k32-steps][2 n-frags][64 lanes][8]   (dense_layer_big.hip):
   //          lane l: out channel nf*16 + (l&15), in channel kk*32 + (l>>4)*8 + j
-  //  [73728] the same 16x16x32 fragments with the 32 output channels dealt over the fragment rows so that a lane of
-  //          the D tile (rows 4*(l>>4)+r of n-frag 0 and of n-frag 1) ends with 8 CONSECUTIVE channels of its pixel:
-  //          row i of n-frag nf <-> out channel 8*(i>>2) + 4*nf + (i&3)   (dense_layer_v2.hip stores them as one 16-B piece)
-  std::vector<f16> p((size_t)3 * 72 * 64 * 8);
+  std::vector<f16> p((size_t)2 * 72 * 64 * 8);
   for (int s = 0; s < 72; ++s) {
     const int tap = s >> 3, kk = s & 7, ky = tap / 3, kx = tap % 3;
     for (int l = 0; l < 64; ++l)
@@ -155,9 +152,6 @@ std::vector<f16> pack_conv3x3(const float *w) {
           for (int j = 0; j < 8; ++j) {
             const int n = nf * 16 + (l & 15), c = kk * 32 + (l >> 4) * 8 + j;
             q[((((size_t)tap * 4 + kk) * 2 + nf) * 64 + l) * 8 + j] = (f16)w[(((size_t)n * 128 + c) * 3 + ky) * 3 + kx];
-            const int i = l & 15, n3 = 8 * (i >> 2) + 4 * nf + (i & 3);
-            q[(size_t)72 * 64 * 8 + ((((size_t)tap * 4 + kk) * 2 + nf) * 64 + l) * 8 + j] =
-                (f16)w[(((size_t)n3 * 128 + c) * 3 + ky) * 3 + kx];
           }
   }
   return p;
@@ -389,7 +383,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
     const int Hh = e->Hb[b], Ww = e->Wb[b];
     const int M = B * Hh * Ww;
     const bool fused = e->fuse && dense_layer_supported(Hh, Ww);
-    if (fused && e->chain && (e->dl_variant & ~(32 | 64 | 128 | 256)) == 0 && Hh == Ww && (Hh == 14 || Hh == 7)) {
+    if (fused && e->chain && (e->dl_variant & ~(32 | 64 | 128)) == 0 && Hh == Ww && (Hh == 14 || Hh == 7)) {
       // one workgroup per frame walks the whole block: no launch gaps, no cold prologue per layer
       auto &L0 = e->layers[b][0];
       const int nl = (int)e->layers[b].size();

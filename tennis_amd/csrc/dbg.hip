@@ -21,7 +21,7 @@ T *up(const std::vector<T> &h) {
 
 std::vector<f16> pack_conv3x3(const float *w);  // api.hip
 
-// fp32 (32,128,3,3) -> the packed fp16 fragment images the 3x3 kernels consume (3 x 72*64*8 halfs).
+// fp32 (32,128,3,3) -> the packed fp16 fragment image the conv3x3 kernel consumes (72*64*8 halfs).
 extern "C" int tn_dbg_pack_conv3x3(const float *w_host, uint16_t *out_host) {
   TN_REQUIRE(w_host && out_host, "tn_dbg_pack_conv3x3: null argument");
   const std::vector<f16> p = pack_conv3x3(w_host);

@@ -8,15 +8,10 @@ bool dense_layer_big_supported(int H, int W);
 bool dense_layer_small_supported(int H, int W);
 int launch_dense_layer_big(const DenseLayerArgs &a, hipStream_t s);
 int launch_dense_layer_small(const DenseLayerArgs &a, hipStream_t s);
-int launch_dense_layer_v2(const DenseLayerArgs &a, hipStream_t s);   // dense_layer_v2.hip: X through registers
-bool dense_layer_v2_supported(int H, int W, int K);
 
 bool dense_layer_supported(int H, int W) { return dense_layer_big_supported(H, W) || dense_layer_small_supported(H, W); }
 
 int launch_dense_layer(const DenseLayerArgs &a, hipStream_t s) {
-  // variant 0 (the default): the second-generation kernel wherever the 8-wave geometry exists; any tuning bit
-  // selects one of the first-generation kernels (bit 8 alone: their default flavour), kept for A/B runs
-  if ((a.variant & 0xffff) == 0 && dense_layer_v2_supported(a.H, a.W, a.K)) return launch_dense_layer_v2(a, s);   // bits 16+: debug switches of the v2 kernel
   if (a.nchain > 0) return launch_dense_layer_big(a, s);   // whole-frame chains (14x14, 7x7)
   const bool big_ok = dense_layer_big_supported(a.H, a.W), small_ok = dense_layer_small_supported(a.H, a.W);
   bool use_big = big_ok;                       // measured: the 8-wave geometry wins at every block size
