@@ -314,6 +314,43 @@ def test_gnmt_oracle_properties():
     assert np.allclose(gn._log_softmax(lg[:, 0]), logp, atol=1e-6)
 
 
+@pytest.mark.parametrize("cell", ["gru", "lstm"])
+def test_gnmt_oracle_matches_independent_torch_restatement(cell):
+    """oracle/gnmt_np.py against oracle/gnmt_torch.py (nn.GRUCell / nn.LSTMCell, F.softmax, torch.topk, float64): one
+    decode step (log-probabilities, recurrent states, attention context) and three beam-search steps (token ids, beam
+    order, scores, finished flags).  reference gnmt.py:369-404, utils/translation.py:51-82."""
+    from oracle import gnmt_np as gn, gnmt_torch as gt
+    from tennis_amd import weights as W
+    F, H, E, V, B, T, beam = 24, 16, 8, 30, 3, 9, 4
+    p = W.make_gnmt_weights(7, cell, F, H, E, V)
+    p["gnmt_tgt_proj_weight"] = (p["gnmt_tgt_proj_weight"] * 25).astype(np.float32)   # spread the log-probabilities
+    rng = np.random.default_rng(11)
+    x = np.abs(rng.normal(0, 1, (B, T, F))).astype(np.float32)
+    vl = np.array([9, 6, 3])
+    mem, st = gn.encoder(x, vl, p, cell, H)
+    dec = gn.Decoder(p, H, cell=cell)
+    states, att = dec.init_state(mem, st, vl)
+    tok = rng.integers(4, V, B)
+    att = np.abs(rng.normal(0, 0.3, att.shape)).astype(np.float32)
+    logp, ns, ctx = dec.step(tok, states, att, np.arange(B))
+    td = gt.TorchDecoder(p, H, E, cell)
+    td.init(mem, vl)
+    tl, tns, tctx = td.step(tok, [torch.from_numpy(s).double() for s in states], torch.from_numpy(att).double(), torch.arange(B))
+    assert np.abs(logp - tl.numpy()).max() < 2e-5 and np.abs(ctx - tctx.numpy()).max() < 2e-6
+    assert len(ns) == len(tns) and max(np.abs(a - b.numpy()).max() for a, b in zip(ns, tns)) < 2e-6
+    assert np.abs(np.exp(logp).sum(1) - 1).max() < 1e-5
+    # masked attention: a padded source step carries no weight (clip 2 has 3 valid steps of 9)
+    mem_pad = mem.copy(); mem_pad[2, 3:] = 99.0
+    dec2 = gn.Decoder(p, H, cell=cell); dec2.init_state(mem_pad, st, vl)
+    assert np.allclose(dec2.step(tok, states, att, np.arange(B))[2][2], ctx[2], atol=1e-6)
+    # three beam-search steps: EOS (id 3) is reachable, so finished beams and the "emit -1" path are exercised
+    s_np, sc_np, _ = gn.beam_search(dec, mem, st, vl, 2, 3, beam=beam, alpha=1.0, K=5, max_length=3)
+    s_t, sc_t, alive_t = gt.beam_search(td, mem, st, vl, 2, 3, beam, 1.0, 5, 3)
+    assert np.array_equal(s_np[:, :, :4], s_t)                     # BOS + 3 steps, same beams in the same order
+    assert np.abs(sc_np - sc_t).max() < 2e-5
+    assert np.array_equal(s_np[:, :, 4] == 3, alive_t)             # gnmt_np appends EOS to the unfinished beams
+
+
 def test_bleu_pinned_to_reference_golden():
     """tennis_amd.metrics.bleu.compute_bleu vs vectors produced by the reference's own metrics/bleu.py
     (tests/golden/make_reference_golden.py): tokenised and plain-text inputs, both tokenisers, smoothing,
