@@ -129,6 +129,7 @@ struct Conv1x1Args {
   int pool;           // 0: Ho=H ; 1: 2x2 average of BN+ReLU'd input before the GEMM
   int H, W;           // input spatial size (used when pool)
   int variant = 0;    // tuning hook: 0 = default kernel choice
+  int exact = 0;      // weights as hi + lo fp16 pairs: w [N][2 K] = [hi | lo] (K % 64 == 0)
 };
 int launch_conv1x1(const Conv1x1Args &a, hipStream_t s);
 
@@ -163,6 +164,7 @@ struct DenseLayerArgs {
   int variant = 0;                   // tuning hook: 0 auto, 1 big tiles, 2 small tiles
   const DenseLayerDev *chain = nullptr;  // device array: run nchain consecutive layers (K, K+32, ...) in one launch
   int nchain = 0;                        // (whole-frame tiles only: 14x14 and 7x7)
+  int exact = 0;                         // weights as hi + lo fp16 pairs: w1 [128][2 Kp] = [hi | lo], w3p = hi image then lo image
 };
 bool dense_layer_supported(int H, int W);
 int launch_dense_layer(const DenseLayerArgs &a, hipStream_t s);

@@ -35,7 +35,9 @@ constexpr int smem_bytes() {
 
 // NB = output channels per workgroup (128, or 256 for the transitions with N >= 256: every column tile streams
 // the pixel tile again and repeats its BN+ReLU+average, so wider tiles cut both)
-template <int MI, bool POOL, int NB>
+// EX (exact-weights mode): w = hi + lo as two fp16 numbers, rows [hi (K) | lo (K)]; the k-tile loop
+// runs over 2 K, the activation side (and its BatchNorm constants) wrapping around after the hi half.
+template <int MI, bool POOL, int NB, bool EX = false>
 __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
   constexpr int BM = 32 * MI;
   constexpr int NSRC = POOL ? 4 : 1;
@@ -89,14 +91,17 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
       xsrc[i][0] = a.x + (long)m * a.ldx;
     }
   }
-  const f16 *wsrc = a.w + (long)(n0 + r0) * K;
+  const int WLD = EX ? 2 * K : K;          // weight row pitch
+  const f16 *wsrc = a.w + (long)(n0 + r0) * WLD;
 
   f16x8 xr[MI][NSRC];
   f16x8 wr[NI];
   float sc[8], sh[8];
 
+  const int nkc = (K + BK - 1) / BK;
   auto load_tile = [&](int kt) {
-    const int kc = kt * BK + c * 8;
+    const int kc = ((EX && kt >= nkc) ? kt - nkc : kt) * BK + c * 8;     // activation channels of this k-tile
+    const int kw = kt * BK + c * 8;                                      // weight columns
     if (kc < K) {
       const float4 s0 = *(const float4 *)(a.scale + kc);
       const float4 s1 = *(const float4 *)(a.scale + kc + 4);
@@ -111,12 +116,12 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
 #pragma unroll
         for (int s = 0; s < NSRC; ++s) xr[i][s] = *(const f16x8 *)(xsrc[i][s] + kc);
 #pragma unroll
-      for (int i = 0; i < NI; ++i) wr[i] = *(const f16x8 *)(wsrc + (long)(32 * i) * K + kc);
+      for (int i = 0; i < NI; ++i) wr[i] = *(const f16x8 *)(wsrc + (long)(32 * i) * WLD + kw);
     }
   };
 
   auto store_tile = [&](int kt) {
-    const int kc = kt * BK + c * 8;
+    const int kc = ((EX && kt >= nkc) ? kt - nkc : kt) * BK + c * 8;
     const bool kv = kc < K;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (K + BK - 1) / BK;
+  const int nk = EX ? 2 * nkc : nkc;
   const int frow = lane & 15;
   const int fch = lane >> 4;
 
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
     if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      if (kt * BK + ks * 32 < K) {
+      if (((EX && kt >= nkc) ? kt - nkc : kt) * BK + ks * 32 < K) {
         f16x8 xb[MI], wa[NI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -215,13 +220,18 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
 int launch_conv1x1(const Conv1x1Args &a, hipStream_t s) {
   TN_REQUIRE(a.K % 32 == 0 && a.N % BN_TILE == 0, "conv1x1: K%32 or N%128");
   TN_REQUIRE(a.ldx % 8 == 0 && a.ldy % 8 == 0 && a.yoff % 8 == 0, "conv1x1: strides must be multiples of 8");
+  TN_REQUIRE(!a.exact || a.pool, "conv1x1: the exact-weights mode is built for the transitions (pool = 1)");
   const dim3 block(256);
   if (a.pool) {
     static const bool narrow = getenv("TN_TRANS_NARROW") != nullptr;   // A/B runs: 128-channel tiles everywhere
     const bool wide = a.N % 256 == 0 && !narrow;
     const int mtiles = (a.M + 63) / 64, NT = a.N / (wide ? 256 : BN_TILE);
     const dim3 grid(((mtiles + 7) / 8) * 8 * NT);
-    if (wide) hipLaunchKernelGGL((conv1x1_kernel<2, true, 256>), grid, block, 0, s, a);
+    if (a.exact) {
+      TN_REQUIRE(a.K % 64 == 0, "conv1x1: the exact-weights mode needs K % 64 == 0");
+      if (wide) hipLaunchKernelGGL((conv1x1_kernel<2, true, 256, true>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((conv1x1_kernel<2, true, 128, true>), grid, block, 0, s, a);
+    } else if (wide) hipLaunchKernelGGL((conv1x1_kernel<2, true, 256>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((conv1x1_kernel<2, true, 128>), grid, block, 0, s, a);
   } else if (a.M >= 128 * 512) {
     const dim3 grid((a.M + 127) / 128, a.N / BN_TILE);

@@ -111,8 +111,13 @@ __device__ __forceinline__ void pp_barrier() {
 // CHAIN (whole-frame tiles only): the workgroup runs a.nchain consecutive layers of the block on its frame
 // inside one launch; layer l reads channels [0, K0 + 32 l) -- its own earlier outputs included, which the
 // same CU's L1 sees coherently once the stores have been waited for -- with parameters from a.chain[l].
-template <int W, int ROUT, int BM, int BK, int PP, bool CHAIN>
+// EX (exact-weights mode): every weight is the sum of two fp16 numbers, w = hi + lo (lo = fp16(w - hi):
+// 22 bits of the fp32 weight).  The 1x1 weights come as [128][2 Kp] = [hi | lo] (Kp = K rounded up to BK) and the K
+// loop simply runs over 2 Kp "channels", the activation side wrapping around after the hi half; the 3x3 weights
+// come as a second packed image and phase B walks 18 taps.  Activations, BatchNorm and accumulation are unchanged.
+template <int W, int ROUT, int BM, int BK, int PP, bool CHAIN, bool EX = false>
 __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
+  static_assert(!EX || PP == 2, "the exact-weights mode exists for the default K loop only");
   using G = DLGeom<W, ROUT, BM, BK>;
   constexpr int WP = G::WP, TR = G::TR, MIW = G::MIW, NI = G::NI;
   static_assert(!G::NSPLIT || PP == 2, "the 4 x 2 wave split exists for the flat K loop only");
@@ -192,8 +197,12 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
 #pragma unroll
     for (int mi = 0; mi < MIW; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)smem);   // LDS byte address of smem
-  const int nk = (K + BK - 1) / BK;
+  const int nkc = (K + BK - 1) / BK;          // k-tiles that carry channels
+  const int nk = EX ? 2 * nkc : nkc;          // k-tiles of the loop (EX: hi pass, then lo pass over the same activations)
+  const int w1ld = EX ? 2 * nkc * BK : K;     // row pitch of the 1x1 weights
   const f16x8 *w3 = (const f16x8 *)a.w3p + 72 * 64 + t;   // second half of the packed buffer: the 16x16x32 layout
+  // packed 3x3 fragments of tap i (EX: taps 9..17 are the lo image, two more layouts further on)
+  auto w3tap = [&](int i) { return (EX && i >= 9) ? w3[2 * 72 * 64 + (i - 9) * 512] : w3[i * 512]; };
   f16x8 wq[3];
   // flat K loops: per-lane DMA source pointers of this wave's PPW pieces (advance by BK halfs per k-tile)
   const f16 *src[PPW];
@@ -212,14 +221,22 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
       }
     }
   };
-  auto issue_pieces = [&](int st, auto j0t, auto j1t) {
+  // after k-tile sidx went out the source pointers move on by BK; EX: the activation pieces wrap around to channel 0
+  // behind the last k-tile of the hi pass (the weight pieces walk on into the lo half of their rows)
+  auto advance = [&](int j, int sidx) {
+    src[j] += BK;
+    if constexpr (EX) {
+      if (sidx == nkc - 1 && wid * PPW + j < G::XPIECES) src[j] -= nkc * BK;
+    }
+  };
+  auto issue_pieces = [&](int st, int sidx, auto j0t, auto j1t) {
 #pragma unroll
     for (int j = decltype(j0t)::value; j < decltype(j1t)::value; ++j) {
       dma16(src[j], lds0 + st * G::STAGE + (wid * PPW + j) * 1024);
-      src[j] += BK;
+      advance(j, sidx);
     }
   };
-  auto issue = [&](int st) { issue_pieces(st, std::integral_constant<int, 0>{}, std::integral_constant<int, PPW>{}); };
+  auto issue = [&](int st, int sidx) { issue_pieces(st, sidx, std::integral_constant<int, 0>{}, std::integral_constant<int, PPW>{}); };
   if constexpr (PP == 1 || PP == 3) {
     constexpr bool XINC = (PP == 3);   // X refill pieces go out between the MFMA groups of the COMPUTE segment
     // Ping-pong K loop.  The two waves of a SIMD (w, w+4) run half a step apart: while one is in its
@@ -366,9 +383,9 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   } else {
   constexpr bool SPREAD = (PP == 2);   // refill pieces interleaved with the MFMA groups instead of up front
   if (!primed) {
-    set_src(xbase, MA, a.w1, K);
-    issue(1);            // stage kt lives in slot (1 + kt) % 3: slot 0 is where the previous tile's
-    if (nk > 1) issue(2);   // output row buffer sits while the next tile's first stages are requested
+    set_src(xbase, MA, a.w1, w1ld);
+    issue(1, 0);            // stage kt lives in slot (1 + kt) % 3: slot 0 is where the previous tile's
+    if (nk > 1) issue(2, 1);   // output row buffer sits while the next tile's first stages are requested
     // BN tables -> LDS (ordinary loads; their wait also covers the two DMA stages above)
     for (int i = t; i < K; i += 512) {
       tab1[i] = a.s1[i];
@@ -399,16 +416,16 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     if (kt == 0) DL_STAMP(1);
     const bool refill = !(TN_EXP & 32) && kt + 2 < nk;
     const int rslot = st >= 1 ? st - 1 : 2;         // slot (kt+2)%3, free since everyone passed the barrier
-    if (!SPREAD && refill) issue(rslot);
+    if (!SPREAD && refill) issue(rslot, kt + 2);
     const unsigned char *Xs = smem + st * G::STAGE;
     const unsigned char *Ws = Xs + G::XS;
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       if (TN_EXP & 16) {
-        if (SPREAD && refill && ks == 0) issue(rslot);
+        if (SPREAD && refill && ks == 0) issue(rslot, kt + 2);
       } else
-      if (kt * BK + ks * 32 < K) {
-        const int kb = kt * BK + ks * 32 + fch * 8;
+      if (((EX && kt >= nkc) ? kt - nkc : kt) * BK + ks * 32 < K) {
+        const int kb = ((EX && kt >= nkc) ? kt - nkc : kt) * BK + ks * 32 + fch * 8;   // activation channels of this k-step
         const float4 s0 = *(const float4 *)(tab1 + kb), s1 = *(const float4 *)(tab1 + kb + 4);
         const float4 t0 = *(const float4 *)(tab1 + 1024 + kb), t1 = *(const float4 *)(tab1 + 1024 + kb + 4);
         const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
@@ -438,7 +455,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
               for (int j = 0; j < PPW; ++j)
                 if (j >= gi * PPW / NG && j < (gi + 1) * PPW / NG) {
                   dma16(src[j], lds0 + rslot * G::STAGE + (wid * PPW + j) * 1024);
-                  src[j] += BK;
+                  advance(j, kt + 2);
                 }
             }
           }
@@ -499,7 +516,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     }
   }
   *(f16x8 *)(ring + t * 16) = wq[0];   // tap 0 -> ring[0]
-  wq[0] = w3[3 * 512];                 // request tap 3
+  wq[0] = w3tap(3);                    // request tap 3
   __syncthreads();
   DL_STAMP(4);
 
@@ -523,15 +540,16 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   // compiler can run the LDS reads ahead of the MFMAs
   auto phase_b = [&](auto nfr_tag) {
     constexpr int NFR = decltype(nfr_tag)::value;
+    constexpr int NT = EX ? 18 : 9;      // EX: the nine taps once more with the lo image of the weights
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int tap = 0; tap < NT; ++tap) {
       // stage the next tap's weights while this tap computes; taps are fully unrolled so
       // the three weight registers rotate with static indices (prefetch distance 3 taps)
-      if (tap + 1 < 9) {
+      if (tap + 1 < NT) {
         *(f16x8 *)(ring + ((tap + 1) & 1) * 8192 + t * 16) = wq[(tap + 1) % 3];
-        if (tap + 4 < 9) wq[(tap + 1) % 3] = w3[(tap + 4) * 512];
+        if (tap + 4 < NT) wq[(tap + 1) % 3] = w3tap(tap + 4);
       }
-      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      const int dy = (tap % 9) / 3 - 1, dx = (tap % 9) - ((tap % 9) / 3) * 3 - 1;
       const int off = WP + dy * WP + dx + px + 16 * u0;   // slot of this lane's pixel, fragment u0
       const unsigned char *wring = ring + (tap & 1) * 8192 + lane * 16;
 #pragma unroll
@@ -572,9 +590,9 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     if constexpr (!CHAIN) {
       if (vb + (int)gridDim.x < nvb) {    // the tile and the 3x3 ring are dead: request the next tile's first stages
         const TileAt nx = tile_at(vb + gridDim.x);
-        set_src(nx.xbase, nx.MA, a.w1, K);
-        issue(1);
-        if (nk > 1) issue(2);
+        set_src(nx.xbase, nx.MA, a.w1, w1ld);
+        issue(1, 0);
+        if (nk > 1) issue(2, 1);
         primed = true;
       }
     } else if (layer + 1 < nlayers) {     // same frame, next layer: its first 128 input channels exist already
@@ -586,9 +604,17 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
         if (idx < nxK) { nxs[i] = dn.s1[idx]; nxt[i] = dn.t1[idx]; }
       }
       if (t < 256) nx2 = t < 128 ? dn.s2[t] : dn.t2[t - 128];
-      set_src(xbase, MA, dn.w1, nxK);
-      issue(1);
-      issue(2);
+      // the next layer's first two k-tiles (its own weight pitch; a chained layer has at least four k-tiles, so
+      // the activation pointers do not wrap yet)
+      const int nxc = (nxK + BK - 1) / BK;
+      set_src(xbase, MA, dn.w1, EX ? 2 * nxc * BK : nxK);
+#pragma unroll
+      for (int st = 1; st <= 2; ++st)
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+          dma16(src[j], lds0 + st * G::STAGE + (wid * PPW + j) * 1024);
+          src[j] += BK;
+        }
       primed = true;
     }
   }
@@ -633,12 +659,12 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   }   // tile
 }
 
-template <int W, int ROUT, int BM, int BK, int PP, bool CHAIN = false>
+template <int W, int ROUT, int BM, int BK, int PP, bool CHAIN = false, bool EX = false>
 int launch_geom(const DenseLayerArgs &a, hipStream_t s) {
   using G = DLGeom<W, ROUT, BM, BK>;
   static bool attr_set = false;
   if (!attr_set) {
-    TN_HIP_CHECK(hipFuncSetAttribute((const void *)dense_layer_kernel<W, ROUT, BM, BK, PP, CHAIN>,
+    TN_HIP_CHECK(hipFuncSetAttribute((const void *)dense_layer_kernel<W, ROUT, BM, BK, PP, CHAIN, EX>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     attr_set = true;
   }
@@ -655,7 +681,7 @@ int launch_geom(const DenseLayerArgs &a, hipStream_t s) {
   // one workgroup per CU walking its tiles (flat K loops, single layer); otherwise one workgroup per tile
   const bool persist = !CHAIN && (PP == 0 || PP == 2) && !(a.variant & 16) && nvb > ncu && ncu > 0;
   const dim3 grid(persist ? ncu : nvb), block(512);
-  hipLaunchKernelGGL((dense_layer_kernel<W, ROUT, BM, BK, PP, CHAIN>), grid, block, G::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((dense_layer_kernel<W, ROUT, BM, BK, PP, CHAIN, EX>), grid, block, G::LDS_BYTES, s, a);
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;
 }
@@ -667,6 +693,18 @@ bool dense_layer_big_supported(int H, int W) { return (H == 56 && W == 56) || (H
 int launch_dense_layer_big(const DenseLayerArgs &a, hipStream_t s) {
   const int klast = a.K + 32 * (a.nchain > 0 ? a.nchain - 1 : 0);
   TN_REQUIRE(a.K % 32 == 0 && klast <= 1024 && a.ldc % 8 == 0 && klast + 32 <= a.ldc, "dense_layer: bad channel geometry");
+  if (a.exact) {     // hi + lo weights: the default K loop only
+    if (a.nchain > 0) {
+      TN_REQUIRE(a.H == a.W && (a.H == 14 || a.H == 7) && a.chain, "dense_layer: layer chaining needs whole-frame tiles (14x14, 7x7)");
+      if (a.H == 14) return launch_geom<14, 14, 256, 64, 2, true, true>(a, s);
+      return launch_geom<7, 7, 64, 64, 2, true, true>(a, s);
+    }
+    if (a.H == 56 && a.W == 56) return launch_geom<56, 7, 512, 32, 2, false, true>(a, s);
+    if (a.H == 28 && a.W == 28) return launch_geom<28, 14, 512, 32, 2, false, true>(a, s);
+    if (a.H == 14 && a.W == 14) return launch_geom<14, 14, 256, 64, 2, false, true>(a, s);
+    if (a.H == 7 && a.W == 7) return launch_geom<7, 7, 128, 64, 2, false, true>(a, s);
+    TN_REQUIRE(false, "dense_layer: unsupported spatial size");
+  }
   if (a.nchain > 0) {
     TN_REQUIRE(a.H == a.W && (a.H == 14 || a.H == 7) && a.chain, "dense_layer: layer chaining needs whole-frame tiles (14x14, 7x7)");
     if (a.H == 14) return launch_geom<14, 14, 256, 64, 2, true>(a, s);
