@@ -124,6 +124,9 @@ def build_parser():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the 256-frame batch on the CPU (minutes)")
     ap.add_argument("--single-region", action="store_true", help="one timed region of K steps only (no repetitions)")
+    ap.add_argument("--exact-weights", action="store_true",
+                    help="NOT the headline configuration: un-rounded fp32 conv weights evaluated as hi + lo fp16 pairs "
+                         "(TN_ENC_EXACT_WEIGHTS), to state what the 1e-3-vs-fp32-weights mode costs")
     return ap
 
 
@@ -142,8 +145,8 @@ def run(argv):
     from tennis_amd.engine import DenseNet121Features
 
     ctx = _lib.Context(dev.index)
-    params = W.make_densenet121_weights(0)
-    enc = DenseNet121Features(params, SIZE, max_batch=args.batch, ctx=ctx)
+    params = W.make_densenet121_weights(0, fp16_model=not args.exact_weights)
+    enc = DenseNet121Features(params, SIZE, max_batch=args.batch, ctx=ctx, exact_weights=args.exact_weights)
     x = make_frames(args.batch, SIZE, 1234 + rank, dev)
     feats = [torch.empty((args.batch, enc.feature_dim), dtype=torch.float32, device=dev) for _ in range(2)]
     gathered = [torch.empty((world * args.batch, enc.feature_dim), dtype=torch.float32, device=dev)
@@ -226,7 +229,9 @@ def run(argv):
                                       "(BASELINE.json configs[1])",
                           "frames_per_step_per_gpu": args.batch, "input": "NHWC fp16 normalised, HBM-resident",
                           "output": "fp32 features (B,1024)" + ("; RCCL all-gather of feature rows" if world > 1 else ""),
-                          "weights": "seeded random-init, conv weights fp16",
+                          "weights": ("seeded random-init, fp32 conv weights as hi + lo fp16 pairs (exact-weights mode, 2x MFMA work "
+                                      "in the dense layers / transitions)") if args.exact_weights
+                                     else "seeded random-init, conv weights fp16",
                           "timing": f"median of {repeats} fenced regions of exactly {args.steps} steps",
                           "region_ms": [round(t * 1e3, 2) for t in times]},
                "roofline": roofline}

@@ -90,6 +90,14 @@ int tn_ctx_destroy(tn_ctx *ctx);
  * 1024*floor(H/32/7)*floor(W/32/7) (1024 @224, 4096 @512; train.py:259). */
 int tn_densenet121_create(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix,
                           int height, int width, int max_batch, tn_encoder **out);
+/* The same with flags.  TN_ENC_EXACT_WEIGHTS: the fp32 convolution weights of the dense layers and transitions are
+ * kept as two fp16 numbers each (hi + lo, 22 bits of the fp32 weight) and every product is formed with both: features
+ * within 1e-3 of the fp32 reference evaluated on the UN-rounded weights (reference models/vision/definitions.py:27-33
+ * evaluates fp32 parameters), at twice the MFMA work of those layers.  Without the flag the weights are rounded to
+ * fp16 once (the served fp16 model).  224 x 224 input only (the fused kernels). */
+#define TN_ENC_EXACT_WEIGHTS 1
+int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix, int height, int width,
+                             int max_batch, int flags, tn_encoder **out);
 int tn_densenet121_feature_dim(const tn_encoder *enc);
 size_t tn_densenet121_workspace_bytes(const tn_encoder *enc);
 /* x: `batch` frames in `layout`; feat: (batch, feature_dim) fp32, NCHW-flatten order. */

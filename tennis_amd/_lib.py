@@ -18,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TENNIS_HIP_LIB") or os.path.join(_HERE, "lib", "libtennis_hip.so")   # env: A/B builds while tuning
 
 LAYOUT_NCHW_F32, LAYOUT_NHWC_F16, LAYOUT_NHWC_U8 = 0, 1, 2
+ENC_EXACT_WEIGHTS = 1
 RNN_GRU, RNN_LSTM = 0, 1
 POOL_MAX, POOL_MEAN = 0, 1
 
@@ -41,6 +42,8 @@ _SIGS = {
     "tn_ctx_destroy": (C.c_int, [_P]),
     "tn_densenet121_create": (C.c_int, [_P, C.POINTER(TnParam), C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int,
                                         C.POINTER(_P)]),
+    "tn_densenet121_create_ex": (C.c_int, [_P, C.POINTER(TnParam), C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.POINTER(_P)]),
     "tn_densenet121_feature_dim": (C.c_int, [_P]),
     "tn_densenet121_workspace_bytes": (C.c_size_t, [_P]),
     "tn_densenet121_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),

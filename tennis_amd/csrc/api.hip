@@ -13,6 +13,8 @@
 #include "rnn.h"
 #include "train.h"
 
+bool dense_layer_big_supported(int H, int W);   // dense_layer_big.hip
+
 // ---------------------------------------------------------------------------
 static thread_local std::string g_err;
 void tn_set_error(const std::string &msg) { g_err = msg; }
@@ -123,6 +125,20 @@ bool fold_bn(const ParamMap &pm, const std::string &name, int c, std::vector<flo
 std::vector<f16> to_f16(const float *w, size_t n) {
   std::vector<f16> h(n + 64, (f16)0.f);
   for (size_t i = 0; i < n; ++i) h[i] = (f16)w[i];
+  return h;
+}
+
+// Exact-weights mode: w = hi + lo with hi = fp16(w), lo = fp16(w - hi) (22 bits of the fp32 weight survive).
+// rows x k fp32 -> [rows][2 kp] fp16 = [hi (k, zero-padded to kp) | lo (...)], + 64 halves of slack like to_f16
+std::vector<f16> split_hi_lo_rows(const float *w, int rows, int k, int kp) {
+  std::vector<f16> h((size_t)rows * 2 * kp + 64, (f16)0.f);
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < k; ++c) {
+      const float v = w[(size_t)r * k + c];
+      const f16 hi = (f16)v;
+      h[(size_t)r * 2 * kp + c] = hi;
+      h[(size_t)r * 2 * kp + kp + c] = (f16)(v - (float)hi);
+    }
   return h;
 }
 
@@ -243,6 +259,7 @@ struct tn_encoder {
   int nsplit;                 // side streams in use (TN_SPLIT, default 2)
   int dl_variant;             // tuning hook: TN_DL_VARIANT -> DenseLayerArgs.variant
   bool chain;                 // whole-frame blocks (14x14, 7x7) run all their layers in one launch (TN_NO_CHAIN disables)
+  bool exact = false;         // TN_ENC_EXACT_WEIGHTS: dense-layer and transition weights as hi + lo fp16 pairs
   DenseLayerDev *chain_dev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipStream_t side[4];
   hipEvent_t ev_in, ev_done[4];
@@ -252,7 +269,13 @@ static const int kBlockCfg[4] = {6, 12, 24, 16};
 
 extern "C" int tn_densenet121_create(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix_c,
                                      int height, int width, int max_batch, tn_encoder **out) {
+  return tn_densenet121_create_ex(ctx, params, n_params, prefix_c, height, width, max_batch, 0, out);
+}
+
+extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix_c,
+                                        int height, int width, int max_batch, int flags, tn_encoder **out) {
   TN_REQUIRE(ctx && params && out && prefix_c, "tn_densenet121_create: null argument");
+  TN_REQUIRE((flags & ~TN_ENC_EXACT_WEIGHTS) == 0, "tn_densenet121_create_ex: unknown flag");
   TN_REQUIRE(max_batch > 0, "tn_densenet121_create: max_batch must be positive");
   TN_REQUIRE(height >= 224 && width >= 224 && height <= 1024 && width <= 1024,
              "tn_densenet121_create: input size must be in [224,1024] (AvgPool2D(7) needs a >=7x7 final map)");
@@ -268,6 +291,7 @@ extern "C" int tn_densenet121_create(tn_ctx *ctx, const tn_param *params, int n_
   if (e->nsplit != 4) e->nsplit = 2;
   e->chain = getenv("TN_NO_CHAIN") == nullptr;   // measured: -20% on the 14x14 / 7x7 blocks, +2.8% end to end
   e->dl_variant = getenv("TN_DL_VARIANT") ? atoi(getenv("TN_DL_VARIANT")) : 0;
+  e->exact = (flags & TN_ENC_EXACT_WEIGHTS) != 0;
   for (int i = 0; i < 4; ++i) {
     if (hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_done[i], hipEventDisableTiming) != hipSuccess) {
@@ -288,6 +312,11 @@ extern "C" int tn_densenet121_create(tn_ctx *ctx, const tn_param *params, int n_
   auto fail = [&](int code) { e->pool.release(); delete e; return code; };
   if (e->PH < 1 || e->PW < 1) { tn_set_error("input too small for AvgPool2D(7)"); return fail(TN_ERR_INVALID); }
   if (e->Wb[0] > 240) { tn_set_error("input too wide for the conv3x3 LDS tile"); return fail(TN_ERR_INVALID); }
+  if (e->exact) {      // the hi + lo weight passes exist in the 8-wave fused layer and the transition kernel only
+    bool ok = e->fuse && (e->dl_variant & ~256) == 0;
+    for (int b = 0; b < 4; ++b) ok = ok && dense_layer_big_supported(e->Hb[b], e->Wb[b]);
+    if (!ok) { tn_set_error("TN_ENC_EXACT_WEIGHTS needs the fused 224x224 path (56/28/14/7 blocks, default kernels)"); return fail(TN_ERR_INVALID); }
+  }
 
   std::vector<float> s, t;
   {  // stem: conv0 + batchnorm0
@@ -308,10 +337,27 @@ extern "C" int tn_densenet121_create(tn_ctx *ctx, const tn_param *params, int n_
       if (!w1 || !w3) return fail(TN_ERR_MISSING);
       if (!fold_bn(pm, sp + "batchnorm" + std::to_string(2 * l), L.cin, s, t)) return fail(TN_ERR_MISSING);
       L.s1 = e->pool.upload(s); L.t1 = e->pool.upload(t);
-      L.w1 = e->pool.upload(to_f16(w1, (size_t)128 * L.cin));
+      if (e->exact) {
+        const int bk = e->Hb[b] >= 28 ? 32 : 64;          // k-tile of the block's fused kernel (dense_layer_big.hip)
+        L.w1 = e->pool.upload(split_hi_lo_rows(w1, 128, L.cin, (L.cin + bk - 1) / bk * bk));
+      } else {
+        L.w1 = e->pool.upload(to_f16(w1, (size_t)128 * L.cin));
+      }
       if (!fold_bn(pm, sp + "batchnorm" + std::to_string(2 * l + 1), 128, s, t)) return fail(TN_ERR_MISSING);
       L.s2 = e->pool.upload(s); L.t2 = e->pool.upload(t);
-      L.w3p = e->pool.upload(pack_conv3x3(w3));
+      if (e->exact) {       // packed image of hi, then packed image of lo
+        std::vector<float> hi(32 * 128 * 9), lo(32 * 128 * 9);
+        for (size_t i = 0; i < hi.size(); ++i) {
+          hi[i] = (float)(f16)w3[i];
+          lo[i] = w3[i] - hi[i];
+        }
+        std::vector<f16> img = pack_conv3x3(hi.data());
+        const std::vector<f16> img_lo = pack_conv3x3(lo.data());
+        img.insert(img.end(), img_lo.begin(), img_lo.end());
+        L.w3p = e->pool.upload(img);
+      } else {
+        L.w3p = e->pool.upload(pack_conv3x3(w3));
+      }
       e->layers[b].push_back(L);
     }
     {
@@ -325,7 +371,8 @@ extern "C" int tn_densenet121_create(tn_ctx *ctx, const tn_param *params, int n_
       const float *wt = pm.get(pre + "conv" + std::to_string(outer) + "_weight", (int64_t)T.cout * T.cin);
       if (!wt || !fold_bn(pm, pre + "batchnorm" + std::to_string(outer), T.cin, s, t)) return fail(TN_ERR_MISSING);
       T.s = e->pool.upload(s); T.t = e->pool.upload(t);
-      T.w = e->pool.upload(to_f16(wt, (size_t)T.cout * T.cin));
+      T.w = e->exact ? e->pool.upload(split_hi_lo_rows(wt, T.cout, T.cin, T.cin))
+                     : e->pool.upload(to_f16(wt, (size_t)T.cout * T.cin));
       ++outer;
     }
   }
@@ -388,6 +435,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
       auto &L0 = e->layers[b][0];
       const int nl = (int)e->layers[b].size();
       DenseLayerArgs af{bbuf[b], e->Cb[b], L0.cin, L0.s1, L0.t1, L0.w1, L0.s2, L0.t2, L0.w3p, B, Hh, Ww, nullptr, e->dl_variant, e->chain_dev[b], nl};
+      af.exact = e->exact;
       double fl = 0, by = 0;
       for (auto &L : e->layers[b]) {
         fl += 2.0 * M * (128.0 * L.cin + 32.0 * 1152);
@@ -401,6 +449,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
     for (auto &L : e->layers[b]) {
       if (fused) {
         DenseLayerArgs af{bbuf[b], e->Cb[b], L.cin, L.s1, L.t1, L.w1, L.s2, L.t2, L.w3p, B, Hh, Ww, nullptr, e->dl_variant};
+        af.exact = e->exact;
         const std::string fam = "dense_layer_fused_" + std::to_string(Hh) + "x" + std::to_string(Ww);
         tm.begin(fam.c_str(), 2.0 * M * (128.0 * L.cin + 32.0 * 1152),
                  (double)M * (L.cin + 32) * 2 + 128.0 * L.cin * 2 + 32.0 * 1152 * 2);
@@ -424,6 +473,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
       auto &T = e->trans[b];
       const int Mo = B * e->Hb[b + 1] * e->Wb[b + 1];
       Conv1x1Args at{bbuf[b], e->Cb[b], T.cin, T.s, T.t, T.w, T.cout, bbuf[b + 1], e->Cb[b + 1], 0, Mo, 1, Hh, Ww};
+      at.exact = e->exact;
       tm.begin("transition_conv1x1_avgpool", 2.0 * M * (double)T.cout * T.cin,
                (double)M * T.cin * 2 + (double)Mo * T.cout * 2 + (double)T.cout * T.cin * 2);
       rc = launch_conv1x1(at, s);

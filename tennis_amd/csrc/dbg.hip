@@ -35,7 +35,8 @@ extern "C" int tn_dbg_conv1x1_dev(tn_ctx *ctx, const void *x_f16, int ldx, int K
                                   int pool, int H, int W, int variant) {
   TN_REQUIRE(ctx && x_f16 && y_f16 && scale && shift && w_f16, "tn_dbg_conv1x1_dev: null argument");
   Conv1x1Args a{(const f16 *)x_f16, ldx, K, scale, shift, (const f16 *)w_f16, N, (f16 *)y_f16, ldy, yoff, M, pool, H, W};
-  a.variant = variant;
+  a.variant = variant & 0xffff;
+  a.exact = (variant >> 17) & 1;      // bit 17: w is [N][2 K] = [hi | lo] (exact-weights mode)
   return launch_conv1x1(a, ctx->stream);
 }
 
@@ -92,7 +93,8 @@ extern "C" int tn_dbg_dense_layer_dev(tn_ctx *ctx, void *buf_f16, int ldc, int K
   TN_REQUIRE(ctx && buf_f16 && s1 && t1 && w1_f16 && s2 && t2 && w3p_f16, "tn_dbg_dense_layer_dev: null argument");
   DenseLayerArgs a{(f16 *)buf_f16, ldc, K, s1, t1, (const f16 *)w1_f16, s2, t2, (const f16 *)w3p_f16, B, H, W};
   a.ts = ts;
-  a.variant = variant;
+  a.variant = variant & 0xffff;
+  a.exact = (variant >> 17) & 1;      // bit 17: w1 is [128][2 Kp] = [hi | lo], w3p the hi image followed by the lo image
   return launch_dense_layer(a, ctx->stream);
 }
 

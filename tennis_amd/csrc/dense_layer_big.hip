@@ -460,6 +460,18 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
             }
           }
         }
+      } else if constexpr (EX && SPREAD) {
+        // a k-step past the channels in the MIDDLE of the loop (last k-tile of the hi pass when K % 64 == 32): its
+        // share of the refill goes out all the same
+        if (refill) {
+          constexpr int NG = (BK / 32) * MIW;
+#pragma unroll
+          for (int j = 0; j < PPW; ++j)
+            if (j >= ks * MIW * PPW / NG && j < (ks + 1) * MIW * PPW / NG) {
+              dma16(src[j], lds0 + rslot * G::STAGE + (wid * PPW + j) * 1024);
+              advance(j, kt + 2);
+            }
+        }
       }
     }
     st = st == 2 ? 0 : st + 1;

@@ -41,15 +41,20 @@ class DenseNet121Features:
     """``get_model('DenseNet121').features`` on the GPU (reference evaluate.py:125)."""
 
     def __init__(self, params: dict, size: int | tuple = 224, max_batch: int = 256, prefix: str = "densenet0_",
-                 ctx: _lib.Context | None = None):
+                 ctx: _lib.Context | None = None, exact_weights: bool = False):
+        """``exact_weights``: keep the fp32 convolution weights of the dense layers / transitions as hi + lo fp16
+        pairs (TN_ENC_EXACT_WEIGHTS) instead of rounding them to fp16 once — for parameters that were NOT converted
+        with ``weights.as_fp16_model`` (a trained fp32 checkpoint) and a 1e-3 agreement with their fp32 evaluation."""
         self.ctx = ctx or _lib.default_context()
         self.lib = self.ctx.lib
         self.size = (size, size) if isinstance(size, int) else tuple(size)
         self.max_batch = max_batch
         arr, keep = _lib.make_params({k: v for k, v in params.items() if k.startswith(prefix)})
         h = C.c_void_p()
-        check(self.lib.tn_densenet121_create(self.ctx.handle, arr, len(arr), prefix.encode(), self.size[0],
-                                             self.size[1], max_batch, C.byref(h)), "tn_densenet121_create")
+        self.exact_weights = bool(exact_weights)
+        check(self.lib.tn_densenet121_create_ex(self.ctx.handle, arr, len(arr), prefix.encode(), self.size[0], self.size[1],
+                                                max_batch, _lib.ENC_EXACT_WEIGHTS if exact_weights else 0, C.byref(h)),
+              "tn_densenet121_create")
         del keep
         self.handle = h
         self.feature_dim = self.lib.tn_densenet121_feature_dim(h)

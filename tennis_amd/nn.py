@@ -86,9 +86,11 @@ class LSTM(_RNNLayer):
 class DenseNet121Backbone(Block):
     """``get_model('DenseNet121', ...).features`` (reference evaluate.py:125): frames -> (B, F) fp32."""
 
-    def __init__(self, seed=0, prefix="densenet0_", max_batch=256, **kwargs):
+    def __init__(self, seed=0, prefix="densenet0_", max_batch=256, exact_weights=False, **kwargs):
+        """``exact_weights=True``: adopted conv weights stay fp32 and the library evaluates them as hi + lo fp16 pairs
+        (engine.DenseNet121Features(exact_weights=True)); default: the fp16 model (weights rounded once on adoption)."""
         super().__init__(prefix=prefix, **kwargs)
-        self._seed, self._max_batch = seed, max_batch
+        self._seed, self._max_batch, self._exact = seed, max_batch, bool(exact_weights)
         convs, final_bn, cfin = W.densenet121_layout()
         names = []
         for cv in convs:
@@ -102,7 +104,7 @@ class DenseNet121Backbone(Block):
     def initialize(self, *a, **k):
         super().initialize(*a, **k)
         if next(iter(self._own_params.values())).data is None:
-            self._adopt(W.make_densenet121_weights(self._seed, self.prefix))
+            self._adopt(W.make_densenet121_weights(self._seed, self.prefix, fp16_model=not self._exact))
 
     def _structural_params(self, path: str = "") -> dict:
         """Structural names of gluon ``model_zoo.vision.densenet121().features`` [EXT]: a HybridSequential of
@@ -138,7 +140,8 @@ class DenseNet121Backbone(Block):
         return out
 
     def _adopt(self, params):
-        super()._adopt(W.as_fp16_model({k: v for k, v in params.items() if k in self._own_params}))
+        own = {k: v for k, v in params.items() if k in self._own_params}
+        super()._adopt(own if self._exact else W.as_fp16_model(own))
 
     def forward(self, x):
         x = _to_device(x)
@@ -152,6 +155,6 @@ class DenseNet121Backbone(Block):
             self._engine = None  # release the old workspace first
             p = {k: v.data for k, v in self._own_params.items()}
             self._engine = engine.DenseNet121Features(p, size, max_batch=max(b, min(self._max_batch, 64)),
-                                                      prefix=self.prefix)
+                                                      prefix=self.prefix, exact_weights=self._exact)
             self._size = size
         return self._engine(x)

@@ -131,3 +131,18 @@ def test_finetune_errors():
     with pytest.raises(RuntimeError, match="stage2_batchnorm5_running_var"):
         FrameModelTrainer(q, 64, 11, batch=2)
     assert lib.tn_finetune_destroy(None) == 0
+
+
+def test_encoder_create_ex_flags():
+    """tn_densenet121_create_ex: unknown flags and the exact-weights mode outside the fused 224x224 path are errors."""
+    import ctypes as C
+    from tennis_amd import _lib, weights as W
+    ctx = _lib.default_context()
+    arr, keep = _lib.make_params(W.make_densenet121_weights(0))
+    h = C.c_void_p()
+    assert ctx.lib.tn_densenet121_create_ex(ctx.handle, arr, len(arr), b"densenet0_", 224, 224, 2, 2, C.byref(h)) != 0
+    assert b"unknown flag" in ctx.lib.tn_last_error()
+    assert ctx.lib.tn_densenet121_create_ex(ctx.handle, arr, len(arr), b"densenet0_", 512, 512, 2, _lib.ENC_EXACT_WEIGHTS, C.byref(h)) != 0
+    assert b"TN_ENC_EXACT_WEIGHTS needs the fused 224x224 path" in ctx.lib.tn_last_error()
+    assert ctx.lib.tn_densenet121_create_ex(ctx.handle, arr, len(arr), b"densenet0_", 224, 224, 2, _lib.ENC_EXACT_WEIGHTS, C.byref(h)) == 0
+    assert ctx.lib.tn_densenet121_destroy(h) == 0

@@ -208,3 +208,75 @@ def test_dense_layer_fused(ctx, report, B, H, K, ldc, variant):
     assert err < 2e-2, err
     keep = np.ones(ldc, bool); keep[K:K + 32] = False
     assert np.array_equal(out[..., keep], buf[..., keep].astype(np.float32))
+
+
+def _split_hi_lo_rows(w, kp):
+    """[rows][2 kp] fp16 = [hi | lo] (+64 halves of slack), the exact-weights operand of the 1x1 convolutions"""
+    n, k = w.shape
+    hi = w.astype(np.float16)
+    lo = (w - hi.astype(np.float32)).astype(np.float16)
+    out = np.zeros((n, 2 * kp), np.float16)
+    out[:, :k] = hi
+    out[:, kp:kp + k] = lo
+    return np.concatenate([out.ravel(), np.zeros(64, np.float16)])
+
+
+@pytest.mark.parametrize("B,H,K,ldc", [(2, 56, 64, 256), (1, 56, 224, 256), (40, 56, 96, 256), (2, 28, 480, 512), (3, 28, 160, 512),
+                                        (2, 14, 256, 1024), (2, 14, 288, 1024), (2, 14, 992, 1024), (3, 7, 512, 1024), (3, 7, 544, 1024)])
+def test_dense_layer_exact_weights(ctx, report, B, H, K, ldc):
+    """TN_ENC_EXACT_WEIGHTS in the fused dense layer (hi + lo fp16 pairs, K loop over [hi | lo], 18-tap phase B) vs the
+    layer evaluated with the fp32 weights; K % 64 == 32 puts a dead k-step in the middle of the 64-channel loops."""
+    from tennis_amd import _lib
+    rng = np.random.default_rng(B * 1000 + H + K)
+    buf = rng.normal(0, 1.5, (B, H, H, ldc)).astype(np.float16)
+    s1 = rng.uniform(0.5, 1.5, K).astype(np.float32); t1 = rng.normal(0, 0.3, K).astype(np.float32)
+    s2 = rng.uniform(0.5, 1.5, 128).astype(np.float32); t2 = rng.normal(0, 0.3, 128).astype(np.float32)
+    w1 = rng.normal(0, np.sqrt(2.0 / K), (128, K)).astype(np.float32)
+    w3 = rng.normal(0, np.sqrt(2.0 / 1152), (32, 128, 3, 3)).astype(np.float32)
+    bk = 32 if H >= 28 else 64
+    kp = (K + bk - 1) // bk * bk
+    w3hi = _h(w3)
+    imgs = []
+    for part in (w3hi, w3 - w3hi):
+        wp = np.empty(2 * 72 * 64 * 8, np.uint16)
+        ctx.lib.tn_dbg_pack_conv3x3(np.ascontiguousarray(part, np.float32).ctypes.data_as(C.c_void_p), wp.ctypes.data_as(C.c_void_p))
+        imgs.append(wp)
+    d = dict(buf=torch.from_numpy(buf).cuda(), s1=torch.from_numpy(s1).cuda(), t1=torch.from_numpy(t1).cuda(),
+             s2=torch.from_numpy(s2).cuda(), t2=torch.from_numpy(t2).cuda(), w1=torch.from_numpy(_split_hi_lo_rows(w1, kp)).cuda(),
+             wp=torch.from_numpy(np.concatenate(imgs).view(np.int16)).cuda())
+    _lib.check(ctx.lib.tn_dbg_dense_layer_dev(ctx.handle, _lib.ptr(d["buf"]), ldc, K, _lib.ptr(d["s1"]), _lib.ptr(d["t1"]), _lib.ptr(d["w1"]),
+                                              _lib.ptr(d["s2"]), _lib.ptr(d["t2"]), _lib.ptr(d["wp"]), B, H, H, None, 1 << 17), "dense_layer")
+    out = d["buf"].cpu().numpy().astype(np.float32)
+    a1 = _bnrelu_h(buf[..., :K].astype(np.float32), s1, t1)
+    bott = (a1.reshape(-1, K).astype(np.float64) @ w1.astype(np.float64).T).reshape(B, H, H, 128).astype(np.float32)
+    a2 = _h(np.maximum(bott * s2 + t2, 0).astype(np.float32))
+    ref = dn.conv2d_nhwc(a2, w3, 1, 1)                                      # fp32 weights, un-rounded
+    err = np.abs(out[..., K:K + 32] - ref).max()
+    report[f"dense_layer_exact_{B}x{H}_K{K}"] = float(err)
+    assert err < 6e-3, err            # fp16 output rounding (values up to ~8: half an ulp = 2e-3 .. 4e-3)
+    keep = np.ones(ldc, bool); keep[K:K + 32] = False
+    assert np.array_equal(out[..., keep], buf[..., keep].astype(np.float32))
+
+
+@pytest.mark.parametrize("B,H,K,N", [(2, 56, 256, 128), (2, 28, 512, 256), (3, 14, 1024, 512)])
+def test_transition_exact_weights(ctx, report, B, H, K, N):
+    """TN_ENC_EXACT_WEIGHTS in the transition kernel (BN+ReLU, 2x2 average, 1x1 conv over [hi | lo] weights)."""
+    from tennis_amd import _lib
+    rng = np.random.default_rng(H + K)
+    M = B * H * H
+    x = rng.normal(0, 1.5, (M, K)).astype(np.float16)
+    sc = rng.uniform(0.5, 1.5, K).astype(np.float32); sh = rng.normal(0, 0.3, K).astype(np.float32)
+    w = rng.normal(0, np.sqrt(2.0 / K), (N, K)).astype(np.float32)
+    Mo = M // 4
+    y = torch.zeros((Mo, N), device="cuda", dtype=torch.float16)
+    d = dict(x=torch.from_numpy(x).cuda(), sc=torch.from_numpy(sc).cuda(), sh=torch.from_numpy(sh).cuda(),
+             w=torch.from_numpy(_split_hi_lo_rows(w, K)).cuda())
+    _lib.check(ctx.lib.tn_dbg_conv1x1_dev(ctx.handle, _lib.ptr(d["x"]), K, K, _lib.ptr(d["sc"]), _lib.ptr(d["sh"]), _lib.ptr(d["w"]), N,
+                                          _lib.ptr(y), N, 0, Mo, 1, H, H, 1 << 17), "conv1x1")
+    a = np.maximum(x.astype(np.float32) * sc + sh, 0).reshape(B, H // 2, 2, H // 2, 2, K).mean(axis=(2, 4))
+    a = _h(a).reshape(Mo, K)
+    ref = a.astype(np.float64) @ w.astype(np.float64).T
+    got = y.cpu().numpy().astype(np.float64)
+    err = np.abs(got - ref).max()
+    report[f"transition_exact_{H}_K{K}"] = float(err)
+    assert err < 4e-3, err            # fp16 output rounding
