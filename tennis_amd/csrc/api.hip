@@ -430,7 +430,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
     const int Hh = e->Hb[b], Ww = e->Wb[b];
     const int M = B * Hh * Ww;
     const bool fused = e->fuse && dense_layer_supported(Hh, Ww);
-    if (fused && e->chain && (e->dl_variant & ~(32 | 64 | 128)) == 0 && Hh == Ww && (Hh == 14 || Hh == 7)) {
+    if (fused && e->chain && (e->dl_variant & ~(32 | 64 | 128 | 256 | 512)) == 0 && Hh == Ww && (Hh == 14 || Hh == 7)) {
       // one workgroup per frame walks the whole block: no launch gaps, no cold prologue per layer
       auto &L0 = e->layers[b][0];
       const int nl = (int)e->layers[b].size();

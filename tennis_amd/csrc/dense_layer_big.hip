@@ -49,7 +49,7 @@ struct DLGeom {
   static constexpr int TILE_BYTES = TSLOT * 256;
   static constexpr int ROWB = BK * 2;                        // bytes per staged row
   static constexpr int XS = BM * ROWB, WS = 128 * ROWB, STAGE = XS + WS;
-  static constexpr int NST = 3;
+  static constexpr int NST = (BM == 64) ? 4 : 3;             // ring slots (7x7: four, for the software-pipelined K loop)
   static constexpr int PIECES = STAGE / 1024, PPW = PIECES / 8, XPIECES = XS / 1024;
   static constexpr int RPP = 1024 / ROWB;                    // rows per 1-KiB DMA piece
   static constexpr int RING_A = NST * STAGE;
@@ -120,7 +120,8 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   static_assert(!EX || PP == 2, "the exact-weights mode exists for the default K loop only");
   using G = DLGeom<W, ROUT, BM, BK>;
   constexpr int WP = G::WP, TR = G::TR, MIW = G::MIW, NI = G::NI;
-  static_assert(!G::NSPLIT || PP == 2, "the 4 x 2 wave split exists for the flat K loop only");
+  static_assert(!G::NSPLIT || PP == 2 || PP == 4, "the 4 x 2 wave split exists for the flat K loops only");
+  static_assert(PP != 4 || (G::NSPLIT && BK == 64), "the software-pipelined K loop is built for the 7x7 geometry");
   constexpr int ROWB = G::ROWB, PPW = G::PPW, RPP = G::RPP, CPR = ROWB / 16;  // chunks per row
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *tile = smem;                   // bottleneck tile (aliases the DMA ring)
@@ -380,6 +381,98 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     }
     // no wave reads the rings any more (the other half is at most inside its last COMPUTE segment):
     // the tile that aliases them may be written
+  } else if constexpr (PP == 4) {
+  // ---------------------------------------------------------------------------------------------------------
+  // Software-pipelined K loop of the 7x7 geometry (64-channel stages).  The flat loop walks, once per k-step and
+  // behind the stage's barrier, a chain LDS reads -> BN+ReLU -> MFMAs with 4 MFMAs per wave at its end (measured:
+  // 1 800 cycles per stage for 128 cycles of MFMA work).  Here the operands of k-step j+1 are read while k-step j
+  // computes, THROUGH the stage boundary: the barrier that publishes stage kt+1 sits in the middle of stage kt (after
+  // its first k-step), and the reads of (kt+1, ks 0) go out before (kt, ks 1) computes.  Four ring slots, stage kt in
+  // slot (1 + kt) % 4: stage kt+3 is requested at that barrier into the slot of stage kt-1 and has two stages of time
+  // to land.  Measured per 64-channel stage (K = 768): 1 810 cycles flat, 1 150 this way; with the request going to
+  // the slot of stage kt instead (three slots; every wave holds (kt, ks 1) in registers by then) 1 450, with five
+  // slots and three stages in flight 1 470; the same loop at 14x14 (8 + 2 fragments per k-step) is 14 % SLOWER than
+  // the flat one there - its K loop is bound by the activation stream, not by the operand chain.
+  // ---------------------------------------------------------------------------------------------------------
+  struct Opnd { f16x8 wa[NI]; f16x8 x[MIW]; float sc[8], sh[8]; };
+  auto read_opnd = [&](Opnd &o, int kt, int ks) {
+    const unsigned char *Xs = smem + ((1 + kt) & 3) * G::STAGE;
+    const unsigned char *Ws = Xs + G::XS;
+    const int kb = kt * BK + ks * 32 + fch * 8;
+    const float4 s0 = *(const float4 *)(tab1 + kb), s1 = *(const float4 *)(tab1 + kb + 4);
+    const float4 t0 = *(const float4 *)(tab1 + 1024 + kb), t1 = *(const float4 *)(tab1 + 1024 + kb + 4);
+    o.sc[0] = s0.x; o.sc[1] = s0.y; o.sc[2] = s0.z; o.sc[3] = s0.w; o.sc[4] = s1.x; o.sc[5] = s1.y; o.sc[6] = s1.z; o.sc[7] = s1.w;
+    o.sh[0] = t0.x; o.sh[1] = t0.y; o.sh[2] = t0.z; o.sh[3] = t0.w; o.sh[4] = t1.x; o.sh[5] = t1.y; o.sh[6] = t1.z; o.sh[7] = t1.w;
+#pragma unroll
+    for (int mi = 0; mi < MIW; ++mi) {
+      const int xrow = mrow0 + mi * 16 + frow;
+      o.x[mi] = *(const f16x8 *)(Xs + xrow * ROWB + (stage_swz<BK>(xrow, ks * 4 + fch) << 4));
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int row = nch0 + ni * 16 + frow;
+      o.wa[ni] = *(const f16x8 *)(Ws + row * ROWB + (stage_swz<BK>(row, ks * 4 + fch) << 4));
+    }
+  };
+  auto compute = [&](const Opnd &o) {
+#pragma unroll
+    for (int mi = 0; mi < MIW; ++mi) {
+      if (mrow0 + mi * 16 < MA) {                  // wave-uniform: fragments past the frame's rows are skipped
+        const f16x8 xb = bn_relu8_mix(o.x[mi], o.sc, o.sh);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.wa[ni], xb, acc[ni][mi], 0, 0, 0);
+      }
+    }
+  };
+  auto issue4 = [&](int kstage) {      // k-tile kstage -> slot (1 + kstage) % 4
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      dma16(src[j], lds0 + ((1 + kstage) & 3) * G::STAGE + (wid * PPW + j) * 1024);
+      src[j] += BK;
+    }
+  };
+  if (!primed) {
+    set_src(xbase, MA, a.w1, K);
+    issue4(0);
+    if (nk > 1) issue4(1);
+    if (nk > 2) issue4(2);
+    for (int i = t; i < K; i += 512) {
+      tab1[i] = a.s1[i];
+      tab1[1024 + i] = a.t1[i];
+    }
+    if (t < 128) {
+      tab2[t] = a.s2[t];
+      tab2[128 + t] = a.t2[t];
+    }
+  }
+  primed = false;
+  wq[0] = w3[0];
+  wq[1] = w3[512];
+  wq[2] = w3[2 * 512];
+  // stage 0 has landed; stages 1, 2 and the three taps above are younger (a cold start has drained everything at its
+  // table loads already)
+  if (nk > 2) wait_vmcnt<2 * PPW + 3>(); else wait_vmcnt<0>();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // table writes of a cold start
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  DL_STAMP(1);
+  Opnd o0, o1;
+  read_opnd(o0, 0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool live1 = kt * BK + 32 < K;          // the stage's second k-step carries channels (K % 64 == 32: not in the last one)
+    if (live1) read_opnd(o1, kt, 1);
+    compute(o0);
+    if (kt + 1 < nk) {
+      // publish stage kt+1: own pieces landed (stage kt+2 may still be in flight), then the barrier
+      if (kt + 2 < nk) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      pp_barrier();
+      if (kt + 3 < nk) issue4(kt + 3);
+      read_opnd(o0, kt + 1, 0);
+    }
+    if (live1) compute(o1);
+  }
+  __syncthreads();   // every wave is done reading the DMA ring; the tile may now be written
   } else {
   constexpr bool SPREAD = (PP == 2);   // refill pieces interleaved with the MFMA groups instead of up front
   if (!primed) {
@@ -598,13 +691,16 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   // pixel's 32 channels contiguously.  The buffer aliases the tile: every wave is past the last tap ----
   float nxs[2] = {0.f, 0.f}, nxt[2] = {0.f, 0.f}, nx2 = 0.f;   // CHAIN: the next layer's BN tables on their way
   int nxK = 0;
-  if constexpr (PP == 0 || PP == 2) {
+  if constexpr (PP == 0 || PP == 2 || PP == 4) {
     if constexpr (!CHAIN) {
       if (vb + (int)gridDim.x < nvb) {    // the tile and the 3x3 ring are dead: request the next tile's first stages
         const TileAt nx = tile_at(vb + gridDim.x);
         set_src(nx.xbase, nx.MA, a.w1, w1ld);
         issue(1, 0);
         if (nk > 1) issue(2, 1);
+        if constexpr (PP == 4) {
+          if (nk > 2) issue(3, 2);
+        }
         primed = true;
       }
     } else if (layer + 1 < nlayers) {     // same frame, next layer: its first 128 input channels exist already
@@ -621,7 +717,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
       const int nxc = (nxK + BK - 1) / BK;
       set_src(xbase, MA, dn.w1, EX ? 2 * nxc * BK : nxK);
 #pragma unroll
-      for (int st = 1; st <= 2; ++st)
+      for (int st = 1; st <= (PP == 4 ? 3 : 2); ++st)       // (the pipelined loop keeps three k-tiles requested: slots 1, 2, 3)
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
           dma16(src[j], lds0 + st * G::STAGE + (wid * PPW + j) * 1024);
@@ -721,7 +817,9 @@ int launch_dense_layer_big(const DenseLayerArgs &a, hipStream_t s) {
     TN_REQUIRE(a.H == a.W && (a.H == 14 || a.H == 7) && a.chain, "dense_layer: layer chaining needs whole-frame tiles (14x14, 7x7)");
     if (a.H == 14) return launch_geom<14, 14, 256, 64, 2, true>(a, s);
     // 7x7: 4 x 2 wave split over a 64-row tile (variant bit 5: the 8 x 1 split over 128 rows, for A/B runs)
-    return (a.variant & 32) ? launch_geom<7, 7, 128, 64, 2, true>(a, s) : launch_geom<7, 7, 64, 64, 2, true>(a, s);
+    // bit 9: the flat K loop instead of the software-pipelined one (A/B runs)
+    if (a.variant & 32) return launch_geom<7, 7, 128, 64, 2, true>(a, s);
+    return (a.variant & 512) ? launch_geom<7, 7, 64, 64, 2, true>(a, s) : launch_geom<7, 7, 64, 64, 4, true>(a, s);
   }
   // K-loop flavour (tuning hook, variant bits 2-3): default 0 -> flat loop with the refill spread over the MFMA
   // groups (measured best); 1 -> ping-pong halves, 2 -> flat with the refill up front, 3 -> ping-pong with the
@@ -734,7 +832,12 @@ int launch_dense_layer_big(const DenseLayerArgs &a, hipStream_t s) {
   if (a.H == 56 && a.W == 56) return TN_GEOM(56, 7, 512, 32);
   if (a.H == 28 && a.W == 28) return TN_GEOM(28, 14, 512, 32);
   if (a.H == 14 && a.W == 14) return TN_GEOM(14, 14, 256, 64);
-  if (a.H == 7 && a.W == 7) return TN_GEOM(7, 7, 128, 64);
+  if (a.H == 7 && a.W == 7) {
+    // default: the 4 x 2 wave split with the software-pipelined K loop, as the chained launch (bit 9: the older
+    // 8 x 1 split over a 128-row tile with the K-loop flavours of bits 2-3)
+    if (!(a.variant & 512) && pp == 2) return launch_geom<7, 7, 64, 64, 4>(a, s);
+    return TN_GEOM(7, 7, 128, 64);
+  }
 #undef TN_GEOM
   TN_REQUIRE(false, "dense_layer: unsupported spatial size");
 }
