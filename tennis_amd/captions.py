@@ -153,7 +153,7 @@ def evaluate(data_loader, model, translator, data_train):
     translation_out, all_inst_ids = [], []
     avg_loss_denom, avg_loss = 0, 0.0
     for src_seq, tgt_seq, src_valid_length, tgt_valid_length, inst_ids in data_loader:
-        src = torch.from_numpy(src_seq).cuda()
+        src = model.embed_source(torch.from_numpy(src_seq).cuda())     # frame mode: the clip's frames through the CNN
         tgt = torch.from_numpy(tgt_seq).cuda()
         svl = torch.from_numpy(src_valid_length).cuda()
         tvl = torch.from_numpy(tgt_valid_length).cuda()

@@ -80,14 +80,18 @@ class Vocab:
 
 class NMTModel(Block):
     """``gluonnlp.model.translation.NMTModel(src_vocab=None, tgt_vocab, encoder, decoder, embed_size,
-    prefix, src_embed, tgt_embed)`` as called at reference train_gnmt.py:228-229: feature-mode source
-    (identity src_embed), Embedding(V, embed) target, Dense(V) projection."""
+    prefix, src_embed, tgt_embed)`` as called at reference train_gnmt.py:228-229: Embedding(V, embed) target,
+    Dense(V) projection, and a source "embedding" that is either the identity (feature mode: pre-extracted frame
+    features, train_gnmt.py:188-192) or ``TimeDistributed(backbone)`` (frame mode, train_gnmt.py:148-170: the clip's
+    frames go through the CNN inside the model).  ``src_embed``: None / identity, or a block mapping
+    (B, T, frame...) -> (B, T, input_size)."""
 
     def __init__(self, src_vocab=None, tgt_vocab=None, encoder=None, decoder=None, embed_size=100, prefix="gnmt_",
                  src_embed=None, tgt_embed=None, input_size=1024, seed=7, **kwargs):
         super().__init__(prefix=prefix)
         self.tgt_vocab, self.encoder, self.decoder = tgt_vocab, encoder, decoder
         self._embed_size, self._input_size, self._seed = embed_size, input_size, seed
+        self.src_embed = src_embed if isinstance(src_embed, Block) else None
         for n in ("tgt_proj_weight", "tgt_proj_bias", "tgt_embed_weight"):
             self._own_params[prefix + n] = Parameter(prefix + n)
         if tgt_embed is not None:                      # train_gnmt.py:211-218: preloaded embedding table
@@ -102,6 +106,16 @@ class NMTModel(Block):
             have = {k: v.data for k, v in self.collect_params().items() if v.data is not None}
             p.update(have)
             self.set_params(p)
+
+    def embed_source(self, src):
+        """``self.src_embed(src)`` of NMTModel.encode [EXT]: frames (B, T, 3, H, W) fp32 / (B, T, H, W, 3) fp16|u8 ->
+        per-frame features (B, T, input_size) through the HIP frame encoder; features pass through unchanged."""
+        if self.src_embed is None or getattr(src, "ndim", 0) != 5:
+            return src
+        feats = self.src_embed(src)
+        if feats.shape[-1] != self._input_size:
+            raise ValueError(f"src_embed yields {feats.shape[-1]}-d frame features, the encoder was built for {self._input_size}")
+        return feats
 
     def _captioner(self, beam, max_length, max_batch, max_src_len):
         from ...engine import GNMTCaptioner

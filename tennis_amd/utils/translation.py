@@ -33,6 +33,7 @@ class BeamSearchTranslator:
         vl = torch.as_tensor(np.asarray(src_valid_length)) if not isinstance(src_valid_length, torch.Tensor) \
             else src_valid_length
         src = src.cuda() if not src.is_cuda else src
+        src = self._model.embed_source(src)          # frame mode: TimeDistributed(backbone) (train_gnmt.py:168-170)
         b, t = src.shape[0], src.shape[1]
         cap = self._model._captioner(self._beam_size, self._max_length, b, t)
         cap.encode(src, vl.to(src.device))                                            # translation.py:76-78

@@ -126,6 +126,38 @@ def test_captioning_evaluate_driver():
         assert sents[i] == gn.ids_to_sentences(rs, rvl, train.vocab.idx_to_token)[0]
 
 
+def test_frame_mode_source_embedding(report):
+    """Frame-mode captioner (reference train_gnmt.py:148-170): ``src_embed = TimeDistributed(FrameModel(...).backbone)`` -
+    the clip's FRAMES go into the model; translations and teacher-forced logits equal those of the feature-mode model
+    fed with the backbone's features of the same frames."""
+    from tennis_amd import weights as W
+    from tennis_amd.model_zoo import get_model
+    from tennis_amd.models.captioning.gnmt import NMTModel, Vocab, get_gnmt_encoder_decoder
+    from tennis_amd.models.vision.definitions import FrameModel
+    from tennis_amd.utils.layers import TimeDistributed
+    from tennis_amd.utils.translation import BeamSearchScorer, BeamSearchTranslator
+    vocab = Vocab({f"w{i}": 30 - i for i in range(26)})
+    cnn_model = FrameModel(get_model("DenseNet121", pretrained=True, seed=0).features, 11)      # train_gnmt.py:150-151
+    src_embed = TimeDistributed(cnn_model.backbone)                                             # :168-170
+    mk = lambda se: NMTModel(src_vocab=None, tgt_vocab=vocab, encoder=get_gnmt_encoder_decoder(cell_type="gru", hidden_size=32)[0],
+                             decoder=get_gnmt_encoder_decoder(cell_type="gru", hidden_size=32)[1], embed_size=16, prefix="gnmt_",
+                             src_embed=se, input_size=1024, seed=5)
+    frame_model, feat_model = mk(src_embed), mk(None)
+    frame_model.initialize(); feat_model.initialize()
+    B, T = 2, 5
+    frames = torch.from_numpy(W.synthetic_frames_u8(B * T, 224).reshape(B, T, 224, 224, 3)).cuda()    # decoded uint8 clips
+    vl = np.array([5, 3], np.float32)
+    feats = cnn_model.backbone(frames.reshape(B * T, 224, 224, 3)).reshape(B, T, 1024)
+    assert torch.equal(frame_model.embed_source(frames), feats)
+    out = []
+    for m, src in ((frame_model, frames), (feat_model, feats)):
+        tr = BeamSearchTranslator(model=m, beam_size=3, scorer=BeamSearchScorer(alpha=1.0, K=5), max_length=10)
+        out.append([t.cpu().numpy() for t in tr.translate(src, vl)])
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+    report["frame_mode_captioner_equals_feature_mode"] = True
+
+
 def test_full_size_c5_properties(report):
     """BASELINE.json config C5 size (32 clips, T=214, F=1024, H=256, E=100, V=254, beam 5, max_len 150) — too long
     for the numpy oracle, so size-independent properties: (1) batch invariance: clip i decoded in the batch of 32
