@@ -369,6 +369,30 @@ def test_bleu_pinned_to_reference_golden():
     assert n == 9
 
 
+def test_mxnet_params_reader_against_hand_built_file():
+    """tests/golden/gluon_tiny.params was written byte by byte from the published NDArray-list layout
+    (tests/golden/make_params_fixture.py, no params_io involved): the reader returns its arrays, dtypes and names,
+    strips the Module ``aux:`` prefix, and ``Block.load_parameters`` maps the Gluon STRUCTURAL names of a
+    ``TemporalPooling(model=None, num_classes=3)`` (reference definitions.py:60-61) onto the block's parameters."""
+    from tennis_amd import params_io as pio
+    from tennis_amd.models.vision.definitions import TemporalPooling
+    f = os.path.join(os.path.dirname(__file__), "golden", "gluon_tiny.params")
+    assert pio.is_mxnet_params(f)
+    d = pio.load_mxnet_params(f)
+    assert list(d) == ["classes.weight", "classes.bias", "half_vector", "running_thing"]
+    assert d["classes.weight"].dtype == np.float32 and d["classes.weight"].shape == (2, 3)
+    assert np.array_equal(d["classes.weight"], np.array([[0.5, -1.25, 2.0], [0.125, 3.5, -0.75]], np.float32))
+    assert np.array_equal(d["classes.bias"], np.array([0.25, -0.5], np.float32))
+    assert d["half_vector"].dtype == np.float16 and np.array_equal(d["half_vector"], np.array([1.0, -2.0, 0.5], np.float16))
+    assert np.array_equal(d["running_thing"], np.array([7.0], np.float32))
+    m = TemporalPooling(None, num_classes=2, pool="max", feats=True)
+    m.load_parameters(f, ignore_extra=True)
+    got = {k[len(m.classes.prefix):]: v.data for k, v in m.collect_params().items()}
+    assert np.array_equal(got["weight"], d["classes.weight"]) and np.array_equal(got["bias"], d["classes.bias"])
+    with pytest.raises(AssertionError, match="half_vector"):        # Gluon's behaviour for names the block does not have
+        TemporalPooling(None, num_classes=2, pool="max", feats=True).load_parameters(f)
+
+
 def test_mxnet_params_container_round_trip(tmp_path):
     """tennis_amd.params_io: NDArray-list container (V2 records) write -> read, dtype flags, 0-d / empty shapes,
     'arg:' / 'aux:' prefixes, and Block.load_parameters picking the format by its magic."""
