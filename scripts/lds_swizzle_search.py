@@ -1,0 +1,60 @@
+import itertools, sys
+groups=[[0,1,2,3,12,13,14,15,20,21,22,23,24,25,26,27],[4,5,6,7,8,9,10,11,16,17,18,19,28,29,30,31],
+        [32,33,34,35,44,45,46,47,52,53,54,55,56,57,58,59],[36,37,38,39,40,41,42,43,48,49,50,51,60,61,62,63]]
+def conflicts(u, chunkmap, pi=lambda j:j, nb=32):
+    tot=0
+    for b in range(nb):
+        for kk in range(4):
+            for g in groups:
+                seen={}
+                for l in g:
+                    px=l&15; kg=l>>4
+                    s=b+pi(px)
+                    un=u(s, chunkmap(kk,kg))&15
+                    seen[un]=seen.get(un,0)+1
+                tot+=sum(v-1 for v in seen.values())
+    return tot
+cur=lambda s,c: c ^ (s&15)
+print("current", conflicts(cur, lambda kk,kg: kk*4+kg))
+# linear GF(2) maps: u = c ^ M*(s & 31)
+best=[]
+def mul(M,s):  # M: list of 4 row masks over 5 bits
+    r=0
+    for i,row in enumerate(M):
+        r |= (bin(row & s).count('1')&1)<<i
+    return r
+import random
+cms={'kk4kg':lambda kk,kg: kk*4+kg, 'kg4kk':lambda kk,kg: kg*4+kk}
+for name,cm in []:
+    found=0
+    for rows in itertools.product(range(32),repeat=4):
+        M=rows
+        # need bijection in low 4 bits of s for writes? not required
+        u=lambda s,c,M=M: c ^ mul(M, s&31)
+        # quick reject using few bases
+        if conflicts(u, cm, nb=2): continue
+        c=conflicts(u, cm)
+        if c==0:
+            print(name, "M rows", [bin(r) for r in rows]); found+=1
+            if found>5: break
+    print(name,"found",found)
+print("---- all solutions, checking write bijectivity")
+def wconf(M, w8=True):
+    # ds_write_b64: groups of 16 contiguous lanes = 16 consecutive slots (ignoring row wrap), same chunk; unit distinct?
+    tot=0
+    for b in range(32):
+        seen={}
+        for p in range(16):
+            un=mul(M,(b+p)&31)&15
+            seen[un]=seen.get(un,0)+1
+        tot+=sum(v-1 for v in seen.values())
+    return tot
+sols=[]
+cm=cms['kk4kg']
+for rows in itertools.product(range(32),repeat=4):
+    u=lambda s,c,M=rows: c ^ mul(M, s&31)
+    if conflicts(u, cm, nb=2): continue
+    if conflicts(u, cm)==0: sols.append(rows)
+print(len(sols),"solutions")
+sols.sort(key=lambda M: wconf(M))
+for M in sols[:8]: print([bin(r) for r in M], "write conflicts", wconf(M))
