@@ -150,6 +150,25 @@ int tn_preproc_destroy(tn_preproc *p);
  * src (pixels, 3) uint8 NHWC, dst (pixels, 3) float NHWC, both DEVICE; mean3 / std3 HOST arrays of 3 floats. */
 int tn_to_tensor_normalize(tn_ctx *ctx, const uint8_t *src, long pixels, const float *mean3, const float *std3, float *dst);
 
+/* ---- JPEG decode on the device ------------------------------------------------ */
+/* Replaces mx.image.imread(path, 1) of the reference's frame loader (dataset.py:204,216: OpenCV imdecode -> libjpeg
+ * with its default parameters, JDCT_ISLOW and fancy upsampling) for a batch of files of ONE geometry (the frames of
+ * a video): baseline / extended sequential Huffman JPEG (SOF0, SOF1), 8 bit, one interleaved scan, grey or YCbCr
+ * 4:4:4 / 4:2:2 / 4:2:0, restart intervals included.  data_host[i] / sizes[i]: the i-th file's bytes in HOST memory;
+ * rgb: DEVICE buffer (n, height, width, 3) uint8 RGB = the src of tn_preproc_forward (grey files are replicated to
+ * three channels, as imread flag=1 does).  Only the marker segments are read on the host; Huffman decoding
+ * (parallel inside each file), IDCT, upsampling and colour conversion run on the device, bit-exact with libjpeg's
+ * integer arithmetic.  Anything else (progressive, arithmetic coding, 12 bit, CMYK, multi-scan, files of different
+ * geometry in one call, corrupt data) is refused with TN_ERR_INVALID and a message naming the file.  The call
+ * synchronises the ctx's stream (it reads back the convergence flag of the parallel Huffman decoder) and may grow
+ * the handle's workspace.  tn_jpeg_info parses one file's header on the host (no device work). */
+typedef struct tn_jpeg tn_jpeg;
+int tn_jpeg_create(tn_ctx *ctx, tn_jpeg **out);
+int tn_jpeg_info(const uint8_t *data_host, size_t size, int *width, int *height, int *components, int *h_samp, int *v_samp);
+int tn_jpeg_decode(tn_jpeg *j, const uint8_t *const *data_host, const size_t *sizes, int n, uint8_t *rgb, int *width, int *height);
+int tn_jpeg_sync_passes(const tn_jpeg *j);   /* diagnostic: decoder passes the last call needed to synchronise */
+int tn_jpeg_destroy(tn_jpeg *j);
+
 /* ---- F.max / F.mean over axis 1 ------------------------------------------ */
 /* Replaces reference models/vision/definitions.py:66-69,107.  x (B,T,F) -> y (B,F). */
 int tn_temporal_pool(tn_ctx *ctx, const float *x, int batch, int steps, int feat, tn_pool_kind kind,

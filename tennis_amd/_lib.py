@@ -62,6 +62,12 @@ _SIGS = {
     "tn_preproc_forward": (C.c_int, [_P, _P, C.c_int, _P]),
     "tn_preproc_destroy": (C.c_int, [_P]),
     "tn_to_tensor_normalize": (C.c_int, [_P, _P, C.c_long, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
+    "tn_jpeg_create": (C.c_int, [_P, C.POINTER(_P)]),
+    "tn_jpeg_info": (C.c_int, [_P, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                               C.POINTER(C.c_int)]),
+    "tn_jpeg_decode": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t), C.c_int, _P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "tn_jpeg_sync_passes": (C.c_int, [_P]),
+    "tn_jpeg_destroy": (C.c_int, [_P]),
     "tn_temporal_pool": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "tn_prf1_update": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
     "tn_head_create": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(TnParam), C.c_int, C.c_char_p, C.c_char_p, C.c_int,

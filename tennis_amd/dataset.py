@@ -14,7 +14,8 @@ frames or (F,) / (T,F) features loaded from ``.npy``.
 Two sources.  ON DISK, used when ``<root>/splits/<split_id>/<split>.txt`` exists: the
 reference's layout (data/README.md) — split lines ``video frame``, per-video label files
 ``annotations/labels/<video>.txt`` (``frame class``), JPEG frames under ``frames/<video>.mp4/<chunk>/<frame>.jpg``
-decoded on the host (the reference decodes on the host too: ``mx.image.imread``), events = runs of equal labels,
+decoded on the host with Pillow (the reference decodes on the host too: ``mx.image.imread``) or, with
+``decode="device"``, on the GPU by ``tennis_amd.image`` (one call per batch, bit-identical pixels), events = runs of equal labels,
 video lengths from the frame directories, optional ``annotations/points.txt`` + ``captions.txt``, ``save_feats``
 padding and ``_balance_classes`` (dataset.py:268-287,300-452).  Frames missing on disk are ignored, as in the
 reference's second pass; extracting them from the ``.mp4`` is not done here.  SYNTHETIC otherwise (the 217 GB
@@ -52,7 +53,7 @@ class TennisSet:
                  vocab=None, inference=False, feats_model=None, save_feats=False,
                  # synthetic-source knobs (not in the reference):
                  data_shape=224, videos=("V006", "V007"), frames_per_video=16, seed=1234, split_first=0,
-                 video_length=None):
+                 video_length=None, decode="host"):
         if captions:
             raise NotImplementedError("caption mode (dataset.py:154-183) is served by tennis_amd.captions.CaptionSet")
         if flow:
@@ -71,6 +72,12 @@ class TennisSet:
         self._save_feats = save_feats
         self._data_shape = data_shape
         self._seed = seed
+        # where the JPEG frames of an on-disk dataset are decoded: "host" (Pillow, as the reference's mx.image.imread on
+        # its DataLoader workers), "device" (tennis_amd.image: the files' bytes go to the GPU, one decode per batch; files
+        # the device decoder refuses raise), "auto" (device, and a batch it refuses is decoded on the host instead)
+        if decode not in ("host", "device", "auto"):
+            raise ValueError("decode must be 'host', 'device' or 'auto'")
+        self.decode = decode
 
         self._frames_dir = os.path.join(root, "frames")
         self.output_dir = os.path.join(root, "outputs", model_id, split)
@@ -251,6 +258,18 @@ class TennisSet:
         s = zlib.crc32(f"{video}:{frame}:{self._seed}".encode())
         return np.random.default_rng(s).integers(0, 256, (self._data_shape, self._data_shape, 3), dtype=np.uint8)
 
+    def frame_bytes(self, video, frame) -> bytes:
+        """the frame's JPEG file as it is on disk (device decode route)"""
+        with open(self.get_image_path(self._frames_dir, video, frame), "rb") as f:
+            return f.read()
+
+    def sample_frames(self, idx):
+        """[(video, frame), ...] that item ``idx`` reads: one frame, or the frames of its window (dataset.py:190-201)"""
+        sample = self._samples[idx]
+        if self._window > 1:
+            return [(sample[0], f) for f in self.window_frames(sample)]
+        return [(sample[0], sample[1])]
+
     def _load(self, video, frame):
         if self._load_feats:
             return np.load(self.get_feature_path(self.feat_dir, video, frame)).astype(np.float32)
@@ -293,9 +312,27 @@ class DataLoader:
 
     def collate(self, ids):
         """(data, labels, idxs) for the dataset items ``ids`` (what one iteration step yields)."""
+        ds = self.dataset
+        tf = getattr(ds, "_transform", None)
+        if (getattr(ds, "decode", "host") != "host" and getattr(ds, "on_disk", False) and not ds._load_feats
+                and getattr(tf, "device_batched", False)):
+            # device decode: the batch's files go to the GPU as bytes and are decoded there in one call
+            from . import image
+            frames = [ds.sample_frames(int(i)) for i in ids]
+            bufs = [ds.frame_bytes(v, f) for fr in frames for (v, f) in fr]
+            try:
+                rgb = image.imdecode_batch(bufs)
+            except image.UnsupportedJpeg:
+                if ds.decode != "auto":
+                    raise
+                rgb = None
+            if rgb is not None:
+                if ds._window > 1:
+                    rgb = rgb.view(len(ids), ds._window, *rgb.shape[1:])
+                labels = np.array([ds.classes.index(ds._samples[int(i)][2]) for i in ids], dtype=np.float32)
+                return tf(rgb), labels, np.array([int(i) for i in ids], dtype=np.int64)
         items = [self.dataset[int(i)] for i in ids]
         data = np.stack([it[0] for it in items])
-        tf = getattr(self.dataset, "_transform", None)
         if getattr(tf, "device_batched", False) and not self.dataset._load_feats:
             data = tf(data)                                                # one Resize+CenterCrop launch per batch
         return (data, np.array([it[1] for it in items], dtype=np.float32),

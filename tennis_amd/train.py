@@ -146,6 +146,7 @@ def build_parser():
     p.add_argument("--feats_model", default=None)
     p.add_argument("--temp_pool", default=None, help="gru or lstm (trained); mean / max need no training")
     p.add_argument("--root", default="data")
+    p.add_argument("--decode", default="device", choices=["device", "host", "auto"], help="where on-disk JPEG frames are decoded (see evaluate.py)")
     p.add_argument("--frames_per_video", type=int, default=16)
     p.add_argument("--exp_root", default=os.path.join("models", "vision", "experiments"))
     return p
@@ -183,7 +184,8 @@ def main(argv=None):
     mk = lambda split, ev, bal: TennisSet(root=flags.root, transform=tf, split=split, every=ev, padding=flags.padding,
                                           stride=flags.stride, window=flags.window, model_id=flags.model_id,
                                           split_id=flags.split_id, balance=bal, feats_model=flags.feats_model,
-                                          data_shape=flags.data_shape, frames_per_video=flags.frames_per_video)
+                                          data_shape=flags.data_shape, frames_per_video=flags.frames_per_video,
+                                          decode=flags.decode)
     train_set, val_set = mk("train", every[0], balance[0]), mk("val", every[1], balance[1])
     n_cls = len(train_set.classes)
     save_dir = os.path.join(flags.exp_root, flags.model_id)

@@ -1,0 +1,181 @@
+"""JPEG decode on the device (csrc/jpeg.hip) through the C ABI: bit-exact against libjpeg's own output (golden
+fixtures and live Pillow) and against oracle/jpeg_np.py; reference call site dataset.py:204,216 (``mx.image.imread``)."""
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import jpeg_np
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = np.load(os.path.join(ROOT, "tests", "golden", "jpeg_cases.npz"))
+CASES = sorted(k[:-6] for k in GOLD.files if k.endswith("__jpeg"))
+
+
+def _img(rng, h, w, kind="smooth"):
+    if kind == "noise":
+        return (rng.random((h, w, 3)) * 255).astype(np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = np.stack([127 + 120 * np.sin(xx / 17.0 + yy / 31.0), 127 + 120 * np.cos(xx / 13.0 - yy / 19.0), (xx * 3 + yy * 5) % 256], -1)
+    return np.clip(a + rng.normal(0, 5, (h, w, 3)), 0, 255).astype(np.uint8)
+
+
+def _encode(a, **kw):
+    from PIL import Image
+    b = io.BytesIO()
+    Image.fromarray(a).save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+def _pillow(data):
+    from PIL import Image
+    return np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_device_decode_matches_libjpeg_golden(name):
+    from tennis_amd import image
+    data = GOLD[name + "__jpeg"].tobytes()
+    out = image.imdecode(data).cpu().numpy()
+    assert out.dtype == np.uint8 and out.shape == GOLD[name + "__rgb"].shape
+    assert np.array_equal(out, GOLD[name + "__rgb"])
+    assert np.array_equal(out, jpeg_np.decode(data))       # and the oracle says the same
+
+
+def test_device_decode_matrix_against_pillow():
+    """sizes around the MCU boundaries x chroma layouts x qualities, one file per call"""
+    pytest.importorskip("PIL")
+    from tennis_amd import image
+    rng = np.random.default_rng(11)
+    for (h, w) in [(16, 16), (17, 33), (64, 48), (100, 131), (8, 8), (2, 2), (5, 3), (1, 1), (31, 250), (240, 7)]:
+        for ss in (0, 1, 2):
+            for q, kind in ((30, "smooth"), (95, "noise"), (100, "noise")):
+                data = _encode(_img(rng, h, w, kind), quality=q, subsampling=ss)
+                out = image.imdecode(data).cpu().numpy()
+                assert np.array_equal(out, _pillow(data)), (h, w, ss, q)
+
+
+def test_device_decode_batch_of_a_video_720p():
+    """a batch of 720p frames, every frame with its own quality (quantisation tables) and every second one with its own
+    optimised Huffman tables; the scans are ~1000 subsequences long, so the parallel decoder really has to synchronise"""
+    pytest.importorskip("PIL")
+    from tennis_amd import image
+    rng = np.random.default_rng(12)
+    base = _img(rng, 720, 1280)
+    files = []
+    for i in range(6):
+        a = np.roll(base, 37 * i, axis=1)
+        a = np.clip(a.astype(np.int16) + rng.integers(-20, 20, a.shape), 0, 255).astype(np.uint8)
+        files.append(_encode(a, quality=60 + 7 * i, subsampling=2, optimize=bool(i & 1)))
+    dec = image.JpegDecoder()
+    out = dec.decode(files).cpu().numpy()
+    assert out.shape == (6, 720, 1280, 3)
+    for i, f in enumerate(files):
+        assert np.array_equal(out[i], _pillow(f)), i
+    assert 1 <= dec.sync_passes <= 8
+    # the same handle again with another geometry and chroma layout (workspace re-use)
+    small = [_encode(_img(rng, 90, 120, "noise"), quality=80, subsampling=1) for _ in range(3)]
+    out2 = dec.decode(small).cpu().numpy()
+    for i, f in enumerate(small):
+        assert np.array_equal(out2[i], _pillow(f))
+
+
+def test_device_decode_restart_intervals_and_grey():
+    pytest.importorskip("PIL")
+    from tennis_amd import image
+    rng = np.random.default_rng(13)
+    a = _img(rng, 200, 312)
+    for kw in (dict(restart_marker_blocks=1), dict(restart_marker_blocks=7), dict(restart_marker_rows=1), dict(restart_marker_rows=3)):
+        for ss in (0, 2):
+            data = _encode(a, quality=85, subsampling=ss, **kw)
+            assert jpeg_np.parse(data)["ri"] > 0
+            assert np.array_equal(image.imdecode(data).cpu().numpy(), _pillow(data)), (kw, ss)
+    g = _encode(a[:, :, 1], quality=70)
+    out = image.imdecode(g).cpu().numpy()
+    assert out.shape == (200, 312, 3) and np.array_equal(out, _pillow(g))
+
+
+def test_device_decode_refusals():
+    """what the decoder does not handle fails loudly and names the file; a good call afterwards still works"""
+    pytest.importorskip("PIL")
+    from tennis_amd import image
+    rng = np.random.default_rng(14)
+    good = _encode(_img(rng, 64, 64), quality=80, subsampling=2)
+    prog = _encode(_img(rng, 64, 64), quality=80, progressive=True)
+    other = _encode(_img(rng, 64, 80), quality=80, subsampling=2)
+    with pytest.raises(RuntimeError, match="file 1: unsupported JPEG process SOF2"):
+        image.imdecode_batch([good, prog])
+    with pytest.raises(RuntimeError, match="file 1 differs from file 0"):
+        image.imdecode_batch([good, other])
+    with pytest.raises(RuntimeError, match="SOI"):
+        image.imdecode(b"not a jpeg at all")
+    cut = good[: len(good) // 2]
+    with pytest.raises(RuntimeError, match="corrupt|truncated"):
+        image.imdecode(cut)
+    scr = bytearray(good)
+    h = jpeg_np.parse(good)
+    start = good.index(h["scan"][:16])
+    for i in range(start + 40, start + 80):
+        scr[i] = (scr[i] * 7 + 13) & 0xFE            # garbage (no FF bytes) in the middle of the scan
+    try:
+        out = image.imdecode(bytes(scr)).cpu().numpy()   # either refused as corrupt, or decoded like libjpeg decodes garbage
+        assert out.shape == (64, 64, 3)
+    except RuntimeError as e:
+        assert "corrupt" in str(e)
+    assert np.array_equal(image.imdecode(good).cpu().numpy(), _pillow(good))
+    with pytest.raises(NotImplementedError):
+        image.imdecode(good, flag=0)
+
+
+def test_jpeg_to_features_end_to_end(tmp_path):
+    """files on disk -> device decode -> Resize/CenterCrop (tn_preproc) -> encoder: identical features to the host-decoded
+    route of the same files (the reference's route: imread on the host, transform, network)"""
+    pytest.importorskip("PIL")
+    from tennis_amd import image, transforms
+    from tennis_amd.nn import DenseNet121Backbone
+    rng = np.random.default_rng(15)
+    paths = []
+    for i in range(4):
+        p = tmp_path / f"{i:010d}.jpg"
+        p.write_bytes(_encode(_img(rng, 360, 640), quality=88, subsampling=2))
+        paths.append(str(p))
+    t = transforms.Compose([transforms.Resize(256), transforms.CenterCrop(224), transforms.ToTensor(),
+                            transforms.Normalize(transforms.IMAGENET_MEAN, transforms.IMAGENET_STD)])
+    dev_frames = image.imread_batch(paths)
+    host_frames = np.stack([_pillow(open(p, "rb").read()) for p in paths])
+    assert np.array_equal(dev_frames.cpu().numpy(), host_frames)
+    net = DenseNet121Backbone(seed=3)
+    fa = net(t(dev_frames)).float().cpu().numpy()
+    fb = net(t(host_frames)).float().cpu().numpy()
+    assert np.array_equal(fa, fb)
+    one = image.imread(paths[2]).cpu().numpy()
+    assert np.array_equal(one, host_frames[2])
+
+
+@pytest.mark.parametrize("window", [1, 3])
+def test_tennisset_device_decode_route(tmp_path, window):
+    """TennisSet(decode="device"): the DataLoader sends the batch's JPEG files to the GPU as bytes and gets the same
+    transformed uint8 batch as the host-decoded (Pillow) route, frame windows included"""
+    pytest.importorskip("PIL")
+    from test_cpu_input_side import _write_dataset
+    from tennis_amd import transforms
+    from tennis_amd.dataset import DataLoader, TennisSet
+    root = str(tmp_path / "data")
+    _write_dataset(root, np.random.default_rng(9), n_frames=(10, 9), size=(90, 160))
+    t = transforms.Compose([transforms.Resize(256), transforms.CenterCrop(224), transforms.ToTensor(),
+                            transforms.Normalize(transforms.IMAGENET_MEAN, transforms.IMAGENET_STD)])
+    kw = dict(root=root, split="test", split_id="02", balance=False, transform=t, window=window)
+    host = list(DataLoader(TennisSet(decode="host", **kw), batch_size=4))
+    dev = list(DataLoader(TennisSet(decode="device", **kw), batch_size=4))
+    auto = list(DataLoader(TennisSet(decode="auto", **kw), batch_size=4))
+    assert len(host) == len(dev) == len(auto) > 1
+    for (a, la, ia), (b, lb, ib), (c, lc, ic) in zip(host, dev, auto):
+        assert b.is_cuda and b.dtype == torch.uint8 and a.shape == b.shape
+        assert a.shape[1:] == ((224, 224, 3) if window == 1 else (window, 224, 224, 3))
+        assert torch.equal(a, b) and torch.equal(a, c)
+        assert np.array_equal(la, lb) and np.array_equal(ia, ib) and np.array_equal(ia, ic)
+    with pytest.raises(ValueError):
+        TennisSet(decode="gpu", **kw)
