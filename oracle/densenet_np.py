@@ -6,7 +6,7 @@ reference evaluate.py:16,125; train.py:18,204) and the reference has no tests
 or golden vectors.  This file restates the *published*
 DenseNet-121 ``.features`` graph (Huang et al. 2017; GluonCV
 ``model_zoo/densenet.py`` [EXT, SURVEY App. A/B]) and is cross-checked against
-``torch.nn.functional`` on CPU in tests/test_oracle_vision.py.
+``torch.nn.functional`` on CPU in tests/test_cpu_oracle.py.
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
 ``cpu_baseline`` leg may import this module.  The product path

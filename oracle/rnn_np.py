@@ -4,7 +4,7 @@ PARITY UNPINNED (see oracle/densenet_np.py header): ``mx.gluon.rnn.GRU/LSTM``
 and the Gluon cell classes are third-party, absent here; equations and gate
 order follow the published cuDNN/MXNet convention [EXT, SURVEY App. B] and are
 cross-checked against ``torch.nn.GRU/LSTM`` (identical convention) in
-tests/test_oracle_vision.py.
+tests/test_cpu_oracle.py.
 
   GRU   gates [r, z, n]:  r = s(Wir x + bir + Whr h + bhr)
                           z = s(Wiz x + biz + Whz h + bhz)

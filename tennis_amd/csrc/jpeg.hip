@@ -7,7 +7,7 @@
 //
 //   1. Huffman decoding, parallel INSIDE each file.  A Huffman stream has no entry points, but it is
 //      self-synchronising: a decoder started at a wrong bit soon falls into step with the true one.  The scan is cut
-//      into 128-byte subsequences, one thread each (Klein & Wiseman 2003; Weissenberger & Schmidt 2018/2021):
+//      into 256-byte subsequences, one thread each (Klein & Wiseman 2003; Weissenberger & Schmidt 2018/2021):
 //        sync pass     every thread decodes its subsequence from its first byte with a guessed state (block start)
 //                      and records where - bit position, MCU slot, coefficient index - its last symbol ended;
 //        fix-up passes every thread restarts from its predecessor's recorded end; repeated until no record changes.
@@ -28,13 +28,17 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.h"
 
 namespace {
 
-constexpr int SUBSEQ = 128;     // bytes of entropy-coded data per decoding thread
+#ifndef TN_JPEG_SUBSEQ
+#define TN_JPEG_SUBSEQ 256
+#endif
+constexpr int SUBSEQ = TN_JPEG_SUBSEQ;     // bytes of entropy-coded data per decoding thread
 constexpr int MAX_SLOTS = 10;   // blocks per MCU (T.81 B.2.3: sum of Hi x Vi <= 10)
 constexpr int LUT_SIZE = 65536; // 16-bit prefix -> (code length << 8) | symbol, 0 = no such code
 constexpr int FAST_BITS = 10, FAST_SIZE = 1 << FAST_BITS;   // first-level table: codes of up to 10 bits (the rest: 0 -> full table)
@@ -134,56 +138,36 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
     }
     if (WRITE && first_block + nblk >= max_blocks) { position(cp, cb); break; }     // the rest of the segment is padding
     if (nb < 32) refill();
-    const int table = k == 0 ? f.slot_dc[slot] : 4 + f.slot_ac[slot];
+    // one symbol, DC difference (F.2.2.1) and AC coefficient (F.2.2.2) through the same straight-line code: the lanes of a
+    // wave are at different places of their blocks, a branch per symbol kind would run both sides for every symbol
+    const bool dc = k == 0;
+    const int table = dc ? f.slot_dc[slot] : 4 + f.slot_ac[slot];
     uint16_t e = fast_base[table * FAST_SIZE + (uint32_t)(buf >> (64 - FAST_BITS))];
     if (e == 0) e = lut_base[(size_t)table * LUT_SIZE + (uint32_t)(buf >> 48)];
-    int len = e >> 8, sym = e & 255;
+    int len = e >> 8;
+    const int sym = e & 255;
     if (len == 0) {           // no such code: a wrong-state decoder steps on one bit, the true decode is corrupt
       if (WRITE) atomicExch(err, 1);
       len = 1;
-      sym = 0;
     }
-    bool block_end = false;
-    int s, nbits;
-    if (k == 0) {             // DC difference (F.2.2.1)
-      s = sym & 15;
-      nbits = len + s;
-      if (WRITE) {
-        const int x = s ? (int)((buf << len) >> (64 - s)) : 0;
-        const int val = (s && x < (1 << (s - 1))) ? x - (1 << s) + 1 : x;
-        coef[(size_t)(first_block + nblk) * 64] = (int16_t)val;
-      }
-      k = 1;
-    } else {                  // AC coefficient (F.2.2.2)
-      const int r = sym >> 4;
-      s = sym & 15;
-      nbits = len + s;
-      if (s) {
-        k += r;
-        if (k > 63) {
-          if (WRITE) atomicExch(err, 1);
-          block_end = true;
-        } else {
-          if (WRITE) {
-            const int x = (int)((buf << len) >> (64 - s));
-            const int val = x < (1 << (s - 1)) ? x - (1 << s) + 1 : x;
-            coef[(size_t)(first_block + nblk) * 64 + c_zigzag[k]] = (int16_t)val;
-          }
-          k += 1;
-          block_end = k > 63;
-        }
-      } else if (r == 15) {
-        k += 16;
-        block_end = k > 63;
+    const int s = sym & 15, r = dc ? 0 : sym >> 4;
+    const int nbits = len + s;
+    const int kk = dc ? 0 : k + r;                                  // zig-zag index the value (if any) belongs to
+    if (WRITE && s) {
+      if (kk > 63) {
+        atomicExch(err, 1);
       } else {
-        block_end = true;     // EOB
+        const int x = (int)((buf << len) >> (64 - s));
+        const int val = x < (1 << (s - 1)) ? x - (1 << s) + 1 : x;   // EXTEND (F.2.2.1)
+        coef[(size_t)(first_block + nblk) * 64 + c_zigzag[kk]] = (int16_t)val;
       }
     }
-    if (block_end) {
-      k = 0;
-      slot = slot + 1 == g.bpm ? 0 : slot + 1;
-      ++nblk;
-    }
+    // next index: behind the value; ZRL (r = 15, s = 0) skips 16; EOB (s = 0 otherwise) ends the block
+    const int kn = dc ? 1 : (s ? kk + 1 : (r == 15 ? k + 16 : 64));
+    const bool block_end = kn > 63;
+    k = block_end ? 0 : kn;
+    slot = block_end ? (slot + 1 == g.bpm ? 0 : slot + 1) : slot;
+    nblk += block_end ? 1u : 0u;
     buf <<= nbits;            // <= 27 bits, nb >= 32
     nb -= nbits;
   }
@@ -476,6 +460,59 @@ __global__ __launch_bounds__(256) void jpeg_color_kernel(Geom g, const uint8_t *
   o[0] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
   o[1] = (uint8_t)(gg < 0 ? 0 : gg > 255 ? 255 : gg);
   o[2] = (uint8_t)(b < 0 ? 0 : b > 255 ? 255 : b);
+}
+
+// 4:2:0 (h2v2 for both chroma planes, the layout video frames come in): four pixels of a row per thread.  The four
+// outputs need the chroma column sums 3 * near row + far row of columns cx0-1 .. cx0+2 only (16 byte loads instead of 32),
+// luma comes as one dword and the 12 output bytes leave as three dwords.
+__global__ __launch_bounds__(256) void jpeg_color420_kernel(Geom g, const uint8_t *__restrict__ planes, uint8_t *__restrict__ rgb) {
+  const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, frame = blockIdx.z;
+  if (x0 >= g.W) return;
+  const uint8_t *pl = planes + (size_t)frame * g.planes_per_frame;
+  const uint32_t y4 = *(const uint32_t *)(pl + g.plane_off[0] + (size_t)y * g.plane_w[0] + x0);
+  const int cw = g.cw[1], ch = g.ch[1];
+  const int cy = y >> 1, oy = (y & 1) ? (cy + 1 < ch ? cy + 1 : ch - 1) : (cy > 0 ? cy - 1 : 0);
+  const int c0 = x0 >> 1;
+  int col[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 - 1 + i;
+    col[i] = c < 0 ? 0 : c > cw - 1 ? cw - 1 : c;
+  }
+  int up[2][4];      // upsampled Cb / Cr of the four pixels
+#pragma unroll
+  for (int comp = 0; comp < 2; ++comp) {
+    const uint8_t *p = pl + g.plane_off[1 + comp];
+    const uint8_t *r0 = p + (size_t)cy * g.plane_w[1 + comp], *r1 = p + (size_t)oy * g.plane_w[1 + comp];
+    int cs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cs[i] = 3 * r0[col[i]] + r1[col[i]];
+    // pixel x0+2 / x0+3 sit on column c0+1; past the plane's last column (only for pixels past W) the clamp repeats it
+    up[comp][0] = (3 * cs[1] + cs[0] + 8) >> 4;
+    up[comp][1] = (3 * cs[1] + cs[2] + 7) >> 4;
+    up[comp][2] = (3 * cs[2] + cs[1] + 8) >> 4;
+    up[comp][3] = (3 * cs[2] + cs[3] + 7) >> 4;
+  }
+  uint8_t px[12];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int Y = (y4 >> (8 * i)) & 255, cb = up[0][i] - 128, cr = up[1][i] - 128;
+    const int r = Y + ((91881 * cr + 32768) >> 16);
+    const int b = Y + ((116130 * cb + 32768) >> 16);
+    const int gg = Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
+    px[3 * i] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+    px[3 * i + 1] = (uint8_t)(gg < 0 ? 0 : gg > 255 ? 255 : gg);
+    px[3 * i + 2] = (uint8_t)(b < 0 ? 0 : b > 255 ? 255 : b);
+  }
+  uint8_t *o = rgb + (((size_t)frame * g.H + y) * g.W + x0) * 3;
+  const int nx = g.W - x0 < 4 ? g.W - x0 : 4;
+  if (nx == 4 && (((size_t)o) & 3) == 0) {
+    uint32_t w[3];
+    __builtin_memcpy(w, px, 12);
+    ((uint32_t *)o)[0] = w[0]; ((uint32_t *)o)[1] = w[1]; ((uint32_t *)o)[2] = w[2];
+  } else {
+    for (int i = 0; i < nx * 3; ++i) o[i] = px[i];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ host: markers
@@ -803,10 +840,8 @@ extern "C" int tn_jpeg_decode(tn_jpeg *j, const uint8_t *const *data_host, const
     f.scan_off = (uint32_t)so;
     f.scan_len = (uint32_t)len;
     const uint8_t *src = data_host[i] + h.scan_begin;
-    memcpy(j->h_scan.p + so, src, len);
     const size_t padded = ((len + SUBSEQ - 1) / SUBSEQ) * SUBSEQ + 16;
-    memset(j->h_scan.p + so + len, 0, padded - len);
-    so += padded;
+    so += padded;       // (the bytes are copied below, by several threads)
     // segments: the whole scan, or one per restart interval (E.2.4: RSTm between intervals of ri MCUs)
     if (h.ri == 0) {
       Seg sg{(uint32_t)i, 0u, (uint32_t)len, 0u, (uint32_t)g.blocks_per_frame, total_sub, (uint32_t)((len + SUBSEQ - 1) / SUBSEQ)};
@@ -831,6 +866,24 @@ extern "C" int tn_jpeg_decode(tn_jpeg *j, const uint8_t *const *data_host, const
         ++p;
       }
       if (interval != nint) { tn_set_error("tn_jpeg_decode: file " + std::to_string(i) + ": restart markers do not match the restart interval"); return TN_ERR_INVALID; }
+    }
+  }
+  {   // entropy-coded bytes -> pinned staging buffer
+    auto copy_range = [&](int a, int b) {
+      for (int i = a; i < b; ++i) {
+        const FrameDev &f = j->h_frames.p[i];
+        const size_t len = f.scan_len, padded = ((len + SUBSEQ - 1) / SUBSEQ) * SUBSEQ + 16;
+        memcpy(j->h_scan.p + f.scan_off, data_host[i] + hd[i].scan_begin, len);
+        memset(j->h_scan.p + f.scan_off + len, 0, padded - len);
+      }
+    };
+    const int nthr = so > (4u << 20) ? std::min(8, n) : 1;
+    if (nthr <= 1) {
+      copy_range(0, n);
+    } else {
+      std::vector<std::thread> th;
+      for (int t = 0; t < nthr; ++t) th.emplace_back(copy_range, (int)((long)n * t / nthr), (int)((long)n * (t + 1) / nthr));
+      for (auto &t : th) t.join();
     }
   }
   const int nseg = (int)segs.size();
@@ -873,7 +926,11 @@ extern "C" int tn_jpeg_decode(tn_jpeg *j, const uint8_t *const *data_host, const
   hipLaunchKernelGGL(jpeg_dc_scan_kernel, dim3(n * g.ncomp), dim3(256), 0, st, g, j->d_coef.p);
   // ---- IDCT, upsampling, colour ----
   hipLaunchKernelGGL(jpeg_idct_kernel, dim3((g.blocks_per_frame + 63) / 64, n), dim3(64), 0, st, g, j->d_frames.p, j->d_coef.p, j->d_planes.p);
-  hipLaunchKernelGGL(jpeg_color_kernel, dim3((g.W + 255) / 256, g.H, n), dim3(256), 0, st, g, j->d_planes.p, rgb);
+  const bool is420 = g.ncomp == 3 && g.hmax == 2 && g.vmax == 2 && g.hs[1] == 1 && g.vs[1] == 1 && g.hs[2] == 1 && g.vs[2] == 1 && g.cw[1] > 2;
+  if (is420)
+    hipLaunchKernelGGL(jpeg_color420_kernel, dim3((g.W + 1023) / 1024, g.H, n), dim3(256), 0, st, g, j->d_planes.p, rgb);
+  else
+    hipLaunchKernelGGL(jpeg_color_kernel, dim3((g.W + 255) / 256, g.H, n), dim3(256), 0, st, g, j->d_planes.p, rgb);
   TN_HIP_CHECK(hipGetLastError());
   TN_HIP_CHECK(hipMemcpyAsync(j->h_flags.p + 1, j->d_flags.p + 1, sizeof(int), hipMemcpyDeviceToHost, st));
   TN_HIP_CHECK(hipStreamSynchronize(st));

@@ -94,36 +94,37 @@ def test_temporal_pooling_shares_classes(zoo):
 
 
 def test_save_features_and_evaluate_model(zoo, tmp_path, report):
-    """BASELINE config C1 plumbing (scaled to 6 frames): evaluate.py --save_feats then evaluate."""
+    """BASELINE config C1 at its full size: 32 frames of (3, 224, 224) through evaluate.py --save_feats, then evaluate."""
     from tennis_amd import evaluate as ev
     from tennis_amd.dataset import DataLoader, TennisSet
     from tennis_amd.metrics.vision import PRF1
     fm, p = zoo
     root = str(tmp_path / "data")
-    ds = TennisSet(root=root, split="test", model_id="0006", save_feats=True, frames_per_video=3, data_shape=224)
-    loader = DataLoader(ds, batch_size=4)
-    assert ev.save_features(fm, loader, ds, verbose=False) == 6
-    path = ds.save_feature_path(4)
-    assert path == os.path.join(root, "features", "0006", "V007.mp4", "0000000000", "0000000001.npy")
+    ds = TennisSet(root=root, split="test", model_id="0006", save_feats=True, frames_per_video=16, data_shape=224)
+    assert len(ds) == 32
+    loader = DataLoader(ds, batch_size=32)
+    assert ev.save_features(fm, loader, ds, verbose=False) == 32
+    path = ds.save_feature_path(20)
+    assert path == os.path.join(root, "features", "0006", "V007.mp4", "0000000000", "0000000004.npy")
     f = np.load(path)
     assert f.dtype == np.float32 and f.shape == (1024,)
-    x = ds[4][0][None]
+    x = ds[20][0][None]
     ref = dn.densenet121_features(x.astype(np.float16).astype(np.float32), p)[0]
     e = float(np.abs(f - ref).max())
     report["save_features_maxabs_err"] = e
     assert e < 5e-3          # input pixels are rounded to fp16 inside the stem for NCHW fp32 frames
     assert ev.save_features(fm, loader, ds, verbose=False) == 0          # skip-if-exists (evaluate.py:318)
 
-    ds2 = TennisSet(root=root, split="test", frames_per_video=3, data_shape=224)
+    ds2 = TennisSet(root=root, split="test", frames_per_video=16, data_shape=224)
     metric = PRF1(label_names=ds2.classes)
-    results, gts = ev.evaluate_model(fm, DataLoader(ds2, batch_size=4), ds2, [metric])
-    assert len(results) == 6 and all(v.shape == (11,) for v in results.values())
+    results, gts = ev.evaluate_model(fm, DataLoader(ds2, batch_size=32), ds2, [metric])
+    assert len(results) == 32 and all(v.shape == (11,) for v in results.values())
     k = ds2.get_image_path(ds2._frames_dir, "V006", 2)
     assert k in results and gts[k] == ds2.classes.index(ds2._samples[2][2])
-    assert len(metric.get()) == 39 and metric.mat.sum() == 6
+    assert len(metric.get()) == 39 and metric.mat.sum() == 32
 
     # features on disk feed the temporal model through the same dataset contract (dataset.py:202-204)
-    ds3 = TennisSet(root=root, split="test", window=3, feats_model="0006", frames_per_video=3, data_shape=224)
+    ds3 = TennisSet(root=root, split="test", window=3, feats_model="0006", frames_per_video=16, data_shape=224)
     xw, _, _ = ds3[1]
     assert xw.shape == (3, 1024)
     assert ev.main(["--root", root, "--model_id", "0007", "--save_feats", "--frames_per_video", "2",
