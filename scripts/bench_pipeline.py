@@ -1,0 +1,78 @@
+"""Files -> features: the reference's real-data route (dataset.py:204 imread -> evaluate.py:93-98 transform -> backbone) with
+every stage on the GPU: JPEG decode (tn_jpeg_decode) -> Resize(256) / CenterCrop(224) (tn_preproc) -> DenseNet-121 features.
+Reports frames/s of the three stages run one after the other, and with the decode of batch i+1 (its own stream, driven by a
+second host thread) overlapping the transform + encode of batch i.
+
+    python scripts/bench_pipeline.py [--frames 256] [--batches 8] [--height 720 --width 1280]
+"""
+import argparse, io, json, os, sys, threading, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from PIL import Image
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=256)
+ap.add_argument("--batches", type=int, default=8)
+ap.add_argument("--height", type=int, default=720)
+ap.add_argument("--width", type=int, default=1280)
+ap.add_argument("--quality", type=int, default=90)
+args = ap.parse_args()
+
+from tennis_amd import _lib, image, transforms
+from tennis_amd.nn import DenseNet121Backbone
+
+rng = np.random.default_rng(0)
+H, W = args.height, args.width
+yy, xx = np.mgrid[0:H, 0:W]
+files = []
+for i in range(16):
+    a = np.zeros((H, W, 3), np.float32)
+    a[..., 1] = 110 + 30 * np.sin(xx / 200.0 + i); a[..., 0] = 60 + 20 * np.cos(yy / 150.0); a[..., 2] = 70
+    a[(yy % 120 < 3) | (xx % 210 < 3)] = 235
+    band = yy < H // 4
+    a[band] = rng.integers(0, 255, (int(band.sum()), 3))
+    a += rng.normal(0, 3, a.shape)
+    b = io.BytesIO()
+    Image.fromarray(np.clip(a, 0, 255).astype(np.uint8)).save(b, "JPEG", quality=args.quality, subsampling=2)
+    files.append(b.getvalue())
+batch = [files[i % 16] for i in range(args.frames)]
+
+tf = transforms.Compose([transforms.Resize(256), transforms.CenterCrop(224), transforms.ToTensor(),
+                         transforms.Normalize(transforms.IMAGENET_MEAN, transforms.IMAGENET_STD)])
+net = DenseNet121Backbone(seed=0)
+dec_stream = torch.cuda.Stream()            # the decoder works on its own stream: it may run beside the encoder
+dec_ctx = _lib.Context(stream=dec_stream)
+dec = image.JpegDecoder(dec_ctx)
+bufs = [torch.empty((args.frames, H, W, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+
+def encode(rgb):
+    return net(tf(rgb))
+
+feat = encode(dec.decode(batch, out=bufs[0]))
+torch.cuda.synchronize()
+
+t0 = time.perf_counter()
+for i in range(args.batches):
+    feat = encode(dec.decode(batch, out=bufs[i & 1]))
+torch.cuda.synchronize()
+serial = (time.perf_counter() - t0) / args.batches
+
+# overlapped: a worker thread decodes batch i+1 while the main thread transforms + encodes batch i
+t0 = time.perf_counter()
+dec.decode(batch, out=bufs[0])
+for i in range(args.batches):
+    th = None
+    if i + 1 < args.batches:
+        th = threading.Thread(target=dec.decode, args=(batch,), kwargs=dict(out=bufs[(i + 1) & 1]))
+        th.start()
+    feat = encode(bufs[i & 1])
+    torch.cuda.synchronize()
+    if th is not None:
+        th.join()
+overl = (time.perf_counter() - t0) / args.batches
+res = dict(frames=args.frames, size=[H, W], serial_ms_per_batch=round(serial * 1e3, 2), serial_frames_per_s=round(args.frames / serial, 1),
+           overlapped_ms_per_batch=round(overl * 1e3, 2), overlapped_frames_per_s=round(args.frames / overl, 1),
+           decode_on_own_stream=True)
+print(json.dumps(res))
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(res, open("gpurun_out/bench_pipeline.json", "w"), indent=1)

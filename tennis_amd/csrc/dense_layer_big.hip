@@ -92,7 +92,11 @@ __device__ __forceinline__ int stage_swz(int row, int chunk) {
 // SQ_LDS_BANK_CONFLICT = 27 % of SQ_LDS_IDX_ACTIVE).  Leaving bit 0 of the chunk alone and folding slot bits 0-2 into
 // chunk bits 1-3 is conflict-free for every start slot, k-step and lane group (exhaustive search over the GF(2)-linear
 // maps, scripts/lds_swizzle_search.py); the price is a 2-way conflict on epilogue A's ds_write_b64 (slots s, s+8).
+#ifdef TN_OLD_SWZ
+__device__ __forceinline__ int tile_swz(int slot) { return slot & 15; }
+#else
 __device__ __forceinline__ int tile_swz(int slot) { return (slot & 7) << 1; }
+#endif
 
 // One LDS-DMA piece: 64 lanes x 16 B, global (per-lane address) -> LDS (wave-uniform base
 // + lane*16).  Issued through inline asm on purpose: hipcc treats the builtin as an LDS
