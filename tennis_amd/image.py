@@ -18,7 +18,9 @@ covers that refusal: a missing library or GPU still raises.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -45,6 +47,17 @@ def image_info(buf) -> tuple:
     return w.value, h.value, c.value
 
 
+_live = weakref.WeakSet()          # decoders that still own device / pinned memory
+
+
+@atexit.register
+def _close_all():
+    # release the workspaces while the HIP runtime is still up (an object that survives until interpreter teardown -
+    # e.g. one kept alive by a traceback - must not call into a runtime that has already shut down)
+    for d in list(_live):
+        d.close()
+
+
 class JpegDecoder:
     """Owns a ``tn_jpeg`` workspace on one context (device + stream)."""
 
@@ -53,9 +66,12 @@ class JpegDecoder:
         hd = C.c_void_p()
         check(self.ctx.lib.tn_jpeg_create(self.ctx.handle, C.byref(hd)), "tn_jpeg_create")
         self._h = hd
+        _live.add(self)
 
     def decode(self, bufs, out: torch.Tensor | None = None) -> torch.Tensor:
         """bufs: sequence of bytes-like JPEG files of one geometry -> (N, H, W, 3) uint8 RGB on the context's device."""
+        if self._h is None:
+            raise RuntimeError("this JpegDecoder has been closed")
         bufs = [b if isinstance(b, bytes) else bytes(b) for b in bufs]
         n = len(bufs)
         if n == 0:

@@ -24,7 +24,8 @@ def _img(rng, h, w, kind="smooth"):
 
 
 def _encode(a, **kw):
-    from PIL import Image
+    from PIL import Image, ImageFile
+    ImageFile.MAXBLOCK = max(ImageFile.MAXBLOCK, 1 << 24)      # optimize / restart options need the whole file in one encoder buffer
     b = io.BytesIO()
     Image.fromarray(a).save(b, "JPEG", **kw)
     return b.getvalue()
@@ -179,3 +180,29 @@ def test_tennisset_device_decode_route(tmp_path, window):
         assert np.array_equal(la, lb) and np.array_equal(ia, ib) and np.array_equal(ia, ic)
     with pytest.raises(ValueError):
         TennisSet(decode="gpu", **kw)
+
+
+def test_device_decode_random_sweep():
+    """120 files of random size (1..300 x 1..300), content, quality, chroma layout, Huffman optimisation and restart
+    interval, decoded in random groups: every one identical to libjpeg's output"""
+    pytest.importorskip("PIL")
+    from tennis_amd import image
+    rng = np.random.default_rng(2024)
+    dec = image.JpegDecoder()
+    for _ in range(40):
+        h, w = int(rng.integers(1, 301)), int(rng.integers(1, 301))
+        kw = dict(quality=int(rng.integers(5, 101)), subsampling=int(rng.integers(0, 3)), optimize=bool(rng.integers(0, 2)))
+        r = int(rng.integers(0, 4))
+        if r == 1:
+            kw["restart_marker_blocks"] = int(rng.integers(1, 9))
+        elif r == 2:
+            kw["restart_marker_rows"] = int(rng.integers(1, 4))
+        files = []
+        for i in range(3):          # three files of this geometry in one call (restart interval included in "geometry")
+            a = _img(rng, h, w, "noise" if rng.integers(0, 2) else "smooth")
+            if rng.integers(0, 4) == 0:
+                a[:] = int(rng.integers(0, 256))          # a flat image: every AC coefficient is zero
+            files.append(_encode(a, **kw))
+        out = dec.decode(files).cpu().numpy()
+        for i, f in enumerate(files):
+            assert np.array_equal(out[i], _pillow(f)), (h, w, kw, i)
