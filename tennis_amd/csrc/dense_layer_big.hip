@@ -657,9 +657,38 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
 
   // NFR = fragments this wave really owns (wave-uniform); the loop body is branch-free so the
   // compiler can run the LDS reads ahead of the MFMAs
+  // Operands double-buffered by hand: the fragments of step (tap, kk + 1) are requested BEFORE the MFMAs of step
+  // (tap, kk) - through the tap boundary for the pixel fragments (the tile does not change during phase B), behind the
+  // tap's barrier for the weight fragments (their ring slot is published by it).  Left to itself hipcc issues every
+  // group of ds_reads directly in front of the MFMAs that need them (s_waitcnt lgkmcnt(1) behind four reads just
+  // issued): 72 exposed LDS round trips per tile, phase B 12 900 cycles for 8 060 cycles of MFMA work on the
+  // busiest SIMD.  sched_barrier keeps the compiler from sinking the prefetch below the MFMAs again.
   auto phase_b = [&](auto nfr_tag) {
     constexpr int NFR = decltype(nfr_tag)::value;
+    constexpr int NX = NFR > 0 ? NFR : 1;
     constexpr int NT = EX ? 18 : 9;      // EX: the nine taps once more with the lo image of the weights
+    f16x8 xb[2][NX], wb[2][2];
+    auto load_x = [&](f16x8 *xf, int tap, int kk) {
+      const int dy = (tap % 9) / 3 - 1, dx = (tap % 9) - ((tap % 9) / 3) * 3 - 1;
+      const int off = WP + dy * WP + dx + px + 16 * u0;   // slot of this lane's pixel, fragment u0
+      const int chunk = kk * 4 + kg;
+#pragma unroll
+      for (int j = 0; j < NFR; ++j) {
+        const int slot = off + 16 * j;
+        xf[j] = *(const f16x8 *)(tile + slot * 256 + ((chunk ^ tile_swz(slot)) << 4));
+      }
+    };
+    auto load_w = [&](f16x8 *wf, int tap, int kk) {
+      const unsigned char *wring = ring + (tap & 1) * 8192 + lane * 16;
+      if constexpr (NFR > 0) {
+        wf[0] = *(const f16x8 *)(wring + (kk * 2) * 1024);
+        wf[1] = *(const f16x8 *)(wring + (kk * 2 + 1) * 1024);
+      } else {
+        wf[0] = wf[1] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    };
+    load_x(xb[0], 0, 0);
+    load_w(wb[0], 0, 0);
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap) {
       // stage the next tap's weights while this tap computes; taps are fully unrolled so
@@ -668,30 +697,25 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
         *(f16x8 *)(ring + ((tap + 1) & 1) * 8192 + t * 16) = wq[(tap + 1) % 3];
         if (tap + 4 < NT) wq[(tap + 1) % 3] = w3tap(tap + 4);
       }
-      const int dy = (tap % 9) / 3 - 1, dx = (tap % 9) - ((tap % 9) / 3) * 3 - 1;
-      const int off = WP + dy * WP + dx + px + 16 * u0;   // slot of this lane's pixel, fragment u0
-      const unsigned char *wring = ring + (tap & 1) * 8192 + lane * 16;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        f16x8 wf0 = {0, 0, 0, 0, 0, 0, 0, 0}, wf1 = wf0;
-        if constexpr (NFR > 0) {
-          wf0 = *(const f16x8 *)(wring + (kk * 2) * 1024);
-          wf1 = *(const f16x8 *)(wring + (kk * 2 + 1) * 1024);
+        const int cur = kk & 1, nxt = cur ^ 1;       // (four steps per tap: the buffers line up again at every tap)
+        if (kk < 3) {
+          load_x(xb[nxt], tap, kk + 1);
+          load_w(wb[nxt], tap, kk + 1);
+        } else if (tap + 1 < NT) {
+          load_x(xb[nxt], tap + 1, 0);
         }
-        const int chunk = kk * 4 + kg;
-        f16x8 xf[NFR > 0 ? NFR : 1];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < NFR; ++j) {
-          const int slot = off + 16 * j;
-          xf[j] = *(const f16x8 *)(tile + slot * 256 + ((chunk ^ tile_swz(slot)) << 4));
+          bacc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[cur][0], xb[cur][j], bacc[j][0], 0, 0, 0);
+          bacc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[cur][1], xb[cur][j], bacc[j][1], 0, 0, 0);
         }
-#pragma unroll
-        for (int j = 0; j < NFR; ++j) {
-          bacc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0, xf[j], bacc[j][0], 0, 0, 0);
-          bacc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1, xf[j], bacc[j][1], 0, 0, 0);
-        }
+        __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();
+      if (tap + 1 < NT) load_w(wb[0], tap + 1, 0);
     }
   };
   if (TN_EXP & 1) {
