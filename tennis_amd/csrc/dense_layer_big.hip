@@ -53,17 +53,18 @@ struct DLGeom {
   static constexpr int PIECES = STAGE / 1024, PPW = PIECES / 8, XPIECES = XS / 1024;
   static constexpr int RPP = 1024 / ROWB;                    // rows per 1-KiB DMA piece
   static constexpr int RING_A = NST * STAGE;
-  // ping-pong K loop: X ring of wave-private row groups + shared W ring
-  static constexpr int SPB = BK / 32;                        // 32-channel sub-steps per stage
-  static constexpr int XPW = (BM / 8) * ROWB / 1024;         // X pieces a wave loads per stage (its own rows)
-  static constexpr int WPW = (128 * ROWB / 1024) / 8;        // W pieces a wave loads per stage
-  static constexpr int WRING = NST * XS;
-  static_assert(NST * (XS + WS) == RING_A, "ping-pong rings use the same LDS as the flat ring");
-  static constexpr int W3RING = TILE_BYTES;                  // 2 x 8 KiB ring of 3x3 weights
-  static constexpr int TAB = (TILE_BYTES + 16384 > RING_A) ? TILE_BYTES + 16384 : RING_A;
-  static constexpr int TAB2 = TAB;                           // s2[128], t2[128]
-  static constexpr int TAB1 = TAB + 1024;                    // s1[K], t1[K]  (K <= 1024)
-  static constexpr int LDS_BYTES = TAB + 1024 + 8192;
+  static constexpr int KMAX = W == 56 ? 256 : W == 28 ? 512 : 1024;   // input channels a layer of this block can have
+  static constexpr int TABS = 1024 + 8 * KMAX;               // s2[128] t2[128] | s1[KMAX] t1[KMAX]
+  static constexpr int W3RING = TILE_BYTES;                  // slots 0 and 1 of the 3 x 8 KiB ring of 3x3 weights
+  static constexpr int W3SLOT2 = TILE_BYTES + 16384;         // slot 2
+  // The BatchNorm tables.  56x56 / 28x28: in the slots between the tile's last row and the highest slot a (discarded)
+  // phase-B fragment still reads - nothing is ever written there, the K-loop ring ends below them, and it is what lets the
+  // third weight slot fit into 160 KB.  14x14 / 7x7 (K-loop ring longer than tile + weight slots): behind the ring.
+  static constexpr bool TABS_IN_SLACK = (TSLOT - NSLOT) * 256 >= TABS && NSLOT * 256 >= RING_A;
+  static constexpr int TAIL = (TILE_BYTES + 24576 > RING_A) ? TILE_BYTES + 24576 : RING_A;
+  static constexpr int TAB2 = TABS_IN_SLACK ? NSLOT * 256 : TAIL;
+  static constexpr int TAB1 = TAB2 + 1024;
+  static constexpr int LDS_BYTES = TABS_IN_SLACK ? TAIL : TAIL + TABS;
   // BM = 64 (7x7 frames, 63 tile rows): the waves split the tile 4 (pixel rows) x 2 (bottleneck channel halves)
   // instead of 8 x 1, so no wave spends MFMAs and weight-fragment reads on rows past the frame
   static constexpr bool NSPLIT = (BM == 64);
@@ -134,12 +135,12 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   static_assert(!EX || PP == 2, "the exact-weights mode exists for the default K loop only");
   using G = DLGeom<W, ROUT, BM, BK>;
   constexpr int WP = G::WP, TR = G::TR, MIW = G::MIW, NI = G::NI;
-  static_assert(!G::NSPLIT || PP == 2 || PP == 4, "the 4 x 2 wave split exists for the flat K loops only");
   static_assert(PP != 4 || (G::NSPLIT && BK == 64), "the software-pipelined K loop is built for the 7x7 geometry");
   constexpr int ROWB = G::ROWB, PPW = G::PPW, RPP = G::RPP, CPR = ROWB / 16;  // chunks per row
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *tile = smem;                   // bottleneck tile (aliases the DMA ring)
-  unsigned char *ring = smem + G::W3RING;       // 3x3 weight ring
+  unsigned char *ring = smem + G::W3RING;       // 3x3 weight ring: slots 0, 1 here, slot 2 at W3SLOT2
+  auto w3slot = [&](int i) { return i == 2 ? smem + G::W3SLOT2 : ring + i * 8192; };
   float *tab2 = (float *)(smem + G::TAB2);
   float *tab1 = (float *)(smem + G::TAB1);
 
@@ -252,150 +253,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     }
   };
   auto issue = [&](int st, int sidx) { issue_pieces(st, sidx, std::integral_constant<int, 0>{}, std::integral_constant<int, PPW>{}); };
-  if constexpr (PP == 1 || PP == 3) {
-    constexpr bool XINC = (PP == 3);   // X refill pieces go out between the MFMA groups of the COMPUTE segment
-    // Ping-pong K loop.  The two waves of a SIMD (w, w+4) run half a step apart: while one is in its
-    // LOAD segment (fragment ds_reads, BN1+ReLU on the VALU, LDS-DMA issue) the other is in its COMPUTE
-    // segment (MFMAs only), one s_barrier per segment.  Each wave's pixel rows are private to it, so
-    // a wave refills its own rows of an X slot right after reading them (three stages ahead, no
-    // cross-wave hand-off); only the shared 1x1-weight stages are published through the barriers.
-    constexpr int XPW = G::XPW, WPW = G::WPW, SPB = G::SPB;
-    const int half = wid >> 2;
-    const f16 *xsrc[XPW], *wsrc[WPW];
-    {
-      const int prow = lane / CPR, p = lane % CPR;
-#pragma unroll
-      for (int j = 0; j < XPW; ++j) {
-        const int row = (wid * XPW + j) * RPP + prow;
-        const int m = row < MA ? row : MA - 1;
-        xsrc[j] = xbase + (long)m * ldc + stage_swz<BK>(row, p) * 8;
-      }
-#pragma unroll
-      for (int j = 0; j < WPW; ++j) {
-        const int row = (wid * WPW + j) * RPP + prow;
-        wsrc[j] = a.w1 + (long)row * K + stage_swz<BK>(row, p) * 8;
-      }
-    }
-    auto issue_x = [&](int slot) {
-#pragma unroll
-      for (int j = 0; j < XPW; ++j) {
-        dma16(xsrc[j], lds0 + slot * G::XS + (wid * XPW + j) * 1024);
-        xsrc[j] += BK;
-      }
-    };
-    auto issue_w = [&](int slot) {
-#pragma unroll
-      for (int j = 0; j < WPW; ++j) {
-        dma16(wsrc[j], lds0 + G::WRING + slot * G::WS + (wid * WPW + j) * 1024);
-        wsrc[j] += BK;
-      }
-    };
-    // BN tables -> LDS by DMA as well (issued first, so the counted wait below covers them): s1/t1 in
-    // 1-KiB pieces of 256 floats (waves 0-3 / 4-7), s2|t2 as one piece (wave 0)
-    {
-      const int p = wid & 3;
-      if (p * 256 < K) {
-        const float *base = (wid < 4) ? a.s1 : a.t1;
-        const int idx = p * 256 + lane * 4;
-        dma16(base + (idx < K ? idx : 0), lds0 + G::TAB1 + (wid < 4 ? 0 : 4096) + p * 1024);
-      }
-      if (wid == 0) dma16((lane < 32 ? a.s2 : a.t2 - 128) + lane * 4, lds0 + G::TAB2);
-    }
-    issue_x(0);
-    issue_w(0);
-    issue_x(1);      // K >= 64 = 2 stages for every geometry (BK = 64 is only used from K = 256)
-    issue_w(1);
-    if (nk > 2) {
-      issue_x(2);
-      wait_vmcnt<2 * XPW + WPW>();     // tables and stage 0 have landed; stages 1, 2 may be in flight
-    } else {
-      wait_vmcnt<XPW + WPW>();
-    }
-    __syncthreads();
-    DL_STAMP(1);
-    wq[0] = w3[0];
-    wq[1] = w3[512];
-    wq[2] = w3[2 * 512];
-
-    int st = 0;
-    // one stage = SPB sub-steps of 32 channels; IW / IX: refill W two and X three stages ahead at the
-    // stage's last sub-step; WN: DMA pieces that may stay in flight once stage q+1 has to have landed
-    auto stage = [&](int q, auto tw, auto tx, auto tn) {
-      constexpr bool IW = decltype(tw)::value, IX = decltype(tx)::value;
-      constexpr int WN = decltype(tn)::value;
-      const unsigned char *Xs = smem + st * G::XS;
-      const unsigned char *Ws = smem + G::WRING + st * G::WS;
-#pragma unroll
-      for (int i = 0; i < SPB; ++i) {
-        const int k0 = q * BK + i * 32;
-        if (k0 < K) {
-          // ---------------- LOAD segment ----------------
-          f16x8 xraw[MIW], wa[8], xb[MIW];
-#pragma unroll
-          for (int mi = 0; mi < MIW; ++mi) {
-            const int row = wid * (BM / 8) + mi * 16 + frow;
-            xraw[mi] = *(const f16x8 *)(Xs + row * ROWB + (stage_swz<BK>(row, i * 4 + fch) << 4));
-          }
-          const int kb = k0 + fch * 8;
-          const float4 s0 = *(const float4 *)(tab1 + kb), s1 = *(const float4 *)(tab1 + kb + 4);
-          const float4 t0 = *(const float4 *)(tab1 + 1024 + kb), t1 = *(const float4 *)(tab1 + 1024 + kb + 4);
-#pragma unroll
-          for (int ni = 0; ni < 8; ++ni) {
-            const int row = ni * 16 + frow;
-            wa[ni] = *(const f16x8 *)(Ws + row * ROWB + (stage_swz<BK>(row, i * 4 + fch) << 4));
-          }
-          if constexpr (IW) {
-            if (i == SPB - 1) issue_w(st >= 1 ? st - 1 : 2);        // W(q+2) -> slot (q+2)%3
-          }
-          const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-          const float sh[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-#pragma unroll
-          for (int mi = 0; mi < MIW; ++mi) xb[mi] = bn_relu8_mix(xraw[mi], sc, sh);
-          if constexpr (IX && !XINC) {
-            if (i == SPB - 1) {
-              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // own X reads are done: refill the rows
-              issue_x(st);                                           // X(q+3) -> the slot just read
-            }
-          }
-          if (i == SPB - 1) wait_vmcnt<WN>();
-          pp_barrier();
-          // ---------------- COMPUTE segment ----------------
-#pragma unroll
-          for (int mi = 0; mi < MIW; ++mi) {
-#pragma unroll
-            for (int ni = 0; ni < 8; ++ni)
-              acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ni], xb[mi], acc[ni][mi], 0, 0, 0);
-            if constexpr (IX && XINC) {
-              if (i == SPB - 1) {
-#pragma unroll
-                for (int j = 0; j < XPW; ++j)
-                  if (j >= mi * XPW / MIW && j < (mi + 1) * XPW / MIW) {
-                    dma16(xsrc[j], lds0 + st * G::XS + (wid * XPW + j) * 1024);
-                    xsrc[j] += BK;
-                  }
-              }
-            }
-          }
-          // the second half's very last COMPUTE segment needs no barrier: nobody waits for it before
-          // the __syncthreads that follows epilogue A (keeps the barrier counts of the halves equal)
-          if (!(half && k0 + 32 >= K)) pp_barrier();
-        }
-      }
-      st = st == 2 ? 0 : st + 1;
-    };
-    using std::integral_constant;
-    if (half) pp_barrier();                         // second half runs one segment behind
-    {
-      int q = 0;
-      // in-flight allowance once stage q+1 must have landed: [X(q+2), W(q+2), X(q+3)] when X is refilled
-      // in the LOAD segment, [X(q+2), W(q+2)] when it is refilled in the following COMPUTE segment
-      for (; q + 3 < nk; ++q) stage(q, integral_constant<bool, true>{}, integral_constant<bool, true>{}, integral_constant<int, (XINC ? 1 : 2) * XPW + WPW>{});
-      if (q + 2 < nk) { stage(q, integral_constant<bool, true>{}, integral_constant<bool, false>{}, integral_constant<int, XPW + WPW>{}); ++q; }
-      for (; q < nk; ++q) stage(q, integral_constant<bool, false>{}, integral_constant<bool, false>{}, integral_constant<int, 0>{});
-    }
-    // no wave reads the rings any more (the other half is at most inside its last COMPUTE segment):
-    // the tile that aliases them may be written
-  } else if constexpr (PP == 4) {
+  if constexpr (PP == 4) {
   // ---------------------------------------------------------------------------------------------------------
   // Software-pipelined K loop of the 7x7 geometry (64-channel stages).  The flat loop walks, once per k-step and
   // behind the stage's barrier, a chain LDS reads -> BN+ReLU -> MFMAs with 4 MFMAs per wave at its end (measured:
@@ -414,7 +272,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     const unsigned char *Ws = Xs + G::XS;
     const int kb = kt * BK + ks * 32 + fch * 8;
     const float4 s0 = *(const float4 *)(tab1 + kb), s1 = *(const float4 *)(tab1 + kb + 4);
-    const float4 t0 = *(const float4 *)(tab1 + 1024 + kb), t1 = *(const float4 *)(tab1 + 1024 + kb + 4);
+    const float4 t0 = *(const float4 *)(tab1 + G::KMAX + kb), t1 = *(const float4 *)(tab1 + G::KMAX + kb + 4);
     o.sc[0] = s0.x; o.sc[1] = s0.y; o.sc[2] = s0.z; o.sc[3] = s0.w; o.sc[4] = s1.x; o.sc[5] = s1.y; o.sc[6] = s1.z; o.sc[7] = s1.w;
     o.sh[0] = t0.x; o.sh[1] = t0.y; o.sh[2] = t0.z; o.sh[3] = t0.w; o.sh[4] = t1.x; o.sh[5] = t1.y; o.sh[6] = t1.z; o.sh[7] = t1.w;
 #pragma unroll
@@ -452,7 +310,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     if (nk > 2) issue4(2);
     for (int i = t; i < K; i += 512) {
       tab1[i] = a.s1[i];
-      tab1[1024 + i] = a.t1[i];
+      tab1[G::KMAX + i] = a.t1[i];
     }
     if (t < 128) {
       tab2[t] = a.s2[t];
@@ -496,7 +354,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     // BN tables -> LDS (ordinary loads; their wait also covers the two DMA stages above)
     for (int i = t; i < K; i += 512) {
       tab1[i] = a.s1[i];
-      tab1[1024 + i] = a.t1[i];
+      tab1[G::KMAX + i] = a.t1[i];
     }
     if (t < 128) {
       tab2[t] = a.s2[t];
@@ -534,7 +392,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
       if (((EX && kt >= nkc) ? kt - nkc : kt) * BK + ks * 32 < K) {
         const int kb = ((EX && kt >= nkc) ? kt - nkc : kt) * BK + ks * 32 + fch * 8;   // activation channels of this k-step
         const float4 s0 = *(const float4 *)(tab1 + kb), s1 = *(const float4 *)(tab1 + kb + 4);
-        const float4 t0 = *(const float4 *)(tab1 + 1024 + kb), t1 = *(const float4 *)(tab1 + 1024 + kb + 4);
+        const float4 t0 = *(const float4 *)(tab1 + G::KMAX + kb), t1 = *(const float4 *)(tab1 + G::KMAX + kb + 4);
         const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
         const float sh[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
         f16x8 wa[NI];
@@ -634,8 +492,11 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
       }
     }
   }
-  *(f16x8 *)(ring + t * 16) = wq[0];   // tap 0 -> ring[0]
-  wq[0] = w3tap(3);                    // request tap 3
+  // 3x3 weights: taps 0 and 1 -> ring slots 0 and 1 (published by the barrier below); the registers go on to taps 3, 4
+  *(f16x8 *)(w3slot(0) + t * 16) = wq[0];
+  *(f16x8 *)(w3slot(1) + t * 16) = wq[1];
+  wq[0] = w3tap(3);
+  wq[1] = w3tap(4);
   __syncthreads();
   DL_STAMP(4);
 
@@ -679,7 +540,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
       }
     };
     auto load_w = [&](f16x8 *wf, int tap, int kk) {
-      const unsigned char *wring = ring + (tap & 1) * 8192 + lane * 16;
+      const unsigned char *wring = w3slot(tap % 3) + lane * 16;
       if constexpr (NFR > 0) {
         wf[0] = *(const f16x8 *)(wring + (kk * 2) * 1024);
         wf[1] = *(const f16x8 *)(wring + (kk * 2 + 1) * 1024);
@@ -691,12 +552,6 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     load_w(wb[0], 0, 0);
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap) {
-      // stage the next tap's weights while this tap computes; taps are fully unrolled so
-      // the three weight registers rotate with static indices (prefetch distance 3 taps)
-      if (tap + 1 < NT) {
-        *(f16x8 *)(ring + ((tap + 1) & 1) * 8192 + t * 16) = wq[(tap + 1) % 3];
-        if (tap + 4 < NT) wq[(tap + 1) % 3] = w3tap(tap + 4);
-      }
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const int cur = kk & 1, nxt = cur ^ 1;       // (four steps per tap: the buffers line up again at every tap)
@@ -705,6 +560,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
           load_w(wb[nxt], tap, kk + 1);
         } else if (tap + 1 < NT) {
           load_x(xb[nxt], tap + 1, 0);
+          load_w(wb[nxt], tap + 1, 0);               // slot (tap+1) % 3: written in tap-1, published by this tap's barrier
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -713,10 +569,20 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
           bacc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[cur][1], xb[cur][j], bacc[j][1], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (kk == 1) {
+          // The tap's one barrier sits in its MIDDLE, where nothing is waited for behind it (the operands of the next
+          // step are on their way already).  Everybody is done with tap-1, so its slot (tap+2) % 3 takes tap+2's weights
+          // now; the NEXT tap's barrier publishes them, one and a half taps before their first read.  Three taps of
+          // prefetch in registers, rotating with static indices.
+          __syncthreads();
+          if (tap + 2 < NT) {
+            *(f16x8 *)(w3slot((tap + 2) % 3) + t * 16) = wq[(tap + 2) % 3];
+            if (tap + 5 < NT) wq[(tap + 2) % 3] = w3tap(tap + 5);
+          }
+        }
       }
-      __syncthreads();
-      if (tap + 1 < NT) load_w(wb[0], tap + 1, 0);
     }
+    __syncthreads();   // every wave is past its last fragment read: the tile and the ring may be overwritten
   };
   if (TN_EXP & 1) {
   } else if (u1 - u0 == MAXU) phase_b(std::integral_constant<int, MAXU>{});
@@ -794,7 +660,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int idx = t + 512 * i;
-        if (idx < nxK) { tab1[idx] = nxs[i]; tab1[1024 + idx] = nxt[i]; }
+        if (idx < nxK) { tab1[idx] = nxs[i]; tab1[G::KMAX + idx] = nxt[i]; }
       }
       if (t < 256) tab2[t] = nx2;
     }
@@ -823,6 +689,7 @@ int launch_geom(const DenseLayerArgs &a, hipStream_t s) {
     ncu = prop.multiProcessorCount > 0 ? (prop.multiProcessorCount / 8) * 8 : 256;
     if (getenv("TN_PERSIST_WGS")) ncu = atoi(getenv("TN_PERSIST_WGS"));   // tuning hook
   }
+  TN_REQUIRE(a.K + 32 * (a.nchain > 0 ? a.nchain - 1 : 0) <= G::KMAX, "dense_layer: more input channels than this block's table space holds");
   const int nvb = a.B * (a.H / ROUT);
   // one workgroup per CU walking its tiles (flat K loops, single layer); otherwise one workgroup per tile
   const bool persist = !CHAIN && (PP == 0 || PP == 2) && !(a.variant & 16) && nvb > ncu && ncu > 0;
@@ -859,14 +726,11 @@ int launch_dense_layer_big(const DenseLayerArgs &a, hipStream_t s) {
     if (a.variant & 32) return launch_geom<7, 7, 128, 64, 2, true>(a, s);
     return (a.variant & 512) ? launch_geom<7, 7, 64, 64, 2, true>(a, s) : launch_geom<7, 7, 64, 64, 4, true>(a, s);
   }
-  // K-loop flavour (tuning hook, variant bits 2-3): default 0 -> flat loop with the refill spread over the MFMA
-  // groups (measured best); 1 -> ping-pong halves, 2 -> flat with the refill up front, 3 -> ping-pong with the
-  // X refill inside the COMPUTE segment
-  static const int pp_of_bits[4] = {2, 1, 0, 3};
-  const int pp = pp_of_bits[(a.variant >> 2) & 3];
-#define TN_GEOM(W_, R_, BM_, BK_) \
-  (pp == 0 ? launch_geom<W_, R_, BM_, BK_, 0>(a, s) : pp == 1 ? launch_geom<W_, R_, BM_, BK_, 1>(a, s) : \
-   pp == 2 ? launch_geom<W_, R_, BM_, BK_, 2>(a, s) : launch_geom<W_, R_, BM_, BK_, 3>(a, s))
+  // K-loop flavour (tuning hook, variant bit 3): default -> flat loop with the refill spread over the MFMA groups (measured
+  // best); bit 3 -> flat with the refill up front.  (The ping-pong variants of round 1, bit 2, measured the same as the
+  // flat loop and are gone.)
+  const int pp = (a.variant & 8) ? 0 : 2;
+#define TN_GEOM(W_, R_, BM_, BK_) (pp == 0 ? launch_geom<W_, R_, BM_, BK_, 0>(a, s) : launch_geom<W_, R_, BM_, BK_, 2>(a, s))
   if (a.H == 56 && a.W == 56) return TN_GEOM(56, 7, 512, 32);
   if (a.H == 28 && a.W == 28) return TN_GEOM(28, 14, 512, 32);
   if (a.H == 14 && a.W == 14) return TN_GEOM(14, 14, 256, 64);
