@@ -91,6 +91,15 @@ __device__ __forceinline__ f16x8 bn_relu8_mix(f16x8 v, const float *__restrict__
   return __builtin_bit_cast(f16x8, out);
 }
 
+// one packed pair of bn_relu8_mix (3 VALU): element j of the fragment's four dwords
+__device__ __forceinline__ unsigned bn_relu2_mix(unsigned in, float s0, float s1, float t0, float t1) {
+  unsigned d, o;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=&v"(d) : "v"(in), "v"(s0), "v"(t0));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(in), "v"(s1), "v"(t1));
+  asm("v_pk_max_f16 %0, %1, 0" : "=v"(o) : "v"(d));
+  return o;
+}
+
 // relu(acc*s+t) for 4 fp32 accumulators -> 4 fp16 (fp32 fma, one rounding, packed ReLU): 6 VALU instead of 10.
 __device__ __forceinline__ f16x4 bn_relu4_from_f32(f32x4 v, float4 s, float4 t) {
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));

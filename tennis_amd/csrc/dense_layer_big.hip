@@ -370,9 +370,22 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   wq[1] = w3[512];
   wq[2] = w3[2 * 512];
 
+  // Fragments this wave computes (wave-uniform): the first nf of its MIW pixel fragments - those inside the tile's rows and,
+  // at 28x28, inside the wave's share.  The K loop is instantiated per count so that a stage is one straight-line block.
+  int nf = 0;
+#pragma unroll
+  for (int mi = 0; mi < MIW; ++mi) nf += (mrow0 + mi * 16 < MA && mi < nfw) ? 1 : 0;
+  // One k-tile: wait until stage kt has landed (YOUNGER = stages issued after it that may still be in flight), barrier,
+  // compute, refilling the slot everyone just finished with.  Per 32-channel k-step ALL operand reads go out first
+  // (BatchNorm constants, the first pixel fragment, the 1x1 weight fragments, the other pixel fragments); then fragment by
+  // fragment 8 MFMAs, with BN+ReLU of the NEXT fragment (12 VALU instructions) issued in the gaps behind the first four of
+  // them and this fragment's share of the refill DMA behind the last.  Left to itself hipcc emits read -> s_waitcnt
+  // lgkmcnt(0) -> 12 VALU -> 8 MFMA per fragment: five exposed LDS round trips per stage and the matrix pipe idle
+  // under every BatchNorm (measured: 2 025 cycles per stage with no DMA at all, for 1 088 cycles of MFMAs).
+  auto kloop = [&](auto nf_tag) {
+  constexpr int NF = decltype(nf_tag)::value;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   int st = 1;
-  // one k-tile: wait until stage kt has landed (YOUNGER = stages issued after it that may still
-  // be in flight), barrier, refill the slot everyone just finished with, compute
   auto ktile = [&](int kt, auto younger_tag) {
     constexpr int YOUNGER = decltype(younger_tag)::value;
     wait_vmcnt<YOUNGER * PPW>();
@@ -384,6 +397,19 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     if (!SPREAD && refill) issue(rslot, kt + 2);
     const unsigned char *Xs = smem + st * G::STAGE;
     const unsigned char *Ws = Xs + G::XS;
+    constexpr int NG = (BK / 32) * MIW;             // refill groups of a stage: one per (k-step, fragment)
+    auto refill_group = [&](int gi) {               // pieces [gi*PPW/NG, (gi+1)*PPW/NG) of the refill
+      if constexpr (SPREAD) {
+        if (refill) {
+#pragma unroll
+          for (int j = 0; j < PPW; ++j)
+            if (j >= gi * PPW / NG && j < (gi + 1) * PPW / NG) {
+              dma16(src[j], lds0 + rslot * G::STAGE + (wid * PPW + j) * 1024);
+              advance(j, kt + 2);
+            }
+        }
+      }
+    };
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       if (TN_EXP & 16) {
@@ -391,52 +417,55 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
       } else
       if (((EX && kt >= nkc) ? kt - nkc : kt) * BK + ks * 32 < K) {
         const int kb = ((EX && kt >= nkc) ? kt - nkc : kt) * BK + ks * 32 + fch * 8;   // activation channels of this k-step
-        const float4 s0 = *(const float4 *)(tab1 + kb), s1 = *(const float4 *)(tab1 + kb + 4);
-        const float4 t0 = *(const float4 *)(tab1 + G::KMAX + kb), t1 = *(const float4 *)(tab1 + G::KMAX + kb + 4);
-        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        const float sh[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-        f16x8 wa[NI];
+        if constexpr (NF > 0) {
+          const float4 s0 = *(const float4 *)(tab1 + kb), s1 = *(const float4 *)(tab1 + kb + 4);
+          const float4 t0 = *(const float4 *)(tab1 + G::KMAX + kb), t1 = *(const float4 *)(tab1 + G::KMAX + kb + 4);
+          const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+          const float sh[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+          u32x4 xraw[NF];
+          f16x8 wa[NI];
+          auto read_x = [&](int mi) {
+            const int row = mrow0 + mi * 16 + frow;
+            xraw[mi] = *(const u32x4 *)(Xs + row * ROWB + (stage_swz<BK>(row, ks * 4 + fch) << 4));
+          };
+          read_x(0);
+          __builtin_amdgcn_sched_barrier(0);      // constants and the first fragment first: BN(0) waits for five reads, not for all
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          const int row = nch0 + ni * 16 + frow;
-          wa[ni] = *(const f16x8 *)(Ws + row * ROWB + (stage_swz<BK>(row, ks * 4 + fch) << 4));
-        }
-#pragma unroll
-        for (int mi = 0; mi < MIW; ++mi) {
-          const int row = mrow0 + mi * 16 + frow;
-          if ((a.variant & 64) || (mrow0 + mi * 16 < MA && mi < nfw)) {   // wave-uniform: fragments past the tile's rows are skipped (bit 6: not)
-          const f16x8 xraw = *(const f16x8 *)(Xs + row * ROWB + (stage_swz<BK>(row, ks * 4 + fch) << 4));
-          const f16x8 xb = bn_relu8_mix(xraw, sc, sh);
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ni], xb, acc[ni][mi], 0, 0, 0);
+          for (int ni = 0; ni < NI; ++ni) {
+            const int row = nch0 + ni * 16 + frow;
+            wa[ni] = *(const f16x8 *)(Ws + row * ROWB + (stage_swz<BK>(row, ks * 4 + fch) << 4));
+            if (ni < 2) __builtin_amdgcn_sched_barrier(0);    // (the first MFMAs wait for these)
           }
-          if constexpr (SPREAD) {
-            constexpr int NG = (BK / 32) * MIW;
-            const int gi = ks * MIW + mi;           // compile-time after unrolling
-            if (refill) {
-              // pieces [gi*PPW/NG, (gi+1)*PPW/NG) of the refill go out behind this group of 8 MFMAs
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-              for (int j = 0; j < PPW; ++j)
-                if (j >= gi * PPW / NG && j < (gi + 1) * PPW / NG) {
-                  dma16(src[j], lds0 + rslot * G::STAGE + (wid * PPW + j) * 1024);
-                  advance(j, kt + 2);
-                }
+          for (int mi = 1; mi < NF; ++mi) read_x(mi);
+          __builtin_amdgcn_sched_barrier(0);
+          u32x4 xb, xn;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xb[j] = bn_relu2_mix(xraw[0][j], sc[2 * j], sc[2 * j + 1], sh[2 * j], sh[2 * j + 1]);
+#pragma unroll
+          for (int mi = 0; mi < NF; ++mi) {
+            const f16x8 xf = __builtin_bit_cast(f16x8, xb);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ni], xf, acc[ni][mi], 0, 0, 0);
+              if (mi + 1 < NF && ni < 4) {
+                xn[ni] = bn_relu2_mix(xraw[mi + 1][ni], sc[2 * ni], sc[2 * ni + 1], sh[2 * ni], sh[2 * ni + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+              }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            refill_group(ks * MIW + mi);
+            xb = xn;
           }
         }
+#pragma unroll
+        for (int mi = NF; mi < MIW; ++mi) refill_group(ks * MIW + mi);     // (fragments this wave does not compute)
       } else if constexpr (EX && SPREAD) {
         // a k-step past the channels in the MIDDLE of the loop (last k-tile of the hi pass when K % 64 == 32): its
         // share of the refill goes out all the same
-        if (refill) {
-          constexpr int NG = (BK / 32) * MIW;
 #pragma unroll
-          for (int j = 0; j < PPW; ++j)
-            if (j >= ks * MIW * PPW / NG && j < (ks + 1) * MIW * PPW / NG) {
-              dma16(src[j], lds0 + rslot * G::STAGE + (wid * PPW + j) * 1024);
-              advance(j, kt + 2);
-            }
-        }
+        for (int mi = 0; mi < MIW; ++mi) refill_group(ks * MIW + mi);
       }
     }
     st = st == 2 ? 0 : st + 1;
@@ -445,6 +474,21 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     int kt = (TN_EXP & 2) ? nk : 0;
     for (; kt + 1 < nk; ++kt) ktile(kt, std::integral_constant<int, 1>{});   // steady state: one younger stage in flight
     for (; kt < nk; ++kt) ktile(kt, std::integral_constant<int, 0>{});       // drain
+  }
+  };
+  if constexpr (MIW == 4) {
+    if (nf == 4) kloop(std::integral_constant<int, 4>{});
+    else if (nf == 3) kloop(std::integral_constant<int, 3>{});
+    else if (nf == 2) kloop(std::integral_constant<int, 2>{});
+    else if (nf == 1) kloop(std::integral_constant<int, 1>{});
+    else kloop(std::integral_constant<int, 0>{});
+  } else if constexpr (MIW == 2) {
+    if (nf == 2) kloop(std::integral_constant<int, 2>{});
+    else if (nf == 1) kloop(std::integral_constant<int, 1>{});
+    else kloop(std::integral_constant<int, 0>{});
+  } else {
+    if (nf == 1) kloop(std::integral_constant<int, 1>{});
+    else kloop(std::integral_constant<int, 0>{});
   }
   __syncthreads();   // every wave is done reading the DMA ring; the tile may now be written
 
