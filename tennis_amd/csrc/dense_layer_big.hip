@@ -62,15 +62,19 @@ struct DLGeom {
   // third weight slot fit into 160 KB.  14x14 / 7x7 (K-loop ring longer than tile + weight slots): behind the ring.
   static constexpr bool TABS_IN_SLACK = (TSLOT - NSLOT) * 256 >= TABS && NSLOT * 256 >= RING_A;
   static constexpr int TAIL = (TILE_BYTES + 24576 > RING_A) ? TILE_BYTES + 24576 : RING_A;
+  // a pixel slot that takes the stores of rows past the tile: the last slot phase B can touch when the tables are not in the
+  // slack (only discarded fragments read it), else one extra slot's worth of bytes behind everything
+  static constexpr int DUMP_SLOT = TABS_IN_SLACK ? (TAIL + 255) / 256 : TSLOT - 1;
   static constexpr int TAB2 = TABS_IN_SLACK ? NSLOT * 256 : TAIL;
   static constexpr int TAB1 = TAB2 + 1024;
-  static constexpr int LDS_BYTES = TABS_IN_SLACK ? TAIL : TAIL + TABS;
+  static constexpr int LDS_BYTES = TABS_IN_SLACK ? (DUMP_SLOT + 1) * 256 : TAIL + TABS;
   // BM = 64 (7x7 frames, 63 tile rows): the waves split the tile 4 (pixel rows) x 2 (bottleneck channel halves)
   // instead of 8 x 1, so no wave spends MFMAs and weight-fragment reads on rows past the frame
   static constexpr bool NSPLIT = (BM == 64);
   static constexpr int NI = NSPLIT ? 4 : 8;                  // 16-channel weight fragments per wave
   static constexpr int MIW = NSPLIT ? 1 : BM / 128;          // 16-row pixel fragments per wave
   static_assert(PIECES % 8 == 0, "DMA pieces must divide over 8 waves");
+  static_assert(DUMP_SLOT >= NSLOT, "the dump slot must not be a pixel or padding slot of the tile");
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
   static_assert(16 * NF16 * 80 <= TILE_BYTES, "output row buffer does not fit");
   static_assert(BM >= TR * W && (BM % 128 == 0 || BM == 64), "phase A tile too small");
@@ -524,16 +528,30 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
       sl15[mi] = tile_swz(slot);
       ok[mi] = m < MA && mi < nfw;
     }
+    // rows past the tile (edge tiles, the last wave): their stores go to a slot of the tile's slack instead of being masked
+    // out (no exec juggling per store); the table constants of channel group ni+1 are requested before group ni is worked on
+    // (hipcc waits for each pair of reads right behind issuing it: eight exposed LDS round trips per wave)
+    unsigned char *wdst[MIW];
+#pragma unroll
+    for (int mi = 0; mi < MIW; ++mi) wdst[mi] = ok[mi] ? dst[mi] : tile + G::DUMP_SLOT * 256;
+    float4 sv = *(const float4 *)(tab2 + nch0 + fch * 4), tv = *(const float4 *)(tab2 + 128 + nch0 + fch * 4);
 #pragma unroll
     for (int ni = 0; ni < ((TN_EXP & 4) ? 0 : NI); ++ni) {
-      const float4 sv = *(const float4 *)(tab2 + nch0 + ni * 16 + fch * 4);
-      const float4 tv = *(const float4 *)(tab2 + 128 + nch0 + ni * 16 + fch * 4);
+      float4 sn = sv, tn = tv;
+      if (ni + 1 < NI) {
+        sn = *(const float4 *)(tab2 + nch0 + (ni + 1) * 16 + fch * 4);
+        tn = *(const float4 *)(tab2 + 128 + nch0 + (ni + 1) * 16 + fch * 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
       const int chunk = (nch0 >> 3) + ni * 2 + (fch >> 1);   // channels n>>3
 #pragma unroll
       for (int mi = 0; mi < MIW; ++mi) {
         const f16x4 hv = bn_relu4_from_f32(acc[ni][mi], sv, tv);
-        if (ok[mi]) *(f16x4 *)(dst[mi] + ((chunk ^ sl15[mi]) << 4)) = hv;
+        *(f16x4 *)(wdst[mi] + ((chunk ^ sl15[mi]) << 4)) = hv;
       }
+      __builtin_amdgcn_sched_barrier(0);
+      sv = sn;
+      tv = tn;
     }
   }
   // 3x3 weights: taps 0 and 1 -> ring slots 0 and 1 (published by the barrier below); the registers go on to taps 3, 4
