@@ -146,3 +146,32 @@ def test_encoder_create_ex_flags():
     assert b"TN_ENC_EXACT_WEIGHTS needs the fused 224x224 path" in ctx.lib.tn_last_error()
     assert ctx.lib.tn_densenet121_create_ex(ctx.handle, arr, len(arr), b"densenet0_", 224, 224, 2, _lib.ENC_EXACT_WEIGHTS, C.byref(h)) == 0
     assert ctx.lib.tn_densenet121_destroy(h) == 0
+
+
+def test_jpeg_argument_errors():
+    """tn_jpeg_*: null arguments and empty batches are status codes, a closed decoder raises, out= must fit"""
+    from tennis_amd import _lib, image
+    lib = _lib.load()
+    ctx = _lib.default_context()
+    h = C.c_void_p()
+    assert lib.tn_jpeg_create(None, C.byref(h)) != 0 and b"null" in lib.tn_last_error()
+    assert lib.tn_jpeg_create(ctx.handle, C.byref(h)) == 0
+    assert lib.tn_jpeg_decode(h, None, None, 1, None, None, None) != 0 and b"null" in lib.tn_last_error()
+    gold = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "jpeg_cases.npz"))
+    data = gold["c420_q85__jpeg"].tobytes()
+    ptrs = (C.c_void_p * 1)(C.cast(C.c_char_p(data), C.c_void_p))
+    sizes = (C.c_size_t * 1)(len(data))
+    out = torch.empty((1, 37, 53, 3), dtype=torch.uint8, device="cuda")
+    assert lib.tn_jpeg_decode(h, ptrs, sizes, 0, _lib.ptr(out), None, None) != 0 and b"batch" in lib.tn_last_error()
+    assert lib.tn_jpeg_decode(h, ptrs, sizes, 1, _lib.ptr(out), None, None) == 0
+    assert np.array_equal(out[0].cpu().numpy(), gold["c420_q85__rgb"])
+    assert lib.tn_jpeg_destroy(h) == 0 and lib.tn_jpeg_destroy(None) == 0
+    assert lib.tn_jpeg_sync_passes(None) == 0
+    dec = image.JpegDecoder()
+    with pytest.raises(ValueError, match="out must be"):
+        dec.decode([data], out=torch.empty((1, 10, 10, 3), dtype=torch.uint8, device="cuda"))
+    with pytest.raises(ValueError, match="no files"):
+        dec.decode([])
+    dec.close()
+    with pytest.raises(RuntimeError, match="closed"):
+        dec.decode([data])
