@@ -302,33 +302,48 @@ class DataLoader:
 
     def __init__(self, dataset, batch_size, shuffle=False, num_workers=0, last_batch="keep", seed=0):
         """``shuffle=True`` (training, train.py:189): a fresh seeded permutation per epoch; ``last_batch='discard'`` drops a
-        ragged final batch (the fine-tuning step needs a fixed batch for its BatchNorm statistics)."""
+        ragged final batch (the fine-tuning step needs a fixed batch for its BatchNorm statistics).  ``num_workers`` (the
+        reference's DataLoader worker processes, train.py:101-102) > 0 on the device-decode route: that many host threads (at
+        most 2), each with its own JPEG decoder on its own stream, read and decode the following batches while the caller works
+        on the current one - one decoder's file reads, header walk and host-to-device copy run beside the other's kernels."""
         self.dataset, self.batch_size, self.shuffle, self.last_batch = dataset, batch_size, shuffle, last_batch
         self._rng = np.random.default_rng(seed)
+        self.num_workers = max(0, min(int(num_workers), 2))
+        self._tls = None
 
     def __len__(self):
         n = len(self.dataset)
         return n // self.batch_size if self.last_batch == "discard" else (n + self.batch_size - 1) // self.batch_size
 
-    def collate(self, ids):
-        """(data, labels, idxs) for the dataset items ``ids`` (what one iteration step yields)."""
+    def _device_route(self):
+        ds = self.dataset
+        return (getattr(ds, "decode", "host") != "host" and getattr(ds, "on_disk", False) and not ds._load_feats
+                and getattr(getattr(ds, "_transform", None), "device_batched", False))
+
+    def _decode_on_device(self, ids, decoder=None):
+        """the batch's JPEG files -> (N[, T], H, W, 3) uint8 on the GPU in one decode call, or None if the device decoder
+        refused them and the dataset allows the host route instead (decode="auto")"""
+        from . import image
+        ds = self.dataset
+        frames = [ds.sample_frames(int(i)) for i in ids]
+        bufs = [ds.frame_bytes(v, f) for fr in frames for (v, f) in fr]
+        try:
+            rgb = decoder.decode(bufs) if decoder is not None else image.imdecode_batch(bufs)
+        except image.UnsupportedJpeg:
+            if ds.decode != "auto":
+                raise
+            return None
+        return rgb.view(len(ids), ds._window, *rgb.shape[1:]) if ds._window > 1 else rgb
+
+    def collate(self, ids, rgb=None):
+        """(data, labels, idxs) for the dataset items ``ids`` (what one iteration step yields); ``rgb``: the batch's frames
+        already decoded on the device by a worker thread."""
         ds = self.dataset
         tf = getattr(ds, "_transform", None)
-        if (getattr(ds, "decode", "host") != "host" and getattr(ds, "on_disk", False) and not ds._load_feats
-                and getattr(tf, "device_batched", False)):
-            # device decode: the batch's files go to the GPU as bytes and are decoded there in one call
-            from . import image
-            frames = [ds.sample_frames(int(i)) for i in ids]
-            bufs = [ds.frame_bytes(v, f) for fr in frames for (v, f) in fr]
-            try:
-                rgb = image.imdecode_batch(bufs)
-            except image.UnsupportedJpeg:
-                if ds.decode != "auto":
-                    raise
-                rgb = None
+        if self._device_route():
+            if rgb is None:
+                rgb = self._decode_on_device(ids)
             if rgb is not None:
-                if ds._window > 1:
-                    rgb = rgb.view(len(ids), ds._window, *rgb.shape[1:])
                 labels = np.array([ds.classes.index(ds._samples[int(i)][2]) for i in ids], dtype=np.float32)
                 return tf(rgb), labels, np.array([int(i) for i in ids], dtype=np.int64)
         items = [self.dataset[int(i)] for i in ids]
@@ -338,11 +353,40 @@ class DataLoader:
         return (data, np.array([it[1] for it in items], dtype=np.float32),
                 np.array([it[2] for it in items], dtype=np.int64))
 
-    def __iter__(self):
+    def _batches(self):
         n = len(self.dataset)
         order = self._rng.permutation(n) if self.shuffle else np.arange(n)
         for s in range(0, n, self.batch_size):
             ids = order[s:s + self.batch_size]
             if self.last_batch == "discard" and len(ids) < self.batch_size:
                 break
-            yield self.collate(ids)
+            yield ids
+
+    def __iter__(self):
+        if self.num_workers == 0 or not self._device_route():
+            for ids in self._batches():
+                yield self.collate(ids)
+            return
+        # worker threads: each owns a decoder on its own stream (tn_jpeg handles are not re-entrant); batches come out in order
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+
+        import torch
+
+        from . import _lib, image
+        tls = threading.local()
+
+        def work(ids):
+            if not hasattr(tls, "dec"):
+                tls.dec = image.JpegDecoder(_lib.Context(stream=torch.cuda.Stream()))
+            return self._decode_on_device(ids, tls.dec)      # (tn_jpeg_decode returns with its stream synchronised)
+
+        with ThreadPoolExecutor(max_workers=self.num_workers) as pool:
+            pending = []
+            for ids in self._batches():
+                pending.append((ids, pool.submit(work, ids)))
+                if len(pending) > self.num_workers:
+                    i0, fut = pending.pop(0)
+                    yield self.collate(i0, fut.result())
+            for i0, fut in pending:
+                yield self.collate(i0, fut.result())

@@ -190,6 +190,8 @@ def build_parser():
     p.add_argument("--feats_model", default=None)
     p.add_argument("--temp_pool", default=None, help="mean, max, gru or lstm")
     p.add_argument("--root", default="data")
+    p.add_argument("--num_workers", type=int, default=2,
+                   help="loader threads (reference: DataLoader worker processes, evaluate.py:113); on the device-decode route each owns a JPEG decoder on its own stream")
     p.add_argument("--decode", default="device", choices=["device", "host", "auto"],
                    help="where on-disk JPEG frames are decoded: on the GPU (tennis_amd.image), on the host (Pillow), or device with a host fallback for files the device decoder refuses")
     p.add_argument("--frames_per_video", type=int, default=16)
@@ -246,7 +248,7 @@ def _main_rank(flags, rank, world, dev):
                          split_id=flags.split_id, balance=False, feats_model=flags.feats_model,
                          save_feats=flags.save_feats, data_shape=flags.data_shape,
                          frames_per_video=flags.frames_per_video, decode=flags.decode)
-    test_data = DataLoader(test_set, batch_size=flags.batch_size, shuffle=False)
+    test_data = DataLoader(test_set, batch_size=flags.batch_size, shuffle=False, num_workers=flags.num_workers)
 
     model = None
     if flags.feats_model is None:                                           # evaluate.py:118-135

@@ -147,6 +147,7 @@ def build_parser():
     p.add_argument("--temp_pool", default=None, help="gru or lstm (trained); mean / max need no training")
     p.add_argument("--root", default="data")
     p.add_argument("--decode", default="device", choices=["device", "host", "auto"], help="where on-disk JPEG frames are decoded (see evaluate.py)")
+    p.add_argument("--num_workers", type=int, default=2, help="loader threads (train.py:101-102), see evaluate.py")
     p.add_argument("--frames_per_video", type=int, default=16)
     p.add_argument("--exp_root", default=os.path.join("models", "vision", "experiments"))
     return p
@@ -218,8 +219,8 @@ def main(argv=None):
         start_epoch = int(os.path.basename(newest).split(".")[0]) + 1
         print("Loaded model params: {}".format(newest))
     head = mk_head({k: v.data for k, v in model.collect_params().items()})
-    train_data = DataLoader(train_set, flags.batch_size, shuffle=True, last_batch=last)
-    val_data = DataLoader(val_set, flags.batch_size, shuffle=False)
+    train_data = DataLoader(train_set, flags.batch_size, shuffle=True, last_batch=last, num_workers=flags.num_workers)
+    val_data = DataLoader(val_set, flags.batch_size, shuffle=False, num_workers=flags.num_workers)
     trainer = Trainer(head, "sgd", {"learning_rate": flags.lr, "momentum": flags.momentum, "wd": flags.wd})
     metrics = [PRF1(label_names=train_set.classes)]
 

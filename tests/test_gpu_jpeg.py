@@ -178,6 +178,12 @@ def test_tennisset_device_decode_route(tmp_path, window):
         assert a.shape[1:] == ((224, 224, 3) if window == 1 else (window, 224, 224, 3))
         assert torch.equal(a, b) and torch.equal(a, c)
         assert np.array_equal(la, lb) and np.array_equal(ia, ib) and np.array_equal(ia, ic)
+    # worker threads (two decoders on two streams): the same batches in the same order
+    for nw in (1, 2):
+        thr = list(DataLoader(TennisSet(decode="device", **kw), batch_size=4, num_workers=nw))
+        assert len(thr) == len(host)
+        for (a, la, ia), (b, lb, ib) in zip(host, thr):
+            assert torch.equal(a, b) and np.array_equal(la, lb) and np.array_equal(ia, ib)
     with pytest.raises(ValueError):
         TennisSet(decode="gpu", **kw)
 
