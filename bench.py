@@ -124,6 +124,7 @@ def build_parser():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the 256-frame batch on the CPU (minutes)")
     ap.add_argument("--single-region", action="store_true", help="one timed region of K steps only (no repetitions)")
+    ap.add_argument("--no-pipeline", action="store_true", help="join the encoder's two half-batch streams inside every forward (A/B against the pipelined default)")
     ap.add_argument("--exact-weights", action="store_true",
                     help="NOT the headline configuration: un-rounded fp32 conv weights evaluated as hi + lo fp16 pairs "
                          "(TN_ENC_EXACT_WEIGHTS), to state what the 1e-3-vs-fp32-weights mode costs")
@@ -152,11 +153,28 @@ def run(argv):
     gathered = [torch.empty((world * args.batch, enc.feature_dim), dtype=torch.float32, device=dev)
                 for _ in range(2)] if world > 1 else None
 
+    # Pipelined forwards (tn_densenet121_set_pipelined): the encoder runs a batch as two half batches on two streams, and
+    # the last chained block of the second half occupies half of the CUs; without a join inside forward the next step's
+    # first half starts beside it.  Results are ordered by the caller: the all-gather of step i is issued one step behind
+    # (join lag 1), and `drain` joins the last step - every one of the K steps is complete before the closing fence.
+    pipelined = not args.no_pipeline
+    enc.set_pipelined(pipelined)
+
     def step(i):
         f = feats[i & 1]
         enc(x, out=f)
         if world > 1:
-            dist.all_gather_into_tensor(gathered[i & 1], f)
+            if not pipelined:
+                dist.all_gather_into_tensor(gathered[i & 1], f)
+            elif i > 0:
+                enc.join(1)
+                dist.all_gather_into_tensor(gathered[(i - 1) & 1], feats[(i - 1) & 1])
+
+    def drain(k):
+        if pipelined and k > 0:
+            enc.join(0)
+            if world > 1:
+                dist.all_gather_into_tensor(gathered[(k - 1) & 1], feats[(k - 1) & 1])
 
     def fence():
         if world > 1:
@@ -169,6 +187,7 @@ def run(argv):
         t0 = time.perf_counter()
         for i in range(k):
             step(i)
+        drain(k)
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -179,6 +198,7 @@ def run(argv):
 
     for i in range(args.warmup):
         step(i)
+    drain(args.warmup)
     repeats = 1 if args.single_region else max(1, -(-MIN_TOTAL_STEPS // args.steps))
     times = [timed_region(args.steps) for _ in range(repeats)]
     dt = float(np.median(times))
@@ -232,7 +252,7 @@ def run(argv):
                           "weights": ("seeded random-init, fp32 conv weights as hi + lo fp16 pairs (exact-weights mode, 2x MFMA work "
                                       "in the dense layers / transitions)") if args.exact_weights
                                      else "seeded random-init, conv weights fp16",
-                          "timing": f"median of {repeats} fenced regions of exactly {args.steps} steps",
+                          "timing": f"median of {repeats} fenced regions of exactly {args.steps} steps" + (", forwards pipelined (results joined one step behind, all joined before the closing fence)" if pipelined else ""),
                           "region_ms": [round(t * 1e3, 2) for t in times]},
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:

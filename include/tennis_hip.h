@@ -102,6 +102,16 @@ int tn_densenet121_feature_dim(const tn_encoder *enc);
 size_t tn_densenet121_workspace_bytes(const tn_encoder *enc);
 /* x: `batch` frames in `layout`; feat: (batch, feature_dim) fp32, NCHW-flatten order. */
 int tn_densenet121_forward(tn_encoder *enc, const void *x, tn_layout layout, int batch, float *feat);
+/* Pipelined forwards.  A large batch runs as two half batches on two library-owned streams; by default forward makes
+ * the ctx's stream wait for both before it returns, so the call is stream-ordered like every other one.  With
+ * set_pipelined(enc, 1) forward does NOT: consecutive forwards then overlap (the first half of call i+1 starts beside
+ * the tail of the second half of call i, which runs on half of the CUs), and the CALLER orders the results:
+ * tn_densenet121_join(enc, 0) makes the ctx's stream wait for the last forward, join(enc, 1) for the one before it
+ * (results consumed one call behind).  Until its join, a forward's input x must not be overwritten and its feat not
+ * read; set_pipelined(enc, 0) joins everything outstanding.  Replaces nothing in the reference (MXNet's engine
+ * overlaps independent ops by itself); it exists for streaming a corpus through the encoder (config C4). */
+int tn_densenet121_set_pipelined(tn_encoder *enc, int on);
+int tn_densenet121_join(tn_encoder *enc, int lag);
 /* Same forward, but every launch is bracketed by HIP events on the ctx stream;
  * fills up to max_stats families and syncs.  For bench.py's roofline. */
 int tn_densenet121_profile(tn_encoder *enc, const void *x, tn_layout layout, int batch, float *feat,

@@ -47,6 +47,8 @@ _SIGS = {
     "tn_densenet121_feature_dim": (C.c_int, [_P]),
     "tn_densenet121_workspace_bytes": (C.c_size_t, [_P]),
     "tn_densenet121_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "tn_densenet121_set_pipelined": (C.c_int, [_P, C.c_int]),
+    "tn_densenet121_join": (C.c_int, [_P, C.c_int]),
     "tn_densenet121_profile": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.POINTER(TnKernelStat), C.c_int,
                                          C.POINTER(C.c_int)]),
     "tn_densenet121_read_tap": (C.c_int, [_P, C.c_char_p, C.c_int, _P, C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -262,7 +262,10 @@ struct tn_encoder {
   bool exact = false;         // TN_ENC_EXACT_WEIGHTS: dense-layer and transition weights as hi + lo fp16 pairs
   DenseLayerDev *chain_dev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipStream_t side[4];
-  hipEvent_t ev_in, ev_done[4];
+  hipEvent_t ev_in, ev_done[2][4];   // completion of the side streams, alternating per forward call
+  bool pipelined = false;            // tn_densenet121_set_pipelined: the caller's stream is not made to wait inside forward
+  long calls = 0;                    // forward calls so far
+  int split_of[2] = {0, 0};          // side streams the call of each parity used (0: it ran on the caller's stream)
 };
 
 static const int kBlockCfg[4] = {6, 12, 24, 16};
@@ -294,7 +297,8 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
   e->exact = (flags & TN_ENC_EXACT_WEIGHTS) != 0;
   for (int i = 0; i < 4; ++i) {
     if (hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_done[i], hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&e->ev_done[0][i], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_done[1][i], hipEventDisableTiming) != hipSuccess) {
       tn_set_error("could not create the side streams");
       delete e;
       return TN_ERR_HIP;
@@ -498,17 +502,56 @@ static int encoder_run(tn_encoder *e, const void *x, tn_layout layout, int B, fl
   // The caller's stream is fenced with events on both sides, so stream order is preserved.
   const int ns = e->nsplit;
   const bool split = e->split && !tm.on && B >= 32 * ns && (B % (8 * ns)) == 0;
-  if (!split) return encoder_run_range(e, x, layout, 0, B, feat, s, tm);
+  const int par = (int)(e->calls & 1);
+  e->calls++;
+  if (!split) {
+    // (a pipelined encoder: earlier calls may still run on the side streams and share the workspace)
+    if (e->pipelined) {
+      for (int h = 0; h < e->split_of[par ^ 1]; ++h) TN_HIP_CHECK(hipStreamWaitEvent(s, e->ev_done[par ^ 1][h], 0));
+      for (int h = 0; h < ns; ++h) TN_HIP_CHECK(hipStreamWaitEvent(s, e->ev_done[par][h], 0));   // (the call before that one)
+    }
+    e->split_of[par] = 0;
+    return encoder_run_range(e, x, layout, 0, B, feat, s, tm);
+  }
   TN_HIP_CHECK(hipEventRecord(e->ev_in, s));
   int rc = TN_OK;
   for (int h = 0; h < ns; ++h) {
     TN_HIP_CHECK(hipStreamWaitEvent(e->side[h], e->ev_in, 0));
     const int r = encoder_run_range(e, x, layout, h * (B / ns), B / ns, feat, e->side[h], tm);
     if (r) rc = r;
-    TN_HIP_CHECK(hipEventRecord(e->ev_done[h], e->side[h]));
-    TN_HIP_CHECK(hipStreamWaitEvent(s, e->ev_done[h], 0));
+    TN_HIP_CHECK(hipEventRecord(e->ev_done[par][h], e->side[h]));
+    // pipelined: the join is the caller's (tn_densenet121_join), so that the next call's first half can start beside
+    // the tail of this call's second half (the last chained block of a half batch runs on half of the CUs)
+    if (!e->pipelined) TN_HIP_CHECK(hipStreamWaitEvent(s, e->ev_done[par][h], 0));
   }
+  e->split_of[par] = ns;
   return rc;
+}
+
+static int encoder_join(tn_encoder *e, int lag) {
+  if (e->calls - 1 - lag < 0) return TN_OK;
+  const int par = (int)((e->calls - 1 - lag) & 1);
+  for (int h = 0; h < e->split_of[par]; ++h) TN_HIP_CHECK(hipStreamWaitEvent(e->ctx->stream, e->ev_done[par][h], 0));
+  return TN_OK;
+}
+
+extern "C" int tn_densenet121_set_pipelined(tn_encoder *enc, int on) {
+  TN_REQUIRE(enc, "tn_densenet121_set_pipelined: null handle");
+  TN_ON_DEVICE(enc->ctx->device);
+  if (enc->pipelined && !on) {            // leaving the mode: everything issued so far is joined
+    int rc = encoder_join(enc, 0);
+    if (rc == TN_OK) rc = encoder_join(enc, 1);
+    if (rc) return rc;
+  }
+  enc->pipelined = on != 0;
+  return TN_OK;
+}
+
+extern "C" int tn_densenet121_join(tn_encoder *enc, int lag) {
+  TN_REQUIRE(enc, "tn_densenet121_join: null handle");
+  TN_REQUIRE(lag == 0 || lag == 1, "tn_densenet121_join: lag must be 0 (the last forward) or 1 (the one before)");
+  TN_ON_DEVICE(enc->ctx->device);
+  return encoder_join(enc, lag);
 }
 
 extern "C" int tn_densenet121_forward(tn_encoder *enc, const void *x, tn_layout layout, int batch, float *feat) {
@@ -557,6 +600,7 @@ extern "C" int tn_densenet121_read_tap(tn_encoder *e, const char *tap_c, int bat
   const size_t px = (size_t)batch * hh * ww;
   *numel = px * cc;
   TN_REQUIRE(capacity >= *numel, "read_tap: host buffer too small");
+  if (int rc = encoder_join(e, 0)) return rc;
   TN_HIP_CHECK(hipStreamSynchronize(e->ctx->stream));
   std::vector<f16> tmp(px * ld);
   TN_HIP_CHECK(hipMemcpy(tmp.data(), src, tmp.size() * sizeof(f16), hipMemcpyDeviceToHost));
@@ -568,7 +612,7 @@ extern "C" int tn_densenet121_read_tap(tn_encoder *e, const char *tap_c, int bat
 extern "C" int tn_densenet121_destroy(tn_encoder *enc) {
   if (!enc) return TN_OK;
   TnDeviceGuard tn_dg_(enc->ctx->device);
-  for (int i = 0; i < 4; ++i) { (void)hipStreamSynchronize(enc->side[i]); (void)hipStreamDestroy(enc->side[i]); (void)hipEventDestroy(enc->ev_done[i]); }
+  for (int i = 0; i < 4; ++i) { (void)hipStreamSynchronize(enc->side[i]); (void)hipStreamDestroy(enc->side[i]); (void)hipEventDestroy(enc->ev_done[0][i]); (void)hipEventDestroy(enc->ev_done[1][i]); }
   (void)hipEventDestroy(enc->ev_in);
   enc->pool.release();
   delete enc;

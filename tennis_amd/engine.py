@@ -70,6 +70,15 @@ class DenseNet121Features:
         check(self.lib.tn_densenet121_forward(self.handle, ptr(x), layout, b, ptr(out)), "tn_densenet121_forward")
         return out
 
+    def set_pipelined(self, on: bool = True):
+        """Consecutive calls overlap on the library's side streams; the caller orders the results with ``join`` (see
+        ``tn_densenet121_set_pipelined`` in include/tennis_hip.h)."""
+        check(self.lib.tn_densenet121_set_pipelined(self.handle, 1 if on else 0), "tn_densenet121_set_pipelined")
+
+    def join(self, lag: int = 0):
+        """The context's stream waits for the last call (``lag=0``) or the one before it (``lag=1``)."""
+        check(self.lib.tn_densenet121_join(self.handle, lag), "tn_densenet121_join")
+
     def profile(self, x: torch.Tensor):
         """One forward with every launch bracketed by HIP events -> list of dicts."""
         x = x.contiguous()

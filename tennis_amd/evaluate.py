@@ -136,20 +136,46 @@ def extract_corpus(backbone, n_frames, batch, size, device, rank, world, block=4
     corpus = SyntheticCorpus(n_frames, size, device, seed)
     cached = {}
 
-    def encode(s, e):
+    def encode_input(s, e):
         if reuse_frames:
             if (e - s) not in cached:
                 cached[e - s] = corpus.frames(s, e)
-            x = cached[e - s]
-        else:
-            x = corpus.frames(s, e)
-        return backbone(x)
+            return cached[e - s]
+        return corpus.frames(s, e)
+
+    def encode(s, e):
+        return backbone(encode_input(s, e))
     fdim = int(backbone(corpus.frames(0, min(batch, n_frames))).shape[-1])      # also builds the engine (untimed)
+    # the HIP encoder runs consecutive batches pipelined (its two half-batch streams are joined once per gather round, not
+    # in every forward); a batch's frames stay referenced until that join
+    eng = getattr(backbone, "_engine", None)
+    pipelined = eng is not None and hasattr(eng, "set_pipelined") and device.type == "cuda"
+    live = []
+
+    def encode_into(s, e, rows):
+        x = encode_input(s, e)
+        if x.shape[0] <= eng.max_batch:
+            live.append(x)
+            eng(x, out=rows)
+        else:
+            rows.copy_(backbone(x))
+
+    def join():
+        eng.join(0)
+        eng.join(1)
+        live.clear()
     fence = (lambda: (torch.distributed.barrier() if world > 1 else None, torch.cuda.synchronize() if device.type == "cuda" else None))
     stats = {}
     fence()
     t0 = time.perf_counter()
-    full = sharding.extract_features_sharded(encode, n_frames, batch, fdim, device, rank=rank, world=world, block=block, stats=stats)
+    if pipelined:
+        eng.set_pipelined(True)
+    try:
+        full = sharding.extract_features_sharded(encode, n_frames, batch, fdim, device, rank=rank, world=world, block=block, stats=stats,
+                                                 encode_into=encode_into if pipelined else None, join=join if pipelined else None)
+    finally:
+        if pipelined:
+            eng.set_pipelined(False)
     fence()
     dt = time.perf_counter() - t0
     stats.update(seconds=dt, frames_per_sec=n_frames / dt, feature_dim=fdim,

@@ -129,10 +129,14 @@ def gather_feature_rows(shard: torch.Tensor, n_frames: int, batch: int, group=No
 
 
 def extract_features_sharded(encode_batch, n_frames: int, batch: int, feature_dim: int, device, rank=None,
-                             world=None, group=None, block: int = 1, stats: dict | None = None) -> torch.Tensor:
+                             world=None, group=None, block: int = 1, stats: dict | None = None,
+                             encode_into=None, join=None) -> torch.Tensor:
     """Run ``encode_batch(start, stop) -> (stop-start, F)`` over this rank's batches and all-gather the rows round by
     round, each round's collective in flight while the next round is encoded.  Returns the full (n_frames, F) matrix
-    on every rank.  ``stats`` (optional dict) receives ``rounds``, ``gather_bytes_per_rank`` and ``frames_local``."""
+    on every rank.  ``stats`` (optional dict) receives ``rounds``, ``gather_bytes_per_rank`` and ``frames_local``.
+    Pipelined encoders (``engine.DenseNet121Features.set_pipelined``): pass ``encode_into(start, stop, rows)`` - it
+    writes its features into ``rows`` without waiting for them - and ``join()``, which orders everything encoded so far
+    in front of what the current stream does next; it is called once per round, in front of the round's collective."""
     if rank is None:
         rank = _rank(group)
     if world is None:
@@ -150,8 +154,13 @@ def extract_features_sharded(encode_batch, n_frames: int, batch: int, feature_di
                 break
             e = min(n_frames, s + batch)
             r0 = c * rows + j * batch
-            shard[r0:r0 + (e - s)] = encode_batch(s, e)
+            if encode_into is not None:
+                encode_into(s, e, shard[r0:r0 + (e - s)])
+            else:
+                shard[r0:r0 + (e - s)] = encode_batch(s, e)
             done += e - s
+        if join is not None and (world > 1 or c == rounds - 1):
+            join()
         if world > 1:
             # rows [c*world*rows, (c+1)*world*rows) of the output = rank-major concatenation of this round's shard chunks
             pending.append(dist.all_gather_into_tensor(out[c * world * rows:(c + 1) * world * rows],

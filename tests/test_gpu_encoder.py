@@ -209,3 +209,34 @@ def test_batch_larger_than_handle_is_an_error():
     x = torch.zeros((3, 224, 224, 3), dtype=torch.float16, device="cuda")
     with pytest.raises(RuntimeError, match="max_batch"):
         enc(x)
+
+
+def test_pipelined_forwards_match_joined_ones():
+    """tn_densenet121_set_pipelined: consecutive forwards overlap on the side streams and the caller joins them - the
+    features are the ones the stream-ordered forwards give, for results consumed at once (lag 0) and one call behind"""
+    from tennis_amd import weights as W
+    from tennis_amd.engine import DenseNet121Features
+    p = W.make_densenet121_weights(0)
+    enc = DenseNet121Features(p, 224, max_batch=64)
+    xs = [torch.from_numpy(W.synthetic_frames_u8(64, 224, seed=s)).cuda() for s in range(4)]
+    ref = [enc(x).clone() for x in xs]
+    torch.cuda.synchronize()
+    enc.set_pipelined(True)
+    outs = [torch.empty_like(ref[0]) for _ in xs]
+    got = []
+    for i, x in enumerate(xs):
+        enc(x, out=outs[i])
+        if i > 0:
+            enc.join(1)
+            got.append(outs[i - 1].clone())         # on torch's stream, behind the join of call i-1
+    enc.join(0)
+    got.append(outs[-1].clone())
+    torch.cuda.synchronize()
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    small = enc(xs[0][:4])                           # an un-split call in the mode: ordered behind everything outstanding
+    enc.set_pipelined(False)
+    assert torch.equal(small, ref[0][:4]) or float((small - ref[0][:4]).abs().max()) < 1e-3
+    again = enc(xs[1])
+    torch.cuda.synchronize()
+    assert torch.equal(again, ref[1])
