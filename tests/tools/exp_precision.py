@@ -1,6 +1,6 @@
-"""Dev experiment: encoder error vs fp32 oracle with (a) fp32 weights, (b) fp16-representable conv weights."""
+"""Checker tool (imports oracle/, hence under tests/; not collected by pytest).  Dev experiment: encoder error vs fp32 oracle with (a) fp32 weights, (b) fp16-representable conv weights."""
 import sys, os, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from tennis_amd import weights as W
 from tennis_amd.engine import DenseNet121Features
