@@ -226,10 +226,26 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   f16x8 wq[3];
   // flat K loops: per-lane DMA source pointers of this wave's PPW pieces (advance by BK halfs per k-tile)
   const f16 *src[PPW];
+  // Which 1-KiB pieces of a stage a wave loads.  OWNX (every geometry but the 4 x 2 wave split of 7x7): first the pieces
+  // that hold the wave's OWN pixel rows, then its share of the weight pieces - a wave's fragment reads of the activations
+  // then depend on its own DMA only (its counted vmcnt orders them, no barrier), and the slot of those rows is refilled by
+  // the wave that read them.  At 28x28 (REBAL) waves 4-7 own three pieces each and take one of the four pieces past the
+  // tile's rows as their fourth.
+  constexpr bool OWNX = !G::NSPLIT && PP != 4 && BK == 32 && G::XPIECES % 8 == 0 && (G::XPIECES / 8) * RPP == BM / 8;   // (14x14, 64-channel stages: measured 2 % slower)
+  constexpr int XPW = G::XPIECES / 8;
+  auto piece_of = [&](int j) {
+    if constexpr (!OWNX) return wid * PPW + j;
+    else {
+      if (j >= XPW) return G::XPIECES + wid * (PPW - XPW) + (j - XPW);
+      if (REBAL) return wid < 4 ? 4 * wid + j : (j < 3 ? 16 + 3 * (wid - 4) + j : 28 + (wid - 4));
+      return wid * XPW + j;
+    }
+  };
+  auto is_x = [&](int j) { return OWNX ? j < XPW : wid * PPW + j < G::XPIECES; };
   auto set_src = [&](const f16 *xb, int ma, const f16 *w1p, int kv) {
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-      const int piece = wid * PPW + j;                 // wave-uniform
+      const int piece = piece_of(j);                   // wave-uniform
       const int prow = lane / CPR, p = lane % CPR;     // row inside the piece, linear chunk position
       if (piece < G::XPIECES) {
         const int row = piece * RPP + prow;
@@ -246,13 +262,13 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   auto advance = [&](int j, int sidx) {
     src[j] += BK;
     if constexpr (EX) {
-      if (sidx == nkc - 1 && wid * PPW + j < G::XPIECES) src[j] -= nkc * BK;
+      if (sidx == nkc - 1 && is_x(j)) src[j] -= nkc * BK;
     }
   };
   auto issue_pieces = [&](int st, int sidx, auto j0t, auto j1t) {
 #pragma unroll
     for (int j = decltype(j0t)::value; j < decltype(j1t)::value; ++j) {
-      dma16(src[j], lds0 + st * G::STAGE + (wid * PPW + j) * 1024);
+      dma16(src[j], lds0 + st * G::STAGE + piece_of(j) * 1024);
       advance(j, sidx);
     }
   };
@@ -392,15 +408,37 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   int st = 1;
   auto ktile = [&](int kt, auto younger_tag) {
     constexpr int YOUNGER = decltype(younger_tag)::value;
+    const unsigned char *Xs = smem + st * G::STAGE;
+    const unsigned char *Ws = Xs + G::XS;
+    auto kx = [&](int ks) { return ((EX && kt >= nkc) ? kt - nkc : kt) * BK + ks * 32; };   // first activation channel of a k-step
+    float4 ps0, ps1, pt0, pt1;                      // BatchNorm constants and pixel fragments of the stage's first k-step
+    u32x4 px[NF > 0 ? NF : 1];
+    auto read_tab_x = [&](int ks, float4 &s0, float4 &s1, float4 &t0, float4 &t1, u32x4 *xr) {
+      const int kb = kx(ks) + fch * 8;
+      s0 = *(const float4 *)(tab1 + kb); s1 = *(const float4 *)(tab1 + kb + 4);
+      t0 = *(const float4 *)(tab1 + G::KMAX + kb); t1 = *(const float4 *)(tab1 + G::KMAX + kb + 4);
+#pragma unroll
+      for (int mi = 0; mi < NF; ++mi) {
+        const int row = mrow0 + mi * 16 + frow;
+        xr[mi] = *(const u32x4 *)(Xs + row * ROWB + (stage_swz<BK>(row, ks * 4 + fch) << 4));
+      }
+    };
     wait_vmcnt<YOUNGER * PPW>();
+    // OWNX: this wave's pixel rows of the stage came through its own DMA pieces, which the wait above has retired: their
+    // fragments (and the constants) are requested BEFORE the barrier, so that behind it only the weight fragments are
+    // waited for (with all sixteen reads of all eight waves behind the barrier the matrix pipes idle until the LDS has
+    // served the lot)
+    constexpr bool PRE = OWNX && NF > 0 && !(TN_EXP & 16);
+    if constexpr (PRE) {
+      if (kx(0) < K) read_tab_x(0, ps0, ps1, pt0, pt1, px);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (kt == 0) DL_STAMP(1);
     const bool refill = !(TN_EXP & 32) && kt + 2 < nk;
     const int rslot = st >= 1 ? st - 1 : 2;         // slot (kt+2)%3, free since everyone passed the barrier
     if (!SPREAD && refill) issue(rslot, kt + 2);
-    const unsigned char *Xs = smem + st * G::STAGE;
-    const unsigned char *Ws = Xs + G::XS;
     constexpr int NG = (BK / 32) * MIW;             // refill groups of a stage: one per (k-step, fragment)
     auto refill_group = [&](int gi) {               // pieces [gi*PPW/NG, (gi+1)*PPW/NG) of the refill
       if constexpr (SPREAD) {
@@ -408,7 +446,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
 #pragma unroll
           for (int j = 0; j < PPW; ++j)
             if (j >= gi * PPW / NG && j < (gi + 1) * PPW / NG) {
-              dma16(src[j], lds0 + rslot * G::STAGE + (wid * PPW + j) * 1024);
+              dma16(src[j], lds0 + rslot * G::STAGE + piece_of(j) * 1024);
               advance(j, kt + 2);
             }
         }
@@ -419,21 +457,19 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
       if (TN_EXP & 16) {
         if (SPREAD && refill && ks == 0) issue(rslot, kt + 2);
       } else
-      if (((EX && kt >= nkc) ? kt - nkc : kt) * BK + ks * 32 < K) {
-        const int kb = ((EX && kt >= nkc) ? kt - nkc : kt) * BK + ks * 32 + fch * 8;   // activation channels of this k-step
+      if (kx(ks) < K) {
         if constexpr (NF > 0) {
-          const float4 s0 = *(const float4 *)(tab1 + kb), s1 = *(const float4 *)(tab1 + kb + 4);
-          const float4 t0 = *(const float4 *)(tab1 + G::KMAX + kb), t1 = *(const float4 *)(tab1 + G::KMAX + kb + 4);
-          const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-          const float sh[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+          float4 s0, s1, t0, t1;
           u32x4 xraw[NF];
           f16x8 wa[NI];
-          auto read_x = [&](int mi) {
-            const int row = mrow0 + mi * 16 + frow;
-            xraw[mi] = *(const u32x4 *)(Xs + row * ROWB + (stage_swz<BK>(row, ks * 4 + fch) << 4));
-          };
-          read_x(0);
-          __builtin_amdgcn_sched_barrier(0);      // constants and the first fragment first: BN(0) waits for five reads, not for all
+          if (PRE && ks == 0) {
+            s0 = ps0; s1 = ps1; t0 = pt0; t1 = pt1;
+#pragma unroll
+            for (int mi = 0; mi < NF; ++mi) xraw[mi] = px[mi];
+          } else {
+            read_tab_x(ks, s0, s1, t0, t1, xraw);
+            __builtin_amdgcn_sched_barrier(0);    // constants and pixel fragments first: BN(0) does not wait for the weights
+          }
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) {
             const int row = nch0 + ni * 16 + frow;
@@ -441,9 +477,8 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
             if (ni < 2) __builtin_amdgcn_sched_barrier(0);    // (the first MFMAs wait for these)
           }
           __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int mi = 1; mi < NF; ++mi) read_x(mi);
-          __builtin_amdgcn_sched_barrier(0);
+          const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+          const float sh[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
           u32x4 xb, xn;
 #pragma unroll
           for (int j = 0; j < 4; ++j) xb[j] = bn_relu2_mix(xraw[0][j], sc[2 * j], sc[2 * j + 1], sh[2 * j], sh[2 * j + 1]);
@@ -686,7 +721,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
       for (int st = 1; st <= (PP == 4 ? 3 : 2); ++st)       // (the pipelined loop keeps three k-tiles requested: slots 1, 2, 3)
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
-          dma16(src[j], lds0 + st * G::STAGE + (wid * PPW + j) * 1024);
+          dma16(src[j], lds0 + st * G::STAGE + piece_of(j) * 1024);
           src[j] += BK;
         }
       primed = true;
