@@ -202,6 +202,14 @@ def run(argv):
     repeats = 1 if args.single_region else max(1, -(-MIN_TOTAL_STEPS // args.steps))
     times = [timed_region(args.steps) for _ in range(repeats)]
     dt = float(np.median(times))
+    # for the record: the same K steps with every forward joined before it returns (one more fenced region, all ranks)
+    dt_joined = None
+    if pipelined and not args.single_region:
+        pipelined = False
+        enc.set_pipelined(False)
+        dt_joined = timed_region(args.steps)
+        enc.set_pipelined(True)
+        pipelined = True
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -253,7 +261,8 @@ def run(argv):
                                       "in the dense layers / transitions)") if args.exact_weights
                                      else "seeded random-init, conv weights fp16",
                           "timing": f"median of {repeats} fenced regions of exactly {args.steps} steps" + (", forwards pipelined (results joined one step behind, all joined before the closing fence)" if pipelined else ""),
-                          "region_ms": [round(t * 1e3, 2) for t in times]},
+                          "region_ms": [round(t * 1e3, 2) for t in times],
+                          "frames_per_sec_forwards_joined": (round(world * args.batch * args.steps / dt_joined, 1) if dt_joined else None)},
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, x, full=args.cpu_baseline_full)
