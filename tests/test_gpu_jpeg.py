@@ -212,3 +212,25 @@ def test_device_decode_random_sweep():
         out = dec.decode(files).cpu().numpy()
         for i, f in enumerate(files):
             assert np.array_equal(out[i], _pillow(f)), (h, w, kw, i)
+
+
+def test_evaluate_save_feats_from_jpeg_frames(tmp_path):
+    """``evaluate.py --save_feats`` on a dataset of JPEG frames on disk (reference evaluate.py:306-321 over the frames of
+    dataset.py:204): the driver's default route - device decode, two loader threads - writes the same .npy feature files as
+    the host-decode route"""
+    pytest.importorskip("PIL")
+    from test_cpu_input_side import _write_dataset
+    from tennis_amd import evaluate as ev
+    roots = []
+    for name, extra in (("dev", []), ("host", ["--decode", "host", "--num_workers", "0"])):
+        root = str(tmp_path / name)
+        _write_dataset(root, np.random.default_rng(21), n_frames=(10, 9), size=(96, 128))
+        assert ev.main(["--root", root, "--model_id", "0006", "--save_feats", "--batch_size", "4", "--split", "test"] + extra) == 0
+        roots.append(root)
+    files = []
+    for dp, _dn, fn in os.walk(os.path.join(roots[0], "features", "0006")):
+        files += [os.path.relpath(os.path.join(dp, f), roots[0]) for f in fn if f.endswith(".npy")]
+    assert len(files) == 19                                     # --save_feats covers every frame of the split's videos (10 + 9)
+    for f in files:
+        a, b = np.load(os.path.join(roots[0], f)), np.load(os.path.join(roots[1], f))
+        assert a.shape == (1024,) and a.dtype == np.float32 and np.array_equal(a, b), f
