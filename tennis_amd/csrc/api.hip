@@ -175,16 +175,17 @@ std::vector<f16> pack_conv3x3(const float *w) {
 namespace {
 
 // stem weights (64,3,7,7) -> MFMA A fragments [7 ky][4 nfrag][64 lanes][8]:
-// lane l: n = nf*16 + (l&15); k slot (l>>4)*8 + j -> x-tap kx = slot>>2, channel c = slot&3.
-std::vector<f16> pack_stem(const float *w) {
+// lane l: n = nf*16 + (l&15); k slot (l>>4)*8 + j -> x-tap kx = slot>>2, channel c = slot&3 (the eighth tap is zero);
+// zero_first: the zero tap comes first, kx = (slot>>2) - 1 (operand alignment of the fused stem + maxpool kernel).
+std::vector<f16> pack_stem(const float *w, bool zero_first) {
   std::vector<f16> p((size_t)7 * 4 * 64 * 8);
   for (int ky = 0; ky < 7; ++ky)
     for (int nf = 0; nf < 4; ++nf)
       for (int l = 0; l < 64; ++l)
         for (int j = 0; j < 8; ++j) {
-          const int n = nf * 16 + (l & 15), slot = (l >> 4) * 8 + j, kx = slot >> 2, c = slot & 3;
+          const int n = nf * 16 + (l & 15), slot = (l >> 4) * 8 + j, kx = (slot >> 2) - (zero_first ? 1 : 0), c = slot & 3;
           float v = 0.f;
-          if (kx < 7 && c < 3) v = w[(((size_t)n * 3 + c) * 7 + ky) * 7 + kx];
+          if (kx >= 0 && kx < 7 && c < 3) v = w[(((size_t)n * 3 + c) * 7 + ky) * 7 + kx];
           p[(((size_t)ky * 4 + nf) * 64 + l) * 8 + j] = (f16)v;
         }
   return p;
@@ -246,7 +247,7 @@ struct tn_encoder {
   int Hb[4], Wb[4];        // dense block spatial sizes
   int Cin[4], Cb[4];       // block input / total channels
   int PH, PW;
-  f16 *stem_wp;
+  f16 *stem_wp, *stem_wp_zf;
   float *stem_scale, *stem_shift;
   struct DenseLayer { float *s1, *t1; f16 *w1; float *s2, *t2; f16 *w3p; int cin; };
   std::vector<DenseLayer> layers[4];
@@ -326,7 +327,8 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
   {  // stem: conv0 + batchnorm0
     const float *w0 = pm.get(pre + "conv0_weight", 64 * 3 * 7 * 7);
     if (!w0 || !fold_bn(pm, pre + "batchnorm0", 64, s, t)) return fail(TN_ERR_MISSING);
-    e->stem_wp = e->pool.upload(pack_stem(w0));
+    e->stem_wp = e->pool.upload(pack_stem(w0, false));
+    e->stem_wp_zf = e->pool.upload(pack_stem(w0, true));
     e->stem_scale = e->pool.upload(s);
     e->stem_shift = e->pool.upload(t);
   }
@@ -412,7 +414,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
   f16 *bbuf[4];
   for (int b = 0; b < 4; ++b) bbuf[b] = e->blockbuf[b] + (size_t)b0 * e->Hb[b] * e->Wb[b] * e->Cb[b];
   {
-    StemArgs a{x, (int)layout, B, e->H, e->W, e->stem_wp, e->stem_scale, e->stem_shift, stem_out, e->Hs, e->Ws};
+    StemArgs a{x, (int)layout, B, e->H, e->W, e->stem_wp, e->stem_wp_zf, e->stem_scale, e->stem_shift, stem_out, e->Hs, e->Ws};
     const double px = fB * e->Hs * e->Ws;
     if (e->fuse) {
       tm.begin("stem_conv_bn_relu_maxpool", 2.0 * px * 64 * 147, fB * e->H * e->W * 3 * 2 + fB * e->Hb[0] * e->Wb[0] * 64 * 2);

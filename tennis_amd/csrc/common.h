@@ -183,6 +183,7 @@ struct StemArgs {
   int layout;         // tn_layout
   int B, H, W;        // input size
   const f16 *wp;      // packed A fragments [7 ky][4 nfrag][64 lanes][8]
+  const f16 *wp_zf;   // the same with the zero x-tap FIRST (k slot = (kx + 1) * 4 + c): fused stem + maxpool kernel
   const float *scale; // [64] folded BN scale
   const float *shift; // [64]
   f16 *y;             // [B][Ho][Wo][64]

@@ -1,20 +1,40 @@
 // K1 fused — stem Convolution 7x7/2 pad 3 (3 -> 64) + BatchNorm + ReLU + MaxPool 3x3/2 pad 1,
 // the first four operators of gluoncv's DenseNet .features (reference call site
 // models/vision/definitions.py:30).  The 112x112x64 conv map never goes
-// to HBM: a workgroup owns a 4 x 14 tile of POOLED pixels, computes the 9 x 32 conv pixels
-// under it (one halo row/column recomputed) on v_mfma_f32_16x16x32_f16, applies BN+ReLU in
-// fp32, parks the fp16 result in LDS and max-pools it from there straight into channels
-// [0,64) of dense block 1's concat buffer.  Post-ReLU values are >= 0, so out-of-range conv
-// positions (MaxPool pads with -inf) are represented by 0.
-// Operand layout as in stem.hip: one k-step per kernel row ky; the 32 k-slots are 8 x-taps x
-// 4 channels (tap 7 and channel 3 carry zero weights), so a lane's 8 values are 2 adjacent
+// to HBM: a tile is 4 x 14 POOLED pixels; the 9 x 32 conv pixels under it (one halo row / column
+// recomputed) run on v_mfma_f32_16x16x32_f16, BN is applied in fp32, the three conv rows of a
+// pooled row are max-ed in registers, the row maxima are parked in LDS and the horizontal 3-max
+// goes from there straight into channels [0,64) of dense block 1's concat buffer.  ReLU is
+// applied to the maximum (it commutes with max), so positions outside the conv map (MaxPool
+// pads with -inf) are represented by 0.
+//
+// The kernel is bound by instruction issue, not by the matrix pipe or by LDS / HBM (phase
+// stamps and knock-out builds): a 16-pass MFMA hides two single-issue VALU
+// instructions, everything beyond that adds its four issue cycles.  Hence
+//  * a wave owns one 16-column half of the conv tile for ALL nine conv rows and half of the
+//    output channels: patch row p feeds the conv rows r with ky = p - 2r in [0,7), so one
+//    16-byte operand read serves up to eight MFMAs (23 reads per tile instead of 63);
+//  * accumulators live in VGPRs (three waves per SIMD requested, so no AGPR copies), BN +
+//    fp16 conversion is one v_fma_mix per value, the vertical max is two v_pk_max_f16 per
+//    row half, border masking is a separate instantiation taken by border tiles only;
+//  * the patch is staged as aligned 64-byte blocks (the k-slot layout starts with the zero
+//    tap, which makes the operand reads 16-byte aligned at that offset);
+//  * workgroups are persistent over a contiguous range of tiles: weights and BN constants are
+//    loaded once, and the patch of the next tile is requested before the MFMAs of this one.
+// Operand layout: one k-step per kernel row ky; the 32 k-slots are 8 x-taps x 4 channels
+// (tap 0 and channel 3 carry zero weights: tap t' = kx + 1), so a lane's 8 values are 2 adjacent
 // NHWC4 pixels = one aligned ds_read_b128 of the staged input patch.
 #include <type_traits>
 
 #include "common.h"
 
-#ifndef TN_STEM_EXP
-#define TN_STEM_EXP 0   // timing experiments: bit 0 skip the conv fragments, bit 1 skip the pooling / store loop
+#ifdef TN_STEM_STAMPS
+__device__ unsigned long long tn_stem_acc[4096 * 16];
+#define ST_ADD(i, v) do { st_sum[i] += (unsigned long long)(v); } while (0)
+#define ST_NOW() __builtin_amdgcn_s_memtime()
+#else
+#define ST_ADD(i, v) do { } while (0)
+#define ST_NOW() 0ull
 #endif
 
 namespace {
@@ -22,9 +42,25 @@ namespace {
 constexpr int PR = 4, PC = 14;            // pooled tile
 constexpr int CR = 2 * PR + 1, CC = 32;   // conv tile (rows, cols; 29 of the 32 columns are needed)
 constexpr int IR = 2 * CR + 5;            // 23 input rows
-constexpr int IPITCH = 576;               // bytes per input patch row: 72 px * 8 B
-constexpr int CPX = 136;                  // bytes per conv pixel in LDS: 64 ch fp16 + 8 pad (bank spread)
-constexpr int NFRAG = CR * 2;             // 16-pixel fragments of the conv tile
+constexpr int IPX = 80;                   // patch row: input pixels ix0 - 3 ... ix0 + 76 (slot = pixel - (ix0 - 3))
+constexpr int IPITCH = IPX * 8;           // bytes per patch row (NHWC4 fp16)
+constexpr int CPX = 136;                  // bytes per pixel of the row-max tile: 64 ch fp16 + 8 pad (bank spread)
+constexpr int GPR = IPX / 8;              // 8-pixel groups per patch row (vector path)
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() would also wait for the global loads of the next patch
+// (in flight on purpose) and for the pooled-output stores to be acknowledged
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// packed fp16 max without the canonicalising max(x, x) the IEEE builtin puts in front of every operand
+__device__ __forceinline__ unsigned pk_max(unsigned x, unsigned y) {
+  unsigned d;
+  asm("v_pk_max_f16 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y));
+  return d;
+}
 
 // raw channel triple of one input pixel (address clamped by the caller, always in bounds)
 template <int LAY>
@@ -44,29 +80,36 @@ __device__ __forceinline__ void load_raw(const StemArgs &a, long pix, long plane
   }
 }
 
+struct Tile { int b, pr0, pc0; };
+
 // VEC (frame width a multiple of 8): the patch is fetched as aligned groups of 8 pixels per thread with
 // 16-byte (fp16 / f32) or 8-byte (u8) loads instead of one element per load.
 template <int LAY, bool VEC>
-__global__ __launch_bounds__(256) void stem_pool_kernel(StemArgs a, f16 *__restrict__ out, int ldy, int Hp, int Wp) {
+// three waves per SIMD where the staging registers allow it (fp16 / u8 vector path), two otherwise
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY != TN_LAYOUT_NCHW_F32) ? 3 : 2))) void stem_pool_kernel(
+    StemArgs a, f16 *__restrict__ out, int ldy, int Hp, int Wp, int nstrip, int ntc, int ntiles) {
   __shared__ __attribute__((aligned(16))) unsigned char patch[IR * IPITCH];
-  __shared__ __attribute__((aligned(16))) unsigned char ctile[CR * CC * CPX];
+  __shared__ __attribute__((aligned(16))) unsigned char vtile[PR * CC * CPX];
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-  const int b = blockIdx.z;
-  const int pr0 = blockIdx.y * PR;
-  const int cy0 = 2 * pr0 - 1;                           // conv row of the tile origin
-  const int iy0 = 2 * cy0 - 3;                           // input row of the patch origin
   const int pl = lane & 15, kc = lane >> 4;
-  const int ntc = (Wp + PC - 1) / PC;                    // column tiles walked by this workgroup
 
-  // a wave owns one half of the output channels (n-fragments 2*nh, 2*nh+1): its 14 weight fragments and BN
-  // constants stay in registers for the whole row strip (all four n-fragments would cost 112 VGPRs and a
-  // third of the occupancy); the other half of each pixel fragment belongs to the partner wave
-  const int nh = wid & 1;
+  // this workgroup's contiguous range of tiles; tile f -> (frame, strip of 4 pooled rows, column tile)
+  const int per = ntiles / (int)gridDim.x, rem = ntiles % (int)gridDim.x;
+  int f = (int)blockIdx.x * per + ((int)blockIdx.x < rem ? (int)blockIdx.x : rem);
+  const int fend = f + per + ((int)blockIdx.x < rem ? 1 : 0);
+  auto tile_of = [&](int i) {
+    const int b = i / (nstrip * ntc), r = i - b * (nstrip * ntc), st = r / ntc;
+    return Tile{b, st * PR, (r - st * ntc) * PC};
+  };
+
+  // a wave owns one half of the output channels (n-fragments 2*nh, 2*nh+1) and one 16-column half of the conv
+  // tile (ch): its 14 weight fragments and BN constants stay in registers for all of its tiles
+  const int nh = wid & 1, ch = wid >> 1;
   f16x8 wa[7][2];
 #pragma unroll
   for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
-    for (int nf = 0; nf < 2; ++nf) wa[ky][nf] = ((const f16x8 *)a.wp)[(ky * 4 + 2 * nh + nf) * 64 + lane];
+    for (int nf = 0; nf < 2; ++nf) wa[ky][nf] = ((const f16x8 *)a.wp_zf)[(ky * 4 + 2 * nh + nf) * 64 + lane];
   float sc[2][4], sh[2][4];
 #pragma unroll
   for (int nf = 0; nf < 2; ++nf)
@@ -76,35 +119,34 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(StemArgs a, f16 *__restr
       sh[nf][r] = a.shift[(2 * nh + nf) * 16 + kc * 4 + r];
     }
 
-  // input patch staging, split in two halves so the loads of tile ct+1 fly during the MFMAs of
-  // tile ct: request (clamped addresses, all loads issued back to back) / commit (zero what lies
-  // outside the frame, write NHWC4 fp16 to LDS)
-  constexpr int NPX = (IR * 72 + 255) / 256;    // 7 pixels per thread (element-wise path)
-  constexpr int GPR = 10;                        // 8-pixel groups per patch row (vector path): px [ix0-3, ix0+77)
+  // input patch staging, split in two halves so the loads of the next tile fly during the MFMAs of this one:
+  // request (clamped addresses, all loads issued back to back) / commit (zero what lies outside the frame, write
+  // NHWC4 fp16 to LDS)
+  constexpr int NPX = (IR * IPX + 255) / 256;   // 8 pixels per thread (element-wise path)
   constexpr int NQ = LAY == TN_LAYOUT_NCHW_F32 ? 6 : 3;   // 16-B (8-B for u8) loads per group
   float raw[VEC ? 1 : NPX][3];
   uint4 vq[VEC ? NQ : 1];
   const long plane = (long)a.H * a.W;
   const int vpr = t / GPR, vg = t - vpr * GPR;   // vector path: this thread's patch row and group
-  auto request = [&](int ct) {
-    const int ix0 = 2 * (2 * ct * PC - 1) - 3;
+  auto request = [&](const Tile &tl) {
+    const int iy0 = 2 * (2 * tl.pr0 - 1) - 3, gx0 = 2 * (2 * tl.pc0 - 1) - 6;   // patch origin (row, first staged pixel)
     if constexpr (VEC) {
-      // ix0 = 56 ct - 5: the groups start at the 8-aligned pixel ix0 - 3 (the frame width is a multiple of 8,
-      // so a group lies entirely inside or entirely outside the frame)
-      const int iy = iy0 + vpr, gx = ix0 - 3 + 8 * vg;
+      // gx0 = 4 pc0 - 8 is a multiple of 8 (pc0 is a multiple of 14) and so is the frame width: a group lies
+      // entirely inside or entirely outside the frame
+      const int iy = iy0 + vpr, gx = gx0 + 8 * vg;
       const int cy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy), cx = gx < 0 ? 0 : (gx > a.W - 8 ? a.W - 8 : gx);
       if (t < IR * GPR) {
         if constexpr (LAY == TN_LAYOUT_NHWC_F16) {
-          const uint4 *src = (const uint4 *)((const f16 *)a.x + (((long)b * a.H + cy) * a.W + cx) * 3);
+          const uint4 *src = (const uint4 *)((const f16 *)a.x + (((long)tl.b * a.H + cy) * a.W + cx) * 3);
           vq[0] = src[0]; vq[1] = src[1]; vq[2] = src[2];
         } else if constexpr (LAY == TN_LAYOUT_NHWC_U8) {
-          const uint2 *src = (const uint2 *)((const uint8_t *)a.x + (((long)b * a.H + cy) * a.W + cx) * 3);
+          const uint2 *src = (const uint2 *)((const uint8_t *)a.x + (((long)tl.b * a.H + cy) * a.W + cx) * 3);
           const uint2 q0 = src[0], q1 = src[1], q2 = src[2];
           vq[0] = make_uint4(q0.x, q0.y, q1.x, q1.y); vq[1] = make_uint4(q2.x, q2.y, 0, 0);
         } else {
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            const uint4 *src = (const uint4 *)((const float *)a.x + ((long)b * 3 + c) * plane + (long)cy * a.W + cx);
+            const uint4 *src = (const uint4 *)((const float *)a.x + ((long)tl.b * 3 + c) * plane + (long)cy * a.W + cx);
             vq[2 * c] = src[0]; vq[2 * c + 1] = src[1];
           }
         }
@@ -114,135 +156,204 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(StemArgs a, f16 *__restr
 #pragma unroll
     for (int i = 0; i < (VEC ? 0 : NPX); ++i) {
       const int p = t + 256 * i;
-      const int pr = p / 72, pc = p - pr * 72;
-      const int iy = iy0 + pr, ix = ix0 + pc;
+      const int pr = p / IPX, pc = p - pr * IPX;
+      const int iy = iy0 + pr, ix = gx0 + pc;
       const int cy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy), cx = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
-      const long pix = LAY == TN_LAYOUT_NCHW_F32 ? (long)b * 3 * plane + (long)cy * a.W + cx
-                                                  : ((long)b * a.H + cy) * a.W + cx;
+      const long pix = LAY == TN_LAYOUT_NCHW_F32 ? (long)tl.b * 3 * plane + (long)cy * a.W + cx
+                                                  : ((long)tl.b * a.H + cy) * a.W + cx;
       load_raw<LAY>(a, pix, plane, raw[i]);
     }
   };
-  auto commit = [&](int ct) {
-    const int ix0 = 2 * (2 * ct * PC - 1) - 3;
+  auto commit = [&](const Tile &tl) {
+    const int iy0 = 2 * (2 * tl.pr0 - 1) - 3, gx0 = 2 * (2 * tl.pc0 - 1) - 6;
     if constexpr (VEC) {
-      const int iy = iy0 + vpr, gx = ix0 - 3 + 8 * vg;
+      const int iy = iy0 + vpr, gx = gx0 + 8 * vg;
       const bool in = (unsigned)iy < (unsigned)a.H && gx >= 0 && gx <= a.W - 8;
-      f16 v[8][3];
+      unsigned o[16];                              // 8 NHWC4 pixels: {c0 c1} {c2 0}
       if constexpr (LAY == TN_LAYOUT_NHWC_F16) {
-        const f16x8 h0 = __builtin_bit_cast(f16x8, vq[0]), h1 = __builtin_bit_cast(f16x8, vq[1]), h2 = __builtin_bit_cast(f16x8, vq[2]);
+        // 24 packed halves d[0..12) -> pixel i starts at half 3i: even pixels are dword-aligned, odd ones straddle
+        const unsigned d[12] = {vq[0].x, vq[0].y, vq[0].z, vq[0].w, vq[1].x, vq[1].y, vq[1].z, vq[1].w,
+                                vq[2].x, vq[2].y, vq[2].z, vq[2].w};
 #pragma unroll
-        for (int i = 0; i < 24; ++i) v[i / 3][i % 3] = i < 8 ? h0[i] : (i < 16 ? h1[i - 8] : h2[i - 16]);
-      } else if constexpr (LAY == TN_LAYOUT_NHWC_U8) {
-        const unsigned w[6] = {vq[0].x, vq[0].y, vq[0].z, vq[0].w, vq[1].x, vq[1].y};
-        const float mean[3] = {0.485f, 0.456f, 0.406f}, sdev[3] = {0.229f, 0.224f, 0.225f};
-#pragma unroll
-        for (int i = 0; i < 24; ++i) {
-          const float u = (float)((w[i >> 2] >> ((i & 3) * 8)) & 255u);
-          // ToTensor (/255) then Normalize (mean,std) -- reference evaluate.py:96-97 (same arithmetic as load_raw)
-          v[i / 3][i % 3] = (f16)((u / 255.0f - mean[i % 3]) / sdev[i % 3]);
+        for (int i = 0; i < 8; i += 2) {
+          const int e = 3 * i / 2;                 // dword of half 3i
+          o[2 * i] = d[e];
+          o[2 * i + 1] = d[e + 1] & 0xffffu;
+          o[2 * i + 2] = __builtin_amdgcn_alignbit(d[e + 2], d[e + 1], 16);
+          o[2 * i + 3] = d[e + 2] >> 16;
         }
       } else {
+        f16 v[8][3];
+        if constexpr (LAY == TN_LAYOUT_NHWC_U8) {
+          const unsigned w[6] = {vq[0].x, vq[0].y, vq[0].z, vq[0].w, vq[1].x, vq[1].y};
+          const float mean[3] = {0.485f, 0.456f, 0.406f}, sdev[3] = {0.229f, 0.224f, 0.225f};
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float f[8] = {__builtin_bit_cast(float, vq[2 * c].x), __builtin_bit_cast(float, vq[2 * c].y),
-                              __builtin_bit_cast(float, vq[2 * c].z), __builtin_bit_cast(float, vq[2 * c].w),
-                              __builtin_bit_cast(float, vq[2 * c + 1].x), __builtin_bit_cast(float, vq[2 * c + 1].y),
-                              __builtin_bit_cast(float, vq[2 * c + 1].z), __builtin_bit_cast(float, vq[2 * c + 1].w)};
+          for (int i = 0; i < 24; ++i) {
+            const float u = (float)((w[i >> 2] >> ((i & 3) * 8)) & 255u);
+            // ToTensor (/255) then Normalize (mean,std) -- reference evaluate.py:96-97 (same arithmetic as load_raw)
+            v[i / 3][i % 3] = (f16)((u / 255.0f - mean[i % 3]) / sdev[i % 3]);
+          }
+        } else {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) v[i][c] = (f16)f[i];
+          for (int c = 0; c < 3; ++c) {
+            const float fl[8] = {__builtin_bit_cast(float, vq[2 * c].x), __builtin_bit_cast(float, vq[2 * c].y),
+                                 __builtin_bit_cast(float, vq[2 * c].z), __builtin_bit_cast(float, vq[2 * c].w),
+                                 __builtin_bit_cast(float, vq[2 * c + 1].x), __builtin_bit_cast(float, vq[2 * c + 1].y),
+                                 __builtin_bit_cast(float, vq[2 * c + 1].z), __builtin_bit_cast(float, vq[2 * c + 1].w)};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i][c] = (f16)fl[i];
+          }
         }
-      }
-      if (t < IR * GPR) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const int q = 8 * vg - 3 + i;          // patch pixel index (0 = ix0)
-          f16x4 o = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-          if (in) { o[0] = v[i][0]; o[1] = v[i][1]; o[2] = v[i][2]; }
-          if (q >= 0 && q < 72) *(f16x4 *)(patch + vpr * IPITCH + q * 8) = o;
+          const f16x4 px = {v[i][0], v[i][1], v[i][2], (f16)0.f};
+          const uint2 u = __builtin_bit_cast(uint2, px);
+          o[2 * i] = u.x; o[2 * i + 1] = u.y;
         }
+      }
+      // wave-uniform test first: interior tiles (most of them) take no selects
+      const bool border = iy0 < 0 || iy0 + IR > a.H || gx0 < 0 || gx0 + IPX > a.W;
+      if (border) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[i] = in ? o[i] : 0u;
+      }
+      if (t < IR * GPR) {
+        uint4 *dst = (uint4 *)(patch + vpr * IPITCH + vg * 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
       }
       return;
     }
 #pragma unroll
     for (int i = 0; i < (VEC ? 0 : NPX); ++i) {
       const int p = t + 256 * i;
-      const int pr = p / 72, pc = p - pr * 72;
-      const int iy = iy0 + pr, ix = ix0 + pc;
+      const int pr = p / IPX, pc = p - pr * IPX;
+      const int iy = iy0 + pr, ix = gx0 + pc;
       const bool in = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
       f16x4 v;
       v[0] = in ? (f16)raw[i][0] : (f16)0.f;
       v[1] = in ? (f16)raw[i][1] : (f16)0.f;
       v[2] = in ? (f16)raw[i][2] : (f16)0.f;
       v[3] = (f16)0.f;
-      if (p < IR * 72) *(f16x4 *)(patch + pr * IPITCH + pc * 8) = v;
+      if (p < IR * IPX) *(f16x4 *)(patch + pr * IPITCH + pc * 8) = v;
     }
   };
 
-  request(0);
-  commit(0);
-  __syncthreads();
-  for (int ct = 0; ct < ntc; ++ct) {
-    const int pc0 = ct * PC, cx0 = 2 * pc0 - 1;
-    if (ct + 1 < ntc) request(ct + 1);
-    // conv + BN + ReLU -> LDS; wave pair p = wid>>1 takes the pixel fragments p, p+2, ..., three at a time so that
-    // the patch reads of one kernel row hide behind the MFMAs of the previous one
-    auto conv_frags = [&](auto nft, int fa, int fb, int fc) {
-      constexpr int NFR = decltype(nft)::value;
-      const int fr[3] = {fa, fb, fc};
-      f32x4 acc[NFR][2];
+  // horizontal 3-max + store: item = (pooled row, pooled column, 8-channel group); 448 items, two rounds.  The item
+  // geometry does not depend on the tile: LDS offset and output offset (relative to the tile's first pixel) are fixed
+  int p_lds[2], p_pr[2], p_pc[2];
+  long p_out[2];
 #pragma unroll
-      for (int q = 0; q < NFR; ++q)
-#pragma unroll
-        for (int nf = 0; nf < 2; ++nf) acc[q][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ky = 0; ky < 7; ++ky) {
-        f16x8 xb[NFR];
-#pragma unroll
-        for (int q = 0; q < NFR; ++q) {
-          const int r = fr[q] >> 1, c = (fr[q] & 1) * 16 + pl;
-          xb[q] = *(const f16x8 *)(patch + (2 * r + ky) * IPITCH + (c + kc) * 16);
-        }
-#pragma unroll
-        for (int q = 0; q < NFR; ++q)
-#pragma unroll
-          for (int nf = 0; nf < 2; ++nf) acc[q][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ky][nf], xb[q], acc[q][nf], 0, 0, 0);
-      }
-#pragma unroll
-      for (int q = 0; q < NFR; ++q) {
-        const int r = fr[q] >> 1, c = (fr[q] & 1) * 16 + pl;          // conv row / column inside the tile
-        const bool valid = (unsigned)(cy0 + r) < (unsigned)a.Ho && (unsigned)(cx0 + c) < (unsigned)a.Wo;
-        unsigned char *dst = ctile + (r * CC + c) * CPX + kc * 8 + nh * 64;
-#pragma unroll
-        for (int nf = 0; nf < 2; ++nf) {
-          f16x4 h;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) h[j] = (f16)fmaxf(fmaf(acc[q][nf][j], sc[nf][j], sh[nf][j]), 0.f);
-          if (!valid) h = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-          *(f16x4 *)(dst + nf * 32) = h;
-        }
-      }
-    };
-    if (!(TN_STEM_EXP & 1)) {
-      static_assert(NFRAG == 18, "9 fragments per wave pair = 3 triples");
-      for (int f = wid >> 1; f < NFRAG; f += 6) conv_frags(std::integral_constant<int, 3>{}, f, f + 2, f + 4);
-    }
-    __syncthreads();                      // conv tile complete; nobody reads the patch any more
-    if (ct + 1 < ntc) commit(ct + 1);
-    // 3x3/2 max pool out of LDS: one (pooled pixel, 4-channel group) per work item
-    for (int id = t; id < ((TN_STEM_EXP & 2) ? 0 : PR * PC * 16); id += 256) {
-      const int pp = id >> 4, cg = id & 15;
-      const int pr = pp / PC, pc = pp - pr * PC;
-      if (pr0 + pr >= Hp || pc0 + pc >= Wp) continue;
-      f16x4 o = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};      // packed fp16 max (exact: values are fp16 already)
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
-          o = __builtin_elementwise_max(o, *(const f16x4 *)(ctile + ((2 * pr + dy) * CC + 2 * pc + dx) * CPX + cg * 8));
-      *(f16x4 *)(out + (((long)b * Hp + pr0 + pr) * Wp + pc0 + pc) * ldy + cg * 4) = o;
-    }
-    __syncthreads();                      // pooling done before the next tile overwrites ctile
+  for (int k = 0; k < 2; ++k) {
+    const int id = t + 256 * k, pr = id / (PC * 8), r2 = id - pr * (PC * 8), pc = r2 >> 3, cg = r2 & 7;
+    p_pr[k] = id < PR * PC * 8 ? pr : 1 << 20;            // out of range: never valid
+    p_pc[k] = pc;
+    p_lds[k] = (pr * CC + 2 * pc) * CPX + cg * 16;
+    p_out[k] = ((long)pr * Wp + pc) * ldy + cg * 8;
   }
+
+  [[maybe_unused]] unsigned long long st_sum[9] = {};
+  [[maybe_unused]] const unsigned long long st_begin = ST_NOW();
+  if (f >= fend) return;
+  Tile cur = tile_of(f);
+  request(cur);
+  commit(cur);
+  __syncthreads();
+  ST_ADD(0, ST_NOW() - st_begin);
+  for (; f < fend; ++f) {
+    [[maybe_unused]] const unsigned long long st0 = ST_NOW();
+    const bool more = f + 1 < fend;
+    const Tile nxt = tile_of(more ? f + 1 : f);
+    if (more) request(nxt);
+    const int cy0 = 2 * cur.pr0 - 1, cx0 = 2 * cur.pc0 - 1;     // conv coordinates of the tile origin
+
+    // conv + BN -> vertical max -> LDS
+    auto conv_tile = [&](auto border_tag) {
+      constexpr bool BORDER = decltype(border_tag)::value;
+      f32x4 acc[CR][2];
+#pragma unroll
+      for (int r = 0; r < CR; ++r)
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) acc[r][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const unsigned char *prow = patch + (ch * 16 + pl + kc + 1) * 16;
+      const int c = ch * 16 + pl;
+      const bool cvalid = (unsigned)(cx0 + c) < (unsigned)a.Wo;
+      unsigned m[2][2];                             // running maximum of the pooled row in progress, per channel fragment
+      // conv row r (complete after patch row 2r + 6): BN in fp32, fp16, max into the pooled rows it belongs to
+      // (r = 2 pr + {0,1,2}); an even row closes pooled row r/2 - 1 (ReLU on the maximum, then LDS) and opens row r/2
+      auto finish_half = [&](int r, int nf) {
+        // fp32 fma, one rounding to fp16: one v_fma_mix per value (left to itself the compiler SLP-packs pairs into
+        // v_pk_fma_f32 + moves + converts, twice the instructions)
+        uint2 u;
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3" : "=&v"(u.x) : "v"(acc[r][nf][0]), "v"(sc[nf][0]), "v"(sh[nf][0]));
+        asm("v_fma_mixhi_f16 %0, %1, %2, %3" : "+v"(u.x) : "v"(acc[r][nf][1]), "v"(sc[nf][1]), "v"(sh[nf][1]));
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3" : "=&v"(u.y) : "v"(acc[r][nf][2]), "v"(sc[nf][2]), "v"(sh[nf][2]));
+        asm("v_fma_mixhi_f16 %0, %1, %2, %3" : "+v"(u.y) : "v"(acc[r][nf][3]), "v"(sc[nf][3]), "v"(sh[nf][3]));
+        if constexpr (BORDER) {
+          const bool valid = cvalid && (unsigned)(cy0 + r) < (unsigned)a.Ho;
+          u.x = valid ? u.x : 0u; u.y = valid ? u.y : 0u;
+        }
+        if (r == 0) { m[nf][0] = u.x; m[nf][1] = u.y; return; }
+        const unsigned x = pk_max(m[nf][0], u.x), y = pk_max(m[nf][1], u.y);
+        if (r & 1) { m[nf][0] = x; m[nf][1] = y; return; }
+        *(uint2 *)(vtile + ((r / 2 - 1) * CC + c) * CPX + nh * 64 + nf * 32 + kc * 8) = make_uint2(pk_max(x, 0u), pk_max(y, 0u));
+        m[nf][0] = u.x; m[nf][1] = u.y;
+      };
+      // operand ring of three: the read of patch row p + 2 is requested before the MFMAs of row p are issued (the
+      // compiler would otherwise place every read right in front of its first consumer and wait for it)
+      f16x8 xb[3];
+      xb[0] = *(const f16x8 *)(prow);
+      xb[1] = *(const f16x8 *)(prow + IPITCH);
+#pragma unroll
+      for (int p = 0; p < IR; ++p) {
+        if (p + 2 < IR) xb[(p + 2) % 3] = *(const f16x8 *)(prow + (p + 2) * IPITCH);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < CR; ++r) {
+          const int ky = p - 2 * r;
+          if (ky >= 0 && ky < 7) {
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) acc[r][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ky][nf], xb[p % 3], acc[r][nf], 0, 0, 0);
+          }
+        }
+        // the two channel fragments of a finished row go one and two patch rows later, between the MFMAs in flight
+        if (p >= 7 && (p - 7) / 2 < CR) finish_half((p - 7) >> 1, (p - 7) & 1);
+      }
+      finish_half(CR - 1, 0);
+      finish_half(CR - 1, 1);
+    };
+    // positions outside the conv map occur in tiles on the frame border only (c <= 28 is what the pooling reads)
+    const bool border = cy0 < 0 || cy0 + CR > a.Ho || cx0 < 0 || cx0 + 29 > a.Wo;
+    if (border) conv_tile(std::true_type{}); else conv_tile(std::false_type{});
+    [[maybe_unused]] const unsigned long long st1 = ST_NOW();
+    lds_barrier();                        // row maxima complete; nobody reads the patch any more
+    [[maybe_unused]] const unsigned long long st2 = ST_NOW();
+    if (more) commit(nxt);
+    [[maybe_unused]] const unsigned long long st3 = ST_NOW();
+    f16 *obase = out + (((long)cur.b * Hp + cur.pr0) * Wp + cur.pc0) * ldy;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (cur.pr0 + p_pr[k] < Hp && cur.pc0 + p_pc[k] < Wp) {
+        const uint4 q0 = *(const uint4 *)(vtile + p_lds[k]), q1 = *(const uint4 *)(vtile + p_lds[k] + CPX),
+                    q2 = *(const uint4 *)(vtile + p_lds[k] + 2 * CPX);
+        uint4 o;
+        o.x = pk_max(pk_max(q0.x, q1.x), q2.x); o.y = pk_max(pk_max(q0.y, q1.y), q2.y);
+        o.z = pk_max(pk_max(q0.z, q1.z), q2.z); o.w = pk_max(pk_max(q0.w, q1.w), q2.w);
+        *(uint4 *)(obase + p_out[k]) = o;
+      }
+    }
+    [[maybe_unused]] const unsigned long long st4 = ST_NOW();
+    lds_barrier();                        // pooling done before the next tile overwrites the row maxima
+    ST_ADD(1, st1 - st0); ST_ADD(2, st2 - st1); ST_ADD(3, st3 - st2); ST_ADD(4, st4 - st3); ST_ADD(5, ST_NOW() - st4);
+    ST_ADD(7, 1);
+    cur = nxt;
+  }
+#ifdef TN_STEM_STAMPS
+  if (t == 0) {
+    st_sum[6] = ST_NOW() - st_begin;
+    for (int i = 0; i < 9; ++i) tn_stem_acc[(blockIdx.x & 4095) * 16 + i] = st_sum[i];
+  }
+#endif
 }
 
 }  // namespace
@@ -250,12 +361,26 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(StemArgs a, f16 *__restr
 // conv output (Ho,Wo) is implied by a.Ho/a.Wo; pooled output (Hp,Wp) = ((Ho-1)/2+1, (Wo-1)/2+1)
 int launch_stem_pool(const StemArgs &a, f16 *out, int ldy, int Hp, int Wp, hipStream_t s) {
   TN_REQUIRE(a.layout >= 0 && a.layout <= 2, "stem: unknown input layout");
-  TN_REQUIRE(ldy % 4 == 0, "stem: output stride must be a multiple of 4");
-  const dim3 grid(1, (Hp + PR - 1) / PR, a.B), block(256);   // a workgroup walks one strip of 4 pooled rows
+  TN_REQUIRE(ldy % 8 == 0, "stem: output stride must be a multiple of 8");
+  TN_REQUIRE(a.wp_zf != nullptr, "stem: packed weights missing");
+  static int slots = 0;
+  if (!slots) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    TN_HIP_CHECK(hipGetDevice(&dev));
+    TN_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    slots = 3 * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);   // three workgroups per CU (registers)
+    if (getenv("TN_STEM_WGS")) slots = atoi(getenv("TN_STEM_WGS"));               // tuning hook
+  }
+  const int nstrip = (Hp + PR - 1) / PR, ntc = (Wp + PC - 1) / PC;
+  const long nt = (long)a.B * nstrip * ntc;
+  TN_REQUIRE(nt > 0 && nt < (1l << 31), "stem: tile count out of range");
+  const int ntiles = (int)nt;
+  const dim3 grid(ntiles < slots ? ntiles : slots), block(256);   // persistent: a workgroup walks a contiguous range of tiles
   static const bool novec = getenv("TN_STEM_NOVEC") != nullptr;   // tuning hook
   const bool vec = (a.W % 8 == 0) && a.W >= 80 && !novec;
-#define TN_STEM(L) do { if (vec) hipLaunchKernelGGL((stem_pool_kernel<L, true>), grid, block, 0, s, a, out, ldy, Hp, Wp); \
-                        else hipLaunchKernelGGL((stem_pool_kernel<L, false>), grid, block, 0, s, a, out, ldy, Hp, Wp); } while (0)
+#define TN_STEM(L) do { if (vec) hipLaunchKernelGGL((stem_pool_kernel<L, true>), grid, block, 0, s, a, out, ldy, Hp, Wp, nstrip, ntc, ntiles); \
+                        else hipLaunchKernelGGL((stem_pool_kernel<L, false>), grid, block, 0, s, a, out, ldy, Hp, Wp, nstrip, ntc, ntiles); } while (0)
   if (a.layout == TN_LAYOUT_NCHW_F32) TN_STEM(TN_LAYOUT_NCHW_F32);
   else if (a.layout == TN_LAYOUT_NHWC_F16) TN_STEM(TN_LAYOUT_NHWC_F16);
   else TN_STEM(TN_LAYOUT_NHWC_U8);
@@ -263,3 +388,11 @@ int launch_stem_pool(const StemArgs &a, f16 *out, int ldy, int Hp, int Wp, hipSt
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;
 }
+
+#ifdef TN_STEM_STAMPS
+extern "C" int tn_dbg_stem_stamps(unsigned long long *out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(tn_stem_acc), sizeof(unsigned long long) * 4096 * 16) != hipSuccess) return -1;
+  if (reset) { static unsigned long long z[4096 * 16]; if (hipMemcpyToSymbol(HIP_SYMBOL(tn_stem_acc), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
