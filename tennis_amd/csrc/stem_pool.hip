@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
   float raw[VEC ? 1 : NPX][3];
   uint4 vq[VEC ? NQ : 1];
   const long plane = (long)a.H * a.W;
-  const int vpr = t / GPR, vg = t - vpr * GPR;   // vector path: this thread's patch row and group
+  const int vg = t % GPR, vpr = t / GPR < IR ? t / GPR : IR - 1;   // vector path: this thread's patch row and group
   auto request = [&](const Tile &tl) {
     const int iy0 = 2 * (2 * tl.pr0 - 1) - 3, gx0 = 2 * (2 * tl.pc0 - 1) - 6;   // patch origin (row, first staged pixel)
     if constexpr (VEC) {
@@ -135,20 +135,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
       // entirely inside or entirely outside the frame
       const int iy = iy0 + vpr, gx = gx0 + 8 * vg;
       const int cy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy), cx = gx < 0 ? 0 : (gx > a.W - 8 ? a.W - 8 : gx);
-      if (t < IR * GPR) {
-        if constexpr (LAY == TN_LAYOUT_NHWC_F16) {
-          const uint4 *src = (const uint4 *)((const f16 *)a.x + (((long)tl.b * a.H + cy) * a.W + cx) * 3);
-          vq[0] = src[0]; vq[1] = src[1]; vq[2] = src[2];
-        } else if constexpr (LAY == TN_LAYOUT_NHWC_U8) {
-          const uint2 *src = (const uint2 *)((const uint8_t *)a.x + (((long)tl.b * a.H + cy) * a.W + cx) * 3);
-          const uint2 q0 = src[0], q1 = src[1], q2 = src[2];
-          vq[0] = make_uint4(q0.x, q0.y, q1.x, q1.y); vq[1] = make_uint4(q2.x, q2.y, 0, 0);
-        } else {
+      // unconditional (the 26 threads past the patch repeat its last row, and the last tile of a workgroup is requested
+      // twice): loads under a branch reach commit() through PHI copies, which the compiler places - with their
+      // s_waitcnt - right behind the loads, and the prefetch is gone
+      if constexpr (LAY == TN_LAYOUT_NHWC_F16) {
+        const uint4 *src = (const uint4 *)((const f16 *)a.x + (((long)tl.b * a.H + cy) * a.W + cx) * 3);
+        vq[0] = src[0]; vq[1] = src[1]; vq[2] = src[2];
+      } else if constexpr (LAY == TN_LAYOUT_NHWC_U8) {
+        const uint2 *src = (const uint2 *)((const uint8_t *)a.x + (((long)tl.b * a.H + cy) * a.W + cx) * 3);
+        const uint2 q0 = src[0], q1 = src[1], q2 = src[2];
+        vq[0] = make_uint4(q0.x, q0.y, q1.x, q1.y); vq[1] = make_uint4(q2.x, q2.y, 0, 0);
+      } else {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const uint4 *src = (const uint4 *)((const float *)a.x + ((long)tl.b * 3 + c) * plane + (long)cy * a.W + cx);
-            vq[2 * c] = src[0]; vq[2 * c + 1] = src[1];
-          }
+        for (int c = 0; c < 3; ++c) {
+          const uint4 *src = (const uint4 *)((const float *)a.x + ((long)tl.b * 3 + c) * plane + (long)cy * a.W + cx);
+          vq[2 * c] = src[0]; vq[2 * c + 1] = src[1];
         }
       }
       return;
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
     [[maybe_unused]] const unsigned long long st0 = ST_NOW();
     const bool more = f + 1 < fend;
     const Tile nxt = tile_of(more ? f + 1 : f);
-    if (more) request(nxt);
+    request(nxt);                         // (the last tile once more: see request)
     const int cy0 = 2 * cur.pr0 - 1, cx0 = 2 * cur.pc0 - 1;     // conv coordinates of the tile origin
 
     // conv + BN -> vertical max -> LDS
@@ -281,14 +282,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
       unsigned m[2][2];                             // running maximum of the pooled row in progress, per channel fragment
       // conv row r (complete after patch row 2r + 6): BN in fp32, fp16, max into the pooled rows it belongs to
       // (r = 2 pr + {0,1,2}); an even row closes pooled row r/2 - 1 (ReLU on the maximum, then LDS) and opens row r/2
-      auto finish_half = [&](int r, int nf) {
-        // fp32 fma, one rounding to fp16: one v_fma_mix per value (left to itself the compiler SLP-packs pairs into
-        // v_pk_fma_f32 + moves + converts, twice the instructions)
+      // TAIL: the row's MFMAs were the last ones issued.  The hazard recogniser does not count wait states in front of
+      // inline asm that reads an MFMA result (seen as garbage in the low halves of the last pooled row), so the two tail
+      // calls convert through plain C++; everywhere else at least three MFMAs lie between a row's last MFMA and its BN
+      auto finish_half = [&](int r, int nf, auto tail_tag) {
         uint2 u;
-        asm("v_fma_mixlo_f16 %0, %1, %2, %3" : "=&v"(u.x) : "v"(acc[r][nf][0]), "v"(sc[nf][0]), "v"(sh[nf][0]));
-        asm("v_fma_mixhi_f16 %0, %1, %2, %3" : "+v"(u.x) : "v"(acc[r][nf][1]), "v"(sc[nf][1]), "v"(sh[nf][1]));
-        asm("v_fma_mixlo_f16 %0, %1, %2, %3" : "=&v"(u.y) : "v"(acc[r][nf][2]), "v"(sc[nf][2]), "v"(sh[nf][2]));
-        asm("v_fma_mixhi_f16 %0, %1, %2, %3" : "+v"(u.y) : "v"(acc[r][nf][3]), "v"(sc[nf][3]), "v"(sh[nf][3]));
+        if constexpr (decltype(tail_tag)::value) {
+          f16x4 h;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) h[j] = (f16)fmaf(acc[r][nf][j], sc[nf][j], sh[nf][j]);
+          u = __builtin_bit_cast(uint2, h);
+        } else {
+          // fp32 fma, one rounding to fp16: one v_fma_mix per value (left to itself the compiler SLP-packs pairs into
+          // v_pk_fma_f32 + moves + converts, twice the instructions)
+          asm("v_fma_mixlo_f16 %0, %1, %2, %3" : "=&v"(u.x) : "v"(acc[r][nf][0]), "v"(sc[nf][0]), "v"(sh[nf][0]));
+          asm("v_fma_mixhi_f16 %0, %1, %2, %3" : "+v"(u.x) : "v"(acc[r][nf][1]), "v"(sc[nf][1]), "v"(sh[nf][1]));
+          asm("v_fma_mixlo_f16 %0, %1, %2, %3" : "=&v"(u.y) : "v"(acc[r][nf][2]), "v"(sc[nf][2]), "v"(sh[nf][2]));
+          asm("v_fma_mixhi_f16 %0, %1, %2, %3" : "+v"(u.y) : "v"(acc[r][nf][3]), "v"(sc[nf][3]), "v"(sh[nf][3]));
+        }
         if constexpr (BORDER) {
           const bool valid = cvalid && (unsigned)(cy0 + r) < (unsigned)a.Ho;
           u.x = valid ? u.x : 0u; u.y = valid ? u.y : 0u;
@@ -317,10 +328,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
           }
         }
         // the two channel fragments of a finished row go one and two patch rows later, between the MFMAs in flight
-        if (p >= 7 && (p - 7) / 2 < CR) finish_half((p - 7) >> 1, (p - 7) & 1);
+        if (p >= 7 && (p - 7) / 2 < CR) finish_half((p - 7) >> 1, (p - 7) & 1, std::false_type{});
       }
-      finish_half(CR - 1, 0);
-      finish_half(CR - 1, 1);
+      finish_half(CR - 1, 0, std::true_type{});
+      finish_half(CR - 1, 1, std::true_type{});
     };
     // positions outside the conv map occur in tiles on the frame border only (c <= 28 is what the pooling reads)
     const bool border = cy0 < 0 || cy0 + CR > a.Ho || cx0 < 0 || cx0 + 29 > a.Wo;
