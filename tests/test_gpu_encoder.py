@@ -132,6 +132,34 @@ def test_encoder_512_features_4096(report):
     assert err < TOL
 
 
+@pytest.mark.parametrize("size", [226, 232, 236])
+def test_stem_and_encoder_at_odd_input_sizes(size, report):
+    """Input sizes off the 224 grid: 232 has partial tiles in both directions (58 x 58 pooled pixels), 236 is not a
+    multiple of 8 wide (element-wise patch staging instead of the vector path), 226 has an odd conv map (113 x 113: the
+    last pooled row / column reaches past it).  Fused stem + maxpool output (tap pool0) and the final features against
+    the numpy oracle, for the three input layouts."""
+    from tennis_amd import weights as W
+    from tennis_amd.engine import DenseNet121Features
+    p = W.make_densenet121_weights(0)
+    frames = W.synthetic_frames_u8(1, size)
+    x16 = W.normalize_to_nchw_f32(frames).astype(np.float16)
+    taps = {}
+    ref = dn.densenet121_features(x16.astype(np.float32), p, taps=taps)
+    enc = DenseNet121Features(p, size, max_batch=1)
+    inputs = {"nhwc_f16": torch.from_numpy(np.ascontiguousarray(x16.transpose(0, 2, 3, 1))).cuda(),
+              "nchw_f32": torch.from_numpy(x16.astype(np.float32)).cuda(),
+              "nhwc_u8": torch.from_numpy(frames).cuda()}
+    for name, x in inputs.items():
+        feat = enc(x).cpu().numpy()
+        pool0 = enc.read_tap("pool0", 1).reshape(taps["pool0"].shape)
+        e0 = float(np.abs(pool0 - taps["pool0"]).max())
+        e = float(np.abs(feat - ref).max())
+        report[f"stem_{size}_{name}_pool0_maxabs_err"] = e0
+        report[f"features_{size}_{name}_maxabs_err"] = e
+        assert e0 < 8e-3, (name, e0)          # fp16 storage of values up to ~8: half an ulp is 4e-3
+        assert e < (5e-3 if name == "nhwc_u8" else TOL), (name, e)
+
+
 def test_full_batch_256_matches_small_batches(report):
     """BASELINE.json configs[1] size (256 frames: two-stream split, XCD-remapped persistent tiles, chained blocks):
     every frame's features must equal, bit for bit, what the same frame gives in a batch of 4 (un-split, one tile
