@@ -37,7 +37,8 @@ constexpr int smem_bytes() {
 // the pixel tile again and repeats its BN+ReLU+average, so wider tiles cut both)
 // EX (exact-weights mode): w = hi + lo as two fp16 numbers, rows [hi (K) | lo (K)]; the k-tile loop
 // runs over 2 K, the activation side (and its BatchNorm constants) wrapping around after the hi half.
-template <int MI, bool POOL, int NB, bool EX = false>
+// ONCE (a transition with a single column tile): the activations are read exactly once, through non-temporal loads.
+template <int MI, bool POOL, int NB, bool EX = false, bool ONCE = false>
 __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
   constexpr int BM = 32 * MI;
   constexpr int NSRC = POOL ? 4 : 1;
@@ -114,7 +115,14 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s) xr[i][s] = *(const f16x8 *)(xsrc[i][s] + kc);
+        for (int s = 0; s < NSRC; ++s) {
+          // a transition with ONE column tile reads every activation exactly once: non-temporal loads (no L2 / MALL
+          // allocation) stream 17 % faster there (92 -> 76 us for the first transition); with two column tiles the second
+          // one lives on the lines the first one left in L2, and the hint costs 3 us.  (Compile-time: under a run-time
+          // condition the compiler merges the two loads into a plain one.)
+          if constexpr (ONCE) xr[i][s] = __builtin_nontemporal_load((const f16x8 *)(xsrc[i][s] + kc));
+          else xr[i][s] = *(const f16x8 *)(xsrc[i][s] + kc);
+        }
 #pragma unroll
       for (int i = 0; i < NI; ++i) wr[i] = *(const f16x8 *)(wsrc + (long)(32 * i) * WLD + kw);
     }
@@ -231,8 +239,20 @@ int launch_conv1x1(const Conv1x1Args &a, hipStream_t s) {
       TN_REQUIRE(a.K % 64 == 0, "conv1x1: the exact-weights mode needs K % 64 == 0");
       if (wide) hipLaunchKernelGGL((conv1x1_kernel<2, true, 256, true>), grid, block, 0, s, a);
       else hipLaunchKernelGGL((conv1x1_kernel<2, true, 128, true>), grid, block, 0, s, a);
-    } else if (wide) hipLaunchKernelGGL((conv1x1_kernel<2, true, 256>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((conv1x1_kernel<2, true, 128>), grid, block, 0, s, a);
+    } else {
+      // non-temporal activation loads: one column tile (every byte is read once) AND a buffer too large to be found in
+      // the 256 MB MALL.  Measured at 256 frames in one launch: transition 1 (411 MB) 92 -> 76 us; transition 2 (205 MB,
+      // partly served by the MALL after the layers that wrote it) 52 -> 53.5 us with the hint.  The encoder runs two
+      // half batches side by side (2 x 205 MB for transition 1): threshold 128 MB, +0.5 ... 1 % end to end against no
+      // hint (same-box A/B; 64 MB and 256 MB are in between)
+      static const bool no_nt = getenv("TN_TRANS_NO_NT") != nullptr;   // A/B runs
+      static const size_t nt_mb = getenv("TN_TRANS_NT_MB") ? (size_t)atoi(getenv("TN_TRANS_NT_MB")) : 128;   // tuning hook
+      const bool stream = NT == 1 && !no_nt && (size_t)a.M * 4 * a.ldx * sizeof(f16) > (nt_mb << 20);
+      if (wide && stream) hipLaunchKernelGGL((conv1x1_kernel<2, true, 256, false, true>), grid, block, 0, s, a);
+      else if (wide) hipLaunchKernelGGL((conv1x1_kernel<2, true, 256>), grid, block, 0, s, a);
+      else if (stream) hipLaunchKernelGGL((conv1x1_kernel<2, true, 128, false, true>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((conv1x1_kernel<2, true, 128>), grid, block, 0, s, a);
+    }
   } else if (a.M >= 128 * 512) {
     const dim3 grid((a.M + 127) / 128, a.N / BN_TILE);
     hipLaunchKernelGGL((conv1x1_kernel<4, false, 128>), grid, block, 0, s, a);
