@@ -74,43 +74,46 @@ __device__ __forceinline__ f16x8 bn_relu8(f16x8 v, const float *__restrict__ s, 
   return r;
 }
 
-// Same result (fp32 fma, one rounding, ReLU) in 12 VALU instructions instead of 20: v_fma_mixlo/mixhi_f16
-// take the fp16 element straight from the packed register, multiply-add in fp32 and round once into the
-// destination half; the ReLU runs on packed halves (max(round(f), 0) == round(max(f, 0))).
+// Same result (fp32 fma, one rounding, ReLU) with the instructions that issue fastest (scripts/scratch/valubench.hip, ns per
+// wave-instruction and SIMD at two waves: v_fma_f32 1.2, v_fma_mix_f32 / v_cvt_pk_f16_f32 / v_pk_max_f16 2.0,
+// v_fma_mixlo/hi_f16 3.6 - 4.2 plus a wait state after every partial write).  fp16 in: v_fma_mix_f32 takes the element
+// straight from the packed register; the pair is rounded by one v_cvt_pk_f16_f32 and the ReLU runs on packed halves
+// (max(round(f), 0) == round(max(f, 0))): 4 instructions / 8.0 ns per dword against 3 / 10.2 ns through mixlo + mixhi.
+__device__ __forceinline__ unsigned bn_relu2_mix(unsigned in, float s0, float s1, float t0, float t1) {
+  float a0, a1;
+  unsigned d, o;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(a0) : "v"(in), "v"(s0), "v"(t0));
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(a1) : "v"(in), "v"(s1), "v"(t1));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d) : "v"(a0), "v"(a1));
+  asm("v_pk_max_f16 %0, %1, 0" : "=v"(o) : "v"(d));
+  return o;
+}
+
 __device__ __forceinline__ f16x8 bn_relu8_mix(f16x8 v, const float *__restrict__ s, const float *__restrict__ t) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const u32x4 in = __builtin_bit_cast(u32x4, v);
   u32x4 out;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    unsigned d;
-    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=&v"(d) : "v"(in[j]), "v"(s[2 * j]), "v"(t[2 * j]));
-    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(in[j]), "v"(s[2 * j + 1]), "v"(t[2 * j + 1]));
-    asm("v_pk_max_f16 %0, %1, 0" : "=v"(out[j]) : "v"(d));
-  }
+  for (int j = 0; j < 4; ++j) out[j] = bn_relu2_mix(in[j], s[2 * j], s[2 * j + 1], t[2 * j], t[2 * j + 1]);
   return __builtin_bit_cast(f16x8, out);
 }
 
-// one packed pair of bn_relu8_mix (3 VALU): element j of the fragment's four dwords
-__device__ __forceinline__ unsigned bn_relu2_mix(unsigned in, float s0, float s1, float t0, float t1) {
-  unsigned d, o;
-  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=&v"(d) : "v"(in), "v"(s0), "v"(t0));
-  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(in), "v"(s1), "v"(t1));
-  asm("v_pk_max_f16 %0, %1, 0" : "=v"(o) : "v"(d));
-  return o;
-}
-
-// relu(acc*s+t) for 4 fp32 accumulators -> 4 fp16 (fp32 fma, one rounding, packed ReLU): 6 VALU instead of 10.
+// relu(acc*s+t) for 4 fp32 accumulators -> 4 fp16 (fp32 fma, one rounding, packed ReLU): 4 v_fma_f32 + 2 v_cvt_pk_f16_f32 +
+// 2 v_pk_max_f16 = 12.9 ns against 18.3 ns for 4 v_fma_mixlo/hi_f16 + 2 v_pk_max_f16 (inline asm: left to itself the
+// compiler SLP-packs the fmas and pays for it in moves).
 __device__ __forceinline__ f16x4 bn_relu4_from_f32(f32x4 v, float4 s, float4 t) {
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  float a0, a1, a2, a3;
   unsigned d0, d1;
-  asm("v_fma_mixlo_f16 %0, %1, %2, %3" : "=&v"(d0) : "v"(v[0]), "v"(s.x), "v"(t.x));
-  asm("v_fma_mixhi_f16 %0, %1, %2, %3" : "+v"(d0) : "v"(v[1]), "v"(s.y), "v"(t.y));
-  asm("v_fma_mixlo_f16 %0, %1, %2, %3" : "=&v"(d1) : "v"(v[2]), "v"(s.z), "v"(t.z));
-  asm("v_fma_mixhi_f16 %0, %1, %2, %3" : "+v"(d1) : "v"(v[3]), "v"(s.w), "v"(t.w));
-  u32x2 o;
-  asm("v_pk_max_f16 %0, %1, 0" : "=v"(o[0]) : "v"(d0));
-  asm("v_pk_max_f16 %0, %1, 0" : "=v"(o[1]) : "v"(d1));
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(a0) : "v"(v[0]), "v"(s.x), "v"(t.x));
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(a1) : "v"(v[1]), "v"(s.y), "v"(t.y));
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(a2) : "v"(v[2]), "v"(s.z), "v"(t.z));
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(a3) : "v"(v[3]), "v"(s.w), "v"(t.w));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d0) : "v"(a0), "v"(a1));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d1) : "v"(a2), "v"(a3));
+  asm("v_pk_max_f16 %0, %0, 0" : "+v"(d0));
+  asm("v_pk_max_f16 %0, %0, 0" : "+v"(d1));
+  const u32x2 o = {d0, d1};
   return __builtin_bit_cast(f16x4, o);
 }
 

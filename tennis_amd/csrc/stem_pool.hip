@@ -15,7 +15,7 @@
 //    output channels: patch row p feeds the conv rows r with ky = p - 2r in [0,7), so one
 //    16-byte operand read serves up to eight MFMAs (23 reads per tile instead of 63);
 //  * accumulators live in VGPRs (three waves per SIMD requested, so no AGPR copies), BN +
-//    fp16 conversion is one v_fma_mix per value, the vertical max is two v_pk_max_f16 per
+//    fp16 conversion is v_fma_f32 + v_cvt_pk_f16_f32 by hand, the vertical max is two v_pk_max_f16 per
 //    row half, border masking is a separate instantiation taken by border tiles only;
 //  * the patch is staged as aligned 64-byte blocks (the k-slot layout starts with the zero
 //    tap, which makes the operand reads 16-byte aligned at that offset);
@@ -293,12 +293,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
           for (int j = 0; j < 4; ++j) h[j] = (f16)fmaf(acc[r][nf][j], sc[nf][j], sh[nf][j]);
           u = __builtin_bit_cast(uint2, h);
         } else {
-          // fp32 fma, one rounding to fp16: one v_fma_mix per value (left to itself the compiler SLP-packs pairs into
-          // v_pk_fma_f32 + moves + converts, twice the instructions)
-          asm("v_fma_mixlo_f16 %0, %1, %2, %3" : "=&v"(u.x) : "v"(acc[r][nf][0]), "v"(sc[nf][0]), "v"(sh[nf][0]));
-          asm("v_fma_mixhi_f16 %0, %1, %2, %3" : "+v"(u.x) : "v"(acc[r][nf][1]), "v"(sc[nf][1]), "v"(sh[nf][1]));
-          asm("v_fma_mixlo_f16 %0, %1, %2, %3" : "=&v"(u.y) : "v"(acc[r][nf][2]), "v"(sc[nf][2]), "v"(sh[nf][2]));
-          asm("v_fma_mixhi_f16 %0, %1, %2, %3" : "+v"(u.y) : "v"(acc[r][nf][3]), "v"(sc[nf][3]), "v"(sh[nf][3]));
+          // fp32 fma, one rounding to fp16: four v_fma_f32 + two v_cvt_pk_f16_f32 (9 ns per SIMD; four v_fma_mixlo/hi_f16
+          // would be 14, and left to itself the compiler SLP-packs pairs into v_pk_fma_f32 + moves + converts)
+          float b0, b1, b2, b3;
+          asm("v_fma_f32 %0, %1, %2, %3" : "=v"(b0) : "v"(acc[r][nf][0]), "v"(sc[nf][0]), "v"(sh[nf][0]));
+          asm("v_fma_f32 %0, %1, %2, %3" : "=v"(b1) : "v"(acc[r][nf][1]), "v"(sc[nf][1]), "v"(sh[nf][1]));
+          asm("v_fma_f32 %0, %1, %2, %3" : "=v"(b2) : "v"(acc[r][nf][2]), "v"(sc[nf][2]), "v"(sh[nf][2]));
+          asm("v_fma_f32 %0, %1, %2, %3" : "=v"(b3) : "v"(acc[r][nf][3]), "v"(sc[nf][3]), "v"(sh[nf][3]));
+          asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u.x) : "v"(b0), "v"(b1));
+          asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u.y) : "v"(b2), "v"(b3));
         }
         if constexpr (BORDER) {
           const bool valid = cvalid && (unsigned)(cy0 + r) < (unsigned)a.Ho;
