@@ -569,6 +569,17 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     unsigned char *wdst[MIW];
 #pragma unroll
     for (int mi = 0; mi < MIW; ++mi) wdst[mi] = ok[mi] ? dst[mi] : tile + G::DUMP_SLOT * 256;
+#ifndef TN_OLD_SWZ
+    // the store address of channel group ni is the one of group 0 with bits 5..7 flipped by ni: the group's chunk
+    // (nch0 >> 3) + 2 ni + (fch >> 1) has ni in bits 1..2(3) and nothing else there, the swizzle XORs those same bits, and
+    // the slot base (256-byte aligned tile, 256-byte slots, + 0 / 8) has zeros in bits 4..7 - one v_xor per store instead
+    // of an or + a shift-add
+    const int chunk0 = (nch0 >> 3) + (fch >> 1);
+    typedef __attribute__((address_space(3))) unsigned char *lds_bytes;   // (an integer XOR on a generic pointer would end in flat stores)
+    unsigned wb0[MIW];
+#pragma unroll
+    for (int mi = 0; mi < MIW; ++mi) wb0[mi] = (unsigned)(size_t)(lds_bytes)(wdst[mi] + ((chunk0 ^ sl15[mi]) << 4));
+#endif
     float4 sv = *(const float4 *)(tab2 + nch0 + fch * 4), tv = *(const float4 *)(tab2 + 128 + nch0 + fch * 4);
 #pragma unroll
     for (int ni = 0; ni < ((TN_EXP & 4) ? 0 : NI); ++ni) {
@@ -578,11 +589,15 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
         tn = *(const float4 *)(tab2 + 128 + nch0 + (ni + 1) * 16 + fch * 4);
       }
       __builtin_amdgcn_sched_barrier(0);
-      const int chunk = (nch0 >> 3) + ni * 2 + (fch >> 1);   // channels n>>3
+      [[maybe_unused]] const int chunk = (nch0 >> 3) + ni * 2 + (fch >> 1);   // channels n>>3
 #pragma unroll
       for (int mi = 0; mi < MIW; ++mi) {
         const f16x4 hv = bn_relu4_from_f32(acc[ni][mi], sv, tv);
+#ifndef TN_OLD_SWZ
+        *(__attribute__((address_space(3))) f16x4 *)(size_t)(wb0[mi] ^ (unsigned)(ni << 5)) = hv;
+#else
         *(f16x4 *)(wdst[mi] + ((chunk ^ sl15[mi]) << 4)) = hv;
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);
       sv = sn;
