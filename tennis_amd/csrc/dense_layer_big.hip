@@ -96,12 +96,15 @@ __device__ __forceinline__ int stage_swz(int row, int chunk) {
 // tap with dx = +-1 - put two lane pairs of each group on the same banks (2-way: 8 LDS cycles per read instead of 4,
 // SQ_LDS_BANK_CONFLICT = 27 % of SQ_LDS_IDX_ACTIVE).  Leaving bit 0 of the chunk alone and folding slot bits 0-2 into
 // chunk bits 1-3 is conflict-free for every start slot, k-step and lane group (exhaustive search over the GF(2)-linear
-// maps, scripts/lds_swizzle_search.py); the price is a 2-way conflict on epilogue A's ds_write_b64 (slots s, s+8).
-#ifdef TN_OLD_SWZ
-__device__ __forceinline__ int tile_swz(int slot) { return slot & 15; }
-#else
-__device__ __forceinline__ int tile_swz(int slot) { return (slot & 7) << 1; }
-#endif
+// maps, scripts/lds_swizzle_search.py); the price is paid by epilogue A's ds_write_b64: a 16-lane store group then covers
+// only four of the eight chunk positions.
+// ALL16 = the first form, `chunk ^ (slot & 15)`: 2-way on the epilogue's stores (153 B/ns/CU in scripts/scratch/ldsstore.hip
+// against 76 for the second form, 195 for contiguous stores) but two lane pairs per group collide in the dx = +-1 taps.
+// Measured per geometry (r2-g, phase stamps and rocprof on one box): at 56x56 the first form wins (epilogue A 5 270 -> 3 970
+// cycles per tile, phase B 11 310 -> 12 160, kernel -1.7 %) and at 28x28 too (-1.1 %); the chained 14x14 block is 0.6 %
+// faster with the second form, the 7x7 block does not care.
+template <bool ALL16>
+__device__ __forceinline__ int tile_swz(int slot) { return ALL16 ? (slot & 15) : ((slot & 7) << 1); }
 
 // One LDS-DMA piece: 64 lanes x 16 B, global (per-lane address) -> LDS (wave-uniform base
 // + lane*16).  Issued through inline asm on purpose: hipcc treats the builtin as an LDS
@@ -141,6 +144,11 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   constexpr int WP = G::WP, TR = G::TR, MIW = G::MIW, NI = G::NI;
   static_assert(PP != 4 || (G::NSPLIT && BK == 64), "the software-pipelined K loop is built for the 7x7 geometry");
   constexpr int ROWB = G::ROWB, PPW = G::PPW, RPP = G::RPP, CPR = ROWB / 16;  // chunks per row
+#ifdef TN_SWZ16_ALL
+  constexpr bool SWZ16 = TN_SWZ16_ALL != 0;
+#else
+  constexpr bool SWZ16 = W >= 28;                // tile swizzle form, see tile_swz
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *tile = smem;                   // bottleneck tile (aliases the DMA ring)
   unsigned char *ring = smem + G::W3RING;       // 3x3 weight ring: slots 0, 1 here, slot 2 at W3SLOT2
@@ -560,7 +568,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
       const int rr = m / W, x = m - rr * W;
       const int slot = (rr + top_pad) * WP + x + 1;
       dst[mi] = tile + slot * 256 + (fch & 1) * 8;
-      sl15[mi] = tile_swz(slot);
+      sl15[mi] = tile_swz<SWZ16>(slot);
       ok[mi] = m < MA && mi < nfw;
     }
     // rows past the tile (edge tiles, the last wave): their stores go to a slot of the tile's slack instead of being masked
@@ -569,9 +577,8 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     unsigned char *wdst[MIW];
 #pragma unroll
     for (int mi = 0; mi < MIW; ++mi) wdst[mi] = ok[mi] ? dst[mi] : tile + G::DUMP_SLOT * 256;
-#ifndef TN_OLD_SWZ
     // the store address of channel group ni is the one of group 0 with bits 5..7 flipped by ni: the group's chunk
-    // (nch0 >> 3) + 2 ni + (fch >> 1) has ni in bits 1..2(3) and nothing else there, the swizzle XORs those same bits, and
+    // (nch0 >> 3) + 2 ni + (fch >> 1) has ni in bits 1..2(3) and nothing else there (so + is ^ and the swizzle's XOR commutes), and
     // the slot base (256-byte aligned tile, 256-byte slots, + 0 / 8) has zeros in bits 4..7 - one v_xor per store instead
     // of an or + a shift-add
     const int chunk0 = (nch0 >> 3) + (fch >> 1);
@@ -579,7 +586,6 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     unsigned wb0[MIW];
 #pragma unroll
     for (int mi = 0; mi < MIW; ++mi) wb0[mi] = (unsigned)(size_t)(lds_bytes)(wdst[mi] + ((chunk0 ^ sl15[mi]) << 4));
-#endif
     float4 sv = *(const float4 *)(tab2 + nch0 + fch * 4), tv = *(const float4 *)(tab2 + 128 + nch0 + fch * 4);
 #pragma unroll
     for (int ni = 0; ni < ((TN_EXP & 4) ? 0 : NI); ++ni) {
@@ -593,11 +599,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
 #pragma unroll
       for (int mi = 0; mi < MIW; ++mi) {
         const f16x4 hv = bn_relu4_from_f32(acc[ni][mi], sv, tv);
-#ifndef TN_OLD_SWZ
         *(__attribute__((address_space(3))) f16x4 *)(size_t)(wb0[mi] ^ (unsigned)(ni << 5)) = hv;
-#else
-        *(f16x4 *)(wdst[mi] + ((chunk ^ sl15[mi]) << 4)) = hv;
-#endif
       }
       __builtin_amdgcn_sched_barrier(0);
       sv = sn;
@@ -648,7 +650,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
 #pragma unroll
       for (int j = 0; j < NFR; ++j) {
         const int slot = off + 16 * j;
-        xf[j] = *(const f16x8 *)(tile + slot * 256 + ((chunk ^ tile_swz(slot)) << 4));
+        xf[j] = *(const f16x8 *)(tile + slot * 256 + ((chunk ^ tile_swz<SWZ16>(slot)) << 4));
       }
     };
     auto load_w = [&](f16x8 *wf, int tap, int kk) {
