@@ -218,8 +218,12 @@ def run(argv):
         # on (separate instrumented passes, so the timed region above carries no events)
         fams = {}
         NPROF = 3
+        for _ in range(2):
+            enc.profile(x)        # (settle: the instrumented pass runs the whole batch on one stream, the timed region did not)
         for _ in range(NPROF):
             stats, _ = enc.profile(x)
+            if os.environ.get("TN_BENCH_DEBUG"):
+                print("profile pass:", {s["name"][:24]: round(s["ms"] / max(1, s["launches"]) * 1e3, 1) for s in stats}, file=sys.stderr)
             for s in stats:
                 a = fams.setdefault(s["name"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
                 a["ms"] += s["ms"]; a["flops"] += s["flops"]; a["bytes"] += s["bytes"]; a["launches"] += s["launches"]

@@ -1,7 +1,7 @@
 """Turn rocprofv3 CSV output (gpurun_out/prof_*) into the summaries committed under profiles/.
 
 usage: python scripts/summarize_profiles.py <tag>        e.g.  r01_d
-  gpurun_out/prof_stats/**/*kernel_stats.csv      -> profiles/<tag>_kernel_stats_bench_steps5.csv
+  gpurun_out/prof_stats/**/*kernel_stats.csv      -> profiles/<tag>_kernel_stats_bench_steps100.csv
   gpurun_out/prof_fetch|prof_write/**/*counter_collection.csv -> profiles/<tag>_pmc_traffic.json
 PMC units and the gfx950 correction follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE
 are KB per dispatch; FETCH_SIZE counts 64 B per 128-B request -> hbm_bytes = (2*FETCH + WRITE) * 1024.
@@ -17,7 +17,7 @@ def newest(pattern):
 tag = sys.argv[1]
 st = newest("gpurun_out/prof_stats/**/*kernel_stats.csv")
 if st:
-    shutil.copy(st[0], f"profiles/{tag}_kernel_stats_bench_steps5.csv")
+    shutil.copy(st[0], f"profiles/{tag}_kernel_stats_bench_steps100.csv")
 
 
 def family(name):
