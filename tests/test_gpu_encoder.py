@@ -84,6 +84,31 @@ def test_determinism(setup):
     assert np.array_equal(a, b)
 
 
+def test_repeatable_bit_for_bit_under_load():
+    """Timing-dependent faults (a missing wait state, a race on an LDS ring slot) show up as run-to-run differences
+    long before they show up against a tolerance: 256 frames through the split, pipelined encoder thirty times, other
+    work queued in between, every run bit-identical to the first - features and the fused stem's output."""
+    from tennis_amd import weights as W
+    from tennis_amd.engine import DenseNet121Features
+    p = W.make_densenet121_weights(0)
+    enc = DenseNet121Features(p, 224, max_batch=256)
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    x = torch.randn((256, 224, 224, 3), generator=g, device="cuda").half()
+    other = torch.randn((4096, 4096), device="cuda")
+    ref_f = enc(x).clone()
+    ref_p = enc.read_tap("pool0", 4).copy()
+    enc.set_pipelined(True)
+    out = [torch.empty_like(ref_f) for _ in range(2)]
+    for i in range(30):
+        if i % 3 == 0: other @ other                 # unrelated kernels on the caller's stream
+        enc(x, out=out[i & 1])
+        enc.join(0)
+        assert torch.equal(out[i & 1], ref_f), f"run {i}: features differ from the first run"
+        if i % 10 == 9:
+            assert np.array_equal(enc.read_tap("pool0", 4), ref_p), f"run {i}: stem output differs"
+    enc.set_pipelined(False)
+
+
 def test_chained_blocks_match_per_layer_launches(monkeypatch):
     """Default: the 14x14 and 7x7 blocks run all their layers inside one launch per block (one workgroup per
     frame, the next layer's first stages and tables requested during the current layer's store); TN_NO_CHAIN=1
