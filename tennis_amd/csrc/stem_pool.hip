@@ -322,6 +322,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
       for (int p = 0; p < IR; ++p) {
         if (p + 2 < IR) xb[(p + 2) % 3] = *(const f16x8 *)(prow + (p + 2) * IPITCH);
         __builtin_amdgcn_sched_barrier(0);
+        // every region opens with (up to) three MFMAs: whatever order the compiler gave the previous region's MFMAs, the
+        // inline-asm BN below then reads an accumulator at least two MFMAs (32 cycles) after the one that completed it
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
 #pragma unroll
         for (int r = 0; r < CR; ++r) {
           const int ky = p - 2 * r;
