@@ -5,7 +5,7 @@ CSRC  := tennis_amd/csrc
 OUT   := tennis_amd/lib/libtennis_hip.so
 SRCS  := $(wildcard $(CSRC)/*.hip)
 OBJS  := $(SRCS:.hip=.o)
-HFLAGS := $(EXTRA) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
+HFLAGS := $(EXTRA) --offload-arch=$(ARCH) -O3 -std=c++20 -fPIC -Wall -Wno-unused-function
 
 all: $(OUT)
 

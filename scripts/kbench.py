@@ -16,6 +16,7 @@ ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--pad", type=int, default=0)
 ap.add_argument("--blocks", default="0,1,2,3")
 ap.add_argument("--lib", default="")
+ap.add_argument("--allk", action="store_true")
 args = ap.parse_args()
 if args.lib: _lib.LIB_PATH = os.path.abspath(args.lib)
 ctx = _lib.default_context(0)
@@ -99,7 +100,7 @@ for v in [int(s) for s in args.variants.split(",")]:
             M = B * hw * hw
             ctot = cin + 32 * nl + args.pad
             buf = torch.randn((M, ctot), device="cuda", dtype=torch.float16)
-            for K in sorted(set([cin, cin + 32 * (nl // 2), cin + 32 * (nl - 1)])):
+            for K in (range(cin, cin + 32 * nl, 32) if args.allk else sorted(set([cin, cin + 32 * (nl // 2), cin + 32 * (nl - 1)]))):
                 wd = (torch.randn((128, K), device="cuda") * (2.0 / K) ** 0.5).half()
                 s1 = torch.rand(K, device="cuda") + 0.5; t1 = torch.randn(K, device="cuda") * 0.3
                 fn = lambda: _lib.check(lib.tn_dbg_dense_layer_dev(ctx.handle, _lib.ptr(buf), ctot, K, _lib.ptr(s1), _lib.ptr(t1),
@@ -132,6 +133,34 @@ for v in [int(s) for s in args.variants.split(",")]:
                 by = M * (K + 32) * 2
                 res.append(dict(k="dl", v=v, hw=hw, K=K, us=round(us, 1), tf=round(fl / us / 1e6, 1), tbs=round(by / us / 1e6, 2)))
                 print(res[-1], flush=True)
+            del buf
+    if "ds" in args.kernels:      # strip-streaming fused dense layer (dense_strip.hip), every layer of the 56x56 / 28x28 blocks it supports
+        w3 = rng.normal(0, 0.03, (32, 128, 3, 3)).astype(np.float32)
+        w3s = np.empty(36864, np.uint16)
+        lib.tn_dbg_pack_strip(None, 32, None, w3.ctypes.data_as(C.c_void_p), w3s.ctypes.data_as(C.c_void_p))
+        w3d = torch.from_numpy(w3s.view(np.int16)).cuda()
+        s2 = torch.rand(128, device="cuda") + 0.5; t2 = torch.randn(128, device="cuda") * 0.3
+        for (hw, cin, nl) in blocks:
+            if hw not in (56, 28): continue
+            M = B * hw * hw
+            ctot = cin + 32 * nl
+            buf = torch.randn((M, ctot), device="cuda", dtype=torch.float16)
+            tot = 0.0
+            for K in range(cin, min(cin + 32 * nl, 321), 32):
+                w1 = rng.normal(0, (2.0 / K) ** 0.5, (128, K)).astype(np.float32)
+                w1s = np.empty(K * 128, np.uint16)
+                lib.tn_dbg_pack_strip(w1.ctypes.data_as(C.c_void_p), K, w1s.ctypes.data_as(C.c_void_p), None, None)
+                w1d = torch.from_numpy(w1s.view(np.int16)).cuda()
+                s1 = torch.rand(K, device="cuda") + 0.5; t1 = torch.randn(K, device="cuda") * 0.3
+                fn = lambda: _lib.check(lib.tn_dbg_dense_strip_dev(ctx.handle, _lib.ptr(buf), ctot, K, _lib.ptr(s1), _lib.ptr(t1),
+                                                                   _lib.ptr(w1d), _lib.ptr(s2), _lib.ptr(t2), _lib.ptr(w3d), B, hw, hw))
+                us = timed(fn, args.iters)
+                tot += us
+                fl = 2.0 * M * (128 * K + 32 * 1152)
+                by = M * (K + 32) * 2
+                res.append(dict(k="ds", hw=hw, K=K, us=round(us, 1), tf=round(fl / us / 1e6, 1), tbs=round(by / us / 1e6, 2)))
+                print(res[-1], flush=True)
+            print("   ds block %d: sum %.1f us" % (hw, tot), flush=True)
             del buf
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(res, open("gpurun_out/kbench.json", "w"), indent=1)

@@ -4,6 +4,7 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 
 #include "../../include/tennis_hip.h"
 
@@ -180,6 +181,21 @@ struct DenseLayerArgs {
 };
 bool dense_layer_supported(int H, int W);
 int launch_dense_layer(const DenseLayerArgs &a, hipStream_t s);
+
+// The strip-streaming fused dense layer (dense_strip.hip): one workgroup per frame, weights resident in LDS.
+struct DenseStripArgs {
+  f16 *buf;              // concat buffer [B][H][W][ldc]: reads channels [0,K), writes [K,K+32)
+  int ldc, K;
+  const float *s1, *t1;  // [K]   folded BN1
+  const f16 *w1s;        // 1x1 weights as A fragments (pack_w1_strip)
+  const float *s2, *t2;  // [128] folded BN2
+  const f16 *w3s;        // 3x3 weights as A fragments (pack_w3_strip)
+  int B, H, W;
+};
+bool dense_strip_supported(int H, int W, int K);
+int launch_dense_strip(const DenseStripArgs &a, hipStream_t s);
+std::vector<f16> pack_w1_strip(const float *w /*[128][K]*/, int K);
+std::vector<f16> pack_w3_strip(const float *w /*(32,128,3,3)*/);
 
 struct StemArgs {
   const void *x;

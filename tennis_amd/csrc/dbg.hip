@@ -105,3 +105,27 @@ extern "C" int tn_dbg_linear(tn_ctx *ctx, const float *x, const float *w, const 
   TN_ON_DEVICE(ctx->device);
   return launch_linear_f32(x, K, w, K, bias, y, N, M, N, K, 0, ctx->stream);
 }
+
+// ---- strip-streaming fused dense layer (dense_strip.hip) ----
+// fp32 (128,K) and (32,128,3,3) -> the fragment images the strip kernel keeps in LDS (K*128 and 36864 halfs)
+extern "C" int tn_dbg_pack_strip(const float *w1_host, int K, uint16_t *w1s_out, const float *w3_host, uint16_t *w3s_out) {
+  TN_REQUIRE(K > 0 && K % 32 == 0, "tn_dbg_pack_strip: K must be a multiple of 32");
+  if (w1_host && w1s_out) {
+    const std::vector<f16> p = pack_w1_strip(w1_host, K);
+    memcpy(w1s_out, p.data(), p.size() * sizeof(f16));
+  }
+  if (w3_host && w3s_out) {
+    const std::vector<f16> p = pack_w3_strip(w3_host);
+    memcpy(w3s_out, p.data(), p.size() * sizeof(f16));
+  }
+  return TN_OK;
+}
+
+// One fused dense layer in place on buf (B,H,W,ldc), asynchronous, device-resident packed operands.
+extern "C" int tn_dbg_dense_strip_dev(tn_ctx *ctx, void *buf_f16, int ldc, int K, const float *s1, const float *t1,
+                                      const void *w1s_f16, const float *s2, const float *t2, const void *w3s_f16,
+                                      int B, int H, int W) {
+  TN_REQUIRE(ctx && buf_f16 && s1 && t1 && w1s_f16 && s2 && t2 && w3s_f16, "tn_dbg_dense_strip_dev: null argument");
+  DenseStripArgs a{(f16 *)buf_f16, ldc, K, s1, t1, (const f16 *)w1s_f16, s2, t2, (const f16 *)w3s_f16, B, H, W};
+  return launch_dense_strip(a, ctx->stream);
+}

@@ -280,3 +280,36 @@ def test_transition_exact_weights(ctx, report, B, H, K, N):
     err = np.abs(got - ref).max()
     report[f"transition_exact_{H}_K{K}"] = float(err)
     assert err < 4e-3, err            # fp16 output rounding
+
+
+@pytest.mark.parametrize("B,H,K,ldc", [(2, 56, 64, 256), (1, 56, 224, 256), (3, 56, 96, 256), (2, 56, 160, 256),
+                                        (3, 28, 128, 512), (2, 28, 320, 512), (5, 28, 160, 512), (1, 28, 288, 512)])
+def test_dense_strip(ctx, report, B, H, K, ldc):
+    """The strip-streaming fused dense layer (dense_strip.hip: one frame per workgroup, weights resident in LDS, bottleneck
+    window in registers through chained MFMA layouts, 3x3 columns combined by DPP shifts) vs the oracle."""
+    from tennis_amd import _lib
+    rng = np.random.default_rng(B * 1000 + H + K)
+    buf = rng.normal(0, 1.5, (B, H, H, ldc)).astype(np.float16)
+    s1 = rng.uniform(0.5, 1.5, K).astype(np.float32); t1 = rng.normal(0, 0.3, K).astype(np.float32)
+    s2 = rng.uniform(0.5, 1.5, 128).astype(np.float32); t2 = rng.normal(0, 0.3, 128).astype(np.float32)
+    w1 = _h(rng.normal(0, np.sqrt(2.0 / K), (128, K)).astype(np.float32))
+    w3 = _h(rng.normal(0, np.sqrt(2.0 / 1152), (32, 128, 3, 3)).astype(np.float32))
+    w1s = np.empty(K * 128, np.uint16); w3s = np.empty(36864, np.uint16)
+    _lib.check(ctx.lib.tn_dbg_pack_strip(w1.ctypes.data_as(C.c_void_p), K, w1s.ctypes.data_as(C.c_void_p),
+                                         w3.ctypes.data_as(C.c_void_p), w3s.ctypes.data_as(C.c_void_p)), "pack_strip")
+    d = dict(buf=torch.from_numpy(buf).cuda(), s1=torch.from_numpy(s1).cuda(), t1=torch.from_numpy(t1).cuda(),
+             s2=torch.from_numpy(s2).cuda(), t2=torch.from_numpy(t2).cuda(),
+             w1s=torch.from_numpy(w1s.view(np.int16)).cuda(), w3s=torch.from_numpy(w3s.view(np.int16)).cuda())
+    _lib.check(ctx.lib.tn_dbg_dense_strip_dev(ctx.handle, _lib.ptr(d["buf"]), ldc, K, _lib.ptr(d["s1"]), _lib.ptr(d["t1"]),
+                                              _lib.ptr(d["w1s"]), _lib.ptr(d["s2"]), _lib.ptr(d["t2"]), _lib.ptr(d["w3s"]),
+                                              B, H, H), "dense_strip")
+    out = d["buf"].cpu().numpy().astype(np.float32)
+    a1 = _bnrelu_h(buf[..., :K].astype(np.float32), s1, t1)
+    bott = (a1.reshape(-1, K) @ w1.T).reshape(B, H, H, 128)
+    a2 = _h(np.maximum(bott * s2 + t2, 0).astype(np.float32))
+    ref = dn.conv2d_nhwc(a2, w3, 1, 1)
+    err = np.abs(out[..., K:K + 32] - ref).max()
+    report[f"dense_strip_{B}x{H}_K{K}"] = float(err)
+    assert err < 2e-2, err
+    keep = np.ones(ldc, bool); keep[K:K + 32] = False
+    assert np.array_equal(out[..., keep], buf[..., keep].astype(np.float32))
