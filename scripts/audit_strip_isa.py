@@ -1,0 +1,89 @@
+"""Audit of dense_strip.hip's ISA (no GPU needed): the kernel keeps its bottleneck window in literal accumulator registers
+a[160:255], which hipcc does not know are live.  This script fails if the compiler's own code touches them.
+
+  python scripts/audit_strip_isa.py <dense_strip ... gfx950.s>
+
+For every dense_strip kernel it checks that
+  1. no instruction OUTSIDE an inline-asm region (;;#ASMSTART .. ;;#ASMEND) names an accumulator register >= 160;
+  2. nothing was spilled to scratch (.private_segment_fixed_size 0, .vgpr_spill_count 0);
+  3. no compiler v_accvgpr_* instruction sits directly in front of an asm MFMA block whose accumulator operands it writes
+     (VALU write -> MFMA operand read needs two wait states, and hipcc pads nothing for an asm consumer).
+"""
+import re
+import sys
+
+WIN_LO = 160
+
+
+def regs_of(tok):
+    m = re.fullmatch(r"a\[(\d+):(\d+)\]", tok)
+    if m:
+        return range(int(m.group(1)), int(m.group(2)) + 1)
+    m = re.fullmatch(r"a(\d+)", tok)
+    if m:
+        return range(int(m.group(1)), int(m.group(1)) + 1)
+    return range(0)
+
+
+def agprs(line):
+    out = set()
+    for tok in re.findall(r"a\[\d+:\d+\]|\ba\d+\b", line):
+        out.update(regs_of(tok))
+    return out
+
+
+def main():
+    path = sys.argv[1]
+    text = open(path).read()
+    bad = 0
+    kernels = 0
+    for m in re.finditer(r"^(\S*dense_strip_kernel\S*):", text, re.M):
+        name = m.group(1)
+        end = text.find(".end_amdhsa_kernel", m.end())
+        body = text[m.end():text.rfind("s_endpgm", m.end(), end) + 8]
+        meta = text[end - 4000:end + 200]
+        kernels += 1
+        in_asm = False
+        prev = []          # last compiler instructions (outside asm) with the AGPRs they write
+        for raw in body.split("\n"):
+            if "#ASMSTART" in raw:
+                in_asm = True
+                first_in_block = True
+                continue
+            if "#ASMEND" in raw:
+                in_asm = False
+                prev = []
+                continue
+            line = raw.split(";")[0].strip()
+            if not line or line.startswith(".") or line.endswith(":"):
+                continue
+            if in_asm:
+                if first_in_block and line.startswith("v_mfma"):
+                    used = agprs(line)
+                    for pl, written in prev[-2:]:
+                        if written & used:
+                            print("%s: compiler '%s' directly in front of asm '%s'" % (name, pl, line))
+                            bad += 1
+                first_in_block = False
+                continue
+            touched = agprs(line)
+            if any(r >= WIN_LO for r in touched):
+                print("%s: compiler instruction touches the window: %s" % (name, line))
+                bad += 1
+            written = set()
+            if line.startswith(("v_accvgpr_write", "v_accvgpr_mov")):
+                written = agprs(line.split(",")[0])
+            prev.append((line, written))
+            if not line.startswith(("v_accvgpr", "s_nop")):
+                prev = prev[-1:] if written else []
+        for key in (".private_segment_fixed_size", ".vgpr_spill_count"):
+            mm = re.search(re.escape(key) + r":?\s+(\d+)", meta)
+            if mm and int(mm.group(1)) != 0:
+                print("%s: %s = %s" % (name, key, mm.group(1)))
+                bad += 1
+    print("audited %d kernels, %d problem(s)" % (kernels, bad))
+    sys.exit(1 if bad or not kernels else 0)
+
+
+if __name__ == "__main__":
+    main()
