@@ -39,7 +39,9 @@ MIN_TOTAL_STEPS = 200
 COMPULSORY_BYTES_PER_FRAME = 301056 + 4096
 WEIGHT_BYTES = 13.7e6
 # profile family (tn_densenet121_profile) -> kernel family key of profiles/*_pmc_traffic.json
-PMC_KEYS = {"dense_layer_fused_56x56": ("dense_layer_56x56", "dense_layer_kernel<56"),
+PMC_KEYS = {"dense_layer_strip_56x56": ("dense_strip_56x56", "dense_strip_kernel<56"),
+            "dense_layer_strip_28x28": ("dense_strip_28x28", "dense_strip_kernel<28"),
+            "dense_layer_fused_56x56": ("dense_layer_56x56", "dense_layer_kernel<56"),
             "dense_layer_fused_28x28": ("dense_layer_28x28", "dense_layer_kernel<28"),
             "dense_block_chained_14x14": ("dense_block_14x14", "dense_layer_kernel<14"),
             "dense_block_chained_7x7": ("dense_block_7x7", "dense_layer_kernel<7"),

@@ -318,7 +318,7 @@ int tn_dbg_linear(tn_ctx *ctx, const float *x, const float *w, const float *bias
 int tn_dbg_pack_strip(const float *w1_host, int K, uint16_t *w1s_out, const float *w3_host, uint16_t *w3s_out);
 int tn_dbg_dense_strip_dev(tn_ctx *ctx, void *buf_f16, int ldc, int K, const float *s1, const float *t1,
                            const void *w1s_f16, const float *s2, const float *t2, const void *w3s_f16, int B,
-                           int H, int W);
+                           int H, int W, unsigned long long *ts /* NULL or 128 s_memtime stamps per frame */);
 
 #ifdef __cplusplus
 }

@@ -17,6 +17,7 @@ ap.add_argument("--pad", type=int, default=0)
 ap.add_argument("--blocks", default="0,1,2,3")
 ap.add_argument("--lib", default="")
 ap.add_argument("--allk", action="store_true")
+ap.add_argument("--stamps", action="store_true")
 args = ap.parse_args()
 if args.lib: _lib.LIB_PATH = os.path.abspath(args.lib)
 ctx = _lib.default_context(0)
@@ -153,9 +154,22 @@ for v in [int(s) for s in args.variants.split(",")]:
                 w1d = torch.from_numpy(w1s.view(np.int16)).cuda()
                 s1 = torch.rand(K, device="cuda") + 0.5; t1 = torch.randn(K, device="cuda") * 0.3
                 fn = lambda: _lib.check(lib.tn_dbg_dense_strip_dev(ctx.handle, _lib.ptr(buf), ctot, K, _lib.ptr(s1), _lib.ptr(t1),
-                                                                   _lib.ptr(w1d), _lib.ptr(s2), _lib.ptr(t2), _lib.ptr(w3d), B, hw, hw))
+                                                                   _lib.ptr(w1d), _lib.ptr(s2), _lib.ptr(t2), _lib.ptr(w3d), B, hw, hw, None))
                 us = timed(fn, args.iters)
                 tot += us
+                if args.stamps:
+                    ts = torch.zeros((B * 128,), dtype=torch.int64, device="cuda")
+                    _lib.check(lib.tn_dbg_dense_strip_dev(ctx.handle, _lib.ptr(buf), ctot, K, _lib.ptr(s1), _lib.ptr(t1), _lib.ptr(w1d), _lib.ptr(s2),
+                                                          _lib.ptr(t2), _lib.ptr(w3d), B, hw, hw, _lib.ptr(ts)))
+                    torch.cuda.synchronize()
+                    t = ts.cpu().numpy().astype(np.float64).reshape(B, 128)
+                    n = int((t[0, :127] > 0).sum())
+                    d = np.diff(t[:, :n], axis=1)
+                    med = np.median(d, axis=0)
+                    print("   stamps (ticks, median over frames): launch->start %d | start->loop %d | rows: A %s | B %s | tail %s | total %d"
+                          % (np.median(t[:, 0] - t[:, 127]), med[0] + (med[1] if n > 2 else 0), np.round(med[2:-2:2][:6]), np.round(med[3:-2:2][:6]), np.round(med[-2:]),
+                             np.median(t[:, n - 1] - t[:, 127])), flush=True)
+                    print("      mean A %.0f  mean B %.0f  (A slots %d, B slots 72)" % (med[2:-2:2].mean(), med[3:-2:2].mean(), K // 4), flush=True)
                 fl = 2.0 * M * (128 * K + 32 * 1152)
                 by = M * (K + 32) * 2
                 res.append(dict(k="ds", hw=hw, K=K, us=round(us, 1), tf=round(fl / us / 1e6, 1), tbs=round(by / us / 1e6, 2)))

@@ -182,6 +182,65 @@ void run16(const u32x4 *src, float *out, const char *what) {
          ms * 1e6 / (iters * 6.0) / (T / 256), tk / (iters * 6.0), hipGetErrorString(hipGetLastError()));
 }
 
+// one 32x32x16 MFMA + one 16-byte-per-lane global load per slot (L2-resident source, fragment-shaped: 32 pixels x 2 halves, 512-B
+// pixel pitch): MODE 0 no load, 1 global_load 64-bit vaddr, 2 global_load saddr + 32-bit voffset, 3 buffer_load offen
+template <int MODE, int NF>
+__global__ __launch_bounds__(256) void kld(const u32x4 *src, const unsigned char *gsrc, float *out, int iters) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  u32x4 wa[6];
+  for (int f = 0; f < 6; ++f) wa[f] = src[f * 64 + lane];
+  const u32x4 b0 = src[7 * 64 + lane];
+  f32x16 acc[6];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  float fl[8];
+  for (int i = 0; i < 8; ++i) fl[i] = (float)lane * 0.001f + i;
+  u32x4 ld[6];
+  for (int i = 0; i < 6; ++i) ld[i] = (u32x4){0, 0, 0, 0};
+  const unsigned voff = (unsigned)((lane & 31) * 512 + (lane >> 5) * 64 + (blockIdx.x & 63) * 16384 + (tid >> 6) * 4096);
+  const unsigned char *vp = gsrc + voff;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)gsrc, 0, 1 << 22, 0x00020000);
+  const long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[s]) : "v"(wa[s]), "v"(b0));
+      if (s == 0 && (it & 1) == 0) {     // one load per 12 slots
+      if constexpr (MODE == 1) asm volatile("global_load_dwordx4 %0, %1, off offset:%c2" : "=v"(ld[s]) : "v"(vp), "n"(s * 16));
+      if constexpr (MODE == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%c3" : "=v"(ld[s]) : "v"(voff), "s"(gsrc), "n"(s * 16));
+      if constexpr (MODE == 3) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%c3" : "=v"(ld[s]) : "v"(voff), "s"(rs), "n"(s * 16));
+      }
+#pragma unroll
+      for (int j = 0; j < NF; ++j) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(fl[j % 8]) : "v"(fl[7]));
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)");
+  const long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0;
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 16; ++j) s += acc[i][j];
+  for (int i = 0; i < 8; ++i) s += fl[i];
+  for (int f = 0; f < 6; ++f) s += __builtin_bit_cast(float, ld[f][0]);
+  out[blockIdx.x * 256 + tid] = s;
+  if (tid == 0) ((long *)(out + 256 * 1024))[blockIdx.x] = t1 - t0;
+}
+template <int MODE, int NF>
+void runld(const u32x4 *src, const unsigned char *gsrc, float *out, const char *what) {
+  const int iters = 2000;
+  hipFuncSetAttribute((const void *)kld<MODE, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  kld<MODE, NF><<<256, 256, 163840>>>(src, gsrc, out, 10);
+  hipDeviceSynchronize();
+  hipEventRecord(a);
+  kld<MODE, NF><<<256, 256, 163840>>>(src, gsrc, out, iters);
+  hipEventRecord(b);
+  hipDeviceSynchronize();
+  float ms = 0;
+  hipEventElapsedTime(&ms, a, b);
+  printf("32x32x16 + load mode %d (%s) NF=%d: %7.2f ns per slot  [%s]\n", MODE, what, NF, ms * 1e6 / (iters * 6.0), hipGetErrorString(hipGetLastError()));
+}
+
 template <int V>
 void run(const u32x4 *src, float *out, const char *what) {
   hipFuncSetAttribute((const void *)k<V>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
@@ -222,6 +281,15 @@ int main() {
   run<1 | 2 | (2 << 2) | 64 | 32>(src, out, "B AGPR + ds_read + 2 fma + 2 accread + waitcnt");
   run<1 | 2 | (4 << 2) | 64 | 32>(src, out, "B AGPR + ds_read + 4 fma + 2 accread + waitcnt");
   run<0 | 2 | (4 << 2) | 64 | 32>(src, out, "B VGPR + ds_read + 4 fma + 2 accread + waitcnt");
+  unsigned char *gsrc; hipMalloc(&gsrc, 1 << 22); hipMemset(gsrc, 0, 1 << 22);
+  runld<0, 0>(src, gsrc, out, "no load");
+  runld<1, 0>(src, gsrc, out, "global_load vaddr64");
+  runld<2, 0>(src, gsrc, out, "global_load saddr+voff");
+  runld<3, 0>(src, gsrc, out, "buffer_load offen");
+  runld<0, 4>(src, gsrc, out, "no load");
+  runld<1, 4>(src, gsrc, out, "global_load vaddr64");
+  runld<2, 4>(src, gsrc, out, "global_load saddr+voff");
+  runld<3, 4>(src, gsrc, out, "buffer_load offen");
   run32<0, 0, 256>(src, out, "");
   run32<2, 0, 256>(src, out, "");
   run32<4, 0, 256>(src, out, "");

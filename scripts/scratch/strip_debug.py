@@ -28,7 +28,7 @@ d = dict(buf=torch.from_numpy(buf).cuda(), s1=torch.from_numpy(s1).cuda(), t1=to
          s2=torch.from_numpy(s2).cuda(), t2=torch.from_numpy(t2).cuda(),
          w1s=torch.from_numpy(w1s.view(np.int16)).cuda(), w3s=torch.from_numpy(w3s.view(np.int16)).cuda())
 _lib.check(ctx.lib.tn_dbg_dense_strip_dev(ctx.handle, _lib.ptr(d["buf"]), ldc, K, _lib.ptr(d["s1"]), _lib.ptr(d["t1"]),
-                                          _lib.ptr(d["w1s"]), _lib.ptr(d["s2"]), _lib.ptr(d["t2"]), _lib.ptr(d["w3s"]), B, H, H), "strip")
+                                          _lib.ptr(d["w1s"]), _lib.ptr(d["s2"]), _lib.ptr(d["t2"]), _lib.ptr(d["w3s"]), B, H, H, None), "strip")
 out = d["buf"].cpu().numpy().astype(np.float32)
 a1 = _h(np.maximum(buf[..., :K].astype(np.float32) * s1 + t1, 0))
 bott = (a1.reshape(-1, K) @ w1.T).reshape(B, H, H, 128)

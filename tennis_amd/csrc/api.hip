@@ -249,7 +249,7 @@ struct tn_encoder {
   int PH, PW;
   f16 *stem_wp, *stem_wp_zf;
   float *stem_scale, *stem_shift;
-  struct DenseLayer { float *s1, *t1; f16 *w1; float *s2, *t2; f16 *w3p; int cin; };
+  struct DenseLayer { float *s1, *t1; f16 *w1; float *s2, *t2; f16 *w3p; int cin; f16 *w1s = nullptr, *w3s = nullptr; };   // w1s / w3s: fragment images of the strip kernel
   std::vector<DenseLayer> layers[4];
   struct Trans { float *s, *t; f16 *w; int cin, cout; } trans[3];
   float *head_s, *head_t;
@@ -261,6 +261,8 @@ struct tn_encoder {
   int dl_variant;             // tuning hook: TN_DL_VARIANT -> DenseLayerArgs.variant
   bool chain;                 // whole-frame blocks (14x14, 7x7) run all their layers in one launch (TN_NO_CHAIN disables)
   bool exact = false;         // TN_ENC_EXACT_WEIGHTS: dense-layer and transition weights as hi + lo fp16 pairs
+  bool strip = true;          // 56x56 / 28x28 layers with K <= 320 run on the strip-streaming kernel (TN_NO_STRIP disables)
+  int strip_min_batch = 64;   // ... from this many frames per launch on (one workgroup per frame: small batches leave CUs idle)
   DenseLayerDev *chain_dev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipStream_t side[4];
   hipEvent_t ev_in, ev_done[2][4];   // completion of the side streams, alternating per forward call
@@ -296,6 +298,8 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
   e->chain = getenv("TN_NO_CHAIN") == nullptr;   // measured: -20% on the 14x14 / 7x7 blocks, +2.8% end to end
   e->dl_variant = getenv("TN_DL_VARIANT") ? atoi(getenv("TN_DL_VARIANT")) : 0;
   e->exact = (flags & TN_ENC_EXACT_WEIGHTS) != 0;
+  e->strip = getenv("TN_NO_STRIP") == nullptr && !e->exact && e->fuse;
+  if (getenv("TN_STRIP_MIN_BATCH")) e->strip_min_batch = atoi(getenv("TN_STRIP_MIN_BATCH"));
   for (int i = 0; i < 4; ++i) {
     if (hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_done[0][i], hipEventDisableTiming) != hipSuccess ||
@@ -363,6 +367,10 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
         L.w3p = e->pool.upload(img);
       } else {
         L.w3p = e->pool.upload(pack_conv3x3(w3));
+      }
+      if (e->strip && dense_strip_supported(e->Hb[b], e->Wb[b], L.cin)) {
+        L.w1s = e->pool.upload(pack_w1_strip(w1, L.cin));
+        L.w3s = e->pool.upload(pack_w3_strip(w3));
       }
       e->layers[b].push_back(L);
     }
@@ -453,6 +461,16 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
       if (rc) return rc;
     } else
     for (auto &L : e->layers[b]) {
+      if (fused && L.w1s && B >= e->strip_min_batch && e->dl_variant == 0) {
+        DenseStripArgs as{bbuf[b], e->Cb[b], L.cin, L.s1, L.t1, L.w1s, L.s2, L.t2, L.w3s, B, Hh, Ww};
+        const std::string fam = "dense_layer_strip_" + std::to_string(Hh) + "x" + std::to_string(Ww);
+        tm.begin(fam.c_str(), 2.0 * M * (128.0 * L.cin + 32.0 * 1152),
+                 (double)M * (L.cin + 32) * 2 + 128.0 * L.cin * 2 + 32.0 * 1152 * 2);
+        rc = launch_dense_strip(as, s);
+        tm.end();
+        if (rc) return rc;
+        continue;
+      }
       if (fused) {
         DenseLayerArgs af{bbuf[b], e->Cb[b], L.cin, L.s1, L.t1, L.w1, L.s2, L.t2, L.w3p, B, Hh, Ww, nullptr, e->dl_variant};
         af.exact = e->exact;

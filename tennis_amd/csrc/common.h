@@ -191,6 +191,7 @@ struct DenseStripArgs {
   const float *s2, *t2;  // [128] folded BN2
   const f16 *w3s;        // 3x3 weights as A fragments (pack_w3_strip)
   int B, H, W;
+  unsigned long long *ts = nullptr;   // tuning hook: s_memtime stamps of wave 0 of every workgroup (128 per workgroup)
 };
 bool dense_strip_supported(int H, int W, int K);
 int launch_dense_strip(const DenseStripArgs &a, hipStream_t s);

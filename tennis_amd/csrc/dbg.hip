@@ -124,8 +124,9 @@ extern "C" int tn_dbg_pack_strip(const float *w1_host, int K, uint16_t *w1s_out,
 // One fused dense layer in place on buf (B,H,W,ldc), asynchronous, device-resident packed operands.
 extern "C" int tn_dbg_dense_strip_dev(tn_ctx *ctx, void *buf_f16, int ldc, int K, const float *s1, const float *t1,
                                       const void *w1s_f16, const float *s2, const float *t2, const void *w3s_f16,
-                                      int B, int H, int W) {
+                                      int B, int H, int W, unsigned long long *ts) {
   TN_REQUIRE(ctx && buf_f16 && s1 && t1 && w1s_f16 && s2 && t2 && w3s_f16, "tn_dbg_dense_strip_dev: null argument");
   DenseStripArgs a{(f16 *)buf_f16, ldc, K, s1, t1, (const f16 *)w1s_f16, s2, t2, (const f16 *)w3s_f16, B, H, W};
+  a.ts = ts;
   return launch_dense_strip(a, ctx->stream);
 }

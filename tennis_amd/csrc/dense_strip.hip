@@ -1,4 +1,4 @@
-// Fused DenseNet dense layer, "strip-streaming" form (round 3; 56x56 and 28x28 blocks):
+// Fused DenseNet dense layer, "strip-streaming" form (round 3; 56x56 and 28x28 blocks, K <= 320):
 //
 //   y[.., K:K+32] = conv3x3( relu(bn2( conv1x1( relu(bn1( x[.., 0:K] )) ) )) )
 //
@@ -7,71 +7,68 @@
 // phases (K loop, epilogue, 3x3, store) one after the other behind barriers, with the bottleneck tile in LDS aliasing the
 // K-loop ring.  This kernel is built the other way round:
 //
-// * a workgroup = one frame, 4 waves = one wave per SIMD with the whole 512-entry register file; NO barrier after the
-//   prologue.  Each wave walks DOWN its own 14-pixel-wide column strip (16 slots with the two halo columns: exactly one
-//   v_mfma_f32_16x16x32_f16 N-fragment per image row) in groups of four rows, so the four SIMDs drift apart and one
-//   wave's VALU / LDS / load phases meet the others' MFMA phases.
-// * the 128-channel bottleneck never touches LDS either: with the weights as the A operand, the accumulator layout of
-//   the 1x1 GEMM (lane = pixel l & 15, rows 4 (l >> 4) + r) IS the B-operand layout of the 3x3's MFMAs once the 3x3
+// * a workgroup = one frame, 4 waves = ONE wave per SIMD with the whole 512-entry register file; no barrier after the
+//   prologue.  A wave owns a pair of adjacent 14-pixel column strips (2 x 16 slots with their halo columns = the N = 32 of
+//   one v_mfma_f32_32x32x16_f16) and walks DOWN its rows one image row at a time.  One wave per SIMD issues one instruction
+//   per ~4 cycles: a 32-cycle 32x32x16 MFMA hides ~6 other instructions, a 16-cycle 16x16x32 only one
+//   (scripts/scratch/slotbench.hip) - and this layer needs ~3.5 element-wise / LDS / load instructions per 16x16x32's worth
+//   of MFMA work, so the kernel is built on the 32x32 shape.
+// * the 128-channel bottleneck never touches LDS: with the weights as the A operand, the accumulator layout of the 1x1 GEMM
+//   (lane = slot l & 31, rows (r & 3) + 8 (r >> 2) + 4 (l >> 5)) IS the B-operand layout of the 3x3's MFMAs once the 3x3
 //   weights are packed with the matching permutation of their input channels (chained MFMAs: BN2 + ReLU + fp16 pack are
-//   lane-local).  A wave keeps a sliding window of six bottleneck rows in registers (96 VGPRs).
-// * the 3x3 convolution applies the three kernel columns to the SAME input fragment (one fragment feeds 6 MFMAs instead
-//   of 2) into three accumulator sets which are combined at the end by two DPP row shifts: out[x] = acc[dx=0][x] +
-//   acc[dx=-1][x-1] + acc[dx=+1][x+1].  The shifts stay inside the 16-lane row = inside the strip (outputs of the two
-//   halo slots are never stored), so there is no cross-fragment carry.
-// * the layer's 1x1 weights (K x 128, as A fragments) and all nine taps of the 3x3 weights (72 KB) are resident in LDS
-//   for the whole launch; activations go HBM -> registers directly in fragment shape (32 B per lane per 64-channel
-//   super-step; the four lanes of a pixel cover one 128-B line) through a register ring three super-steps deep that runs
-//   one row-group ahead of the MFMAs.
+//   lane-local).  The sliding window of three bottleneck rows lives in 96 literal accumulator registers.
+// * the 3x3 convolution applies the three kernel columns to the SAME input fragment into three accumulator sets which are
+//   combined at the end by two DPP row shifts: out[x] = acc[dx=0][x] + acc[dx=-1][x-1] + acc[dx=+1][x+1].  The shifts stay
+//   inside the 16-lane row = inside one strip (outputs of the halo slots are never stored): no cross-fragment carry.
+// * the layer's 1x1 weights (K x 128, as A fragments) and all nine taps of the 3x3 weights (72 KB) are resident in LDS for
+//   the whole launch; activations go HBM -> registers directly in fragment shape (64 B per lane per 64-channel super-step;
+//   the two lanes of a pixel cover one 128-B line) through a register ring that holds one whole row and is refilled with
+//   the next row as it is read out.
+// * the schedule is pinned by hand: the body is a sequence of SLOTS - one MFMA followed by its share of everything else -
+//   with a scheduling barrier behind each.  1x1 slots carry BN1 + ReLU of the next k-step, the weight-fragment and constant
+//   reads, the ring refill and the DPP epilogue of the PREVIOUS output row; 3x3 slots carry the weight-fragment reload, the
+//   BN2 epilogue of the row just computed (its window row is only needed by the last third of the slots) and the first
+//   operands of the next row.  Nothing runs outside an MFMA's shadow in the steady state.
 //
-// No halo recompute in y when a wave owns the frame's full height (56x56); 16/14 in x.
+// No halo recompute in y at 56x56 beyond one row per wave (29 / 28); 16 / 14 in x.
 #include <type_traits>
 
 #include "common.h"
 
 #ifndef TN_DS_EXP
-#define TN_DS_EXP 0   // timing experiments only (results wrong): bit 0 no activation loads inside the group loop, bit 1 no 3x3 phase, bit 2 no 1x1 phase
+#define TN_DS_EXP 0   // timing experiments only (results wrong): bit 0 no activation loads inside the row loop, bit 1 no 3x3 phase, bit 2 no 1x1 phase
 #endif
 
 namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 
-constexpr int kW3Bytes = 3 * 4 * 3 * 2 * 1024;   // [dy][t][dx][of] fragments of 1 KiB
+constexpr int kW3Bytes = 3 * 8 * 3 * 1024;   // [dy][k16-step][dx] fragments of 1 KiB
 
 template <int W, int KS>
 struct DSGeom {
-  static constexpr int NS = W / 14;              // strips per frame
-  static constexpr int NV = 4 / NS;              // vertical parts (waves stacked in y)
+  static constexpr int NPAIR = W / 28;           // strip pairs per frame
+  static constexpr int NV = 4 / NPAIR;           // vertical parts (waves stacked in y)
   static constexpr int ROWS = W / NV;            // output rows per wave
-  static constexpr int NG = ROWS / 4;            // full row groups
-  static constexpr bool TAIL = (ROWS % 4) == 2;  // + one half group
+  static constexpr int KQ = 2 * KS;              // 16-channel k-steps
   static constexpr int NSU = (KS + 1) / 2;       // 64-channel super-steps (the last one is half when KS is odd)
   static constexpr int W1OFF = kW3Bytes;
   static constexpr int T1OFF = W1OFF + KS * 8192;          // s1[K] | t1[K]
   static constexpr int T2OFF = T1OFF + KS * 32 * 8;        // s2[128] | t2[128]
   static constexpr int ZOFF = T2OFF + 1024;                // 1 KiB of zeros: BN2 "tables" of padding pixels
   static constexpr int LDS_BYTES = ZOFF + 1024;
-  static_assert(W % 14 == 0 && (NS == 1 || NS == 2 || NS == 4), "strip geometry");
-  static_assert(ROWS % 2 == 0, "rows per wave");
+  static_assert(W % 28 == 0 && (NPAIR == 1 || NPAIR == 2), "strip geometry");
+  static_assert(NSU <= 5, "the activation ring holds five super-steps");
   static_assert(LDS_BYTES <= 160 * 1024, "weights do not fit LDS");
 };
 
-__device__ __forceinline__ f32x4 mfma16(const u32x4 a, const u32x4 b, const f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-
-// MFMA with the B operand (and the accumulator) in the accumulator half of the register file.  The builtin takes A / B from
-// VGPRs only (hipcc copies an AGPR value back first), so the 3x3's MFMAs - whose B operands are the 96-register bottleneck
-// window - are issued through inline asm; hipcc neither pads hazards around an asm statement nor knows it is an MFMA
-// (cdna_hip_programming.md 5.7): the writers of the window end with s_nop 1, and the accumulators pass through
-// mfma_results_ready() before anything but an MFMA of the same chain touches them.
-// The bottleneck window lives in LITERAL accumulator registers a[160:255] (six rows x four 32-channel k-steps x one 4-register
-// MFMA B operand): hipcc's MFMA builtin takes A / B from VGPRs only, and a window held in compiler-allocated AGPR values gets
-// its live ranges split and copied through VGPRs (measured: ~200 extra v_accvgpr moves per row group, some of them directly
-// in front of the asm MFMA that reads the register two cycles later - a hazard hipcc cannot see).  Every statement that
-// writes the window names all 96 registers as clobbered, which keeps compiler values out of them and makes the kernel
-// descriptor allocate them (cdna_hip_programming.md 5.7 item 4; scripts/audit_strip_isa.py checks the ISA for strays).
+// The bottleneck window lives in LITERAL accumulator registers a[160:255] (three rows x eight 16-channel k-steps x one
+// 4-register MFMA B operand): hipcc's MFMA builtin takes A / B from VGPRs only, and a window held in compiler-allocated AGPR
+// values gets its live ranges split and copied through VGPRs (measured in the first version: ~200 extra v_accvgpr moves per
+// row group, some of them directly in front of the asm MFMA that reads the register two cycles later - a hazard hipcc cannot
+// see).  Every slot of the kernel body names all 96 registers as clobbered, which keeps compiler values out of them;
+// scripts/audit_strip_isa.py checks the ISA for strays (cdna_hip_programming.md 5.7 item 4).
 #define TN_WIN_BASE 160
 #define TN_WIN_CLOBBER                                                                                                              \
   "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175",   \
@@ -80,47 +77,38 @@ __device__ __forceinline__ f32x4 mfma16(const u32x4 a, const u32x4 b, const f32x
   "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223",   \
   "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239",   \
   "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
-constexpr int win_reg(int row, int t) { return TN_WIN_BASE + 16 * row + 4 * t; }
+constexpr int win_reg(int prow, int t) { return TN_WIN_BASE + 32 * prow + 4 * t; }
+// keeps compiler values that are live here out of the window registers (no instruction)
+#define TN_WIN_FENCE() asm volatile("" ::: TN_WIN_CLOBBER)
 
-// four packed VGPRs -> window tuple (ROW, T); the trailing s_nop 1 covers v_accvgpr_write -> MFMA operand read
-template <int ROW, int T>
+// four packed VGPRs -> window tuple (physical row PROW, k-step T); the trailing s_nop 1 covers v_accvgpr_write -> MFMA operand read
+template <int PROW, int T>
 __device__ __forceinline__ void win_write(const unsigned v0, const unsigned v1, const unsigned v2, const unsigned v3) {
-  constexpr int B = win_reg(ROW, T);
+  constexpr int B = win_reg(PROW, T);
   asm volatile("v_accvgpr_write_b32 a%c4, %0\n\tv_accvgpr_write_b32 a%c5, %1\n\tv_accvgpr_write_b32 a%c6, %2\n\tv_accvgpr_write_b32 a%c7, %3\n\ts_nop 1"
                :: "v"(v0), "v"(v1), "v"(v2), "v"(v3), "n"(B), "n"(B + 1), "n"(B + 2), "n"(B + 3) : TN_WIN_CLOBBER);
 }
-#define TN_MV(d, s_) "v_accvgpr_mov_b32 a" #d ", a" #s_ "\n\t"
-// window rows 4, 5 -> rows 0, 1 (the next group's first two rows)
-__device__ __forceinline__ void win_shift() {
-  asm volatile(
-      TN_MV(160, 224) TN_MV(161, 225) TN_MV(162, 226) TN_MV(163, 227) TN_MV(164, 228) TN_MV(165, 229) TN_MV(166, 230) TN_MV(167, 231)
-      TN_MV(168, 232) TN_MV(169, 233) TN_MV(170, 234) TN_MV(171, 235) TN_MV(172, 236) TN_MV(173, 237) TN_MV(174, 238) TN_MV(175, 239)
-      TN_MV(176, 240) TN_MV(177, 241) TN_MV(178, 242) TN_MV(179, 243) TN_MV(180, 244) TN_MV(181, 245) TN_MV(182, 246) TN_MV(183, 247)
-      TN_MV(184, 248) TN_MV(185, 249) TN_MV(186, 250) TN_MV(187, 251) TN_MV(188, 252) TN_MV(189, 253) TN_MV(190, 254) TN_MV(191, 255)
-      "s_nop 1" ::: TN_WIN_CLOBBER);
+template <int R>
+__device__ __forceinline__ void win_zero_reg() {
+  asm volatile("v_accvgpr_write_b32 a%c0, 0" :: "n"(R) : TN_WIN_CLOBBER);
 }
-// window rows 2, 3 -> rows 4, 5 (start-up: the first two rows were computed as a half group)
-template <int DST, int SRC>
-__device__ __forceinline__ void win_copy2() {
-  static_assert(DST == 4 && SRC == 2, "only the start-up copy exists");
-  asm volatile(
-      TN_MV(224, 192) TN_MV(225, 193) TN_MV(226, 194) TN_MV(227, 195) TN_MV(228, 196) TN_MV(229, 197) TN_MV(230, 198) TN_MV(231, 199)
-      TN_MV(232, 200) TN_MV(233, 201) TN_MV(234, 202) TN_MV(235, 203) TN_MV(236, 204) TN_MV(237, 205) TN_MV(238, 206) TN_MV(239, 207)
-      TN_MV(240, 208) TN_MV(241, 209) TN_MV(242, 210) TN_MV(243, 211) TN_MV(244, 212) TN_MV(245, 213) TN_MV(246, 214) TN_MV(247, 215)
-      TN_MV(248, 216) TN_MV(249, 217) TN_MV(250, 218) TN_MV(251, 219) TN_MV(252, 220) TN_MV(253, 221) TN_MV(254, 222) TN_MV(255, 223)
-      "s_nop 1" ::: TN_WIN_CLOBBER);
+// a bottleneck row above / below the image: zeros
+template <int PROW>
+__device__ __forceinline__ void win_zero() {
+  [&]<int... I>(std::integer_sequence<int, I...>) { (win_zero_reg<win_reg(PROW, 0) + I>(), ...); }(std::make_integer_sequence<int, 32>{});
+  asm volatile("s_nop 1");
 }
-#undef TN_MV
-// one 3x3 weight fragment against window tuples (ROW, T) and (ROW + 1, T): the two MFMAs of a slot
-template <bool FIRST, int ROW, int T>
-__device__ __forceinline__ void mfma16_pair(f32x4 &d0, f32x4 &d1, const u32x4 a) {
-  constexpr int B0 = win_reg(ROW, T), B1 = win_reg(ROW + 1, T);
+// one 3x3 weight fragment against window tuple (PROW, T)
+template <bool FIRST, int PROW, int T>
+__device__ __forceinline__ void mfma32_win(f32x16 &d, const u32x4 a) {
+  constexpr int B0 = win_reg(PROW, T);
   if constexpr (FIRST)
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %2, a[%c3:%c4], 0\n\tv_mfma_f32_16x16x32_f16 %1, %2, a[%c5:%c6], 0"
-                 : "=&a"(d0), "=&a"(d1) : "v"(a), "n"(B0), "n"(B0 + 3), "n"(B1), "n"(B1 + 3));
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], 0" : "=&a"(d) : "v"(a), "n"(B0), "n"(B0 + 3));
   else
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %2, a[%c3:%c4], %0\n\tv_mfma_f32_16x16x32_f16 %1, %2, a[%c5:%c6], %1"
-                 : "+a"(d0), "+a"(d1) : "v"(a), "n"(B0), "n"(B0 + 3), "n"(B1), "n"(B1 + 3));
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], %0" : "+a"(d) : "v"(a), "n"(B0), "n"(B0 + 3));
+}
+__device__ __forceinline__ f32x16 mfma32(const u32x4 a, const u32x4 b, const f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
 template <int CTRL>
@@ -128,26 +116,24 @@ __device__ __forceinline__ float dpp_f32(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 
+#define TN_INL __attribute__((always_inline))
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F &&f) {
-  [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
+  [&]<int... I>(std::integer_sequence<int, I...>) TN_INL { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
 }
 template <int V>
 using ic = std::integral_constant<int, V>;
 
-// The schedule is pinned by hand: hipcc's scheduler, left alone, issues every LDS read right in front of its consumer and
-// piles the element-wise epilogues up in MFMA-free stretches.  The body below is written as a sequence of SLOTS - one MFMA
-// (1x1 phase) or one two-MFMA block (3x3 phase) followed by its share of everything else - with a scheduling barrier
-// behind each, so that program order IS issue order.
 #define TN_SB() __builtin_amdgcn_sched_barrier(0)
 
 template <int W, int KS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void dense_strip_kernel(DenseStripArgs a) {
   using G = DSGeom<W, KS>;
-  constexpr int H = W, NSU = G::NSU, K = KS * 32;
+  constexpr int H = W, NSU = G::NSU, K = KS * 32, KQ = G::KQ, ROWS = G::ROWS;
   constexpr bool ODD = (KS & 1) != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
+  if (a.ts && tid == 0) a.ts[(size_t)blockIdx.x * 128 + 127] = __builtin_amdgcn_s_memtime();
 
   // ---- prologue: the layer's weights and tables -> LDS (once per launch) ----
   {
@@ -175,264 +161,292 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = lane & 15, g4 = lane >> 4;
-  const int strip = wid % G::NS, part = wid / G::NS;
-  const int r_lo = part * G::ROWS;
-  const int x = 14 * strip - 1 + n;
+  const int n = lane & 31, h = lane >> 5;
+  const int pair = wid % G::NPAIR, part = wid / G::NPAIR;
+  const int r_lo = part * ROWS, r_hi = r_lo + ROWS;
+  const int x = 14 * (2 * pair + (n >> 4)) - 1 + (n & 15);
   const bool xvalid = x >= 0 && x < W;
   const int xc = x < 0 ? 0 : (x >= W ? W - 1 : x);
   const int ldc = a.ldc;
   const unsigned rowpitch = (unsigned)W * ldc * 2;
   unsigned char *fb = (unsigned char *)(a.buf + (size_t)blockIdx.x * H * W * ldc);
-  const unsigned colb = (unsigned)xc * ldc * 2 + 32 * g4;     // full super-steps: 32 B per lane
-  const unsigned colh = (unsigned)xc * ldc * 2 + 16 * g4;     // the trailing half super-step: 16 B per lane
-  const bool store_ok = n >= 1 && n <= 14;
-  const unsigned outb = store_ok ? (unsigned)xc * ldc * 2 + K * 2 + 16 * g4 : 0x80000000u;
+  const unsigned colb = (unsigned)xc * ldc * 2 + 64 * h;     // full super-steps: 64 B per lane
+  const unsigned colh = (unsigned)xc * ldc * 2 + 32 * h;     // the trailing half super-step: 32 B per lane
+  const bool store_ok = (n & 15) >= 1 && (n & 15) <= 14;
+  const unsigned outb = (unsigned)xc * ldc * 2 + K * 2 + 32 * h;
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(fb, 0, (int)((unsigned)H * rowpitch), 0x00020000);
 
   const unsigned char *w1l = smem + G::W1OFF + lane * 16;
   const unsigned char *w3l = smem + lane * 16;
   const float *tab1 = (const float *)(smem + G::T1OFF);
-  const unsigned tab2_lane = xvalid ? (unsigned)(G::T2OFF + 16 * g4) : (unsigned)G::ZOFF;
+  const unsigned tab2_lane = xvalid ? (unsigned)(G::T2OFF + 16 * h) : (unsigned)G::ZOFF;   // BN2 of padding columns: scale 0, shift 0
 
   // ================= state that lives across slots =================
-  u32x4 ring[3][4][2];   // activation ring [slot][row][k-step of the super-step]: 16 B per lane = 8 channels of the row's pixel
-  // (the bottleneck window - row Y - 1 + i of the group of output rows Y .. Y + 3 in window row i - lives in a[160:255])
-  f32x4 acc[4][8];       // 1x1 accumulators [row][16-channel fragment]
-  u32x4 wa[8];           // 1x1 weight fragments of the current k-step (reloaded for the next one behind their last use)
-  u32x4 xb[2][4];        // BN1 + ReLU'd pixel fragments [k-step parity][row]
-  float cs[2][8], ct[2][8];   // BN1 constants [k-step parity]
-  float bnt0 = 0.f, bnt1 = 0.f;
-  u32x4 w3f[6];          // 3x3 weight fragments [dx * 2 + of] of the current (dy, t) step
-  f32x4 bacc[2][2][3][2];   // 3x3 accumulators [row pair][row][dx][of]
-  float4 e_sv[2], e_tv[2];  // epilogue A: BN2 constants [fragment parity]
+  u32x4 ring[5][4];      // activation ring [super-step][k-step]: 16 B per lane = 8 channels of the lane's pixel; holds one row
+  f32x16 acc[4];         // 1x1 accumulators [32-channel block]
+  // every LDS read is issued two k-steps (6 - 8 slots, >= 200 cycles) ahead of its consumer: with one wave per SIMD nothing
+  // else covers an exposed LDS round trip
+  u32x4 wa[2][4];        // 1x1 weight fragments [k-step parity][block] (a register is reloaded for k-step + 2 behind its MFMA)
+  u32x4 xb[2];           // BN1 + ReLU'd pixel fragment [k-step parity]
+  float cs[3][8], ct[3][8];   // BN1 constants [k-step % 3]
+  u32x4 w3f[2][3];       // 3x3 weight fragments [step parity][dx] (reloaded for step + 2 behind their MFMA)
+  f32x16 bacc[3];        // 3x3 accumulators [dx]
+  float4 e_sv[3], e_tv[3];  // epilogue A: BN2 constants [group % 3]
   float e_f[4];
   unsigned e_pk[4];
-  float o_v[4];
-  u32x4 o_pk;
+  unsigned o_pk[8];
 
-  auto rowbase = [&](int y) __attribute__((always_inline)) {
+  auto rowbase = [&](int y) TN_INL {
     const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
     return fb + (unsigned)yc * rowpitch;
   };
-  // one 16-byte activation load: item i of the 8 (4 for the trailing half super-step) of ring slot SLOT <- super-step U, rows y0 ..
-  auto ld_item = [&](auto slot_tag, auto u_tag, auto i_tag, int y0) __attribute__((always_inline)) {
-    constexpr int SLOT = decltype(slot_tag)::value, U = decltype(u_tag)::value, I = decltype(i_tag)::value;
+  // one 16-byte activation load: k-step I of super-step U of row y -> ring[U][I]
+  auto ld_item = [&](auto u_tag, auto i_tag, int y) TN_INL {
+    constexpr int U = decltype(u_tag)::value, I = decltype(i_tag)::value;
     constexpr bool HALF = ODD && U == NSU - 1;
-    if ((TN_DS_EXP & 1) && y0 > r_lo) return;
     if constexpr (HALF) {
-      if constexpr (I < 4) ring[SLOT][I][0] = *(const u32x4 *)(rowbase(y0 + I) + colh + 128 * U);
+      if constexpr (I < 2) ring[U][I] = *(const u32x4 *)(rowbase(y) + colh + 128 * U + 16 * I);
     } else {
-      ring[SLOT][I >> 1][I & 1] = *(const u32x4 *)(rowbase(y0 + (I >> 1)) + colb + 128 * U + 16 * (I & 1));
+      ring[U][I] = *(const u32x4 *)(rowbase(y) + colb + 128 * U + 16 * I);
     }
   };
-  auto consts_item = [&](auto q_tag, auto p_tag) __attribute__((always_inline)) {     // one ds_read_b128 of k-step Q's BN1 constants (P: s lo, s hi, t lo, t hi)
+  auto consts_item = [&](auto q_tag, auto p_tag) TN_INL {     // one ds_read_b128 of k-step Q's BN1 constants (P: s lo, s hi, t lo, t hi)
     constexpr int Q = decltype(q_tag)::value, P = decltype(p_tag)::value;
-    constexpr int U = Q >> 1, I = Q & 1;
-    constexpr bool half = ODD && Q == KS - 1;
-    const int c0 = (half ? 64 * U + 8 * g4 : 64 * U + 16 * g4 + 8 * I) + (P & 1) * 4 + (P >> 1) * K;
+    constexpr int U = Q >> 2, I = Q & 3;
+    constexpr bool HALF = ODD && U == NSU - 1;
+    const int c0 = (HALF ? 64 * U + 16 * h : 64 * U + 32 * h) + 8 * I + (P & 1) * 4 + (P >> 1) * K;
     const float4 v = *(const float4 *)(tab1 + c0);
-    float *d = (P >> 1) ? ct[Q & 1] : cs[Q & 1];
+    float *d = (P >> 1) ? ct[Q % 3] : cs[Q % 3];
     d[(P & 1) * 4 + 0] = v.x; d[(P & 1) * 4 + 1] = v.y; d[(P & 1) * 4 + 2] = v.z; d[(P & 1) * 4 + 3] = v.w;
   };
-  auto wa_item = [&](auto q_tag, auto mf_tag) __attribute__((always_inline)) {
-    constexpr int Q = decltype(q_tag)::value, MF = decltype(mf_tag)::value;
-    wa[MF] = *(const u32x4 *)(w1l + (Q * 8 + MF) * 1024);
+  auto wa_item = [&](auto q_tag, auto mb_tag) TN_INL {
+    constexpr int Q = decltype(q_tag)::value, MB = decltype(mb_tag)::value;
+    wa[Q & 1][MB] = *(const u32x4 *)(w1l + (Q * 4 + MB) * 1024);
   };
-  // BN1 + ReLU micro-item I of k-step Q (two VALU instructions): row I >> 3, dword (I >> 1) & 3, first / second half
-  auto bn_item = [&](auto q_tag, auto i_tag) __attribute__((always_inline)) {
-    constexpr int Q = decltype(q_tag)::value, I = decltype(i_tag)::value;
-    constexpr int U = Q >> 1, SLOT = U % 3, R = I >> 3, J = (I >> 1) & 3;
-    float &t0 = bnt0, &t1 = bnt1;     // (asm operands alone do not capture in a generic lambda)
-    if constexpr ((I & 1) == 0) {
-      const unsigned in = ring[SLOT][R][Q & 1][J];
-      const float s0 = cs[Q & 1][2 * J], s1 = cs[Q & 1][2 * J + 1], h0 = ct[Q & 1][2 * J], h1 = ct[Q & 1][2 * J + 1];
-      asm("v_fma_mix_f32 %0, %2, %3, %4 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %2, %5, %6 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-          : "=&v"(t0), "=&v"(t1) : "v"(in), "v"(s0), "v"(h0), "v"(s1), "v"(h1));
-    } else {
-      unsigned o;
-      asm("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_f16 %0, %0, 0" : "=v"(o) : "v"(t0), "v"(t1));
-      xb[Q & 1][R][J] = o;
-    }
+  // BN1 + ReLU of dword J of k-step Q's pixel fragment (fp32 fma, one rounding, packed ReLU)
+  auto bn_item = [&](auto q_tag, auto j_tag) TN_INL {
+    constexpr int Q = decltype(q_tag)::value, J = decltype(j_tag)::value;
+    const unsigned in = ring[Q >> 2][Q & 3][J];
+    const float s0 = cs[Q % 3][2 * J], s1 = cs[Q % 3][2 * J + 1], h0 = ct[Q % 3][2 * J], h1 = ct[Q % 3][2 * J + 1];
+    float t0, t1;
+    unsigned o;
+    asm("v_fma_mix_f32 %0, %2, %3, %4 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %2, %5, %6 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(t0), "=&v"(t1) : "v"(in), "v"(s0), "v"(h0), "v"(s1), "v"(h1));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_f16 %0, %0, 0" : "=v"(o) : "v"(t0), "v"(t1));
+    xb[Q & 1][J] = o;
   };
-  // everything the first k-step of a group needs, as 16 + 8 NR items: constants of k-steps 0 and 1, the weight fragments and
-  // the BN'd pixel fragments of k-step 0 (run as fillers of the PREVIOUS group's 3x3 phase, or exposed at the start)
-  auto pro_item = [&](auto nr_tag, auto i_tag) __attribute__((always_inline)) {
-    constexpr int NR = decltype(nr_tag)::value, I = decltype(i_tag)::value;
-    if constexpr (I < 4) consts_item(ic<0>{}, ic<I>{});
-    else if constexpr (I < 8) { if constexpr (KS > 1) consts_item(ic<1>{}, ic<I - 4>{}); }
-    else if constexpr (I < 16) wa_item(ic<0>{}, ic<I - 8>{});
-    else if constexpr (I < 16 + 8 * NR) bn_item(ic<0>{}, ic<I - 16>{});
+  // everything the first k-steps of a row need, as 24 items: constants of k-steps 0 - 2, the weight fragments of k-steps 0
+  // and 1, the BN'd pixel fragment of k-step 0 (run as fillers of the PREVIOUS row's 3x3 phase, or exposed at the start)
+  auto pro_item = [&](auto i_tag) TN_INL {
+    constexpr int I = decltype(i_tag)::value;
+    if constexpr (I < 12) consts_item(ic<I / 4>{}, ic<I % 4>{});
+    else if constexpr (I < 20) wa_item(ic<(I - 12) / 4>{}, ic<(I - 12) % 4>{});
+    else if constexpr (I < 24) bn_item(ic<0>{}, ic<I - 20>{});
+  };
+  auto prologue_exposed = [&]() TN_INL {
+    static_for<24>([&](auto i_tag) TN_INL { pro_item(i_tag); });
+    TN_SB();
   };
 
-  // ---- epilogue A items: acc rows R0, R0 + 1 -> win[2 + R0], win[3 + R0]; 36 items per row ----
-  unsigned e_tb = 0;
-  auto epa_consts = [&](auto mf_tag, auto buf_tag) __attribute__((always_inline)) {
-    constexpr int MF = decltype(mf_tag)::value, B = decltype(buf_tag)::value;
-    e_sv[B] = *(const float4 *)(smem + e_tb + 64 * MF);
-    e_tv[B] = *(const float4 *)(smem + e_tb + 512 + 64 * MF);
+  // ---- epilogue A: acc -> BN2 + ReLU (fp32), one rounding to fp16, lane-local pack -> window row PROW; 48 sub-items ----
+  // sub-item E: block MB = E / 12, register group G4 = (E % 12) / 3 (accumulators 4 G4 .. 4 G4 + 3 = bottleneck channels
+  // 32 MB + 8 G4 + 4 h + (0..3)), part (E % 3): 0 the constants of the NEXT group + the first two fmas, 1 the other two,
+  // 2 convert / ReLU (+ the window write behind every second group)
+  auto epa_consts = [&](auto l_tag) TN_INL {
+    constexpr int L = decltype(l_tag)::value;      // group 4 MB + G4
+    e_sv[L % 3] = *(const float4 *)(smem + tab2_lane + 32 * L);
+    e_tv[L % 3] = *(const float4 *)(smem + tab2_lane + 512 + 32 * L);
   };
-  auto epa_set_row = [&](int y) __attribute__((always_inline)) { e_tb = (y >= 0 && y < H) ? tab2_lane : (unsigned)G::ZOFF; };   // rows above / below the image are zero
-  auto epa_item = [&](auto r0_tag, auto i_tag, int ynew) __attribute__((always_inline)) {
-    constexpr int R0 = decltype(r0_tag)::value, I = decltype(i_tag)::value;
-    constexpr int R = R0 + I / 36, KI = I % 36, T = KI / 9, J = KI % 9;
+  auto epa_item = [&](auto prow_tag, auto e_tag) TN_INL {
+    constexpr int PROW = decltype(prow_tag)::value, E = decltype(e_tag)::value;
+    constexpr int MB = E / 12, G4 = (E % 12) / 3, P = E % 3, L = 4 * MB + G4;
     float (&ef)[4] = e_f;             // (asm operands alone do not capture in a generic lambda)
     unsigned (&epk)[4] = e_pk;
-    f32x4 (&accr)[4][8] = acc;
-    if constexpr (J == 8) {
-      win_write<2 + R, T>(epk[0], epk[1], epk[2], epk[3]);
+    f32x16 (&accr)[4] = acc;
+    if constexpr (P == 0) {
+      if constexpr (L + 2 < 16) epa_consts(ic<L + 2>{});
+    }
+    if constexpr (P <= 1) {
+      constexpr int C = P * 2;
+      const float4 sv = e_sv[L % 3], tv = e_tv[L % 3];
+      const float s0 = C ? sv.z : sv.x, s1 = C ? sv.w : sv.y, t0 = C ? tv.z : tv.x, t1 = C ? tv.w : tv.y;
+      const float a0 = accr[MB][4 * G4 + C], a1 = accr[MB][4 * G4 + C + 1];
+      asm("v_fma_f32 %0, %2, %3, %4\n\tv_fma_f32 %1, %5, %6, %7" : "=&v"(ef[C]), "=&v"(ef[C + 1]) : "v"(a0), "v"(s0), "v"(t0), "v"(a1), "v"(s1), "v"(t1));
     } else {
-      constexpr int E = J >> 2, P = J & 3, MF = 2 * T + E;
-      if constexpr (P == 0) {            // constants of the NEXT fragment (of the next row behind the last one)
-        if constexpr (MF < 7) epa_consts(ic<MF + 1>{}, ic<(MF + 1) & 1>{});
-        else if constexpr (I / 36 == 0) { epa_set_row(ynew + R + 1); epa_consts(ic<0>{}, ic<0>{}); }
-      } else if constexpr (P == 1 || P == 2) {
-        constexpr int C = (P - 1) * 2;
-        const float4 sv = e_sv[MF & 1], tv = e_tv[MF & 1];
-        const float s0 = C ? sv.z : sv.x, s1 = C ? sv.w : sv.y, t0 = C ? tv.z : tv.x, t1 = C ? tv.w : tv.y;
-        const float a0 = accr[R][MF][C], a1 = accr[R][MF][C + 1];
-        asm("v_fma_f32 %0, %2, %3, %4\n\tv_fma_f32 %1, %5, %6, %7" : "=&v"(ef[C]), "=&v"(ef[C + 1]) : "v"(a0), "v"(s0), "v"(t0), "v"(a1), "v"(s1), "v"(t1));
-      } else {
-        asm("v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5\n\tv_pk_max_f16 %0, %0, 0\n\tv_pk_max_f16 %1, %1, 0"
-            : "=&v"(epk[2 * E]), "=&v"(epk[2 * E + 1]) : "v"(ef[0]), "v"(ef[1]), "v"(ef[2]), "v"(ef[3]));
-      }
+      constexpr int E2 = G4 & 1;
+      asm("v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5\n\tv_pk_max_f16 %0, %0, 0\n\tv_pk_max_f16 %1, %1, 0"
+          : "=&v"(epk[2 * E2]), "=&v"(epk[2 * E2 + 1]) : "v"(ef[0]), "v"(ef[1]), "v"(ef[2]), "v"(ef[3]));
+      if constexpr (E2 == 1) win_write<PROW, 2 * MB + (G4 >> 1)>(epk[0], epk[1], epk[2], epk[3]);
     }
   };
-  // ---- epilogue B items: output rows of row pair RP (12 items per row): out[x] = acc[dx=0][x] + acc[dx=-1][x-1] + acc[dx=+1][x+1] ----
-  auto epb_item = [&](auto rp_tag, auto i_tag, int y0) __attribute__((always_inline)) {
-    constexpr int RP = decltype(rp_tag)::value, I = decltype(i_tag)::value;
-    constexpr int R = I / 12, KI = I % 12, OF = KI / 6, J = KI % 6;
-    if constexpr (J == 0) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) o_v[c] = bacc[RP][R][1][OF][c];
-    } else if constexpr (J <= 4) {
-      constexpr int DX = J <= 2 ? 0 : 2, C = ((J - 1) & 1) * 2;
-      if constexpr (DX == 0) {
-        o_v[C] += dpp_f32<0x111>(bacc[RP][R][0][OF][C]);           // row_shr:1: lane x reads lane x - 1
-        o_v[C + 1] += dpp_f32<0x111>(bacc[RP][R][0][OF][C + 1]);
-      } else {
-        o_v[C] += dpp_f32<0x101>(bacc[RP][R][2][OF][C]);           // row_shl:1: lane x reads lane x + 1
-        o_v[C + 1] += dpp_f32<0x101>(bacc[RP][R][2][OF][C + 1]);
-      }
-    } else {
-      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-      const h2 p0 = {(f16)o_v[0], (f16)o_v[1]}, p1 = {(f16)o_v[2], (f16)o_v[3]};
-      o_pk[OF * 2] = __builtin_bit_cast(unsigned, p0);
-      o_pk[OF * 2 + 1] = __builtin_bit_cast(unsigned, p1);
-      // (the two halo lanes carry an offset past the descriptor's range: the hardware drops their store, no branch)
-      if constexpr (OF == 1) __builtin_amdgcn_raw_buffer_store_b128(o_pk, orsrc, outb + (unsigned)(y0 + 2 * RP + R) * rowpitch, 0, 0);
+  auto epilogue_a_exposed = [&](auto prow_tag) TN_INL {
+    static_for<48>([&](auto e_tag) TN_INL { epa_item(prow_tag, e_tag); });
+    TN_SB();
+  };
+  // ---- epilogue B: 8 items; item P: out channels 16 h + 2 P, + 1 of the lane's pixel: out[x] = acc[dx=0][x] + acc[dx=-1][x-1] +
+  // acc[dx=+1][x+1], fp16; 16 B stored behind every fourth.  `off`: byte offset of the lane's 32 B (halo lanes / no previous
+  // row: past the descriptor's range - the hardware drops the store, no branch) ----
+  auto epb_item = [&](auto p_tag, unsigned off) TN_INL {
+    constexpr int P = decltype(p_tag)::value;
+    const float v0 = bacc[1][2 * P] + dpp_f32<0x111>(bacc[0][2 * P]) + dpp_f32<0x101>(bacc[2][2 * P]);   // row_shr:1: lane x reads x - 1; row_shl:1: x + 1
+    const float v1 = bacc[1][2 * P + 1] + dpp_f32<0x111>(bacc[0][2 * P + 1]) + dpp_f32<0x101>(bacc[2][2 * P + 1]);
+    const h2_t p = {(f16)v0, (f16)v1};
+    o_pk[P] = __builtin_bit_cast(unsigned, p);
+    if constexpr (P == 3 || P == 7) {
+      const u32x4 o = {o_pk[P - 3], o_pk[P - 2], o_pk[P - 1], o_pk[P]};
+      __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, off + (P == 7 ? 16 : 0), 0, 0);
     }
   };
-  auto w3_item = [&](auto s_tag, auto f_tag) __attribute__((always_inline)) {
-    constexpr int S = decltype(s_tag)::value, F = decltype(f_tag)::value;
-    w3f[F] = *(const u32x4 *)(w3l + (S * 6 + F) * 1024);
+  auto out_offset = [&](int yo, bool valid) TN_INL { return (valid && store_ok) ? outb + (unsigned)yo * rowpitch : 0x80000000u; };
+  auto bacc_ready = [&]() TN_INL {   // an asm MFMA's result may be read by anything but the next MFMA of its chain only 18+ wait states after issue
+    f32x16 (&b)[3] = bacc;
+    asm volatile("s_nop 15\n\ts_nop 3" : "+a"(b[0]), "+a"(b[1]), "+a"(b[2]));
+  };
+  auto epilogue_b_exposed = [&](int yo) TN_INL {
+    bacc_ready();
+    const unsigned off = out_offset(yo, true);
+    static_for<8>([&](auto p_tag) TN_INL { epb_item(p_tag, off); });
+    TN_SB();
+  };
+  auto w3_item = [&](auto s_tag, auto dx_tag) TN_INL {
+    constexpr int S = decltype(s_tag)::value, DX = decltype(dx_tag)::value;
+    w3f[S & 1][DX] = *(const u32x4 *)(w3l + (S * 3 + DX) * 1024);
   };
 
-  // ================= 1x1 phase: NR new bottleneck rows ynew ..; reloads the ring for this group / the group at ynext =================
-  auto phase_a = [&](auto nr_tag, int ynew, int ynext) __attribute__((always_inline)) {
-    constexpr int NR = decltype(nr_tag)::value;
-    static_for<KS>([&](auto q_tag) __attribute__((always_inline)) {
+  // ================= 1x1 phase of one bottleneck row (the ring holds it; it is refilled with row ynext) =================
+  // fillers: BN1 of the next k-step, weight fragments / constants one and two k-steps ahead, the ring refill behind a
+  // super-step's last k-step, epilogue B of the previous output row (yo_prev), the first BN2 constants of this row
+  auto phase_a = [&](int ynext, int yo_prev, bool prev_valid) TN_INL {
+    constexpr int NSLOT = 4 * KQ;
+    bacc_ready();
+    const unsigned off_prev = out_offset(yo_prev, prev_valid);
+    static_for<KQ>([&](auto q_tag) TN_INL {
       constexpr int Q = decltype(q_tag)::value;
-      // the ring slot whose last k-step is Q has been read out (its BN items ran during step Q - 1): it is reloaded during this step
-      constexpr int UL = Q >> 1;
-      constexpr bool RELOAD = (Q & 1) == 1 || (ODD && Q == KS - 1);
-      static_for<8 * NR>([&](auto i_tag) __attribute__((always_inline)) {
-        constexpr int I = decltype(i_tag)::value;
-        constexpr int MF = I / NR, R = I % NR;
-        if constexpr (Q == 0) acc[R][MF] = mfma16(wa[MF], xb[0][R], (f32x4){0.f, 0.f, 0.f, 0.f});
-        else acc[R][MF] = mfma16(wa[MF], xb[Q & 1][R], acc[R][MF]);
-        if constexpr (Q + 1 < KS) {
-          bn_item(ic<Q + 1>{}, i_tag);
-          if constexpr (R == NR - 1) wa_item(ic<Q + 1>{}, ic<MF>{});
-        }
-        if constexpr (Q + 2 < KS && (I % (2 * NR)) == 1) consts_item(ic<Q + 2>{}, ic<I / (2 * NR)>{});
-        if constexpr (RELOAD && (I % NR) == (NR > 2 ? 2 : 0) && I / NR < 8) {
-          if constexpr (UL + 3 < NSU) ld_item(ic<UL % 3>{}, ic<UL + 3>{}, ic<I / NR>{}, ynew);
-          else ld_item(ic<UL % 3>{}, ic<UL % 3>{}, ic<I / NR>{}, ynext);
-        }
-        TN_SB();
-      });
-    });
-  };
-  // epilogue A of rows R0, R0 + 1, exposed (no MFMAs beside it)
-  auto epilogue_a = [&](auto r0_tag, int ynew) __attribute__((always_inline)) {
-    constexpr int R0 = decltype(r0_tag)::value;
-    epa_set_row(ynew + R0);
-    epa_consts(ic<0>{}, ic<0>{});
-    static_for<72>([&](auto i_tag) __attribute__((always_inline)) { epa_item(r0_tag, i_tag, ynew + R0 - decltype(r0_tag)::value); });
-  };
-
-  // ================= 3x3 phase: NR output rows y0 .. from win[0 .. NR + 1] =================
-  // row-pair-major: the two MFMAs of a slot apply one weight fragment to the two rows of the pair.  Fillers of the first pair:
-  // epilogue A of the 1x1 rows 2, 3 (their window rows are first needed by the second pair); of the second pair (of the only
-  // pair of a half group): epilogue B of the first pair, then the next group's 1x1 prologue.
-  auto phase_b = [&](auto nr_tag, auto nrnext_tag, int y0, int ynew) __attribute__((always_inline)) {
-    constexpr int NR = decltype(nr_tag)::value, NRNEXT = decltype(nrnext_tag)::value;
-    constexpr int NP = NR / 2;
-    static_for<NP>([&](auto rp_tag) __attribute__((always_inline)) {
-      constexpr int RP = decltype(rp_tag)::value;
-      f32x4 (&bq)[2][2][3][2] = bacc;
-      if constexpr (RP == 1) {      // the first pair's accumulators are read by this pair's fillers
-        asm volatile("s_nop 7" : "+a"(bq[0][0][0][0]), "+a"(bq[0][0][0][1]), "+a"(bq[0][0][1][0]), "+a"(bq[0][0][1][1]), "+a"(bq[0][0][2][0]), "+a"(bq[0][0][2][1]),
-                                 "+a"(bq[0][1][0][0]), "+a"(bq[0][1][0][1]), "+a"(bq[0][1][1][0]), "+a"(bq[0][1][1][1]), "+a"(bq[0][1][2][0]), "+a"(bq[0][1][2][1]));
-      }
-      static_for<72>([&](auto s_tag) __attribute__((always_inline)) {
-        constexpr int SL = decltype(s_tag)::value;
-        constexpr int S = SL / 6, F = SL % 6, DY = S / 4, T = S % 4;
-        mfma16_pair<S == 0, 2 * RP + DY, T>(bacc[RP][0][F >> 1][F & 1], bacc[RP][1][F >> 1][F & 1], w3f[F]);
-        // this fragment's register takes the fragment of the next step (of the next pair's first step)
-        if constexpr (S < 11) w3_item(ic<S + 1>{}, ic<F>{});
-        else if constexpr (RP + 1 < NP) w3_item(ic<0>{}, ic<F>{});
-        if constexpr (NP == 2 && RP == 0) {
-          epa_item(ic<2>{}, s_tag, ynew);
+      constexpr int U = Q >> 2;
+      constexpr bool HALFU = ODD && U == NSU - 1;
+      constexpr bool LAST_OF_U = HALFU ? (Q & 3) == 1 : (Q & 3) == 3;
+      static_for<4>([&](auto mb_tag) TN_INL {
+        constexpr int MB = decltype(mb_tag)::value, SL = 4 * Q + MB;
+        if constexpr (Q == 0) {
+          f32x16 z;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) z[i] = 0.f;
+          acc[MB] = mfma32(wa[0][MB], xb[0], z);
         } else {
-          constexpr int PRO0 = NP == 2 ? 24 : 0;        // (a half group: epilogue B runs exposed behind the phase)
-          if constexpr (NP == 2 && SL < 24) epb_item(ic<0>{}, s_tag, y0);
-          else if constexpr (NRNEXT > 0 && SL - PRO0 < 16 + 8 * NRNEXT) pro_item(nrnext_tag, ic<SL - PRO0>{});
+          acc[MB] = mfma32(wa[Q & 1][MB], xb[Q & 1], acc[MB]);
         }
+        if constexpr (Q + 1 < KQ) bn_item(ic<Q + 1>{}, mb_tag);
+        if constexpr (Q + 2 < KQ) wa_item(ic<Q + 2>{}, mb_tag);
+        if constexpr (Q + 3 < KQ) consts_item(ic<Q + 3>{}, mb_tag);
+        if constexpr (LAST_OF_U) {
+          if (!(TN_DS_EXP & 1)) ld_item(ic<U>{}, mb_tag, ynext);
+        }
+        // epilogue B item P sits in slot P * NSLOT / 8
+        static_for<8>([&](auto p_tag) TN_INL {
+          constexpr int P = decltype(p_tag)::value;
+          if constexpr ((P * NSLOT) / 8 == SL) epb_item(p_tag, off_prev);
+        });
+        if constexpr (SL == NSLOT - 2) epa_consts(ic<0>{});
+        if constexpr (SL == NSLOT - 1) epa_consts(ic<1>{});
+        TN_WIN_FENCE();
         TN_SB();
       });
     });
-    // the last pair's accumulators: wait, then epilogue B exposed
-    constexpr int LP = NP - 1;
-    asm volatile("s_nop 15" : "+a"(bacc[LP][0][0][0]), "+a"(bacc[LP][0][0][1]), "+a"(bacc[LP][0][1][0]), "+a"(bacc[LP][0][1][1]), "+a"(bacc[LP][0][2][0]), "+a"(bacc[LP][0][2][1]),
-                              "+a"(bacc[LP][1][0][0]), "+a"(bacc[LP][1][0][1]), "+a"(bacc[LP][1][1][0]), "+a"(bacc[LP][1][1][1]), "+a"(bacc[LP][1][2][0]), "+a"(bacc[LP][1][2][1]));
-    static_for<24>([&](auto i_tag) __attribute__((always_inline)) { epb_item(ic<LP>{}, i_tag, y0); });
-  };
-  auto load_w3_first = [&]() __attribute__((always_inline)) { static_for<6>([&](auto f_tag) __attribute__((always_inline)) { w3_item(ic<0>{}, f_tag); }); };
-  // one group of NR output rows y .. (new bottleneck rows y + 1 ..), the next group has NRNEXT rows (0: none)
-  auto group = [&](auto nr_tag, auto nrnext_tag, int y) __attribute__((always_inline)) {
-    constexpr int NR = decltype(nr_tag)::value;
-    win_shift();
-    TN_SB();
-    if (!(TN_DS_EXP & 4)) phase_a(nr_tag, y + 1, y + 1 + NR);
-    load_w3_first();
-    if (!(TN_DS_EXP & 4)) epilogue_a(ic<0>{}, y + 1);
-    TN_SB();
-    if (!(TN_DS_EXP & 2)) phase_b(nr_tag, nrnext_tag, y, y + 1);
-    TN_SB();
   };
 
-  // ================= the wave's program: rows r_lo - 1, r_lo first, then groups of four output rows (+ a half group) =================
-  static_for<3>([&](auto u_tag) __attribute__((always_inline)) {
-    constexpr int U = decltype(u_tag)::value;
-    if constexpr (U < NSU) static_for<8>([&](auto i_tag) __attribute__((always_inline)) { ld_item(u_tag, u_tag, i_tag, r_lo - 1); });
-  });
-  static_for<16 + 16>([&](auto i_tag) __attribute__((always_inline)) { pro_item(ic<2>{}, i_tag); });
-  TN_SB();
-  phase_a(ic<2>{}, r_lo - 1, r_lo + 1);
-  epilogue_a(ic<0>{}, r_lo - 1);
-  win_copy2<4, 2>();
-  constexpr int NFIRST = G::NG > 0 ? 4 : 2;
-  static_for<16 + 8 * NFIRST>([&](auto i_tag) __attribute__((always_inline)) { pro_item(ic<NFIRST>{}, i_tag); });
-  TN_SB();
-  int y = r_lo;
-  for (int g = 0; g + 1 < G::NG; ++g, y += 4) group(ic<4>{}, ic<4>{}, y);
-  if constexpr (G::NG > 0) {
-    group(ic<4>{}, ic<(G::TAIL ? 2 : 0)>{}, y);
-    y += 4;
+  // ================= 3x3 phase of one output row: window rows (ROT + 1) % 3, (ROT + 2) % 3, ROT (the new one) =================
+  // slot (dy, k-step, dx); the first 48 slots (dy = -1, 0: the two older rows) carry epilogue A of the new row into window row
+  // ROT, the last 24 the next row's first operands
+  auto phase_b = [&](auto rot_tag, auto epa_tag) TN_INL {
+    constexpr int ROT = decltype(rot_tag)::value;
+    constexpr bool HAS_EPA = decltype(epa_tag)::value != 0;
+    static_for<72>([&](auto e_tag) TN_INL {
+      constexpr int E = decltype(e_tag)::value;
+      constexpr int S = E / 3, DX = E % 3, DY = S / 8, T = S % 8;
+      constexpr int PROW = (ROT + 1 + DY) % 3;
+      mfma32_win<S == 0, PROW, T>(bacc[DX], w3f[S & 1][DX]);
+      if constexpr (S + 2 < 24) w3_item(ic<S + 2>{}, ic<DX>{});
+      if constexpr (E < 48) {
+        if constexpr (HAS_EPA) epa_item(rot_tag, e_tag);
+      } else {
+        pro_item(ic<E - 48>{});
+      }
+      TN_WIN_FENCE();
+      TN_SB();
+    });
+  };
+  auto load_w3_first = [&]() TN_INL { static_for<6>([&](auto i_tag) TN_INL { w3_item(ic<decltype(i_tag)::value / 3>{}, ic<decltype(i_tag)::value % 3>{}); }); };
+
+  int nstamp = 0;
+  auto stamp = [&]() TN_INL {
+    if (a.ts && wid == 0 && nstamp < 128) {
+      if (lane == 0) a.ts[(size_t)blockIdx.x * 128 + nstamp] = __builtin_amdgcn_s_memtime();
+      ++nstamp;
+    }
+  };
+  // one steady-state row: bottleneck row yb (1x1 phase, into window row ROT through the 3x3 phase's fillers), output row yb - 1
+  auto row_event = [&](auto rot_tag, int yb, bool prev_valid) TN_INL {
+    stamp();
+    if (!(TN_DS_EXP & 4)) phase_a(yb + 1, yb - 2, prev_valid);
+    load_w3_first();
+    TN_SB();
+    stamp();
+    if (!(TN_DS_EXP & 2)) phase_b(rot_tag, ic<1>{});
+  };
+
+  // ================= the wave's program =================
+  {   // accumulators of the 3x3 start defined (the first 1x1 phases run an epilogue B whose store is dropped)
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    bacc[0] = z; bacc[1] = z; bacc[2] = z;
   }
-  if constexpr (G::TAIL) group(ic<2>{}, ic<0>{}, y);
+#ifdef TN_DS_STAGGER
+  // the four waves of a CU (and neighbouring CUs) start their row loops a fraction of a row period apart, so that the 1x1
+  // phases - the only ones that issue activation loads - do not all fall together
+  for (int i = 0; i < ((wid + (int)blockIdx.x) & 3) * TN_DS_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);
+#endif
+  stamp();
+  const int yfirst = r_lo > 0 ? r_lo - 1 : 0;
+  static_for<NSU>([&](auto u_tag) TN_INL { static_for<4>([&](auto i_tag) TN_INL { ld_item(u_tag, i_tag, yfirst); }); });
+  // bottleneck row r_lo - 1 -> window row 0 (zeros above the image)
+  if (r_lo > 0) {
+    prologue_exposed();
+    phase_a(r_lo, 0, false);
+    epilogue_a_exposed(ic<0>{});
+  } else {
+    win_zero<0>();
+  }
+  // bottleneck row r_lo -> window row 1
+  prologue_exposed();
+  phase_a(r_lo + 1, 0, false);
+  epilogue_a_exposed(ic<1>{});
+  prologue_exposed();
+  stamp();
+  // rows r_lo + 1 .. r_hi - 1: the steady state, window rotation 2, 0, 1, ...
+  int yb = r_lo + 1;
+  for (; yb + 2 < r_hi; yb += 3) {
+    row_event(ic<2>{}, yb, yb > r_lo + 1);
+    row_event(ic<0>{}, yb + 1, true);
+    row_event(ic<1>{}, yb + 2, true);
+  }
+  constexpr int NREM = (ROWS - 1) % 3;          // steady-state rows left over
+  if constexpr (NREM >= 1) { row_event(ic<2>{}, yb, yb > r_lo + 1); ++yb; }
+  if constexpr (NREM >= 2) { row_event(ic<0>{}, yb, true); ++yb; }
+  // bottleneck row r_hi (zeros below the image) -> window row (ROWS + 1) % 3, output row r_hi - 1
+  constexpr int ROTL = (ROWS + 1) % 3;
+  if (r_hi < H) {
+    row_event(ic<ROTL>{}, r_hi, true);
+  } else {
+    epilogue_b_exposed(r_hi - 2);
+    win_zero<ROTL>();
+    load_w3_first();
+    TN_SB();
+    phase_b(ic<ROTL>{}, ic<0>{});
+  }
+  stamp();
+  epilogue_b_exposed(r_hi - 1);
+  stamp();
 }
 
 template <int W, int KS>
@@ -478,39 +492,38 @@ int launch_dense_strip(const DenseStripArgs &a, hipStream_t s) {
 }
 
 // ---- host-side packing (api.hip, dbg.hip) ----
-// 1x1 weights [128][K] -> A fragments [K/32 k-steps][8 m-frags][64 lanes][8]: lane l: bottleneck channel 16 mf + (l & 15),
-// input channels of 64-channel super-step u, k-step i: 64 u + 16 (l >> 4) + 8 i + j (a lane's two k-steps are 32 contiguous
-// bytes of the pixel); the trailing 32-channel step of an odd K/32: 64 u + 8 (l >> 4) + j.
+// 1x1 weights [128][K] -> v_mfma_f32_32x32x16_f16 A fragments [K/16 k-steps][4 blocks][64 lanes][8]: lane l: bottleneck channel
+// 32 mb + (l & 31); input channels of 64-channel super-step u, k-step i: 64 u + 32 (l >> 5) + 8 i + j (a lane's four k-steps
+// are 64 contiguous bytes of the pixel); the trailing 32-channel half super-step of an odd K/32: 64 u + 16 (l >> 5) + 8 i + j.
 std::vector<f16> pack_w1_strip(const float *w, int K) {
-  const int ks = K / 32;
-  std::vector<f16> p((size_t)ks * 8 * 64 * 8);
-  for (int q = 0; q < ks; ++q) {
-    const int u = q >> 1, i = q & 1;
-    const bool half = (ks & 1) && q == ks - 1;
-    for (int mf = 0; mf < 8; ++mf)
+  const int ks = K / 32, kq = K / 16, nsu = (ks + 1) / 2;
+  std::vector<f16> p((size_t)kq * 4 * 64 * 8);
+  for (int q = 0; q < kq; ++q) {
+    const int u = q >> 2, i = q & 3;
+    const bool half = (ks & 1) && u == nsu - 1;
+    for (int mb = 0; mb < 4; ++mb)
       for (int l = 0; l < 64; ++l)
         for (int j = 0; j < 8; ++j) {
-          const int c = half ? 64 * u + 8 * (l >> 4) + j : 64 * u + 16 * (l >> 4) + 8 * i + j;
-          p[(((size_t)q * 8 + mf) * 64 + l) * 8 + j] = (f16)w[(size_t)(16 * mf + (l & 15)) * K + c];
+          const int c = (half ? 64 * u + 16 * (l >> 5) : 64 * u + 32 * (l >> 5)) + 8 * i + j;
+          p[(((size_t)q * 4 + mb) * 64 + l) * 8 + j] = (f16)w[(size_t)(32 * mb + (l & 31)) * K + c];
         }
   }
   return p;
 }
 
-// 3x3 weights (32,128,3,3) -> A fragments [3 dy][4 t][3 dx][2 of][64 lanes][8]: lane l, m = l & 15: output channel
-// 8 (m >> 2) + 4 of + (m & 3) (so that a lane of the result holds 8 consecutive output channels of its pixel), bottleneck
-// channel 32 t + 16 (j >> 2) + 4 (l >> 4) + (j & 3): the order in which the 1x1's accumulators hold them.
+// 3x3 weights (32,128,3,3) -> A fragments [3 dy][8 k-steps][3 dx][64 lanes][8]: lane l, m = l & 31: output channel
+// 16 ((m >> 2) & 1) + (m & 3) + 4 (m >> 3) (so that a lane of the result holds 16 consecutive output channels of its pixel),
+// bottleneck channel 16 t + 8 (j >> 2) + 4 (l >> 5) + (j & 3): the order in which the 1x1's accumulators hold them.
 std::vector<f16> pack_w3_strip(const float *w) {
   std::vector<f16> p((size_t)kW3Bytes / 2);
   for (int dy = 0; dy < 3; ++dy)
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 8; ++t)
       for (int dx = 0; dx < 3; ++dx)
-        for (int of = 0; of < 2; ++of)
-          for (int l = 0; l < 64; ++l)
-            for (int j = 0; j < 8; ++j) {
-              const int m = l & 15, o = 8 * (m >> 2) + 4 * of + (m & 3);
-              const int c = 32 * t + 16 * (j >> 2) + 4 * (l >> 4) + (j & 3);
-              p[((((((size_t)dy * 4 + t) * 3 + dx) * 2 + of) * 64) + l) * 8 + j] = (f16)w[(((size_t)o * 128 + c) * 3 + dy) * 3 + dx];
-            }
+        for (int l = 0; l < 64; ++l)
+          for (int j = 0; j < 8; ++j) {
+            const int m = l & 31, o = 16 * ((m >> 2) & 1) + (m & 3) + 4 * (m >> 3);
+            const int c = 16 * t + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
+            p[(((((size_t)dy * 8 + t) * 3 + dx) * 64) + l) * 8 + j] = (f16)w[(((size_t)o * 128 + c) * 3 + dy) * 3 + dx];
+          }
   return p;
 }

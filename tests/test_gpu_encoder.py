@@ -185,10 +185,13 @@ def test_stem_and_encoder_at_odd_input_sizes(size, report):
         assert e < (5e-3 if name == "nhwc_u8" else TOL), (name, e)
 
 
-def test_full_batch_256_matches_small_batches(report):
-    """BASELINE.json configs[1] size (256 frames: two-stream split, XCD-remapped persistent tiles, chained blocks):
-    every frame's features must equal, bit for bit, what the same frame gives in a batch of 4 (un-split, one tile
-    per workgroup) - frames are independent and the per-frame arithmetic order does not depend on the batch."""
+def test_full_batch_256_matches_small_batches(report, monkeypatch):
+    """BASELINE.json configs[1] size (256 frames: two-stream split, one-frame-per-workgroup strip kernels in the 56x56 / 28x28
+    blocks, XCD-remapped persistent tiles, chained blocks): frames are independent and the per-frame arithmetic order of a
+    kernel does not depend on the batch, so every frame's features must equal, bit for bit, what the same frame gives in a
+    smaller batch THROUGH THE SAME KERNELS: 256 vs 128 frames on the default path (strip kernels from 64 frames per launch
+    on), 256 vs 4 frames with the strip kernels switched off (TN_NO_STRIP: the 8-wave tile kernels at every batch size).
+    The two kernel families accumulate in different orders: they agree to fp16 rounding noise, far inside 1e-3."""
     from tennis_amd import weights as W
     from tennis_amd.engine import DenseNet121Features
     p = W.make_densenet121_weights(2)
@@ -196,11 +199,19 @@ def test_full_batch_256_matches_small_batches(report):
     small = DenseNet121Features(p, 224, max_batch=4)(base)
     idx = torch.arange(256, device="cuda") % 4
     big_in = base[idx].permute(0, 2, 3, 1).contiguous().half()          # NHWC fp16, as bench.py feeds it
-    enc = DenseNet121Features(p, 224, max_batch=256)
-    big = enc(big_in)
+    big = DenseNet121Features(p, 224, max_batch=256)(big_in)
+    mid = DenseNet121Features(p, 224, max_batch=128)(big_in[:128])      # (two half batches of 64: still the strip kernels)
+    assert torch.equal(big[:128], mid)
+    assert torch.equal(big[:4], big[252:256])
     ref = DenseNet121Features(p, 224, max_batch=4)(base.permute(0, 2, 3, 1).contiguous().half())
-    assert torch.equal(big, ref[idx])
+    monkeypatch.setenv("TN_NO_STRIP", "1")
+    big_tiles = DenseNet121Features(p, 224, max_batch=256)(big_in)
+    monkeypatch.delenv("TN_NO_STRIP")
+    assert torch.equal(big_tiles, ref[idx])
     report["full_batch_vs_small_batch_bit_identical"] = True
+    d = float((big - big_tiles).abs().max())
+    report["strip_vs_tile_kernels_maxabs_diff"] = d
+    assert d < 2e-3, d          # two fp16 pipelines with independent rounding, each within 1e-3 of the fp32 oracle (test_strip_path_vs_oracle)
     # and the NHWC fp16 hand-over agrees with the reference NCHW fp32 layout to fp16 input rounding
     assert float((ref - small).abs().max()) < 2e-3
 
@@ -240,15 +251,38 @@ def test_fp32_weights_exact_mode(report):
     assert torch.equal(enc64(xd[idx].contiguous()), enc4(xd)[idx])
 
 
-@pytest.mark.parametrize("B", [1, 3, 5, 13, 40, 64, 72])
+def test_strip_path_vs_oracle(report):
+    """The batch sizes the benchmark runs (>= 64 frames per launch) take the strip kernels in the 56x56 / 28x28 blocks: 128
+    frames (two distinct ones, tiled) against the fp32 oracle on the same fp16-model parameters, same 1e-3 bar as the
+    small-batch path of test_encoder_stages."""
+    from tennis_amd import weights as W
+    from tennis_amd.engine import DenseNet121Features
+    p = W.make_densenet121_weights(0)
+    x16 = W.normalize_to_nchw_f32(W.synthetic_frames_u8(2, 224)).astype(np.float16)
+    ref = dn.densenet121_features(x16.astype(np.float32), p)
+    xd = torch.from_numpy(np.ascontiguousarray(x16.transpose(0, 2, 3, 1))).cuda()
+    idx = torch.arange(128, device="cuda") % 2
+    feat = DenseNet121Features(p, 224, max_batch=128)(xd[idx].contiguous()).cpu().numpy()
+    e = float(np.abs(feat - ref[idx.cpu().numpy()]).max())
+    report["features_224_strip_path_b128_maxabs_err"] = e
+    assert e < TOL, e
+
+
+@pytest.mark.parametrize("B", [1, 3, 5, 13, 40, 64, 72, 136])
 def test_ragged_batch_sizes(B):
     """Batch sizes that are not multiples of 8 take the un-remapped tile order, 40 / 72 are too small or too ragged for
-    the two-stream split, 64 is the smallest split batch: every frame must come out exactly as in a batch of 4."""
+    the two-stream split, 64 is the smallest split batch: every frame must come out exactly as in a batch of 4.  From 64
+    frames per launch on (72 un-split, 136 = two halves of 68) the 56x56 / 28x28 blocks run on the strip kernels: those
+    frames must come out exactly as in a batch of 128 (two halves of 64)."""
     from tennis_amd import weights as W
     from tennis_amd.engine import DenseNet121Features
     p = W.make_densenet121_weights(2)
     base = torch.from_numpy(W.normalize_to_nchw_f32(W.synthetic_frames_u8(4, 224))).cuda().permute(0, 2, 3, 1).contiguous().half()
-    ref = DenseNet121Features(p, 224, max_batch=4)(base)
+    strip = B >= 72
+    if strip:
+        ref = DenseNet121Features(p, 224, max_batch=128)(base[torch.arange(128, device="cuda") % 4].contiguous())[:4]
+    else:
+        ref = DenseNet121Features(p, 224, max_batch=4)(base)
     idx = (torch.arange(B, device="cuda") * 3) % 4
     got = DenseNet121Features(p, 224, max_batch=B)(base[idx].contiguous())
     assert got.shape == (B, 1024) and torch.equal(got, ref[idx])

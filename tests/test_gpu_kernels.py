@@ -302,7 +302,7 @@ def test_dense_strip(ctx, report, B, H, K, ldc):
              w1s=torch.from_numpy(w1s.view(np.int16)).cuda(), w3s=torch.from_numpy(w3s.view(np.int16)).cuda())
     _lib.check(ctx.lib.tn_dbg_dense_strip_dev(ctx.handle, _lib.ptr(d["buf"]), ldc, K, _lib.ptr(d["s1"]), _lib.ptr(d["t1"]),
                                               _lib.ptr(d["w1s"]), _lib.ptr(d["s2"]), _lib.ptr(d["t2"]), _lib.ptr(d["w3s"]),
-                                              B, H, H), "dense_strip")
+                                              B, H, H, None), "dense_strip")
     out = d["buf"].cpu().numpy().astype(np.float32)
     a1 = _bnrelu_h(buf[..., :K].astype(np.float32), s1, t1)
     bott = (a1.reshape(-1, K) @ w1.T).reshape(B, H, H, 128)
