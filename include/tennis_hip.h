@@ -312,13 +312,15 @@ int tn_dbg_dense_layer_dev(tn_ctx *ctx, void *buf_f16, int ldc, int K, const flo
                            int H, int W, unsigned long long *ts /* NULL or stamps */, int variant /* 0 auto, 1 big, 2 small */);
 int tn_dbg_linear(tn_ctx *ctx, const float *x, const float *w, const float *bias, float *y, int M, int N,
                   int K);
-/* The strip-streaming fused dense layer (csrc/dense_strip.hip; 56x56 / 28x28 blocks, K <= 320): fp32 (128,K) 1x1 and
- * (32,128,3,3) 3x3 weights -> the MFMA A-fragment images the kernel keeps resident in LDS (K*128 and 36864 halves;
- * either pair of pointers may be NULL), and one asynchronous launch on device-resident packed operands. */
-int tn_dbg_pack_strip(const float *w1_host, int K, uint16_t *w1s_out, const float *w3_host, uint16_t *w3s_out);
+/* The strip-streaming fused dense layer (csrc/dense_strip.hip; 56x56 / 28x28 blocks, K <= 320): fp32 (128,K) 1x1 weights
+ * with the folded scale / shift (128 each) of the BatchNorm behind them, and (32,128,3,3) 3x3 weights -> the MFMA
+ * A-fragment images the kernel keeps resident in LDS ((K+16)*128 and 36864 halves; either output may be NULL), and one
+ * asynchronous launch on device-resident packed operands. */
+int tn_dbg_pack_strip(const float *w1_host, int K, const float *s2_host, const float *t2_host, uint16_t *w1s_out,
+                      const float *w3_host, uint16_t *w3s_out);
 int tn_dbg_dense_strip_dev(tn_ctx *ctx, void *buf_f16, int ldc, int K, const float *s1, const float *t1,
-                           const void *w1s_f16, const float *s2, const float *t2, const void *w3s_f16, int B,
-                           int H, int W, unsigned long long *ts /* NULL or 128 s_memtime stamps per frame */);
+                           const void *w1s_f16, const void *w3s_f16, int B, int H, int W,
+                           unsigned long long *ts /* NULL or 128 s_memtime stamps per frame */);
 
 #ifdef __cplusplus
 }

@@ -138,9 +138,9 @@ for v in [int(s) for s in args.variants.split(",")]:
     if "ds" in args.kernels:      # strip-streaming fused dense layer (dense_strip.hip), every layer of the 56x56 / 28x28 blocks it supports
         w3 = rng.normal(0, 0.03, (32, 128, 3, 3)).astype(np.float32)
         w3s = np.empty(36864, np.uint16)
-        lib.tn_dbg_pack_strip(None, 32, None, w3.ctypes.data_as(C.c_void_p), w3s.ctypes.data_as(C.c_void_p))
+        lib.tn_dbg_pack_strip(None, 32, None, None, None, w3.ctypes.data_as(C.c_void_p), w3s.ctypes.data_as(C.c_void_p))
         w3d = torch.from_numpy(w3s.view(np.int16)).cuda()
-        s2 = torch.rand(128, device="cuda") + 0.5; t2 = torch.randn(128, device="cuda") * 0.3
+        s2 = (rng.random(128) + 0.5).astype(np.float32); t2 = (rng.normal(0, 0.3, 128)).astype(np.float32)
         for (hw, cin, nl) in blocks:
             if hw not in (56, 28): continue
             M = B * hw * hw
@@ -149,18 +149,18 @@ for v in [int(s) for s in args.variants.split(",")]:
             tot = 0.0
             for K in range(cin, min(cin + 32 * nl, 321), 32):
                 w1 = rng.normal(0, (2.0 / K) ** 0.5, (128, K)).astype(np.float32)
-                w1s = np.empty(K * 128, np.uint16)
-                lib.tn_dbg_pack_strip(w1.ctypes.data_as(C.c_void_p), K, w1s.ctypes.data_as(C.c_void_p), None, None)
+                w1s = np.empty((K + 16) * 128, np.uint16)
+                lib.tn_dbg_pack_strip(w1.ctypes.data_as(C.c_void_p), K, s2.ctypes.data_as(C.c_void_p), t2.ctypes.data_as(C.c_void_p), w1s.ctypes.data_as(C.c_void_p), None, None)
                 w1d = torch.from_numpy(w1s.view(np.int16)).cuda()
                 s1 = torch.rand(K, device="cuda") + 0.5; t1 = torch.randn(K, device="cuda") * 0.3
                 fn = lambda: _lib.check(lib.tn_dbg_dense_strip_dev(ctx.handle, _lib.ptr(buf), ctot, K, _lib.ptr(s1), _lib.ptr(t1),
-                                                                   _lib.ptr(w1d), _lib.ptr(s2), _lib.ptr(t2), _lib.ptr(w3d), B, hw, hw, None))
+                                                                   _lib.ptr(w1d), _lib.ptr(w3d), B, hw, hw, None))
                 us = timed(fn, args.iters)
                 tot += us
                 if args.stamps:
                     ts = torch.zeros((B * 128,), dtype=torch.int64, device="cuda")
-                    _lib.check(lib.tn_dbg_dense_strip_dev(ctx.handle, _lib.ptr(buf), ctot, K, _lib.ptr(s1), _lib.ptr(t1), _lib.ptr(w1d), _lib.ptr(s2),
-                                                          _lib.ptr(t2), _lib.ptr(w3d), B, hw, hw, _lib.ptr(ts)))
+                    _lib.check(lib.tn_dbg_dense_strip_dev(ctx.handle, _lib.ptr(buf), ctot, K, _lib.ptr(s1), _lib.ptr(t1), _lib.ptr(w1d),
+                                                          _lib.ptr(w3d), B, hw, hw, _lib.ptr(ts)))
                     torch.cuda.synchronize()
                     t = ts.cpu().numpy().astype(np.float64).reshape(B, 128)
                     n = int((t[0, :127] > 0).sum())

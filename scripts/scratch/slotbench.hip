@@ -88,8 +88,17 @@ __global__ __launch_bounds__(T) void k32(const u32x4 *src, float *out, int iters
       if constexpr (DS) asm volatile("s_waitcnt lgkmcnt(5)");
       asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[s]) : "v"(wa[s]), "v"(b0));
       if constexpr (DS) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(wa[s]) : "v"(lp), "n"(s * 1024));
+      if constexpr (NF >= 100) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int j = 0; j < NF - 100; ++j) {
+          f2 &p = *(f2 *)&fl[2 * (j % 3)];
+          asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(p) : "v"(*(f2 *)&fl[6]));
+        }
+      } else {
 #pragma unroll
       for (int j = 0; j < NF; ++j) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(fl[j % 8]) : "v"(fl[7]));
+      }
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)");
@@ -295,6 +304,11 @@ int main() {
   run32<4, 0, 256>(src, out, "");
   run32<6, 0, 256>(src, out, "");
   run32<8, 0, 256>(src, out, "");
+  run32<104, 0, 256>(src, out, "4 v_pk_fma_f32");
+  run32<106, 0, 256>(src, out, "6 v_pk_fma_f32");
+  run32<108, 0, 256>(src, out, "8 v_pk_fma_f32");
+  run32<10, 0, 256>(src, out, "10 v_fma");
+  run32<12, 0, 256>(src, out, "12 v_fma");
   run32<4, 1, 256>(src, out, "");
   run32<6, 1, 256>(src, out, "");
   run16<0, 0, 512>(src, out, "2 waves/SIMD");

@@ -113,8 +113,8 @@ _SIGS = {
     "tn_dbg_dense_layer_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int,
                                          _P, C.c_int]),
     "tn_dbg_linear": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
-    "tn_dbg_pack_strip": (C.c_int, [_P, C.c_int, _P, _P, _P]),
-    "tn_dbg_dense_strip_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "tn_dbg_pack_strip": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),
+    "tn_dbg_dense_strip_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
 }
 
 _lib = None

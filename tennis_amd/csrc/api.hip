@@ -253,6 +253,7 @@ struct tn_encoder {
   std::vector<DenseLayer> layers[4];
   struct Trans { float *s, *t; f16 *w; int cin, cout; } trans[3];
   float *head_s, *head_t;
+  float *zeros128 = nullptr;   // a BatchNorm shift of zeros (un-fused dense layers: the shift was added by the 1x1)
   f16 *stem_out, *bott, *blockbuf[4];
   size_t workspace_bytes;
   int last_batch;
@@ -336,6 +337,7 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
     e->stem_scale = e->pool.upload(s);
     e->stem_shift = e->pool.upload(t);
   }
+  e->zeros128 = e->pool.upload(std::vector<float>(128, 0.0f));
   int outer = 1;
   for (int b = 0; b < 4; ++b) {
     const std::string sp = pre + "stage" + std::to_string(b + 1) + "_";
@@ -347,14 +349,22 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
       if (!w1 || !w3) return fail(TN_ERR_MISSING);
       if (!fold_bn(pm, sp + "batchnorm" + std::to_string(2 * l), L.cin, s, t)) return fail(TN_ERR_MISSING);
       L.s1 = e->pool.upload(s); L.t1 = e->pool.upload(t);
+      // The scale of the BatchNorm BEHIND the 1x1 convolution is folded into its weights before they are rounded to fp16
+      // (or split into hi + lo): bn2(conv(a)) = conv'(a) + shift with w'[n][k] = scale[n] w[n][k].  That is how the fp16
+      // model is defined (weights.as_fp16_model hands over w with scale[n] w[n][k] fp16-representable); the kernels that
+      // still apply a scale get ones.
+      if (!fold_bn(pm, sp + "batchnorm" + std::to_string(2 * l + 1), 128, s, t)) return fail(TN_ERR_MISSING);
+      std::vector<float> w1f((size_t)128 * L.cin);
+      for (int n = 0; n < 128; ++n)
+        for (int k = 0; k < L.cin; ++k) w1f[(size_t)n * L.cin + k] = s[n] * w1[(size_t)n * L.cin + k];
       if (e->exact) {
         const int bk = e->Hb[b] >= 28 ? 32 : 64;          // k-tile of the block's fused kernel (dense_layer_big.hip)
-        L.w1 = e->pool.upload(split_hi_lo_rows(w1, 128, L.cin, (L.cin + bk - 1) / bk * bk));
+        L.w1 = e->pool.upload(split_hi_lo_rows(w1f.data(), 128, L.cin, (L.cin + bk - 1) / bk * bk));
       } else {
-        L.w1 = e->pool.upload(to_f16(w1, (size_t)128 * L.cin));
+        L.w1 = e->pool.upload(to_f16(w1f.data(), (size_t)128 * L.cin));
       }
-      if (!fold_bn(pm, sp + "batchnorm" + std::to_string(2 * l + 1), 128, s, t)) return fail(TN_ERR_MISSING);
-      L.s2 = e->pool.upload(s); L.t2 = e->pool.upload(t);
+      if (e->strip && dense_strip_supported(e->Hb[b], e->Wb[b], L.cin)) L.w1s = e->pool.upload(pack_w1_strip(w1f.data(), L.cin, t.data()));
+      L.s2 = e->pool.upload(std::vector<float>(128, 1.0f)); L.t2 = e->pool.upload(t);
       if (e->exact) {       // packed image of hi, then packed image of lo
         std::vector<float> hi(32 * 128 * 9), lo(32 * 128 * 9);
         for (size_t i = 0; i < hi.size(); ++i) {
@@ -368,10 +378,7 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
       } else {
         L.w3p = e->pool.upload(pack_conv3x3(w3));
       }
-      if (e->strip && dense_strip_supported(e->Hb[b], e->Wb[b], L.cin)) {
-        L.w1s = e->pool.upload(pack_w1_strip(w1, L.cin));
-        L.w3s = e->pool.upload(pack_w3_strip(w3));
-      }
+      if (L.w1s) L.w3s = e->pool.upload(pack_w3_strip(w3));
       e->layers[b].push_back(L);
     }
     {
@@ -462,7 +469,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
     } else
     for (auto &L : e->layers[b]) {
       if (fused && L.w1s && B >= e->strip_min_batch && e->dl_variant == 0) {
-        DenseStripArgs as{bbuf[b], e->Cb[b], L.cin, L.s1, L.t1, L.w1s, L.s2, L.t2, L.w3s, B, Hh, Ww};
+        DenseStripArgs as{bbuf[b], e->Cb[b], L.cin, L.s1, L.t1, L.w1s, L.w3s, B, Hh, Ww};
         const std::string fam = "dense_layer_strip_" + std::to_string(Hh) + "x" + std::to_string(Ww);
         tm.begin(fam.c_str(), 2.0 * M * (128.0 * L.cin + 32.0 * 1152),
                  (double)M * (L.cin + 32) * 2 + 128.0 * L.cin * 2 + 32.0 * 1152 * 2);
@@ -482,12 +489,14 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
         if (rc) return rc;
         continue;
       }
+      // un-fused: BN2 (scale folded into the weights) adds its shift in the 1x1's epilogue, the 3x3 only applies the ReLU
       Conv1x1Args a1{bbuf[b], e->Cb[b], L.cin, L.s1, L.t1, L.w1, 128, bott, 128, 0, M, 0, Hh, Ww};
+      a1.bias = L.t2;
       tm.begin("conv1x1_bnrelu", 2.0 * M * 128.0 * L.cin, (double)M * (L.cin + 128) * 2 + 128.0 * L.cin * 2);
       rc = launch_conv1x1(a1, s);
       tm.end();
       if (rc) return rc;
-      Conv3x3Args a3{bott, L.s2, L.t2, L.w3p, bbuf[b], e->Cb[b], L.cin, M, Hh, Ww};
+      Conv3x3Args a3{bott, L.s2, e->zeros128, L.w3p, bbuf[b], e->Cb[b], L.cin, M, Hh, Ww};
       tm.begin("conv3x3_bnrelu", 2.0 * M * 32.0 * 1152, (double)M * (128 + 32) * 2 + 32.0 * 1152 * 2);
       rc = launch_conv3x3(a3, s);
       tm.end();

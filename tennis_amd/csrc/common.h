@@ -143,6 +143,7 @@ struct Conv1x1Args {
   int H, W;           // input spatial size (used when pool)
   int variant = 0;    // tuning hook: 0 = default kernel choice
   int exact = 0;      // weights as hi + lo fp16 pairs: w [N][2 K] = [hi | lo] (K % 64 == 0)
+  const float *bias = nullptr;   // [N] added to the fp32 result before the rounding to fp16 (no pooling)
 };
 int launch_conv1x1(const Conv1x1Args &a, hipStream_t s);
 
@@ -187,15 +188,14 @@ struct DenseStripArgs {
   f16 *buf;              // concat buffer [B][H][W][ldc]: reads channels [0,K), writes [K,K+32)
   int ldc, K;
   const float *s1, *t1;  // [K]   folded BN1
-  const f16 *w1s;        // 1x1 weights as A fragments (pack_w1_strip)
-  const float *s2, *t2;  // [128] folded BN2
+  const f16 *w1s;        // 1x1 weights (BN2 scale folded in) + BN2 shift as A fragments (pack_w1_strip)
   const f16 *w3s;        // 3x3 weights as A fragments (pack_w3_strip)
   int B, H, W;
   unsigned long long *ts = nullptr;   // tuning hook: s_memtime stamps of wave 0 of every workgroup (128 per workgroup)
 };
 bool dense_strip_supported(int H, int W, int K);
 int launch_dense_strip(const DenseStripArgs &a, hipStream_t s);
-std::vector<f16> pack_w1_strip(const float *w /*[128][K]*/, int K);
+std::vector<f16> pack_w1_strip(const float *w /*[128][K], BN2 scale folded in*/, int K, const float *shift /*[128] BN2 shift*/);
 std::vector<f16> pack_w3_strip(const float *w /*(32,128,3,3)*/);
 
 struct StemArgs {

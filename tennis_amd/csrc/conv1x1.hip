@@ -206,8 +206,13 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
       const int m = wm * 16 * MI + mi * 16 + frow;
       const int n = wn * (NB / 2) + ni * 16 + fch * 4;
       f16x4 h;
+      // (bias: the shift of a BatchNorm folded behind the convolution is added BEFORE the one rounding to fp16 - added to
+      // the rounded value by the consumer, every pixel of a channel would carry the same rounding offset)
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.bias) bv = *(const float4 *)(a.bias + n0 + n);
+      const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h[r] = (f16)acc[ni][mi][r];
+      for (int r = 0; r < 4; ++r) h[r] = (f16)(acc[ni][mi][r] + b4[r]);
       *(f16x4 *)(smem + m * CPITCH + n * 2) = h;
     }
   __syncthreads();

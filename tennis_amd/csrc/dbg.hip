@@ -107,11 +107,17 @@ extern "C" int tn_dbg_linear(tn_ctx *ctx, const float *x, const float *w, const 
 }
 
 // ---- strip-streaming fused dense layer (dense_strip.hip) ----
-// fp32 (128,K) and (32,128,3,3) -> the fragment images the strip kernel keeps in LDS (K*128 and 36864 halfs)
-extern "C" int tn_dbg_pack_strip(const float *w1_host, int K, uint16_t *w1s_out, const float *w3_host, uint16_t *w3s_out) {
+// fp32 (128,K) 1x1 weights with BN2's folded scale / shift (128 each) and (32,128,3,3) 3x3 weights -> the fragment images the
+// strip kernel keeps in LDS ((K+16)*128 and 36864 halfs); the scale is multiplied into the weights before the fp16 rounding
+extern "C" int tn_dbg_pack_strip(const float *w1_host, int K, const float *s2_host, const float *t2_host, uint16_t *w1s_out,
+                                 const float *w3_host, uint16_t *w3s_out) {
   TN_REQUIRE(K > 0 && K % 32 == 0, "tn_dbg_pack_strip: K must be a multiple of 32");
   if (w1_host && w1s_out) {
-    const std::vector<f16> p = pack_w1_strip(w1_host, K);
+    TN_REQUIRE(s2_host && t2_host, "tn_dbg_pack_strip: the 1x1 image needs BN2's scale and shift");
+    std::vector<float> wf((size_t)128 * K);
+    for (int n = 0; n < 128; ++n)
+      for (int k = 0; k < K; ++k) wf[(size_t)n * K + k] = w1_host[(size_t)n * K + k] * s2_host[n];
+    const std::vector<f16> p = pack_w1_strip(wf.data(), K, t2_host);
     memcpy(w1s_out, p.data(), p.size() * sizeof(f16));
   }
   if (w3_host && w3s_out) {
@@ -123,10 +129,9 @@ extern "C" int tn_dbg_pack_strip(const float *w1_host, int K, uint16_t *w1s_out,
 
 // One fused dense layer in place on buf (B,H,W,ldc), asynchronous, device-resident packed operands.
 extern "C" int tn_dbg_dense_strip_dev(tn_ctx *ctx, void *buf_f16, int ldc, int K, const float *s1, const float *t1,
-                                      const void *w1s_f16, const float *s2, const float *t2, const void *w3s_f16,
-                                      int B, int H, int W, unsigned long long *ts) {
-  TN_REQUIRE(ctx && buf_f16 && s1 && t1 && w1s_f16 && s2 && t2 && w3s_f16, "tn_dbg_dense_strip_dev: null argument");
-  DenseStripArgs a{(f16 *)buf_f16, ldc, K, s1, t1, (const f16 *)w1s_f16, s2, t2, (const f16 *)w3s_f16, B, H, W};
+                                      const void *w1s_f16, const void *w3s_f16, int B, int H, int W, unsigned long long *ts) {
+  TN_REQUIRE(ctx && buf_f16 && s1 && t1 && w1s_f16 && w3s_f16, "tn_dbg_dense_strip_dev: null argument");
+  DenseStripArgs a{(f16 *)buf_f16, ldc, K, s1, t1, (const f16 *)w1s_f16, (const f16 *)w3s_f16, B, H, W};
   a.ts = ts;
   return launch_dense_strip(a, ctx->stream);
 }

@@ -24,6 +24,11 @@
 //   the whole launch; activations go HBM -> registers directly in fragment shape (64 B per lane per 64-channel super-step;
 //   the two lanes of a pixel cover one 128-B line) through a register ring that holds one whole row and is refilled with
 //   the next row as it is read out.
+// * BN2 costs no element-wise multiply-add: its scale is folded into the 1x1 weights on the host (before the fp16 rounding:
+//   the fp16 model is DEFINED that way, weights.as_fp16_model) and its shift enters the GEMM through one extra 16-channel
+//   k-step whose pixel fragment is the constant (1, 1, m, 0, ...): weight columns shift_hi, shift_lo (two fp16 numbers = 22
+//   bits of the fp32 shift) and 1; m = -60000 in the lanes of padding columns, so that their ReLU'd bottleneck is 0 as
+//   the convolution's zero padding demands.  What is left of epilogue A is convert + ReLU + the window write.
 // * the schedule is pinned by hand: the body is a sequence of SLOTS - one MFMA followed by its share of everything else -
 //   with a scheduling barrier behind each.  1x1 slots carry BN1 + ReLU of the next k-step, the weight-fragment and constant
 //   reads, the ring refill and the DPP epilogue of the PREVIOUS output row; 3x3 slots carry the weight-fragment reload, the
@@ -53,11 +58,9 @@ struct DSGeom {
   static constexpr int ROWS = W / NV;            // output rows per wave
   static constexpr int KQ = 2 * KS;              // 16-channel k-steps
   static constexpr int NSU = (KS + 1) / 2;       // 64-channel super-steps (the last one is half when KS is odd)
-  static constexpr int W1OFF = kW3Bytes;
-  static constexpr int T1OFF = W1OFF + KS * 8192;          // s1[K] | t1[K]
-  static constexpr int T2OFF = T1OFF + KS * 32 * 8;        // s2[128] | t2[128]
-  static constexpr int ZOFF = T2OFF + 1024;                // 1 KiB of zeros: BN2 "tables" of padding pixels
-  static constexpr int LDS_BYTES = ZOFF + 1024;
+  static constexpr int W1OFF = kW3Bytes;                   // KQ + 1 k-steps of 4 fragments: the last one carries BN2's shift
+  static constexpr int T1OFF = W1OFF + (KQ + 1) * 4096;    // s1[K] | t1[K]
+  static constexpr int LDS_BYTES = T1OFF + KS * 32 * 8;
   static_assert(W % 28 == 0 && (NPAIR == 1 || NPAIR == 2), "strip geometry");
   static_assert(NSU <= 5, "the activation ring holds five super-steps");
   static_assert(LDS_BYTES <= 160 * 1024, "weights do not fit LDS");
@@ -144,18 +147,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const uint4 *g1 = (const uint4 *)a.w1s;
     uint4 *l1 = (uint4 *)(smem + G::W1OFF);
 #pragma unroll 4
-    for (int i = tid; i < KS * 512; i += 256) l1[i] = g1[i];
+    for (int i = tid; i < (KQ + 1) * 256; i += 256) l1[i] = g1[i];
     float *t1 = (float *)(smem + G::T1OFF);
     for (int i = tid; i < K; i += 256) {
       t1[i] = a.s1[i];
       t1[K + i] = a.t1[i];
     }
-    float *t2 = (float *)(smem + G::T2OFF);
-    if (tid < 128) {
-      t2[tid] = a.s2[tid];
-      t2[128 + tid] = a.t2[tid];
-    }
-    ((float *)(smem + G::ZOFF))[tid] = 0.f;
   }
   __syncthreads();
 
@@ -179,7 +176,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const unsigned char *w1l = smem + G::W1OFF + lane * 16;
   const unsigned char *w3l = smem + lane * 16;
   const float *tab1 = (const float *)(smem + G::T1OFF);
-  const unsigned tab2_lane = xvalid ? (unsigned)(G::T2OFF + 16 * h) : (unsigned)G::ZOFF;   // BN2 of padding columns: scale 0, shift 0
+  // the pixel fragment of the shift k-step: (1, 1, mask, 0, 0, 0, 0, 0) in the lanes that hold k = 0 .. 7
+  const u32x4 xb_shift = {h == 0 ? 0x3c003c00u : 0u, (h == 0 && !xvalid) ? 0x0000fb53u : 0u, 0u, 0u};   // fp16 1.0 = 0x3c00, -60000 = 0xfb53
 
   // ================= state that lives across slots =================
   u32x4 ring[5][4];      // activation ring [super-step][k-step]: 16 B per lane = 8 channels of the lane's pixel; holds one row
@@ -191,8 +189,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   float cs[3][8], ct[3][8];   // BN1 constants [k-step % 3]
   u32x4 w3f[2][3];       // 3x3 weight fragments [step parity][dx] (reloaded for step + 2 behind their MFMA)
   f32x16 bacc[3];        // 3x3 accumulators [dx]
-  float4 e_sv[3], e_tv[3];  // epilogue A: BN2 constants [group % 3]
-  float e_f[4];
   unsigned e_pk[4];
   unsigned o_pk[8];
 
@@ -248,35 +244,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     TN_SB();
   };
 
-  // ---- epilogue A: acc -> BN2 + ReLU (fp32), one rounding to fp16, lane-local pack -> window row PROW; 48 sub-items ----
+  // ---- epilogue A: acc (= BN2 applied) -> ReLU, one rounding to fp16, lane-local pack -> window row PROW; 48 sub-items ----
   // sub-item E: block MB = E / 12, register group G4 = (E % 12) / 3 (accumulators 4 G4 .. 4 G4 + 3 = bottleneck channels
-  // 32 MB + 8 G4 + 4 h + (0..3)), part (E % 3): 0 the constants of the NEXT group + the first two fmas, 1 the other two,
-  // 2 convert / ReLU (+ the window write behind every second group)
-  auto epa_consts = [&](auto l_tag) TN_INL {
-    constexpr int L = decltype(l_tag)::value;      // group 4 MB + G4
-    e_sv[L % 3] = *(const float4 *)(smem + tab2_lane + 32 * L);
-    e_tv[L % 3] = *(const float4 *)(smem + tab2_lane + 512 + 32 * L);
-  };
+  // 32 MB + 8 G4 + 4 h + (0..3)), part (E % 3): 0 / 1 convert + ReLU of two values each, 2 the window write (every second group)
   auto epa_item = [&](auto prow_tag, auto e_tag) TN_INL {
     constexpr int PROW = decltype(prow_tag)::value, E = decltype(e_tag)::value;
-    constexpr int MB = E / 12, G4 = (E % 12) / 3, P = E % 3, L = 4 * MB + G4;
-    float (&ef)[4] = e_f;             // (asm operands alone do not capture in a generic lambda)
-    unsigned (&epk)[4] = e_pk;
+    constexpr int MB = E / 12, G4 = (E % 12) / 3, P = E % 3, E2 = G4 & 1;
+    unsigned (&epk)[4] = e_pk;             // (asm operands alone do not capture in a generic lambda)
     f32x16 (&accr)[4] = acc;
-    if constexpr (P == 0) {
-      if constexpr (L + 2 < 16) epa_consts(ic<L + 2>{});
-    }
     if constexpr (P <= 1) {
-      constexpr int C = P * 2;
-      const float4 sv = e_sv[L % 3], tv = e_tv[L % 3];
-      const float s0 = C ? sv.z : sv.x, s1 = C ? sv.w : sv.y, t0 = C ? tv.z : tv.x, t1 = C ? tv.w : tv.y;
-      const float a0 = accr[MB][4 * G4 + C], a1 = accr[MB][4 * G4 + C + 1];
-      asm("v_fma_f32 %0, %2, %3, %4\n\tv_fma_f32 %1, %5, %6, %7" : "=&v"(ef[C]), "=&v"(ef[C + 1]) : "v"(a0), "v"(s0), "v"(t0), "v"(a1), "v"(s1), "v"(t1));
-    } else {
-      constexpr int E2 = G4 & 1;
-      asm("v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5\n\tv_pk_max_f16 %0, %0, 0\n\tv_pk_max_f16 %1, %1, 0"
-          : "=&v"(epk[2 * E2]), "=&v"(epk[2 * E2 + 1]) : "v"(ef[0]), "v"(ef[1]), "v"(ef[2]), "v"(ef[3]));
-      if constexpr (E2 == 1) win_write<PROW, 2 * MB + (G4 >> 1)>(epk[0], epk[1], epk[2], epk[3]);
+      const float a0 = accr[MB][4 * G4 + 2 * P], a1 = accr[MB][4 * G4 + 2 * P + 1];
+      asm("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_f16 %0, %0, 0" : "=v"(epk[2 * E2 + P]) : "v"(a0), "v"(a1));
+    } else if constexpr (E2 == 1) {
+      win_write<PROW, 2 * MB + (G4 >> 1)>(epk[0], epk[1], epk[2], epk[3]);
     }
   };
   auto epilogue_a_exposed = [&](auto prow_tag) TN_INL {
@@ -317,14 +297,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // fillers: BN1 of the next k-step, weight fragments / constants one and two k-steps ahead, the ring refill behind a
   // super-step's last k-step, epilogue B of the previous output row (yo_prev), the first BN2 constants of this row
   auto phase_a = [&](int ynext, int yo_prev, bool prev_valid) TN_INL {
-    constexpr int NSLOT = 4 * KQ;
+    constexpr int NSLOT = 4 * (KQ + 1);
     bacc_ready();
     const unsigned off_prev = out_offset(yo_prev, prev_valid);
-    static_for<KQ>([&](auto q_tag) TN_INL {
+    static_for<KQ + 1>([&](auto q_tag) TN_INL {
       constexpr int Q = decltype(q_tag)::value;
       constexpr int U = Q >> 2;
       constexpr bool HALFU = ODD && U == NSU - 1;
-      constexpr bool LAST_OF_U = HALFU ? (Q & 3) == 1 : (Q & 3) == 3;
+      constexpr bool LAST_OF_U = Q < KQ && (HALFU ? (Q & 3) == 1 : (Q & 3) == 3);
       static_for<4>([&](auto mb_tag) TN_INL {
         constexpr int MB = decltype(mb_tag)::value, SL = 4 * Q + MB;
         if constexpr (Q == 0) {
@@ -332,11 +312,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
           for (int i = 0; i < 16; ++i) z[i] = 0.f;
           acc[MB] = mfma32(wa[0][MB], xb[0], z);
+        } else if constexpr (Q == KQ) {
+          acc[MB] = mfma32(wa[Q & 1][MB], xb_shift, acc[MB]);
         } else {
           acc[MB] = mfma32(wa[Q & 1][MB], xb[Q & 1], acc[MB]);
         }
         if constexpr (Q + 1 < KQ) bn_item(ic<Q + 1>{}, mb_tag);
-        if constexpr (Q + 2 < KQ) wa_item(ic<Q + 2>{}, mb_tag);
+        if constexpr (Q + 2 < KQ + 1) wa_item(ic<Q + 2>{}, mb_tag);
         if constexpr (Q + 3 < KQ) consts_item(ic<Q + 3>{}, mb_tag);
         if constexpr (LAST_OF_U) {
           if (!(TN_DS_EXP & 1)) ld_item(ic<U>{}, mb_tag, ynext);
@@ -346,8 +328,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           constexpr int P = decltype(p_tag)::value;
           if constexpr ((P * NSLOT) / 8 == SL) epb_item(p_tag, off_prev);
         });
-        if constexpr (SL == NSLOT - 2) epa_consts(ic<0>{});
-        if constexpr (SL == NSLOT - 1) epa_consts(ic<1>{});
         TN_WIN_FENCE();
         TN_SB();
       });
@@ -486,18 +466,29 @@ bool dense_strip_supported(int H, int W, int K) {
 
 int launch_dense_strip(const DenseStripArgs &a, hipStream_t s) {
   TN_REQUIRE(dense_strip_supported(a.H, a.W, a.K), "dense_strip: unsupported geometry");
+  TN_REQUIRE(a.buf && a.s1 && a.t1 && a.w1s && a.w3s, "dense_strip: null operand");
   TN_REQUIRE(a.ldc % 64 == 0 && a.K + 32 <= a.ldc, "dense_strip: bad channel geometry");
   if (a.W == 56) return launch_strip_w<56>(a, s);
   return launch_strip_w<28>(a, s);
 }
 
 // ---- host-side packing (api.hip, dbg.hip) ----
-// 1x1 weights [128][K] -> v_mfma_f32_32x32x16_f16 A fragments [K/16 k-steps][4 blocks][64 lanes][8]: lane l: bottleneck channel
-// 32 mb + (l & 31); input channels of 64-channel super-step u, k-step i: 64 u + 32 (l >> 5) + 8 i + j (a lane's four k-steps
-// are 64 contiguous bytes of the pixel); the trailing 32-channel half super-step of an odd K/32: 64 u + 16 (l >> 5) + 8 i + j.
-std::vector<f16> pack_w1_strip(const float *w, int K) {
+// 1x1 weights [128][K] (BN2's scale already folded in) + BN2's shift [128] -> v_mfma_f32_32x32x16_f16 A fragments
+// [K/16 + 1 k-steps][4 blocks][64 lanes][8]: lane l: bottleneck channel 32 mb + (l & 31); input channels of 64-channel
+// super-step u, k-step i: 64 u + 32 (l >> 5) + 8 i + j (a lane's four k-steps are 64 contiguous bytes of the pixel); the
+// trailing 32-channel half super-step of an odd K/32: 64 u + 16 (l >> 5) + 8 i + j.  The last k-step multiplies the constant
+// pixel fragment (1, 1, mask, 0, ...): columns fp16(shift), fp16(shift - fp16(shift)), 1.
+std::vector<f16> pack_w1_strip(const float *w, int K, const float *shift) {
   const int ks = K / 32, kq = K / 16, nsu = (ks + 1) / 2;
-  std::vector<f16> p((size_t)kq * 4 * 64 * 8);
+  std::vector<f16> p((size_t)(kq + 1) * 4 * 64 * 8, (f16)0.f);
+  for (int mb = 0; mb < 4; ++mb)
+    for (int l = 0; l < 32; ++l) {       // (lanes 32 .. 63 hold k = 8 .. 15 of the shift step: zeros)
+      f16 *d = &p[(((size_t)kq * 4 + mb) * 64 + l) * 8];
+      const float t = shift[32 * mb + l];
+      d[0] = (f16)t;
+      d[1] = (f16)(t - (float)d[0]);
+      d[2] = (f16)1.f;
+    }
   for (int q = 0; q < kq; ++q) {
     const int u = q >> 2, i = q & 3;
     const bool half = (ks & 1) && u == nsu - 1;

@@ -63,18 +63,37 @@ def _bn(rng, prefix, c, var_center=1.0):
     }
 
 
+BN_EPS = 1e-5     # gluon BatchNorm default (csrc/api.hip kBnEps)
+
+
 def as_fp16_model(params: dict) -> dict:
-    """Model conversion for the fp16 encoder: round every conv ``*_weight`` to the
-    nearest fp16 value (kept as fp32 arrays).  The served model IS these rounded
-    weights — the GPU path and the fp32 CPU oracle both evaluate them — so weight
-    quantisation is a one-off conversion step, not kernel error.  BN statistics,
-    Dense and RNN parameters stay fp32.  (Measured on MI355X: with un-rounded
-    fp32 conv weights the pooled features differ by up to 3.3e-3 because weight
-    rounding is coherent across the 49 pooled pixels; with converted weights the
-    kernels' own error is 7e-4 max, DESIGN.md "Numerics".)"""
+    """Model conversion for the fp16 encoder: every conv ``*_weight`` is rounded once to
+    fp16 (kept as fp32 arrays).  The served model IS these converted weights — the GPU
+    path and the fp32 CPU oracle both evaluate them — so weight quantisation is a one-off
+    conversion step, not kernel error.  BN statistics, Dense and RNN parameters stay fp32.
+
+    The 1x1 convolution of a dense layer (``stageB_conv{2l}``) is followed directly by a
+    BatchNorm (``stageB_batchnorm{2l+1}``) whose scale the encoder folds into the
+    weights (the usual conv-BN fusion; csrc/api.hip, csrc/dense_strip.hip): for those the
+    number that is rounded to fp16 is ``scale[n] * w[n][k]``, and the converted weight is
+    ``fp16(scale[n] w[n][k]) / scale[n]`` — one rounding per weight either way.
+
+    (Measured on MI355X: with un-rounded fp32 conv weights the pooled features differ by
+    up to 3.3e-3 because weight rounding is coherent across the 49 pooled pixels; with
+    converted weights the kernels' own error is 7e-4 max, DESIGN.md "Numerics".)"""
+    import re
     out = dict(params)
     for k, v in params.items():
-        if k.endswith("_weight") and v.ndim == 4:
+        if not (k.endswith("_weight") and v.ndim == 4):
+            continue
+        m = re.fullmatch(r"(.*stage\d+_)conv(\d+)_weight", k)
+        bn = m and int(m.group(2)) % 2 == 0 and v.shape[2:] == (1, 1) and f"{m.group(1)}batchnorm{int(m.group(2)) + 1}"
+        if bn and bn + "_gamma" in params:
+            s = (params[bn + "_gamma"] / np.sqrt(params[bn + "_running_var"] + np.float32(BN_EPS))).astype(np.float32)
+            s = s.reshape(-1, 1, 1, 1)
+            folded = (v * s).astype(np.float32).astype(np.float16).astype(np.float32)
+            out[k] = np.where(s != 0, folded / np.where(s != 0, s, 1), v).astype(np.float32)
+        else:
             out[k] = v.astype(np.float16).astype(np.float32)
     return out
 

@@ -292,21 +292,19 @@ def test_dense_strip(ctx, report, B, H, K, ldc):
     buf = rng.normal(0, 1.5, (B, H, H, ldc)).astype(np.float16)
     s1 = rng.uniform(0.5, 1.5, K).astype(np.float32); t1 = rng.normal(0, 0.3, K).astype(np.float32)
     s2 = rng.uniform(0.5, 1.5, 128).astype(np.float32); t2 = rng.normal(0, 0.3, 128).astype(np.float32)
-    w1 = _h(rng.normal(0, np.sqrt(2.0 / K), (128, K)).astype(np.float32))
+    w1 = rng.normal(0, np.sqrt(2.0 / K), (128, K)).astype(np.float32)
     w3 = _h(rng.normal(0, np.sqrt(2.0 / 1152), (32, 128, 3, 3)).astype(np.float32))
-    w1s = np.empty(K * 128, np.uint16); w3s = np.empty(36864, np.uint16)
-    _lib.check(ctx.lib.tn_dbg_pack_strip(w1.ctypes.data_as(C.c_void_p), K, w1s.ctypes.data_as(C.c_void_p),
-                                         w3.ctypes.data_as(C.c_void_p), w3s.ctypes.data_as(C.c_void_p)), "pack_strip")
+    w1s = np.empty((K + 16) * 128, np.uint16); w3s = np.empty(36864, np.uint16)
+    _lib.check(ctx.lib.tn_dbg_pack_strip(w1.ctypes.data_as(C.c_void_p), K, s2.ctypes.data_as(C.c_void_p), t2.ctypes.data_as(C.c_void_p),
+                                         w1s.ctypes.data_as(C.c_void_p), w3.ctypes.data_as(C.c_void_p), w3s.ctypes.data_as(C.c_void_p)), "pack_strip")
     d = dict(buf=torch.from_numpy(buf).cuda(), s1=torch.from_numpy(s1).cuda(), t1=torch.from_numpy(t1).cuda(),
-             s2=torch.from_numpy(s2).cuda(), t2=torch.from_numpy(t2).cuda(),
              w1s=torch.from_numpy(w1s.view(np.int16)).cuda(), w3s=torch.from_numpy(w3s.view(np.int16)).cuda())
     _lib.check(ctx.lib.tn_dbg_dense_strip_dev(ctx.handle, _lib.ptr(d["buf"]), ldc, K, _lib.ptr(d["s1"]), _lib.ptr(d["t1"]),
-                                              _lib.ptr(d["w1s"]), _lib.ptr(d["s2"]), _lib.ptr(d["t2"]), _lib.ptr(d["w3s"]),
-                                              B, H, H, None), "dense_strip")
+                                              _lib.ptr(d["w1s"]), _lib.ptr(d["w3s"]), B, H, H, None), "dense_strip")
     out = d["buf"].cpu().numpy().astype(np.float32)
     a1 = _bnrelu_h(buf[..., :K].astype(np.float32), s1, t1)
-    bott = (a1.reshape(-1, K) @ w1.T).reshape(B, H, H, 128)
-    a2 = _h(np.maximum(bott * s2 + t2, 0).astype(np.float32))
+    bott = (a1.reshape(-1, K) @ _h(w1 * s2[:, None]).T).reshape(B, H, H, 128)      # BN2's scale is folded into the weights before the fp16 rounding
+    a2 = _h(np.maximum(bott + t2, 0).astype(np.float32))
     ref = dn.conv2d_nhwc(a2, w3, 1, 1)
     err = np.abs(out[..., K:K + 32] - ref).max()
     report[f"dense_strip_{B}x{H}_K{K}"] = float(err)
