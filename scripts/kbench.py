@@ -163,7 +163,11 @@ for v in [int(s) for s in args.variants.split(",")]:
                                                           _lib.ptr(w3d), B, hw, hw, _lib.ptr(ts)))
                     torch.cuda.synchronize()
                     t = ts.cpu().numpy().astype(np.float64).reshape(B, 128)
-                    n = int((t[0, :127] > 0).sum())
+                    n = int((t[0, :125] > 0).sum())
+                    real_us = (t[:, 125] - t[:, 126]) / 100.0
+                    print("   wave 0: %.1f us of wall clock (median; min %.1f max %.1f; launch span %.1f us), shader clock %.2f GHz"
+                          % (np.median(real_us), real_us.min(), real_us.max(), (t[:, 125].max() - t[:, 126].min()) / 100.0,
+                             np.median((t[:, n - 1] - t[:, 127]) / (real_us * 1e3))), flush=True)
                     d = np.diff(t[:, :n], axis=1)
                     med = np.median(d, axis=0)
                     print("   stamps (ticks, median over frames): launch->start %d | start->loop %d | rows: A %s | B %s | tail %s | total %d"

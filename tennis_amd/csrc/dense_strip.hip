@@ -36,6 +36,7 @@
 //   operands of the next row.  Nothing runs outside an MFMA's shadow in the steady state.
 //
 // No halo recompute in y at 56x56 beyond one row per wave (29 / 28); 16 / 14 in x.
+#include <array>
 #include <type_traits>
 
 #include "common.h"
@@ -84,11 +85,12 @@ constexpr int win_reg(int prow, int t) { return TN_WIN_BASE + 32 * prow + 4 * t;
 // keeps compiler values that are live here out of the window registers (no instruction)
 #define TN_WIN_FENCE() asm volatile("" ::: TN_WIN_CLOBBER)
 
-// four packed VGPRs -> window tuple (physical row PROW, k-step T); the trailing s_nop 1 covers v_accvgpr_write -> MFMA operand read
+// four packed VGPRs -> window tuple (physical row PROW, k-step T).  v_accvgpr_write -> MFMA operand read needs two wait states:
+// the schedule puts at least eight slots between the write of a tuple and the first MFMA that reads it
 template <int PROW, int T>
 __device__ __forceinline__ void win_write(const unsigned v0, const unsigned v1, const unsigned v2, const unsigned v3) {
   constexpr int B = win_reg(PROW, T);
-  asm volatile("v_accvgpr_write_b32 a%c4, %0\n\tv_accvgpr_write_b32 a%c5, %1\n\tv_accvgpr_write_b32 a%c6, %2\n\tv_accvgpr_write_b32 a%c7, %3\n\ts_nop 1"
+  asm volatile("v_accvgpr_write_b32 a%c4, %0\n\tv_accvgpr_write_b32 a%c5, %1\n\tv_accvgpr_write_b32 a%c6, %2\n\tv_accvgpr_write_b32 a%c7, %3"
                :: "v"(v0), "v"(v1), "v"(v2), "v"(v3), "n"(B), "n"(B + 1), "n"(B + 2), "n"(B + 3) : TN_WIN_CLOBBER);
 }
 template <int R>
@@ -129,14 +131,90 @@ using ic = std::integral_constant<int, V>;
 
 #define TN_SB() __builtin_amdgcn_sched_barrier(0)
 
+// ---- the static schedule ----
+struct PItem { int kind, q, j; };     // kind: 0 none, 1 C(q), 2 BN(q).j, 3 LD(u = q).i = j
+template <int KS>
+struct PList { PItem it[7 * 2 * KS + 8]; int n; };
+template <int KS>
+constexpr PList<KS> make_pl() {
+  constexpr int KQ = 2 * KS, NSU = (KS + 1) / 2;
+  constexpr bool ODD = (KS & 1) != 0;
+  PList<KS> l{};
+  int n = 0;
+  for (int c = 0; c < 3 && c < KQ; ++c) l.it[n++] = PItem{1, c, 0};
+  for (int q = 0; q < KQ; ++q) {
+    for (int j = 0; j < 4; ++j) l.it[n++] = PItem{2, q, j};
+    if (q + 3 < KQ) l.it[n++] = PItem{1, q + 3, 0};
+    const int u = q >> 2;
+    const bool half = ODD && u == NSU - 1;
+    if (half ? (q & 3) == 1 : (q & 3) == 3)
+      for (int i = 0; i < (half ? 2 : 4); ++i) l.it[n++] = PItem{3, u, i};
+  }
+  l.n = n;
+  return l;
+}
+template <int KS>
+inline constexpr PList<KS> kPL = make_pl<KS>();
+template <int KS>
+constexpr PItem pl_at(int idx) { return idx >= 0 && idx < kPL<KS>.n ? kPL<KS>.it[idx] : PItem{0, 0, 0}; }
+template <int KS>
+constexpr int pl_len() { return kPL<KS>.n; }
+constexpr int kPLB = 30;                 // pipeline items that run in the previous row's 3x3 phase (slots 42 - 71)
+constexpr int kXN = 8;                   // pixel-fragment buffers
+struct ASlot { int pl0, npl, epb0, nepb; };
+template <int N> struct ASched { ASlot s[N]; };
+// 1x1 slot i (k-step i / 4): pipeline items [pl0, pl0 + npl) and epilogue B items [epb0, epb0 + nepb).  The items left are
+// spread evenly over the slots left; BN(q) has to be complete when k-step q starts, so the pipeline goes first whenever it is
+// needed within the current k-step, otherwise the epilogue B items (24) are used up first.
+template <int KS>
+constexpr auto make_a_sched() {
+  constexpr int KQ = 2 * KS, NA = 4 * (KQ + 1), NPL = pl_len<KS>();
+  ASched<NA> r{};
+  int bn3[KQ + 1] = {};                                   // index of BN(q).3 in the list
+  for (int i = 0; i < NPL; ++i)
+    if (kPL<KS>.it[i].kind == 2 && kPL<KS>.it[i].j == 3) bn3[kPL<KS>.it[i].q] = i;
+  int pos = NPL < kPLB ? NPL : kPLB, epb = 0;
+  for (int i = 0; i < NA; ++i) {
+    const int qn = i / 4 + 1, rem = 3 - i % 4;          // next k-step, slots left in this one behind slot i
+    const int need_end = qn < KQ ? bn3[qn] + 1 : 0;
+    const int left = NA - i, total = (NPL - pos) + (24 - epb);
+    int quota = (total + left - 1) / left;
+    int must = need_end - rem - pos;                    // items the pipeline has to run in this slot not to fall behind
+    if (must < 0) must = 0;
+    if (must > NPL - pos) must = NPL - pos;
+    int npl = must;
+    if (quota < npl) quota = npl;
+    int ne = 24 - epb < quota - npl ? 24 - epb : quota - npl;
+    const int more = NPL - pos - npl < quota - npl - ne ? NPL - pos - npl : quota - npl - ne;
+    npl += more;
+    r.s[i] = ASlot{pos, npl, epb, ne};
+    pos += npl;
+    epb += ne;
+  }
+  return r;
+}
+template <int KS>
+constexpr bool a_sched_complete() {        // every epilogue B item and every pipeline item has a slot
+  constexpr int KQ = 2 * KS, NA = 4 * (KQ + 1);
+  constexpr auto sa = make_a_sched<KS>();
+  int npl = pl_len<KS>() < kPLB ? pl_len<KS>() : kPLB, nepb = 0;
+  for (int i = 0; i < NA; ++i) { npl += sa.s[i].npl; nepb += sa.s[i].nepb; }
+  return npl == pl_len<KS>() && nepb == 24;
+}
+
 template <int W, int KS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void dense_strip_kernel(DenseStripArgs a) {
   using G = DSGeom<W, KS>;
   constexpr int H = W, NSU = G::NSU, K = KS * 32, KQ = G::KQ, ROWS = G::ROWS;
   constexpr bool ODD = (KS & 1) != 0;
+  constexpr int XN = kXN, NPL = pl_len<KS>(), PLB = NPL < kPLB ? NPL : kPLB;
+  static_assert(a_sched_complete<KS>(), "1x1 slot schedule leaves work unassigned");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
-  if (a.ts && tid == 0) a.ts[(size_t)blockIdx.x * 128 + 127] = __builtin_amdgcn_s_memtime();
+  if (a.ts && tid == 0) {
+    a.ts[(size_t)blockIdx.x * 128 + 127] = __builtin_amdgcn_s_memtime();
+    a.ts[(size_t)blockIdx.x * 128 + 126] = __builtin_amdgcn_s_memrealtime();     // 100 MHz
+  }
 
   // ---- prologue: the layer's weights and tables -> LDS (once per launch) ----
   {
@@ -180,101 +258,118 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const u32x4 xb_shift = {h == 0 ? 0x3c003c00u : 0u, (h == 0 && !xvalid) ? 0x0000fb53u : 0u, 0u, 0u};   // fp16 1.0 = 0x3c00, -60000 = 0xfb53
 
   // ================= state that lives across slots =================
+  // every LDS read is issued at least two k-steps (6 - 8 slots, >= 200 cycles) ahead of its consumer: with one wave per SIMD
+  // nothing else covers an exposed LDS round trip
   u32x4 ring[5][4];      // activation ring [super-step][k-step]: 16 B per lane = 8 channels of the lane's pixel; holds one row
   f32x16 acc[4];         // 1x1 accumulators [32-channel block]
-  // every LDS read is issued two k-steps (6 - 8 slots, >= 200 cycles) ahead of its consumer: with one wave per SIMD nothing
-  // else covers an exposed LDS round trip
   u32x4 wa[2][4];        // 1x1 weight fragments [k-step parity][block] (a register is reloaded for k-step + 2 behind its MFMA)
-  u32x4 xb[2];           // BN1 + ReLU'd pixel fragment [k-step parity]
+  u32x4 xb[XN];          // BN1 + ReLU'd pixel fragments [k-step % XN]: the BN pipeline runs up to XN - 2 k-steps ahead
   float cs[3][8], ct[3][8];   // BN1 constants [k-step % 3]
   u32x4 w3f[2][3];       // 3x3 weight fragments [step parity][dx] (reloaded for step + 2 behind their MFMA)
   f32x16 bacc[3];        // 3x3 accumulators [dx]
   unsigned e_pk[4];
+  float o_c[2], o_l[2], o_r[2];
   unsigned o_pk[8];
 
   auto rowbase = [&](int y) TN_INL {
     const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
     return fb + (unsigned)yc * rowpitch;
   };
-  // one 16-byte activation load: k-step I of super-step U of row y -> ring[U][I]
+  // ---------------- the BN pipeline: an ordered list of items per bottleneck row ----------------
+  //   C(q)    the four ds_read_b128 of k-step q's BN1 constants
+  //   BN(q).j BN1 + ReLU of dword j of k-step q's pixel fragment (4 VALU instructions)
+  //   LD(u).i one 16-byte activation load of the NEXT row into ring slot u, behind the last BN item that read the slot
+  // in the order C0 C1 C2 | BN(0).0-3 C3 | BN(1).0-3 C4 | ... ; the list is consumed one item per slot, first by the spare slots
+  // of the previous row's 3x3 phase (PLB items), then by the row's own 1x1 slots (see make_a_sched)
   auto ld_item = [&](auto u_tag, auto i_tag, int y) TN_INL {
     constexpr int U = decltype(u_tag)::value, I = decltype(i_tag)::value;
     constexpr bool HALF = ODD && U == NSU - 1;
-    if constexpr (HALF) {
-      if constexpr (I < 2) ring[U][I] = *(const u32x4 *)(rowbase(y) + colh + 128 * U + 16 * I);
-    } else {
-      ring[U][I] = *(const u32x4 *)(rowbase(y) + colb + 128 * U + 16 * I);
-    }
+    if ((TN_DS_EXP & 1) && y > r_lo + 1) return;
+    if constexpr (HALF) ring[U][I] = *(const u32x4 *)(rowbase(y) + colh + 128 * U + 16 * I);
+    else ring[U][I] = *(const u32x4 *)(rowbase(y) + colb + 128 * U + 16 * I);
   };
-  auto consts_item = [&](auto q_tag, auto p_tag) TN_INL {     // one ds_read_b128 of k-step Q's BN1 constants (P: s lo, s hi, t lo, t hi)
-    constexpr int Q = decltype(q_tag)::value, P = decltype(p_tag)::value;
+  auto consts_item = [&](auto q_tag) TN_INL {
+    constexpr int Q = decltype(q_tag)::value;
     constexpr int U = Q >> 2, I = Q & 3;
     constexpr bool HALF = ODD && U == NSU - 1;
-    const int c0 = (HALF ? 64 * U + 16 * h : 64 * U + 32 * h) + 8 * I + (P & 1) * 4 + (P >> 1) * K;
-    const float4 v = *(const float4 *)(tab1 + c0);
-    float *d = (P >> 1) ? ct[Q % 3] : cs[Q % 3];
-    d[(P & 1) * 4 + 0] = v.x; d[(P & 1) * 4 + 1] = v.y; d[(P & 1) * 4 + 2] = v.z; d[(P & 1) * 4 + 3] = v.w;
+    const int c0 = (HALF ? 64 * U + 16 * h : 64 * U + 32 * h) + 8 * I;
+    const float4 s0 = *(const float4 *)(tab1 + c0), s1 = *(const float4 *)(tab1 + c0 + 4);
+    const float4 t0 = *(const float4 *)(tab1 + K + c0), t1 = *(const float4 *)(tab1 + K + c0 + 4);
+    float *cd = cs[Q % 3], *td = ct[Q % 3];
+    cd[0] = s0.x; cd[1] = s0.y; cd[2] = s0.z; cd[3] = s0.w; cd[4] = s1.x; cd[5] = s1.y; cd[6] = s1.z; cd[7] = s1.w;
+    td[0] = t0.x; td[1] = t0.y; td[2] = t0.z; td[3] = t0.w; td[4] = t1.x; td[5] = t1.y; td[6] = t1.z; td[7] = t1.w;
   };
-  auto wa_item = [&](auto q_tag, auto mb_tag) TN_INL {
-    constexpr int Q = decltype(q_tag)::value, MB = decltype(mb_tag)::value;
-    wa[Q & 1][MB] = *(const u32x4 *)(w1l + (Q * 4 + MB) * 1024);
-  };
-  // BN1 + ReLU of dword J of k-step Q's pixel fragment (fp32 fma, one rounding, packed ReLU)
   auto bn_item = [&](auto q_tag, auto j_tag) TN_INL {
     constexpr int Q = decltype(q_tag)::value, J = decltype(j_tag)::value;
     const unsigned in = ring[Q >> 2][Q & 3][J];
     const float s0 = cs[Q % 3][2 * J], s1 = cs[Q % 3][2 * J + 1], h0 = ct[Q % 3][2 * J], h1 = ct[Q % 3][2 * J + 1];
     float t0, t1;
-    unsigned o;
-    asm("v_fma_mix_f32 %0, %2, %3, %4 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %2, %5, %6 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-        : "=&v"(t0), "=&v"(t1) : "v"(in), "v"(s0), "v"(h0), "v"(s1), "v"(h1));
-    asm("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_f16 %0, %0, 0" : "=v"(o) : "v"(t0), "v"(t1));
-    xb[Q & 1][J] = o;
+    unsigned o;      // (one statement: between two, hipcc pads the dependency with an s_nop the hardware does not need)
+    asm("v_fma_mix_f32 %1, %3, %4, %5 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %2, %3, %6, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_f16 %0, %0, 0"
+        : "=&v"(o), "=&v"(t0), "=&v"(t1) : "v"(in), "v"(s0), "v"(h0), "v"(s1), "v"(h1));
+    xb[Q % XN][J] = o;
   };
-  // everything the first k-steps of a row need, as 24 items: constants of k-steps 0 - 2, the weight fragments of k-steps 0
-  // and 1, the BN'd pixel fragment of k-step 0 (run as fillers of the PREVIOUS row's 3x3 phase, or exposed at the start)
-  auto pro_item = [&](auto i_tag) TN_INL {
-    constexpr int I = decltype(i_tag)::value;
-    if constexpr (I < 12) consts_item(ic<I / 4>{}, ic<I % 4>{});
-    else if constexpr (I < 20) wa_item(ic<(I - 12) / 4>{}, ic<(I - 12) % 4>{});
-    else if constexpr (I < 24) bn_item(ic<0>{}, ic<I - 20>{});
+  // pipeline item IDX of the row ybn
+  auto pl_item = [&](auto idx_tag, int ybn) TN_INL {
+    constexpr PItem it = pl_at<KS>(decltype(idx_tag)::value);
+    if constexpr (it.kind == 1) consts_item(ic<it.q>{});
+    else if constexpr (it.kind == 2) bn_item(ic<it.q>{}, ic<it.j>{});
+    else if constexpr (it.kind == 3) ld_item(ic<it.q>{}, ic<it.j>{}, ybn + 1);
   };
-  auto prologue_exposed = [&]() TN_INL {
-    static_for<24>([&](auto i_tag) TN_INL { pro_item(i_tag); });
+  auto wa_item = [&](auto q_tag, auto mb_tag) TN_INL {
+    constexpr int Q = decltype(q_tag)::value, MB = decltype(mb_tag)::value;
+    wa[Q & 1][MB] = *(const u32x4 *)(w1l + (Q * 4 + MB) * 1024);
+  };
+  auto wa_group = [&](auto q_tag) TN_INL { static_for<4>([&](auto mb_tag) TN_INL { wa_item(q_tag, mb_tag); }); };
+  // what the 3x3 phase of the previous row would have done for this row (first rows of a wave)
+  auto prologue_exposed = [&](int ybn) TN_INL {
+    wa_group(ic<0>{});
+    wa_group(ic<1>{});
+    static_for<PLB>([&](auto i_tag) TN_INL { pl_item(i_tag, ybn); });
     TN_SB();
   };
 
-  // ---- epilogue A: acc (= BN2 applied) -> ReLU, one rounding to fp16, lane-local pack -> window row PROW; 48 sub-items ----
-  // sub-item E: block MB = E / 12, register group G4 = (E % 12) / 3 (accumulators 4 G4 .. 4 G4 + 3 = bottleneck channels
-  // 32 MB + 8 G4 + 4 h + (0..3)), part (E % 3): 0 / 1 convert + ReLU of two values each, 2 the window write (every second group)
+  // ---- epilogue A: acc (= BN2 applied) -> ReLU, one rounding to fp16, lane-local pack -> window row PROW; 40 items: per window
+  // tuple T (k-step of the 3x3: accumulators 8 (T & 1) .. + 7 of block T >> 1) four convert + ReLU items of two values each and
+  // the window write ----
   auto epa_item = [&](auto prow_tag, auto e_tag) TN_INL {
     constexpr int PROW = decltype(prow_tag)::value, E = decltype(e_tag)::value;
-    constexpr int MB = E / 12, G4 = (E % 12) / 3, P = E % 3, E2 = G4 & 1;
+    constexpr int T = E / 5, I = E % 5, MB = T >> 1, R0 = 8 * (T & 1);
     unsigned (&epk)[4] = e_pk;             // (asm operands alone do not capture in a generic lambda)
     f32x16 (&accr)[4] = acc;
-    if constexpr (P <= 1) {
-      const float a0 = accr[MB][4 * G4 + 2 * P], a1 = accr[MB][4 * G4 + 2 * P + 1];
-      asm("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_f16 %0, %0, 0" : "=v"(epk[2 * E2 + P]) : "v"(a0), "v"(a1));
-    } else if constexpr (E2 == 1) {
-      win_write<PROW, 2 * MB + (G4 >> 1)>(epk[0], epk[1], epk[2], epk[3]);
+    if constexpr (I < 4) {
+      const float a0 = accr[MB][R0 + 2 * I], a1 = accr[MB][R0 + 2 * I + 1];
+      asm("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_f16 %0, %0, 0" : "=v"(epk[I]) : "v"(a0), "v"(a1));
+    } else {
+      win_write<PROW, T>(epk[0], epk[1], epk[2], epk[3]);
     }
   };
   auto epilogue_a_exposed = [&](auto prow_tag) TN_INL {
-    static_for<48>([&](auto e_tag) TN_INL { epa_item(prow_tag, e_tag); });
+    static_for<40>([&](auto e_tag) TN_INL { epa_item(prow_tag, e_tag); });
     TN_SB();
   };
-  // ---- epilogue B: 8 items; item P: out channels 16 h + 2 P, + 1 of the lane's pixel: out[x] = acc[dx=0][x] + acc[dx=-1][x-1] +
-  // acc[dx=+1][x+1], fp16; 16 B stored behind every fourth.  `off`: byte offset of the lane's 32 B (halo lanes / no previous
-  // row: past the descriptor's range - the hardware drops the store, no branch) ----
-  auto epb_item = [&](auto p_tag, unsigned off) TN_INL {
-    constexpr int P = decltype(p_tag)::value;
-    const float v0 = bacc[1][2 * P] + dpp_f32<0x111>(bacc[0][2 * P]) + dpp_f32<0x101>(bacc[2][2 * P]);   // row_shr:1: lane x reads x - 1; row_shl:1: x + 1
-    const float v1 = bacc[1][2 * P + 1] + dpp_f32<0x111>(bacc[0][2 * P + 1]) + dpp_f32<0x101>(bacc[2][2 * P + 1]);
-    const h2_t p = {(f16)v0, (f16)v1};
-    o_pk[P] = __builtin_bit_cast(unsigned, p);
-    if constexpr (P == 3 || P == 7) {
-      const u32x4 o = {o_pk[P - 3], o_pk[P - 2], o_pk[P - 1], o_pk[P]};
-      __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, off + (P == 7 ? 16 : 0), 0, 0);
+  // ---- epilogue B: 24 items; output dword P = out channels 16 h + 2 P, + 1 of the lane's pixel: out[x] = acc[dx=0][x] +
+  // acc[dx=-1][x-1] + acc[dx=+1][x+1], fp16; 16 B stored behind every fourth dword.  `off`: byte offset of the lane's 32 B (halo
+  // lanes / no previous row: past the descriptor's range - the hardware drops the store, no branch) ----
+  auto epb_item = [&](auto i_tag, unsigned off) TN_INL {
+    constexpr int I = decltype(i_tag)::value, P = I / 3, PART = I % 3;
+    if constexpr (PART == 0) {
+      o_c[0] = bacc[1][2 * P]; o_c[1] = bacc[1][2 * P + 1];
+      o_l[0] = bacc[0][2 * P]; o_l[1] = bacc[0][2 * P + 1];
+    } else if constexpr (PART == 1) {
+      o_c[0] += dpp_f32<0x111>(o_l[0]);     // row_shr:1: lane x reads lane x - 1
+      o_c[1] += dpp_f32<0x111>(o_l[1]);
+      o_r[0] = bacc[2][2 * P]; o_r[1] = bacc[2][2 * P + 1];
+    } else {
+      o_c[0] += dpp_f32<0x101>(o_r[0]);     // row_shl:1: lane x reads lane x + 1
+      o_c[1] += dpp_f32<0x101>(o_r[1]);
+      const h2_t p = {(f16)o_c[0], (f16)o_c[1]};
+      o_pk[P] = __builtin_bit_cast(unsigned, p);
+      if constexpr (P == 3 || P == 7) {
+        const u32x4 o = {o_pk[P - 3], o_pk[P - 2], o_pk[P - 1], o_pk[P]};
+        __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, off + (P == 7 ? 16 : 0), 0, 0);
+      }
     }
   };
   auto out_offset = [&](int yo, bool valid) TN_INL { return (valid && store_ok) ? outb + (unsigned)yo * rowpitch : 0x80000000u; };
@@ -285,28 +380,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   auto epilogue_b_exposed = [&](int yo) TN_INL {
     bacc_ready();
     const unsigned off = out_offset(yo, true);
-    static_for<8>([&](auto p_tag) TN_INL { epb_item(p_tag, off); });
-    TN_SB();
+    static_for<24>([&](auto i_tag) TN_INL { epb_item(i_tag, off); TN_SB(); });
   };
   auto w3_item = [&](auto s_tag, auto dx_tag) TN_INL {
     constexpr int S = decltype(s_tag)::value, DX = decltype(dx_tag)::value;
     w3f[S & 1][DX] = *(const u32x4 *)(w3l + (S * 3 + DX) * 1024);
   };
 
-  // ================= 1x1 phase of one bottleneck row (the ring holds it; it is refilled with row ynext) =================
-  // fillers: BN1 of the next k-step, weight fragments / constants one and two k-steps ahead, the ring refill behind a
-  // super-step's last k-step, epilogue B of the previous output row (yo_prev), the first BN2 constants of this row
-  auto phase_a = [&](int ynext, int yo_prev, bool prev_valid) TN_INL {
-    constexpr int NSLOT = 4 * (KQ + 1);
+  // ================= 1x1 phase of bottleneck row yb (its first PLB pipeline items have run) =================
+  // a slot: the MFMA, the reload of its weight register for k-step + 2, and ONE item: the next of the row's BN pipeline (when the
+  // pipeline would otherwise fall behind the MFMAs) or the next of the previous output row's epilogue B (make_a_sched)
+  auto phase_a = [&](int yb, int yo_prev, bool prev_valid) TN_INL {
+    constexpr auto SA = make_a_sched<KS>();
     bacc_ready();
     const unsigned off_prev = out_offset(yo_prev, prev_valid);
     static_for<KQ + 1>([&](auto q_tag) TN_INL {
       constexpr int Q = decltype(q_tag)::value;
-      constexpr int U = Q >> 2;
-      constexpr bool HALFU = ODD && U == NSU - 1;
-      constexpr bool LAST_OF_U = Q < KQ && (HALFU ? (Q & 3) == 1 : (Q & 3) == 3);
       static_for<4>([&](auto mb_tag) TN_INL {
         constexpr int MB = decltype(mb_tag)::value, SL = 4 * Q + MB;
+        if constexpr (MB == 0) {     // one wait for the four weight fragments of the k-step (requested two k-steps ago); inputs only:
+          u32x4 (&w)[4] = wa[Q & 1];   // an output would draw hipcc's asm boundary pad (s_nop) in front of the MFMA
+          asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));
+        }
         if constexpr (Q == 0) {
           f32x16 z;
 #pragma unroll
@@ -315,19 +410,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         } else if constexpr (Q == KQ) {
           acc[MB] = mfma32(wa[Q & 1][MB], xb_shift, acc[MB]);
         } else {
-          acc[MB] = mfma32(wa[Q & 1][MB], xb[Q & 1], acc[MB]);
+          acc[MB] = mfma32(wa[Q & 1][MB], xb[Q % XN], acc[MB]);
         }
-        if constexpr (Q + 1 < KQ) bn_item(ic<Q + 1>{}, mb_tag);
         if constexpr (Q + 2 < KQ + 1) wa_item(ic<Q + 2>{}, mb_tag);
-        if constexpr (Q + 3 < KQ) consts_item(ic<Q + 3>{}, mb_tag);
-        if constexpr (LAST_OF_U) {
-          if (!(TN_DS_EXP & 1)) ld_item(ic<U>{}, mb_tag, ynext);
-        }
-        // epilogue B item P sits in slot P * NSLOT / 8
-        static_for<8>([&](auto p_tag) TN_INL {
-          constexpr int P = decltype(p_tag)::value;
-          if constexpr ((P * NSLOT) / 8 == SL) epb_item(p_tag, off_prev);
-        });
+        constexpr ASlot sl = SA.s[SL];
+        static_for<sl.npl>([&](auto k_tag) TN_INL { pl_item(ic<sl.pl0 + decltype(k_tag)::value>{}, yb); });
+        static_for<sl.nepb>([&](auto k_tag) TN_INL { epb_item(ic<sl.epb0 + decltype(k_tag)::value>{}, off_prev); });
         TN_WIN_FENCE();
         TN_SB();
       });
@@ -335,21 +423,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
 
   // ================= 3x3 phase of one output row: window rows (ROT + 1) % 3, (ROT + 2) % 3, ROT (the new one) =================
-  // slot (dy, k-step, dx); the first 48 slots (dy = -1, 0: the two older rows) carry epilogue A of the new row into window row
-  // ROT, the last 24 the next row's first operands
-  auto phase_b = [&](auto rot_tag, auto epa_tag) TN_INL {
+  // slot (dy, k-step, dx): the MFMA, the reload of its weight register for step + 2, and one item: slots 0 - 39 epilogue A of the
+  // new row into window row ROT (first needed by slot 48), 40 / 41 the next row's first weight fragments, 42 - 71 the first PLB
+  // items of the next row's BN pipeline
+  auto phase_b = [&](auto rot_tag, auto epa_tag, int ybn) TN_INL {
     constexpr int ROT = decltype(rot_tag)::value;
     constexpr bool HAS_EPA = decltype(epa_tag)::value != 0;
     static_for<72>([&](auto e_tag) TN_INL {
       constexpr int E = decltype(e_tag)::value;
       constexpr int S = E / 3, DX = E % 3, DY = S / 8, T = S % 8;
       constexpr int PROW = (ROT + 1 + DY) % 3;
+      if constexpr (DX == 0) {     // one wait for the step's three weight fragments
+        u32x4 (&w)[3] = w3f[S & 1];
+        asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]));
+      }
       mfma32_win<S == 0, PROW, T>(bacc[DX], w3f[S & 1][DX]);
       if constexpr (S + 2 < 24) w3_item(ic<S + 2>{}, ic<DX>{});
-      if constexpr (E < 48) {
+      if constexpr (E < 40) {
         if constexpr (HAS_EPA) epa_item(rot_tag, e_tag);
-      } else {
-        pro_item(ic<E - 48>{});
+      } else if constexpr (E < 42) {
+        wa_group(ic<E - 40>{});
+      } else if constexpr (E - 42 < PLB) {
+        pl_item(ic<E - 42>{}, ybn);
       }
       TN_WIN_FENCE();
       TN_SB();
@@ -359,7 +454,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   int nstamp = 0;
   auto stamp = [&]() TN_INL {
-    if (a.ts && wid == 0 && nstamp < 128) {
+    if (a.ts && wid == 0 && nstamp < 125) {
       if (lane == 0) a.ts[(size_t)blockIdx.x * 128 + nstamp] = __builtin_amdgcn_s_memtime();
       ++nstamp;
     }
@@ -367,11 +462,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // one steady-state row: bottleneck row yb (1x1 phase, into window row ROT through the 3x3 phase's fillers), output row yb - 1
   auto row_event = [&](auto rot_tag, int yb, bool prev_valid) TN_INL {
     stamp();
-    if (!(TN_DS_EXP & 4)) phase_a(yb + 1, yb - 2, prev_valid);
+    if (!(TN_DS_EXP & 4)) phase_a(yb, yb - 2, prev_valid);
     load_w3_first();
     TN_SB();
     stamp();
-    if (!(TN_DS_EXP & 2)) phase_b(rot_tag, ic<1>{});
+    if (!(TN_DS_EXP & 2)) phase_b(rot_tag, ic<1>{}, yb + 1);
   };
 
   // ================= the wave's program =================
@@ -381,27 +476,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = 0; i < 16; ++i) z[i] = 0.f;
     bacc[0] = z; bacc[1] = z; bacc[2] = z;
   }
-#ifdef TN_DS_STAGGER
-  // the four waves of a CU (and neighbouring CUs) start their row loops a fraction of a row period apart, so that the 1x1
-  // phases - the only ones that issue activation loads - do not all fall together
-  for (int i = 0; i < ((wid + (int)blockIdx.x) & 3) * TN_DS_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);
-#endif
   stamp();
   const int yfirst = r_lo > 0 ? r_lo - 1 : 0;
-  static_for<NSU>([&](auto u_tag) TN_INL { static_for<4>([&](auto i_tag) TN_INL { ld_item(u_tag, i_tag, yfirst); }); });
+  static_for<NSU>([&](auto u_tag) TN_INL {
+    constexpr bool HALF = ODD && decltype(u_tag)::value == NSU - 1;
+    static_for<(HALF ? 2 : 4)>([&](auto i_tag) TN_INL { ring[decltype(u_tag)::value][decltype(i_tag)::value] =
+        *(const u32x4 *)(rowbase(yfirst) + (HALF ? colh : colb) + 128 * decltype(u_tag)::value + 16 * decltype(i_tag)::value); });
+  });
   // bottleneck row r_lo - 1 -> window row 0 (zeros above the image)
   if (r_lo > 0) {
-    prologue_exposed();
-    phase_a(r_lo, 0, false);
+    prologue_exposed(r_lo - 1);
+    phase_a(r_lo - 1, 0, false);
     epilogue_a_exposed(ic<0>{});
   } else {
     win_zero<0>();
   }
   // bottleneck row r_lo -> window row 1
-  prologue_exposed();
-  phase_a(r_lo + 1, 0, false);
+  prologue_exposed(r_lo);
+  phase_a(r_lo, 0, false);
   epilogue_a_exposed(ic<1>{});
-  prologue_exposed();
+  prologue_exposed(r_lo + 1);
   stamp();
   // rows r_lo + 1 .. r_hi - 1: the steady state, window rotation 2, 0, 1, ...
   int yb = r_lo + 1;
@@ -422,11 +516,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     win_zero<ROTL>();
     load_w3_first();
     TN_SB();
-    phase_b(ic<ROTL>{}, ic<0>{});
+    phase_b(ic<ROTL>{}, ic<0>{}, r_hi);
   }
   stamp();
   epilogue_b_exposed(r_hi - 1);
   stamp();
+  if (a.ts && wid == 0 && lane == 0) a.ts[(size_t)blockIdx.x * 128 + 125] = __builtin_amdgcn_s_memrealtime();
 }
 
 template <int W, int KS>
