@@ -154,6 +154,15 @@ def run(argv):
     feats = [torch.empty((args.batch, enc.feature_dim), dtype=torch.float32, device=dev) for _ in range(2)]
     gathered = [torch.empty((world * args.batch, enc.feature_dim), dtype=torch.float32, device=dev)
                 for _ in range(2)] if world > 1 else None
+    # the exchange step goes through the library's own RCCL communicator (tn_allgather_features); torch.distributed only
+    # carries the barrier and the max over ranks of the timing
+    comm = sharding.feature_comm(dev) if world > 1 else None
+    gather_h = [None, None]
+
+    def allgather(j):
+        if gather_h[j] is not None:
+            gather_h[j].wait()          # the previous collective into this buffer pair
+        gather_h[j] = comm.allgather_features(feats[j], gathered[j])
 
     # Pipelined forwards (tn_densenet121_set_pipelined): the encoder runs a batch as two half batches on two streams, and
     # the last chained block of the second half occupies half of the CUs; without a join inside forward the next step's
@@ -167,16 +176,20 @@ def run(argv):
         enc(x, out=f)
         if world > 1:
             if not pipelined:
-                dist.all_gather_into_tensor(gathered[i & 1], f)
+                allgather(i & 1)
             elif i > 0:
                 enc.join(1)
-                dist.all_gather_into_tensor(gathered[(i - 1) & 1], feats[(i - 1) & 1])
+                allgather((i - 1) & 1)
 
     def drain(k):
         if pipelined and k > 0:
             enc.join(0)
             if world > 1:
-                dist.all_gather_into_tensor(gathered[(k - 1) & 1], feats[(k - 1) & 1])
+                allgather((k - 1) & 1)
+        for j in (0, 1):
+            if gather_h[j] is not None:
+                gather_h[j].wait()
+                gather_h[j] = None
 
     def fence():
         if world > 1:

@@ -259,6 +259,35 @@ int tn_gnmt_trainer_destroy(tn_gnmt_trainer *t);
 int tn_prf1_update(tn_ctx *ctx, const float *logits, const int32_t *labels, int rows, int classes,
                    int64_t *mat);
 
+/* ---- multi-GPU exchange: RCCL over xGMI, one process per GPU (csrc/comm.hip) ------------
+ * The path's one exchange step (BASELINE config C4).  The reference splits every DataLoader batch over its ctx list and
+ * exchanges the per-frame feature rows through the file system: evaluate.py:278-281,308-321 writes
+ * <root>/features/<model_id>/<video>/<frame>.npy, dataset.py:202-204 np.load()s them for the temporal / caption stage.
+ * Here every rank keeps its shard of feature rows in HBM and one all-gather puts the whole (N, F) matrix on every rank.
+ * Also: the sum / mean of the three trainers' flat gradient buffers (train.py:410-424 `trainer.step` over a ctx list =
+ * kvstore 'device' all-reduce) and of the PRF1 confusion counts.
+ *
+ * Rank 0 calls tn_comm_unique_id and hands the 128 bytes to the other ranks by any out-of-band channel (a file, a TCP
+ * store, MPI); every rank then calls tn_comm_create with its own context (one process per GPU, the context's device).
+ * All collectives are asynchronous and ordered on the context's stream like every other entry point; librccl is opened
+ * at run time (a process that already holds one - PyTorch's - shares it), a world of 1 needs none (TN_COMM_FORCE_RCCL
+ * makes a single rank go through RCCL all the same: the self-test of 1-GPU boxes). */
+#define TN_UNIQUE_ID_BYTES 128
+#define TN_COMM_FORCE_RCCL 1
+typedef struct tn_comm tn_comm;
+int tn_comm_unique_id(void *id_out /* TN_UNIQUE_ID_BYTES */);
+int tn_comm_create(tn_ctx *ctx, int rank, int world, const void *unique_id /* NULL for world 1 */, int flags,
+                   tn_comm **out);
+int tn_comm_rank(const tn_comm *c);
+int tn_comm_world(const tn_comm *c);
+/* out (world*rows, F) = rank-major concatenation of every rank's shard (rows, F); equal `rows` on every rank (pad the last
+ * round, sharding.local_rows); shard may alias its own slot of out. */
+int tn_allgather_features(tn_comm *c, const float *shard, int rows, int F, float *out);
+/* in place; average != 0 divides by the world size (Trainer.step's rescale) */
+int tn_allreduce_f32(tn_comm *c, float *buf, size_t n, int average);
+int tn_allreduce_i64(tn_comm *c, int64_t *buf, size_t n);
+int tn_comm_destroy(tn_comm *c);
+
 /* ---- GNMT captioner: encoder + attention decoder + beam search -------------- */
 /* Replaces get_gnmt_encoder_decoder / NMTModel / BeamSearchTranslator as assembled at
  * reference train_gnmt.py:223-252 and driven by evaluate() (train_gnmt.py:264-302):

@@ -113,6 +113,14 @@ _SIGS = {
     "tn_dbg_dense_layer_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int,
                                          _P, C.c_int]),
     "tn_dbg_linear": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int]),
+    "tn_comm_unique_id": (C.c_int, [_P]),
+    "tn_comm_create": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.POINTER(_P)]),
+    "tn_comm_rank": (C.c_int, [_P]),
+    "tn_comm_world": (C.c_int, [_P]),
+    "tn_allgather_features": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "tn_allreduce_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_int]),
+    "tn_allreduce_i64": (C.c_int, [_P, _P, C.c_size_t]),
+    "tn_comm_destroy": (C.c_int, [_P]),
     "tn_dbg_pack_strip": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),
     "tn_dbg_dense_strip_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
 }

@@ -270,6 +270,7 @@ struct tn_encoder {
   bool pipelined = false;            // tn_densenet121_set_pipelined: the caller's stream is not made to wait inside forward
   long calls = 0;                    // forward calls so far
   int split_of[2] = {0, 0};          // side streams the call of each parity used (0: it ran on the caller's stream)
+  int split_batch = 0;               // batch size of the last split call (pipelined calls share the workspace by row range)
 };
 
 static const int kBlockCfg[4] = {6, 12, 24, 16};
@@ -543,6 +544,16 @@ static int encoder_run(tn_encoder *e, const void *x, tn_layout layout, int B, fl
     return encoder_run_range(e, x, layout, 0, B, feat, s, tm);
   }
   TN_HIP_CHECK(hipEventRecord(e->ev_in, s));
+  // Pipelined calls overlap on the side streams, and half h of every call works in workspace rows [h B / ns, (h + 1) B / ns):
+  // equal batch sizes keep each row range on one stream, whose order then separates consecutive calls.  When the batch size
+  // changes (a corpus' ragged last batch) the ranges shift across streams: every side stream first waits for everything the
+  // earlier calls left on ANY side stream.
+  if (e->pipelined && e->split_batch != 0 && e->split_batch != B) {
+    for (int h = 0; h < ns; ++h)
+      for (int p2 = 0; p2 < 2; ++p2)
+        for (int g = 0; g < e->split_of[p2]; ++g) TN_HIP_CHECK(hipStreamWaitEvent(e->side[h], e->ev_done[p2][g], 0));
+  }
+  e->split_batch = B;
   int rc = TN_OK;
   for (int h = 0; h < ns; ++h) {
     TN_HIP_CHECK(hipStreamWaitEvent(e->side[h], e->ev_in, 0));

@@ -310,6 +310,7 @@ class DataLoader:
         self._rng = np.random.default_rng(seed)
         self.num_workers = max(0, min(int(num_workers), 2))
         self._tls = None
+        self._decoders = []          # (stream, JpegDecoder) of the worker threads, kept across epochs
 
     def __len__(self):
         n = len(self.dataset)
@@ -362,6 +363,12 @@ class DataLoader:
                 break
             yield ids
 
+    def batches_of(self, rank: int, world: int):
+        """The batches b with b mod world == rank, collated: a rank of a sharded run reads, decodes and resizes only its own."""
+        for b, ids in enumerate(self._batches()):
+            if b % world == rank:
+                yield self.collate(ids)
+
     def __iter__(self):
         if self.num_workers == 0 or not self._device_route():
             for ids in self._batches():
@@ -375,11 +382,22 @@ class DataLoader:
 
         from . import _lib, image
         tls = threading.local()
+        lock = threading.Lock()
+        free = list(self._decoders)      # decoders (contexts, streams, pinned workspaces) of earlier epochs are re-used
 
         def work(ids):
             if not hasattr(tls, "dec"):
-                tls.dec = image.JpegDecoder(_lib.Context(stream=torch.cuda.Stream()))
-            return self._decode_on_device(ids, tls.dec)      # (tn_jpeg_decode returns with its stream synchronised)
+                with lock:
+                    if free:
+                        tls.stream, tls.dec = free.pop()
+                    else:
+                        tls.stream = torch.cuda.Stream()
+                        tls.dec = image.JpegDecoder(_lib.Context(stream=tls.stream))
+                        self._decoders.append((tls.stream, tls.dec))
+            # the output is allocated AND written under the worker's stream: the caching allocator then never hands the worker
+            # a block whose last reader is still queued on another stream (tn_jpeg_decode returns with its stream synchronised)
+            with torch.cuda.stream(tls.stream):
+                return self._decode_on_device(ids, tls.dec)
 
         with ThreadPoolExecutor(max_workers=self.num_workers) as pool:
             pending = []

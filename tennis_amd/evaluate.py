@@ -104,8 +104,9 @@ def save_features_sharded(net, loader, dataset, device=None, rank=None, world=No
         return feat
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    comm = sharding.feature_comm(device, group) if world > 1 else None
     full = sharding.extract_features_sharded(encode, len(dataset), loader.batch_size, fdim, device, rank=rank, world=world,
-                                             group=group, block=block, stats=stats)
+                                             group=group, block=block, stats=stats, comm=comm)
     return full, written[0]
 
 
@@ -165,6 +166,7 @@ def extract_corpus(backbone, n_frames, batch, size, device, rank, world, block=4
         eng.join(1)
         live.clear()
     fence = (lambda: (torch.distributed.barrier() if world > 1 else None, torch.cuda.synchronize() if device.type == "cuda" else None))
+    comm = sharding.feature_comm(device) if world > 1 else None
     stats = {}
     fence()
     t0 = time.perf_counter()
@@ -172,7 +174,8 @@ def extract_corpus(backbone, n_frames, batch, size, device, rank, world, block=4
         eng.set_pipelined(True)
     try:
         full = sharding.extract_features_sharded(encode, n_frames, batch, fdim, device, rank=rank, world=world, block=block, stats=stats,
-                                                 encode_into=encode_into if pipelined else None, join=join if pipelined else None)
+                                                 encode_into=encode_into if pipelined else None, join=join if pipelined else None,
+                                                 comm=comm)
     finally:
         if pipelined:
             eng.set_pipelined(False)
@@ -240,10 +243,12 @@ def main(argv=None):
         return 0
     rank, world, dev = sharding.init_distributed()
     try:
-        return _main_rank(flags, rank, world, dev)
+        rc = _main_rank(flags, rank, world, dev)
+        if world > 1 and torch.distributed.is_initialized():
+            torch.distributed.barrier()          # success path only: a rank that raised must not park the others' collectives
+        return rc
     finally:
         if world > 1 and torch.distributed.is_initialized():
-            torch.distributed.barrier()
             torch.distributed.destroy_process_group()
 
 
@@ -317,9 +322,13 @@ def _main_rank(flags, rank, world, dev):
     tic = time.time()
     if world > 1:                                                           # each rank tests batches rank::world
         results, gts = evaluate_model(model, _RankBatches(test_data, rank, world), test_set, test_metrics)
+        comm = sharding.feature_comm(dev)
         for m in test_metrics:                                              # confusion counts add up over the ranks
             packed = torch.from_numpy(np.concatenate([m.mat.ravel(), m.scores.ravel()])).to(dev)
-            torch.distributed.all_reduce(packed)
+            if comm is not None and packed.dtype in (torch.float32, torch.int64):
+                comm.allreduce_(packed).wait()                              # tn_allreduce_* of the C-ABI
+            else:
+                torch.distributed.all_reduce(packed)
             packed = packed.cpu().numpy()
             m.mat = packed[:m.mat.size].reshape(m.mat.shape)
             m.scores = packed[m.mat.size:].reshape(m.scores.shape)
@@ -348,6 +357,11 @@ class _RankBatches:
         self.loader, self.rank, self.world = loader, rank, world
 
     def __iter__(self):
+        # batch ids are filtered BEFORE collation where the loader allows it (tennis_amd.dataset.DataLoader.batches_of): a
+        # rank then reads, decodes and resizes only its own batches
+        if hasattr(self.loader, "batches_of"):
+            yield from self.loader.batches_of(self.rank, self.world)
+            return
         for b, batch in enumerate(self.loader):
             if b % self.world == self.rank:
                 yield batch

@@ -128,15 +128,26 @@ def gather_feature_rows(shard: torch.Tensor, n_frames: int, batch: int, group=No
     return out[:n_frames]
 
 
+def feature_comm(device, group=None):
+    """The C-ABI communicator (tennis_amd.comm.Comm: RCCL behind ``tn_comm_*``) over the ranks of ``group`` when the
+    process runs on a GPU, else None (the CPU tests exchange through torch.distributed / gloo)."""
+    if torch.device(device).type != "cuda":
+        return None
+    from .comm import Comm
+    return Comm.from_process_group(group, torch.device(device).index)
+
+
 def extract_features_sharded(encode_batch, n_frames: int, batch: int, feature_dim: int, device, rank=None,
                              world=None, group=None, block: int = 1, stats: dict | None = None,
-                             encode_into=None, join=None) -> torch.Tensor:
+                             encode_into=None, join=None, comm=None) -> torch.Tensor:
     """Run ``encode_batch(start, stop) -> (stop-start, F)`` over this rank's batches and all-gather the rows round by
     round, each round's collective in flight while the next round is encoded.  Returns the full (n_frames, F) matrix
     on every rank.  ``stats`` (optional dict) receives ``rounds``, ``gather_bytes_per_rank`` and ``frames_local``.
     Pipelined encoders (``engine.DenseNet121Features.set_pipelined``): pass ``encode_into(start, stop, rows)`` - it
     writes its features into ``rows`` without waiting for them - and ``join()``, which orders everything encoded so far
-    in front of what the current stream does next; it is called once per round, in front of the round's collective."""
+    in front of what the current stream does next; it is called once per round, in front of the round's collective.
+    ``comm`` (``feature_comm``): the collectives go through the library's own RCCL communicator (``tn_allgather_features``)
+    instead of torch.distributed."""
     if rank is None:
         rank = _rank(group)
     if world is None:
@@ -159,12 +170,15 @@ def extract_features_sharded(encode_batch, n_frames: int, batch: int, feature_di
             else:
                 shard[r0:r0 + (e - s)] = encode_batch(s, e)
             done += e - s
-        if join is not None and (world > 1 or c == rounds - 1):
-            join()
+        if join is not None:
+            join()       # every round (a few stream waits): bounds what a pipelined encoder keeps referenced, also with one rank
         if world > 1:
             # rows [c*world*rows, (c+1)*world*rows) of the output = rank-major concatenation of this round's shard chunks
-            pending.append(dist.all_gather_into_tensor(out[c * world * rows:(c + 1) * world * rows],
-                                                       shard[c * rows:(c + 1) * rows], group=group, async_op=True))
+            if comm is not None:
+                pending.append(comm.allgather_features(shard[c * rows:(c + 1) * rows], out[c * world * rows:(c + 1) * world * rows]))
+            else:
+                pending.append(dist.all_gather_into_tensor(out[c * world * rows:(c + 1) * world * rows],
+                                                           shard[c * rows:(c + 1) * rows], group=group, async_op=True))
             if len(pending) > 4:                           # bound the collectives in flight
                 pending.pop(0).wait()
     for w in pending:

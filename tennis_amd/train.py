@@ -24,8 +24,25 @@ def allreduce_and_step(trainer, global_batch_size: int, lr: float, momentum: flo
     ``trainer.step(FLAGS.batch_size)``, train.py:424)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(trainer.grads, op=dist.ReduceOp.SUM)
+        comm = _grad_comm(trainer.grads.device)
+        if comm is not None:
+            comm.allreduce_(trainer.grads).wait()      # tn_allreduce_f32: RCCL behind the C-ABI
+        else:
+            dist.all_reduce(trainer.grads, op=dist.ReduceOp.SUM)
     trainer.step(global_batch_size, lr, momentum, wd)
+
+
+_COMMS = {}
+
+
+def _grad_comm(device):
+    """The process's C-ABI communicator over the default group (GPU runs; None on CPU: the gloo tests)."""
+    if device.type != "cuda":
+        return None
+    if device.index not in _COMMS:
+        from . import sharding
+        _COMMS[device.index] = sharding.feature_comm(device)
+    return _COMMS[device.index]
 
 
 class Trainer:

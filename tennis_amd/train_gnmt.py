@@ -36,8 +36,14 @@ def allreduce_grads(trainer, n_tokens: int):
         g = trainer.grads
         cnt = torch.tensor([float(n_tokens)], dtype=torch.float32, device=g.device)
         g *= float(n_tokens)
-        dist.all_reduce(g, op=dist.ReduceOp.SUM)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        from .train import _grad_comm
+        comm = _grad_comm(g.device)
+        if comm is not None:                     # tn_allreduce_f32: RCCL behind the C-ABI
+            comm.allreduce_(g)
+            comm.allreduce_(cnt).wait()
+        else:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         g /= cnt
 
 

@@ -298,6 +298,31 @@ def test_batch_larger_than_handle_is_an_error():
         enc(x)
 
 
+def test_pipelined_forwards_with_changing_batch_size():
+    """Pipelined split forwards share the workspace by row range per side stream; a call with a different batch size (a
+    corpus' ragged last batch: 128 behind 256) moves the ranges across the streams and must be ordered behind everything
+    the earlier calls left on either of them (api.hip split path)."""
+    from tennis_amd import weights as W
+    from tennis_amd.engine import DenseNet121Features
+    p = W.make_densenet121_weights(0)
+    enc = DenseNet121Features(p, 224, max_batch=256)
+    big = [torch.from_numpy(W.synthetic_frames_u8(256, 224, seed=s)).cuda() for s in (11, 12)]
+    small = torch.from_numpy(W.synthetic_frames_u8(128, 224, seed=13)).cuda()
+    ref = [enc(x).clone() for x in (big[0], small, big[1])]
+    torch.cuda.synchronize()
+    enc.set_pipelined(True)
+    for _ in range(3):
+        outs = [torch.empty_like(r) for r in ref]
+        for x, o in zip((big[0], small, big[1]), outs):
+            enc(x, out=o)
+        enc.join(0)
+        enc.join(1)
+        torch.cuda.synchronize()
+        for a, b in zip(ref, outs):
+            assert torch.equal(a, b)
+    enc.set_pipelined(False)
+
+
 def test_pipelined_forwards_match_joined_ones():
     """tn_densenet121_set_pipelined: consecutive forwards overlap on the side streams and the caller joins them - the
     features are the ones the stream-ordered forwards give, for results consumed at once (lag 0) and one call behind"""

@@ -92,3 +92,72 @@ def test_bench_line_and_self_spawn():
         r = _run(["bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"])
         assert r.returncode == 0, r.stdout + r.stderr
         assert _json_line(r.stdout)["n_gpus"] == 2
+
+
+# ---- the exchange step behind the C-ABI (tn_comm_* / tn_allgather_features / tn_allreduce_*) ----
+def _comm_rank_main(rank, world, idfile, outfile):
+    """one rank of the C-ABI communicator test (a spawned process per GPU)"""
+    import time
+    import torch
+    torch.cuda.set_device(rank)
+    from tennis_amd.comm import Comm
+    if rank == 0:
+        uid = Comm.new_unique_id()
+        with open(idfile + ".tmp", "wb") as f:
+            f.write(uid)
+        os.replace(idfile + ".tmp", idfile)          # the out-of-band channel of this test: a file
+    else:
+        for _ in range(600):
+            if os.path.exists(idfile):
+                break
+            time.sleep(0.1)
+        uid = open(idfile, "rb").read()
+    comm = Comm(rank, world, uid, device=rank)
+    rows, f = 96, 1024
+    g = torch.Generator().manual_seed(100 + rank)
+    shard = torch.rand((rows, f), generator=g).cuda()
+    out = torch.zeros((world * rows, f), device="cuda")
+    comm.allgather_features(shard, out).wait()
+    grads = torch.full((1000,), float(rank + 1), device="cuda")
+    comm.allreduce_(grads).wait()
+    counts = torch.arange(121, dtype=torch.int64, device="cuda") * (rank + 1)
+    comm.allreduce_(counts).wait()
+    torch.cuda.synchronize()
+    torch.save({"out": out.cpu(), "grads": grads.cpu(), "counts": counts.cpu()}, outfile % rank)
+    comm.close()
+
+
+@pytest.mark.parametrize("force_rccl", [False, True])
+def test_comm_single_rank_through_the_abi(force_rccl):
+    """world 1: the all-gather is the identity and the all-reduces leave their buffers alone - without RCCL, and with
+    TN_COMM_FORCE_RCCL through a real one-rank RCCL communicator (librccl opened by its SONAME: the instance PyTorch holds)."""
+    from tennis_amd.comm import Comm
+    comm = Comm(0, 1, Comm.new_unique_id() if force_rccl else None, force_rccl=force_rccl)
+    shard = torch.rand((64, 1024), device="cuda")
+    out = torch.zeros_like(shard)
+    comm.allgather_features(shard, out).wait()
+    g = torch.rand(777, device="cuda")
+    g0 = g.clone()
+    comm.allreduce_(g, average=True).wait()
+    c = torch.arange(50, dtype=torch.int64, device="cuda")
+    comm.allreduce_(c).wait()
+    torch.cuda.synchronize()
+    assert torch.equal(out, shard) and torch.equal(g, g0) and torch.equal(c, torch.arange(50, dtype=torch.int64, device="cuda"))
+    comm.close()
+
+
+def test_comm_all_ranks_of_the_box(tmp_path):
+    """One process per GPU of the box (1 on the test box: the spawn path with one rank; asserted against the un-sharded
+    matrix for any number): tn_allgather_features puts every rank's rows in rank-major order on every rank,
+    tn_allreduce_f32 / _i64 sum over the ranks."""
+    import torch.multiprocessing as mp
+    world = torch.cuda.device_count()
+    idfile, outfile = str(tmp_path / "uid"), str(tmp_path / "rank%d.pt")
+    mp.spawn(_comm_rank_main, args=(world, idfile, outfile), nprocs=world, join=True)
+    rows, f = 96, 1024
+    expect = torch.cat([torch.rand((rows, f), generator=torch.Generator().manual_seed(100 + r)) for r in range(world)])
+    for r in range(world):
+        got = torch.load(outfile % r)
+        assert torch.equal(got["out"], expect)
+        assert torch.equal(got["grads"], torch.full((1000,), float(world * (world + 1) // 2)))
+        assert torch.equal(got["counts"], torch.arange(121, dtype=torch.int64) * (world * (world + 1) // 2))
