@@ -101,19 +101,21 @@ __device__ __forceinline__ f16x8 bn_relu8_mix(f16x8 v, const float *__restrict__
 
 // relu(acc*s+t) for 4 fp32 accumulators -> 4 fp16 (fp32 fma, one rounding, packed ReLU): 4 v_fma_f32 + 2 v_cvt_pk_f16_f32 +
 // 2 v_pk_max_f16 = 12.9 ns against 18.3 ns for 4 v_fma_mixlo/hi_f16 + 2 v_pk_max_f16 (inline asm: left to itself the
-// compiler SLP-packs the fmas and pays for it in moves).
+// compiler fuses fma + conversion into the slow mixlo / mixhi forms, or SLP-packs the fmas and pays for it in moves).
+// `v` is an MFMA result, and hipcc pads no MFMA -> VALU hazard in front of an asm statement (it does not know what the
+// statement reads; garbage was seen in round 2 when the scheduler happened to put the last MFMA right in front of it): the
+// statement therefore OPENS with the wait states an 8-pass MFMA result needs (12, cdna_hip_programming.md 5.7 item 2) - one
+// statement, so nothing can be scheduled between the wait and the reads.  Correctness no longer depends on where the
+// compiler places the MFMAs.
 __device__ __forceinline__ f16x4 bn_relu4_from_f32(f32x4 v, float4 s, float4 t) {
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   float a0, a1, a2, a3;
   unsigned d0, d1;
-  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(a0) : "v"(v[0]), "v"(s.x), "v"(t.x));
-  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(a1) : "v"(v[1]), "v"(s.y), "v"(t.y));
-  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(a2) : "v"(v[2]), "v"(s.z), "v"(t.z));
-  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(a3) : "v"(v[3]), "v"(s.w), "v"(t.w));
-  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d0) : "v"(a0), "v"(a1));
-  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d1) : "v"(a2), "v"(a3));
-  asm("v_pk_max_f16 %0, %0, 0" : "+v"(d0));
-  asm("v_pk_max_f16 %0, %0, 0" : "+v"(d1));
+  asm("s_nop 11\n\t"
+      "v_fma_f32 %2, %6, %10, %14\n\tv_fma_f32 %3, %7, %11, %15\n\tv_fma_f32 %4, %8, %12, %16\n\tv_fma_f32 %5, %9, %13, %17\n\t"
+      "v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5\n\tv_pk_max_f16 %0, %0, 0\n\tv_pk_max_f16 %1, %1, 0"
+      : "=&v"(d0), "=&v"(d1), "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(s.x), "v"(s.y), "v"(s.z), "v"(s.w), "v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w));
   const u32x2 o = {d0, d1};
   return __builtin_bit_cast(f16x4, o);
 }

@@ -282,9 +282,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
       unsigned m[2][2];                             // running maximum of the pooled row in progress, per channel fragment
       // conv row r (complete after patch row 2r + 6): BN in fp32, fp16, max into the pooled rows it belongs to
       // (r = 2 pr + {0,1,2}); an even row closes pooled row r/2 - 1 (ReLU on the maximum, then LDS) and opens row r/2
-      // TAIL: the row's MFMAs were the last ones issued.  The hazard recogniser does not count wait states in front of
-      // inline asm that reads an MFMA result (seen as garbage in the low halves of the last pooled row), so the two tail
-      // calls convert through plain C++; everywhere else at least three MFMAs lie between a row's last MFMA and its BN
+      // The hazard recogniser does not count wait states in front of inline asm that reads an MFMA result (seen in round 2
+      // as garbage in the low halves of the last pooled row, depending on where the scheduler put the row's last MFMA): the
+      // statement OPENS with the 12 wait states an 8-pass MFMA result needs and is ONE statement, so nothing can come
+      // between the wait and the reads - correctness does not depend on MFMA placement (the tail calls keep the plain C++ form)
       auto finish_half = [&](int r, int nf, auto tail_tag) {
         uint2 u;
         if constexpr (decltype(tail_tag)::value) {
@@ -296,12 +297,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
           // fp32 fma, one rounding to fp16: four v_fma_f32 + two v_cvt_pk_f16_f32 (9 ns per SIMD; four v_fma_mixlo/hi_f16
           // would be 14, and left to itself the compiler SLP-packs pairs into v_pk_fma_f32 + moves + converts)
           float b0, b1, b2, b3;
-          asm("v_fma_f32 %0, %1, %2, %3" : "=v"(b0) : "v"(acc[r][nf][0]), "v"(sc[nf][0]), "v"(sh[nf][0]));
-          asm("v_fma_f32 %0, %1, %2, %3" : "=v"(b1) : "v"(acc[r][nf][1]), "v"(sc[nf][1]), "v"(sh[nf][1]));
-          asm("v_fma_f32 %0, %1, %2, %3" : "=v"(b2) : "v"(acc[r][nf][2]), "v"(sc[nf][2]), "v"(sh[nf][2]));
-          asm("v_fma_f32 %0, %1, %2, %3" : "=v"(b3) : "v"(acc[r][nf][3]), "v"(sc[nf][3]), "v"(sh[nf][3]));
-          asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u.x) : "v"(b0), "v"(b1));
-          asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u.y) : "v"(b2), "v"(b3));
+          asm("s_nop 11\n\t"
+              "v_fma_f32 %2, %6, %10, %14\n\tv_fma_f32 %3, %7, %11, %15\n\tv_fma_f32 %4, %8, %12, %16\n\tv_fma_f32 %5, %9, %13, %17\n\t"
+              "v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5"
+              : "=&v"(u.x), "=&v"(u.y), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+              : "v"(acc[r][nf][0]), "v"(acc[r][nf][1]), "v"(acc[r][nf][2]), "v"(acc[r][nf][3]),
+                "v"(sc[nf][0]), "v"(sc[nf][1]), "v"(sc[nf][2]), "v"(sc[nf][3]), "v"(sh[nf][0]), "v"(sh[nf][1]), "v"(sh[nf][2]), "v"(sh[nf][3]));
         }
         if constexpr (BORDER) {
           const bool valid = cvalid && (unsigned)(cy0 + r) < (unsigned)a.Ho;
@@ -322,9 +323,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
       for (int p = 0; p < IR; ++p) {
         if (p + 2 < IR) xb[(p + 2) % 3] = *(const f16x8 *)(prow + (p + 2) * IPITCH);
         __builtin_amdgcn_sched_barrier(0);
-        // every region opens with (up to) three MFMAs: whatever order the compiler gave the previous region's MFMAs, the
-        // inline-asm BN below then reads an accumulator at least two MFMAs (32 cycles) after the one that completed it
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
 #pragma unroll
         for (int r = 0; r < CR; ++r) {
           const int ky = p - 2 * r;
