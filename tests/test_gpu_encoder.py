@@ -61,7 +61,25 @@ def test_encoder_layouts_agree(setup, report):
     f_u8 = enc(torch.from_numpy(setup["frames"]).cuda()).cpu().numpy()
     e = float(np.abs(f_u8 - setup["ref"]).max())
     report["encoder_u8_feat_maxabs_err"] = e
-    assert e < 5e-3, e   # u8 path re-derives the normalised pixel (one extra fp16 rounding of the input)
+    assert e < TOL, e    # (the u8 path derives the normalised pixel in fp32 and rounds it once: measured 5.5e-4)
+
+
+def test_unrounded_input_is_inside_the_bar(setup, report):
+    """What the reference's test transform produces (evaluate.py:93-98: ToTensor + Normalize of the uint8 frame) is fp32 and
+    NOT fp16-representable; the encoder rounds it to fp16 on the way in (fp32 NCHW hand-over: in the layout kernel; uint8
+    hand-over: (u8/255 - mean)/std evaluated in fp32, rounded once).  Here the oracle is fed the UN-rounded fp32 tensor: the
+    input rounding is part of the measured error, and the bar stays 1e-3."""
+    from tennis_amd import weights as W
+    enc, frames = setup["enc"], setup["frames"]
+    x32 = W.normalize_to_nchw_f32(frames)                      # fp32, un-rounded
+    assert (x32.astype(np.float16).astype(np.float32) != x32).any()
+    ref = dn.densenet121_features(x32, setup["p"])
+    f_u8 = enc(torch.from_numpy(frames).cuda()).cpu().numpy()
+    f_nchw = enc(torch.from_numpy(x32).cuda()).cpu().numpy()
+    e_u8, e_nchw = float(np.abs(f_u8 - ref).max()), float(np.abs(f_nchw - ref).max())
+    report["encoder_u8_vs_unrounded_oracle_maxabs_err"] = e_u8
+    report["encoder_nchw_f32_vs_unrounded_oracle_maxabs_err"] = e_nchw
+    assert e_u8 < TOL and e_nchw < TOL, (e_u8, e_nchw)
 
 
 def test_frame_logits(setup, report):
@@ -182,7 +200,7 @@ def test_stem_and_encoder_at_odd_input_sizes(size, report):
         report[f"stem_{size}_{name}_pool0_maxabs_err"] = e0
         report[f"features_{size}_{name}_maxabs_err"] = e
         assert e0 < 8e-3, (name, e0)          # fp16 storage of values up to ~8: half an ulp is 4e-3
-        assert e < (5e-3 if name == "nhwc_u8" else TOL), (name, e)
+        assert e < TOL, (name, e)
 
 
 def test_full_batch_256_matches_small_batches(report, monkeypatch):

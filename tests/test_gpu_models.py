@@ -109,10 +109,10 @@ def test_save_features_and_evaluate_model(zoo, tmp_path, report):
     f = np.load(path)
     assert f.dtype == np.float32 and f.shape == (1024,)
     x = ds[20][0][None]
-    ref = dn.densenet121_features(x.astype(np.float16).astype(np.float32), p)[0]
+    ref = dn.densenet121_features(x.astype(np.float32), p)[0]       # the oracle on the UN-rounded fp32 frame the transform produces
     e = float(np.abs(f - ref).max())
     report["save_features_maxabs_err"] = e
-    assert e < 5e-3          # input pixels are rounded to fp16 inside the stem for NCHW fp32 frames
+    assert e < 1e-3          # (the encoder rounds the pixels to fp16 on the way in: inside the bar, measured 5.7e-4)
     assert ev.save_features(fm, loader, ds, verbose=False) == 0          # skip-if-exists (evaluate.py:318)
 
     ds2 = TennisSet(root=root, split="test", frames_per_video=16, data_shape=224)
