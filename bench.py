@@ -127,6 +127,7 @@ def build_parser():
     ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the 256-frame batch on the CPU (minutes)")
     ap.add_argument("--single-region", action="store_true", help="one timed region of K steps only (no repetitions)")
     ap.add_argument("--no-pipeline", action="store_true", help="join the encoder's two half-batch streams inside every forward (A/B against the pipelined default)")
+    ap.add_argument("--no-exact-line", action="store_true", help="skip the extra fenced region that times the exact-weights mode")
     ap.add_argument("--exact-weights", action="store_true",
                     help="NOT the headline configuration: un-rounded fp32 conv weights evaluated as hi + lo fp16 pairs "
                          "(TN_ENC_EXACT_WEIGHTS), to state what the 1e-3-vs-fp32-weights mode costs")
@@ -226,6 +227,23 @@ def run(argv):
         enc.set_pipelined(True)
         pipelined = True
 
+    # for the record: the rate of the configuration that meets "1e-3 of the reference" against UN-rounded fp32
+    # parameters - the exact-weights mode (hi + lo fp16 weight pairs: twice the MFMA work of the dense layers and transitions)
+    # - on the same box: one more fenced region of exactly K steps with a second encoder
+    fps_exact = None
+    if not args.exact_weights and not args.single_region and not args.no_exact_line:
+        params_x = W.make_densenet121_weights(0, fp16_model=False)
+        enc_f16 = enc
+        enc = DenseNet121Features(params_x, SIZE, max_batch=args.batch, ctx=ctx, exact_weights=True)
+        enc.set_pipelined(pipelined)
+        for i in range(min(args.warmup, 5)):
+            step(i)
+        drain(min(args.warmup, 5))
+        fps_exact = world * args.batch * args.steps / timed_region(args.steps)
+        enc.set_pipelined(False)
+        enc = enc_f16
+        del params_x
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         fps = world * args.batch * args.steps / dt
@@ -281,7 +299,10 @@ def run(argv):
                                      else "seeded random-init, conv weights fp16",
                           "timing": f"median of {repeats} fenced regions of exactly {args.steps} steps" + (", forwards pipelined (results joined one step behind, all joined before the closing fence)" if pipelined else ""),
                           "region_ms": [round(t * 1e3, 2) for t in times],
-                          "frames_per_sec_forwards_joined": (round(world * args.batch * args.steps / dt_joined, 1) if dt_joined else None)},
+                          "frames_per_sec_forwards_joined": (round(world * args.batch * args.steps / dt_joined, 1) if dt_joined else None),
+                          "exact_weights_frames_per_sec": (round(fps_exact, 1) if fps_exact else None),
+                          "exact_weights_note": "un-rounded fp32 conv weights as hi + lo fp16 pairs (features within 1e-3 of the fp32 oracle on fp32 "
+                                                "weights: tests/test_gpu_encoder.py::test_fp32_weights_exact_mode); 2x the MFMA work of the dense layers"},
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, x, full=args.cpu_baseline_full)
