@@ -120,6 +120,14 @@ class Block:
             out.update(child._structural_params(path + name + "."))
         return out
 
+    def _structural_transposed(self, path: str = "") -> set:
+        """Structural names whose array is stored transposed in a Gluon checkpoint relative to the engine's own
+        parameter (only the captioner's attention projection, models/captioning/gnmt.py)."""
+        out = set()
+        for name, child in self._children.items():
+            out |= child._structural_transposed(path + name + ".")
+        return out
+
     def save_parameters(self, filename, structural=None):
         """``<name>.params`` (the only form the reference writes, train.py:497) -> the MXNet NDArray-list container
         with Gluon's structural names, which ``mx.gluon.Block.load_parameters`` of the reference reads back;
@@ -129,8 +137,12 @@ class Block:
             structural = str(filename).endswith(".params")
         if structural:
             from .params_io import save_mxnet_params
-            names = {v: k for k, v in self._structural_params().items()}
-            save_mxnet_params(filename, {names[k]: a for k, a in pd.items()})
+            names = {}
+            for k, v in self._structural_params().items():
+                names.setdefault(v, k)          # the first structural name of a parameter is the one Gluon writes
+            tr = self._structural_transposed()
+            save_mxnet_params(filename, {names[k]: (np.ascontiguousarray(a.T) if names[k] in tr else a)
+                                         for k, a in pd.items()})
             return
         with open(filename, "wb") as f:
             np.savez(f, **pd)
@@ -147,7 +159,8 @@ class Block:
         smap = self._structural_params()
         known = set(self.collect_params())
         if any(k in smap and k not in known for k in loaded):       # Gluon save_parameters: structural names
-            loaded = {smap.get(k, k): v for k, v in loaded.items()}
+            tr = self._structural_transposed()
+            loaded = {smap.get(k, k): (np.ascontiguousarray(v.T) if k in tr else v) for k, v in loaded.items()}
         extra = [k for k in loaded if k not in known]
         if extra and not ignore_extra:
             raise AssertionError(f"Parameter '{extra[0]}' loaded from file '{filename}' is not present in this block")

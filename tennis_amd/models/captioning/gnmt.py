@@ -14,8 +14,11 @@ from ...block import Block, Parameter
 __all__ = ["GNMTEncoder", "GNMTDecoder", "get_gnmt_encoder_decoder", "NMTModel", "Vocab"]
 
 
+_CELL = ("i2h_weight", "h2h_weight", "i2h_bias", "h2h_bias")
+
+
 def _cell_params(block, pref):
-    for n in ("i2h_weight", "h2h_weight", "i2h_bias", "h2h_bias"):
+    for n in _CELL:
         block._own_params[pref + n] = Parameter(pref + n)
 
 
@@ -35,6 +38,20 @@ class GNMTEncoder(Block):
             else:
                 _cell_params(self, f"{self.prefix}rnn{i}_")
 
+    def _structural_params(self, path=""):
+        """The block tree reference gnmt.py:84-111 builds: ``rnn_cells`` is a HybridSequential (children named by
+        index) of ``BidirectionalCell(l_cell, r_cell)`` for i < num_bi_layers and plain cells after; a cell's own
+        parameters are ``i2h_weight`` ... [EXT: Block._collect_params_with_prefix, BidirectionalCell.register_child]."""
+        out = {}
+        for i in range(self._num_layers):
+            for n in _CELL:
+                if i < self._num_bi_layers:
+                    out[f"{path}rnn_cells.{i}.l_cell.{n}"] = f"{self.prefix}rnn{i}_l_{n}"
+                    out[f"{path}rnn_cells.{i}.r_cell.{n}"] = f"{self.prefix}rnn{i}_r_{n}"
+                else:
+                    out[f"{path}rnn_cells.{i}.{n}"] = f"{self.prefix}rnn{i}_{n}"
+        return out
+
 
 class GNMTDecoder(Block):
     """reference gnmt.py:163-404."""
@@ -47,6 +64,27 @@ class GNMTDecoder(Block):
         for i in range(num_layers):
             _cell_params(self, f"{self.prefix}rnn{i}_")
         self._own_params[self.prefix + "attention_key_weight"] = Parameter(self.prefix + "attention_key_weight")
+
+    # reference gnmt.py:212-221: ``attention_cell`` (gluonnlp DotProductAttentionCell(units=H, scaled=True,
+    # luong_style=True, use_bias=False)), ``dropout_layer``, ``rnn_cells`` HybridSequential of ``num_layers`` cells.
+    # [EXT, gluonnlp attention_cell.py] In luong style the cell owns ONE bias-free Dense(H), held in the attribute
+    # ``_proj_query`` and applied to the query: score = <W q, k> / sqrt(H).  The engine keeps the same bilinear form
+    # with the matrix on the memory side (keys are projected once per clip, not once per step):
+    # <W q, k> = <q, W^T k>, so attention_key_weight = W^T and the checkpoint array is stored transposed.
+    # A file that names the matrix ``_proj_key.weight`` (score = <q, W k>) is accepted as is.
+    _ATT_QUERY = "attention_cell._proj_query.weight"
+    _ATT_KEY = "attention_cell._proj_key.weight"
+
+    def _structural_params(self, path=""):
+        out = {path + self._ATT_QUERY: self.prefix + "attention_key_weight",
+               path + self._ATT_KEY: self.prefix + "attention_key_weight"}
+        for i in range(self._num_layers):
+            for n in _CELL:
+                out[f"{path}rnn_cells.{i}.{n}"] = f"{self.prefix}rnn{i}_{n}"
+        return out
+
+    def _structural_transposed(self, path=""):
+        return {path + self._ATT_QUERY}
 
 
 def get_gnmt_encoder_decoder(cell_type="lstm", attention_cell="scaled_luong", num_layers=2, num_bi_layers=1,
@@ -94,8 +132,22 @@ class NMTModel(Block):
         self.src_embed = src_embed if isinstance(src_embed, Block) else None
         for n in ("tgt_proj_weight", "tgt_proj_bias", "tgt_embed_weight"):
             self._own_params[prefix + n] = Parameter(prefix + n)
+        self._tgt_embed_given = tgt_embed is not None
         if tgt_embed is not None:                      # train_gnmt.py:211-218: preloaded embedding table
             self._own_params[prefix + "tgt_embed_weight"].data = np.ascontiguousarray(tgt_embed, dtype=np.float32)
+
+    def _structural_params(self, path=""):
+        """[EXT, gluonnlp NMTModel.__init__] children ``src_embed``, ``tgt_embed``, ``encoder``, ``decoder``,
+        ``tgt_proj`` (Dense).  ``tgt_embed`` is a HybridSequential(Embedding, Dropout) when the model builds it
+        (``tgt_embed.0.weight``) and the caller's ``nn.Embedding`` itself when one is passed (train_gnmt.py:211-218:
+        ``tgt_embed.weight``); both names are read, the one this model was built with is written."""
+        emb = ["tgt_embed.weight", "tgt_embed.0.weight"] if self._tgt_embed_given else ["tgt_embed.0.weight", "tgt_embed.weight"]
+        out = {path + n: self.prefix + "tgt_embed_weight" for n in emb}
+        out[path + "tgt_proj.weight"] = self.prefix + "tgt_proj_weight"
+        out[path + "tgt_proj.bias"] = self.prefix + "tgt_proj_bias"
+        for name, child in self._children.items():      # encoder, decoder, src_embed (TimeDistributed(backbone))
+            out.update(child._structural_params(path + name + "."))
+        return out
 
     def initialize(self, init=None, ctx=None, **kwargs):
         super().initialize()

@@ -5,6 +5,13 @@ what ``mx.gluon.Block.save_parameters`` of a ``TemporalPooling(model=None, num_c
 (reference models/vision/definitions.py:60-61: one Dense ``classes``): structural names ``classes.weight`` /
 ``classes.bias``, plus one float16 array and one ``aux:``-prefixed name as Module checkpoints carry them.
 
+A second file, gluon_gnmt_tiny.params, carries the structural names ``save_parameters`` writes for the captioner the
+reference builds (train_gnmt.py:221-229: gluonnlp NMTModel around models/captioning/gnmt.py:84-111,212-221 with
+cell_type gru, num_layers 2, num_bi_layers 1, hidden 2, 3-d source features, embed 2, vocabulary 5): the
+``rnn_cells`` HybridSequential children by index, ``l_cell`` / ``r_cell`` of the BidirectionalCell, the attention
+cell's single projection, ``tgt_embed.0`` (HybridSequential(Embedding, Dropout)) and the ``tgt_proj`` Dense.  Array
+values are ``index_of_array + 0.01 * position`` so that every mapping and the one transposition are checkable.
+
     python tests/golden/make_params_fixture.py
 """
 import os
@@ -40,6 +47,33 @@ for n in names:
     out += struct.pack("<Q", len(n)) + n
 
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gluon_tiny.params")
+with open(path, "wb") as f:
+    f.write(bytes(out))
+print(path, len(out), "bytes")
+
+
+# ---- captioner checkpoint ------------------------------------------------------------------------------------
+H, F, E, V, G = 2, 3, 2, 5, 3
+cell = lambda fin: [("i2h_weight", (G * H, fin)), ("h2h_weight", (G * H, H)), ("i2h_bias", (G * H,)), ("h2h_bias", (G * H,))]
+entries = []
+entries += [("encoder.rnn_cells.0.l_cell." + n, sh) for n, sh in cell(F)]
+entries += [("encoder.rnn_cells.0.r_cell." + n, sh) for n, sh in cell(F)]
+entries += [("encoder.rnn_cells.1." + n, sh) for n, sh in cell(2 * H)]
+entries += [("decoder.attention_cell._proj_query.weight", (H, H))]
+entries += [("decoder.rnn_cells.0." + n, sh) for n, sh in cell(E + H)]
+entries += [("decoder.rnn_cells.1." + n, sh) for n, sh in cell(2 * H)]
+entries += [("tgt_embed.0.weight", (V, E)), ("tgt_proj.weight", (V, H)), ("tgt_proj.bias", (V,))]
+out = bytearray()
+out += struct.pack("<QQQ", 0x112, 0, len(entries))
+for i, (name, shape) in enumerate(entries):
+    n = 1
+    for d in shape:
+        n *= d
+    out += ndarray_v2(shape, 0, struct.pack("<%df" % n, *[i + 0.01 * j for j in range(n)]))
+out += struct.pack("<Q", len(entries))
+for name, _ in entries:
+    out += struct.pack("<Q", len(name)) + name.encode()
+path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gluon_gnmt_tiny.params")
 with open(path, "wb") as f:
     f.write(bytes(out))
 print(path, len(out), "bytes")

@@ -393,6 +393,59 @@ def test_mxnet_params_reader_against_hand_built_file():
         TemporalPooling(None, num_classes=2, pool="max", feats=True).load_parameters(f)
 
 
+def test_captioner_checkpoint_structural_names(tmp_path):
+    """tests/golden/gluon_gnmt_tiny.params (hand-built, make_params_fixture.py) holds the names Gluon's
+    ``save_parameters`` writes for the reference's captioner block tree (gnmt.py:84-111,212-221 inside gluonnlp's
+    NMTModel, train_gnmt.py:221-229).  ``NMTModel.load_parameters`` must place every array on the right engine
+    parameter - the attention projection transposed (query-side Dense in the file, key-side matrix in the engine) -
+    and ``save_parameters`` must write the same names and arrays back."""
+    from tennis_amd import params_io as pio
+    from tennis_amd.models.captioning.gnmt import NMTModel, get_gnmt_encoder_decoder, Vocab
+    f = os.path.join(os.path.dirname(__file__), "golden", "gluon_gnmt_tiny.params")
+    d = pio.load_mxnet_params(f)
+    assert len(d) == 4 * 5 + 1 + 3
+
+    def build(**kw):
+        enc, dec = get_gnmt_encoder_decoder(cell_type="gru", hidden_size=2, num_layers=2, num_bi_layers=1)
+        return NMTModel(src_vocab=None, tgt_vocab=Vocab({"a": 1}), encoder=enc, decoder=dec, embed_size=2,
+                        prefix="gnmt_", input_size=3, **kw)
+    m = build()
+    assert len(m.tgt_vocab) == 5
+    m.load_parameters(f)
+    got = {k: v.data for k, v in m.collect_params().items()}
+    assert all(v is not None for v in got.values()) and len(got) == len(d)
+    pairs = {"encoder.rnn_cells.0.l_cell.i2h_weight": "gnmt_enc_rnn0_l_i2h_weight",
+             "encoder.rnn_cells.0.r_cell.h2h_bias": "gnmt_enc_rnn0_r_h2h_bias",
+             "encoder.rnn_cells.1.h2h_weight": "gnmt_enc_rnn1_h2h_weight",
+             "decoder.rnn_cells.0.i2h_weight": "gnmt_dec_rnn0_i2h_weight",
+             "decoder.rnn_cells.1.i2h_bias": "gnmt_dec_rnn1_i2h_bias",
+             "tgt_embed.0.weight": "gnmt_tgt_embed_weight",
+             "tgt_proj.weight": "gnmt_tgt_proj_weight", "tgt_proj.bias": "gnmt_tgt_proj_bias"}
+    for sname, pname in pairs.items():
+        assert np.array_equal(got[pname], d[sname]), sname
+    wq = d["decoder.attention_cell._proj_query.weight"]
+    assert wq[0, 1] != wq[1, 0] and np.array_equal(got["gnmt_dec_attention_key_weight"], wq.T)
+    # every array of the file landed somewhere, once
+    assert sorted(float(v.flat[0]) for v in got.values()) == sorted(float(v.flat[0]) for v in d.values())
+    g = str(tmp_path / "0003.params")
+    m.save_parameters(g)
+    back = pio.load_mxnet_params(g)
+    assert set(back) == set(d) and all(np.array_equal(back[k], d[k]) for k in d)
+    # a model given its embedding table (train_gnmt.py:211-218) holds the Embedding itself: ``tgt_embed.weight``
+    m2 = build(tgt_embed=got["gnmt_tgt_embed_weight"])
+    m2.load_parameters(g, allow_missing=True)
+    m2.save_parameters(g)
+    assert "tgt_embed.weight" in pio.load_mxnet_params(g)
+    m3 = build()
+    m3.load_parameters(g)                                   # ... and a model that built its own reads that name too
+    assert np.array_equal(m3.collect_params()["gnmt_tgt_embed_weight"].data, d["tgt_embed.0.weight"])
+    # a file naming the projection on the key side is taken as is
+    d2 = dict(d); d2["decoder.attention_cell._proj_key.weight"] = d2.pop("decoder.attention_cell._proj_query.weight")
+    pio.save_mxnet_params(g, d2)
+    m4 = build(); m4.load_parameters(g)
+    assert np.array_equal(m4.collect_params()["gnmt_dec_attention_key_weight"].data, wq)
+
+
 def test_mxnet_params_container_round_trip(tmp_path):
     """tennis_amd.params_io: NDArray-list container (V2 records) write -> read, dtype flags, 0-d / empty shapes,
     'arg:' / 'aux:' prefixes, and Block.load_parameters picking the format by its magic."""
