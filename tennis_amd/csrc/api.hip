@@ -147,7 +147,7 @@ std::vector<f16> split_hi_lo_rows(const float *w, int rows, int k, int kp) {
 // k-step s = tap*8 + kk; lane l: n = l&31, channel = kk*16 + (l>>5)*8 + j.
 std::vector<f16> pack_conv3x3(const float *w) {
   // two MFMA operand layouts back to back (72*64*8 halves each):
-  //  [0]     v_mfma_f32_32x32x16_f16 A fragments [9 taps x 8 k16-steps][64 lanes][8]   (conv3x3.hip, dense_layer_small.hip)
+  //  [0]     v_mfma_f32_32x32x16_f16 A fragments [9 taps x 8 k16-steps][64 lanes][8]   (conv3x3.hip)
   //  [36864] v_mfma_f32_16x16x32_f16 A fragments [9 taps][4 k32-steps][2 n-frags][64 lanes][8]   (dense_layer_big.hip):
   //          lane l: out channel nf*16 + (l&15), in channel kk*32 + (l>>4)*8 + j
   std::vector<f16> p((size_t)2 * 72 * 64 * 8);

@@ -31,6 +31,15 @@ __device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + expf(-v))
 
 // ---- beam-search step kernels: 1024 threads = 16 waves ----
 constexpr int kBeamThreads = 1024;
+// dynamic LDS the step kernels may ask for: a launch above 64 KiB needs the kernel's limit raised first (160 KiB per CU on
+// gfx950; 8 KiB are left for the kernels' static arrays)
+constexpr size_t kStepLdsMax = 152 * 1024;
+template <typename KernT>
+static int allow_lds(KernT kern, size_t bytes) {
+  if (bytes > 64 * 1024)
+    TN_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStepLdsMax));
+  return TN_OK;
+}
 #ifdef TN_DEC_STAMPS   // tuning builds only (EXTRA=-DTN_DEC_STAMPS): phase boundaries of workgroup 0, 100 MHz ticks
 __device__ long long g_dec_stamps[24];
 #define DEC_STAMP(i) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) g_dec_stamps[i] = wall_clock64(); } while (0)
@@ -934,8 +943,11 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
   const int nbm = beam <= 4 ? 4 : beam == 5 ? 5 : beam <= 8 ? 8 : 16;   // beam 5: the reference's flag default
   const size_t att_lds = ((size_t)(H + T) * 4 + (size_t)4 * (T > H ? T : H)) * sizeof(float);   // one row per workgroup
   const size_t beam_lds = ((size_t)2 * ((nbm + 3) & ~3) * H + (size_t)5 * beam * V + 16) * sizeof(float);
-  TN_REQUIRE(beam_lds <= 64 * 1024 && att_lds <= 64 * 1024,
-             "tn_gnmt_beam_search: beam * (2*hidden + 5*vocab) or 8 * max(hidden, source length) exceeds the step kernels' 64 KiB of LDS");
+  TN_REQUIRE(beam_lds <= kStepLdsMax && att_lds <= kStepLdsMax,
+             "tn_gnmt_beam_search: beam * (2*hidden + 5*vocab) or 8 * max(hidden, source length) exceeds the step kernels' 152 KiB of LDS");
+  if (int rc = allow_lds(dec_attention_kernel<1>, att_lds)) return rc;
+  if (int rc = nbm == 4 ? allow_lds(dec_beam_kernel<4>, beam_lds) : nbm == 5 ? allow_lds(dec_beam_kernel<5>, beam_lds)
+               : nbm == 8 ? allow_lds(dec_beam_kernel<8>, beam_lds) : allow_lds(dec_beam_kernel<16>, beam_lds)) return rc;
   TN_HIP_CHECK(hipMemsetAsync(g->samples[0], 0xff, sizeof(int32_t) * (size_t)R * L, s));
   TN_HIP_CHECK(hipMemsetAsync(g->samples[1], 0xff, sizeof(int32_t) * (size_t)R * L, s));
   // decoder layer 0 starts from the encoder's BACKWARD layer-0 state, layer 1 from the uni layer (gnmt.py:146-150,224-252)
@@ -1011,7 +1023,8 @@ extern "C" int tn_gnmt_decode_seq(tn_gnmt *g, const int32_t *tgt, int ld, int st
   const bool lstm = g->G == 4;
   const int nb = (R * H + 255) / 256;
   const size_t att_lds = ((size_t)(H + T) * 4 + (size_t)4 * (T > H ? T : H)) * sizeof(float);
-  TN_REQUIRE(att_lds <= 64 * 1024, "tn_gnmt_decode_seq: 8 * max(hidden, source length) exceeds the step kernel's 64 KiB of LDS");
+  TN_REQUIRE(att_lds <= kStepLdsMax, "tn_gnmt_decode_seq: 8 * max(hidden, source length) exceeds the step kernel's 152 KiB of LDS");
+  if (int rc = allow_lds(dec_attention_kernel<1>, att_lds)) return rc;
   for (int i = 0; i < steps; ++i) {
     // decoder layer 0 starts from the encoder's BACKWARD layer-0 state, layer 1 from the uni layer (gnmt.py:146-150,224-252)
     const float *h0p = i ? g->h0n : g->hl0 + (size_t)B * H, *h1p = i ? g->h1n : g->hl1;
@@ -1199,7 +1212,9 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
   const bool lstm = G == 4;
   const size_t att_lds = ((size_t)(H + T) * 4 + (size_t)4 * (T > H ? T : H)) * sizeof(float);
   const size_t attb_lds = (size_t)(2 * H + T + 256) * sizeof(float);
-  TN_REQUIRE(att_lds <= 64 * 1024 && attb_lds <= 64 * 1024, "tn_gnmt_trainer: 8 * max(hidden, source length) exceeds 64 KiB of LDS");
+  TN_REQUIRE(att_lds <= kStepLdsMax && attb_lds <= kStepLdsMax, "tn_gnmt_trainer: 8 * max(hidden, source length) exceeds 152 KiB of LDS");
+  if (int rc = allow_lds(dec_attention_kernel<1>, att_lds)) return rc;
+  if (int rc = allow_lds(trn_att_bwd_kernel, attb_lds)) return rc;
   float *w = t->w, *g = t->g;
   int rc;
 #define TN_TRY(e) do { rc = (e); if (rc) return rc; } while (0)

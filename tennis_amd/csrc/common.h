@@ -177,7 +177,7 @@ struct DenseLayerArgs {
   const f16 *w3p;        // packed 3x3 fragments [72][64][8]
   int B, H, W;
   unsigned long long *ts = nullptr;  // tuning hook: 8 s_memtime stamps per workgroup
-  int variant = 0;                   // tuning hook: 0 auto, 1 big tiles, 2 small tiles
+  int variant = 0;                   // tuning hook of the K loop: bit 3 = refill up front
   const DenseLayerDev *chain = nullptr;  // device array: run nchain consecutive layers (K, K+32, ...) in one launch
   int nchain = 0;                        // (whole-frame tiles only: 14x14 and 7x7)
   int exact = 0;                         // weights as hi + lo fp16 pairs: w1 [128][2 Kp] = [hi | lo], w3p = hi image then lo image

@@ -1,24 +1,15 @@
-// Fused DenseNet dense layer: dispatch between the two workgroup geometries
-// (dense_layer_big.hip: 8 waves, ROUT full image rows, one workgroup per CU;
-//  dense_layer_small.hip: 4 waves, 28x7 / whole-frame tiles, >= 2 workgroups per CU).
-// The choice per block is empirical (scripts/kbench.py on MI355X, batch 256).
+// Fused DenseNet dense layer of the tile kernels (dense_layer_big.hip: 8 waves, ROUT full image rows, one workgroup
+// per CU; whole-frame layer chains at 14x14 and 7x7).  The 56x56 / 28x28 layers with K <= 320 go to dense_strip.hip at
+// batch >= 64 (api.hip).  Round 1's 4-wave geometry (28x7 tiles, two workgroups per CU) lost at every block size and
+// is gone; spatial sizes none of these kernels tile run un-fused (conv1x1.hip + conv3x3.hip).
 #include "common.h"
 
 bool dense_layer_big_supported(int H, int W);
-bool dense_layer_small_supported(int H, int W);
 int launch_dense_layer_big(const DenseLayerArgs &a, hipStream_t s);
-int launch_dense_layer_small(const DenseLayerArgs &a, hipStream_t s);
 
-bool dense_layer_supported(int H, int W) { return dense_layer_big_supported(H, W) || dense_layer_small_supported(H, W); }
+bool dense_layer_supported(int H, int W) { return dense_layer_big_supported(H, W); }
 
 int launch_dense_layer(const DenseLayerArgs &a, hipStream_t s) {
-  if (a.nchain > 0) return launch_dense_layer_big(a, s);   // whole-frame chains (14x14, 7x7)
-  const bool big_ok = dense_layer_big_supported(a.H, a.W), small_ok = dense_layer_small_supported(a.H, a.W);
-  bool use_big = big_ok;                       // measured: the 8-wave geometry wins at every block size
-  if ((a.variant & 3) == 1) use_big = true;
-  if ((a.variant & 3) == 2) use_big = false;
-  if (use_big && big_ok) return launch_dense_layer_big(a, s);
-  if (small_ok) return launch_dense_layer_small(a, s);
-  if (big_ok) return launch_dense_layer_big(a, s);
-  TN_REQUIRE(false, "dense_layer: unsupported spatial size");
+  TN_REQUIRE(dense_layer_big_supported(a.H, a.W), "dense_layer: unsupported spatial size");
+  return launch_dense_layer_big(a, s);
 }
