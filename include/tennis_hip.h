@@ -351,6 +351,14 @@ int tn_dbg_dense_strip_dev(tn_ctx *ctx, void *buf_f16, int ldc, int K, const flo
                            const void *w1s_f16, const void *w3s_f16, int B, int H, int W,
                            unsigned long long *ts /* NULL or 128 s_memtime stamps per frame */);
 
+/* The LDS-resident 7x7 dense block (csrc/dense_block7.hip): nl layers from K0 input channels in ONE launch on a device
+ * concat buffer (B,7,7,ldc) fp16.  w1_all: the (128, K_l) 1x1 weights one after the other (K_l = K0 + 32 l); s1_all / t1_all
+ * folded BN1 scale / shift (K_l each); s2_all / t2_all folded BN2 scale / shift (128 per layer); w3_all nl x (32,128,3,3). */
+int tn_dbg_block7_create(tn_ctx *ctx, int K0, int nl, const float *w1_all, const float *s1_all, const float *t1_all,
+                         const float *s2_all, const float *t2_all, const float *w3_all, void **out);
+int tn_dbg_block7_run(void *handle, void *buf_f16, int ldc, int B);
+void tn_dbg_block7_destroy(void *handle);
+
 #ifdef __cplusplus
 }
 #endif

@@ -180,5 +180,23 @@ for v in [int(s) for s in args.variants.split(",")]:
                 print(res[-1], flush=True)
             print("   ds block %d: sum %.1f us" % (hw, tot), flush=True)
             del buf
+    if "b7" in args.kernels:      # the LDS-resident 7x7 dense block (dense_block7.hip): the whole block in one launch
+        K0, nl = 512, 16
+        Ks = [K0 + 32 * l for l in range(nl)]
+        cat = lambda xs: np.ascontiguousarray(np.concatenate([x.ravel() for x in xs]))
+        w1 = cat([rng.normal(0, (2.0 / K) ** 0.5, (128, K)).astype(np.float32) for K in Ks])
+        s1 = cat([(rng.random(K) + 0.5).astype(np.float32) for K in Ks]); t1 = cat([rng.normal(0, 0.3, K).astype(np.float32) for K in Ks])
+        s2 = (rng.random((nl, 128)) + 0.5).astype(np.float32); t2 = rng.normal(0, 0.3, (nl, 128)).astype(np.float32)
+        w3 = rng.normal(0, 0.03, (nl, 32, 128, 3, 3)).astype(np.float32)
+        vp = lambda a_: a_.ctypes.data_as(C.c_void_p)
+        h = C.c_void_p()
+        _lib.check(lib.tn_dbg_block7_create(ctx.handle, K0, nl, vp(w1), vp(s1), vp(t1), vp(s2), vp(t2), vp(w3), C.byref(h)))
+        buf = torch.randn((B * 49, 1024), device="cuda", dtype=torch.float16)
+        fn = lambda: _lib.check(lib.tn_dbg_block7_run(h, _lib.ptr(buf), 1024, B))
+        us = timed(fn, args.iters)
+        fl = sum(2.0 * B * 49 * (128 * K + 32 * 1152) for K in Ks)
+        res.append(dict(k="b7", us=round(us, 1), tf=round(fl / us / 1e6, 1)))
+        print(res[-1], flush=True)
+        lib.tn_dbg_block7_destroy(h)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(res, open("gpurun_out/kbench.json", "w"), indent=1)

@@ -200,6 +200,25 @@ int launch_dense_strip(const DenseStripArgs &a, hipStream_t s);
 std::vector<f16> pack_w1_strip(const float *w /*[128][K], BN2 scale folded in*/, int K, const float *shift /*[128] BN2 shift*/);
 std::vector<f16> pack_w3_strip(const float *w /*(32,128,3,3)*/);
 
+// The 7x7 dense block with the frame's concat buffer resident in LDS (dense_block7.hip): one launch, one workgroup per frame.
+struct DenseBlock7Args {
+  f16 *buf;              // concat buffer [B][49][ldc]: reads channels [0,K0), appends [K0, K0 + 32 nl)
+  int ldc, K0, nl, B;
+  const f16 *wa, *wb;    // per-wave weight streams (pack_block7)
+  const float *tab;      // per layer s1[1024] | t1[1024] | t2[128]
+  unsigned a_off[4], b_off[4];   // start of each wave's streams, in 16-byte units
+  unsigned long long *ts = nullptr;
+};
+struct Block7Layer { const float *w1f /*[128][K], BN2 scale folded in*/, *w3 /*(32,128,3,3)*/, *s1, *t1 /*[K]*/, *t2 /*[128]*/; };
+struct Block7Image {
+  std::vector<f16> wa, wb;
+  std::vector<float> tab;
+  unsigned a_off[4], b_off[4];
+};
+bool dense_block7_supported(int H, int W, int K0, int nl);
+Block7Image pack_block7(const std::vector<Block7Layer> &layers, int K0);
+int launch_dense_block7(const DenseBlock7Args &a, hipStream_t s);
+
 struct StemArgs {
   const void *x;
   int layout;         // tn_layout

@@ -135,3 +135,64 @@ extern "C" int tn_dbg_dense_strip_dev(tn_ctx *ctx, void *buf_f16, int ldc, int K
   a.ts = ts;
   return launch_dense_strip(a, ctx->stream);
 }
+
+
+// ---- the LDS-resident 7x7 dense block (dense_block7.hip) ----
+// nl layers from K0 input channels: w1_all = the (128, K_l) 1x1 weights one after the other, s1_all / t1_all the folded BN1
+// scale / shift (K_l each), s2_all / t2_all the folded BN2 scale / shift (128 per layer), w3_all nl x (32,128,3,3).
+struct tn_dbg_block7 {
+  tn_ctx *ctx;
+  void *wa = nullptr, *wb = nullptr, *tab = nullptr;
+  DenseBlock7Args args;
+};
+
+extern "C" int tn_dbg_block7_create(tn_ctx *ctx, int K0, int nl, const float *w1_all, const float *s1_all, const float *t1_all,
+                                    const float *s2_all, const float *t2_all, const float *w3_all, void **out) {
+  TN_REQUIRE(ctx && w1_all && s1_all && t1_all && s2_all && t2_all && w3_all && out, "tn_dbg_block7_create: null argument");
+  TN_REQUIRE(dense_block7_supported(7, 7, K0, nl), "tn_dbg_block7_create: unsupported geometry");
+  TN_ON_DEVICE(ctx->device);
+  std::vector<std::vector<float>> folded(nl);
+  std::vector<Block7Layer> layers(nl);
+  size_t o1 = 0, ok = 0;
+  for (int l = 0; l < nl; ++l) {
+    const int K = K0 + 32 * l;
+    folded[l].resize((size_t)128 * K);
+    for (int n = 0; n < 128; ++n)
+      for (int k = 0; k < K; ++k) folded[l][(size_t)n * K + k] = w1_all[o1 + (size_t)n * K + k] * s2_all[(size_t)l * 128 + n];
+    layers[l] = Block7Layer{folded[l].data(), w3_all + (size_t)l * 32 * 128 * 9, s1_all + ok, t1_all + ok, t2_all + (size_t)l * 128};
+    o1 += (size_t)128 * K;
+    ok += K;
+  }
+  const Block7Image img = pack_block7(layers, K0);
+  tn_dbg_block7 *b = new tn_dbg_block7();
+  b->ctx = ctx;
+  auto up = [&](void **dst, const void *src, size_t bytes) {
+    if (hipMalloc(dst, bytes) != hipSuccess) return false;
+    return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+  };
+  if (!up(&b->wa, img.wa.data(), img.wa.size() * sizeof(f16)) || !up(&b->wb, img.wb.data(), img.wb.size() * sizeof(f16)) ||
+      !up(&b->tab, img.tab.data(), img.tab.size() * sizeof(float))) {
+    tn_set_error("tn_dbg_block7_create: device allocation failed");
+    return TN_ERR_NOMEM;
+  }
+  b->args = DenseBlock7Args{nullptr, 0, K0, nl, 0, (const f16 *)b->wa, (const f16 *)b->wb, (const float *)b->tab};
+  for (int w = 0; w < 4; ++w) { b->args.a_off[w] = img.a_off[w]; b->args.b_off[w] = img.b_off[w]; }
+  *out = b;
+  return TN_OK;
+}
+
+extern "C" int tn_dbg_block7_run(void *handle, void *buf_f16, int ldc, int B) {
+  tn_dbg_block7 *b = (tn_dbg_block7 *)handle;
+  TN_REQUIRE(b && buf_f16, "tn_dbg_block7_run: null argument");
+  TN_ON_DEVICE(b->ctx->device);
+  DenseBlock7Args a = b->args;
+  a.buf = (f16 *)buf_f16; a.ldc = ldc; a.B = B;
+  return launch_dense_block7(a, b->ctx->stream);
+}
+
+extern "C" void tn_dbg_block7_destroy(void *handle) {
+  tn_dbg_block7 *b = (tn_dbg_block7 *)handle;
+  if (!b) return;
+  (void)hipFree(b->wa); (void)hipFree(b->wb); (void)hipFree(b->tab);
+  delete b;
+}
