@@ -265,6 +265,8 @@ struct tn_encoder {
   bool strip = true;          // 56x56 / 28x28 layers with K <= 320 run on the strip-streaming kernel (TN_NO_STRIP disables)
   int strip_min_batch = 64;   // ... from this many frames per launch on (one workgroup per frame: small batches leave CUs idle)
   DenseLayerDev *chain_dev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool block7 = true;         // a 7x7 block runs on the LDS-resident kernel of dense_block7.hip (TN_NO_BLOCK7 disables)
+  DenseBlock7Args b7[4] = {};  // its packed operands per block (buf == nullptr: not packed)
   hipStream_t side[4];
   hipEvent_t ev_in, ev_done[2][4];   // completion of the side streams, alternating per forward call
   bool pipelined = false;            // tn_densenet121_set_pipelined: the caller's stream is not made to wait inside forward
@@ -297,6 +299,7 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
   e->split = getenv("TN_NO_SPLIT") == nullptr;
   e->nsplit = getenv("TN_SPLIT") ? atoi(getenv("TN_SPLIT")) : 2;
   if (e->nsplit != 4) e->nsplit = 2;
+  e->block7 = getenv("TN_NO_BLOCK7") == nullptr;
   e->chain = getenv("TN_NO_CHAIN") == nullptr;   // measured: -20% on the 14x14 / 7x7 blocks, +2.8% end to end
   e->dl_variant = getenv("TN_DL_VARIANT") ? atoi(getenv("TN_DL_VARIANT")) : 0;
   e->exact = (flags & TN_ENC_EXACT_WEIGHTS) != 0;
@@ -342,6 +345,9 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
   int outer = 1;
   for (int b = 0; b < 4; ++b) {
     const std::string sp = pre + "stage" + std::to_string(b + 1) + "_";
+    const bool pack7 = e->fuse && e->block7 && !e->exact && dense_block7_supported(e->Hb[b], e->Wb[b], e->Cin[b], kBlockCfg[b]);
+    std::vector<std::vector<float>> h7[4];     // host copies for pack_block7: folded 1x1 weights, s1, t1, t2 per layer
+    std::vector<const float *> h7w3;
     for (int l = 0; l < kBlockCfg[b]; ++l) {
       tn_encoder::DenseLayer L;
       L.cin = e->Cin[b] + 32 * l;
@@ -350,6 +356,7 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
       if (!w1 || !w3) return fail(TN_ERR_MISSING);
       if (!fold_bn(pm, sp + "batchnorm" + std::to_string(2 * l), L.cin, s, t)) return fail(TN_ERR_MISSING);
       L.s1 = e->pool.upload(s); L.t1 = e->pool.upload(t);
+      if (pack7) { h7[1].push_back(s); h7[2].push_back(t); h7w3.push_back(w3); }
       // The scale of the BatchNorm BEHIND the 1x1 convolution is folded into its weights before they are rounded to fp16
       // (or split into hi + lo): bn2(conv(a)) = conv'(a) + shift with w'[n][k] = scale[n] w[n][k].  That is how the fp16
       // model is defined (weights.as_fp16_model hands over w with scale[n] w[n][k] fp16-representable); the kernels that
@@ -364,6 +371,7 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
       } else {
         L.w1 = e->pool.upload(to_f16(w1f.data(), (size_t)128 * L.cin));
       }
+      if (pack7) { h7[0].push_back(w1f); h7[3].push_back(t); }
       if (e->strip && dense_strip_supported(e->Hb[b], e->Wb[b], L.cin)) L.w1s = e->pool.upload(pack_w1_strip(w1f.data(), L.cin, t.data()));
       L.s2 = e->pool.upload(std::vector<float>(128, 1.0f)); L.t2 = e->pool.upload(t);
       if (e->exact) {       // packed image of hi, then packed image of lo
@@ -381,6 +389,16 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
       }
       if (L.w1s) L.w3s = e->pool.upload(pack_w3_strip(w3));
       e->layers[b].push_back(L);
+    }
+    if (pack7) {
+      std::vector<Block7Layer> bl;
+      for (int l = 0; l < kBlockCfg[b]; ++l)
+        bl.push_back(Block7Layer{h7[0][l].data(), h7w3[l], h7[1][l].data(), h7[2][l].data(), h7[3][l].data()});
+      const Block7Image img = pack_block7(bl, e->Cin[b]);
+      DenseBlock7Args &a7 = e->b7[b];
+      a7.wa = e->pool.upload(img.wa); a7.wb = e->pool.upload(img.wb); a7.tab = e->pool.upload(img.tab);
+      for (int w = 0; w < 4; ++w) { a7.a_off[w] = img.a_off[w]; a7.b_off[w] = img.b_off[w]; }
+      a7.ldc = e->Cb[b]; a7.K0 = e->Cin[b]; a7.nl = kBlockCfg[b];
     }
     {
       std::vector<DenseLayerDev> cd;
@@ -452,7 +470,20 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
     const int Hh = e->Hb[b], Ww = e->Wb[b];
     const int M = B * Hh * Ww;
     const bool fused = e->fuse && dense_layer_supported(Hh, Ww);
-    if (fused && e->chain && (e->dl_variant & ~(32 | 64 | 128 | 256 | 512)) == 0 && Hh == Ww && (Hh == 14 || Hh == 7)) {
+    if (e->b7[b].wa && e->dl_variant == 0) {
+      // the frame's concat buffer stays in LDS for the whole block; only the weights stream (dense_block7.hip)
+      DenseBlock7Args a7 = e->b7[b];
+      a7.buf = bbuf[b]; a7.B = B;
+      double fl = 0, by = 0;
+      for (auto &L : e->layers[b]) {
+        fl += 2.0 * M * (128.0 * L.cin + 32.0 * 1152);
+        by += (double)M * (L.cin + 32) * 2 + 128.0 * L.cin * 2 + 32.0 * 1152 * 2;
+      }
+      tm.begin("dense_block_lds_7x7", fl, by);
+      rc = launch_dense_block7(a7, s);
+      tm.end();
+      if (rc) return rc;
+    } else if (fused && e->chain && (e->dl_variant & ~(32 | 64 | 128 | 256 | 512)) == 0 && Hh == Ww && (Hh == 14 || Hh == 7)) {
       // one workgroup per frame walks the whole block: no launch gaps, no cold prologue per layer
       auto &L0 = e->layers[b][0];
       const int nl = (int)e->layers[b].size();

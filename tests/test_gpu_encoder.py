@@ -130,17 +130,38 @@ def test_repeatable_bit_for_bit_under_load():
 def test_chained_blocks_match_per_layer_launches(monkeypatch):
     """Default: the 14x14 and 7x7 blocks run all their layers inside one launch per block (one workgroup per
     frame, the next layer's first stages and tables requested during the current layer's store); TN_NO_CHAIN=1
-    launches every layer separately.  Same arithmetic in the same order -> bit-identical features."""
+    launches every layer separately.  Same arithmetic in the same order -> bit-identical features.  (TN_NO_BLOCK7: the 7x7
+    block on the tile kernel too, as in exact-weights mode, instead of dense_block7.hip.)"""
     import os
     from tennis_amd import weights as W
     from tennis_amd.engine import DenseNet121Features
     p = W.make_densenet121_weights(5)
     x = torch.from_numpy(W.normalize_to_nchw_f32(W.synthetic_frames_u8(8, 224))).cuda()
+    monkeypatch.setenv("TN_NO_BLOCK7", "1")
     monkeypatch.setenv("TN_NO_CHAIN", "1")
     ref = DenseNet121Features(p, 224, max_batch=8)(x).cpu().numpy()
     monkeypatch.delenv("TN_NO_CHAIN", raising=False)
     got = DenseNet121Features(p, 224, max_batch=8)(x).cpu().numpy()
     assert np.array_equal(ref, got)
+
+
+def test_lds_resident_7x7_block_vs_tile_kernel(setup, report, monkeypatch):
+    """Default: the 7x7 block runs on dense_block7.hip (concat buffer in LDS, K split over four waves); TN_NO_BLOCK7=1 puts it
+    back on the chained tile kernel.  Different summation orders: both within the bar of the fp32 oracle, and within fp16
+    rounding noise of each other; the default path gives the same bits for a frame whatever the batch around it."""
+    from tennis_amd.engine import DenseNet121Features
+    x = torch.from_numpy(setup["x16"].astype(np.float32)).cuda()
+    got = DenseNet121Features(setup["p"], 224, max_batch=2)(x)
+    monkeypatch.setenv("TN_NO_BLOCK7", "1")
+    old = DenseNet121Features(setup["p"], 224, max_batch=2)(x)
+    monkeypatch.delenv("TN_NO_BLOCK7")
+    e_new = float(np.abs(got.cpu().numpy() - setup["ref"]).max()); e_old = float(np.abs(old.cpu().numpy() - setup["ref"]).max())
+    report["features_block7_maxabs_err"] = e_new
+    report["features_block7_off_maxabs_err"] = e_old
+    assert e_new < TOL and e_old < TOL, (e_new, e_old)
+    assert float((got - old).abs().max()) < 2e-3
+    big = DenseNet121Features(setup["p"], 224, max_batch=34)(x[torch.arange(34, device="cuda") % 2])
+    assert torch.equal(big[:2], got) and torch.equal(big[32:], got)
 
 
 def test_unfused_fallback_path(setup, report, monkeypatch):
