@@ -357,6 +357,8 @@ int tn_dbg_dense_strip_dev(tn_ctx *ctx, void *buf_f16, int ldc, int K, const flo
 int tn_dbg_block7_create(tn_ctx *ctx, int K0, int nl, const float *w1_all, const float *s1_all, const float *t1_all,
                          const float *s2_all, const float *t2_all, const float *w3_all, void **out);
 int tn_dbg_block7_run(void *handle, void *buf_f16, int ldc, int B);
+int tn_dbg_block7_run_ts(void *handle, void *buf_f16, int ldc, int B,
+                         unsigned long long *ts /* NULL or 128 per frame: s_memtime stamps of wave 0 (start, then 5 per layer) */);
 void tn_dbg_block7_destroy(void *handle);
 
 #ifdef __cplusplus

@@ -18,6 +18,7 @@ ap.add_argument("--blocks", default="0,1,2,3")
 ap.add_argument("--lib", default="")
 ap.add_argument("--allk", action="store_true")
 ap.add_argument("--stamps", action="store_true")
+ap.add_argument("--b7stamps", type=int, default=5)
 args = ap.parse_args()
 if args.lib: _lib.LIB_PATH = os.path.abspath(args.lib)
 ctx = _lib.default_context(0)
@@ -195,6 +196,20 @@ for v in [int(s) for s in args.variants.split(",")]:
         fn = lambda: _lib.check(lib.tn_dbg_block7_run(h, _lib.ptr(buf), 1024, B))
         us = timed(fn, args.iters)
         fl = sum(2.0 * B * 49 * (128 * K + 32 * 1152) for K in Ks)
+        if args.stamps:
+            ts = torch.zeros((B * 128,), dtype=torch.int64, device="cuda")
+            _lib.check(lib.tn_dbg_block7_run_ts(h, _lib.ptr(buf), 1024, B, _lib.ptr(ts)))
+            torch.cuda.synchronize()
+            t = ts.cpu().numpy().astype(np.float64).reshape(B, 128)
+            real_us = (t[:, 126] - t[:, 127]) / 100.0
+            ns = args.b7stamps
+            d = np.diff(t[:, :1 + ns * nl], axis=1).reshape(B, nl, ns)
+            med = np.median(d, axis=0)
+            print("   wave 0: %.1f us wall (median; min %.1f max %.1f), shader clock %.2f GHz" % (np.median(real_us), real_us.min(), real_us.max(),
+                  np.median((t[:, ns * nl] - t[:, 0]) / (real_us * 1e3))))
+            print("   per layer (ticks): 1x1 | reduce | epilogue | 3x3 | append")
+            for l in range(nl): print("   l%2d K=%4d  %s  sum %d" % (l, Ks[l], np.round(med[l]).astype(int), med[l].sum()))
+            print("   totals %s = %d" % (np.round(med.sum(axis=0)).astype(int), med.sum()), flush=True)
         res.append(dict(k="b7", us=round(us, 1), tf=round(fl / us / 1e6, 1)))
         print(res[-1], flush=True)
         lib.tn_dbg_block7_destroy(h)

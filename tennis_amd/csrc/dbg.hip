@@ -181,12 +181,14 @@ extern "C" int tn_dbg_block7_create(tn_ctx *ctx, int K0, int nl, const float *w1
   return TN_OK;
 }
 
-extern "C" int tn_dbg_block7_run(void *handle, void *buf_f16, int ldc, int B) {
+extern "C" int tn_dbg_block7_run_ts(void *handle, void *buf_f16, int ldc, int B, unsigned long long *ts);
+extern "C" int tn_dbg_block7_run(void *handle, void *buf_f16, int ldc, int B) { return tn_dbg_block7_run_ts(handle, buf_f16, ldc, B, nullptr); }
+extern "C" int tn_dbg_block7_run_ts(void *handle, void *buf_f16, int ldc, int B, unsigned long long *ts) {
   tn_dbg_block7 *b = (tn_dbg_block7 *)handle;
   TN_REQUIRE(b && buf_f16, "tn_dbg_block7_run: null argument");
   TN_ON_DEVICE(b->ctx->device);
   DenseBlock7Args a = b->args;
-  a.buf = (f16 *)buf_f16; a.ldc = ldc; a.B = B;
+  a.buf = (f16 *)buf_f16; a.ldc = ldc; a.B = B; a.ts = ts;
   return launch_dense_block7(a, b->ctx->stream);
 }
 

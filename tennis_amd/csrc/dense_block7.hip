@@ -33,6 +33,10 @@
 
 #include "common.h"
 
+#ifndef TN_B7_EXP
+#define TN_B7_EXP 0   // timing experiments only (results wrong): bit 0 no ring refill, bit 1 no BatchNorm of the pixel fragments, bit 2 no LDS fragment reads
+#endif
+
 namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -75,11 +79,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   auto lds_f4 = [&](unsigned ad) TN_INL -> f32x4 { return *(const f32x4 *)(smem + ad); };
 
   // ---- the weight streams of this wave (16-byte units, this lane's cell of each fragment) ----
-  const f16x8 *wa = (const f16x8 *)a.wa + a.a_off[w] + lane;
-  const f16x8 *wb = (const f16x8 *)a.wb + a.b_off[w] + lane;
+  // (wave-uniform bases + the lane's cell: the loads take the base from SGPRs and need no per-lane pointer arithmetic)
+  const f16x8 *wa = (const f16x8 *)a.wa + a.a_off[w];
+  const f16x8 *wb = (const f16x8 *)a.wb + a.b_off[w];
   f16x8 ring[D][4];
   static_for<D>([&](auto i_tag) TN_INL {
-    static_for<4>([&](auto m_tag) TN_INL { ring[i_tag.value][m_tag.value] = wa[i_tag.value * kStepUnits + m_tag.value * 64]; });
+    static_for<4>([&](auto m_tag) TN_INL { ring[i_tag.value][m_tag.value] = wa[i_tag.value * kStepUnits + m_tag.value * 64 + lane]; });
   });
   wa += D * kStepUnits;
 
@@ -117,90 +122,126 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   }
 
   f32x16 acc[4][2];
-#pragma unroll
-  for (int m = 0; m < 4; ++m)
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) acc[m][t][j] = 0.f;
 
   // pixel fragments: raw values + BatchNorm constants of the NEXT k-step, and the finished fragments of this / the next one
-  u32x4 raw[2], x[2][2];
-  f32x4 cs[4];
-  auto read_next = [&](unsigned aad, unsigned cad, auto i_tag) TN_INL {
-    constexpr int I = decltype(i_tag)::value;
-    raw[0] = __builtin_bit_cast(u32x4, lds_h8(aad + I * 2 * kChunkRow));
-    raw[1] = __builtin_bit_cast(u32x4, lds_h8(aad + I * 2 * kChunkRow + 512));
-    cs[0] = lds_f4(cad + I * 64);
-    cs[1] = lds_f4(cad + I * 64 + 16);
-    cs[2] = lds_f4(cad + I * 64 + 4096);
-    cs[3] = lds_f4(cad + I * 64 + 4096 + 16);
+  // (the LDS reads run TWO steps ahead of the MFMAs, BatchNorm one step ahead: a read issued in step P is consumed by the
+  // element-wise work in the shadow of step P+1's MFMAs)
+  u32x4 raw[2][2], x[2][2];
+  f32x4 cs[2][4];
+  auto read_step = [&](unsigned aad, unsigned cad, auto i_tag) TN_INL {     // step I (relative to aad / cad) -> buffers I & 1
+    constexpr int I = decltype(i_tag)::value, Bf = I & 1;
+    raw[Bf][0] = __builtin_bit_cast(u32x4, lds_h8(aad + I * 2 * kChunkRow));
+    raw[Bf][1] = __builtin_bit_cast(u32x4, lds_h8(aad + I * 2 * kChunkRow + 512));
+    cs[Bf][0] = lds_f4(cad + I * 64);
+    cs[Bf][1] = lds_f4(cad + I * 64 + 16);
+    cs[Bf][2] = lds_f4(cad + I * 64 + 4096);
+    cs[Bf][3] = lds_f4(cad + I * 64 + 4096 + 16);
   };
-  auto bn_unit = [&](auto u_tag, auto par_tag) TN_INL {     // one dword (two channels) of one tile
-    constexpr int U = decltype(u_tag)::value, T = U >> 2, Dw = U & 3, PAR = decltype(par_tag)::value;
-    const unsigned in = raw[T][Dw];
-    const float s0 = cs[Dw >> 1][(2 * Dw) & 3], s1 = cs[Dw >> 1][(2 * Dw + 1) & 3];
-    const float h0 = cs[2 + (Dw >> 1)][(2 * Dw) & 3], h1 = cs[2 + (Dw >> 1)][(2 * Dw + 1) & 3];
-    float t0, t1;
-    unsigned o;      // fp32 fma, one rounding, packed ReLU (one statement: between two, hipcc pads the dependency with an s_nop)
-    asm("v_fma_mix_f32 %1, %3, %4, %5 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %2, %3, %6, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_f16 %0, %0, 0"
-        : "=&v"(o), "=&v"(t0), "=&v"(t1) : "v"(in), "v"(s0), "v"(h0), "v"(s1), "v"(h1));
-    x[PAR][T][Dw] = o;
+  // BatchNorm + ReLU of two dwords (four channels) of one tile: fp32 fma, one rounding, packed ReLU.  Two independent chains
+  // interleaved in ONE statement: with a single wave on the SIMD nothing else hides the VALU result latency between
+  // fma -> convert -> max, and between two statements hipcc pads the dependency with an s_nop the hardware does not need.
+  auto bn_pair = [&](auto u_tag, auto par_tag) TN_INL {
+    constexpr int U = decltype(u_tag)::value, T = U >> 1, D0 = 2 * (U & 1), D1 = D0 + 1, PAR = decltype(par_tag)::value;
+    const unsigned in0 = raw[PAR][T][D0], in1 = raw[PAR][T][D1];
+    const f32x4 sc = cs[PAR][U & 1], sh = cs[PAR][2 + (U & 1)];     // channels 4 (U & 1) .. + 3 of the lane's eight
+    float t0, t1, t2, t3;
+    unsigned o0, o1;
+    asm("v_fma_mix_f32 %2, %6, %8, %12 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %3, %6, %9, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %4, %7, %10, %14 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %5, %7, %11, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5\n\tv_pk_max_f16 %0, %0, 0\n\tv_pk_max_f16 %1, %1, 0"
+        : "=&v"(o0), "=&v"(o1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(in0), "v"(in1), "v"(sc[0]), "v"(sc[1]), "v"(sc[2]), "v"(sc[3]), "v"(sh[0]), "v"(sh[1]), "v"(sh[2]), "v"(sh[3]));
+    x[PAR][T][D0] = o0;
+    x[PAR][T][D1] = o1;
   };
   // One k-step: 8 MFMAs (4 M-tiles x 2 pixel tiles) on ring slot S with the fragments of parity P & 1; in their shadow the
   // LDS reads and BatchNorm of the next step and the refill of the slot: KIND 0 none, 1 the next step of the stream,
   // 2 step S of the next layer (the stream pointer then stands at that layer's first step).
-  auto step = [&](auto s_tag, auto p_tag, auto kind_tag, auto next_tag, unsigned aad, unsigned cad) TN_INL {
-    constexpr int S = decltype(s_tag)::value, P = decltype(p_tag)::value, KIND = decltype(kind_tag)::value, PAR = P & 1;
-    constexpr bool NEXT = decltype(next_tag)::value != 0;
-    if constexpr (NEXT) read_next(aad, cad, ic<P + 1>{});
+  // P = position relative to aad / cad (parity and LDS immediates), slot P % D; LAST = the last position of a straight-line
+  // stretch that ends the layer (0: more steps follow); position 0 is the layer's first step and starts the accumulators.
+  auto step = [&](auto p_tag, auto kind_tag, auto last_tag, unsigned aad, unsigned cad) TN_INL {
+    constexpr int P = decltype(p_tag)::value, S = P % D, KIND = decltype(kind_tag)::value, PAR = P & 1;
+    constexpr int LAST = decltype(last_tag)::value;
+    constexpr bool NEXT = LAST == 0 || P + 1 <= LAST, NEXT2 = LAST == 0 || P + 2 <= LAST;
     static_for<8>([&](auto j_tag) TN_INL {
       constexpr int J = decltype(j_tag)::value, M = J >> 1, T = J & 1;
-      acc[M][T] = mfma32(ring[S][M], __builtin_bit_cast(f16x8, x[PAR][T]), acc[M][T]);
-      if constexpr (NEXT && J >= 1) bn_unit(ic<J - 1>{}, ic<PAR ^ 1>{});
-      if constexpr (NEXT && J == 7) bn_unit(ic<7>{}, ic<PAR ^ 1>{});
-      if constexpr (T == 1 && KIND == 1) ring[S][M] = wa[M * 64];
-      if constexpr (T == 1 && KIND == 2) ring[S][M] = wa[S * kStepUnits + M * 64];
+      if constexpr (J == 0 && NEXT2 && !(TN_B7_EXP & 4)) read_step(aad, cad, ic<P + 2>{});
+      if constexpr (P == 0) {
+        f32x16 z;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) z[e] = 0.f;
+        acc[M][T] = mfma32(ring[S][M], __builtin_bit_cast(f16x8, x[PAR][T]), z);
+      } else {
+        acc[M][T] = mfma32(ring[S][M], __builtin_bit_cast(f16x8, x[PAR][T]), acc[M][T]);
+      }
+      if constexpr (NEXT && !(TN_B7_EXP & 2) && (J & 1) == 0) bn_pair(ic<(J >> 1)>{}, ic<PAR ^ 1>{});
+      if constexpr (T == 1 && KIND == 1 && !(TN_B7_EXP & 1)) ring[S][M] = wa[M * 64 + lane];
+      if constexpr (T == 1 && KIND == 2 && !(TN_B7_EXP & 1)) ring[S][M] = wa[S * kStepUnits + M * 64 + lane];
       TN_SB();
     });
     if constexpr (KIND == 1) wa += kStepUnits;
   };
 
+  int nstamp = 0;
+  auto stamp = [&]() TN_INL {
+    if (a.ts) {
+      const unsigned long long tnow = __builtin_amdgcn_s_memtime();
+      if (w == 0 && lane == 0 && nstamp < 126) a.ts[(size_t)blockIdx.x * 128 + nstamp] = tnow;
+      ++nstamp;
+    }
+  };
+  if (a.ts && w == 0 && lane == 0) a.ts[(size_t)blockIdx.x * 128 + 127] = __builtin_amdgcn_s_memrealtime();
+  stamp();
   int K = a.K0;
   for (int l = 0; l < a.nl; ++l, K += 32) {
     const int G = K >> 4, gbase = G >> 2, grem = G & 3;
     const int nA = gbase + (w < grem ? 1 : 0);
     const int g0 = w * gbase + (w < grem ? w : grem);
 
-    // this layer's 3x3 fragments (needed a whole 1x1 GEMM later)
-    f16x8 w3f[18];
-    static_for<18>([&](auto u_tag) TN_INL { w3f[u_tag.value] = wb[u_tag.value * 64]; });
-    wb += kW3Units;
+    // The ring's first D steps were requested a whole reduce + 3x3 ago, in an order that depends on the previous layer's
+    // remainder variant.  An explicit vmcnt(0) here costs nothing and gives hipcc's wait-count pass ONE state to start the
+    // layer from: merged over the six variants it would otherwise assume the worst of each and drain the queue (every load
+    // of the k loop included) in front of the first ring read - 2 700 cycles per layer, measured.
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), expcnt / lgkmcnt untouched
 
     // ======================= 1x1: partial bottleneck over this wave's k-steps =======================
     unsigned aad = aaddr0 + (unsigned)g0 * (2 * kChunkRow), cad = caddr0 + (unsigned)g0 * 64;
-    read_next(aad, cad, ic<0>{});
-    static_for<8>([&](auto u_tag) TN_INL { bn_unit(u_tag, ic<0>{}); });
+    read_step(aad, cad, ic<0>{});
+    read_step(aad, cad, ic<1>{});
+    static_for<4>([&](auto u_tag) TN_INL { bn_pair(u_tag, ic<0>{}); });
     TN_SB();
-    int s = 0;
-    while (s + 2 * D <= nA) {
-      static_for<D>([&](auto i_tag) TN_INL { step(i_tag, i_tag, ic<1>{}, ic<1>{}, aad, cad); });
+    step(ic<0>{}, ic<1>{}, ic<0>{}, aad, cad);          // step 0 starts the accumulators (C = 0); its slot takes step D
+#ifdef TN_B7_STAMPS_A
+    stamp();
+#endif
+    int b = 0;                                          // steps b+1 .. are still to come; the ring holds b+1 .. b+D
+    while (b + 2 * D + 1 <= nA) {
+      static_for<D>([&](auto i_tag) TN_INL { step(ic<decltype(i_tag)::value + 1>{}, ic<1>{}, ic<0>{}, aad, cad); });
       aad += D * 2 * kChunkRow;
       cad += D * 64;
-      s += D;
+      b += D;
     }
-    const int r = nA - s - D;        // 0 .. D-1 steps still to be requested
+#ifdef TN_B7_STAMPS_A
+    stamp();
+#endif
+    const int r = nA - 1 - b - D;        // 0 .. D-1 steps of this layer still to be requested
     static_for<D>([&](auto r_tag) TN_INL {
       constexpr int R = decltype(r_tag)::value;
       if (r == R) {
-        static_for<D + R>([&](auto p_tag) TN_INL {
-          constexpr int P = decltype(p_tag)::value;
-          step(ic<(P % D)>{}, p_tag, ic<(P < R ? 1 : 2)>{}, ic<(P + 1 < D + R ? 1 : 0)>{}, aad, cad);
+        static_for<D + R>([&](auto i_tag) TN_INL {
+          constexpr int P = decltype(i_tag)::value + 1;
+          step(ic<P>{}, ic<(P <= R ? 1 : 2)>{}, ic<D + R>{}, aad, cad);
         });
       }
     });
     wa += D * kStepUnits;
+    // this layer's 3x3 fragments: requested here, they land during the reduction (requested before the 1x1 they would sit in
+    // 72 registers through the whole k loop, and hipcc then moves some of them between register files right behind their
+    // loads: a full L2 latency per layer, measured)
+    f16x8 w3f[18];
+    static_for<18>([&](auto u_tag) TN_INL { w3f[u_tag.value] = wb[u_tag.value * 64 + lane]; });
+    wb += kW3Units;
+    stamp();
 
     // ======================= reduce the four partial tiles: wave w keeps M-tile w = accumulator set 0 =======================
     const float *tbn = a.tab + (size_t)(l + 1) * kTabFloats;
@@ -237,6 +278,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
       if constexpr (RD < 3) __syncthreads();
     });
 
+    stamp();
     // ======================= BN2 shift + ReLU + fp16 -> this wave's 32 channels of the pixel-slot tile =======================
     {
       const unsigned t2ad = kTabOff + 8192 + (unsigned)(32 * w + 4 * h) * 4;
@@ -255,6 +297,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
       });
     }
 
+    stamp();
     // ======================= 3x3 over this wave's 32 bottleneck channels (all nine taps) =======================
     f32x16 q[2];
     f16x8 bq[2][2];
@@ -272,17 +315,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         q[T] = mfma32(w3f[U], bq[U & 1][T], q[T]);
       }
       (void)TAP; (void)SS;
-      // the 1x1 accumulators of the next layer start from zero: cleared here, in the shadow of these MFMAs
-      if constexpr (I < 32) {
-        constexpr int Mz = I >> 3, Tz = (I >> 2) & 1, Qz = I & 3;
-        acc[Mz][Tz][4 * Qz] = 0.f;
-        acc[Mz][Tz][4 * Qz + 1] = 0.f;
-        acc[Mz][Tz][4 * Qz + 2] = 0.f;
-        acc[Mz][Tz][4 * Qz + 3] = 0.f;
-      }
       TN_SB();
     });
 
+    stamp();
     // ======================= reduce the four partial outputs; append the layer's 32 channels =======================
     {
       const unsigned base = kRedOff + (unsigned)w * 8192 + lane * 16;
@@ -319,7 +355,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
       }
     }
     __syncthreads();
+    stamp();
   }
+  if (a.ts && w == 0 && lane == 0) a.ts[(size_t)blockIdx.x * 128 + 126] = __builtin_amdgcn_s_memrealtime();
 }
 
 constexpr int kRingDepth = 6;
@@ -327,7 +365,7 @@ constexpr int kRingDepth = 6;
 }  // namespace
 
 bool dense_block7_supported(int H, int W, int K0, int nl) {
-  return H == 7 && W == 7 && K0 % 32 == 0 && K0 >= 64 * kRingDepth && nl >= 1 && K0 + 32 * nl <= 1024;
+  return H == 7 && W == 7 && K0 % 32 == 0 && K0 >= 64 * (kRingDepth + 1) && nl >= 1 && K0 + 32 * nl <= 1024;
 }
 
 // Host side: the per-wave weight streams and the per-layer tables.

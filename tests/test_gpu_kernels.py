@@ -282,7 +282,7 @@ def test_transition_exact_weights(ctx, report, B, H, K, N):
     assert err < 4e-3, err            # fp16 output rounding
 
 
-@pytest.mark.parametrize("B,K0,nl,ldc", [(3, 512, 16, 1024), (2, 384, 3, 512), (1, 512, 1, 1024), (5, 448, 5, 1024), (2, 480, 7, 768),
+@pytest.mark.parametrize("B,K0,nl,ldc", [(3, 512, 16, 1024), (2, 576, 3, 768), (1, 512, 1, 1024), (5, 448, 5, 1024), (2, 480, 7, 768),
                                           (300, 512, 2, 1024)])
 def test_dense_block7(ctx, report, B, K0, nl, ldc):
     """The LDS-resident 7x7 dense block (dense_block7.hip: one frame per workgroup, concat buffer in LDS, weights streamed
