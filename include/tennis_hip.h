@@ -295,16 +295,22 @@ int tn_comm_destroy(tn_comm *c);
  *                         + decoder.init_state_from_encoder (gnmt.py:224-252)
  *   tn_gnmt_beam_search = BeamSearchTranslator.translate (utils/translation.py:55-82): the whole
  *                         decode_step / log_softmax / BeamSearchSampler loop on the device.
- * params: "<prefix>enc_rnn0_{l,r}_*", "<prefix>enc_rnn1_*", "<prefix>dec_rnn{0,1}_*"
- * ({i2h,h2h}_{weight,bias}), "<prefix>dec_attention_key_weight" (H,H), "<prefix>tgt_proj_{weight,bias}",
- * "<prefix>tgt_embed_weight" (V,E).  Only the reference defaults are built: cell_type gru,
- * num_layers 2, num_bi_layers 1, scaled_luong attention, no residual, dropout off.
+ * params: "<prefix>enc_rnn{i}_{l,r}_*" for the num_bi_layers bidirectional encoder layers, "<prefix>enc_rnn{i}_*" for
+ * the uni-directional ones, "<prefix>dec_rnn{i}_*" ({i2h,h2h}_{weight,bias}; i < num_layers),
+ * "<prefix>dec_attention_key_weight" (H,H), "<prefix>tgt_proj_{weight,bias}", "<prefix>tgt_embed_weight" (V,E).
+ * cell_type gru | lstm, 2 <= num_layers <= 8, 0 <= num_bi_layers < num_layers (gnmt.py:78-80; with every layer
+ * bidirectional the memory is 2H wide, which gluonnlp's Luong attention with units = H refuses), scaled_luong attention,
+ * dropout off (inference); tn_gnmt_create_ex(flags = TN_GNMT_USE_RESIDUAL): use_residual (gnmt.py:155-157,394-395).
  * src (B,T,F) fp32 features, valid_len (B,) int32; samples (B,beam,max_length+2) int32 padded
  * with -1 (leading BOS), scores (B,beam) descending, valid_length (B,beam) int32;
  * *length_host = number of meaningful columns of `samples` (the width the reference returns). */
 int tn_gnmt_create(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix, int cell_kind,
                    int input_size, int hidden, int embed, int vocab, int num_layers, int num_bi_layers,
                    int max_batch, int max_src_len, int beam, int max_length, tn_gnmt **out);
+#define TN_GNMT_USE_RESIDUAL 1
+int tn_gnmt_create_ex(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix, int cell_kind,
+                      int input_size, int hidden, int embed, int vocab, int num_layers, int num_bi_layers,
+                      int max_batch, int max_src_len, int beam, int max_length, int flags, tn_gnmt **out);
 int tn_gnmt_encode(tn_gnmt *g, const float *src, const int32_t *valid_len, int batch, int steps, float *mem_out);
 int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, float K, int max_length, int32_t *samples,
                         float *scores, int32_t *valid_length, int *length_host);

@@ -31,8 +31,8 @@ from . import rnn_np as rn
 NEG = np.float32(-1e18)
 
 
-def encoder(x, valid_length, p, cell="gru", hidden=128, num_layers=2, num_bi_layers=1, prefix="gnmt_enc_"):
-    """gnmt.py:136-160 (dropout off, use_residual=False).  x (B,T,F) -> (mem (B,T,H), states)."""
+def encoder(x, valid_length, p, cell="gru", hidden=128, num_layers=2, num_bi_layers=1, prefix="gnmt_enc_", use_residual=False):
+    """gnmt.py:136-160 (dropout off).  x (B,T,F) -> (mem (B,T,H), states)."""
     states = []
     inp = x
     for i in range(num_layers):
@@ -44,6 +44,8 @@ def encoder(x, valid_length, p, cell="gru", hidden=128, num_layers=2, num_bi_lay
         else:
             out, h, c = rn.rnn_direction(inp, p, f"{prefix}rnn{i}_", cell, False, valid_length)
             states.append((h, c))
+        if use_residual and i > num_bi_layers:      # gnmt.py:155-157
+            out = (out + inp).astype(np.float32)
         inp = out
     # SequenceMask (gnmt.py:157-159): padded steps are already zero in rnn_direction's output
     return inp, states
@@ -63,8 +65,8 @@ class Decoder:
     """One-step GNMT decoder + target embedding + projection (GRU or LSTM cells).  The recurrent state travels
     as a flat list of (R,H) arrays: [h0, h1] for GRU, [h0, c0, h1, c1] for LSTM (the cell output is h)."""
 
-    def __init__(self, p, hidden, num_layers=2, prefix="gnmt_", cell="gru"):
-        self.p, self.h, self.nl, self.pre, self.cell = p, hidden, num_layers, prefix, cell
+    def __init__(self, p, hidden, num_layers=2, prefix="gnmt_", cell="gru", use_residual=False):
+        self.p, self.h, self.nl, self.pre, self.cell, self.residual = p, hidden, num_layers, prefix, cell, use_residual
 
     def init_state(self, mem, enc_states, valid_length):
         """gnmt.py:224-252"""
@@ -102,9 +104,12 @@ class Decoder:
         ctx = np.einsum("rt,rth->rh", w, self.mem[rows]).astype(np.float32)
         out = h0
         for i in range(1, self.nl):
-            out, ci = cell(i, np.concatenate([out, ctx], axis=-1))
-            new_states += [out, ci] if lstm else [out]
+            cur = out
+            hi, ci = cell(i, np.concatenate([cur, ctx], axis=-1))
+            new_states += [hi, ci] if lstm else [hi]
+            out = (hi + cur).astype(np.float32) if self.residual else hi      # gnmt.py:394-395: the STATE stays the cell's
         logits = out @ p[self.pre + "tgt_proj_weight"].T + p[self.pre + "tgt_proj_bias"]
+        self.last_logits = logits.astype(np.float32)        # the un-normalised projection of this step (decode_seq)
         return _log_softmax(logits.astype(np.float32)), new_states, ctx
 
 
@@ -170,9 +175,7 @@ def decode_seq(dec: Decoder, mem, enc_states, valid_length, tgt):
     outs = []
     for i in range(L):
         logp, rnn_states, att = dec.step(np.maximum(tgt[:, i], 0), rnn_states, att, rows)
-        # recover the un-normalised logits: recompute the projection from the top state
-        top = rnn_states[-2] if dec.cell == "lstm" else rnn_states[-1]
-        outs.append((top @ p[pre + "tgt_proj_weight"].T + p[pre + "tgt_proj_bias"]).astype(np.float32))
+        outs.append(dec.last_logits)
     return np.stack(outs, axis=1)
 
 

@@ -97,6 +97,8 @@ _SIGS = {
     "tn_gnmt_trainer_destroy": (C.c_int, [_P]),
     "tn_gnmt_create": (C.c_int, [_P, C.POINTER(TnParam), C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "tn_gnmt_create_ex": (C.c_int, [_P, C.POINTER(TnParam), C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "tn_gnmt_encode": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
     "tn_gnmt_beam_search": (C.c_int, [_P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, _P, _P, _P,
                                       C.POINTER(C.c_int)]),

@@ -215,7 +215,11 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
     const float *__restrict__ ctx, const float *__restrict__ c0n, float *__restrict__ x0, float *__restrict__ c0cur,
     const float *__restrict__ emb, int H, int E, int V, int beam, int step, float alpha, float Kp, int eos,
     float *__restrict__ scores, int32_t *__restrict__ alive, int32_t *__restrict__ vlen,
-    const int32_t *__restrict__ samples_in, int32_t *__restrict__ samples_out, int L, int32_t *__restrict__ any_alive) {
+    const int32_t *__restrict__ samples_in, int32_t *__restrict__ samples_out, int L, int32_t *__restrict__ any_alive,
+    float *__restrict__ hstate = nullptr, int32_t *__restrict__ parent_out = nullptr) {
+  // hstate != NULL: use_residual (gnmt.py:394-395) - the projection sees h + the cell's input x1[:, 0:H], the recurrent
+  // state stays h and goes through this (R,H) scratch; parent_out: the chosen parent beam of every row, for the states of
+  // the decoder layers between the first and the last one (num_layers > 2)
   extern __shared__ float sm[];   // h1n[H][NP] | c1n[H][NP] | logits[beam*V] | part[4*beam*V] (cand aliases part) | lse[16]
   const int b = blockIdx.x, t = threadIdx.x, NC = beam * V + beam, K0 = E + 2 * H, K1 = 3 * H;
   constexpr int NP = (NBM + 3) & ~3;   // LDS pitch of one k: NBM beam rows padded to 16-byte multiples
@@ -240,6 +244,10 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
         const float rg = sigm(g[u]), zg = sigm(g[H + u]);
         const float ng = tanhf(g[2 * H + u] + rg * g[3 * H + u]);
         v = (1.f - zg) * ng + zg * x1[r * K1 + 2 * H + u];
+      }
+      if (hstate) {
+        hstate[r * H + u] = v;
+        v += x1[r * K1 + u];
       }
     }
     h1n[u * NP + k] = v;       // k-major: a projection thread reads its NBM rows with one or two wide LDS loads
@@ -384,6 +392,7 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
     alive[b * beam + t] = al;
     sel_par[t] = bid;
     sel_word[t] = word;
+    if (parent_out) parent_out[b * beam + t] = bid;
     if (al) atomicOr(any_alive, 1);
   }
   __syncthreads();
@@ -410,7 +419,7 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
   for (int idx = t; idx < beam * H; idx += kBeamThreads) {
     const int k = idx / H, u = idx - k * H;
     const long r = (long)b * beam + k, pr = (long)b * beam + sel_par[k];
-    x1[r * K1 + 2 * H + u] = h1n[u * NP + sel_par[k]];
+    x1[r * K1 + 2 * H + u] = hstate ? hstate[pr * H + u] : h1n[u * NP + sel_par[k]];
     if (lstm) {
       c1cur[r * H + u] = c1n[u * NP + sel_par[k]];
       c0cur[r * H + u] = c0n[pr * H + u];
@@ -440,7 +449,7 @@ __global__ void dec_tf_prep_kernel(const float *__restrict__ emb, const int32_t 
 
 __global__ void dec_tf_cell1_kernel(const float *__restrict__ g1, const float *__restrict__ x1, int lstm,
                                     const float *__restrict__ c1cur, float *__restrict__ h1n, float *__restrict__ c1n,
-                                    int R, int H) {
+                                    int R, int H, float *__restrict__ out = nullptr) {
   const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= (long)R * H) return;
   const long r = id / H;
@@ -456,6 +465,53 @@ __global__ void dec_tf_cell1_kernel(const float *__restrict__ g1, const float *_
     const float ng = tanhf(g[2 * H + u] + rg * g[3 * H + u]);
     h1n[id] = (1.f - zg) * ng + zg * x1[r * 3 * H + 2 * H + u];
   }
+  if (out) out[id] = h1n[id] + x1[r * 3 * H + u];     // use_residual: what the projection sees
+}
+
+// A decoder cell between the first and the last one (num_layers > 2; gnmt.py:385-397): gates on the stacked
+// pre-activations g (R,4H) of x = [out of the layer below, attention, h_prev]; the new state goes to hn / cn, the layer's
+// output (h, or h + the layer's input with use_residual) and the attention vector to the next layer's input.
+__global__ void dec_mid_cell_kernel(const float *__restrict__ g, const float *__restrict__ x, int lstm,
+                                    const float *__restrict__ ccur, float *__restrict__ hn, float *__restrict__ cn,
+                                    float *__restrict__ xnext, int residual, int R, int H) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)R * H) return;
+  const long r = id / H;
+  const int u = (int)(id - r * H);
+  const float *gr = g + r * 4 * H;
+  float h;
+  if (lstm) {
+    const float ig = sigm(gr[u]), fg = sigm(gr[H + u]), gg = tanhf(gr[2 * H + u]), og = sigm(gr[3 * H + u]);
+    const float c2 = fg * ccur[id] + ig * gg;
+    cn[id] = c2;
+    h = og * tanhf(c2);
+  } else {
+    const float rg = sigm(gr[u]), zg = sigm(gr[H + u]);
+    const float ng = tanhf(gr[2 * H + u] + rg * gr[3 * H + u]);
+    h = (1.f - zg) * ng + zg * x[r * 3 * H + 2 * H + u];
+  }
+  hn[id] = h;
+  xnext[r * 3 * H + u] = residual ? h + x[r * 3 * H + u] : h;
+  xnext[r * 3 * H + H + u] = x[r * 3 * H + H + u];
+}
+
+// The recurrent state of such a layer for the next step: x[:, 2H:3H] = hn[row or its parent beam], ccur likewise (LSTM).
+// parent == NULL (teacher forcing, or hn / cn = the encoder's states of the clip with `beam` rows per clip): by row / clip.
+__global__ void dec_mid_state_kernel(const int32_t *__restrict__ parent, const float *__restrict__ hn,
+                                     const float *__restrict__ cn, float *__restrict__ x, float *__restrict__ ccur,
+                                     int from_clip, int beam, int R, int H) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)R * H) return;
+  const long r = id / H;
+  const int u = (int)(id - r * H);
+  const long pr = from_clip ? r / beam : parent ? (r / beam) * beam + parent[r] : r;
+  x[r * 3 * H + 2 * H + u] = hn[pr * H + u];
+  if (cn) ccur[id] = cn[pr * H + u];
+}
+
+__global__ void add_inplace_kernel(float *__restrict__ y, const float *__restrict__ x, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += x[i];
 }
 
 // first step's inputs: x0 = [embed(bos), 0, h0 of the clip], x1[:, 2H:3H] = h1 of the clip, cell states (LSTM)
@@ -772,15 +828,26 @@ struct DevBuf {
 
 }  // namespace
 
+// a decoder cell between the first and the last one (num_layers > 2)
+struct GnmtMid { float *w, *b, *sx, *g, *hn, *cn, *ccur; };
+
 struct tn_gnmt {
   tn_ctx *ctx;
   DevBuf pool;
-  tn_birnn *enc0, *enc1;   // bi layer (F -> 2H), uni layer (2H -> H)
+  // encoder: num_bi_layers bidirectional layers (F | 2H -> 2H), then uni-directional ones (2H | H -> H); gnmt.py:84-111
+  std::vector<tn_birnn *> enc;
+  int NL, NBI;
+  bool residual;            // use_residual (gnmt.py:155-157, 394-395)
+  std::vector<float *> hl, cl;   // final states per encoder layer (bi: [fwd, bwd]); the decoder layer i starts from layer i's
+  float *seqB;              // second sequence buffer (layers ping-pong between seq0 and seqB; the last one writes mem)
+  std::vector<GnmtMid> mid; // decoder layers 1 .. NL-2
+  float *hstate;            // last decoder layer's state when use_residual (the LDS copy then holds h + input)
+  int32_t *parent;          // parent beam per row (for the states of `mid`)
   int F, H, E, V, maxB, maxT, beam, maxL;
   float *wk, *wp, *bp, *emb;
   // per-call workspace
   int G;                   // gates per cell: 3 GRU, 4 LSTM
-  float *seq0, *mem, *keyproj, *hl0, *hl1, *cl0, *cl1;
+  float *seq0, *mem, *keyproj;
   int32_t *vl;
   float *scores;
   int32_t *alive, *vlen, *tok, *samples[2], *flag;
@@ -790,12 +857,27 @@ struct tn_gnmt {
   int B, T;
 };
 
+extern "C" int tn_gnmt_create_ex(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix_c, int cell_kind,
+                                 int input_size, int hidden, int embed, int vocab, int num_layers, int num_bi_layers,
+                                 int max_batch, int max_src_len, int beam, int max_length, int flags, tn_gnmt **out);
+
 extern "C" int tn_gnmt_create(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix_c, int cell_kind,
                               int input_size, int hidden, int embed, int vocab, int num_layers, int num_bi_layers,
                               int max_batch, int max_src_len, int beam, int max_length, tn_gnmt **out) {
+  return tn_gnmt_create_ex(ctx, params, n_params, prefix_c, cell_kind, input_size, hidden, embed, vocab, num_layers, num_bi_layers,
+                           max_batch, max_src_len, beam, max_length, 0, out);
+}
+
+extern "C" int tn_gnmt_create_ex(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix_c, int cell_kind,
+                                 int input_size, int hidden, int embed, int vocab, int num_layers, int num_bi_layers,
+                                 int max_batch, int max_src_len, int beam, int max_length, int flags, tn_gnmt **out) {
   TN_REQUIRE(ctx && params && prefix_c && out, "tn_gnmt_create: null argument");
   TN_REQUIRE(cell_kind == TN_RNN_GRU || cell_kind == TN_RNN_LSTM, "tn_gnmt_create: cell_type must be 'gru' or 'lstm'");
-  TN_REQUIRE(num_layers == 2 && num_bi_layers == 1, "tn_gnmt_create: only num_layers=2, num_bi_layers=1 (reference defaults)");
+  TN_REQUIRE((flags & ~TN_GNMT_USE_RESIDUAL) == 0, "tn_gnmt_create_ex: unknown flag");
+  // gnmt.py:78-80 asserts num_bi_layers <= num_layers; with num_bi_layers == num_layers the memory is 2H wide and gluonnlp's
+  // Luong-style attention (key width = units = H) refuses it [EXT]; a one-layer decoder has no cell behind the attention
+  TN_REQUIRE(num_layers >= 2 && num_layers <= 8 && num_bi_layers >= 0 && num_bi_layers < num_layers,
+             "tn_gnmt_create: need 2 <= num_layers <= 8 and 0 <= num_bi_layers < num_layers");
   TN_REQUIRE(beam >= 1 && beam <= 16 && vocab >= beam && max_length >= 1, "tn_gnmt_create: bad beam/vocab/max_length");
   TN_REQUIRE(input_size > 0 && hidden > 0 && hidden % 4 == 0 && embed > 0 && max_batch > 0 && max_src_len > 0,
              "tn_gnmt_create: bad shape");
@@ -812,37 +894,32 @@ extern "C" int tn_gnmt_create(tn_ctx *ctx, const tn_param *params, int n_params,
   tn_gnmt *g = new tn_gnmt();   // value-initialised: every pointer member starts null
   g->ctx = ctx; g->F = input_size; g->H = hidden; g->E = embed; g->V = vocab; g->maxB = max_batch; g->maxT = max_src_len;
   g->beam = beam; g->maxL = max_length + 2; g->G = cell_kind == TN_RNN_GRU ? 3 : 4;
-  auto fail = [&](int code) { g->pool.release(); if (g->enc0) tn_birnn_destroy(g->enc0); if (g->enc1) tn_birnn_destroy(g->enc1); delete g; return code; };
-  // encoder layers: rename "<pre>enc_rnn0_{l,r}_*" -> "{l,r}0_*" for tn_birnn
-  std::vector<tn_param> p0, p1;
-  std::vector<std::string> names;
-  names.reserve(16);
+  g->NL = num_layers; g->NBI = num_bi_layers; g->residual = (flags & TN_GNMT_USE_RESIDUAL) != 0;
+  auto fail = [&](int code) { g->pool.release(); for (tn_birnn *e : g->enc) tn_birnn_destroy(e); delete g; return code; };
   const char *sfx[4] = {"i2h_weight", "h2h_weight", "i2h_bias", "h2h_bias"};
   const int H = hidden, G3 = g->G * hidden;   // (G3: gates * hidden, 3H or 4H)
-  for (int d = 0; d < 2; ++d)
-    for (int k = 0; k < 4; ++k) {
-      const std::string src = pre + "enc_rnn0_" + (d ? "r_" : "l_") + sfx[k];
-      const int64_t n = k == 0 ? (int64_t)G3 * input_size : k == 1 ? (int64_t)G3 * H : G3;
-      const float *v = get(src, n);
-      if (!v) return fail(TN_ERR_MISSING);
-      names.push_back(std::string(d ? "r0_" : "l0_") + sfx[k]);
-      p0.push_back(tn_param{nullptr, v, n});
-    }
-  for (size_t i = 0; i < p0.size(); ++i) p0[i].name = names[i].c_str();
-  std::vector<std::string> names1;
-  names1.reserve(8);
-  for (int k = 0; k < 4; ++k) {
-    const int64_t n = k == 0 ? (int64_t)G3 * 2 * H : k == 1 ? (int64_t)G3 * H : G3;
-    const float *v = get(pre + "enc_rnn1_" + sfx[k], n);
-    if (!v) return fail(TN_ERR_MISSING);
-    names1.push_back(std::string("l0_") + sfx[k]);
-    p1.push_back(tn_param{nullptr, v, n});
+  // encoder layers: "<pre>enc_rnn{i}_{l,r}_*" (bidirectional) / "<pre>enc_rnn{i}_*" -> the "{l,r}0_*" names of tn_birnn
+  for (int i = 0, fin = input_size; i < num_layers; ++i) {
+    const bool bi = i < num_bi_layers;
+    std::vector<tn_param> pl;
+    std::vector<std::string> names;
+    names.reserve(8);
+    for (int d = 0; d < (bi ? 2 : 1); ++d)
+      for (int k = 0; k < 4; ++k) {
+        const std::string src = pre + "enc_rnn" + std::to_string(i) + "_" + (bi ? (d ? "r_" : "l_") : "") + sfx[k];
+        const int64_t n = k == 0 ? (int64_t)G3 * fin : k == 1 ? (int64_t)G3 * H : G3;
+        const float *v = get(src, n);
+        if (!v) return fail(TN_ERR_MISSING);
+        names.push_back(std::string(d ? "r0_" : "l0_") + sfx[k]);
+        pl.push_back(tn_param{nullptr, v, n});
+      }
+    for (size_t k = 0; k < pl.size(); ++k) pl[k].name = names[k].c_str();
+    tn_birnn *e = nullptr;
+    const int rc = tn_birnn_create(ctx, (tn_rnn_kind)cell_kind, fin, H, pl.data(), (int)pl.size(), "", bi ? 1 : 0, max_batch * max_src_len, &e);
+    if (rc) return fail(rc);
+    g->enc.push_back(e);
+    fin = bi ? 2 * H : H;
   }
-  for (size_t i = 0; i < p1.size(); ++i) p1[i].name = names1[i].c_str();
-  int rc = tn_birnn_create(ctx, (tn_rnn_kind)cell_kind, input_size, H, p0.data(), (int)p0.size(), "", 1, max_batch * max_src_len, &g->enc0);
-  if (rc) return fail(rc);
-  rc = tn_birnn_create(ctx, (tn_rnn_kind)cell_kind, 2 * H, H, p1.data(), (int)p1.size(), "", 0, max_batch * max_src_len, &g->enc1);
-  if (rc) return fail(rc);
   // decoder
   const float *a;
 #define UP(dst, name, n) do { a = get(pre + name, (int64_t)(n)); if (!a) return fail(TN_ERR_MISSING); dst = g->pool.upload(a, (size_t)(n)); } while (0)
@@ -878,7 +955,11 @@ extern "C" int tn_gnmt_create(tn_ctx *ctx, const tn_param *params, int n_params,
       *b_out = g->pool.upload(bv.data(), bv.size());
       return true;
     };
-    if (!stack("dec_rnn0_", embed + H, &g->w0c, &g->b0c) || !stack("dec_rnn1_", 2 * H, &g->w1c, &g->b1c)) return fail(TN_ERR_MISSING);
+    if (!stack("dec_rnn0_", embed + H, &g->w0c, &g->b0c) ||
+        !stack("dec_rnn" + std::to_string(num_layers - 1) + "_", 2 * H, &g->w1c, &g->b1c)) return fail(TN_ERR_MISSING);
+    g->mid.resize(num_layers - 2);
+    for (int i = 1; i + 1 < num_layers; ++i)
+      if (!stack("dec_rnn" + std::to_string(i) + "_", 2 * H, &g->mid[i - 1].w, &g->mid[i - 1].b)) return fail(TN_ERR_MISSING);
     const float *wp = get(pre + "tgt_proj_weight", (int64_t)vocab * H);
     std::vector<float> wt((size_t)H * vocab);
     for (int v = 0; v < vocab; ++v)
@@ -887,8 +968,17 @@ extern "C" int tn_gnmt_create(tn_ctx *ctx, const tn_param *params, int n_params,
   }
   const size_t BT = (size_t)max_batch * max_src_len, R = (size_t)max_batch * beam;
   g->seq0 = g->pool.alloc<float>(BT * 2 * H); g->mem = g->pool.alloc<float>(BT * H); g->keyproj = g->pool.alloc<float>(BT * H);
-  g->hl0 = g->pool.alloc<float>(2 * (size_t)max_batch * H); g->hl1 = g->pool.alloc<float>((size_t)max_batch * H);
-  g->cl0 = g->pool.alloc<float>(2 * (size_t)max_batch * H); g->cl1 = g->pool.alloc<float>((size_t)max_batch * H);
+  g->seqB = num_layers > 2 ? g->pool.alloc<float>(BT * 2 * H) : nullptr;
+  for (int i = 0; i < num_layers; ++i) {
+    g->hl.push_back(g->pool.alloc<float>(2 * (size_t)max_batch * H));
+    g->cl.push_back(g->pool.alloc<float>(2 * (size_t)max_batch * H));
+  }
+  for (GnmtMid &m : g->mid) {
+    m.sx = g->pool.alloc<float>(R * 3 * H); m.g = g->pool.alloc<float>(R * 4 * H);
+    m.hn = g->pool.alloc<float>(R * H); m.cn = g->pool.alloc<float>(R * H); m.ccur = g->pool.alloc<float>(R * H);
+  }
+  g->hstate = g->residual ? g->pool.alloc<float>(R * H) : nullptr;
+  g->parent = g->mid.empty() ? nullptr : g->pool.alloc<int32_t>(R);
   g->vl = g->pool.alloc<int32_t>(max_batch);
   for (int i = 0; i < 2; ++i) g->samples[i] = g->pool.alloc<int32_t>(R * g->maxL);
   g->scores = g->pool.alloc<float>(R); g->alive = g->pool.alloc<int32_t>(R); g->vlen = g->pool.alloc<int32_t>(R);
@@ -912,10 +1002,20 @@ extern "C" int tn_gnmt_encode(tn_gnmt *g, const float *src, const int32_t *valid
   hipStream_t s = g->ctx->stream;
   const int H = g->H;
   TN_HIP_CHECK(hipMemcpyAsync(g->vl, valid_len, sizeof(int32_t) * batch, hipMemcpyDeviceToDevice, s));
-  int rc = tn_birnn_forward(g->enc0, src, batch, steps, g->vl, g->seq0, g->hl0, g->cl0);   // hl0 / cl0 = [fwd, bwd] final states
-  if (rc) return rc;
-  rc = tn_birnn_forward(g->enc1, g->seq0, batch, steps, g->vl, g->mem, g->hl1, g->cl1);
-  if (rc) return rc;
+  // layer i reads the previous layer's sequence and writes the other buffer; the last one writes mem.  Outputs past
+  // valid_len are zero after every layer (tn_birnn_forward), so the closing SequenceMask (gnmt.py:159-161) is already applied.
+  int rc = TN_OK;
+  const float *in = src;
+  for (int i = 0; i < g->NL; ++i) {
+    float *outp = i == g->NL - 1 ? g->mem : (i & 1) ? g->seqB : g->seq0;
+    rc = tn_birnn_forward(g->enc[i], in, batch, steps, g->vl, outp, g->hl[i], g->cl[i]);   // bi: hl / cl = [fwd, bwd] final states
+    if (rc) return rc;
+    if (g->residual && i > g->NBI) {      // gnmt.py:155-157: outputs + inputs from the SECOND uni-directional layer on
+      const long nel = (long)batch * steps * H;
+      hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, s, outp, in, nel);
+    }
+    in = outp;
+  }
   rc = launch_linear_f32(g->mem, H, g->wk, H, nullptr, g->keyproj, H, batch * steps, H, H, 0, s);
   if (rc) return rc;
   hipLaunchKernelGGL(transpose_bth_kernel, dim3((H + 31) / 32, (steps + 31) / 32, batch), dim3(256), 0, s, (const float *)g->keyproj,
@@ -950,10 +1050,17 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
                : nbm == 8 ? allow_lds(dec_beam_kernel<8>, beam_lds) : allow_lds(dec_beam_kernel<16>, beam_lds)) return rc;
   TN_HIP_CHECK(hipMemsetAsync(g->samples[0], 0xff, sizeof(int32_t) * (size_t)R * L, s));
   TN_HIP_CHECK(hipMemsetAsync(g->samples[1], 0xff, sizeof(int32_t) * (size_t)R * L, s));
-  // decoder layer 0 starts from the encoder's BACKWARD layer-0 state, layer 1 from the uni layer (gnmt.py:146-150,224-252)
-  hipLaunchKernelGGL(dec_init_kernel, dim3(R), dim3(256), 0, s, (const float *)g->emb, bos, (const float *)(g->hl0 + (size_t)B * H),
-                     (const float *)g->hl1, lstm ? (const float *)(g->cl0 + (size_t)B * H) : (const float *)nullptr,
-                     (const float *)g->cl1, g->sx0, g->sx1, g->c0cur, g->c1cur, beam, H, E);
+  // decoder layer i starts from encoder layer i's state, the BACKWARD direction's for a bidirectional layer (gnmt.py:146-150,224-252)
+  const int NL = g->NL, nmid = NL - 2;
+  auto hinit = [&](int i) { return (const float *)(g->hl[i] + (i < g->NBI ? (size_t)B * H : 0)); };
+  auto cinit = [&](int i) { return (const float *)(g->cl[i] + (i < g->NBI ? (size_t)B * H : 0)); };
+  hipLaunchKernelGGL(dec_init_kernel, dim3(R), dim3(256), 0, s, (const float *)g->emb, bos, hinit(0), hinit(NL - 1),
+                     lstm ? cinit(0) : (const float *)nullptr, cinit(NL - 1), g->sx0, g->sx1, g->c0cur, g->c1cur, beam, H, E);
+  const int nbm_ = (R * H + 255) / 256;
+  for (int j = 0; j < nmid; ++j)
+    hipLaunchKernelGGL(dec_mid_state_kernel, dim3(nbm_), dim3(256), 0, s, (const int32_t *)nullptr, hinit(j + 1),
+                       lstm ? cinit(j + 1) : (const float *)nullptr, g->mid[j].sx, g->mid[j].ccur, 1, beam, R, H);
+  float *x_after0 = nmid ? g->mid[0].sx : g->sx1;       // input of the cell behind the attention
   hipLaunchKernelGGL(beam_init_kernel, dim3((R + 255) / 256), dim3(256), 0, s, g->scores, g->alive, g->vlen, g->tok, g->samples[0], L, B, beam, bos);
   int steps_done = 0, all_dead = 0;
   // one step = 4 launches: the loop is bound by launch-to-launch dependency latency, not by arithmetic
@@ -963,8 +1070,15 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
     int rc = launch_linear_f32(g->sx0, K0, g->w0c, K0, g->b0c, g->g0, 4 * H, R, 4 * H, K0, 0, s);
     if (rc) return rc;
     hipLaunchKernelGGL(dec_attention_kernel<1>, dim3(R), dim3(kBeamThreads), att_lds, s, (const float *)g->g0,
-                       (const float *)(g->sx0 + E + H), K0, (const float *)g->c0cur, lstm ? 1 : 0, g->h0n, g->c0n, g->sx1, K1,
+                       (const float *)(g->sx0 + E + H), K0, (const float *)g->c0cur, lstm ? 1 : 0, g->h0n, g->c0n, x_after0, K1,
                        (const float *)g->keyprojT, (const float *)g->mem, (const int32_t *)g->vl, g->ctxn, beam, 1, T, H);
+    for (int j = 0; j < nmid; ++j) {
+      GnmtMid &m = g->mid[j];
+      rc = launch_linear_f32(m.sx, K1, m.w, K1, m.b, m.g, 4 * H, R, 4 * H, K1, 0, s);
+      if (rc) return rc;
+      hipLaunchKernelGGL(dec_mid_cell_kernel, dim3(nbm_), dim3(256), 0, s, (const float *)m.g, (const float *)m.sx, lstm ? 1 : 0,
+                         (const float *)m.ccur, m.hn, m.cn, j + 1 < nmid ? g->mid[j + 1].sx : g->sx1, g->residual ? 1 : 0, R, H);
+    }
     rc = launch_linear_f32(g->sx1, K1, g->w1c, K1, g->b1c, g->g1, 4 * H, R, 4 * H, K1, 0, s);
     if (rc) return rc;
 #define TN_BEAM_LAUNCH(NBM)                                                                                              \
@@ -972,12 +1086,15 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
                      lstm ? 1 : 0, g->c1cur, (const float *)g->wpT, (const float *)g->bp, (const float *)g->h0n,          \
                      (const float *)g->ctxn, (const float *)g->c0n, g->sx0, g->c0cur, (const float *)g->emb, H, E, V,     \
                      beam, step, alpha, K, eos, g->scores, g->alive, g->vlen, (const int32_t *)g->samples[0],             \
-                     g->samples[1], L, g->flag)
+                     g->samples[1], L, g->flag, g->hstate, g->parent)
     if (nbm == 4) TN_BEAM_LAUNCH(4);
     else if (nbm == 5) TN_BEAM_LAUNCH(5);
     else if (nbm == 8) TN_BEAM_LAUNCH(8);
     else TN_BEAM_LAUNCH(16);
 #undef TN_BEAM_LAUNCH
+    for (int j = 0; j < nmid; ++j)      // the middle layers' states follow their rows' parent beams
+      hipLaunchKernelGGL(dec_mid_state_kernel, dim3(nbm_), dim3(256), 0, s, (const int32_t *)g->parent, (const float *)g->mid[j].hn,
+                         lstm ? (const float *)g->mid[j].cn : (const float *)nullptr, g->mid[j].sx, g->mid[j].ccur, 0, beam, R, H);
     {
       int32_t *tmp = g->samples[0]; g->samples[0] = g->samples[1]; g->samples[1] = tmp;
     }
@@ -1025,22 +1142,37 @@ extern "C" int tn_gnmt_decode_seq(tn_gnmt *g, const int32_t *tgt, int ld, int st
   const size_t att_lds = ((size_t)(H + T) * 4 + (size_t)4 * (T > H ? T : H)) * sizeof(float);
   TN_REQUIRE(att_lds <= kStepLdsMax, "tn_gnmt_decode_seq: 8 * max(hidden, source length) exceeds the step kernel's 152 KiB of LDS");
   if (int rc = allow_lds(dec_attention_kernel<1>, att_lds)) return rc;
+  const int NL = g->NL, nmid = NL - 2;
+  auto hinit = [&](int i) { return (const float *)(g->hl[i] + (i < g->NBI ? (size_t)B * H : 0)); };
+  auto cinit = [&](int i) { return (const float *)(g->cl[i] + (i < g->NBI ? (size_t)B * H : 0)); };
+  float *x_after0 = nmid ? g->mid[0].sx : g->sx1;
+  float *proj_in = g->residual ? g->hstate : g->h1n;     // use_residual: the projection sees h + the last cell's input
   for (int i = 0; i < steps; ++i) {
-    // decoder layer 0 starts from the encoder's BACKWARD layer-0 state, layer 1 from the uni layer (gnmt.py:146-150,224-252)
-    const float *h0p = i ? g->h0n : g->hl0 + (size_t)B * H, *h1p = i ? g->h1n : g->hl1;
-    const float *c0p = !lstm ? nullptr : i ? g->c0n : g->cl0 + (size_t)B * H, *c1p = !lstm ? nullptr : i ? g->c1n : g->cl1;
+    // decoder layer j starts from encoder layer j's state, the BACKWARD direction's for a bidirectional layer (gnmt.py:146-150,224-252)
+    const float *h0p = i ? g->h0n : hinit(0), *h1p = i ? g->h1n : hinit(NL - 1);
+    const float *c0p = !lstm ? nullptr : i ? g->c0n : cinit(0), *c1p = !lstm ? nullptr : i ? g->c1n : cinit(NL - 1);
     hipLaunchKernelGGL(dec_tf_prep_kernel, dim3(R), dim3(256), 0, s, (const float *)g->emb, tgt, ld, i,
                        i ? (const float *)g->ctxn : (const float *)nullptr, h0p, h1p, c0p, c1p, g->sx0, g->sx1, g->c0cur, g->c1cur, H, E);
+    for (int j = 0; j < nmid; ++j)
+      hipLaunchKernelGGL(dec_mid_state_kernel, dim3(nb), dim3(256), 0, s, (const int32_t *)nullptr, i ? (const float *)g->mid[j].hn : hinit(j + 1),
+                         !lstm ? (const float *)nullptr : i ? (const float *)g->mid[j].cn : cinit(j + 1), g->mid[j].sx, g->mid[j].ccur, 0, 1, R, H);
     int rc = launch_linear_f32(g->sx0, K0, g->w0c, K0, g->b0c, g->g0, 4 * H, R, 4 * H, K0, 0, s);
     if (rc) return rc;
     hipLaunchKernelGGL(dec_attention_kernel<1>, dim3(R), dim3(kBeamThreads), att_lds, s, (const float *)g->g0,
-                       (const float *)(g->sx0 + E + H), K0, (const float *)g->c0cur, lstm ? 1 : 0, g->h0n, g->c0n, g->sx1, K1,
+                       (const float *)(g->sx0 + E + H), K0, (const float *)g->c0cur, lstm ? 1 : 0, g->h0n, g->c0n, x_after0, K1,
                        (const float *)g->keyprojT, (const float *)g->mem, (const int32_t *)g->vl, g->ctxn, 1, 1, T, H);
+    for (int j = 0; j < nmid; ++j) {
+      GnmtMid &m = g->mid[j];
+      rc = launch_linear_f32(m.sx, K1, m.w, K1, m.b, m.g, 4 * H, R, 4 * H, K1, 0, s);
+      if (rc) return rc;
+      hipLaunchKernelGGL(dec_mid_cell_kernel, dim3(nb), dim3(256), 0, s, (const float *)m.g, (const float *)m.sx, lstm ? 1 : 0,
+                         (const float *)m.ccur, m.hn, m.cn, j + 1 < nmid ? g->mid[j + 1].sx : g->sx1, g->residual ? 1 : 0, R, H);
+    }
     rc = launch_linear_f32(g->sx1, K1, g->w1c, K1, g->b1c, g->g1, 4 * H, R, 4 * H, K1, 0, s);
     if (rc) return rc;
     hipLaunchKernelGGL(dec_tf_cell1_kernel, dim3(nb), dim3(256), 0, s, (const float *)g->g1, (const float *)g->sx1, lstm ? 1 : 0,
-                       (const float *)g->c1cur, g->h1n, g->c1n, R, H);
-    rc = launch_linear_f32(g->h1n, H, g->wp, H, g->bp, logits + (size_t)i * V, steps * V, R, V, H, 0, s);
+                       (const float *)g->c1cur, g->h1n, g->c1n, R, H, g->residual ? g->hstate : (float *)nullptr);
+    rc = launch_linear_f32(proj_in, H, g->wp, H, g->bp, logits + (size_t)i * V, steps * V, R, V, H, 0, s);
     if (rc) return rc;
   }
   TN_HIP_CHECK(hipGetLastError());
@@ -1451,8 +1583,7 @@ extern "C" int tn_dbg_dec_stamps(long long *out) {
 extern "C" int tn_gnmt_destroy(tn_gnmt *g) {
   if (!g) return TN_OK;
   TnDeviceGuard tn_dg_(g->ctx->device);
-  tn_birnn_destroy(g->enc0);
-  tn_birnn_destroy(g->enc1);
+  for (tn_birnn *e : g->enc) tn_birnn_destroy(e);
   g->pool.release();
   delete g;
   return TN_OK;

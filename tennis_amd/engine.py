@@ -222,17 +222,19 @@ class GNMTCaptioner:
 
     def __init__(self, params: dict, input_size: int, hidden: int, embed: int, vocab: int, beam: int = 4,
                  max_length: int = 150, max_batch: int = 32, max_src_len: int = 640, prefix: str = "gnmt_",
-                 cell_type: str = "gru", num_layers: int = 2, num_bi_layers: int = 1,
+                 cell_type: str = "gru", num_layers: int = 2, num_bi_layers: int = 1, use_residual: bool = False,
                  ctx: _lib.Context | None = None):
+        """``num_layers`` / ``num_bi_layers`` / ``use_residual`` as in ``get_gnmt_encoder_decoder`` (reference gnmt.py:407-455):
+        2 <= num_layers, num_bi_layers < num_layers (gnmt.py:78-80 and the attention's key width, see tn_gnmt_create_ex)."""
         self.ctx = ctx or _lib.default_context()
         self.lib = self.ctx.lib
         self.hidden, self.beam, self.max_length, self.vocab = hidden, beam, max_length, vocab
         arr, keep = _lib.make_params({k: v for k, v in params.items() if k.startswith(prefix)})
         h = C.c_void_p()
         kind = _lib.RNN_GRU if cell_type == "gru" else _lib.RNN_LSTM
-        check(self.lib.tn_gnmt_create(self.ctx.handle, arr, len(arr), prefix.encode(), kind, input_size, hidden, embed,
-                                      vocab, num_layers, num_bi_layers, max_batch, max_src_len, beam, max_length,
-                                      C.byref(h)), "tn_gnmt_create")
+        check(self.lib.tn_gnmt_create_ex(self.ctx.handle, arr, len(arr), prefix.encode(), kind, input_size, hidden, embed,
+                                         vocab, num_layers, num_bi_layers, max_batch, max_src_len, beam, max_length,
+                                         1 if use_residual else 0, C.byref(h)), "tn_gnmt_create")
         del keep
         self.handle = h
         self._batch = 0

@@ -1,8 +1,9 @@
 """Encoder and decoder of the captioner — mirror of reference models/captioning/gnmt.py
 (itself derived from gluon-nlp) and of the NMTModel the reference builds from gluonnlp
 (train_gnmt.py:228-229).  The blocks hold configuration and Gluon-named parameters; the
-compute runs in libtennis_hip.so (tn_gnmt_*).  Only the configuration the reference
-actually uses is built: cell_type 'gru' (flag default) or 'lstm', attention 'scaled_luong', use_residual False.
+compute runs in libtennis_hip.so (tn_gnmt_*): cell_type 'gru' (flag default) or 'lstm', attention 'scaled_luong',
+num_layers >= 2 with num_bi_layers < num_layers, use_residual on or off (inference; the training step keeps the
+reference's flag defaults num_layers 2 / num_bi_layers 1 / no residual).
 """
 from __future__ import annotations
 
@@ -177,6 +178,6 @@ class NMTModel(Block):
             enc = self.encoder
             cap = GNMTCaptioner(p, self._input_size, enc._hidden_size, self._embed_size, len(self.tgt_vocab), beam,
                                 max_length, max(max_batch, 32), max(max_src_len, 256), self.prefix, enc._cell_type,
-                                enc._num_layers, enc._num_bi_layers)
+                                enc._num_layers, enc._num_bi_layers, bool(enc._use_residual))
             self._engine = (key, cap, max(max_batch, 32), max(max_src_len, 256))
         return self._engine[1]

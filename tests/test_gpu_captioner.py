@@ -9,21 +9,22 @@ from oracle import gnmt_np as gn
 pytestmark = pytest.mark.gpu
 
 
-def _case(seed, B, T, F, H, E, V, beam, max_length, eos_bias=0.0, proj_scale=1.0, cell="gru"):
+def _case(seed, B, T, F, H, E, V, beam, max_length, eos_bias=0.0, proj_scale=1.0, cell="gru", nl=2, nbi=1, res=False):
     from tennis_amd import weights as W
     from tennis_amd.engine import GNMTCaptioner
-    p = W.make_gnmt_weights(seed, cell, F, H, E, V)
+    p = W.make_gnmt_weights(seed, cell, F, H, E, V, num_layers=nl, num_bi_layers=nbi)
     p["gnmt_tgt_proj_weight"] = (p["gnmt_tgt_proj_weight"] * proj_scale).astype(np.float32)   # peakier word distribution
     p["gnmt_tgt_proj_bias"][3] += eos_bias          # steer how early <eos> wins
     rng = np.random.default_rng(seed)
     src = (np.abs(rng.normal(0, 1, (B, T, F))) * 0.5).astype(np.float32)
     vl = rng.integers(max(1, T // 3), T + 1, B).astype(np.int32)
     vl[0] = T
-    cap = GNMTCaptioner(p, F, H, E, V, beam=beam, max_length=max_length, max_batch=B, max_src_len=T, cell_type=cell)
+    cap = GNMTCaptioner(p, F, H, E, V, beam=beam, max_length=max_length, max_batch=B, max_src_len=T, cell_type=cell,
+                        num_layers=nl, num_bi_layers=nbi, use_residual=res)
     mem = cap.encode(torch.from_numpy(src).cuda(), torch.from_numpy(vl).cuda()).cpu().numpy()
     samples, scores, vlen = cap.beam_search(2, 3, 1.0, 5.0)
-    rmem, rstates = gn.encoder(src, vl, p, cell, H)
-    dec = gn.Decoder(p, H, cell=cell)
+    rmem, rstates = gn.encoder(src, vl, p, cell, H, num_layers=nl, num_bi_layers=nbi, use_residual=res)
+    dec = gn.Decoder(p, H, num_layers=nl, cell=cell, use_residual=res)
     rs, rsc, rvl = gn.beam_search(dec, rmem, rstates, vl, 2, 3, beam, 1.0, 5, max_length)
     return (mem, samples.cpu().numpy(), scores.cpu().numpy(), vlen.cpu().numpy()), (rmem, rs, rsc, rvl)
 
@@ -41,11 +42,17 @@ def _case(seed, B, T, F, H, E, V, beam, max_length, eos_bias=0.0, proj_scale=1.0
     dict(seed=7, B=3, T=17, F=32, H=24, E=10, V=30, beam=3, max_length=16, proj_scale=30.0),
     dict(seed=8, B=2, T=300, F=48, H=32, E=16, V=300, beam=7, max_length=20, proj_scale=40.0),
     dict(seed=9, B=2, T=40, F=48, H=32, E=16, V=61, beam=10, max_length=20, proj_scale=40.0, cell="lstm"),
+    # --num_layers / --num_bi_layers other than the flag defaults (train_gnmt.py:72-75), use_residual (gnmt.py:155-157,394-395)
+    dict(seed=10, B=3, T=19, F=40, H=32, E=16, V=40, beam=4, max_length=24, proj_scale=30.0, nl=3, nbi=1),
+    dict(seed=11, B=3, T=19, F=40, H=32, E=16, V=40, beam=5, max_length=24, proj_scale=30.0, nl=4, nbi=2, cell="lstm"),
+    dict(seed=12, B=4, T=15, F=40, H=32, E=16, V=40, beam=4, max_length=24, proj_scale=30.0, nl=4, nbi=1, res=True),
+    dict(seed=13, B=3, T=15, F=40, H=32, E=16, V=40, beam=4, max_length=24, proj_scale=30.0, nl=2, nbi=1, res=True, cell="lstm"),
+    dict(seed=14, B=3, T=15, F=40, H=32, E=16, V=40, beam=3, max_length=20, proj_scale=30.0, nl=3, nbi=0, res=True),
 ])
 def test_beam_search_matches_oracle(cfg, report):
     (mem, s, sc, vl), (rmem, rs, rsc, rvl) = _case(**cfg)
     assert np.abs(mem - rmem).max() < 1e-4
-    report[f"gnmt_{cfg.get('cell', 'gru')}_seed{cfg['seed']}_ps{cfg.get('proj_scale', 1.0)}_score_maxabs_err"] = float(np.abs(sc - rsc).max())
+    report[f"gnmt_{cfg.get('cell', 'gru')}_seed{cfg['seed']}_nl{cfg.get('nl', 2)}_ps{cfg.get('proj_scale', 1.0)}_score_maxabs_err"] = float(np.abs(sc - rsc).max())
     assert s.shape == rs.shape, (s.shape, rs.shape)
     assert np.array_equal(vl, rvl)
     assert np.array_equal(s, rs)                       # caption token ids equal
@@ -100,6 +107,31 @@ def test_teacher_forcing_and_loss(report):
     report["gnmt_teacher_forced_logits_maxabs_err"] = float(np.abs(logits.cpu().numpy() - rl).max())
     assert np.abs(logits.cpu().numpy() - rl).max() < 1e-4
     assert np.abs(loss - rloss).max() < 1e-5
+
+
+@pytest.mark.parametrize("nl,nbi,res,cell", [(3, 1, False, "gru"), (4, 2, True, "lstm"), (2, 1, True, "gru")])
+def test_teacher_forcing_layer_counts_and_residual(report, nl, nbi, res, cell):
+    """decode_seq logits with num_layers / num_bi_layers / use_residual other than the reference's defaults vs the oracle."""
+    from tennis_amd import weights as W
+    from tennis_amd.engine import GNMTCaptioner
+    B, T, F, H, E, V, L = 3, 13, 40, 32, 16, 50, 8
+    p = W.make_gnmt_weights(20 + nl, cell, F, H, E, V, num_layers=nl, num_bi_layers=nbi)
+    rng = np.random.default_rng(nl)
+    src = (np.abs(rng.normal(0, 1, (B, T, F))) * 0.5).astype(np.float32)
+    svl = np.array([13, 6, 9], np.int32)
+    tgt = rng.integers(4, V, (B, L)).astype(np.int32)
+    cap = GNMTCaptioner(p, F, H, E, V, beam=2, max_length=12, max_batch=B, max_src_len=T, cell_type=cell, num_layers=nl,
+                        num_bi_layers=nbi, use_residual=res)
+    mem = cap.encode(torch.from_numpy(src).cuda(), torch.from_numpy(svl).cuda()).cpu().numpy()
+    logits = cap.decode_seq(torch.from_numpy(tgt).cuda()).cpu().numpy()
+    rmem, rstates = gn.encoder(src, svl, p, cell, H, num_layers=nl, num_bi_layers=nbi, use_residual=res)
+    rl = gn.decode_seq(gn.Decoder(p, H, num_layers=nl, cell=cell, use_residual=res), rmem, rstates, svl, tgt)
+    assert np.abs(mem - rmem).max() < 1e-4
+    err = float(np.abs(logits - rl).max())
+    report[f"gnmt_tf_nl{nl}_nbi{nbi}_res{int(res)}_{cell}_logits_maxabs_err"] = err
+    assert err < 1e-4, err
+    with pytest.raises(RuntimeError):       # every layer bidirectional: the memory would be 2H wide (tn_gnmt_create_ex)
+        GNMTCaptioner(W.make_gnmt_weights(1, cell, F, H, E, V, num_layers=2, num_bi_layers=2), F, H, E, V, num_layers=2, num_bi_layers=2)
 
 
 def test_captioning_evaluate_driver():
