@@ -158,7 +158,7 @@ def run(argv):
                 for _ in range(2)] if world > 1 else None
     # the exchange step goes through the library's own RCCL communicator (tn_allgather_features); torch.distributed only
     # carries the barrier and the max over ranks of the timing
-    comm = sharding.feature_comm(dev) if world > 1 else None
+    comm = sharding.feature_comm(dev) if world > 1 else None      # (comm.bring_up: agreed fall-back to torch's RCCL communicator)
     gather_h = [None, None]
 
     def allgather(j):
@@ -298,6 +298,7 @@ def run(argv):
                           "weights": ("seeded random-init, fp32 conv weights as hi + lo fp16 pairs (exact-weights mode, 2x MFMA work "
                                       "in the dense layers / transitions)") if args.exact_weights
                                      else "seeded random-init, conv weights fp16",
+                          "exchange": (comm.transport + f", all-gather of {args.batch} x {enc.feature_dim} fp32 rows per rank and step") if comm is not None else "none (1 rank)",
                           "timing": f"median of {repeats} fenced regions of exactly {args.steps} steps" + (", forwards pipelined (results joined one step behind, all joined before the closing fence)" if pipelined else ""),
                           "region_ms": [round(t * 1e3, 2) for t in times],
                           "frames_per_sec_forwards_joined": (round(world * args.batch * args.steps / dt_joined, 1) if dt_joined else None),

@@ -104,3 +104,80 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+class GroupComm:
+    """The same two collectives through torch.distributed (backend nccl = RCCL): what ``feature_comm`` hands out when the
+    library's own communicator cannot be brought up on EVERY rank of a multi-rank job (agreed by an all-reduce, so no rank
+    is left waiting inside a collective the others never enter).  It is the same RCCL library and the same collectives, only
+    issued through torch's communicator; the reason is printed once, by rank 0, and ``bench.py`` names the transport it
+    used in ``config.exchange``."""
+    transport = "torch.distributed (RCCL)"
+
+    class _Work:
+        def __init__(self, work):
+            self._work = work
+
+        def wait(self):
+            self._work.wait()
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self._dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def allgather_features(self, shard: torch.Tensor, out: torch.Tensor):
+        return self._Work(self._dist.all_gather_into_tensor(out, shard, group=self.group, async_op=True))
+
+    def allreduce_(self, buf: torch.Tensor, average: bool = False):
+        w = self._dist.all_reduce(buf, op=self._dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if average:
+            w.wait()
+            buf /= self.world
+        return self._Work(w)
+
+    def close(self):
+        pass
+
+
+Comm.transport = "tn_allgather_features (librccl behind the C ABI)"
+
+
+def bring_up(group=None, device: int | None = None):
+    """``Comm.from_process_group`` with a handshake: every rank reports whether its communicator came up AND a probe
+    all-gather returned every rank's number; only if all did is the library communicator used, otherwise all ranks fall
+    back to ``GroupComm`` together."""
+    import sys
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    comm, err = None, ""
+    try:
+        comm = Comm.from_process_group(group, device)
+    except Exception as e:          # dlopen of librccl, ncclCommInitRank ...
+        err = repr(e)
+    if not multi:
+        if comm is None:
+            raise RuntimeError(err)
+        return comm
+    dev = torch.device("cuda", _lib.default_device() if device is None else int(device))
+    ok = comm is not None
+    if ok:
+        try:
+            mine = torch.full((1, 4), float(comm.rank), dtype=torch.float32, device=dev)
+            allr = torch.full((comm.world, 4), -1.0, dtype=torch.float32, device=dev)
+            comm.allgather_features(mine, allr).wait()
+            torch.cuda.synchronize(dev)
+            ok = bool(torch.equal(allr[:, 0].cpu(), torch.arange(comm.world, dtype=torch.float32)))
+            err = err or ("" if ok else "probe all-gather returned wrong rows")
+        except Exception as e:
+            ok, err = False, repr(e)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 1:
+        return comm
+    if comm is not None:
+        comm.close()
+    if dist.get_rank(group) == 0 or err:
+        print(f"tennis_amd.comm: library communicator not usable on every rank ({err or 'another rank failed'}); "
+              "the exchange step goes through torch.distributed's RCCL communicator instead", file=sys.stderr, flush=True)
+    return GroupComm(group)

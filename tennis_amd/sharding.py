@@ -133,8 +133,8 @@ def feature_comm(device, group=None):
     process runs on a GPU, else None (the CPU tests exchange through torch.distributed / gloo)."""
     if torch.device(device).type != "cuda":
         return None
-    from .comm import Comm
-    return Comm.from_process_group(group, torch.device(device).index)
+    from .comm import bring_up
+    return bring_up(group, torch.device(device).index)
 
 
 def extract_features_sharded(encode_batch, n_frames: int, batch: int, feature_dim: int, device, rank=None,
