@@ -131,6 +131,16 @@ using ic = std::integral_constant<int, V>;
 
 #define TN_SB() __builtin_amdgcn_sched_barrier(0)
 
+// One LDS-DMA piece: 64 lanes x 16 B, global (per-lane address) -> LDS (wave-uniform base in M0 + lane * 16).  Inline asm:
+// hipcc treats the builtin as an LDS store and orders every later ds_read behind a vmcnt(0) (dense_layer_big.hip).
+__device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
 // ---- the static schedule ----
 struct PItem { int kind, q, j; };     // kind: 0 none, 1 C(q), 2 BN(q).j, 3 LD(u = q).i = j
 template <int KS>
@@ -217,20 +227,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 
   // ---- prologue: the layer's weights and tables -> LDS (once per launch) ----
+  // LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no registers): every piece of the 72 + 4 (KQ + 1) KiB is in
+  // flight at once and ONE wait follows.  Through registers (load, ds_write, 4 - 6 pieces per round trip) the copy took
+  // 9 800 cycles at K = 320 - 13 % of a 28x28 launch, whose waves only have eight rows each to amortise it over.
   {
-    const uint4 *g3 = (const uint4 *)a.w3s;
-    uint4 *l3 = (uint4 *)smem;
-#pragma unroll 6
-    for (int i = tid; i < kW3Bytes / 16; i += 256) l3[i] = g3[i];
-    const uint4 *g1 = (const uint4 *)a.w1s;
-    uint4 *l1 = (uint4 *)(smem + G::W1OFF);
-#pragma unroll 4
-    for (int i = tid; i < (KQ + 1) * 256; i += 256) l1[i] = g1[i];
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)smem);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
+    constexpr int P3 = kW3Bytes / 1024, P1 = (KQ + 1) * 4;
+    const unsigned char *g3 = (const unsigned char *)a.w3s + ln * 16, *g1 = (const unsigned char *)a.w1s + ln * 16;
+    for (int p = wv; p < P3; p += 4) dma16(g3 + p * 1024, lds0 + p * 1024);
+    for (int p = wv; p < P1; p += 4) dma16(g1 + p * 1024, lds0 + G::W1OFF + p * 1024);
     float *t1 = (float *)(smem + G::T1OFF);
     for (int i = tid; i < K; i += 256) {
       t1[i] = a.s1[i];
       t1[K + i] = a.t1[i];
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
 
