@@ -328,7 +328,7 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
   if (e->Wb[0] > 240) { tn_set_error("input too wide for the conv3x3 LDS tile"); return fail(TN_ERR_INVALID); }
   if (e->exact) {      // the hi + lo weight passes exist in the 8-wave fused layer and the transition kernel only
     bool ok = e->fuse && (e->dl_variant & ~256) == 0;
-    for (int b = 0; b < 4; ++b) ok = ok && dense_layer_big_supported(e->Hb[b], e->Wb[b]);
+    for (int b = 0; b < 4; ++b) ok = ok && dense_layer_big_supported(e->Hb[b], e->Wb[b]) && e->Cb[b] - 32 <= dense_layer_kmax(e->Wb[b]);
     if (!ok) { tn_set_error("TN_ENC_EXACT_WEIGHTS needs the fused 224x224 path (56/28/14/7 blocks, default kernels)"); return fail(TN_ERR_INVALID); }
   }
 
@@ -483,7 +483,8 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
       rc = launch_dense_block7(a7, s);
       tm.end();
       if (rc) return rc;
-    } else if (fused && e->chain && (e->dl_variant & ~(32 | 64 | 128 | 256 | 512)) == 0 && Hh == Ww && (Hh == 14 || Hh == 7)) {
+    } else if (fused && e->chain && (e->dl_variant & ~(32 | 64 | 128 | 256 | 512)) == 0 && Hh == Ww && (Hh == 14 || Hh == 7) &&
+               e->layers[b].back().cin <= dense_layer_kmax(Ww)) {
       // one workgroup per frame walks the whole block: no launch gaps, no cold prologue per layer
       auto &L0 = e->layers[b][0];
       const int nl = (int)e->layers[b].size();
@@ -510,7 +511,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
         if (rc) return rc;
         continue;
       }
-      if (fused) {
+      if (fused && L.cin <= dense_layer_kmax(Ww)) {
         DenseLayerArgs af{bbuf[b], e->Cb[b], L.cin, L.s1, L.t1, L.w1, L.s2, L.t2, L.w3p, B, Hh, Ww, nullptr, e->dl_variant};
         af.exact = e->exact;
         const std::string fam = "dense_layer_fused_" + std::to_string(Hh) + "x" + std::to_string(Ww);

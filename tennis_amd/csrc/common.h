@@ -183,6 +183,7 @@ struct DenseLayerArgs {
   int exact = 0;                         // weights as hi + lo fp16 pairs: w1 [128][2 Kp] = [hi | lo], w3p = hi image then lo image
 };
 bool dense_layer_supported(int H, int W);
+int dense_layer_kmax(int W);       // most input channels a fused layer of that (supported) map width takes
 int launch_dense_layer(const DenseLayerArgs &a, hipStream_t s);
 
 // The strip-streaming fused dense layer (dense_strip.hip): one workgroup per frame, weights resident in LDS.

@@ -5,9 +5,11 @@
 #include "common.h"
 
 bool dense_layer_big_supported(int H, int W);
+int dense_layer_big_kmax(int W);
 int launch_dense_layer_big(const DenseLayerArgs &a, hipStream_t s);
 
 bool dense_layer_supported(int H, int W) { return dense_layer_big_supported(H, W); }
+int dense_layer_kmax(int W) { return dense_layer_big_kmax(W); }
 
 int launch_dense_layer(const DenseLayerArgs &a, hipStream_t s) {
   TN_REQUIRE(dense_layer_big_supported(a.H, a.W), "dense_layer: unsupported spatial size");

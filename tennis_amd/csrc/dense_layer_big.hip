@@ -816,6 +816,9 @@ int launch_geom(const DenseLayerArgs &a, hipStream_t s) {
 }  // namespace
 
 bool dense_layer_big_supported(int H, int W) { return (H == 56 && W == 56) || (H == 28 && W == 28) || (H == 14 && W == 14) || (H == 7 && W == 7); }
+// input channels a layer of that map size may have (the BatchNorm tables' share of LDS, DLGeom::KMAX): an input size other
+// than 224 can put a 56x56 map into the second block (448: K up to 480), where the tile kernel has no room for it
+int dense_layer_big_kmax(int W) { return W == 56 ? 256 : W == 28 ? 512 : 1024; }
 
 int launch_dense_layer_big(const DenseLayerArgs &a, hipStream_t s) {
   const int klast = a.K + 32 * (a.nchain > 0 ? a.nchain - 1 : 0);

@@ -196,6 +196,31 @@ def test_encoder_512_features_4096(report):
     assert err < TOL
 
 
+def test_encoder_448_mixed_kernels(report):
+    """448 x 448 input: the maps are 112 / 56 / 28 / 14 pixels, i.e. the sizes the fused kernels tile - one block later than
+    at 224, with that block's (larger) channel counts.  Every layer must pick a kernel that takes its K: strip kernel up to
+    K = 320 in the 56 / 28 blocks, tile kernel up to its table space (256 / 512 / 1024), layer-wise kernels for the rest and
+    for the 112-pixel block; checked against the torch-CPU fp32 restatement.  (Round 3 fix: the fused tile kernel used to be
+    chosen by map size alone and refused K = 288 at 56 x 56.)"""
+    from oracle.torch_ref import TorchDenseNet121
+    from tennis_amd import weights as W
+    from tennis_amd.engine import DenseNet121Features
+    p = W.make_densenet121_weights(0)
+    x16 = W.normalize_to_nchw_f32(W.synthetic_frames_u8(2, 448)).astype(np.float16)
+    with torch.no_grad():
+        ref = TorchDenseNet121(p)(torch.from_numpy(x16.astype(np.float32))).numpy()
+    xd = torch.from_numpy(x16.astype(np.float32)).cuda()
+    got = DenseNet121Features(p, 448, max_batch=2)(xd).cpu().numpy()
+    assert got.shape == ref.shape == (2, 4096)
+    err = float(np.abs(got - ref).max())
+    report["features_448_maxabs_err"] = err
+    assert err < TOL
+    big = DenseNet121Features(p, 448, max_batch=66)(xd[torch.arange(66, device="cuda") % 2]).cpu().numpy()   # strip kernels (batch >= 64)
+    err = float(np.abs(big[:2] - ref).max())
+    report["features_448_strip_maxabs_err"] = err
+    assert err < TOL and np.array_equal(big[64:], big[:2])
+
+
 @pytest.mark.parametrize("size", [226, 232, 236])
 def test_stem_and_encoder_at_odd_input_sizes(size, report):
     """Input sizes off the 224 grid: 232 has partial tiles in both directions (58 x 58 pooled pixels), 236 is not a
