@@ -231,7 +231,7 @@ def run(argv):
     # for the record: the rate of the configuration that meets "1e-3 of the reference" against UN-rounded fp32
     # parameters - the exact-weights mode (hi + lo fp16 weight pairs: twice the MFMA work of the dense layers and transitions)
     # - on the same box: one more fenced region of exactly K steps with a second encoder
-    fps_exact = None
+    fps_exact = fps_calibrated = None
     if not args.exact_weights and not args.single_region and not args.no_exact_line:
         params_x = W.make_densenet121_weights(0, fp16_model=False)
         enc_f16 = enc
@@ -241,6 +241,19 @@ def run(argv):
             step(i)
         drain(min(args.warmup, 5))
         fps_exact = world * args.batch * args.steps / timed_region(args.steps)
+        enc.set_pipelined(False)
+        # ... and of the CALIBRATED conversion of the same fp32 parameters (tennis_amd.calibrate: one fp16 number per weight,
+        # rounded with error feedback against the mean activations of eight calibration frames; the same bar, the default kernels)
+        from tennis_amd.calibrate import calibrated_fp16_model
+        g = torch.Generator(device=dev); g.manual_seed(4321 + rank)
+        calib = torch.randint(0, 256, (8, SIZE, SIZE, 3), dtype=torch.uint8, device=dev, generator=g)
+        enc = None
+        enc = DenseNet121Features(calibrated_fp16_model(params_x, calib, SIZE, ctx=ctx), SIZE, max_batch=args.batch, ctx=ctx)
+        enc.set_pipelined(pipelined)
+        for i in range(min(args.warmup, 5)):
+            step(i)
+        drain(min(args.warmup, 5))
+        fps_calibrated = world * args.batch * args.steps / timed_region(args.steps)
         enc.set_pipelined(False)
         enc = enc_f16
         del params_x
@@ -302,6 +315,10 @@ def run(argv):
                           "timing": f"median of {repeats} fenced regions of exactly {args.steps} steps" + (", forwards pipelined (results joined one step behind, all joined before the closing fence)" if pipelined else ""),
                           "region_ms": [round(t * 1e3, 2) for t in times],
                           "frames_per_sec_forwards_joined": (round(world * args.batch * args.steps / dt_joined, 1) if dt_joined else None),
+                          "fp32_weights_calibrated_frames_per_sec": (round(fps_calibrated, 1) if fps_calibrated else None),
+                          "fp32_weights_calibrated_note": "un-rounded fp32 conv weights converted to ONE fp16 number each by calibrated "
+                                                          "error-feedback rounding (tennis_amd/calibrate.py; features within 1e-3 of the fp32 oracle on "
+                                                          "fp32 weights: tests/test_gpu_encoder.py::test_fp32_weights_calibrated_rounding); the default kernels",
                           "exact_weights_frames_per_sec": (round(fps_exact, 1) if fps_exact else None),
                           "exact_weights_note": "un-rounded fp32 conv weights as hi + lo fp16 pairs (features within 1e-3 of the fp32 oracle on fp32 "
                                                 "weights: tests/test_gpu_encoder.py::test_fp32_weights_exact_mode); 2x the MFMA work of the dense layers"},

@@ -119,6 +119,12 @@ int tn_densenet121_profile(tn_encoder *enc, const void *x, tn_layout layout, int
 /* Test hook: copy an internal NHWC fp16 activation of the LAST forward to a host
  * fp32 buffer.  tap in {"stem","pool0","stage1".."stage4","trans1".."trans3",
  * "stage<k>_l0_bottleneck"}; returns the element count through *numel. */
+/* Calibration statistics for the calibrated fp16 conversion (tennis_amd/weights.py::as_fp16_model(input_means=...)):
+ * `batch` frames go through the layer-wise kernels, and for each of the 119 convolutions behind the stem, in execution order
+ * (per dense layer the 1x1's K input channels, then the 3x3's 128; a transition's inputs after its block), the mean over all
+ * pixels of the activation that convolution reads is written to means_host (fp32, *numel values). */
+int tn_densenet121_input_means(tn_encoder *enc, const void *x, tn_layout layout, int batch, float *means_host,
+                               int64_t capacity, int64_t *numel);
 int tn_densenet121_read_tap(tn_encoder *enc, const char *tap, int batch, float *out_host,
                             size_t capacity, size_t *numel);
 int tn_densenet121_destroy(tn_encoder *enc);

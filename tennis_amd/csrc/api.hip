@@ -265,6 +265,9 @@ struct tn_encoder {
   bool strip = true;          // 56x56 / 28x28 layers with K <= 320 run on the strip-streaming kernel (TN_NO_STRIP disables)
   int strip_min_batch = 64;   // ... from this many frames per launch on (one workgroup per frame: small batches leave CUs idle)
   DenseLayerDev *chain_dev[4] = {nullptr, nullptr, nullptr, nullptr};
+  float *calib_dev = nullptr;   // tn_densenet121_input_means: where the layer-wise pass leaves the mean of every convolution's input
+  double *calib_scratch = nullptr;
+  float *ones128 = nullptr;
   bool block7 = true;         // a 7x7 block runs on the LDS-resident kernel of dense_block7.hip (TN_NO_BLOCK7 disables)
   DenseBlock7Args b7[4] = {};  // its packed operands per block (buf == nullptr: not packed)
   hipStream_t side[4];
@@ -342,6 +345,7 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
     e->stem_shift = e->pool.upload(t);
   }
   e->zeros128 = e->pool.upload(std::vector<float>(128, 0.0f));
+  e->ones128 = e->pool.upload(std::vector<float>(128, 1.0f));
   int outer = 1;
   for (int b = 0; b < 4; ++b) {
     const std::string sp = pre + "stage" + std::to_string(b + 1) + "_";
@@ -466,11 +470,20 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
       if (rc) return rc;
     }
   }
+  // calibration pass (tn_densenet121_input_means): layer-wise kernels only, and behind every BatchNorm + ReLU that feeds a
+  // convolution the per-channel mean of that input, in execution order
+  const bool cal = e->calib_dev != nullptr;
+  float *cal_out = e->calib_dev;
+  auto cal_mean = [&](const f16 *xin, int ld, int K, const float *sc, const float *sh, long rows) {
+    const int rc2 = launch_channel_mean(xin, ld, K, sc, sh, rows, e->calib_scratch, cal_out, s);
+    cal_out += K;
+    return rc2;
+  };
   for (int b = 0; b < 4; ++b) {
     const int Hh = e->Hb[b], Ww = e->Wb[b];
     const int M = B * Hh * Ww;
-    const bool fused = e->fuse && dense_layer_supported(Hh, Ww);
-    if (e->b7[b].wa && e->dl_variant == 0) {
+    const bool fused = !cal && e->fuse && dense_layer_supported(Hh, Ww);
+    if (!cal && e->b7[b].wa && e->dl_variant == 0) {
       // the frame's concat buffer stays in LDS for the whole block; only the weights stream (dense_block7.hip)
       DenseBlock7Args a7 = e->b7[b];
       a7.buf = bbuf[b]; a7.B = B;
@@ -523,12 +536,14 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
         continue;
       }
       // un-fused: BN2 (scale folded into the weights) adds its shift in the 1x1's epilogue, the 3x3 only applies the ReLU
+      if (cal && (rc = cal_mean(bbuf[b], e->Cb[b], L.cin, L.s1, L.t1, M))) return rc;
       Conv1x1Args a1{bbuf[b], e->Cb[b], L.cin, L.s1, L.t1, L.w1, 128, bott, 128, 0, M, 0, Hh, Ww};
       a1.bias = L.t2;
       tm.begin("conv1x1_bnrelu", 2.0 * M * 128.0 * L.cin, (double)M * (L.cin + 128) * 2 + 128.0 * L.cin * 2);
       rc = launch_conv1x1(a1, s);
       tm.end();
       if (rc) return rc;
+      if (cal && (rc = cal_mean(bott, 128, 128, e->ones128, e->zeros128, M))) return rc;
       Conv3x3Args a3{bott, L.s2, e->zeros128, L.w3p, bbuf[b], e->Cb[b], L.cin, M, Hh, Ww};
       tm.begin("conv3x3_bnrelu", 2.0 * M * 32.0 * 1152, (double)M * (128 + 32) * 2 + 32.0 * 1152 * 2);
       rc = launch_conv3x3(a3, s);
@@ -538,6 +553,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
     if (b < 3) {
       auto &T = e->trans[b];
       const int Mo = B * e->Hb[b + 1] * e->Wb[b + 1];
+      if (cal && (rc = cal_mean(bbuf[b], e->Cb[b], T.cin, T.s, T.t, M))) return rc;
       Conv1x1Args at{bbuf[b], e->Cb[b], T.cin, T.s, T.t, T.w, T.cout, bbuf[b + 1], e->Cb[b + 1], 0, Mo, 1, Hh, Ww};
       at.exact = e->exact;
       tm.begin("transition_conv1x1_avgpool", 2.0 * M * (double)T.cout * T.cin,
@@ -644,6 +660,44 @@ extern "C" int tn_densenet121_profile(tn_encoder *enc, const void *x, tn_layout 
   for (int i = 0; i < n; ++i) stats[i] = tm.fams[i];
   *n_stats = n;
   return TN_OK;
+}
+
+// Calibration statistics for weights.as_fp16_model(input_means=...): runs `batch` frames through the LAYER-WISE kernels and
+// returns, for the 119 convolutions behind the stem in execution order (per dense layer: the 1x1's K inputs, then the 3x3's
+// 128; a transition's inputs behind its block), the per-input-channel mean of the activation the convolution reads.
+extern "C" int tn_densenet121_input_means(tn_encoder *e, const void *x, tn_layout layout, int batch, float *means_host,
+                                          int64_t capacity, int64_t *numel) {
+  TN_REQUIRE(e && x && means_host && numel, "tn_densenet121_input_means: null argument");
+  TN_REQUIRE(batch > 0 && batch <= e->maxB, "tn_densenet121_input_means: batch exceeds max_batch");
+  TN_REQUIRE(!e->exact, "tn_densenet121_input_means: not for an exact-weights encoder");
+  TN_ON_DEVICE(e->ctx->device);
+  int64_t n = 0;
+  for (int b = 0; b < 4; ++b) {
+    for (auto &L : e->layers[b]) n += L.cin + 128;
+    if (b < 3) n += e->trans[b].cin;
+  }
+  *numel = n;
+  TN_REQUIRE(capacity >= n, "tn_densenet121_input_means: host buffer too small");
+  if (int rc = encoder_join(e, 0)) return rc;
+  hipStream_t s = e->ctx->stream;
+  float *dev = nullptr, *feat = nullptr;
+  double *scratch = nullptr;
+  auto release = [&]() { (void)hipFree(dev); (void)hipFree(feat); (void)hipFree(scratch); e->calib_dev = nullptr; e->calib_scratch = nullptr; };
+  if (hipMalloc((void **)&dev, sizeof(float) * n) != hipSuccess || hipMalloc((void **)&feat, sizeof(float) * (size_t)batch * e->feat_dim) != hipSuccess ||
+      hipMalloc((void **)&scratch, sizeof(double) * 32 * 1024) != hipSuccess) {
+    release();
+    tn_set_error("tn_densenet121_input_means: device allocation failed");
+    return TN_ERR_NOMEM;
+  }
+  e->calib_dev = dev; e->calib_scratch = scratch;
+  EventTimer tm;
+  int rc = encoder_run_range(e, x, layout, 0, batch, feat, s, tm);
+  if (!rc && hipMemcpyAsync(means_host, dev, sizeof(float) * n, hipMemcpyDeviceToHost, s) != hipSuccess) rc = TN_ERR_HIP;
+  if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = TN_ERR_HIP;
+  release();
+  if (rc == TN_ERR_HIP) tn_set_error("tn_densenet121_input_means: HIP error");
+  e->last_batch = batch;
+  return rc;
 }
 
 extern "C" int tn_densenet121_read_tap(tn_encoder *e, const char *tap_c, int batch, float *out_host, size_t capacity,

@@ -236,5 +236,7 @@ int launch_stem(const StemArgs &a, hipStream_t s);
 int launch_stem_pool(const StemArgs &a, f16 *out, int ldy, int Hp, int Wp, hipStream_t s);
 
 int launch_maxpool3x3s2(const f16 *x, int B, int H, int W, int C, f16 *y, int ldy, int Ho, int Wo, hipStream_t s);
+int launch_channel_mean(const f16 *x, int ld, int K, const float *scale, const float *shift, long rows, double *scratch /* 32 * K doubles */,
+                        float *out, hipStream_t s);
 int launch_head(const f16 *x, int B, int H, int W, int C, const float *scale, const float *shift,
                 float *feat, int PH, int PW, hipStream_t s);

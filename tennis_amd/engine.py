@@ -92,6 +92,26 @@ class DenseNet121Features:
         return [dict(name=stats[i].name.decode(), launches=stats[i].launches, ms=stats[i].ms,
                      flops=stats[i].flops, bytes=stats[i].bytes) for i in range(n.value)], out
 
+    def input_means(self, x: torch.Tensor, prefix: str = "densenet0_") -> dict:
+        """Calibration statistics (``tn_densenet121_input_means``): ``{conv weight name: mean of every input channel of that
+        convolution}`` over the frames ``x``, for the 119 convolutions behind the stem - what
+        ``weights.as_fp16_model(params, input_means=...)`` needs."""
+        from . import weights as W
+        x = x.contiguous()
+        layout = _layout_of(x, self.size)
+        convs, _, _ = W.densenet121_layout()
+        convs = [c for c in convs if c["kind"] != "stem"]
+        buf = np.empty(sum(c["cin"] for c in convs), dtype=np.float32)
+        n = C.c_int64(0)
+        check(self.lib.tn_densenet121_input_means(self.handle, ptr(x), layout, x.shape[0], buf.ctypes.data_as(C.c_void_p), buf.size,
+                                                  C.byref(n)), "tn_densenet121_input_means")
+        assert n.value == buf.size
+        out, o = {}, 0
+        for c in convs:
+            out[prefix + c["name"] + "_weight"] = buf[o:o + c["cin"]].copy()
+            o += c["cin"]
+        return out
+
     def read_tap(self, tap: str, batch: int) -> np.ndarray:
         buf = np.empty(self._tap_numel(batch), dtype=np.float32)
         n = C.c_size_t(0)

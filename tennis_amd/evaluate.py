@@ -205,6 +205,10 @@ def best_or_newest_params(mod_path, need_scores):
 def build_parser():
     p = argparse.ArgumentParser(description="tennis_amd evaluate (flags of reference evaluate.py:30-75)")
     p.add_argument("--backbone", default="DenseNet121")
+    p.add_argument("--fp16_conversion", default="nearest", choices=["nearest", "calibrated", "exact"],
+                   help="how the checkpoint's fp32 conv weights become the fp16 model (not a reference flag): plain rounding, "
+                        "rounding calibrated on the first frames processed (features within 1e-3 of the fp32 evaluation at full "
+                        "speed), or hi + lo weight pairs (the same bar at twice the MFMAs)")
     p.add_argument("--model_id", default="0000")
     p.add_argument("--split_id", default="02")
     p.add_argument("--split", default="test")
@@ -255,7 +259,7 @@ def main(argv=None):
 def _main_rank(flags, rank, world, dev):
     every = [int(s) for s in flags.every.split(",")]
     if flags.corpus_frames > 0:                                             # BASELINE config C4
-        backbone = get_model(flags.backbone, pretrained=True, max_batch=flags.batch_size).features
+        backbone = get_model(flags.backbone, pretrained=True, max_batch=flags.batch_size, conversion=flags.fp16_conversion).features
         full, st = extract_corpus(backbone, flags.corpus_frames, flags.batch_size, flags.data_shape, dev, rank, world,
                                   block=flags.gather_block, reuse_frames=flags.corpus_reuse_frames)
         if rank == 0:
@@ -283,10 +287,10 @@ def _main_rank(flags, rank, world, dev):
 
     model = None
     if flags.feats_model is None:                                           # evaluate.py:118-135
-        backbone_net = get_model(flags.backbone, pretrained=True).features
+        backbone_net = get_model(flags.backbone, pretrained=True, conversion=flags.fp16_conversion).features
         model = FrameModel(backbone_net, len(test_set.classes))
     elif flags.temp_pool in ["max", "mean"]:                                # evaluate.py:136-138
-        backbone_net = get_model(flags.backbone, pretrained=True).features
+        backbone_net = get_model(flags.backbone, pretrained=True, conversion=flags.fp16_conversion).features
         model = FrameModel(backbone_net, len(test_set.classes))
     if flags.window > 1:                                                    # evaluate.py:139-162
         if flags.temp_pool in ["gru", "lstm"]:

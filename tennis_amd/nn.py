@@ -86,11 +86,19 @@ class LSTM(_RNNLayer):
 class DenseNet121Backbone(Block):
     """``get_model('DenseNet121', ...).features`` (reference evaluate.py:125): frames -> (B, F) fp32."""
 
-    def __init__(self, seed=0, prefix="densenet0_", max_batch=256, exact_weights=False, **kwargs):
-        """``exact_weights=True``: adopted conv weights stay fp32 and the library evaluates them as hi + lo fp16 pairs
-        (engine.DenseNet121Features(exact_weights=True)); default: the fp16 model (weights rounded once on adoption)."""
+    def __init__(self, seed=0, prefix="densenet0_", max_batch=256, exact_weights=False, conversion="nearest", **kwargs):
+        """How adopted fp32 conv weights become the fp16 model the kernels evaluate:
+        ``conversion="nearest"`` (default): rounded once to the nearest fp16 on adoption;
+        ``conversion="calibrated"``: kept in fp32 until ``calibrate(frames)`` - or the first forward, which calibrates on its
+        first eight frames - and then rounded with error feedback against the measured mean activations
+        (tennis_amd.calibrate): one fp16 number per weight, full speed, features within 1e-3 of the fp32 evaluation;
+        ``exact_weights=True`` / ``conversion="exact"``: conv weights stay fp32 and the library evaluates them as hi + lo
+        fp16 pairs (engine.DenseNet121Features(exact_weights=True)) at twice the MFMAs."""
         super().__init__(prefix=prefix, **kwargs)
-        self._seed, self._max_batch, self._exact = seed, max_batch, bool(exact_weights)
+        if conversion not in ("nearest", "calibrated", "exact"):
+            raise ValueError(f"conversion must be 'nearest', 'calibrated' or 'exact', got {conversion!r}")
+        self._seed, self._max_batch, self._exact = seed, max_batch, bool(exact_weights) or conversion == "exact"
+        self._calibrated_mode, self._converted = conversion == "calibrated" and not self._exact, None
         convs, final_bn, cfin = W.densenet121_layout()
         names = []
         for cv in convs:
@@ -104,7 +112,7 @@ class DenseNet121Backbone(Block):
     def initialize(self, *a, **k):
         super().initialize(*a, **k)
         if next(iter(self._own_params.values())).data is None:
-            self._adopt(W.make_densenet121_weights(self._seed, self.prefix, fp16_model=not self._exact))
+            self._adopt(W.make_densenet121_weights(self._seed, self.prefix, fp16_model=not (self._exact or self._calibrated_mode)))
 
     def _structural_params(self, path: str = "") -> dict:
         """Structural names of gluon ``model_zoo.vision.densenet121().features`` [EXT]: a HybridSequential of
@@ -141,7 +149,19 @@ class DenseNet121Backbone(Block):
 
     def _adopt(self, params):
         own = {k: v for k, v in params.items() if k in self._own_params}
-        super()._adopt(own if self._exact else W.as_fp16_model(own))
+        keep_fp32 = self._exact or self._calibrated_mode
+        super()._adopt(own if keep_fp32 else W.as_fp16_model(own))
+        self._converted = None
+
+    def calibrate(self, frames):
+        """``conversion="calibrated"``: measure the mean activation of every convolution input on ``frames`` (any layout the
+        encoder takes; a few frames of the material to be processed) and convert the fp32 weights against them."""
+        from .calibrate import calibrated_fp16_model
+        frames = _to_device(frames)
+        size = tuple(frames.shape[2:]) if frames.shape[1] == 3 and frames.dtype == torch.float32 else tuple(frames.shape[1:3])
+        self._engine = None
+        p = {k: v.data for k, v in self._own_params.items()}
+        self._converted = calibrated_fp16_model(p, frames, size, prefix=self.prefix)
 
     def forward(self, x):
         x = _to_device(x)
@@ -153,7 +173,9 @@ class DenseNet121Backbone(Block):
         b = x.shape[0]
         if self._engine is None or self._size != size or self._engine.max_batch < b:
             self._engine = None  # release the old workspace first
-            p = {k: v.data for k, v in self._own_params.items()}
+            if self._calibrated_mode and self._converted is None:
+                self.calibrate(x[:8])
+            p = self._converted if self._calibrated_mode else {k: v.data for k, v in self._own_params.items()}
             self._engine = engine.DenseNet121Features(p, size, max_batch=max(b, min(self._max_batch, 64)),
                                                       prefix=self.prefix, exact_weights=self._exact)
             self._size = size

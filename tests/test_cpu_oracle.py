@@ -369,6 +369,41 @@ def test_bleu_pinned_to_reference_golden():
     assert n == 9
 
 
+def test_error_feedback_rounding_properties():
+    """weights._round_fp16_error_feedback / as_fp16_model(input_means=...): every weight lands on one of its two fp16 neighbours,
+    fp16-representable weights do not move, the mean-weighted row error is far below round-to-nearest's, and - on the oracle,
+    with the means measured on OTHER frames - the conversion error of a conv + ReLU + average-pool stack drops accordingly."""
+    from tennis_amd import weights as W
+    rng = np.random.default_rng(0)
+    w = rng.normal(0, 0.05, (32, 600)).astype(np.float64)
+    m = np.abs(rng.normal(0.4, 0.2, 600))
+    r = W._round_fp16_error_feedback(w, m)
+    lo = w.astype(np.float16)
+    up = np.nextafter(lo, np.where(w > lo.astype(np.float64), np.float16(np.inf), np.float16(-np.inf)).astype(np.float16))
+    assert np.all((r == lo.astype(np.float64)) | (r == up.astype(np.float64)))
+    assert np.array_equal(r.astype(np.float16).astype(np.float64), r)
+    e_rtn = np.abs(((lo.astype(np.float64) - w) * m).sum(1)); e_ef = np.abs(((r - w) * m).sum(1))
+    assert e_ef.mean() < 0.1 * e_rtn.mean() and e_ef.max() < 0.5 * e_rtn.mean(), (e_ef.mean(), e_ef.max(), e_rtn.mean())
+    w16 = lo.astype(np.float64)
+    assert np.array_equal(W._round_fp16_error_feedback(w16, m), w16)
+    # end to end on a toy layer: positive activations, pooled output
+    a_cal = np.maximum(rng.normal(0.3, 1.0, (4000, 600)), 0) * m[None, :]
+    a_tst = np.maximum(rng.normal(0.3, 1.0, (4000, 600)), 0) * m[None, :]
+    r2 = W._round_fp16_error_feedback(w, a_cal.mean(0))
+    pool = lambda ww: (a_tst @ ww.T).mean(0)
+    err_rtn, err_ef = np.abs(pool(lo.astype(np.float64)) - pool(w)).max(), np.abs(pool(r2) - pool(w)).max()
+    assert err_ef < 0.2 * err_rtn, (err_ef, err_rtn)
+    # through as_fp16_model: only convs named in input_means change, with the BN2 fold applied before the rounding
+    p = W.make_densenet121_weights(3, fp16_model=False)
+    name = "densenet0_stage1_conv0_weight"
+    q = W.as_fp16_model(p, input_means={name: np.full(p[name].shape[1], 0.5)})
+    plain = W.as_fp16_model(p)
+    assert all(np.array_equal(q[k], plain[k]) for k in p if k != name) and (q[name] != plain[name]).any()
+    s2 = p["densenet0_stage1_batchnorm1_gamma"] / np.sqrt(p["densenet0_stage1_batchnorm1_running_var"] + np.float32(W.BN_EPS))
+    folded = (q[name] * s2.reshape(-1, 1, 1, 1)).astype(np.float32)
+    assert np.abs(folded - folded.astype(np.float16).astype(np.float32)).max() < 1e-6 * np.abs(folded).max() + 1e-9
+
+
 def test_mxnet_params_reader_against_hand_built_file():
     """tests/golden/gluon_tiny.params was written byte by byte from the published NDArray-list layout
     (tests/golden/make_params_fixture.py, no params_io involved): the reader returns its arrays, dtypes and names,

@@ -315,6 +315,43 @@ def test_fp32_weights_exact_mode(report):
     assert torch.equal(enc64(xd[idx].contiguous()), enc4(xd)[idx])
 
 
+def test_fp32_weights_calibrated_rounding(report):
+    """The same bar with ONE fp16 number per weight (tennis_amd.calibrate): eight calibration frames (other frames than the
+    test's) go through the layer-wise kernels for the mean activation of every convolution input, each weight is rounded to
+    the fp16 neighbour that keeps the mean-weighted rounding error of its output row at zero, and the DEFAULT kernels - small
+    batch, and the strip / LDS-resident kernels at 128 frames - evaluate the converted model: features and logits within 1e-3
+    of the fp32 oracle on the UN-rounded fp32 weights, where plain rounding is off by ~3e-3."""
+    from oracle.torch_ref import TorchDenseNet121
+    from tennis_amd import weights as W
+    from tennis_amd.calibrate import calibrated_fp16_model
+    from tennis_amd.engine import Dense, DenseNet121Features
+    p = W.make_densenet121_weights(0, fp16_model=False)
+    p.update(W.make_dense_weights(1, 11, 1024, "framemodel0_dense0_"))
+    x16 = W.normalize_to_nchw_f32(W.synthetic_frames_u8(4, 224)).astype(np.float16)
+    ref = TorchDenseNet121(p)(torch.from_numpy(x16.astype(np.float32))).numpy()          # fp32 graph, fp32 weights
+    ref_logits = dn.dense(ref, p, "framemodel0_dense0_")
+    calib = torch.from_numpy(W.synthetic_frames_u8(8, 224, seed=4321)).cuda()            # NHWC u8, as the frame loader hands them over
+    q = calibrated_fp16_model(p, calib)
+    changed = sum(int((q[k] != W.as_fp16_model(p)[k]).sum()) for k in q if k.endswith("_weight") and q[k].ndim == 4)
+    assert changed > 100000                      # a good part of the 6.9 M roundings went the other way
+    xd = torch.from_numpy(np.ascontiguousarray(x16.transpose(0, 2, 3, 1))).cuda()
+    cls = Dense(p["framemodel0_dense0_weight"], p["framemodel0_dense0_bias"])
+    feat = DenseNet121Features(q, 224, max_batch=4)(xd)
+    e_f, e_l = float(np.abs(feat.cpu().numpy() - ref).max()), float(np.abs(cls(feat).cpu().numpy() - ref_logits).max())
+    big = DenseNet121Features(q, 224, max_batch=128)(xd[torch.arange(128, device="cuda") % 4].contiguous())
+    e_b = float(np.abs(big[:4].cpu().numpy() - ref).max())
+    report["fp32_weights_calibrated_rounding_feature_err"], report["fp32_weights_calibrated_rounding_logits_err"] = e_f, e_l
+    report["fp32_weights_calibrated_rounding_feature_err_b128"] = e_b
+    print("fp32 weights, calibrated rounding: features %.2e (batch 128: %.2e), logits %.2e" % (e_f, e_b, e_l))
+    assert e_f < 1e-3 and e_l < 1e-3 and e_b < 1e-3, (e_f, e_l, e_b)
+    # the same through the model surface: get_model(..., conversion="calibrated") keeps the adopted fp32 weights until calibrate()
+    from tennis_amd.model_zoo import get_model
+    net = get_model("DenseNet121", pretrained=False, conversion="calibrated").features
+    net.set_params({k: v for k, v in p.items() if k.startswith("densenet0_")})
+    net.calibrate(calib)
+    assert torch.equal(net(xd), feat)
+
+
 def test_strip_path_vs_oracle(report):
     """The batch sizes the benchmark runs (>= 64 frames per launch) take the strip kernels in the 56x56 / 28x28 blocks: 128
     frames (two distinct ones, tiled) against the fp32 oracle on the same fp16-model parameters, same 1e-3 bar as the
