@@ -15,3 +15,9 @@ for _ in range(n): enc(x)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 print(f"size {size} batch {B}: {dt*1e3:.2f} ms per batch, {B/dt:.0f} frames/s, {B/dt*(size/224)**2:.0f} 224-equivalent frames/s")
 prof = getattr(enc, "profile", None)
+stats, _ = enc.profile(x)
+stats, _ = enc.profile(x)
+tot = sum(s["ms"] for s in stats)
+for s in stats:
+    print("  %-32s %3d launches %7.3f ms  %5.1f %%  %6.1f TFLOP/s" % (s["name"], s["launches"], s["ms"], 100 * s["ms"] / tot, s["flops"] / max(s["ms"], 1e-9) / 1e9))
+print("  total %.3f ms" % tot)

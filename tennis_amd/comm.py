@@ -143,37 +143,47 @@ class GroupComm:
 Comm.transport = "tn_allgather_features (librccl behind the C ABI)"
 
 
-def bring_up(group=None, device: int | None = None):
+def bring_up(group=None, device=None, _make=None):
     """``Comm.from_process_group`` with a handshake: every rank reports whether its communicator came up AND a probe
     all-gather returned every rank's number; only if all did is the library communicator used, otherwise all ranks fall
-    back to ``GroupComm`` together."""
+    back to ``GroupComm`` together.  (``_make``: the factory, replaced by the gloo test of this handshake.)"""
     import sys
     import torch.distributed as dist
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    index = device.index if isinstance(device, torch.device) else device
+    make = _make or (lambda: Comm.from_process_group(group, index))
     comm, err = None, ""
     try:
-        comm = Comm.from_process_group(group, device)
+        comm = make()
     except Exception as e:          # dlopen of librccl, ncclCommInitRank ...
         err = repr(e)
     if not multi:
         if comm is None:
             raise RuntimeError(err)
         return comm
-    dev = torch.device("cuda", _lib.default_device() if device is None else int(device))
-    ok = comm is not None
+    dev = device if isinstance(device, torch.device) else torch.device("cuda", _lib.default_device() if device is None else int(device))
+
+    def agreed(ok: bool) -> bool:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return int(flag.item()) == 1
+
+    # 1. did every rank get a communicator?  (a rank without one must not leave the others waiting inside the probe)
+    ok = agreed(comm is not None)
+    # 2. does a collective on it deliver every rank's rows?
     if ok:
         try:
             mine = torch.full((1, 4), float(comm.rank), dtype=torch.float32, device=dev)
             allr = torch.full((comm.world, 4), -1.0, dtype=torch.float32, device=dev)
             comm.allgather_features(mine, allr).wait()
-            torch.cuda.synchronize(dev)
-            ok = bool(torch.equal(allr[:, 0].cpu(), torch.arange(comm.world, dtype=torch.float32)))
-            err = err or ("" if ok else "probe all-gather returned wrong rows")
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            good = bool(torch.equal(allr[:, 0].cpu(), torch.arange(comm.world, dtype=torch.float32)))
+            err = err or ("" if good else "probe all-gather returned wrong rows")
         except Exception as e:
-            ok, err = False, repr(e)
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag.item()) == 1:
+            good, err = False, repr(e)
+        ok = agreed(good)
+    if ok:
         return comm
     if comm is not None:
         comm.close()

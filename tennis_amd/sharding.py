@@ -134,7 +134,7 @@ def feature_comm(device, group=None):
     if torch.device(device).type != "cuda":
         return None
     from .comm import bring_up
-    return bring_up(group, torch.device(device).index)
+    return bring_up(group, torch.device(device))
 
 
 def extract_features_sharded(encode_batch, n_frames: int, batch: int, feature_dim: int, device, rank=None,

@@ -33,6 +33,60 @@ def test_sharded_extract_allgather_world2():
             assert np.array_equal(ret[r], want)
 
 
+class _FakeLibComm:
+    """Stands in for tennis_amd.comm.Comm on gloo (the library communicator needs GPUs): same surface, optionally broken."""
+    transport = "fake library communicator"
+
+    def __init__(self, rank, world, wrong_rows=False):
+        self.rank, self.world, self.wrong, self.closed = rank, world, wrong_rows, False
+
+    class _H:
+        def wait(self):
+            pass
+
+    def allgather_features(self, shard, out):
+        dist.all_gather_into_tensor(out, shard)
+        if self.wrong:
+            out[0] = 99.0
+        return self._H()
+
+    def close(self):
+        self.closed = True
+
+
+def _bringup_worker(rank, world, port, mode, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tennis_amd import comm as cm
+
+    def make():
+        if mode == "rank1_raises" and rank == 1:
+            raise RuntimeError("ncclCommInitRank failed (simulated)")
+        return _FakeLibComm(rank, world, wrong_rows=(mode == "rank0_wrong_rows" and rank == 0))
+    c = cm.bring_up(None, torch.device("cpu"), _make=make)
+    # whatever was agreed on must work on every rank
+    mine = torch.full((2, 3), float(rank))
+    allr = torch.empty((2 * world, 3))
+    c.allgather_features(mine, allr).wait()
+    ret[rank] = (type(c).__name__, allr[:, 0].tolist())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_comm_bring_up_handshake_world2():
+    """comm.bring_up: the library communicator is used only if it came up AND passed a probe all-gather on EVERY rank; if one
+    rank fails to create it, or one rank's probe returns wrong rows, all ranks switch to the torch.distributed transport
+    together (no rank is left inside a collective the others never enter)."""
+    for port, mode, want in ((29541, "ok", "_FakeLibComm"), (29542, "rank1_raises", "GroupComm"), (29543, "rank0_wrong_rows", "GroupComm")):
+        with mp.Manager() as mgr:
+            ret = mgr.dict()
+            mp.spawn(_bringup_worker, args=(2, port, mode, ret), nprocs=2, join=True)
+            for r in range(2):
+                assert ret[r][0] == want, (mode, ret[r])
+                assert ret[r][1] == [0.0, 0.0, 1.0, 1.0] or mode == "ok"
+
+
 def test_rank_batches_partition():
     for n, b, w, blk in [(786455, 256, 8, 1), (786455, 256, 8, 4), (37, 8, 2, 1), (37, 8, 2, 3), (5, 8, 4, 2), (256, 256, 1, 1)]:
         seen = []
