@@ -7,7 +7,10 @@ For every dense_strip kernel it checks that
   1. no instruction OUTSIDE an inline-asm region (;;#ASMSTART .. ;;#ASMEND) names an accumulator register >= 160;
   2. nothing was spilled to scratch (.private_segment_fixed_size 0, .vgpr_spill_count 0);
   3. no compiler v_accvgpr_* instruction sits directly in front of an asm MFMA block whose accumulator operands it writes
-     (VALU write -> MFMA operand read needs two wait states, and hipcc pads nothing for an asm consumer).
+     (VALU write -> MFMA operand read needs two wait states, and hipcc pads nothing for an asm consumer);
+  4. no compiler instruction reads an accumulator register that an asm MFMA wrote fewer than 18 wait states earlier (hipcc
+     does not know the latency of an asm MFMA; round 3: v_accvgpr_mov copies at a control-flow join, four instructions
+     behind the last MFMA of the 3x3 phase).
 """
 import re
 import sys
@@ -45,6 +48,7 @@ def main():
         kernels += 1
         in_asm = False
         prev = []          # last compiler instructions (outside asm) with the AGPRs they write
+        fresh = {}         # AGPR -> wait states since an asm MFMA wrote it
         for raw in body.split("\n"):
             if "#ASMSTART" in raw:
                 in_asm = True
@@ -57,6 +61,29 @@ def main():
             line = raw.split(";")[0].strip()
             if not line or line.startswith(".") or line.endswith(":"):
                 continue
+            # ---- check 4: wait states between an asm MFMA's write and a compiler read of the register
+            states = 1
+            mm = re.fullmatch(r"s_nop (\d+)", line)
+            if mm:
+                states = int(mm.group(1)) + 1
+            if in_asm and line.startswith("v_mfma"):
+                dst = agprs(line.split(",")[0])
+                for r in fresh:
+                    fresh[r] += states
+                for r in dst:
+                    fresh[r] = 0
+            else:
+                if not in_asm and not line.startswith(("s_", "v_accvgpr_write")):
+                    ops = line.split(None, 1)[1] if " " in line else ""
+                    srcs = agprs(",".join(ops.split(",")[1:])) if line.startswith(("v_accvgpr_read", "v_accvgpr_mov")) else agprs(ops)
+                    early = [r for r in srcs if r in fresh and fresh[r] < 18]
+                    if early and not line.startswith("v_mfma"):
+                        print("%s: compiler '%s' reads a%d %d wait states behind the asm MFMA that wrote it" % (name, line, early[0], fresh[early[0]]))
+                        bad += 1
+                for r in list(fresh):
+                    fresh[r] += states
+                    if fresh[r] > 64:
+                        del fresh[r]
             if in_asm:
                 if first_in_block and line.startswith("v_mfma"):
                     used = agprs(line)

@@ -514,7 +514,8 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
       if (rc) return rc;
     } else
     for (auto &L : e->layers[b]) {
-      if (fused && L.w1s && B >= e->strip_min_batch && e->dl_variant == 0) {
+      // (one workgroup per 56 x 56 / 28 x 28 frame, 5 / 3 per 128 x 128 / 64 x 64 frame: enough of them to fill the chip?)
+      if (e->fuse && L.w1s && B * (Hh == 128 ? 5 : Hh == 64 ? 3 : 1) >= e->strip_min_batch && e->dl_variant == 0 && !cal) {
         DenseStripArgs as{bbuf[b], e->Cb[b], L.cin, L.s1, L.t1, L.w1s, L.w3s, B, Hh, Ww};
         const std::string fam = "dense_layer_strip_" + std::to_string(Hh) + "x" + std::to_string(Ww);
         tm.begin(fam.c_str(), 2.0 * M * (128.0 * L.cin + 32.0 * 1152),

@@ -54,15 +54,20 @@ constexpr int kW3Bytes = 3 * 8 * 3 * 1024;   // [dy][k16-step][dx] fragments of 
 
 template <int W, int KS>
 struct DSGeom {
-  static constexpr int NPAIR = W / 28;           // strip pairs per frame
-  static constexpr int NV = 4 / NPAIR;           // vertical parts (waves stacked in y)
-  static constexpr int ROWS = W / NV;            // output rows per wave
+  // A frame = NPAIR strip pairs (28 columns each; the last pair of a width that is no multiple of 28 is partly empty) x NCHUNK
+  // row chunks of ROWS output rows = NITEM work items, one per wave, four per workgroup: 56 x 56 and 28 x 28 frames are one
+  // workgroup (2 x 2 and 1 x 4 items); the 128 x 128 / 64 x 64 maps of a 512 x 512 input take 5 x 4 = 20 / 3 x 4 = 12 items =
+  // 5 / 3 workgroups per frame.  A chunk recomputes the bottleneck row above and below it.
+  static constexpr int NPAIR = (W + 27) / 28;    // strip pairs per frame
+  static constexpr int ROWS = W == 56 ? 28 : W == 28 ? 7 : W / 4;     // output rows per wave
+  static constexpr int NCHUNK = W / ROWS;
+  static constexpr int NITEM = NPAIR * NCHUNK, WGS = NITEM / 4;       // workgroups per frame
   static constexpr int KQ = 2 * KS;              // 16-channel k-steps
   static constexpr int NSU = (KS + 1) / 2;       // 64-channel super-steps (the last one is half when KS is odd)
   static constexpr int W1OFF = kW3Bytes;                   // KQ + 1 k-steps of 4 fragments: the last one carries BN2's shift
   static constexpr int T1OFF = W1OFF + (KQ + 1) * 4096;    // s1[K] | t1[K]
   static constexpr int LDS_BYTES = T1OFF + KS * 32 * 8;
-  static_assert(W % 28 == 0 && (NPAIR == 1 || NPAIR == 2), "strip geometry");
+  static_assert(W % ROWS == 0 && NITEM % 4 == 0 && ROWS >= 4, "strip geometry");
   static_assert(NSU <= 5, "the activation ring holds five super-steps");
   static_assert(LDS_BYTES <= 160 * 1024, "weights do not fit LDS");
 };
@@ -111,6 +116,19 @@ __device__ __forceinline__ void mfma32_win(f32x16 &d, const u32x4 a) {
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], 0" : "=&a"(d) : "v"(a), "n"(B0), "n"(B0 + 3));
   else
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], %0" : "+a"(d) : "v"(a), "n"(B0), "n"(B0 + 3));
+}
+// The LAST k-step of a 3x3 phase: its three MFMAs (one per kernel column) and the wait states their results need before
+// anything but an MFMA of the same chain may read them, in ONE statement.  hipcc knows nothing about the latency of an asm
+// MFMA: where the accumulators change registers at a control-flow join it put v_accvgpr_mov copies four instructions behind
+// the last MFMA, in front of the wait states the consumer carried (round 3, the 128 x 128 geometry: registers 14 / 15 of every
+// accumulator - the last pass of the MFMA - copied too early; which instantiations get such copies is the register
+// allocator's choice).  With the wait inside the producing statement no copy can come between.
+template <int PROW, int T>
+__device__ __forceinline__ void mfma32_win_last3(f32x16 &d0, f32x16 &d1, f32x16 &d2, const u32x4 a0, const u32x4 a1, const u32x4 a2) {
+  constexpr int B0 = win_reg(PROW, T);
+  asm volatile("v_mfma_f32_32x32x16_f16 %0, %3, a[%c6:%c7], %0\n\tv_mfma_f32_32x32x16_f16 %1, %4, a[%c6:%c7], %1\n\t"
+               "v_mfma_f32_32x32x16_f16 %2, %5, a[%c6:%c7], %2\n\ts_nop 15\n\ts_nop 3"
+               : "+a"(d0), "+a"(d1), "+a"(d2) : "v"(a0), "v"(a1), "v"(a2), "n"(B0), "n"(B0 + 3));
 }
 __device__ __forceinline__ f32x16 mfma32(const u32x4 a, const u32x4 b, const f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -250,17 +268,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 31, h = lane >> 5;
-  const int pair = wid % G::NPAIR, part = wid / G::NPAIR;
+  const int item = (int)(blockIdx.x % G::WGS) * 4 + wid;
+  const int pair = item % G::NPAIR, part = item / G::NPAIR;
   const int r_lo = part * ROWS, r_hi = r_lo + ROWS;
   const int x = 14 * (2 * pair + (n >> 4)) - 1 + (n & 15);
   const bool xvalid = x >= 0 && x < W;
   const int xc = x < 0 ? 0 : (x >= W ? W - 1 : x);
   const int ldc = a.ldc;
   const unsigned rowpitch = (unsigned)W * ldc * 2;
-  unsigned char *fb = (unsigned char *)(a.buf + (size_t)blockIdx.x * H * W * ldc);
+  unsigned char *fb = (unsigned char *)(a.buf + (size_t)(blockIdx.x / G::WGS) * H * W * ldc);
   const unsigned colb = (unsigned)xc * ldc * 2 + 64 * h;     // full super-steps: 64 B per lane
   const unsigned colh = (unsigned)xc * ldc * 2 + 32 * h;     // the trailing half super-step: 32 B per lane
-  const bool store_ok = (n & 15) >= 1 && (n & 15) <= 14;
+  const bool store_ok = (n & 15) >= 1 && (n & 15) <= 14 && xvalid;
   const unsigned outb = (unsigned)xc * ldc * 2 + K * 2 + 32 * h;
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(fb, 0, (int)((unsigned)H * rowpitch), 0x00020000);
 
@@ -386,6 +405,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
   };
   auto out_offset = [&](int yo, bool valid) TN_INL { return (valid && store_ok) ? outb + (unsigned)yo * rowpitch : 0x80000000u; };
+  // (belt and braces: the 3x3 phase's last statement already carries these wait states, mfma32_win_last3)
   auto bacc_ready = [&]() TN_INL {   // an asm MFMA's result may be read by anything but the next MFMA of its chain only 18+ wait states after issue
     f32x16 (&b)[3] = bacc;
     asm volatile("s_nop 15\n\ts_nop 3" : "+a"(b[0]), "+a"(b[1]), "+a"(b[2]));
@@ -450,7 +470,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         u32x4 (&w)[3] = w3f[S & 1];
         asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]));
       }
-      mfma32_win<S == 0, PROW, T>(bacc[DX], w3f[S & 1][DX]);
+      if constexpr (S < 23) mfma32_win<S == 0, PROW, T>(bacc[DX], w3f[S & 1][DX]);
+      else if constexpr (DX == 2) mfma32_win_last3<PROW, T>(bacc[0], bacc[1], bacc[2], w3f[S & 1][0], w3f[S & 1][1], w3f[S & 1][2]);
       if constexpr (S + 2 < 24) w3_item(ic<S + 2>{}, ic<DX>{});
       if constexpr (E < 40) {
         if constexpr (HAS_EPA) epa_item(rot_tag, e_tag);
@@ -545,7 +566,7 @@ int launch_strip(const DenseStripArgs &a, hipStream_t s) {
     TN_HIP_CHECK(hipFuncSetAttribute((const void *)dense_strip_kernel<W, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     attr_set = true;
   }
-  hipLaunchKernelGGL((dense_strip_kernel<W, KS>), dim3(a.B), dim3(256), G::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((dense_strip_kernel<W, KS>), dim3(a.B * G::WGS), dim3(256), G::LDS_BYTES, s, a);
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;
 }
@@ -569,7 +590,7 @@ int launch_strip_w(const DenseStripArgs &a, hipStream_t s) {
 }  // namespace
 
 bool dense_strip_supported(int H, int W, int K) {
-  return H == W && (W == 56 || W == 28) && K % 32 == 0 && K >= 64 && K <= 320;
+  return H == W && (W == 56 || W == 28 || W == 128 || W == 64) && K % 32 == 0 && K >= 64 && K <= 320;
 }
 
 int launch_dense_strip(const DenseStripArgs &a, hipStream_t s) {
@@ -577,6 +598,8 @@ int launch_dense_strip(const DenseStripArgs &a, hipStream_t s) {
   TN_REQUIRE(a.buf && a.s1 && a.t1 && a.w1s && a.w3s, "dense_strip: null operand");
   TN_REQUIRE(a.ldc % 64 == 0 && a.K + 32 <= a.ldc, "dense_strip: bad channel geometry");
   if (a.W == 56) return launch_strip_w<56>(a, s);
+  if (a.W == 128) return launch_strip_w<128>(a, s);
+  if (a.W == 64) return launch_strip_w<64>(a, s);
   return launch_strip_w<28>(a, s);
 }
 

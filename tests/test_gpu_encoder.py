@@ -194,6 +194,13 @@ def test_encoder_512_features_4096(report):
     err = float(np.abs(got - ref).max())
     report["features_512_maxabs_err"] = err
     assert err < TOL
+    # from 13 / 22 frames per launch on, the 128 x 128 / 64 x 64 layers up to K = 320 run on the strip kernels (5 / 3 workgroups
+    # per frame): same frame, same bar, and the same bits whatever its position in the batch
+    xb = torch.from_numpy(x16.astype(np.float32)).cuda().expand(24, -1, -1, -1).contiguous()
+    big = DenseNet121Features(p, 512, max_batch=24)(xb).cpu().numpy()
+    err = float(np.abs(big[:1] - ref).max())
+    report["features_512_strip_maxabs_err"] = err
+    assert err < TOL and np.array_equal(big[23:], big[:1])
 
 
 def test_encoder_448_mixed_kernels(report):
