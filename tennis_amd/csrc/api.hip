@@ -496,7 +496,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
       rc = launch_dense_block7(a7, s);
       tm.end();
       if (rc) return rc;
-    } else if (fused && e->chain && (e->dl_variant & ~(32 | 64 | 128 | 256 | 512)) == 0 && Hh == Ww && (Hh == 14 || Hh == 7) &&
+    } else if (fused && e->chain && (e->dl_variant & ~(32 | 64 | 128 | 256 | 512)) == 0 && Hh == Ww && (Hh == 14 || Hh == 7 || Hh == 16) &&
                e->layers[b].back().cin <= dense_layer_kmax(Ww)) {
       // one workgroup per frame walks the whole block: no launch gaps, no cold prologue per layer
       auto &L0 = e->layers[b][0];
@@ -508,7 +508,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
         fl += 2.0 * M * (128.0 * L.cin + 32.0 * 1152);
         by += (double)M * (L.cin + 32) * 2 + 128.0 * L.cin * 2 + 32.0 * 1152 * 2;
       }
-      tm.begin(Hh == 14 ? "dense_block_chained_14x14" : "dense_block_chained_7x7", fl, by);
+      tm.begin(Hh == 14 ? "dense_block_chained_14x14" : Hh == 16 ? "dense_block_chained_16x16" : "dense_block_chained_7x7", fl, by);
       rc = launch_dense_layer(af, s);
       tm.end();
       if (rc) return rc;

@@ -529,11 +529,17 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
     else if (nf == 2) kloop(std::integral_constant<int, 2>{});
     else if (nf == 1) kloop(std::integral_constant<int, 1>{});
     else kloop(std::integral_constant<int, 0>{});
+  } else if constexpr (MIW == 3) {
+    if (nf == 3) kloop(std::integral_constant<int, 3>{});
+    else if (nf == 2) kloop(std::integral_constant<int, 2>{});
+    else if (nf == 1) kloop(std::integral_constant<int, 1>{});
+    else kloop(std::integral_constant<int, 0>{});
   } else if constexpr (MIW == 2) {
     if (nf == 2) kloop(std::integral_constant<int, 2>{});
     else if (nf == 1) kloop(std::integral_constant<int, 1>{});
     else kloop(std::integral_constant<int, 0>{});
   } else {
+    static_assert(MIW == 1, "K loop dispatch: unknown fragment count per wave");
     if (nf == 1) kloop(std::integral_constant<int, 1>{});
     else kloop(std::integral_constant<int, 0>{});
   }
@@ -546,8 +552,8 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
   // ---- zero padding of the tile: the two pad columns of every row, out-of-image halo rows ----
   {
     const uint4 z4 = make_uint4(0, 0, 0, 0);
-    if (t < TR * 32) {
-      const int tr = t >> 5, side = (t >> 4) & 1, ch = t & 15;
+    for (int i = t; i < TR * 32; i += 512) {      // (TR = 18 at 16 x 16: more pad cells than threads)
+      const int tr = i >> 5, side = (i >> 4) & 1, ch = i & 15;
       *(uint4 *)(tile + (tr * WP + side * (WP - 1)) * 256 + ch * 16) = z4;
     }
     if (top_pad)
@@ -815,7 +821,8 @@ int launch_geom(const DenseLayerArgs &a, hipStream_t s) {
 
 }  // namespace
 
-bool dense_layer_big_supported(int H, int W) { return (H == 56 && W == 56) || (H == 28 && W == 28) || (H == 14 && W == 14) || (H == 7 && W == 7); }
+// (32 x 32 and 16 x 16: the third and fourth block of a 512 x 512 input)
+bool dense_layer_big_supported(int H, int W) { return H == W && (H == 56 || H == 28 || H == 14 || H == 7 || H == 32 || H == 16); }
 // input channels a layer of that map size may have (the BatchNorm tables' share of LDS, DLGeom::KMAX): an input size other
 // than 224 can put a 56x56 map into the second block (448: K up to 480), where the tile kernel has no room for it
 int dense_layer_big_kmax(int W) { return W == 56 ? 256 : W == 28 ? 512 : 1024; }
@@ -836,8 +843,9 @@ int launch_dense_layer_big(const DenseLayerArgs &a, hipStream_t s) {
     TN_REQUIRE(false, "dense_layer: unsupported spatial size");
   }
   if (a.nchain > 0) {
-    TN_REQUIRE(a.H == a.W && (a.H == 14 || a.H == 7) && a.chain, "dense_layer: layer chaining needs whole-frame tiles (14x14, 7x7)");
+    TN_REQUIRE(a.H == a.W && (a.H == 14 || a.H == 7 || a.H == 16) && a.chain, "dense_layer: layer chaining needs whole-frame tiles (16x16, 14x14, 7x7)");
     if (a.H == 14) return launch_geom<14, 14, 256, 64, 2, true>(a, s);
+    if (a.H == 16) return launch_geom<16, 16, 384, 32, 2, true>(a, s);
     // 7x7: 4 x 2 wave split over a 64-row tile (variant bit 5: the 8 x 1 split over 128 rows, for A/B runs)
     // bit 9: the flat K loop instead of the software-pipelined one (A/B runs)
     if (a.variant & 32) return launch_geom<7, 7, 128, 64, 2, true>(a, s);
@@ -851,6 +859,8 @@ int launch_dense_layer_big(const DenseLayerArgs &a, hipStream_t s) {
   if (a.H == 56 && a.W == 56) return TN_GEOM(56, 7, 512, 32);
   if (a.H == 28 && a.W == 28) return TN_GEOM(28, 14, 512, 32);
   if (a.H == 14 && a.W == 14) return TN_GEOM(14, 14, 256, 64);
+  if (a.H == 32 && a.W == 32) return TN_GEOM(32, 8, 384, 32);
+  if (a.H == 16 && a.W == 16) return TN_GEOM(16, 16, 384, 32);
   if (a.H == 7 && a.W == 7) {
     // default: the 4 x 2 wave split with the software-pipelined K loop, as the chained launch (bit 9: the older
     // 8 x 1 split over a 128-row tile with the K-loop flavours of bits 2-3)
