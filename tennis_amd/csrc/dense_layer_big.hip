@@ -822,7 +822,7 @@ int launch_geom(const DenseLayerArgs &a, hipStream_t s) {
 }  // namespace
 
 // (32 x 32 and 16 x 16: the third and fourth block of a 512 x 512 input)
-bool dense_layer_big_supported(int H, int W) { return H == W && (H == 56 || H == 28 || H == 14 || H == 7 || H == 32 || H == 16); }
+bool dense_layer_big_supported(int H, int W) { return H == W && (H == 56 || H == 28 || H == 14 || H == 7 || H == 64 || H == 32 || H == 16); }
 // input channels a layer of that map size may have (the BatchNorm tables' share of LDS, DLGeom::KMAX): an input size other
 // than 224 can put a 56x56 map into the second block (448: K up to 480), where the tile kernel has no room for it
 int dense_layer_big_kmax(int W) { return W == 56 ? 256 : W == 28 ? 512 : 1024; }
@@ -859,6 +859,7 @@ int launch_dense_layer_big(const DenseLayerArgs &a, hipStream_t s) {
   if (a.H == 56 && a.W == 56) return TN_GEOM(56, 7, 512, 32);
   if (a.H == 28 && a.W == 28) return TN_GEOM(28, 14, 512, 32);
   if (a.H == 14 && a.W == 14) return TN_GEOM(14, 14, 256, 64);
+  if (a.H == 64 && a.W == 64) return TN_GEOM(64, 4, 384, 32);      // (second block of a 512 x 512 input past K = 320: 1.5 x halo rows)
   if (a.H == 32 && a.W == 32) return TN_GEOM(32, 8, 384, 32);
   if (a.H == 16 && a.W == 16) return TN_GEOM(16, 16, 384, 32);
   if (a.H == 7 && a.W == 7) {

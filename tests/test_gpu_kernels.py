@@ -179,7 +179,7 @@ def test_temporal_pool_and_prf1(ctx):
                                         (3, 14, 256, 1024), (2, 14, 992, 1024), (8, 7, 512, 1024), (5, 7, 992, 1024), (3, 7, 544, 1024),
                                         (8, 28, 160, 512), (2, 14, 288, 1024), (1, 56, 96, 256),
                                         (33, 56, 64, 256), (40, 56, 96, 256),
-                                        (2, 32, 256, 1024), (3, 32, 992, 1024), (70, 32, 416, 1024), (2, 16, 512, 1024), (5, 16, 992, 1024)])   # 32 / 16: the maps of a 512 x 512 input; > 256 tiles: persistent workgroups, uneven tile counts, with and without the XCD remap
+                                        (2, 32, 256, 1024), (3, 32, 992, 1024), (70, 32, 416, 1024), (2, 16, 512, 1024), (5, 16, 992, 1024), (2, 64, 352, 512), (20, 64, 480, 512)])   # 32 / 16: the maps of a 512 x 512 input; > 256 tiles: persistent workgroups, uneven tile counts, with and without the XCD remap
 @pytest.mark.parametrize("variant", [1, 9])   # K loops: 1 refill spread over the MFMA groups (default), 9 refill up front
 def test_dense_layer_fused(ctx, report, B, H, K, ldc, variant):
     """One fused dense layer (1x1 -> LDS bottleneck tile -> 3x3, in-place concat) vs the oracle."""
