@@ -13,7 +13,7 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/tennis_hip.h
 	$(HIPCC) $(HFLAGS) -c $< -o $@
 
 # the strip kernel pins its own schedule: SLP packing of its scalar f32 arithmetic (v_pk_add_f32 ...) only costs issue slots
-$(CSRC)/dense_strip.o: HFLAGS += -fno-slp-vectorize
+$(CSRC)/dense_strip_w56.o $(CSRC)/dense_strip_w28.o $(CSRC)/dense_strip_w128.o $(CSRC)/dense_strip_w64.o: HFLAGS += -fno-slp-vectorize
 
 $(OUT): $(OBJS)
 	@mkdir -p $(dir $(OUT))

@@ -1,7 +1,7 @@
 """Audit of dense_strip.hip's ISA (no GPU needed): the kernel keeps its bottleneck window in literal accumulator registers
 a[160:255], which hipcc does not know are live.  This script fails if the compiler's own code touches them.
 
-  python scripts/audit_strip_isa.py <dense_strip ... gfx950.s>
+  python scripts/audit_strip_isa.py <dense_strip_w56 ... gfx950.s> [more .s files]   (scripts/isa_build.sh tennis_amd/csrc/dense_strip_w56.hip -fno-slp-vectorize)
 
 For every dense_strip kernel it checks that
   1. no instruction OUTSIDE an inline-asm region (;;#ASMSTART .. ;;#ASMEND) names an accumulator register >= 160;
@@ -36,8 +36,7 @@ def agprs(line):
 
 
 def main():
-    path = sys.argv[1]
-    text = open(path).read()
+    text = "\n".join(open(p).read() for p in sys.argv[1:])
     bad = 0
     kernels = 0
     for m in re.finditer(r"^(\S*dense_strip_kernel\S*):", text, re.M):
