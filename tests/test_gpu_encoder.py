@@ -201,6 +201,17 @@ def test_encoder_512_features_4096(report):
     err = float(np.abs(big[:1] - ref).max())
     report["features_512_strip_maxabs_err"] = err
     assert err < TOL and np.array_equal(big[23:], big[:1])
+    # ... and un-rounded fp32 weights at this size: the calibrated conversion (two other frames for the statistics) keeps the bar
+    # against the fp32 oracle on the fp32 weights (the hi + lo mode only exists for 224 x 224)
+    from tennis_amd.calibrate import calibrated_fp16_model
+    p32 = W.make_densenet121_weights(0, fp16_model=False)
+    with torch.no_grad():
+        ref32 = TorchDenseNet121(p32)(torch.from_numpy(x16.astype(np.float32))).numpy()
+    q = calibrated_fp16_model(p32, torch.from_numpy(W.synthetic_frames_u8(2, 512, seed=77)).cuda(), 512)
+    got = DenseNet121Features(q, 512, max_batch=1)(torch.from_numpy(x16.astype(np.float32)).cuda()).cpu().numpy()
+    err = float(np.abs(got - ref32).max())
+    report["features_512_fp32_weights_calibrated_maxabs_err"] = err
+    assert err < TOL, err
 
 
 def test_encoder_448_mixed_kernels(report):
