@@ -175,3 +175,40 @@ def test_jpeg_argument_errors():
     dec.close()
     with pytest.raises(RuntimeError, match="closed"):
         dec.decode([data])
+
+
+def test_round3_entry_point_errors():
+    """The entry points added in round 3 refuse what they cannot do, with a message: calibration statistics on an
+    exact-weights encoder or past max_batch, captioner layer counts the reference itself (or its attention cell) rejects,
+    unknown flags, a 7x7 block the LDS-resident kernel has no room for, a communicator with a rank outside its world."""
+    import ctypes as C
+    from tennis_amd import _lib
+    from tennis_amd import weights as W
+    from tennis_amd.engine import DenseNet121Features, GNMTCaptioner
+    p = W.make_densenet121_weights(0)
+    enc = DenseNet121Features(p, 224, max_batch=2)
+    with pytest.raises(RuntimeError, match="max_batch"):
+        enc.input_means(torch.zeros((3, 224, 224, 3), dtype=torch.uint8, device="cuda"))
+    ex = DenseNet121Features(W.make_densenet121_weights(0, fp16_model=False), 224, max_batch=2, exact_weights=True)
+    with pytest.raises(RuntimeError, match="exact"):
+        ex.input_means(torch.zeros((2, 224, 224, 3), dtype=torch.uint8, device="cuda"))
+    with pytest.raises(RuntimeError, match="224"):                       # hi + lo weight passes exist for the 224 x 224 maps only
+        DenseNet121Features(W.make_densenet121_weights(0, fp16_model=False), 512, max_batch=1, exact_weights=True)
+    g = W.make_gnmt_weights(1, "gru", 24, 16, 12, 30, num_layers=2, num_bi_layers=2)
+    with pytest.raises(RuntimeError, match="num_bi_layers"):
+        GNMTCaptioner(g, 24, 16, 12, 30, num_layers=2, num_bi_layers=2)
+    with pytest.raises(RuntimeError, match="num_layers"):
+        GNMTCaptioner(W.make_gnmt_weights(1, "gru", 24, 16, 12, 30, num_layers=1, num_bi_layers=0), 24, 16, 12, 30, num_layers=1, num_bi_layers=0)
+    lib = _lib.load()
+    ctx = _lib.default_context()
+    h = C.c_void_p()
+    arr, keep = _lib.make_params(W.make_gnmt_weights(1, "gru", 24, 16, 12, 30))
+    assert lib.tn_gnmt_create_ex(ctx.handle, arr, len(arr), b"gnmt_", _lib.RNN_GRU, 24, 16, 12, 30, 2, 1, 4, 8, 2, 5, 64, C.byref(h)) != 0
+    assert b"flag" in lib.tn_last_error()
+    one = np.ones(128 * 64 + 128 * 96, np.float32)
+    vp = lambda a_: a_.ctypes.data_as(C.c_void_p)
+    assert lib.tn_dbg_block7_create(ctx.handle, 64, 2, vp(one), vp(one), vp(one), vp(one), vp(one), vp(np.ones(2 * 32 * 128 * 9, np.float32)), C.byref(h)) != 0
+    assert b"unsupported" in lib.tn_last_error()
+    hc = C.c_void_p()
+    assert lib.tn_comm_create(ctx.handle, 3, 2, None, 0, C.byref(hc)) != 0      # rank 3 of 2
+    assert lib.tn_last_error() != b""
