@@ -1,4 +1,4 @@
-"""Audit of dense_strip.hip's ISA (no GPU needed): the kernel keeps its bottleneck window in literal accumulator registers
+"""Audit of the strip kernel's ISA (dense_strip_impl.h, instantiated in dense_strip_w*.hip) (no GPU needed): the kernel keeps its bottleneck window in literal accumulator registers
 a[160:255], which hipcc does not know are live.  This script fails if the compiler's own code touches them.
 
   python scripts/audit_strip_isa.py <dense_strip_w56 ... gfx950.s> [more .s files]   (scripts/isa_build.sh tennis_amd/csrc/dense_strip_w56.hip -fno-slp-vectorize)

@@ -136,7 +136,7 @@ for v in [int(s) for s in args.variants.split(",")]:
                 res.append(dict(k="dl", v=v, hw=hw, K=K, us=round(us, 1), tf=round(fl / us / 1e6, 1), tbs=round(by / us / 1e6, 2)))
                 print(res[-1], flush=True)
             del buf
-    if "ds" in args.kernels:      # strip-streaming fused dense layer (dense_strip.hip), every layer of the 56x56 / 28x28 blocks it supports
+    if "ds" in args.kernels:      # strip-streaming fused dense layer (dense_strip_impl.h), every layer of the 56x56 / 28x28 blocks it supports
         w3 = rng.normal(0, 0.03, (32, 128, 3, 3)).astype(np.float32)
         w3s = np.empty(36864, np.uint16)
         lib.tn_dbg_pack_strip(None, 32, None, None, None, w3.ctypes.data_as(C.c_void_p), w3s.ctypes.data_as(C.c_void_p))

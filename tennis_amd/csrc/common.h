@@ -186,7 +186,7 @@ bool dense_layer_supported(int H, int W);
 int dense_layer_kmax(int W);       // most input channels a fused layer of that (supported) map width takes
 int launch_dense_layer(const DenseLayerArgs &a, hipStream_t s);
 
-// The strip-streaming fused dense layer (dense_strip.hip): one workgroup per frame, weights resident in LDS.
+// The strip-streaming fused dense layer (dense_strip_impl.h): one workgroup per frame, weights resident in LDS.
 struct DenseStripArgs {
   f16 *buf;              // concat buffer [B][H][W][ldc]: reads channels [0,K), writes [K,K+32)
   int ldc, K;

@@ -106,7 +106,7 @@ extern "C" int tn_dbg_linear(tn_ctx *ctx, const float *x, const float *w, const 
   return launch_linear_f32(x, K, w, K, bias, y, N, M, N, K, 0, ctx->stream);
 }
 
-// ---- strip-streaming fused dense layer (dense_strip.hip) ----
+// ---- strip-streaming fused dense layer (dense_strip_impl.h) ----
 // fp32 (128,K) 1x1 weights with BN2's folded scale / shift (128 each) and (32,128,3,3) 3x3 weights -> the fragment images the
 // strip kernel keeps in LDS ((K+16)*128 and 36864 halfs); the scale is multiplied into the weights before the fp16 rounding
 extern "C" int tn_dbg_pack_strip(const float *w1_host, int K, const float *s2_host, const float *t2_host, uint16_t *w1s_out,

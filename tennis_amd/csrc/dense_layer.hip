@@ -1,5 +1,5 @@
 // Fused DenseNet dense layer of the tile kernels (dense_layer_big.hip: 8 waves, ROUT full image rows, one workgroup
-// per CU; whole-frame layer chains at 14x14 and 7x7).  The 56x56 / 28x28 layers with K <= 320 go to dense_strip.hip at
+// per CU; whole-frame layer chains at 14x14 and 7x7).  The 56x56 / 28x28 layers with K <= 320 go to the strip kernel (dense_strip_impl.h) at
 // batch >= 64 (api.hip).  Round 1's 4-wave geometry (28x7 tiles, two workgroups per CU) lost at every block size and
 // is gone; spatial sizes none of these kernels tile run un-fused (conv1x1.hip + conv3x3.hip).
 #include "common.h"

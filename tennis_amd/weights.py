@@ -91,7 +91,7 @@ def as_fp16_model(params: dict, input_means: dict | None = None) -> dict:
 
     The 1x1 convolution of a dense layer (``stageB_conv{2l}``) is followed directly by a
     BatchNorm (``stageB_batchnorm{2l+1}``) whose scale the encoder folds into the
-    weights (the usual conv-BN fusion; csrc/api.hip, csrc/dense_strip.hip): for those the
+    weights (the usual conv-BN fusion; csrc/api.hip, csrc/dense_strip_impl.h): for those the
     number that is rounded to fp16 is ``scale[n] * w[n][k]``, and the converted weight is
     ``fp16(scale[n] w[n][k]) / scale[n]`` — one rounding per weight either way.
 

@@ -329,7 +329,7 @@ def test_dense_block7(ctx, report, B, K0, nl, ldc):
                                         (3, 28, 128, 512), (2, 28, 320, 512), (5, 28, 160, 512), (1, 28, 288, 512),
                                         (2, 128, 64, 256), (1, 128, 224, 256), (3, 64, 128, 512), (2, 64, 320, 512)])   # 512 x 512 input: 5 / 3 workgroups per frame, partly empty last strip pair
 def test_dense_strip(ctx, report, B, H, K, ldc):
-    """The strip-streaming fused dense layer (dense_strip.hip: one frame per workgroup, weights resident in LDS, bottleneck
+    """The strip-streaming fused dense layer (dense_strip_impl.h: one frame per workgroup, weights resident in LDS, bottleneck
     window in registers through chained MFMA layouts, 3x3 columns combined by DPP shifts) vs the oracle."""
     from tennis_amd import _lib
     rng = np.random.default_rng(B * 1000 + H + K)
