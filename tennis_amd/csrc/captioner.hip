@@ -1067,19 +1067,19 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
   for (int i = 0; i < max_length; ++i) {
     const int step = i + 1;
     if ((i & 15) == 0) TN_HIP_CHECK(hipMemsetAsync(g->flag, 0, sizeof(int32_t), s));
-    int rc = launch_linear_f32(g->sx0, K0, g->w0c, K0, g->b0c, g->g0, 4 * H, R, 4 * H, K0, 0, s);
+    int rc = launch_linear_f32_lat(g->sx0, K0, g->w0c, K0, g->b0c, g->g0, 4 * H, R, 4 * H, K0, s);
     if (rc) return rc;
     hipLaunchKernelGGL(dec_attention_kernel<1>, dim3(R), dim3(kBeamThreads), att_lds, s, (const float *)g->g0,
                        (const float *)(g->sx0 + E + H), K0, (const float *)g->c0cur, lstm ? 1 : 0, g->h0n, g->c0n, x_after0, K1,
                        (const float *)g->keyprojT, (const float *)g->mem, (const int32_t *)g->vl, g->ctxn, beam, 1, T, H);
     for (int j = 0; j < nmid; ++j) {
       GnmtMid &m = g->mid[j];
-      rc = launch_linear_f32(m.sx, K1, m.w, K1, m.b, m.g, 4 * H, R, 4 * H, K1, 0, s);
+      rc = launch_linear_f32_lat(m.sx, K1, m.w, K1, m.b, m.g, 4 * H, R, 4 * H, K1, s);
       if (rc) return rc;
       hipLaunchKernelGGL(dec_mid_cell_kernel, dim3(nbm_), dim3(256), 0, s, (const float *)m.g, (const float *)m.sx, lstm ? 1 : 0,
                          (const float *)m.ccur, m.hn, m.cn, j + 1 < nmid ? g->mid[j + 1].sx : g->sx1, g->residual ? 1 : 0, R, H);
     }
-    rc = launch_linear_f32(g->sx1, K1, g->w1c, K1, g->b1c, g->g1, 4 * H, R, 4 * H, K1, 0, s);
+    rc = launch_linear_f32_lat(g->sx1, K1, g->w1c, K1, g->b1c, g->g1, 4 * H, R, 4 * H, K1, s);
     if (rc) return rc;
 #define TN_BEAM_LAUNCH(NBM)                                                                                              \
   hipLaunchKernelGGL(dec_beam_kernel<NBM>, dim3(B), dim3(kBeamThreads), beam_lds, s, (const float *)g->g1, g->sx1,       \
@@ -1156,19 +1156,19 @@ extern "C" int tn_gnmt_decode_seq(tn_gnmt *g, const int32_t *tgt, int ld, int st
     for (int j = 0; j < nmid; ++j)
       hipLaunchKernelGGL(dec_mid_state_kernel, dim3(nb), dim3(256), 0, s, (const int32_t *)nullptr, i ? (const float *)g->mid[j].hn : hinit(j + 1),
                          !lstm ? (const float *)nullptr : i ? (const float *)g->mid[j].cn : cinit(j + 1), g->mid[j].sx, g->mid[j].ccur, 0, 1, R, H);
-    int rc = launch_linear_f32(g->sx0, K0, g->w0c, K0, g->b0c, g->g0, 4 * H, R, 4 * H, K0, 0, s);
+    int rc = launch_linear_f32_lat(g->sx0, K0, g->w0c, K0, g->b0c, g->g0, 4 * H, R, 4 * H, K0, s);
     if (rc) return rc;
     hipLaunchKernelGGL(dec_attention_kernel<1>, dim3(R), dim3(kBeamThreads), att_lds, s, (const float *)g->g0,
                        (const float *)(g->sx0 + E + H), K0, (const float *)g->c0cur, lstm ? 1 : 0, g->h0n, g->c0n, x_after0, K1,
                        (const float *)g->keyprojT, (const float *)g->mem, (const int32_t *)g->vl, g->ctxn, 1, 1, T, H);
     for (int j = 0; j < nmid; ++j) {
       GnmtMid &m = g->mid[j];
-      rc = launch_linear_f32(m.sx, K1, m.w, K1, m.b, m.g, 4 * H, R, 4 * H, K1, 0, s);
+      rc = launch_linear_f32_lat(m.sx, K1, m.w, K1, m.b, m.g, 4 * H, R, 4 * H, K1, s);
       if (rc) return rc;
       hipLaunchKernelGGL(dec_mid_cell_kernel, dim3(nb), dim3(256), 0, s, (const float *)m.g, (const float *)m.sx, lstm ? 1 : 0,
                          (const float *)m.ccur, m.hn, m.cn, j + 1 < nmid ? g->mid[j + 1].sx : g->sx1, g->residual ? 1 : 0, R, H);
     }
-    rc = launch_linear_f32(g->sx1, K1, g->w1c, K1, g->b1c, g->g1, 4 * H, R, 4 * H, K1, 0, s);
+    rc = launch_linear_f32_lat(g->sx1, K1, g->w1c, K1, g->b1c, g->g1, 4 * H, R, 4 * H, K1, s);
     if (rc) return rc;
     hipLaunchKernelGGL(dec_tf_cell1_kernel, dim3(nb), dim3(256), 0, s, (const float *)g->g1, (const float *)g->sx1, lstm ? 1 : 0,
                        (const float *)g->c1cur, g->h1n, g->c1n, R, H, g->residual ? g->hstate : (float *)nullptr);

@@ -186,7 +186,68 @@ __global__ __launch_bounds__(256) void linear_f32_skinny_kernel(const float *__r
   }
 }
 
+// Latency-bound skinny problems (the captioner's per-step gate GEMMs: 160 rows, N = 1024, K = 612 / 768): a 16 x 16 output tile per
+// workgroup, its four waves each take a QUARTER of K and request ALL their operand data up front (one float4 per lane and 16
+// k-values, 6 x 2 loads in flight) - one or two L2 round trips per wave instead of the twenty dependent k-tiles the 32 x 32 kernel
+// walks - and the four partial tiles meet in LDS, added in wave order (deterministic).  A lane (r = lane & 15, q = lane >> 4)
+// holds X[m0 + r][16 j + 4 q + e] / W[n0 + r][same k] for e = 0..3: MFMA e of chunk j contracts the k-values 16 j + 4 q' + e over
+// q' = 0..3 - any bijection of k works as long as both operands use it.
+constexpr int kLatGroup = 6;
+__global__ __launch_bounds__(256) void linear_f32_lat_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw,
+                                                             const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int K) {
+  __shared__ float red[4][64][4];
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+  const int nch = (K + 63) / 64;                     // 16-wide k chunks per wave
+  const int kbeg = wid * nch * 16;
+  const int xm = min(m0 + r, M - 1), wn = min(n0 + r, N - 1);
+  const float *xrow = X + (long)xm * ldx + 4 * q, *wrow = Wt + (long)wn * ldw + 4 * q;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < nch; c0 += kLatGroup) {
+    float4 xa[kLatGroup], wb[kLatGroup];
+#pragma unroll
+    for (int j = 0; j < kLatGroup; ++j) {
+      const int k = kbeg + (c0 + j) * 16 + 4 * q;
+      const bool ok = c0 + j < nch && k < K;        // (K % 4 == 0: a float4 is all inside or all outside)
+      xa[j] = ok ? *(const float4 *)(xrow + kbeg + (c0 + j) * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+      wb[j] = ok ? *(const float4 *)(wrow + kbeg + (c0 + j) * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < kLatGroup; ++j) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].x, wb[j].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].y, wb[j].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].z, wb[j].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].w, wb[j].w, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[wid][lane][e] = acc[e];
+  __syncthreads();
+  if (wid == 0) {
+    const int n = n0 + r;
+    if (n < N) {
+      const float bz = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + q * 4 + e;
+        if (m < M) Y[(long)m * ldy + n] = ((red[0][lane][e] + red[1][lane][e]) + (red[2][lane][e] + red[3][lane][e])) + bz;
+      }
+    }
+  }
+}
+
 }  // namespace
+
+int launch_linear_f32_lat(const float *X, int ldx, const float *Wt, int ldw, const float *bias, float *Y, int ldy, int M, int N, int K,
+                          hipStream_t s) {
+  if (M <= 0 || N <= 0) return TN_OK;
+  const bool vec = ((ldx | ldw | K) & 3) == 0 && (((uintptr_t)X | (uintptr_t)Wt) & 15) == 0;
+  if (!vec || K < 128 || (long)((N + 15) / 16) * ((M + 15) / 16) > 4096) return launch_linear_f32(X, ldx, Wt, ldw, bias, Y, ldy, M, N, K, 0, s);
+  const dim3 grid((N + 15) / 16, (M + 15) / 16), block(256);
+  hipLaunchKernelGGL(linear_f32_lat_kernel, grid, block, 0, s, X, ldx, Wt, ldw, bias, Y, ldy, M, N, K);
+  TN_HIP_CHECK(hipGetLastError());
+  return TN_OK;
+}
 
 int launch_linear_f32(const float *X, int ldx, const float *Wt, int ldw, const float *bias, float *Y, int ldy,
                       int M, int N, int K, int accumulate, hipStream_t s) {
