@@ -12,8 +12,25 @@ all: $(OUT)
 $(CSRC)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/tennis_hip.h
 	$(HIPCC) $(HFLAGS) -c $< -o $@
 
-# the strip kernel pins its own schedule: SLP packing of its scalar f32 arithmetic (v_pk_add_f32 ...) only costs issue slots
-$(CSRC)/dense_strip_w56.o $(CSRC)/dense_strip_w28.o $(CSRC)/dense_strip_w128.o $(CSRC)/dense_strip_w64.o: HFLAGS += -fno-slp-vectorize
+# the strip kernel pins its own schedule: SLP packing of its scalar f32 arithmetic (v_pk_add_f32 ...) only costs issue slots.
+# Its units are compiled with -save-temps so that the ISA that IS in the object (not a second compile) can be audited:
+# the kernel keeps a window of bottleneck rows in literal accumulator registers behind hipcc's back
+# (scripts/audit_strip_isa.py; `make audit`, run by __graft_entry__.build() and tests/test_cpu_build.py).
+STRIP_UNITS := dense_strip_w56 dense_strip_w28 dense_strip_w128 dense_strip_w64
+STRIP_OBJS  := $(STRIP_UNITS:%=$(CSRC)/%.o)
+ISA_DIR     := $(CSRC)/isa
+# (grouped target: one recipe makes the object AND its ISA listing)
+define STRIP_RULE
+$(CSRC)/$(1).o $(ISA_DIR)/$(1).s &: $(CSRC)/$(1).hip $(wildcard $(CSRC)/*.h) include/tennis_hip.h
+	@mkdir -p $(ISA_DIR)
+	$(HIPCC) $(HFLAGS) -fno-slp-vectorize -save-temps=obj -c $(CSRC)/$(1).hip -o $(CSRC)/$(1).o
+	@mv $(CSRC)/$(1)-hip-amdgcn-amd-amdhsa-gfx950.s $(ISA_DIR)/$(1).s
+	@rm -f $(CSRC)/$(1)-hip-amdgcn-amd-amdhsa-gfx950.* $(CSRC)/$(1)-host-x86_64-unknown-linux-gnu.* $(CSRC)/$(1).hip-hip-amdgcn-amd-amdhsa.hipfb
+endef
+$(foreach u,$(STRIP_UNITS),$(eval $(call STRIP_RULE,$(u))))
+
+audit: $(STRIP_UNITS:%=$(ISA_DIR)/%.s)
+	python3 scripts/audit_strip_isa.py $(STRIP_UNITS:%=$(ISA_DIR)/%.s)
 
 $(OUT): $(OBJS)
 	@mkdir -p $(dir $(OUT))
@@ -21,5 +38,6 @@ $(OUT): $(OBJS)
 
 clean:
 	rm -f $(OBJS) $(OUT)
+	rm -rf $(ISA_DIR)
 
-.PHONY: all clean
+.PHONY: all clean audit

@@ -118,6 +118,44 @@ def cpu_baseline(params, frames_nhwc_f16, full=False):
     return out
 
 
+class StepLoop:
+    """The step / join / all-gather ordering of the timed loop, apart from the GPU so that tests/test_cpu_distributed.py can
+    drive exactly this code on gloo with a stand-in encoder (the first multi-GPU run must not be the first time it executes).
+
+    ``enc(x, out=f)`` encodes one batch into ``f``; with pipelined forwards ``f`` is only valid after ``enc.join(lag)``
+    (``lag`` 0: every call so far, 1: every call but the last).  Feature buffers and gather buffers alternate by step parity;
+    a buffer pair is reused two steps later, behind the wait for the collective that last read / wrote it."""
+
+    def __init__(self, enc, x, feats, gathered, comm, world, pipelined):
+        self.enc, self.x, self.feats, self.gathered, self.comm = enc, x, feats, gathered, comm
+        self.world, self.pipelined = world, pipelined
+        self.gather_h = [None, None]
+
+    def allgather(self, j):
+        if self.gather_h[j] is not None:
+            self.gather_h[j].wait()          # the previous collective into this buffer pair
+        self.gather_h[j] = self.comm.allgather_features(self.feats[j], self.gathered[j])
+
+    def step(self, i):
+        self.enc(self.x, out=self.feats[i & 1])
+        if self.world > 1:
+            if not self.pipelined:
+                self.allgather(i & 1)
+            elif i > 0:
+                self.enc.join(1)
+                self.allgather((i - 1) & 1)
+
+    def drain(self, k):
+        if self.pipelined and k > 0:
+            self.enc.join(0)
+            if self.world > 1:
+                self.allgather((k - 1) & 1)
+        for j in (0, 1):
+            if self.gather_h[j] is not None:
+                self.gather_h[j].wait()
+                self.gather_h[j] = None
+
+
 def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,39 +214,14 @@ def run(argv):
     # the exchange step goes through the library's own RCCL communicator (tn_allgather_features); torch.distributed only
     # carries the barrier and the max over ranks of the timing
     comm = sharding.feature_comm(dev) if world > 1 else None      # (comm.bring_up: agreed fall-back to torch's RCCL communicator)
-    gather_h = [None, None]
-
-    def allgather(j):
-        if gather_h[j] is not None:
-            gather_h[j].wait()          # the previous collective into this buffer pair
-        gather_h[j] = comm.allgather_features(feats[j], gathered[j])
-
     # Pipelined forwards (tn_densenet121_set_pipelined): the encoder runs a batch as two half batches on two streams, and
     # the last chained block of the second half occupies half of the CUs; without a join inside forward the next step's
-    # first half starts beside it.  Results are ordered by the caller: the all-gather of step i is issued one step behind
-    # (join lag 1), and `drain` joins the last step - every one of the K steps is complete before the closing fence.
+    # first half starts beside it.  Results are ordered by the caller (StepLoop): the all-gather of step i is issued one step
+    # behind (join lag 1), and `drain` joins the last step - every one of the K steps is complete before the closing fence.
     pipelined = not args.no_pipeline
     enc.set_pipelined(pipelined)
-
-    def step(i):
-        f = feats[i & 1]
-        enc(x, out=f)
-        if world > 1:
-            if not pipelined:
-                allgather(i & 1)
-            elif i > 0:
-                enc.join(1)
-                allgather((i - 1) & 1)
-
-    def drain(k):
-        if pipelined and k > 0:
-            enc.join(0)
-            if world > 1:
-                allgather((k - 1) & 1)
-        for j in (0, 1):
-            if gather_h[j] is not None:
-                gather_h[j].wait()
-                gather_h[j] = None
+    loop = StepLoop(enc, x, feats, gathered, comm, world, pipelined)
+    step, drain = loop.step, loop.drain
 
     def fence():
         if world > 1:
@@ -239,11 +252,11 @@ def run(argv):
     # for the record: the same K steps with every forward joined before it returns (one more fenced region, all ranks)
     dt_joined = None
     if pipelined and not args.single_region:
-        pipelined = False
+        loop.pipelined = False
         enc.set_pipelined(False)
         dt_joined = timed_region(args.steps)
         enc.set_pipelined(True)
-        pipelined = True
+        loop.pipelined = True
 
     # for the record: the rate of the configuration that meets "1e-3 of the reference" against UN-rounded fp32
     # parameters - the exact-weights mode (hi + lo fp16 weight pairs: twice the MFMA work of the dense layers and transitions)
@@ -254,12 +267,14 @@ def run(argv):
         enc_f16 = enc
         enc = DenseNet121Features(params_x, SIZE, max_batch=args.batch, ctx=ctx, exact_weights=True)
         enc.set_pipelined(pipelined)
+        loop.enc = enc
         for i in range(min(args.warmup, 5)):
             step(i)
         drain(min(args.warmup, 5))
         fps_exact = world * args.batch * args.steps / timed_region(args.steps)
         enc.set_pipelined(False)
         enc = enc_f16
+        loop.enc = enc
         del params_x
 
     if rank == 0:

@@ -43,7 +43,6 @@ def main():
         name = m.group(1)
         end = text.find(".end_amdhsa_kernel", m.end())
         body = text[m.end():text.rfind("s_endpgm", m.end(), end) + 8]
-        meta = text[end - 4000:end + 200]
         kernels += 1
         in_asm = False
         prev = []          # last compiler instructions (outside asm) with the AGPRs they write
@@ -102,11 +101,20 @@ def main():
             prev.append((line, written))
             if not line.startswith(("v_accvgpr", "s_nop")):
                 prev = prev[-1:] if written else []
-        for key in (".private_segment_fixed_size", ".vgpr_spill_count"):
-            mm = re.search(re.escape(key) + r":?\s+(\d+)", meta)
-            if mm and int(mm.group(1)) != 0:
-                print("%s: %s = %s" % (name, key, mm.group(1)))
-                bad += 1
+        # scratch: the kernel descriptor that follows the code (.amdhsa_private_segment_fixed_size) and hipcc's own summary
+        # comment (; ScratchSize:) - both must be there and both must say 0
+        desc = text[end - 6000:end]
+        seen = 0
+        for pat in (r"\.amdhsa_private_segment_fixed_size\s+(\d+)", r";\s*ScratchSize:\s*(\d+)"):
+            found = re.findall(pat, desc if "amdhsa" in pat else text[end:end + 3000])
+            if found:
+                seen += 1
+                if int(found[-1] if "amdhsa" in pat else found[0]) != 0:
+                    print("%s: scratch in use (%s = %s)" % (name, pat.split("\\s")[0].replace("\\", ""), found[0]))
+                    bad += 1
+        if not seen:
+            print("%s: no scratch-size record found in the listing (audit out of date with the assembler's output?)" % name)
+            bad += 1
     print("audited %d kernels, %d problem(s)" % (kernels, bad))
     sys.exit(1 if bad or not kernels else 0)
 

@@ -1,0 +1,142 @@
+"""Synthetic frame families for the calibrated fp16 conversion (tennis_amd/calibrate.py) and its robustness tests.
+
+The reference evaluates fp32 parameters on whatever frames arrive (models/vision/definitions.py:27-33); a conversion that is
+calibrated on frames must therefore hold on frames that do not look like its calibration set.  No video ships with the
+reference, so the families below stand in for "different kinds of content": what matters to the conversion is how the
+per-channel mean activations of a frame differ from those it was calibrated on (dark / bright scenes, flat regions, edges,
+texture).  All generators are seeded and return NHWC uint8.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+FAMILIES = ["noise", "lowcontrast", "constant", "gradient", "halfblack", "blobs", "scene"]
+
+
+def _noise(rng, n, s):
+    return rng.integers(0, 256, (n, s, s, 3), dtype=np.uint8)
+
+
+def _lowcontrast(rng, n, s):
+    base = rng.integers(60, 200, (n, 1, 1, 3))
+    return np.clip(base + rng.normal(0, 12, (n, s, s, 3)), 0, 255).astype(np.uint8)
+
+
+def _constant(rng, n, s):
+    return np.broadcast_to(rng.integers(0, 256, (n, 1, 1, 3), dtype=np.uint8), (n, s, s, 3)).copy()
+
+
+def _gradient(rng, n, s):
+    t = np.linspace(0.0, 1.0, s)
+    out = np.empty((n, s, s, 3), np.float64)
+    for i in range(n):
+        c0, c1 = rng.uniform(0, 255, 3), rng.uniform(0, 255, 3)
+        ang = rng.uniform(0, 2 * np.pi)
+        g = np.clip(0.5 + (np.cos(ang) * (t[None, :] - 0.5) + np.sin(ang) * (t[:, None] - 0.5)), 0, 1)
+        out[i] = c0 + g[..., None] * (c1 - c0)
+    return out.astype(np.uint8)
+
+
+def _halfblack(rng, n, s):
+    f = _noise(rng, n, s)
+    for i in range(n):
+        if i & 1:
+            f[i, :, : s // 2] = 0
+        else:
+            f[i, : s // 2] = 0
+    return f
+
+
+def _blobs(rng, n, s):
+    """low-pass filtered noise (1/f-like): smooth coloured regions with soft edges"""
+    fy = np.fft.fftfreq(s)[:, None]
+    fx = np.fft.rfftfreq(s)[None, :]
+    amp = 1.0 / np.maximum(np.hypot(fy, fx), 1.0 / s) ** 1.5
+    out = np.empty((n, s, s, 3), np.float64)
+    for i in range(n):
+        for c in range(3):
+            spec = (rng.normal(size=(s, s // 2 + 1)) + 1j * rng.normal(size=(s, s // 2 + 1))) * amp
+            img = np.fft.irfft2(spec, (s, s))
+            img = (img - img.mean()) / (img.std() + 1e-9)
+            out[i, ..., c] = 128 + rng.uniform(-40, 40) + img * rng.uniform(25, 70)
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def _scene(rng, n, s):
+    """a court-like composition: large flat rectangles, thin bright lines, a textured band, sensor noise"""
+    out = np.empty((n, s, s, 3), np.float64)
+    for i in range(n):
+        img = np.empty((s, s, 3))
+        img[:] = rng.uniform(20, 120, 3)
+        for _ in range(int(rng.integers(2, 6))):
+            y0, x0 = rng.integers(0, s - 8, 2)
+            h, w = rng.integers(8, s // 2, 2)
+            img[y0:y0 + h, x0:x0 + w] = rng.uniform(0, 255, 3)
+        for _ in range(int(rng.integers(2, 7))):
+            if rng.random() < 0.5:
+                y = int(rng.integers(0, s - 2)); img[y:y + 2, :] = rng.uniform(200, 255)
+            else:
+                x = int(rng.integers(0, s - 2)); img[:, x:x + 2] = rng.uniform(200, 255)
+        y0 = int(rng.integers(0, s - 32))
+        img[y0:y0 + 32] += rng.normal(0, 40, (32, s, 3))
+        out[i] = img + rng.normal(0, 4, (s, s, 3))
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def _stripes(rng, n, s):
+    out = np.empty((n, s, s, 3), np.float64)
+    t = np.arange(s)
+    for i in range(n):
+        period = rng.integers(2, 40)
+        c0, c1 = rng.uniform(0, 255, 3), rng.uniform(0, 255, 3)
+        m = ((t // period) & 1).astype(np.float64)
+        m = m[None, :] if rng.random() < 0.5 else m[:, None]
+        out[i] = c0 + np.broadcast_to(m, (s, s))[..., None] * (c1 - c0)
+    return out.astype(np.uint8)
+
+
+def _checker(rng, n, s):
+    out = np.empty((n, s, s, 3), np.float64)
+    t = np.arange(s)
+    for i in range(n):
+        p = rng.integers(1, 32)
+        c0, c1 = rng.uniform(0, 255, 3), rng.uniform(0, 255, 3)
+        m = (((t[:, None] // p) + (t[None, :] // p)) & 1).astype(np.float64)
+        out[i] = c0 + m[..., None] * (c1 - c0)
+    return out.astype(np.uint8)
+
+
+def _dark(rng, n, s):
+    return (_scene(rng, n, s).astype(np.float64) * rng.uniform(0.08, 0.3, (n, 1, 1, 1))).astype(np.uint8)
+
+
+def _bright(rng, n, s):
+    return (255 - (255 - _blobs(rng, n, s).astype(np.float64)) * rng.uniform(0.1, 0.35, (n, 1, 1, 1))).astype(np.uint8)
+
+
+def _tinted(rng, n, s):
+    """noise through a random per-frame colour transform (gain + offset per channel)"""
+    f = _noise(rng, n, s).astype(np.float64)
+    return np.clip(f * rng.uniform(0.2, 1.0, (n, 1, 1, 3)) + rng.uniform(0, 120, (n, 1, 1, 3)), 0, 255).astype(np.uint8)
+
+
+# families that are NOT part of the built-in calibration set: the robustness tests evaluate on them
+HELD_OUT = ["stripes", "checker", "dark", "bright", "tinted"]
+
+_GEN = {"stripes": _stripes, "checker": _checker, "dark": _dark, "bright": _bright, "tinted": _tinted, "noise": _noise, "lowcontrast": _lowcontrast, "constant": _constant, "gradient": _gradient, "halfblack": _halfblack,
+        "blobs": _blobs, "scene": _scene}
+
+
+def frames(family: str, n: int, size: int = 224, seed: int = 0) -> np.ndarray:
+    """``n`` NHWC uint8 frames of one family."""
+    if family not in _GEN:
+        raise ValueError(f"unknown frame family {family!r}; one of {FAMILIES}")
+    rng = np.random.default_rng([seed, (FAMILIES + HELD_OUT).index(family)])
+    return np.ascontiguousarray(_GEN[family](rng, n, size))
+
+
+def default_calibration_frames(size: int = 224, n: int = 28, seed: int = 4321) -> np.ndarray:
+    """The built-in calibration set: ``n`` frames dealt round-robin over all families (``n`` = 28: four of each).  A caller
+    with real frames of the footage to be processed should ADD those (calibrate(frames) concatenates)."""
+    per = [(n + len(FAMILIES) - 1 - i) // len(FAMILIES) for i in range(len(FAMILIES))]
+    return np.concatenate([frames(f, k, size, seed) for f, k in zip(FAMILIES, per) if k > 0])

@@ -59,8 +59,19 @@ class Comm:
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return cls(0, 1, None, device)
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [cls.new_unique_id() if rank == 0 else None]
+        # rank 0 ALWAYS takes part in the broadcast: if it cannot make an id (dlopen of librccl, ncclGetUniqueId) it sends the
+        # error instead, and every rank raises behind the broadcast - so that all ranks leave this function together and
+        # reach bring_up()'s agreement step (a rank 0 that raised in front of the broadcast would be inside that step's
+        # all-reduce while the others still sit in the broadcast: mismatched collectives, a hang instead of a fall-back)
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = cls.new_unique_id()
+            except Exception as e:
+                box[0] = ("error", repr(e))
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if isinstance(box[0], tuple):
+            raise RuntimeError(f"rank 0 could not create a communicator id: {box[0][1]}")
         return cls(rank, world, box[0], device)
 
     # -- collectives ----------------------------------------------------------------------------------------------

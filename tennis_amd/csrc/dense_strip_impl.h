@@ -583,7 +583,9 @@ int launch_strip_w(const DenseStripArgs &a, hipStream_t s) {
     case 7: return launch_strip<W, 7>(a, s);
     case 8: return launch_strip<W, 8>(a, s);
     case 9: return launch_strip<W, 9>(a, s);
-    case 10: return launch_strip<W, 10>(a, s);
+    case 10:
+      if constexpr (W != 128) return launch_strip<W, 10>(a, s);     // (W = 128: K <= 288, dense_strip_supported)
+      break;
   }
   TN_REQUIRE(false, "dense_strip: K out of range");
 }

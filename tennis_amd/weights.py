@@ -83,6 +83,40 @@ def _round_fp16_error_feedback(wf: np.ndarray, mean: np.ndarray) -> np.ndarray:
     return out
 
 
+def _round_fp16_vector_feedback(wf: np.ndarray, A: np.ndarray, sweeps: int = 3, ridge: float = 0.05) -> np.ndarray:
+    """(N, K) float64 values -> fp16-representable values, each one of its two fp16 neighbours, chosen so that the rounding
+    error of every output row is (nearly) orthogonal to ALL rows of ``A`` (F, K) at once - the mean input activations of F
+    calibration frames - instead of to their average only (``_round_fp16_error_feedback``): minimises, per output row n,
+    ``|| A d_n ||^2 + ridge * sum_k (d_n[k] * a_rms[k])^2`` over the 2^K neighbour choices by one greedy pass along k followed
+    by ``sweeps`` passes of coordinate descent (each weight re-decided against the residual of all the others).  The ridge term
+    keeps a weight on its nearest neighbour unless moving it buys something, which bounds what the conversion can do to frames
+    whose activations lie outside the span of the calibration set (they see at most the plain-rounding error statistics)."""
+    N, K = wf.shape
+    F = A.shape[0]
+    rtn = wf.astype(np.float16)
+    rtn_f = rtn.astype(np.float64)
+    other = np.nextafter(rtn, np.where(wf > rtn_f, np.float16(np.inf), np.float16(-np.inf)).astype(np.float16)).astype(np.float64)
+    other = np.where(np.isfinite(other), other, rtn_f)
+    d1, d2 = rtn_f - wf, other - wf                          # the two possible errors of each weight (N, K)
+    An = A / np.sqrt(F)                                       # mean square over the frames
+    a2 = (An * An).sum(0)                                     # (K,) = a_rms^2
+    use2 = np.zeros((N, K), bool)
+    r = np.zeros((N, F))
+    for sweep in range(sweeps + 1):
+        for k in range(K):
+            ak = An[:, k]
+            if sweep:
+                r -= np.where(use2[:, k], d2[:, k], d1[:, k])[:, None] * ak[None, :]
+            # cost of choice c: || r + d_c a_k ||^2 + ridge d_c^2 a2_k  =  const + 2 d_c (r . a_k) + d_c^2 a2_k (1 + ridge)
+            ra = r @ ak
+            c1 = 2 * d1[:, k] * ra + d1[:, k] ** 2 * a2[k] * (1 + ridge)
+            c2 = 2 * d2[:, k] * ra + d2[:, k] ** 2 * a2[k] * (1 + ridge)
+            u = c2 < c1
+            use2[:, k] = u
+            r += np.where(u, d2[:, k], d1[:, k])[:, None] * ak[None, :]
+    return np.where(use2, other, rtn_f)
+
+
 def as_fp16_model(params: dict, input_means: dict | None = None) -> dict:
     """Model conversion for the fp16 encoder: every conv ``*_weight`` is rounded once to
     fp16 (kept as fp32 arrays).  The served model IS these converted weights — the GPU
@@ -119,8 +153,13 @@ def as_fp16_model(params: dict, input_means: dict | None = None) -> dict:
             s = s.reshape(-1, 1, 1, 1)
         folded = (v * s).astype(np.float32) if s is not None else v.astype(np.float32)
         if input_means is not None and k in input_means:
-            mean = np.repeat(np.asarray(input_means[k], np.float64), v.shape[2] * v.shape[3])      # (cin, kh, kw) flattening
-            r = _round_fp16_error_feedback(folded.astype(np.float64).reshape(v.shape[0], -1), mean).reshape(v.shape).astype(np.float32)
+            m = np.asarray(input_means[k], np.float64)
+            taps = v.shape[2] * v.shape[3]
+            if m.ndim == 2:      # one row per calibration frame: vector error feedback
+                r = _round_fp16_vector_feedback(folded.astype(np.float64).reshape(v.shape[0], -1), np.repeat(m, taps, axis=1))
+            else:                # (cin, kh, kw) flattening
+                r = _round_fp16_error_feedback(folded.astype(np.float64).reshape(v.shape[0], -1), np.repeat(m, taps))
+            r = r.reshape(v.shape).astype(np.float32)
         else:
             r = folded.astype(np.float16).astype(np.float32)
         if s is not None:

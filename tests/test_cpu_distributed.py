@@ -64,6 +64,15 @@ def _bringup_worker(rank, world, port, mode, ret):
         if mode == "rank1_raises" and rank == 1:
             raise RuntimeError("ncclCommInitRank failed (simulated)")
         return _FakeLibComm(rank, world, wrong_rows=(mode == "rank0_wrong_rows" and rank == 0))
+    if mode == "rank0_id_fails":
+        # the real factory (Comm.from_process_group), with the two calls that need librccl / a GPU replaced: rank 0 cannot make
+        # a unique id (dlopen of librccl failing there).  It must still enter the id broadcast, or rank 1 waits in it forever
+        # while rank 0 sits in the agreement all-reduce.
+        def no_id():
+            raise OSError("librccl.so: cannot open shared object file (simulated)")
+        cm.Comm.new_unique_id = staticmethod(no_id)
+        cm.Comm.__init__ = lambda self, *a, **k: (_ for _ in ()).throw(AssertionError("no communicator may be built without an id"))
+        make = None
     c = cm.bring_up(None, torch.device("cpu"), _make=make)
     # whatever was agreed on must work on every rank
     mine = torch.full((2, 3), float(rank))
@@ -77,8 +86,10 @@ def _bringup_worker(rank, world, port, mode, ret):
 def test_comm_bring_up_handshake_world2():
     """comm.bring_up: the library communicator is used only if it came up AND passed a probe all-gather on EVERY rank; if one
     rank fails to create it, or one rank's probe returns wrong rows, all ranks switch to the torch.distributed transport
-    together (no rank is left inside a collective the others never enter)."""
-    for port, mode, want in ((29541, "ok", "_FakeLibComm"), (29542, "rank1_raises", "GroupComm"), (29543, "rank0_wrong_rows", "GroupComm")):
+    together (no rank is left inside a collective the others never enter) - also when rank 0 cannot even make the unique id
+    (it used to raise in front of the id broadcast)."""
+    for port, mode, want in ((29541, "ok", "_FakeLibComm"), (29542, "rank1_raises", "GroupComm"), (29543, "rank0_wrong_rows", "GroupComm"),
+                             (29544, "rank0_id_fails", "GroupComm")):
         with mp.Manager() as mgr:
             ret = mgr.dict()
             mp.spawn(_bringup_worker, args=(2, port, mode, ret), nprocs=2, join=True)
@@ -217,3 +228,86 @@ def test_data_parallel_training_step_matches_single_process():
     for pr in procs:
         pr.join(timeout=60)
     assert all(e < 1e-12 for _, e in res), res
+
+
+class _LateEncoder:
+    """Stands in for the pipelined HIP encoder: a forward only QUEUES its work; the output buffer is written when the caller
+    joins (``join(1)``: everything but the newest call, ``join(0)``: everything) - so a loop that gathers a buffer before
+    joining its forward, or reuses a buffer too early, reads stale rows and the test sees it."""
+
+    def __init__(self, rank):
+        self.rank, self.queue, self.calls, self.pipelined = rank, [], 0, False
+
+    def set_pipelined(self, on):
+        self.pipelined = on
+
+    def __call__(self, x, out):
+        i = self.calls
+        self.calls += 1
+
+        def work():
+            out.copy_(x * 0 + (1000.0 * self.rank + i))
+        if self.pipelined:
+            out.fill_(-1.0)          # what a consumer would see if it did not wait
+            self.queue.append(work)
+        else:
+            work()
+
+    def join(self, lag):
+        keep = self.queue[len(self.queue) - lag:] if lag else []
+        for w in self.queue[:len(self.queue) - lag]:
+            w()
+        self.queue = keep
+
+
+class _RecordingComm:
+    """GroupComm (the torch.distributed transport bench.py falls back to) that keeps what every collective delivered."""
+
+    def __init__(self):
+        from tennis_amd.comm import GroupComm
+        self.inner, self.log = GroupComm(), []
+
+    def allgather_features(self, shard, out):
+        h = self.inner.allgather_features(shard, out)
+        h.wait()
+        self.log.append(out.clone())
+        return h
+
+
+def _steploop_worker(rank, world, port, pipelined, k, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    b, f = 3, 4
+    enc = _LateEncoder(rank)
+    enc.set_pipelined(pipelined)
+    x = torch.zeros((b, f))
+    feats = [torch.empty((b, f)) for _ in range(2)]
+    gathered = [torch.empty((world * b, f)) for _ in range(2)]
+    comm = _RecordingComm()
+    loop = bench.StepLoop(enc, x, feats, gathered, comm, world, pipelined)
+    for i in range(k):
+        loop.step(i)
+    loop.drain(k)
+    dist.barrier()
+    ret[rank] = [t[:, 0].tolist() for t in comm.log]
+    dist.destroy_process_group()
+
+
+def test_bench_step_loop_world2():
+    """bench.py's timed loop (StepLoop: forward, join one step behind, all-gather, drain) on gloo, world 2, through the
+    torch.distributed transport: every one of the K steps is gathered exactly once, in order, with every rank's rows of THAT
+    step - pipelined and joined, odd and even K (`bench.py --gpus 2` was only reachable on a multi-GPU box)."""
+    port = 29561
+    for pipelined in (True, False):
+        for k in (1, 4, 5):
+            with mp.Manager() as mgr:
+                ret = mgr.dict()
+                mp.spawn(_steploop_worker, args=(2, port, pipelined, k, ret), nprocs=2, join=True)
+                port += 1
+                want = [[1000.0 * r + i for r in range(2) for _ in range(3)] for i in range(k)]
+                for r in range(2):
+                    assert ret[r] == want, (pipelined, k, ret[r])
