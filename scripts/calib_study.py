@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--calib", default="")
     ap.add_argument("--out", default="")
     ap.add_argument("--quad", action="store_true")
+    ap.add_argument("--ridge", type=float, default=0.05)
+    ap.add_argument("--sweeps", type=int, default=3)
+    ap.add_argument("--train-error", action="store_true", help="also evaluate on the calibration frames themselves")
     a = ap.parse_args()
     torch.set_num_threads(8)
     global QUAD
@@ -121,7 +124,12 @@ def main():
             if a.method == "mean":
                 q = W.as_fp16_model(p, input_means={k: v.mean(0) for k, v in fm.items()})
             else:
+                W._VEC_RIDGE, W._VEC_SWEEPS = a.ridge, a.sweeps
                 q = W.as_fp16_model(p, input_means=fm)
+                if a.train_error:
+                    net = Net(q)
+                    xc = torch.from_numpy(W.normalize_to_nchw_f32(cal))
+                    print("   training error (the calibration frames themselves): %.2e" % float((net(xc) - ref_net(xc)).abs().max()))
             res[f"{cf}/{n}"] = evaluate(q, f"cal {cf}/{n} ({time.time() - t0:.0f}s)")
     if a.out:
         json.dump(res, open(a.out, "w"), indent=1)

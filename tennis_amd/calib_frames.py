@@ -10,7 +10,8 @@ from __future__ import annotations
 
 import numpy as np
 
-FAMILIES = ["noise", "lowcontrast", "constant", "gradient", "halfblack", "blobs", "scene"]
+# the families of the built-in calibration set
+FAMILIES = ["noise", "lowcontrast", "constant", "gradient", "halfblack", "blobs", "scene", "stripes", "checker", "dark", "bright", "tinted"]
 
 
 def _noise(rng, n, s):
@@ -120,10 +121,54 @@ def _tinted(rng, n, s):
     return np.clip(f * rng.uniform(0.2, 1.0, (n, 1, 1, 3)) + rng.uniform(0, 120, (n, 1, 1, 3)), 0, 255).astype(np.uint8)
 
 
-# families that are NOT part of the built-in calibration set: the robustness tests evaluate on them
-HELD_OUT = ["stripes", "checker", "dark", "bright", "tinted"]
+def _text(rng, n, s):
+    """dark glyph-like rectangles on a light page"""
+    out = np.empty((n, s, s, 3), np.float64)
+    for i in range(n):
+        img = np.empty((s, s, 3)); img[:] = rng.uniform(190, 255, 3)
+        ink = rng.uniform(0, 60, 3)
+        for y in range(6, s - 10, int(rng.integers(10, 18))):
+            x = 6
+            while x < s - 10:
+                w = int(rng.integers(2, 9))
+                if rng.random() < 0.8:
+                    img[y:y + int(rng.integers(5, 9)), x:x + w] = ink
+                x += w + int(rng.integers(1, 5))
+        out[i] = img
+    return out.astype(np.uint8)
 
-_GEN = {"stripes": _stripes, "checker": _checker, "dark": _dark, "bright": _bright, "tinted": _tinted, "noise": _noise, "lowcontrast": _lowcontrast, "constant": _constant, "gradient": _gradient, "halfblack": _halfblack,
+
+def _saturated(rng, n, s):
+    """patchwork of fully saturated primaries / secondaries"""
+    pal = np.array([[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0], [0, 255, 255], [255, 0, 255], [255, 255, 255], [0, 0, 0]], np.float64)
+    out = np.empty((n, s, s, 3), np.float64)
+    for i in range(n):
+        p = int(rng.integers(8, 80))
+        idx = rng.integers(0, len(pal), ((s + p - 1) // p, (s + p - 1) // p))
+        out[i] = pal[np.repeat(np.repeat(idx, p, 0), p, 1)[:s, :s]]
+    return out.astype(np.uint8)
+
+
+def _photo(rng, n, s):
+    """photo-like: blobs + a few hard-edged objects + film grain + vignette"""
+    base = _blobs(rng, n, s).astype(np.float64)
+    yy, xx = np.mgrid[0:s, 0:s]
+    for i in range(n):
+        for _ in range(int(rng.integers(1, 5))):
+            cy, cx, r = rng.integers(0, s), rng.integers(0, s), rng.integers(6, s // 3)
+            m = (yy - cy) ** 2 + (xx - cx) ** 2 < r * r
+            base[i][m] = base[i][m] * 0.3 + rng.uniform(0, 255, 3) * 0.7
+        vign = 1.0 - rng.uniform(0.0, 0.5) * (((yy - s / 2) ** 2 + (xx - s / 2) ** 2) / (s * s / 2.0))
+        base[i] = base[i] * vign[..., None] + rng.normal(0, rng.uniform(1, 10), (s, s, 3))
+    return np.clip(base, 0, 255).astype(np.uint8)
+
+
+# families that are NOT part of the built-in calibration set: the robustness tests evaluate on them
+HELD_OUT = ["text", "saturated", "photo"]
+
+_GEN = {"text": _text, "saturated": _saturated, "photo": _photo,
+        "stripes": _stripes, "checker": _checker, "dark": _dark, "bright": _bright, "tinted": _tinted, "noise": _noise,
+        "lowcontrast": _lowcontrast, "constant": _constant, "gradient": _gradient, "halfblack": _halfblack,
         "blobs": _blobs, "scene": _scene}
 
 

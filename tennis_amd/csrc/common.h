@@ -220,6 +220,20 @@ bool dense_block7_supported(int H, int W, int K0, int nl);
 Block7Image pack_block7(const std::vector<Block7Layer> &layers, int K0);
 int launch_dense_block7(const DenseBlock7Args &a, hipStream_t s);
 
+// The 14x14 dense block as one launch of pixel-owning waves with all weights streamed through an LDS ring (dense_block14.hip).
+struct DenseBlock14Args {
+  f16 *buf;                      // concat buffer [B][196][ldc]: reads channels [0,K0), appends [K0, K0 + 32 nl)
+  int ldc, K0, nl, B;
+  const unsigned char *stream;   // the block's weight stream (pack_block14)
+  int total_units;               // dense_block14_units(K0, nl)
+  unsigned long long *ts = nullptr;   // tuning hook: s_memtime per layer (64 per workgroup)
+};
+struct Block14Layer { const float *w1f /*[128][K], BN2 scale folded in*/, *w3 /*(32,128,3,3)*/, *s1, *t1 /*[K]*/, *t2 /*[128]*/; };
+bool dense_block14_supported(int H, int W, int K0, int nl);
+int dense_block14_units(int K0, int nl);
+std::vector<unsigned char> pack_block14(const std::vector<Block14Layer> &layers, int K0);
+int launch_dense_block14(const DenseBlock14Args &a, hipStream_t s);
+
 struct StemArgs {
   const void *x;
   int layout;         // tn_layout

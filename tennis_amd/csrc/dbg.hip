@@ -198,3 +198,59 @@ extern "C" void tn_dbg_block7_destroy(void *handle) {
   (void)hipFree(b->wa); (void)hipFree(b->wb); (void)hipFree(b->tab);
   delete b;
 }
+
+
+// ---- the streamed 14x14 dense block (dense_block14.hip) ----
+// same operand convention as tn_dbg_block7_create
+struct tn_dbg_block14 {
+  tn_ctx *ctx;
+  void *stream = nullptr;
+  DenseBlock14Args args;
+};
+
+extern "C" int tn_dbg_block14_create(tn_ctx *ctx, int K0, int nl, const float *w1_all, const float *s1_all, const float *t1_all,
+                                     const float *s2_all, const float *t2_all, const float *w3_all, void **out) {
+  TN_REQUIRE(ctx && w1_all && s1_all && t1_all && s2_all && t2_all && w3_all && out, "tn_dbg_block14_create: null argument");
+  TN_REQUIRE(dense_block14_supported(14, 14, K0, nl), "tn_dbg_block14_create: unsupported geometry");
+  TN_ON_DEVICE(ctx->device);
+  std::vector<std::vector<float>> folded(nl);
+  std::vector<Block14Layer> layers(nl);
+  size_t o1 = 0, ok = 0;
+  for (int l = 0; l < nl; ++l) {
+    const int K = K0 + 32 * l;
+    folded[l].resize((size_t)128 * K);
+    for (int n = 0; n < 128; ++n)
+      for (int k = 0; k < K; ++k) folded[l][(size_t)n * K + k] = w1_all[o1 + (size_t)n * K + k] * s2_all[(size_t)l * 128 + n];
+    layers[l] = Block14Layer{folded[l].data(), w3_all + (size_t)l * 32 * 128 * 9, s1_all + ok, t1_all + ok, t2_all + (size_t)l * 128};
+    o1 += (size_t)128 * K;
+    ok += K;
+  }
+  const std::vector<unsigned char> img = pack_block14(layers, K0);
+  tn_dbg_block14 *b = new tn_dbg_block14();
+  b->ctx = ctx;
+  if (hipMalloc(&b->stream, img.size()) != hipSuccess || hipMemcpy(b->stream, img.data(), img.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    tn_set_error("tn_dbg_block14_create: device allocation failed");
+    delete b;
+    return TN_ERR_NOMEM;
+  }
+  b->args = DenseBlock14Args{nullptr, 0, K0, nl, 0, (const unsigned char *)b->stream, dense_block14_units(K0, nl)};
+  *out = b;
+  return TN_OK;
+}
+
+extern "C" int tn_dbg_block14_run_ts(void *handle, void *buf_f16, int ldc, int B, unsigned long long *ts) {
+  tn_dbg_block14 *b = (tn_dbg_block14 *)handle;
+  TN_REQUIRE(b && buf_f16, "tn_dbg_block14_run: null argument");
+  TN_ON_DEVICE(b->ctx->device);
+  DenseBlock14Args a = b->args;
+  a.buf = (f16 *)buf_f16; a.ldc = ldc; a.B = B; a.ts = ts;
+  return launch_dense_block14(a, b->ctx->stream);
+}
+extern "C" int tn_dbg_block14_run(void *handle, void *buf_f16, int ldc, int B) { return tn_dbg_block14_run_ts(handle, buf_f16, ldc, B, nullptr); }
+
+extern "C" void tn_dbg_block14_destroy(void *handle) {
+  tn_dbg_block14 *b = (tn_dbg_block14 *)handle;
+  if (!b) return;
+  (void)hipFree(b->stream);
+  delete b;
+}

@@ -83,7 +83,10 @@ def _round_fp16_error_feedback(wf: np.ndarray, mean: np.ndarray) -> np.ndarray:
     return out
 
 
-def _round_fp16_vector_feedback(wf: np.ndarray, A: np.ndarray, sweeps: int = 3, ridge: float = 0.05) -> np.ndarray:
+_VEC_RIDGE, _VEC_SWEEPS = 0.05, 3
+
+
+def _round_fp16_vector_feedback(wf: np.ndarray, A: np.ndarray, sweeps: int | None = None, ridge: float | None = None) -> np.ndarray:
     """(N, K) float64 values -> fp16-representable values, each one of its two fp16 neighbours, chosen so that the rounding
     error of every output row is (nearly) orthogonal to ALL rows of ``A`` (F, K) at once - the mean input activations of F
     calibration frames - instead of to their average only (``_round_fp16_error_feedback``): minimises, per output row n,
@@ -91,6 +94,8 @@ def _round_fp16_vector_feedback(wf: np.ndarray, A: np.ndarray, sweeps: int = 3, 
     by ``sweeps`` passes of coordinate descent (each weight re-decided against the residual of all the others).  The ridge term
     keeps a weight on its nearest neighbour unless moving it buys something, which bounds what the conversion can do to frames
     whose activations lie outside the span of the calibration set (they see at most the plain-rounding error statistics)."""
+    sweeps = _VEC_SWEEPS if sweeps is None else sweeps
+    ridge = _VEC_RIDGE if ridge is None else ridge
     N, K = wf.shape
     F = A.shape[0]
     rtn = wf.astype(np.float16)
