@@ -44,6 +44,7 @@ PMC_KEYS = {"dense_layer_strip_56x56": ("dense_strip_56x56", "dense_strip_kernel
             "dense_layer_fused_56x56": ("dense_layer_56x56", "dense_layer_kernel<56"),
             "dense_layer_fused_28x28": ("dense_layer_28x28", "dense_layer_kernel<28"),
             "dense_block_chained_14x14": ("dense_block_14x14", "dense_layer_kernel<14"),
+            "dense_block_stream_14x14": ("dense_block14_kernel",),
             "dense_block_chained_7x7": ("dense_block_7x7", "dense_layer_kernel<7"),
             "dense_block_lds_7x7": ("dense_block7_kernel",),
             "stem_conv_bn_relu_maxpool": ("stem_pool_kernel",), "transition_conv1x1_avgpool": ("conv1x1_kernel",),

@@ -213,5 +213,45 @@ for v in [int(s) for s in args.variants.split(",")]:
         res.append(dict(k="b7", us=round(us, 1), tf=round(fl / us / 1e6, 1)))
         print(res[-1], flush=True)
         lib.tn_dbg_block7_destroy(h)
+    if "b14" in args.kernels:     # the streamed 14x14 dense block (dense_block14.hip) next to the chained tile kernel (dl14)
+        K0, nl = 256, 24
+        Ks = [K0 + 32 * l for l in range(nl)]
+        cat = lambda xs: np.ascontiguousarray(np.concatenate([x.ravel() for x in xs]))
+        w1 = cat([rng.normal(0, (2.0 / K) ** 0.5, (128, K)).astype(np.float32) for K in Ks])
+        s1 = cat([(rng.random(K) + 0.5).astype(np.float32) for K in Ks]); t1 = cat([rng.normal(0, 0.3, K).astype(np.float32) for K in Ks])
+        s2 = (rng.random((nl, 128)) + 0.5).astype(np.float32); t2 = rng.normal(0, 0.3, (nl, 128)).astype(np.float32)
+        w3 = rng.normal(0, 0.03, (nl, 32, 128, 3, 3)).astype(np.float32)
+        vp = lambda a_: a_.ctypes.data_as(C.c_void_p)
+        h = C.c_void_p()
+        _lib.check(lib.tn_dbg_block14_create(ctx.handle, K0, nl, vp(w1), vp(s1), vp(t1), vp(s2), vp(t2), vp(w3), C.byref(h)))
+        buf = torch.randn((B * 196, 1024), device="cuda", dtype=torch.float16)
+        fn = lambda: _lib.check(lib.tn_dbg_block14_run(h, _lib.ptr(buf), 1024, B))
+        us = timed(fn, args.iters)
+        fl = sum(2.0 * B * 196 * (128 * K + 32 * 1152) for K in Ks)
+        if args.stamps:
+            ts = torch.zeros((B * 160,), dtype=torch.int64, device="cuda")
+            _lib.check(lib.tn_dbg_block14_run_ts(h, _lib.ptr(buf), 1024, B, _lib.ptr(ts)))
+            torch.cuda.synchronize()
+            tall = ts.cpu().numpy().astype(np.float64)
+            t = tall[:B * 64].reshape(B, 64)
+            t2 = tall[B * 64:].reshape(B, 96)
+            if t2.any():      # a -DTN_B14_STAMPS build: per layer [start of tail, start of 3x3, end of 3x3]
+                nsu_ = [(K - 32 + 63) // 64 for K in Ks]
+                starts = np.concatenate([t[:, 63:64], t[:, :nl - 1]], axis=1)        # end of the previous layer's epilogue B
+                su = np.median(t2[:, 0::3][:, :nl] - starts, axis=0); tl = np.median(t2[:, 1::3][:, :nl] - t2[:, 0::3][:, :nl], axis=0)
+                bb = np.median(t2[:, 2::3][:, :nl] - t2[:, 1::3][:, :nl], axis=0); ep = np.median(t[:, :nl] - t2[:, 2::3][:, :nl], axis=0)
+                print("   ticks per slot: super-steps %s" % " ".join("%.0f" % (su[l] / (32 * nsu_[l])) for l in range(nl)))
+                print("                   tail (24)   %s" % " ".join("%.0f" % (tl[l] / 24) for l in range(nl)))
+                print("                   3x3 (144)   %s" % " ".join("%.0f" % (bb[l] / 144) for l in range(nl)))
+                print("   epilogue B (ticks)          %s" % " ".join("%.0f" % ep[l] for l in range(nl)))
+            d = np.diff(np.concatenate([t[:, 63:64], t[:, :nl]], axis=1), axis=1)
+            med = np.median(d, axis=0)
+            nsu = [(K - 32 + 63) // 64 for K in Ks]
+            print("   per layer (ticks, median over frames): prologue+l0 %d | %s" % (med[0], " ".join("%d" % x for x in med[1:])))
+            print("   ticks per MFMA slot (layer l: %s slots): %s" % ("32 nsu + 168", " ".join("%.1f" % (med[l] / (32 * nsu[l] + 168)) for l in range(1, nl))))
+            print("   whole kernel %d ticks" % np.median(t[:, 62] - t[:, 63]), flush=True)
+        res.append(dict(k="b14", us=round(us, 1), tf=round(fl / us / 1e6, 1)))
+        print(res[-1], flush=True)
+        lib.tn_dbg_block14_destroy(h)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(res, open("gpurun_out/kbench.json", "w"), indent=1)

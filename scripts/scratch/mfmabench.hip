@@ -2,6 +2,8 @@
 // (registers only), optionally with ds_read_b128 / VALU mixed in at the K-loop's ratios.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -60,7 +62,11 @@ void run(const char *name, int iters) {
            fl / ms / 1e9, c[0], c[0] / (ms * 1e6), (double)c[0] / iters);
   }
 }
-int main() {
+int main(int argc, char **argv) {
+  if (argc > 2 && !strcmp(argv[1], "loop")) {      // mfmabench loop <n>: n long MFMA-only launches back to back (scripts/power_trace.py)
+    for (int i = 0; i < atoi(argv[2]); ++i) run<0>("mfma only (long)", 400000);
+    return 0;
+  }
   run<0>("mfma only", 20000);
   run<1>("mfma + 16 ds_read", 20000);
   run<2>("mfma + ds_read + valu", 20000);

@@ -270,6 +270,9 @@ struct tn_encoder {
   float *ones128 = nullptr;
   bool block7 = true;         // a 7x7 block runs on the LDS-resident kernel of dense_block7.hip (TN_NO_BLOCK7 disables)
   DenseBlock7Args b7[4] = {};  // its packed operands per block (buf == nullptr: not packed)
+  bool block14 = true;        // a 14x14 block runs on the streamed kernel of dense_block14.hip (TN_NO_BLOCK14 disables)
+  DenseBlock14Args b14[4] = {};
+  f16 *b14_scratch[4] = {nullptr, nullptr, nullptr, nullptr};   // its k-step-major working copy of the block's frames
   hipStream_t side[4];
   hipEvent_t ev_in, ev_done[2][4];   // completion of the side streams, alternating per forward call
   bool pipelined = false;            // tn_densenet121_set_pipelined: the caller's stream is not made to wait inside forward
@@ -303,6 +306,7 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
   e->nsplit = getenv("TN_SPLIT") ? atoi(getenv("TN_SPLIT")) : 2;
   if (e->nsplit != 4) e->nsplit = 2;
   e->block7 = getenv("TN_NO_BLOCK7") == nullptr;
+  e->block14 = getenv("TN_NO_BLOCK14") == nullptr;
   e->chain = getenv("TN_NO_CHAIN") == nullptr;   // measured: -20% on the 14x14 / 7x7 blocks, +2.8% end to end
   e->dl_variant = getenv("TN_DL_VARIANT") ? atoi(getenv("TN_DL_VARIANT")) : 0;
   e->exact = (flags & TN_ENC_EXACT_WEIGHTS) != 0;
@@ -349,7 +353,8 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
   int outer = 1;
   for (int b = 0; b < 4; ++b) {
     const std::string sp = pre + "stage" + std::to_string(b + 1) + "_";
-    const bool pack7 = e->fuse && e->block7 && !e->exact && dense_block7_supported(e->Hb[b], e->Wb[b], e->Cin[b], kBlockCfg[b]);
+    const bool pack14 = e->fuse && e->block14 && !e->exact && dense_block14_supported(e->Hb[b], e->Wb[b], e->Cin[b], kBlockCfg[b]);
+    const bool pack7 = (e->fuse && e->block7 && !e->exact && dense_block7_supported(e->Hb[b], e->Wb[b], e->Cin[b], kBlockCfg[b])) || pack14;
     std::vector<std::vector<float>> h7[4];     // host copies for pack_block7: folded 1x1 weights, s1, t1, t2 per layer
     std::vector<const float *> h7w3;
     for (int l = 0; l < kBlockCfg[b]; ++l) {
@@ -394,7 +399,15 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
       if (L.w1s) L.w3s = e->pool.upload(pack_w3_strip(w3));
       e->layers[b].push_back(L);
     }
-    if (pack7) {
+    if (pack14) {
+      std::vector<Block14Layer> bl;
+      for (int l = 0; l < kBlockCfg[b]; ++l)
+        bl.push_back(Block14Layer{h7[0][l].data(), h7w3[l], h7[1][l].data(), h7[2][l].data(), h7[3][l].data()});
+      DenseBlock14Args &a14 = e->b14[b];
+      a14.stream = e->pool.upload(pack_block14(bl, e->Cin[b]));
+      a14.total_units = dense_block14_units(e->Cin[b], kBlockCfg[b]);
+      a14.ldc = e->Cb[b]; a14.K0 = e->Cin[b]; a14.nl = kBlockCfg[b];
+    } else if (pack7) {
       std::vector<Block7Layer> bl;
       for (int l = 0; l < kBlockCfg[b]; ++l)
         bl.push_back(Block7Layer{h7[0][l].data(), h7w3[l], h7[1][l].data(), h7[2][l].data(), h7[3][l].data()});
@@ -429,8 +442,18 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
   e->bott = (f16 *)e->pool.alloc(B * e->Hb[0] * e->Wb[0] * 128 * sizeof(f16));
   for (int b = 0; b < 4; ++b)
     e->blockbuf[b] = (f16 *)e->pool.alloc(B * e->Hb[b] * e->Wb[b] * e->Cb[b] * sizeof(f16));
+  for (int b = 0; b < 4; ++b)
+    if (e->b14[b].stream) e->b14_scratch[b] = (f16 *)e->pool.alloc(B * dense_block14_scratch_halfs() * sizeof(f16));
   e->workspace_bytes = e->pool.bytes - weights_bytes;
   if (e->pool.failed) { tn_set_error("device allocation failed"); return fail(TN_ERR_NOMEM); }
+  // dense_block14.hip reads the 32 channels a layer is about to write as the zero-weighted pad of its last 64-channel super-step:
+  // whatever is there must be finite, so the buffer does not start as whatever the allocator left in it
+  for (int b = 0; b < 4; ++b)
+    if (e->b14[b].stream && (hipMemset(e->blockbuf[b], 0, B * e->Hb[b] * e->Wb[b] * e->Cb[b] * sizeof(f16)) != hipSuccess ||
+                             hipMemset(e->b14_scratch[b], 0, B * dense_block14_scratch_halfs() * sizeof(f16)) != hipSuccess)) {
+      tn_set_error("hipMemset failed");
+      return fail(TN_ERR_HIP);
+    }
   *out = e;
   return TN_OK;
 }
@@ -483,7 +506,21 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
     const int Hh = e->Hb[b], Ww = e->Wb[b];
     const int M = B * Hh * Ww;
     const bool fused = !cal && e->fuse && dense_layer_supported(Hh, Ww);
-    if (!cal && e->b7[b].wa && e->dl_variant == 0) {
+    if (!cal && e->b14[b].stream && e->dl_variant == 0) {
+      // pixel-owning waves, all weights streamed through an LDS ring (dense_block14.hip)
+      DenseBlock14Args a14 = e->b14[b];
+      a14.buf = bbuf[b]; a14.B = B;
+      a14.scratch = e->b14_scratch[b] + (size_t)b0 * dense_block14_scratch_halfs();
+      double fl = 0, by = 0;
+      for (auto &L : e->layers[b]) {
+        fl += 2.0 * M * (128.0 * L.cin + 32.0 * 1152);
+        by += (double)M * (L.cin + 32) * 2 + 128.0 * L.cin * 2 + 32.0 * 1152 * 2;
+      }
+      tm.begin("dense_block_stream_14x14", fl, by);
+      rc = launch_dense_block14(a14, s);
+      tm.end();
+      if (rc) return rc;
+    } else if (!cal && e->b7[b].wa && e->dl_variant == 0) {
       // the frame's concat buffer stays in LDS for the whole block; only the weights stream (dense_block7.hip)
       DenseBlock7Args a7 = e->b7[b];
       a7.buf = bbuf[b]; a7.B = B;

@@ -226,11 +226,13 @@ struct DenseBlock14Args {
   int ldc, K0, nl, B;
   const unsigned char *stream;   // the block's weight stream (pack_block14)
   int total_units;               // dense_block14_units(K0, nl)
+  f16 *scratch = nullptr;        // B x dense_block14_scratch_halfs(): the kernel's k-step-major working copy of the frames
   unsigned long long *ts = nullptr;   // tuning hook: s_memtime per layer (64 per workgroup)
 };
 struct Block14Layer { const float *w1f /*[128][K], BN2 scale folded in*/, *w3 /*(32,128,3,3)*/, *s1, *t1 /*[K]*/, *t2 /*[128]*/; };
 bool dense_block14_supported(int H, int W, int K0, int nl);
 int dense_block14_units(int K0, int nl);
+size_t dense_block14_scratch_halfs();   // per frame
 std::vector<unsigned char> pack_block14(const std::vector<Block14Layer> &layers, int K0);
 int launch_dense_block14(const DenseBlock14Args &a, hipStream_t s);
 

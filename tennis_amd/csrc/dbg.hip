@@ -204,7 +204,8 @@ extern "C" void tn_dbg_block7_destroy(void *handle) {
 // same operand convention as tn_dbg_block7_create
 struct tn_dbg_block14 {
   tn_ctx *ctx;
-  void *stream = nullptr;
+  void *stream = nullptr, *scratch = nullptr;
+  int scratch_frames = 0;
   DenseBlock14Args args;
 };
 
@@ -242,8 +243,18 @@ extern "C" int tn_dbg_block14_run_ts(void *handle, void *buf_f16, int ldc, int B
   tn_dbg_block14 *b = (tn_dbg_block14 *)handle;
   TN_REQUIRE(b && buf_f16, "tn_dbg_block14_run: null argument");
   TN_ON_DEVICE(b->ctx->device);
+  if (b->scratch_frames < B) {
+    (void)hipFree(b->scratch);
+    b->scratch = nullptr; b->scratch_frames = 0;
+    if (hipMalloc(&b->scratch, (size_t)B * dense_block14_scratch_halfs() * sizeof(f16)) != hipSuccess) {
+      tn_set_error("tn_dbg_block14_run: device allocation failed");
+      return TN_ERR_NOMEM;
+    }
+    b->scratch_frames = B;
+    TN_HIP_CHECK(hipMemset(b->scratch, 0, (size_t)B * dense_block14_scratch_halfs() * sizeof(f16)));
+  }
   DenseBlock14Args a = b->args;
-  a.buf = (f16 *)buf_f16; a.ldc = ldc; a.B = B; a.ts = ts;
+  a.buf = (f16 *)buf_f16; a.ldc = ldc; a.B = B; a.ts = ts; a.scratch = (f16 *)b->scratch;
   return launch_dense_block14(a, b->ctx->stream);
 }
 extern "C" int tn_dbg_block14_run(void *handle, void *buf_f16, int ldc, int B) { return tn_dbg_block14_run_ts(handle, buf_f16, ldc, B, nullptr); }
@@ -252,5 +263,6 @@ extern "C" void tn_dbg_block14_destroy(void *handle) {
   tn_dbg_block14 *b = (tn_dbg_block14 *)handle;
   if (!b) return;
   (void)hipFree(b->stream);
+  (void)hipFree(b->scratch);
   delete b;
 }

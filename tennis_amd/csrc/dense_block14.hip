@@ -37,8 +37,11 @@
 
 #include "common.h"
 
+#ifndef TN_B14_STAMPS
+#define TN_B14_STAMPS 0   // tuning build: wave 0 also stamps the start of every layer's tail and 3x3 phase and the end of its 3x3 phase (ts[64 ..])
+#endif
 #ifndef TN_B14_EXP
-#define TN_B14_EXP 0   // timing experiments only (results wrong): bit 0 no ring loads, bit 1 no 3x3 phase, bit 2 no BN items, bit 3 no DMA
+#define TN_B14_EXP 0   // timing experiments only (results wrong): bit 0 no ring loads, bit 1 no 3x3 phase, bit 2 no BN items, bit 3 no DMA, bit 4 ring loads read 1 KiB contiguous per instruction
 #endif
 
 namespace {
@@ -53,6 +56,8 @@ constexpr int kTileRowB = 4096;                   // 16 slots x 256 B (128 bottl
 constexpr int kTileRows = 18;                     // row 0: zeros above the image, 1 .. 14 the image, 15: zeros below, 16 / 17: wave 3's rows that do not exist
 constexpr int kTileBytes = kTileRows * kTileRowB;
 constexpr int kLdsBytes = kTileBytes + kNR * kUnitBytes;
+constexpr int kPlaneB = 196 * 32;                 // one k-step (16 channels) of a frame in the private k-step-major copy
+constexpr int kFrameScrB = 64 * kPlaneB;          // 1024 channels
 static_assert(kLdsBytes <= 160 * 1024, "LDS");
 
 // s_waitcnt vmcnt(N) constants (asm loads only; tests/test_cpu_block14.py derives every one of them from the issue order)
@@ -121,8 +126,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (a.ts && tid == 0) a.ts[(size_t)blockIdx.x * 64 + 63] = __builtin_amdgcn_s_memtime();
 
   // ---- per-lane geometry: fragment F (0 = X, 1 = Y) holds row r0 + F + 2 st, column slot16 - 1 ----
-  unsigned voff[2];          // byte offset of the lane's pixel (+ 64 h: the lane's half of a 128-byte super-step line)
-  unsigned soff[2];          // store offset of the lane's 32 output bytes (without the layer's 2 K); invalid slots: out of range
+  // The block works on a PRIVATE copy of the frame in k-step-major layout, scr[k-step = channel / 16][pixel][16 channels]: a
+  // fragment load (lane = (pixel slot, half of the k-step), 16 B) then reads two runs of 448 contiguous bytes (eight 128-byte
+  // lines) instead of 32 B out of each of 32 lines of the NHWC buffer - the texture-address path, not HBM, bounded the first
+  // version of this kernel (and bounds the strip kernel): 72-81 cycles per MFMA slot in the 1x1 phase, 52-56 with contiguous
+  // loads (TN_B14_EXP bit 4).  Channels 0 .. K0 - 1 are copied there in the prologue, every layer appends its 32 channels to
+  // both copies (the NHWC buffer is what the transition reads).
+  unsigned voff[2];          // scr: byte offset of the lane's 16 B inside a k-step plane
+  unsigned noff[2];          // NHWC: byte offset of the lane's pixel
+  unsigned soff[2], sscr[2]; // store offsets of the lane's 32 output bytes: NHWC (without the layer's 2 K) / scr (k-step h of the pair); invalid slots: out of range
   bool valid[2];
   const int col = slot16 < 1 ? 0 : (slot16 > 14 ? 13 : slot16 - 1);
 #pragma unroll
@@ -130,23 +142,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int row = r0 + f + 2 * st;
     const int rowc = row > 13 ? 13 : row;
     valid[f] = row < 14 && slot16 >= 1 && slot16 <= 14;
-    const unsigned pix = (unsigned)(rowc * 14 + col) * ldc * 2;
-    voff[f] = pix + 64 * h;
-    soff[f] = valid[f] ? pix + 32 * h : 0x80000000u;
+    const unsigned px = (unsigned)(rowc * 14 + col);
+    noff[f] = px * ldc * 2;
+    voff[f] = px * 32 + 16 * h;
+    soff[f] = valid[f] ? noff[f] + 32 * h : 0x80000000u;
+    sscr[f] = valid[f] ? px * 32 + (unsigned)h * kPlaneB : 0x80000000u;
   }
+  unsigned char *scr = (unsigned char *)a.scratch + (size_t)blockIdx.x * kFrameScrB;
+  const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(scr, 0, (int)kFrameScrB, 0x00020000);
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(fb, 0, (int)(196u * ldc * 2), 0x00020000);
   // the pixel fragment of the shift k-step: (1, 1, mask, 0 ...) in the lanes that hold k = 0 .. 7; mask = -60000 where the slot is padding
-  u32x4 xb_shift[2];
-#pragma unroll
-  for (int f = 0; f < 2; ++f) xb_shift[f] = u32x4{h == 0 ? 0x3c003c00u : 0u, (h == 0 && !valid[f]) ? 0x0000fb53u : 0u, 0u, 0u};
-  // bottleneck tile: cell of (row R, slot, tuple T, half h) at R * 4096 + slot * 256 + ((2 T + h) ^ slot) * 16; a lane's eight
-  // tuple addresses for its strip of fragment X with dy = -1 (row R = r0 + 2 st): fragment F, kernel row dy add (F + dy + 1) * 4096
-  unsigned lt[8];
-  {
-    const unsigned base = (unsigned)(r0 + 2 * st) * kTileRowB + slot16 * 256 + (((unsigned)(slot16 ^ h)) << 4);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) lt[t] = base ^ (32u * t);
-  }
+  // (a padding column, or one of wave 3's rows 14 / 15: the same lanes in both fragments)
+  const u32x4 xb_shift = u32x4{h == 0 ? 0x3c003c00u : 0u, (h == 0 && !valid[0]) ? 0x0000fb53u : 0u, 0u, 0u};
+  // bottleneck tile: cell of (row R, slot, tuple T, half h) at R * 4096 + slot * 256 + ((2 T + h) ^ slot) * 16 = lt0 ^ 32 T for the
+  // lane's strip of fragment X with dy = -1 (row R = r0 + 2 st): fragment F, kernel row dy add (F + dy + 1) * 4096
+  const unsigned lt0 = (unsigned)(r0 + 2 * st) * kTileRowB + slot16 * 256 + (((unsigned)(slot16 ^ h)) << 4);
   const unsigned lane16 = lane * 16, lane4 = lane * 4;
 
   // ================= the weight stream =================
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   u32x4 xb[2][2];        // BN1 + ReLU'd pixel fragments [k-step parity][fragment]: produced one k-step ahead of the MFMAs
   u32x4 wa[4];           // 1x1 weight fragments [32-channel block]: reloaded for the next k-step behind the block's second MFMA
   u32x4 wsh[2];          // ... of the shift k-step [block parity]
-  float4 cb[2];          // BN1 constants (s0, s1, t0, t1) of dword J of the k-step in production [J parity]
+  float4 cb[2];          // BN1 constants (s0, s1, t0, t1) of dword J of the k-step in production [J parity]; reloaded for dword J + 2 behind the dword's second item
   f32x16 acc[4][2];      // 1x1 accumulators [block][fragment]
   u32x4 fwd[2][2];       // the newest 32 channels, raw fp16 [fragment][k-step]: channels K - 32 + 16 h + 8 k .. + 7 of the lane's pixel
   u32x4 w3f[2][3];       // 3x3 weight fragments [step parity][dx]
@@ -196,12 +206,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   f32x16 bacc[3][2];     // 3x3 accumulators [dx][fragment]
 
   // ---- ring: asm loads into literal registers + counted waits ----
-  const unsigned char *rb_a = fb, *rb_b = fb;     // frame base + 128 * (super-step index) of the two refill targets of an interval
+  const unsigned char *rb_a = scr, *rb_b = scr;   // scr + 4 planes * (super-step index) of the two refill targets of an interval
   auto ring_load = [&](auto rs_tag, auto k_tag, auto f_tag, const unsigned char *base) TN_INL {
     constexpr int KQ = decltype(k_tag)::value, F = decltype(f_tag)::value, R = ring_reg(decltype(rs_tag)::value, KQ, F);
     if (TN_B14_EXP & 1) return;
-    const unsigned vo = voff[F];
-    asm volatile("global_load_dwordx4 v[%c0:%c1], %2, %3 offset:%c4" ::"n"(R), "n"(R + 3), "v"(vo), "s"(base), "n"(16 * KQ) : TN_RING_CLOBBER);
+    const unsigned vo = (TN_B14_EXP & 16) ? lane16 + (unsigned)(wid * 8 + F * 4 + KQ) * 1024u : voff[F];
+    const unsigned char *pb = base + KQ * kPlaneB;
+    asm volatile("global_load_dwordx4 v[%c0:%c1], %2, %3" ::"n"(R), "n"(R + 3), "v"(vo), "s"(pb) : TN_RING_CLOBBER);
   };
   auto ring_wait = [&](auto rs_tag, auto k_tag) TN_INL { asm volatile("s_waitcnt vmcnt(%c0)" ::"n"(kVmRing) : TN_RING_CLOBBER); };
   // BN1 + ReLU of one dword (two channels) of a pixel fragment: fp16 in, fp32 fma, one rounding, packed max (dense_strip_impl.h)
@@ -276,18 +287,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         } else {
           if (!(TN_B14_EXP & 4)) xb[0][BF][J] = bn_dword(fwd[BF][0][J], ic<J>{});
         }
-        // constants two items (one dword) ahead: dword J + 1 of the same k-step, or dword 0 of the k-step after it
-        if constexpr (BF == 0) {
-          if constexpr (J < 3) {
-            if constexpr (Q < 3) consts_read(vc_cur, ic<Q + 1>{}, ic<J + 1>{});
-            else consts_read(vc_next, ic<0>{}, ic<J + 1>{});
+        // behind a dword's second item its constant register is free: the constants two dwords on (three slots ahead of their
+        // first use) - of this k-step, or dwords 0 / 1 of the k-step produced next
+        if constexpr (BF == 1) {
+          if constexpr (J < 2) {
+            if constexpr (Q < 3) consts_read(vc_cur, ic<Q + 1>{}, ic<J + 2>{});
+            else consts_read(vc_next, ic<0>{}, ic<J + 2>{});
           } else {
-            if constexpr (Q < 2) consts_read(vc_cur, ic<Q + 2>{}, ic<0>{});
-            else if constexpr (Q == 2) consts_read(vc_next, ic<0>{}, ic<0>{});
-            else consts_read(vc_next, ic<1>{}, ic<0>{});      // (q = 3: the next unit's k-step 1, produced during its k-step 0)
+            if constexpr (Q < 2) consts_read(vc_cur, ic<Q + 2>{}, ic<J - 2>{});
+            else consts_read(vc_next, ic<Q - 2>{}, ic<J - 2>{});
           }
         }
       }
+      if constexpr (LAST && Q == 3) TN_RING_FENCE();      // (no ring statement in these slots)
       if constexpr (E == 7) {
         if constexpr (Q == 0) dma_pair(ic<0>{});
         else if constexpr (Q == 1) dma_pair(ic<1>{});
@@ -312,7 +324,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const float a0 = accr[MB][F][R0 + 2 * I], a1 = accr[MB][F][R0 + 2 * I + 1];
       asm("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_f16 %0, %0, 0" : "=v"(epk[I]) : "v"(a0), "v"(a1));
     } else {
-      *(u32x4 *)(smem + lt[T] + (F + 1) * kTileRowB) = u32x4{epk[0], epk[1], epk[2], epk[3]};
+      *(u32x4 *)(smem + (lt0 ^ (32u * T)) + (F + 1) * kTileRowB) = u32x4{epk[0], epk[1], epk[2], epk[3]};
     }
   };
   auto w3_read = [&](auto s_tag, auto dx_tag, const unsigned vb) TN_INL {      // fragment (step S, dx) = fragment 3 (S & 3) + dx of its unit
@@ -322,7 +334,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   auto bop_read = [&](auto s_tag, auto f_tag) TN_INL {       // pixel fragment of step S = (dy index, tuple): kernel rows in the order 0, -1, +1
     constexpr int S = decltype(s_tag)::value, F = decltype(f_tag)::value, DYI = S / 8, T = S % 8;
     constexpr int DY = DYI == 0 ? 0 : (DYI == 1 ? -1 : 1);
-    bop[S & 1][F] = *(const u32x4 *)(smem + lt[T] + (F + DY + 1) * kTileRowB);
+    bop[S & 1][F] = *(const u32x4 *)(smem + (lt0 ^ (32u * T)) + (F + DY + 1) * kTileRowB);
   };
   auto tail_interval = [&]() TN_INL {
     begin_interval(ic<kVmDmaTail>{});
@@ -331,7 +343,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       acc[MB][F] = mfma32(wa[MB], xb[0][F], acc[MB][F]);
       if constexpr (F == 1) wa_read(ic<MB>{}, vb_cur, ic<1>{});
       if (!(TN_B14_EXP & 4)) xb[1][BF][J] = bn_dword(fwd[BF][1][J], ic<J>{});
-      if constexpr (BF == 0 && J < 3) consts_read(vc_cur, ic<1>{}, ic<J + 1>{});
+      if constexpr (BF == 1 && J < 2) consts_read(vc_cur, ic<1>{}, ic<J + 2>{});
       if constexpr (I == 5) wsh[0] = *(const u32x4 *)(smem + vb_cur + (2 * 4 + 0) * 1024);
       if constexpr (I == 7) dma_pair(ic<0>{});
       TN_RING_FENCE();
@@ -340,7 +352,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     static_for<16>([&](auto i_tag) TN_INL {       // k-step B and the shift k-step, block by block
       constexpr int I = decltype(i_tag)::value, MB = I >> 2, SH = (I >> 1) & 1, F = I & 1;
       if constexpr (SH == 0) acc[MB][F] = mfma32(wa[MB], xb[1][F], acc[MB][F]);
-      else acc[MB][F] = mfma32(wsh[MB & 1], xb_shift[F], acc[MB][F]);
+      else acc[MB][F] = mfma32(wsh[MB & 1], xb_shift, acc[MB][F]);
       if constexpr ((I & 3) == 1 && MB < 3) wsh[(MB + 1) & 1] = *(const u32x4 *)(smem + vb_cur + (2 * 4 + MB + 1) * 1024);
       if constexpr (MB >= 1) {        // epilogue A of block MB - 1: 20 items over 4 slots
         static_for<5>([&](auto k_tag) TN_INL { epa_item(ic<MB - 1>{}, ic<(I & 3) * 5 + decltype(k_tag)::value>{}); });
@@ -362,20 +374,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // The barrier of J = 1 publishes the tile (kernel row -1, the first that needs the neighbours' rows, starts in J = 2; its reads are issued one step ahead).
   auto pre_item = [&](auto pn_tag, auto i_tag) TN_INL {      // the next layer's k-step 0 (ring slot PN): constants, 8 BN items, weights
     constexpr int PN = decltype(pn_tag)::value, I = decltype(i_tag)::value;
-    // item 0: constants of dword 0; 1 - 8: BN items (J, fragment) with the constants of dword J + 1 behind the first of a pair, the
-    // ring refills behind dword 3; 9 - 12: weight fragments of k-step 0; 13: constants of k-step 1, dword 0
-    if constexpr (I == 0) {
-      consts_read(vc_next, ic<0>{}, ic<0>{});
-    } else if constexpr (I < 9) {
-      constexpr int E = I - 1, J = E >> 1, BF = E & 1;
+    // items 0, 1: constants of k-step 0, dwords 0 / 1; 2 - 9: BN items (dword, fragment), behind a dword's second item the constants
+    // two dwords on (dwords 0 / 1 of k-step 1 at the end) and behind dword 3 the ring refills; 10 - 13: weight fragments of k-step 0
+    if constexpr (I < 2) {
+      consts_read(vc_next, ic<0>{}, ic<I>{});
+    } else if constexpr (I < 10) {
+      constexpr int E = I - 2, J = E >> 1, BF = E & 1;
       if constexpr (E == 0) ring_wait(ic<PN>{}, ic<0>{});
       if (!(TN_B14_EXP & 4)) xb[0][BF][J] = bn_ring(ic<ring_reg(PN, 0, BF) + J>{}, ic<J>{});
       if constexpr (J == 3) ring_load(ic<PN>{}, ic<0>{}, ic<BF>{}, rb_a);
-      if constexpr (BF == 0 && J < 3) consts_read(vc_next, ic<0>{}, ic<J + 1>{});
-    } else if constexpr (I < 13) {
-      wa_read(ic<I - 9>{}, vb_next, ic<0>{});
+      if constexpr (BF == 1) {
+        if constexpr (J < 2) consts_read(vc_next, ic<0>{}, ic<J + 2>{});
+        else consts_read(vc_next, ic<1>{}, ic<J - 2>{});
+      }
     } else {
-      consts_read(vc_next, ic<1>{}, ic<0>{});
+      wa_read(ic<I - 10>{}, vb_next, ic<0>{});
     }
   };
   constexpr int kPreItems = 14;
@@ -433,11 +446,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         c1 += dpp_f32<0x101>(bacc[2][f][2 * p + 1]);
         const h2_t pk = {(f16)c0, (f16)c1};
         o[p] = __builtin_bit_cast(unsigned, pk);
+        TN_RING_FENCE();      // (the ring holds the next layer's first super-steps: no temporaries in its registers)
       }
       fwd[f][0] = u32x4{o[0], o[1], o[2], o[3]};
       fwd[f][1] = u32x4{o[4], o[5], o[6], o[7]};
       __builtin_amdgcn_raw_buffer_store_b128(fwd[f][0], orsrc, soff[f], 2 * K, 0);
       __builtin_amdgcn_raw_buffer_store_b128(fwd[f][1], orsrc, soff[f] + 16, 2 * K, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(fwd[f][0], srsrc, sscr[f], (K >> 4) * kPlaneB, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(fwd[f][1], srsrc, sscr[f] + 16, (K >> 4) * kPlaneB, 0);
     }
   };
 
@@ -456,14 +472,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       dma_consts();
       advance_dma();
     }
+    // channels 0 .. K0 - 1 of this wave's pixels: NHWC -> the k-step-major copy (a wave only ever reads its own pixels' planes)
+    for (int q = 0; q < a.K0 / 16; ++q)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const u32x4 v = *(const u32x4 *)(fb + noff[f] + 32 * q + 16 * h);
+        if (valid[f]) *(u32x4 *)(scr + (size_t)q * kPlaneB + voff[f]) = v;
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // the first layer's ring: super-steps 0 (slot 0) and 1 (slot 1); its "forwarded" channels K0 - 32 .. K0 - 1 from memory
     static_for<16>([&](auto i_tag) TN_INL {
       constexpr int I = decltype(i_tag)::value;
-      ring_load(ic<(I >> 3)>{}, ic<((I >> 1) & 3)>{}, ic<(I & 1)>{}, fb + 128 * (I >> 3));
+      ring_load(ic<(I >> 3)>{}, ic<((I >> 1) & 3)>{}, ic<(I & 1)>{}, scr + 4 * kPlaneB * (I >> 3));
     });
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
-      const unsigned char *p = fb + (voff[f] - 64 * h) + 2 * (a.K0 - 32) + 32 * h;
+      const unsigned char *p = fb + noff[f] + 2 * (a.K0 - 32) + 32 * h;
       fwd[f][0] = *(const u32x4 *)p;
       fwd[f][1] = *(const u32x4 *)(p + 16);
     }
@@ -472,7 +496,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     vb_next = kTileBytes + lane16;                 // the head of the pipeline reads unit 0 as "the next unit" of an interval that does not exist
     vc_next = kTileBytes + kUnitFrag + 64 * h;
     nxt = kTileBytes + kUnitBytes;                 // ... and interval 0 will find unit 1 there
-    rb_a = fb + 128 * 2;                         // its refill: super-step 2, k-step 0
+    rb_a = scr + 4 * kPlaneB * 2;                // its refill: super-step 2, k-step 0
     static_for<kPreItems>([&](auto i_tag) TN_INL { pre_item(ic<0>{}, i_tag); });
     TN_SB();
   }
@@ -487,8 +511,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // layer's last one: the next layer's, same addresses - a pixel's channels do not move)
     auto refill_bases = [&](int u) TN_INL {
       const int ua = u + 2 < nsu ? u + 2 : u + 2 - nsu, ub = u + 3 < nsu ? u + 3 : u + 3 - nsu;
-      rb_a = fb + 128 * ua;
-      rb_b = fb + 128 * ub;
+      rb_a = scr + 4 * kPlaneB * ua;
+      rb_b = scr + 4 * kPlaneB * ub;
     };
     auto front = [&](auto p_tag) TN_INL {
       constexpr int P = decltype(p_tag)::value;
@@ -513,16 +537,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     if (par) front(ic<1>{});
     else front(ic<0>{});
+    if (TN_B14_STAMPS && a.ts && tid == 0) a.ts[(size_t)gridDim.x * 64 + (size_t)blockIdx.x * 96 + 3 * l] = __builtin_amdgcn_s_memtime();
     tail_interval();
+    if (TN_B14_STAMPS && a.ts && tid == 0) a.ts[(size_t)gridDim.x * 64 + (size_t)blockIdx.x * 96 + 3 * l + 1] = __builtin_amdgcn_s_memtime();
     b_interval(ic<0>{}, ic<0>{}, ic<kVmDmaB0>{});
     b_interval(ic<1>{}, ic<0>{}, ic<kVmDmaB>{});
     b_interval(ic<2>{}, ic<0>{}, ic<kVmDmaB>{});
     b_interval(ic<3>{}, ic<0>{}, ic<kVmDmaB>{});
     b_interval(ic<4>{}, ic<0>{}, ic<kVmDmaB>{});
     par = (par + nsu) & 1;
-    rb_a = fb + 128 * (2 < nsu_next ? 2 : 0);    // the head of the next layer's pipeline refills its super-step 2, k-step 0
+    rb_a = scr + 4 * kPlaneB * (2 < nsu_next ? 2 : 0);    // the head of the next layer's pipeline refills its super-step 2, k-step 0
     if (par) b_interval(ic<5>{}, ic<1>{}, ic<kVmDmaB>{});
     else b_interval(ic<5>{}, ic<0>{}, ic<kVmDmaB>{});
+    if (TN_B14_STAMPS && a.ts && tid == 0) a.ts[(size_t)gridDim.x * 64 + (size_t)blockIdx.x * 96 + 3 * l + 2] = __builtin_amdgcn_s_memtime();
     epilogue_b(K);
     if (a.ts && tid == 0 && l < 62) a.ts[(size_t)blockIdx.x * 64 + l] = __builtin_amdgcn_s_memtime();
   }
@@ -542,8 +569,10 @@ int dense_block14_units(int K0, int nl) {      // (with the four units of paddin
   return n;
 }
 
+size_t dense_block14_scratch_halfs() { return (size_t)kFrameScrB / 2; }
+
 int launch_dense_block14(const DenseBlock14Args &a, hipStream_t s) {
-  TN_REQUIRE(a.buf && a.stream, "dense_block14: null operand");
+  TN_REQUIRE(a.buf && a.stream && a.scratch, "dense_block14: null operand");
   TN_REQUIRE(dense_block14_supported(14, 14, a.K0, a.nl) && a.ldc % 64 == 0 && a.K0 + 32 * a.nl <= a.ldc, "dense_block14: unsupported geometry");
   TN_REQUIRE(a.total_units == dense_block14_units(a.K0, a.nl), "dense_block14: stream does not match the block");
   TN_HIP_CHECK(hipFuncSetAttribute((const void *)dense_block14_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
@@ -555,9 +584,9 @@ int launch_dense_block14(const DenseBlock14Args &a, hipStream_t s) {
 // ---- host-side packing: the block's weight stream ----
 // Per layer (K input channels, G = K - 32 of them read from memory): ceil(G / 64) super-step units, the tail unit, six 3x3 units;
 // every unit is kUnitBytes = 16 fragments [64 lanes][8 halfs] + 128 floats of BN1 constants.
-//   super-step unit u: fragment (q, mb): lane l, j: bottleneck channel 32 mb + (l & 31), input channel c = 64 u + 32 (l >> 5) +
-//     8 q + j (zero weight and zero constants for c >= G: the pad half of the last super-step is the forwarded channels, which
-//     the tail takes); constants (q, h): s1[c .. c + 7] | t1[c .. c + 7] for c = 64 u + 32 h + 8 q
+//   super-step unit u: fragment (q, mb): lane l, j: bottleneck channel 32 mb + (l & 31), input channel c = 64 u + 16 q + 8 (l >> 5)
+//     + j (zero weight and zero constants for c >= G: the pad half of the last super-step is the forwarded channels, which
+//     the tail takes); constants (q, h), dword J: s1[c + 2 J], s1[c + 2 J + 1], t1[c + 2 J], t1[c + 2 J + 1] for c = 64 u + 16 q + 8 h
 //   tail unit: k-step 0 / 1: input channel G + 16 (l >> 5) + 8 ks + j (the order in which the previous layer's 3x3 leaves its 32
 //     output channels in registers); k-step 2: the shift k-step of dense_strip.hip (fp16 hi + lo of BN2's shift, and 1 for the mask)
 //   3x3 unit J: fragments (step 4 J + s, dx), s = 0 .. 3: kernel rows in the order ky = 1, 0, 2, tuple t = step % 8; lane layout as
@@ -577,14 +606,14 @@ std::vector<unsigned char> pack_block14(const std::vector<Block14Layer> &layers,
           f16 *d = frag(unit, q * 4 + mb);
           for (int ln = 0; ln < 64; ++ln)
             for (int j = 0; j < 8; ++j) {
-              const int c = 64 * u + 32 * (ln >> 5) + 8 * q + j;
+              const int c = 64 * u + 16 * q + 8 * (ln >> 5) + j;
               d[ln * 8 + j] = c < G ? (f16)L.w1f[(size_t)(32 * mb + (ln & 31)) * K + c] : (f16)0.f;
             }
         }
         for (int h = 0; h < 2; ++h) {
           float *d = cons(unit, q, h);
           for (int j = 0; j < 8; ++j) {
-            const int c = 64 * u + 32 * h + 8 * q + j;
+            const int c = 64 * u + 16 * q + 8 * h + j;
             d[4 * (j >> 1) + (j & 1)] = c < G ? L.s1[c] : 0.f;
             d[4 * (j >> 1) + 2 + (j & 1)] = c < G ? L.t1[c] : 0.f;
           }
