@@ -336,33 +336,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int DY = DYI == 0 ? 0 : (DYI == 1 ? -1 : 1);
     bop[S & 1][F] = *(const u32x4 *)(smem + (lt0 ^ (32u * T)) + (F + DY + 1) * kTileRowB);
   };
+  // epilogue A item k (0 .. 19) of block MB, `n` of them from K0 on
+  auto epa_items = [&](auto mb_tag, auto k0_tag, auto n_tag) TN_INL {
+    static_for<decltype(n_tag)::value>([&](auto k_tag) TN_INL { epa_item(mb_tag, ic<decltype(k0_tag)::value + decltype(k_tag)::value>{}); });
+  };
+  // 24 slots: k-step A (its slots carry BN1 of k-step B), k-step B, the shift k-step - each in block order, so that an
+  // accumulator is touched every 8th slot (back-to-back MFMAs on one accumulator wait for each other: the first version ran
+  // k-step B and the shift k-step of a block right behind each other, 100 cycles per slot).  Block 0 is final after slot 17: its
+  // epilogue A (convert + ReLU + the tile write of tuples 0, 1) runs under slots 18 - 22; the other blocks' under the first 3x3 slots.
   auto tail_interval = [&]() TN_INL {
     begin_interval(ic<kVmDmaTail>{});
-    static_for<8>([&](auto i_tag) TN_INL {        // k-step A
-      constexpr int I = decltype(i_tag)::value, MB = I >> 1, F = I & 1, J = I >> 1, BF = I & 1;
-      acc[MB][F] = mfma32(wa[MB], xb[0][F], acc[MB][F]);
-      if constexpr (F == 1) wa_read(ic<MB>{}, vb_cur, ic<1>{});
-      if (!(TN_B14_EXP & 4)) xb[1][BF][J] = bn_dword(fwd[BF][1][J], ic<J>{});
-      if constexpr (BF == 1 && J < 2) consts_read(vc_cur, ic<1>{}, ic<J + 2>{});
-      if constexpr (I == 5) wsh[0] = *(const u32x4 *)(smem + vb_cur + (2 * 4 + 0) * 1024);
-      if constexpr (I == 7) dma_pair(ic<0>{});
-      TN_RING_FENCE();
-      TN_SB();
-    });
-    static_for<16>([&](auto i_tag) TN_INL {       // k-step B and the shift k-step, block by block
-      constexpr int I = decltype(i_tag)::value, MB = I >> 2, SH = (I >> 1) & 1, F = I & 1;
-      if constexpr (SH == 0) acc[MB][F] = mfma32(wa[MB], xb[1][F], acc[MB][F]);
-      else acc[MB][F] = mfma32(wsh[MB & 1], xb_shift, acc[MB][F]);
-      if constexpr ((I & 3) == 1 && MB < 3) wsh[(MB + 1) & 1] = *(const u32x4 *)(smem + vb_cur + (2 * 4 + MB + 1) * 1024);
-      if constexpr (MB >= 1) {        // epilogue A of block MB - 1: 20 items over 4 slots
-        static_for<5>([&](auto k_tag) TN_INL { epa_item(ic<MB - 1>{}, ic<(I & 3) * 5 + decltype(k_tag)::value>{}); });
+    static_for<24>([&](auto i_tag) TN_INL {
+      constexpr int I = decltype(i_tag)::value, KS = I >> 3, MB = (I >> 1) & 3, F = I & 1;
+      if constexpr (KS == 0) {
+        constexpr int J = (I & 7) >> 1, BF = I & 1;
+        acc[MB][F] = mfma32(wa[MB], xb[0][F], acc[MB][F]);
+        if constexpr (F == 1) wa_read(ic<MB>{}, vb_cur, ic<1>{});
+        if (!(TN_B14_EXP & 4)) xb[1][BF][J] = bn_dword(fwd[BF][1][J], ic<J>{});
+        if constexpr (BF == 1 && J < 2) consts_read(vc_cur, ic<1>{}, ic<J + 2>{});
+      } else if constexpr (KS == 1) {
+        acc[MB][F] = mfma32(wa[MB], xb[1][F], acc[MB][F]);
+      } else {
+        acc[MB][F] = mfma32(wsh[MB & 1], xb_shift, acc[MB][F]);
       }
-      if constexpr (I == 3) dma_pair(ic<1>{});
-      if constexpr (I == 7) dma_consts();
+      // the shift k-step's fragments (k-step 2 of the unit), two registers: blocks 0 / 1 early, 2 / 3 behind the last use of 0 / 1
+      if constexpr (I == 5) wsh[0] = *(const u32x4 *)(smem + vb_cur + (2 * 4 + 0) * 1024);
+      if constexpr (I == 9) wsh[1] = *(const u32x4 *)(smem + vb_cur + (2 * 4 + 1) * 1024);
+      if constexpr (I == 17) wsh[0] = *(const u32x4 *)(smem + vb_cur + (2 * 4 + 2) * 1024);
+      if constexpr (I == 19) wsh[1] = *(const u32x4 *)(smem + vb_cur + (2 * 4 + 3) * 1024);
+      if constexpr (I >= 18 && I < 23) epa_items(ic<0>{}, ic<(I - 18) * 4>{}, ic<4>{});
+      if constexpr (I == 7) dma_pair(ic<0>{});
+      if constexpr (I == 11) dma_pair(ic<1>{});
+      if constexpr (I == 15) dma_consts();
       // the 3x3's first operands: weight fragments of steps 0 / 1 (unit g + 1), pixel fragments of step 0 (tuple 0: block 0's epilogue is done)
-      if constexpr (I >= 10) w3_read(ic<(I - 10) / 3>{}, ic<(I - 10) % 3>{}, vb_next);
-      if constexpr (I == 14) bop_read(ic<0>{}, ic<0>{});
-      if constexpr (I == 15) bop_read(ic<0>{}, ic<1>{});
+      if constexpr (I >= 12 && I < 18) w3_read(ic<(I - 12) / 3>{}, ic<(I - 12) % 3>{}, vb_next);
+      if constexpr (I == 23) { bop_read(ic<0>{}, ic<0>{}); bop_read(ic<0>{}, ic<1>{}); }
       TN_RING_FENCE();
       TN_SB();
     });
@@ -370,8 +378,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
 
   // ================= the 3x3 intervals: J = 0 .. 5, steps 4 J .. 4 J + 3, slot (step, dx, f) =================
-  // J = 0 carries epilogue A of block 3; J = 5 carries the head of the NEXT layer's BN1 pipeline (pre_item).
-  // The barrier of J = 1 publishes the tile (kernel row -1, the first that needs the neighbours' rows, starts in J = 2; its reads are issued one step ahead).
+  // J = 0 / 1 carry epilogue A of blocks 1 - 3 (each ahead of the first read of its tuples); J = 5 carries the head of the NEXT
+  // layer's BN1 pipeline (pre_item).  The barrier of J = 2 publishes the tile: kernel row -1 (steps 8 ..) is the first that needs
+  // the neighbours' rows; step 8 reads fragment X's operand behind that barrier and runs fragment Y first.
   auto pre_item = [&](auto pn_tag, auto i_tag) TN_INL {      // the next layer's k-step 0 (ring slot PN): constants, 8 BN items, weights
     constexpr int PN = decltype(pn_tag)::value, I = decltype(i_tag)::value;
     // items 0, 1: constants of k-step 0, dwords 0 / 1; 2 - 9: BN items (dword, fragment), behind a dword's second item the constants
@@ -394,16 +403,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int kPreItems = 14;
   auto b_interval = [&](auto j_tag, auto pn_tag, auto vm_tag) TN_INL {
     constexpr int J = decltype(j_tag)::value;
-    // the barrier in front of unit 1 publishes the bottleneck tile (every wave's last tile write is in unit 0; the first read of a
-    // neighbour's row is issued in unit 1): the writes have to be complete, not only issued, when the wave arrives
-    if constexpr (J == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // the tile writes of every wave (the last ones sit in J = 1) have to be complete, not only issued, when the wave arrives
+    if constexpr (J == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     begin_interval(vm_tag);
     static_for<24>([&](auto i_tag) TN_INL {
-      constexpr int I = decltype(i_tag)::value, S = 4 * J + I / 6, DX = (I % 6) >> 1, F = I & 1;
-      if constexpr ((I % 6) == 0) {
+      constexpr int I = decltype(i_tag)::value, S = 4 * J + I / 6, P = I % 6;
+      constexpr bool YFIRST = S == 8;                       // slot order (dx, f), or fragment Y's three MFMAs first
+      constexpr int DX = YFIRST ? P % 3 : P >> 1, F = YFIRST ? (P < 3 ? 1 : 0) : (P & 1);
+      constexpr bool SECOND_USE = YFIRST ? P >= 3 : F == 1;  // of the weight register w3f[S & 1][DX]
+      if constexpr (P == 0) {
         u32x4 (&w)[3] = w3f[S & 1];
-        u32x4 (&b)[2] = bop[S & 1];
-        asm volatile("" ::"v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(b[0]), "v"(b[1]));
+        asm volatile("" ::"v"(w[0]), "v"(w[1]), "v"(w[2]));
       }
       if (!(TN_B14_EXP & 2)) {
         if constexpr (S == 0) {
@@ -415,12 +425,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           bacc[DX][F] = mfma32(w3f[S & 1][DX], bop[S & 1][F], bacc[DX][F]);
         }
       }
-      if constexpr (F == 1 && S + 2 < 24) {          // weight fragments of step S + 2: this unit or the next
+      if constexpr (SECOND_USE && S + 2 < 24) {      // weight fragments of step S + 2: this unit or the next
         if constexpr (((S + 2) >> 2) == J) w3_read(ic<S + 2>{}, ic<DX>{}, vb_cur);
         else w3_read(ic<S + 2>{}, ic<DX>{}, vb_next);
       }
-      if constexpr (S + 1 < 24 && (I % 6) < 2) bop_read(ic<S + 1>{}, ic<I % 6>{});     // pixel fragments of step S + 1 (the other parity's last MFMAs were step S - 1's)
-      if constexpr (J == 0 && I < 20) epa_item(ic<3>{}, ic<I>{});
+      // pixel fragments of step S + 1 (its parity's last MFMAs were step S - 1's), three slots ahead; step 8's fragment X
+      // (the first operand with a neighbour's row) behind the barrier that publishes the tile, at the top of the step
+      if constexpr (S + 1 < 24 && (P == 2 || P == 3) && !(S + 1 == 8 && P == 2)) bop_read(ic<S + 1>{}, ic<P - 2>{});
+      if constexpr (S == 8 && P == 0) bop_read(ic<8>{}, ic<0>{});
+      // epilogue A of blocks 1, 2, 3: 20 items each, ahead of the first read of their tuples
+      if constexpr (J == 0 && I < 8) epa_items(ic<1>{}, ic<I * 5 / 2>{}, ic<(I + 1) * 5 / 2 - I * 5 / 2>{});
+      if constexpr (J == 0 && I >= 8 && I < 20) epa_items(ic<2>{}, ic<(I - 8) * 5 / 3>{}, ic<(I - 7) * 5 / 3 - (I - 8) * 5 / 3>{});
+      if constexpr (J == 0 && I >= 20) epa_items(ic<3>{}, ic<(I - 20) * 5 / 3>{}, ic<(I - 19) * 5 / 3 - (I - 20) * 5 / 3>{});
+      if constexpr (J == 1 && I < 8) epa_items(ic<3>{}, ic<(I + 4) * 5 / 3>{}, ic<(I + 5) * 5 / 3 - (I + 4) * 5 / 3>{});
       if constexpr (J == 5 && I < kPreItems) pre_item(pn_tag, ic<I>{});     // (ahead of the interval's DMA statements: kVmRing counts on it)
       if constexpr (I == 15) dma_pair(ic<0>{});
       if constexpr (I == 19) dma_pair(ic<1>{});
