@@ -33,7 +33,27 @@ SIZE = 224
 FLOP_PER_FRAME = 5.666e9          # 2 x 2.8331 GMAC over the 120 convolutions
 MFMA_PEAK_TFLOPS = 2500.0         # MI355X dense fp16 MFMA (MI355X_MICROARCH.md)
 HBM_PEAK_TBS = 8.0                # MI355X HBM3E (MI355X_MICROARCH.md)
-MIN_TOTAL_STEPS = 200
+MIN_TOTAL_STEPS = 1000        # (~2 s of GPU time at the default batch: a median over >= 5 regions of 200 steps, and long enough for a 1 Hz power / utilisation sampler to see it)
+
+
+def calibration_note():
+    """What tests/test_gpu_calibration.py measured on MI355X for the conversion the headline model uses (the committed matrix
+    profiles/r04_calibration_matrix.json: feature max-abs error vs the fp32 oracle on the un-rounded weights, per frame family)."""
+    path = os.path.join(ROOT, "profiles", "r04_calibration_matrix.json")
+    try:
+        m = json.load(open(path))["feature_max_abs_error"]
+        d, ex, pl, ker = (m[k] for k in ("built-in set, 72 frames", "exact-weights mode (hi + lo pairs)", "plain rounding",
+                                         "kernels alone (oracle on the converted weights)"))
+        inside = sorted(f for f in d if d[f] < 1e-3)
+        outside = sorted(f for f in d if d[f] >= 1e-3)
+        rng = lambda fs, row: "%.2e .. %.2e" % (min(row[f] for f in fs), max(row[f] for f in fs)) if fs else "-"
+        return (f"within 1e-3 on {len(inside)} of {len(d)} families ({rng(inside, d)}: {', '.join(inside)}); {rng(outside, d)} on frames with large "
+                f"perfectly flat regions ({', '.join(outside)}), where the fp16 activation path alone measures {rng(outside, ker)} and the "
+                f"exact-weights mode {rng(outside, ex)} (every pixel of a flat region makes the same activation-rounding error, which the average "
+                f"pool cannot reduce: not a property of the weight conversion); plain rounding {rng(list(pl), pl)}; worst case {max(d.values()):.2e}")
+    except Exception as e:      # (a tree without the committed matrix)
+        return f"see tests/test_gpu_calibration.py ({type(e).__name__}: profiles/r04_calibration_matrix.json not readable)"
+
 # compulsory HBM bytes per frame if every intermediate stayed on chip (SURVEY §8d): fp16 NHWC frame in, fp32
 # features out (+ 13.7 MB of fp16 weights per batch)
 COMPULSORY_BYTES_PER_FRAME = 301056 + 4096
@@ -192,10 +212,11 @@ def run(argv):
 
     ctx = _lib.Context(dev.index)
     # The measured model: seeded fp32 conv weights that are NOT fp16-representable (what a trained checkpoint looks like),
-    # converted to ONE fp16 number per weight by calibrated error-feedback rounding on eight synthetic calibration frames
-    # (tennis_amd/calibrate.py) - the configuration whose features / logits are within 1e-3 of the fp32 oracle evaluated on the
-    # un-rounded weights (tests/test_gpu_encoder.py::test_fp32_weights_calibrated_rounding), so the headline rate and the 1e-3
-    # bar belong to the same configuration.  --plain-rounding: seeded weights that are fp16-representable to begin with.
+    # converted to ONE fp16 number per weight by calibrated rounding against the library's 72 built-in calibration frames
+    # (tennis_amd/calibrate.py: vector error feedback, round 4).  Its features are within 1e-3 of the fp32 oracle evaluated on the
+    # un-rounded weights on natural-looking content and on most synthetic families; the measured per-family figures and the
+    # worst case are in tests/test_gpu_calibration.py / gpurun_out/parity_report.json and quoted in config.weights below.
+    # --plain-rounding: seeded weights that are fp16-representable to begin with (same kernels, same rate).
     params32 = W.make_densenet121_weights(0, fp16_model=False)
     if args.exact_weights:
         params = params32
@@ -203,10 +224,7 @@ def run(argv):
         params = W.make_densenet121_weights(0)
     else:
         from tennis_amd.calibrate import calibrated_fp16_model
-        g = torch.Generator(device=dev); g.manual_seed(4321)          # the same calibration frames (= the same model) on every rank
-        calib = torch.randint(0, 256, (8, SIZE, SIZE, 3), dtype=torch.uint8, device=dev, generator=g)
-        params = calibrated_fp16_model(params32, calib, SIZE, ctx=ctx)
-        del calib
+        params = calibrated_fp16_model(params32, None, SIZE, ctx=ctx)     # the built-in calibration frames: the same model on every rank
     enc = DenseNet121Features(params, SIZE, max_batch=args.batch, ctx=ctx, exact_weights=args.exact_weights)
     x = make_frames(args.batch, SIZE, 1234 + rank, dev)
     feats = [torch.empty((args.batch, enc.feature_dim), dtype=torch.float32, device=dev) for _ in range(2)]
@@ -332,8 +350,9 @@ def run(argv):
                                       "in the dense layers / transitions)") if args.exact_weights
                                      else ("seeded random-init, conv weights fp16-representable" if args.plain_rounding else
                                            "seeded random-init fp32 conv weights (not fp16-representable), converted to one fp16 number per weight by "
-                                           "calibrated error-feedback rounding on 8 synthetic calibration frames (tennis_amd/calibrate.py): features within "
-                                           "1e-3 of the fp32 oracle on the UN-rounded weights (tests/test_gpu_encoder.py::test_fp32_weights_calibrated_rounding)"),
+                                           "calibrated rounding (vector error feedback against the 72 built-in calibration frames of 12 families, "
+                                           "tennis_amd/calibrate.py).  Feature error vs the fp32 oracle on the UN-rounded weights, measured per frame family "
+                                           "(tests/test_gpu_calibration.py, profiles/r04_calibration_matrix.json): " + calibration_note()),
                           "exchange": (comm.transport + f", all-gather of {args.batch} x {enc.feature_dim} fp32 rows per rank and step") if comm is not None else "none (1 rank)",
                           "timing": f"median of {repeats} fenced regions of exactly {args.steps} steps" + (", forwards pipelined (results joined one step behind, all joined before the closing fence)" if pipelined else ""),
                           "region_ms": [round(t * 1e3, 2) for t in times],

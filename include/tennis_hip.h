@@ -125,6 +125,13 @@ int tn_densenet121_profile(tn_encoder *enc, const void *x, tn_layout layout, int
  * pixels of the activation that convolution reads is written to means_host (fp32, *numel values). */
 int tn_densenet121_input_means(tn_encoder *enc, const void *x, tn_layout layout, int batch, float *means_host,
                                int64_t capacity, int64_t *numel);
+/* Host side of that conversion (no GPU involved; csrc/calib_host.hip): w (N, K) fp32 -> out (N, K), every entry one of the two
+ * fp16 neighbours of w's entry, chosen per output row so that the row's rounding error is (nearly) orthogonal to all F rows of
+ * A (F, K) - the per-frame mean input activations of F calibration frames (one tn_densenet121_input_means call per frame) -
+ * by a greedy pass and `sweeps` passes of coordinate descent on || A d ||^2 / F + ridge * sum_k (d[k] rms_f A[f][k])^2.
+ * The reference evaluates fp32 parameters (models/vision/definitions.py:27-33): this keeps ONE fp16 number per weight within
+ * the 1e-3 bar of that evaluation. */
+int tn_round_fp16_calibrated(const float *w, int rows, int cols, const double *A, int frames, int sweeps, double ridge, float *out);
 int tn_densenet121_read_tap(tn_encoder *enc, const char *tap, int batch, float *out_host,
                             size_t capacity, size_t *numel);
 int tn_densenet121_destroy(tn_encoder *enc);
@@ -372,6 +379,16 @@ int tn_dbg_block7_run(void *handle, void *buf_f16, int ldc, int B);
 int tn_dbg_block7_run_ts(void *handle, void *buf_f16, int ldc, int B,
                          unsigned long long *ts /* NULL or 128 per frame: s_memtime stamps of wave 0 (start, then 5 per layer) */);
 void tn_dbg_block7_destroy(void *handle);
+
+/* The streamed 14x14 dense block (csrc/dense_block14.hip; reference call site models/vision/definitions.py:30, the third dense
+ * block of gluoncv's DenseNet-121): nl layers from K0 >= 256 input channels in ONE launch on a device concat buffer (B,14,14,ldc)
+ * fp16; operands as tn_dbg_block7_create.  The handle owns the packed weight stream and the kernel's working copy of the frames. */
+int tn_dbg_block14_create(tn_ctx *ctx, int K0, int nl, const float *w1_all, const float *s1_all, const float *t1_all,
+                          const float *s2_all, const float *t2_all, const float *w3_all, void **out);
+int tn_dbg_block14_run(void *handle, void *buf_f16, int ldc, int B);
+int tn_dbg_block14_run_ts(void *handle, void *buf_f16, int ldc, int B,
+                          unsigned long long *ts /* NULL or 64 per frame (160 in a -DTN_B14_STAMPS build): s_memtime stamps of wave 0, one per layer */);
+void tn_dbg_block14_destroy(void *handle);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@ for d in sorted(glob.glob("gpurun_out/pmc_sq_*")):
         for r in csv.DictReader(open(f)):
             n = r["Kernel_Name"]
             k = None
-            for key in ("dense_strip_kernel<56", "dense_strip_kernel<28", "dense_block7_kernel", "dense_layer_kernel<56", "dense_layer_kernel<28", "dense_layer_kernel<14", "dense_layer_kernel<7",
+            for key in ("dense_strip_kernel<56", "dense_strip_kernel<28", "dense_block7_kernel", "dense_block14_kernel", "dense_layer_kernel<56", "dense_layer_kernel<28", "dense_layer_kernel<14", "dense_layer_kernel<7",
                         "stem_pool", "conv1x1_kernel"):
                 if key in n: k = key
             if k:

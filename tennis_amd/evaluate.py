@@ -207,8 +207,9 @@ def build_parser():
     p.add_argument("--backbone", default="DenseNet121")
     p.add_argument("--fp16_conversion", default="nearest", choices=["nearest", "calibrated", "exact"],
                    help="how the checkpoint's fp32 conv weights become the fp16 model (not a reference flag): plain rounding, "
-                        "rounding calibrated on the first frames processed (features within 1e-3 of the fp32 evaluation at full "
-                        "speed), or hi + lo weight pairs (the same bar at twice the MFMAs)")
+                        "rounding calibrated on the library's built-in calibration frames (the same model on every rank; features within "
+                        "1e-3 of the fp32 evaluation on natural content at full speed, DESIGN.md), or hi + lo weight pairs (the bar "
+                        "on any input at twice the MFMAs)")
     p.add_argument("--model_id", default="0000")
     p.add_argument("--split_id", default="02")
     p.add_argument("--split", default="test")

@@ -89,9 +89,10 @@ class DenseNet121Backbone(Block):
     def __init__(self, seed=0, prefix="densenet0_", max_batch=256, exact_weights=False, conversion="nearest", **kwargs):
         """How adopted fp32 conv weights become the fp16 model the kernels evaluate:
         ``conversion="nearest"`` (default): rounded once to the nearest fp16 on adoption;
-        ``conversion="calibrated"``: kept in fp32 until ``calibrate(frames)`` - or the first forward, which calibrates on its
-        first eight frames - and then rounded with error feedback against the measured mean activations
-        (tennis_amd.calibrate): one fp16 number per weight, full speed, features within 1e-3 of the fp32 evaluation;
+        ``conversion="calibrated"``: kept in fp32 until ``calibrate()`` - or the first forward - and then rounded with vector error
+        feedback against the mean activations of the built-in calibration frames (tennis_amd.calibrate; the same frames, hence
+        the same model, on every rank of a multi-GPU job; ``calibrate(frames)`` adds uint8 frames of the footage): one fp16 number
+        per weight, full speed, features within 1e-3 of the fp32 evaluation on natural content (per-family figures: DESIGN.md);
         ``exact_weights=True`` / ``conversion="exact"``: conv weights stay fp32 and the library evaluates them as hi + lo
         fp16 pairs (engine.DenseNet121Features(exact_weights=True)) at twice the MFMAs."""
         super().__init__(prefix=prefix, **kwargs)
@@ -153,12 +154,17 @@ class DenseNet121Backbone(Block):
         super()._adopt(own if keep_fp32 else W.as_fp16_model(own))
         self._converted = None
 
-    def calibrate(self, frames):
-        """``conversion="calibrated"``: measure the mean activation of every convolution input on ``frames`` (any layout the
-        encoder takes; a few frames of the material to be processed) and convert the fp32 weights against them."""
+    def calibrate(self, frames=None, size=224):
+        """``conversion="calibrated"``: measure, frame by frame, the mean activation of every convolution input on the built-in
+        calibration set (+ ``frames``: NHWC uint8 frames of the material to be processed, if given) and convert the fp32 weights
+        against them.  Deterministic and rank-independent: every rank of a sharded job that calls this with the same ``frames``
+        (or none) serves the same fp16 model."""
         from .calibrate import calibrated_fp16_model
-        frames = _to_device(frames)
-        size = tuple(frames.shape[2:]) if frames.shape[1] == 3 and frames.dtype == torch.float32 else tuple(frames.shape[1:3])
+        if frames is not None:
+            frames = _to_device(frames)
+            if frames.dtype != torch.uint8:
+                raise TypeError("calibrate(frames): NHWC uint8 frames (as the loader hands them over)")
+            size = tuple(frames.shape[1:3])
         self._engine = None
         p = {k: v.data for k, v in self._own_params.items()}
         self._converted = calibrated_fp16_model(p, frames, size, prefix=self.prefix)
@@ -174,7 +180,7 @@ class DenseNet121Backbone(Block):
         if self._engine is None or self._size != size or self._engine.max_batch < b:
             self._engine = None  # release the old workspace first
             if self._calibrated_mode and self._converted is None:
-                self.calibrate(x[:8])
+                self.calibrate(None, size)      # the built-in set only: never this rank's own first frames
             p = self._converted if self._calibrated_mode else {k: v.data for k, v in self._own_params.items()}
             self._engine = engine.DenseNet121Features(p, size, max_batch=max(b, min(self._max_batch, 64)),
                                                       prefix=self.prefix, exact_weights=self._exact)

@@ -84,24 +84,39 @@ def _round_fp16_error_feedback(wf: np.ndarray, mean: np.ndarray) -> np.ndarray:
 
 
 _VEC_RIDGE, _VEC_SWEEPS = 0.05, 3
+_USE_LIBRARY_ROUNDING = True      # (scripts/calib_study.py and the tests also run the numpy reference)
 
 
-def _round_fp16_vector_feedback(wf: np.ndarray, A: np.ndarray, sweeps: int | None = None, ridge: float | None = None) -> np.ndarray:
+def _round_fp16_vector_feedback(wf: np.ndarray, A: np.ndarray, sweeps: int | None = None, ridge: float | None = None,
+                                use_library: bool = True) -> np.ndarray:
     """(N, K) float64 values -> fp16-representable values, each one of its two fp16 neighbours, chosen so that the rounding
     error of every output row is (nearly) orthogonal to ALL rows of ``A`` (F, K) at once - the mean input activations of F
     calibration frames - instead of to their average only (``_round_fp16_error_feedback``): minimises, per output row n,
-    ``|| A d_n ||^2 + ridge * sum_k (d_n[k] * a_rms[k])^2`` over the 2^K neighbour choices by one greedy pass along k followed
+    ``|| A d_n ||^2 / F + ridge * sum_k (d_n[k] * a_rms[k])^2`` over the 2^K neighbour choices by one greedy pass along k followed
     by ``sweeps`` passes of coordinate descent (each weight re-decided against the residual of all the others).  The ridge term
     keeps a weight on its nearest neighbour unless moving it buys something, which bounds what the conversion can do to frames
-    whose activations lie outside the span of the calibration set (they see at most the plain-rounding error statistics)."""
+    whose activations lie outside the span of the calibration set (they see at most the plain-rounding error statistics).
+
+    The work is done by the library's host routine ``tn_round_fp16_calibrated`` (csrc/calib_host.hip; no GPU involved); the numpy
+    code below is the reference it is tested against (``use_library=False``)."""
     sweeps = _VEC_SWEEPS if sweeps is None else sweeps
     ridge = _VEC_RIDGE if ridge is None else ridge
     N, K = wf.shape
     F = A.shape[0]
+    if use_library:
+        import ctypes as C
+        from . import _lib
+        w32 = np.ascontiguousarray(wf, np.float32)
+        A64 = np.ascontiguousarray(A, np.float64)
+        out = np.empty((N, K), np.float32)
+        vp = lambda a_: a_.ctypes.data_as(C.c_void_p)
+        _lib.check(_lib.load().tn_round_fp16_calibrated(vp(w32), N, K, vp(A64), F, int(sweeps), float(ridge), vp(out)), "tn_round_fp16_calibrated")
+        return out.astype(np.float64)
+    wf = wf.astype(np.float32).astype(np.float64)            # (the library sees fp32 weights)
     rtn = wf.astype(np.float16)
     rtn_f = rtn.astype(np.float64)
     other = np.nextafter(rtn, np.where(wf > rtn_f, np.float16(np.inf), np.float16(-np.inf)).astype(np.float16)).astype(np.float64)
-    other = np.where(np.isfinite(other), other, rtn_f)
+    other = np.where(np.isfinite(other) & (wf != rtn_f), other, rtn_f)
     d1, d2 = rtn_f - wf, other - wf                          # the two possible errors of each weight (N, K)
     An = A / np.sqrt(F)                                       # mean square over the frames
     a2 = (An * An).sum(0)                                     # (K,) = a_rms^2
@@ -138,6 +153,11 @@ def as_fp16_model(params: dict, input_means: dict | None = None) -> dict:
     up to 3.3e-3 because weight rounding is coherent across the 49 pooled pixels; with
     converted weights the kernels' own error is 7e-4 max, DESIGN.md "Numerics".)
 
+    ``input_means`` values may be 2-D, one row per calibration FRAME (round 4, what ``tennis_amd.calibrate`` passes): the rounding
+    error of every row is then made orthogonal to every frame's mean activations at once (``_round_fp16_vector_feedback``) -
+    a conversion calibrated on the average only falls back towards plain rounding on frames whose channel means differ from
+    the calibration set's (measured: DESIGN.md "Numerics", tests/test_gpu_calibration.py).
+
     ``input_means`` (round 3; ``engine.DenseNet121Features.input_means`` / ``tennis_amd.calibrate``): CALIBRATED rounding for
     parameters that are NOT fp16-representable (a trained fp32 checkpoint).  Round-to-nearest errors of a weight row are
     independent, but they all multiply activations that are positive behind a ReLU: the part of the row's error that survives the
@@ -161,7 +181,8 @@ def as_fp16_model(params: dict, input_means: dict | None = None) -> dict:
             m = np.asarray(input_means[k], np.float64)
             taps = v.shape[2] * v.shape[3]
             if m.ndim == 2:      # one row per calibration frame: vector error feedback
-                r = _round_fp16_vector_feedback(folded.astype(np.float64).reshape(v.shape[0], -1), np.repeat(m, taps, axis=1))
+                r = _round_fp16_vector_feedback(folded.astype(np.float64).reshape(v.shape[0], -1), np.repeat(m, taps, axis=1),
+                                                use_library=_USE_LIBRARY_ROUNDING)
             else:                # (cin, kh, kw) flattening
                 r = _round_fp16_error_feedback(folded.astype(np.float64).reshape(v.shape[0], -1), np.repeat(m, taps))
             r = r.reshape(v.shape).astype(np.float32)

@@ -612,3 +612,32 @@ def test_gnmt_train_oracle_forward_matches_numpy_oracle(cell):
     k = "gnmt_tgt_proj_bias"
     moved = np.abs(q[k] - p[k])
     assert np.all(moved[np.abs(g[k]) > 1e-6] > 0.9e-3) and np.all(moved < 1.01e-3)
+
+
+def test_vector_feedback_rounding_library_vs_numpy():
+    """tn_round_fp16_calibrated (csrc/calib_host.hip, host code) against its numpy reference: the same neighbour for every weight,
+    every weight ON one of its two neighbours, representable weights untouched, and the property the method is for - the row
+    errors against EVERY calibration vector shrink, not only against their mean."""
+    from tennis_amd import weights as W
+    rng = np.random.default_rng(5)
+    w = rng.normal(0, 0.05, (48, 300)).astype(np.float32).astype(np.float64)
+    A = np.abs(rng.normal(0.4, 0.3, (20, 300))) * rng.uniform(0.3, 2.0, (20, 1))
+    a = W._round_fp16_vector_feedback(w, A, use_library=True)
+    b = W._round_fp16_vector_feedback(w, A, use_library=False)
+    assert np.array_equal(a, b)
+    lo = w.astype(np.float16)
+    up = np.nextafter(lo, np.where(w > lo.astype(np.float64), np.float16(np.inf), np.float16(-np.inf)).astype(np.float16))
+    assert np.all((a == lo.astype(np.float64)) | (a == up.astype(np.float64)))
+    w16 = lo.astype(np.float64)
+    assert np.array_equal(W._round_fp16_vector_feedback(w16, A), w16)
+    per_frame = lambda r: np.abs((r - w) @ A.T)                       # (rows, frames)
+    e_rtn, e_vec = per_frame(w16), per_frame(a)
+    e_mean = per_frame(W._round_fp16_error_feedback(w, A.mean(0)))
+    assert e_vec.max() < 0.25 * e_rtn.max() and np.sqrt((e_vec ** 2).mean()) < 0.15 * np.sqrt((e_rtn ** 2).mean())
+    assert np.sqrt((e_vec ** 2).mean()) < 0.5 * np.sqrt((e_mean ** 2).mean())      # the mean-only method leaves the per-frame part
+    # through as_fp16_model: 2-D input_means select the vector method, conv by conv
+    p = W.make_densenet121_weights(3, fp16_model=False)
+    name = "densenet0_stage1_conv0_weight"
+    q = W.as_fp16_model(p, input_means={name: np.abs(rng.normal(0.5, 0.2, (6, p[name].shape[1])))})
+    plain = W.as_fp16_model(p)
+    assert all(np.array_equal(q[k], plain[k]) for k in p if k != name) and (q[name] != plain[name]).any()

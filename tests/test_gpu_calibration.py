@@ -1,0 +1,128 @@
+"""-m gpu: the calibrated fp16 conversion OFF its calibration frames.
+
+The headline configuration serves fp32 parameters converted to one fp16 number per weight (tennis_amd/calibrate.py), and the bar
+is the fp32 evaluation of the UN-rounded parameters (reference models/vision/definitions.py:27-33) on whatever frames arrive.
+Round 3 only ever tested the conversion on frames of the kind it was calibrated on.  Here every configuration is evaluated on
+sixteen frame families - the twelve of the built-in calibration set (other frames than the calibration set's), three synthetic
+families the calibration set does not contain, and the decoded JPEG fixtures - against the fp32 torch-CPU oracle, and the whole
+matrix goes to gpurun_out/calibration_matrix.json (committed as profiles/r04_calibration_matrix.json)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# families without large perfectly flat regions (on a flat region every pixel makes the SAME fp16 activation-rounding error, which the
+# average pool cannot reduce: that part belongs to the fp16 activation path, not to the weight conversion - rows "kernels alone" /
+# "exact-weights mode" of the matrix)
+NATURAL = ["noise", "lowcontrast", "blobs", "scene", "dark", "bright", "tinted", "photo", "jpeg", "stripes", "checker"]
+
+
+def _jpeg_frames(n, size=224):
+    """the decoded fixtures of tests/golden/jpeg_cases.npz, enlarged (nearest neighbour) and tiled to size x size"""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "jpeg_cases.npz"))
+    imgs = [z[k] for k in sorted(z.files) if k.endswith("__rgb") and z[k].shape[0] >= 24]
+    out = []
+    for i in range(n):
+        im = imgs[i % len(imgs)]
+        k = 2 + i % 3
+        big = np.repeat(np.repeat(im, k, 0), k, 1)
+        reps = (-(-size // big.shape[0]), -(-size // big.shape[1]), 1)
+        out.append(np.tile(big, reps)[:size, :size])
+    return np.ascontiguousarray(np.stack(out))
+
+
+@pytest.fixture(scope="module")
+def world():
+    from oracle.torch_ref import TorchDenseNet121
+    from tennis_amd import calib_frames as CF
+    from tennis_amd import weights as W
+    p = W.make_densenet121_weights(0, fp16_model=False)             # what a trained checkpoint looks like: not fp16-representable
+    fams = CF.FAMILIES + CF.HELD_OUT + ["jpeg"]
+    frames = {f: (CF.frames(f, 2, 224, seed=99) if f != "jpeg" else _jpeg_frames(2)) for f in fams}
+    net = TorchDenseNet121(p)
+    ref = {f: net(torch.from_numpy(W.normalize_to_nchw_f32(frames[f]))).numpy() for f in fams}      # fp32 graph, fp32 weights, un-rounded input
+    return dict(p=p, fams=fams, frames=frames, ref=ref)
+
+
+def _errors(world, q, ref=None, exact=False):
+    from tennis_amd.engine import DenseNet121Features
+    enc = DenseNet121Features(q, 224, max_batch=2, exact_weights=exact)
+    ref = world["ref"] if ref is None else ref
+    out = {}
+    for f in world["fams"]:
+        feat = enc(torch.from_numpy(world["frames"][f]).cuda()).cpu().numpy()
+        out[f] = float(np.abs(feat - ref[f]).max())
+    del enc
+    return out
+
+
+def test_calibration_matrix(world, report):
+    from tennis_amd import calib_frames as CF
+    from tennis_amd import weights as W
+    from tennis_amd.calibrate import calibrated_fp16_model, frame_means
+    p = world["p"]
+    matrix = {}
+    matrix["plain rounding"] = _errors(world, W.as_fp16_model(p))
+    # what the fp16 activation path costs by itself, family by family: the kernels against the fp32 oracle ON THE SAME converted
+    # weights, and the exact-weights mode (hi + lo fp16 weight pairs: no weight error at all) against the bar's oracle
+    from oracle.torch_ref import TorchDenseNet121
+    q_def = calibrated_fp16_model(p, None, 224)
+    net_q = TorchDenseNet121(q_def)
+    ref_q = {f: net_q(torch.from_numpy(W.normalize_to_nchw_f32(world["frames"][f]))).numpy() for f in world["fams"]}
+    matrix["kernels alone (oracle on the converted weights)"] = _errors(world, q_def, ref=ref_q)
+    matrix["exact-weights mode (hi + lo pairs)"] = _errors(world, p, exact=True)
+    # round 3's method, for the record: error feedback against the AVERAGE of eight noise frames
+    fm = frame_means(p, W.synthetic_frames_u8(8, 224, seed=4321))
+    matrix["round 3: mean of 8 noise frames"] = _errors(world, W.as_fp16_model(p, input_means={k: v.mean(0) for k, v in fm.items()}))
+    # the built-in calibration set at three sizes (72 is the default)
+    for n in (12, 24, 72):
+        matrix[f"built-in set, {n} frames"] = _errors(world, calibrated_fp16_model(p, None, 224, builtin_frames=n))
+    # ... plus eight frames of a family the set does not contain (a user who adds frames of the footage)
+    for extra in ("text", "jpeg"):
+        add = CF.frames(extra, 8, 224, seed=7) if extra != "jpeg" else _jpeg_frames(8)[::-1].copy()
+        matrix[f"built-in set + 8 {extra} frames"] = _errors(world, calibrated_fp16_model(p, add, 224))
+    # ... and a single-family calibration (what round 3 would have been with the new method)
+    matrix["vector feedback, 8 noise frames only"] = _errors(world, calibrated_fp16_model(p, W.synthetic_frames_u8(8, 224, seed=4321), 224, builtin_frames=0))
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump({"bar": 1e-3, "oracle": "oracle/torch_ref.py (fp32 graph, un-rounded fp32 weights, un-rounded normalised input), 2 frames per family",
+               "held_out_families": CF.HELD_OUT + ["jpeg"], "feature_max_abs_error": matrix}, open("gpurun_out/calibration_matrix.json", "w"), indent=1)
+    for k, row in matrix.items():
+        print("%-40s " % k + " ".join("%s %.1e" % (f[:5], row[f]) for f in world["fams"]) + "  worst %.2e" % max(row.values()))
+        report["calibration_worst_" + k.replace(" ", "_")] = max(row.values())
+    default = matrix["built-in set, 72 frames"]
+    plain = matrix["plain rounding"]
+    report["calibrated_default_worst_family_err"] = max(default.values())
+    report["calibrated_default_worst_natural_err"] = max(default[f] for f in NATURAL)
+    exact = matrix["exact-weights mode (hi + lo pairs)"]
+    report["exact_mode_worst_family_err"] = max(exact.values())
+    # the bar holds on every family without large flat regions, held-out ones included ...
+    for f in NATURAL:
+        assert default[f] < 1e-3, (f, default[f])
+    # ... frames with large perfectly flat regions (constant colour, saturated patches, half-black, text on white, gradients) stay
+    # within 2e-3 - their measured values are what bench.py quotes - and no further from the bar than the exact-weights mode is
+    # on the same frames plus 5e-4: what is left there is the fp16 activation path, not the conversion
+    assert max(default.values()) < 2e-3, default
+    assert all(default[f] < max(1e-3, exact[f] + 5e-4) for f in world["fams"]), (default, exact)
+    assert max(default.values()) < 0.45 * max(plain.values()) and all(default[f] < plain[f] for f in world["fams"]), (default, plain)
+    # and the set matters: one family of calibration frames leaves the others outside (the round-3 hole, now measured)
+    assert max(matrix["round 3: mean of 8 noise frames"].values()) > 1.5 * max(default.values())
+
+
+def test_calibrated_model_is_rank_independent():
+    """the lazily calibrated model used to depend on each rank's own first frames.  It is now a function of the
+    parameters alone: two backbones fed different first batches serve bit-identical features for the same frame."""
+    from tennis_amd import weights as W
+    from tennis_amd.model_zoo import get_model
+    p = {k: v for k, v in W.make_densenet121_weights(0, fp16_model=False).items() if k.startswith("densenet0_")}
+    a = get_model("DenseNet121", pretrained=False, conversion="calibrated").features
+    b = get_model("DenseNet121", pretrained=False, conversion="calibrated").features
+    a.set_params(p); b.set_params(p)
+    xa = torch.from_numpy(W.synthetic_frames_u8(4, 224, seed=1)).cuda()
+    xb = torch.from_numpy(W.synthetic_frames_u8(12, 224, seed=2)).cuda()
+    a(xa); b(xb)                                  # "rank 0" and "rank 1" see different first batches
+    probe = torch.from_numpy(W.synthetic_frames_u8(3, 224, seed=3)).cuda()
+    assert torch.equal(a(probe), b(probe))
