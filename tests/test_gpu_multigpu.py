@@ -79,7 +79,8 @@ def test_bench_line_and_self_spawn():
     assert r.returncode == 0, r.stdout + r.stderr
     line = _json_line(r.stdout)
     assert line["n_gpus"] == 1 and line["steps"] == 5 and line["roofline"]["bound"] == "mfma"
-    assert line["config"]["timing"].startswith("median of 40 fenced regions of exactly 5 steps")
+    import bench
+    assert line["config"]["timing"].startswith(f"median of {bench.MIN_TOTAL_STEPS // 5} fenced regions of exactly 5 steps")
     code = ("import sys; sys.path.insert(0, %r); import bench; from tennis_amd import sharding; "
             "sharding.launch(bench.run, 1, (['--gpus', '1', '--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--single-region'],))" % ROOT)
     r = _run(["-c", code])
