@@ -48,7 +48,7 @@ def calibration_note():
         outside = sorted(f for f in d if d[f] >= 1e-3)
         rng = lambda fs, row: "%.2e .. %.2e" % (min(row[f] for f in fs), max(row[f] for f in fs)) if fs else "-"
         return (f"within 1e-3 on {len(inside)} of {len(d)} families ({rng(inside, d)}: {', '.join(inside)}); {rng(outside, d)} on frames with large "
-                f"perfectly flat regions ({', '.join(outside)}), where the fp16 activation path alone measures {rng(outside, ker)} and the "
+                f"flat regions ({', '.join(outside)}), where the fp16 activation path alone measures {rng(outside, ker)} and the "
                 f"exact-weights mode {rng(outside, ex)} (every pixel of a flat region makes the same activation-rounding error, which the average "
                 f"pool cannot reduce: not a property of the weight conversion); plain rounding {rng(list(pl), pl)}; worst case {max(d.values()):.2e}")
     except Exception as e:      # (a tree without the committed matrix)

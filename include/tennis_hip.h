@@ -132,6 +132,13 @@ int tn_densenet121_input_means(tn_encoder *enc, const void *x, tn_layout layout,
  * The reference evaluates fp32 parameters (models/vision/definitions.py:27-33): this keeps ONE fp16 number per weight within
  * the 1e-3 bar of that evaluation. */
 int tn_round_fp16_calibrated(const float *w, int rows, int cols, const double *A, int frames, int sweeps, double ridge, float *out);
+/* BatchNorm -> ReLU in front of a dense layer's 1x1 convolution (gluoncv DenseNet _make_dense_layer, reference call site
+ * models/vision/definitions.py:30) re-parametrised for the fused kernels' packed-half form: relu(scale x + shift) = m relu(a x + b)
+ * with a and b fp16 numbers (a exactly scale / m, b the best of 33 candidates for shift / m); m[k] multiplies column k of the 1x1
+ * weights before they are rounded to fp16, which is part of how the fp16 model is defined (weights.as_fp16_model calls this so
+ * that the host and the library agree on m bit for bit).  Host code, no GPU involved (csrc/calib_host.hip). */
+int tn_bn_relu_fold_fp16(const float *gamma, const float *beta, const float *running_mean, const float *running_var, int channels,
+                         float *a, float *b, float *m);
 int tn_densenet121_read_tap(tn_encoder *enc, const char *tap, int batch, float *out_host,
                             size_t capacity, size_t *numel);
 int tn_densenet121_destroy(tn_encoder *enc);

@@ -112,11 +112,7 @@ bool fold_bn(const ParamMap &pm, const std::string &name, int c, std::vector<flo
   if (!g || !b || !mu || !var) return false;
   scale.resize(c);
   shift.resize(c);
-  for (int i = 0; i < c; ++i) {
-    const float s = g[i] / std::sqrt(var[i] + kBnEps);
-    scale[i] = s;
-    shift[i] = b[i] - mu[i] * s;
-  }
+  bn_scale_shift(g, b, mu, var, c, kBnEps, scale.data(), shift.data());
   return true;
 }
 
@@ -364,6 +360,10 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
       const float *w3 = pm.get(sp + "conv" + std::to_string(2 * l + 1) + "_weight", 32 * 128 * 9);
       if (!w1 || !w3) return fail(TN_ERR_MISSING);
       if (!fold_bn(pm, sp + "batchnorm" + std::to_string(2 * l), L.cin, s, t)) return fail(TN_ERR_MISSING);
+      // BN1 + ReLU as relu(s x + t) = m relu(a x + b) with a, b fp16 numbers (calib_host.hip: what the strip / streamed-block kernels'
+      // packed-half BN needs); every kernel of the layer gets (a, b) as its constants and m[k] w[n][k] as its weights
+      std::vector<float> m1(L.cin);
+      bn_relu_fold_fp16(std::vector<float>(s).data(), std::vector<float>(t).data(), L.cin, s.data(), t.data(), m1.data());
       L.s1 = e->pool.upload(s); L.t1 = e->pool.upload(t);
       if (pack7) { h7[1].push_back(s); h7[2].push_back(t); h7w3.push_back(w3); }
       // The scale of the BatchNorm BEHIND the 1x1 convolution is folded into its weights before they are rounded to fp16
@@ -373,7 +373,7 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
       if (!fold_bn(pm, sp + "batchnorm" + std::to_string(2 * l + 1), 128, s, t)) return fail(TN_ERR_MISSING);
       std::vector<float> w1f((size_t)128 * L.cin);
       for (int n = 0; n < 128; ++n)
-        for (int k = 0; k < L.cin; ++k) w1f[(size_t)n * L.cin + k] = s[n] * w1[(size_t)n * L.cin + k];
+        for (int k = 0; k < L.cin; ++k) w1f[(size_t)n * L.cin + k] = s[n] * m1[k] * w1[(size_t)n * L.cin + k];
       if (e->exact) {
         const int bk = e->Hb[b] >= 28 ? 32 : 64;          // k-tile of the block's fused kernel (dense_layer_big.hip)
         L.w1 = e->pool.upload(split_hi_lo_rows(w1f.data(), 128, L.cin, (L.cin + bk - 1) / bk * bk));

@@ -80,3 +80,71 @@ extern "C" int tn_round_fp16_calibrated(const float *w, int N, int K, const doub
   for (auto &x : th) x.join();
   return TN_OK;
 }
+
+// ---- BatchNorm + ReLU in front of a dense layer's 1x1 convolution as TWO packed-half instructions (round 4) ----
+// The strip / streamed-block kernels are issue-bound: one wave per SIMD, and every 32-cycle MFMA of the 1x1 phase carried one
+// BN1 + ReLU item of four VALU instructions (two v_fma_mix_f32, v_cvt_pk_f16_f32, v_pk_max_f16: fp32 constants).  With fp16
+// constants the item is v_pk_fma_f16 + v_pk_max_f16 - measured 10 - 17 % on the layers with K >= 192 - but rounding s and t to
+// fp16 is an error that is the same in every pixel (the average pool does not reduce it, like a weight-rounding error).  So
+// the constants are not rounded, the layer is re-parametrised: for m > 0
+//     relu(s x + t) = m relu(a x + b),   a = s / m,  b = t / m,
+// and m goes into column k of the 1x1 weights BEFORE they are rounded to fp16 (where BN2's scale already goes).  m is chosen
+// so that a is an fp16 number exactly (a = fp16(s) moved by j ulps, |j| <= 16, m = s / a) and b = t / m is as close to one as
+// the 33 candidates allow (the fraction of b's ulp moves by ~ |b / a| per step: expected residual 1/33 of half an ulp).
+// v_pk_fma_f16 is fused, so a x + b is rounded once - as the fp32 path rounded it.
+void bn_scale_shift(const float *gamma, const float *beta, const float *mean, const float *var, int n, float eps, float *scale, float *shift) {
+  for (int i = 0; i < n; ++i) {
+    const float s = gamma[i] / std::sqrt(var[i] + eps);
+    scale[i] = s;
+    shift[i] = beta[i] - mean[i] * s;
+  }
+}
+
+void bn_relu_fold_fp16(const float *scale, const float *shift, int n, float *a_out, float *b_out, float *m_out) {
+  auto half_clamped = [](double v) {          // nearest fp16 number, +-65504 beyond the range, 0 for a NaN
+    if (!(v == v)) return 0.f;
+    if (v > 65504.0) return 65504.f;
+    if (v < -65504.0) return -65504.f;
+    return (float)(f16)(float)v;
+  };
+  for (int i = 0; i < n; ++i) {
+    double s = scale[i], t = std::isfinite(shift[i]) ? (double)shift[i] : 0.0;
+    if (!std::isfinite(scale[i]) || s == 0.0) {     // relu(t): a constant
+      a_out[i] = 0.f; b_out[i] = half_clamped(t); m_out[i] = 1.f;
+      continue;
+    }
+    // a scale outside fp16's comfortable range: a power of two of it goes into m first (exact)
+    double m0 = 1.0;
+    if (std::fabs(s) < 0x1p-10 || std::fabs(s) > 0x1p12) {
+      int e;
+      (void)std::frexp(s, &e);
+      m0 = std::ldexp(1.0, e);
+      s /= m0; t /= m0;
+    }
+    const f16 a0 = (f16)(float)s;
+    const unsigned short bits0 = __builtin_bit_cast(unsigned short, a0);
+    double best = 1e300;
+    int bj = 0;
+    for (int k = 0; k <= 32; ++k) {
+      const int j = (k & 1) ? -((k + 1) >> 1) : (k >> 1);          // 0, -1, 1, -2, 2, ...: ties go to the smallest |j|
+      const unsigned short bj_bits = (unsigned short)(bits0 + j);    // same sign, exponent stays normal (|s| in [2^-10, 2^12], |j| <= 16 < 1024)
+      const double aj = (double)(float)__builtin_bit_cast(f16, bj_bits);
+      const double bt = t * aj / s;
+      const double err = std::fabs((double)half_clamped(bt) - bt);
+      if (err < best) { best = err; bj = j; }
+    }
+    const unsigned short ab = (unsigned short)(bits0 + bj);
+    const float a = (float)__builtin_bit_cast(f16, ab);
+    a_out[i] = a;
+    m_out[i] = (float)(m0 * s / (double)a);
+    b_out[i] = half_clamped(t * (double)a / s);
+  }
+}
+
+extern "C" int tn_bn_relu_fold_fp16(const float *gamma, const float *beta, const float *mean, const float *var, int n, float *a, float *b, float *m) {
+  TN_REQUIRE(gamma && beta && mean && var && a && b && m && n > 0, "tn_bn_relu_fold_fp16: null argument");
+  std::vector<float> s(n), t(n);
+  bn_scale_shift(gamma, beta, mean, var, n, 1e-5f, s.data(), t.data());
+  bn_relu_fold_fp16(s.data(), t.data(), n, a, b, m);
+  return TN_OK;
+}

@@ -252,6 +252,10 @@ int launch_stem(const StemArgs &a, hipStream_t s);
 int launch_stem_pool(const StemArgs &a, f16 *out, int ldy, int Hp, int Wp, hipStream_t s);
 
 int launch_maxpool3x3s2(const f16 *x, int B, int H, int W, int C, f16 *y, int ldy, int Ho, int Wo, hipStream_t s);
+// BN1 + ReLU of the dense layers as two packed-half instructions: relu(s x + t) = m relu(a x + b) with a, b fp16 numbers and m folded
+// into the 1x1 weights (csrc/calib_host.hip)
+void bn_scale_shift(const float *gamma, const float *beta, const float *mean, const float *var, int n, float eps, float *scale, float *shift);
+void bn_relu_fold_fp16(const float *scale, const float *shift, int n, float *a, float *b, float *m);
 int launch_channel_mean(const f16 *x, int ld, int K, const float *scale, const float *shift, long rows, double *scratch /* 32 * K doubles */,
                         float *out, hipStream_t s);
 int launch_head(const f16 *x, int B, int H, int W, int C, const float *scale, const float *shift,

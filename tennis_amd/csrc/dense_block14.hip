@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   u32x4 xb[2][2];        // BN1 + ReLU'd pixel fragments [k-step parity][fragment]: produced one k-step ahead of the MFMAs
   u32x4 wa[4];           // 1x1 weight fragments [32-channel block]: reloaded for the next k-step behind the block's second MFMA
   u32x4 wsh[2];          // ... of the shift k-step [block parity]
-  float4 cb[2];          // BN1 constants (s0, s1, t0, t1) of dword J of the k-step in production [J parity]; reloaded for dword J + 2 behind the dword's second item
+  u32x4 cb[2];           // BN1 constants of dword J of the k-step in production [J parity]: .x = (a0, a1), .y = (b0, b1) as packed halves (bn_relu_fold_fp16); reloaded for dword J + 2 behind the dword's second item
   f32x16 acc[4][2];      // 1x1 accumulators [block][fragment]
   u32x4 fwd[2][2];       // the newest 32 channels, raw fp16 [fragment][k-step]: channels K - 32 + 16 h + 8 k .. + 7 of the lane's pixel
   u32x4 w3f[2][3];       // 3x3 weight fragments [step parity][dx]
@@ -216,31 +216,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("global_load_dwordx4 v[%c0:%c1], %2, %3" ::"n"(R), "n"(R + 3), "v"(vo), "s"(pb) : TN_RING_CLOBBER);
   };
   auto ring_wait = [&](auto rs_tag, auto k_tag) TN_INL { asm volatile("s_waitcnt vmcnt(%c0)" ::"n"(kVmRing) : TN_RING_CLOBBER); };
-  // BN1 + ReLU of one dword (two channels) of a pixel fragment: fp16 in, fp32 fma, one rounding, packed max (dense_strip_impl.h)
+  // BN1 + ReLU of one dword (two channels) of a pixel fragment: relu(a x + b) with fp16 constants, fused multiply-add (one rounding), packed max
   auto bn_ring = [&](auto reg_tag, auto j_tag) TN_INL -> unsigned {      // input: ring register REG
     constexpr int J = decltype(j_tag)::value, REG = decltype(reg_tag)::value;
-    const float4 c = cb[J & 1];
-    float t0, t1;
+    const u32x4 c = cb[J & 1];
     unsigned o;
-    asm volatile("v_fma_mix_f32 %1, v%c7, %3, %4 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %2, v%c7, %5, %6 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-                 "v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_f16 %0, %0, 0"
-                 : "=&v"(o), "=&v"(t0), "=&v"(t1) : "v"(c.x), "v"(c.z), "v"(c.y), "v"(c.w), "n"(REG) : TN_RING_CLOBBER);
+    asm volatile("v_pk_fma_f16 %0, v%c3, %1, %2\n\tv_pk_max_f16 %0, %0, 0" : "=v"(o) : "v"(c.x), "v"(c.y), "n"(REG) : TN_RING_CLOBBER);
     return o;
   };
   auto bn_dword = [&](const unsigned in, auto j_tag) TN_INL -> unsigned {
     constexpr int J = decltype(j_tag)::value;
-    const float4 c = cb[J & 1];
-    float t0, t1;
+    const u32x4 c = cb[J & 1];
     unsigned o;
-    asm("v_fma_mix_f32 %1, %3, %4, %5 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %2, %3, %6, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_f16 %0, %0, 0"
-        : "=&v"(o), "=&v"(t0), "=&v"(t1) : "v"(in), "v"(c.x), "v"(c.z), "v"(c.y), "v"(c.w));
+    asm("v_pk_fma_f16 %0, %1, %2, %3\n\tv_pk_max_f16 %0, %0, 0" : "=v"(o) : "v"(in), "v"(c.x), "v"(c.y));
     return o;
   };
-  // constants of dword J of k-step KQ of the unit at vc: (s[2J], s[2J+1], t[2J], t[2J+1]) - 16 B per lane
+  // constants of dword J of k-step KQ of the unit at vc: halves (a[2J], a[2J+1]), (b[2J], b[2J+1]), 8 B unused - 16 B per lane
   auto consts_read = [&](const unsigned vc, auto kq_tag, auto j_tag) TN_INL {
     constexpr int KQ = decltype(kq_tag)::value, J = decltype(j_tag)::value;
-    cb[J & 1] = *(const float4 *)(smem + vc + 128 * KQ + 16 * J);
+    cb[J & 1] = *(const u32x4 *)(smem + vc + 128 * KQ + 16 * J);
   };
   auto wa_read = [&](auto mb_tag, const unsigned vb, auto kq_tag) TN_INL {
     constexpr int MB = decltype(mb_tag)::value, KQ = decltype(kq_tag)::value;
@@ -607,7 +601,8 @@ int launch_dense_block14(const DenseBlock14Args &a, hipStream_t s) {
 // every unit is kUnitBytes = 16 fragments [64 lanes][8 halfs] + 128 floats of BN1 constants.
 //   super-step unit u: fragment (q, mb): lane l, j: bottleneck channel 32 mb + (l & 31), input channel c = 64 u + 16 q + 8 (l >> 5)
 //     + j (zero weight and zero constants for c >= G: the pad half of the last super-step is the forwarded channels, which
-//     the tail takes); constants (q, h), dword J: s1[c + 2 J], s1[c + 2 J + 1], t1[c + 2 J], t1[c + 2 J + 1] for c = 64 u + 16 q + 8 h
+//     the tail takes); constants (q, h), dword J: halves a1[c + 2 J], a1[c + 2 J + 1], b1[c + 2 J], b1[c + 2 J + 1] (+ 8 B unused)
+//     for c = 64 u + 16 q + 8 h (s1 / t1 of Block14Layer are those fp16 numbers: bn_relu_fold_fp16)
 //   tail unit: k-step 0 / 1: input channel G + 16 (l >> 5) + 8 ks + j (the order in which the previous layer's 3x3 leaves its 32
 //     output channels in registers); k-step 2: the shift k-step of dense_strip.hip (fp16 hi + lo of BN2's shift, and 1 for the mask)
 //   3x3 unit J: fragments (step 4 J + s, dx), s = 0 .. 3: kernel rows in the order ky = 1, 0, 2, tuple t = step % 8; lane layout as
@@ -617,7 +612,12 @@ std::vector<unsigned char> pack_block14(const std::vector<Block14Layer> &layers,
   std::vector<unsigned char> out((size_t)dense_block14_units(K0, nl) * kUnitBytes, 0);
   size_t unit = 0;
   auto frag = [&](size_t u, int fi) { return (f16 *)(out.data() + u * kUnitBytes + (size_t)fi * 1024); };
-  auto cons = [&](size_t u, int q, int h) { return (float *)(out.data() + u * kUnitBytes + kUnitFrag + (q * 2 + h) * 64); };
+  auto cons = [&](size_t u, int q, int h) { return (f16 *)(out.data() + u * kUnitBytes + kUnitFrag + (q * 2 + h) * 64); };
+  // channel j (0 .. 7) of a (k-step, half) group: dword J = j >> 1 holds halves (a[2J], a[2J+1]) | (b[2J], b[2J+1]) | 8 B unused
+  auto put_const = [](f16 *d, int j, float a, float b) {
+    d[8 * (j >> 1) + (j & 1)] = (f16)a;
+    d[8 * (j >> 1) + 2 + (j & 1)] = (f16)b;
+  };
   for (int l = 0; l < nl; ++l) {
     const Block14Layer &L = layers[l];
     const int K = K0 + 32 * l, G = K - 32, nsu = (G + 63) / 64;
@@ -632,11 +632,10 @@ std::vector<unsigned char> pack_block14(const std::vector<Block14Layer> &layers,
             }
         }
         for (int h = 0; h < 2; ++h) {
-          float *d = cons(unit, q, h);
+          f16 *d = cons(unit, q, h);
           for (int j = 0; j < 8; ++j) {
             const int c = 64 * u + 16 * q + 8 * h + j;
-            d[4 * (j >> 1) + (j & 1)] = c < G ? L.s1[c] : 0.f;
-            d[4 * (j >> 1) + 2 + (j & 1)] = c < G ? L.t1[c] : 0.f;
+            put_const(d, j, c < G ? L.s1[c] : 0.f, c < G ? L.t1[c] : 0.f);
           }
         }
       }
@@ -651,11 +650,10 @@ std::vector<unsigned char> pack_block14(const std::vector<Block14Layer> &layers,
             }
         }
         for (int h = 0; h < 2; ++h) {
-          float *d = cons(unit, ks, h);
+          f16 *d = cons(unit, ks, h);
           for (int j = 0; j < 8; ++j) {
             const int c = G + 16 * h + 8 * ks + j;
-            d[4 * (j >> 1) + (j & 1)] = L.s1[c];
-            d[4 * (j >> 1) + 2 + (j & 1)] = L.t1[c];
+            put_const(d, j, L.s1[c], L.t1[c]);
           }
         }
       }

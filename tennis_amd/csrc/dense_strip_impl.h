@@ -66,8 +66,8 @@ struct DSGeom {
   static constexpr int KQ = 2 * KS;              // 16-channel k-steps
   static constexpr int NSU = (KS + 1) / 2;       // 64-channel super-steps (the last one is half when KS is odd)
   static constexpr int W1OFF = kW3Bytes;                   // KQ + 1 k-steps of 4 fragments: the last one carries BN2's shift
-  static constexpr int T1OFF = W1OFF + (KQ + 1) * 4096;    // s1[K] | t1[K]
-  static constexpr int LDS_BYTES = T1OFF + KS * 32 * 8;
+  static constexpr int T1OFF = W1OFF + (KQ + 1) * 4096;    // a1[K] | b1[K] (fp16: BN1 as v_pk_fma_f16, csrc/calib_host.hip)
+  static constexpr int LDS_BYTES = T1OFF + KS * 32 * 4;
   static_assert(W % ROWS == 0 && NITEM % 4 == 0 && ROWS >= 4, "strip geometry");
   static_assert(NSU <= 5, "the activation ring holds five super-steps");
   static_assert(LDS_BYTES <= 160 * 1024, "weights do not fit LDS");
@@ -257,10 +257,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned char *g3 = (const unsigned char *)a.w3s + ln * 16, *g1 = (const unsigned char *)a.w1s + ln * 16;
     for (int p = wv; p < P3; p += 4) dma16(g3 + p * 1024, lds0 + p * 1024);
     for (int p = wv; p < P1; p += 4) dma16(g1 + p * 1024, lds0 + G::W1OFF + p * 1024);
-    float *t1 = (float *)(smem + G::T1OFF);
+    f16 *t1 = (f16 *)(smem + G::T1OFF);      // (the constants ARE fp16 numbers: bn_relu_fold_fp16)
     for (int i = tid; i < K; i += 256) {
-      t1[i] = a.s1[i];
-      t1[K + i] = a.t1[i];
+      t1[i] = (f16)a.s1[i];
+      t1[K + i] = (f16)a.t1[i];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   const unsigned char *w1l = smem + G::W1OFF + lane * 16;
   const unsigned char *w3l = smem + lane * 16;
-  const float *tab1 = (const float *)(smem + G::T1OFF);
+  const f16 *tab1 = (const f16 *)(smem + G::T1OFF);
   // the pixel fragment of the shift k-step: (1, 1, mask, 0, 0, 0, 0, 0) in the lanes that hold k = 0 .. 7
   const u32x4 xb_shift = {h == 0 ? 0x3c003c00u : 0u, (h == 0 && !xvalid) ? 0x0000fb53u : 0u, 0u, 0u};   // fp16 1.0 = 0x3c00, -60000 = 0xfb53
 
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   f32x16 acc[4];         // 1x1 accumulators [32-channel block]
   u32x4 wa[2][4];        // 1x1 weight fragments [k-step parity][block] (a register is reloaded for k-step + 2 behind its MFMA)
   u32x4 xb[XN];          // BN1 + ReLU'd pixel fragments [k-step % XN]: the BN pipeline runs up to XN - 2 k-steps ahead
-  float cs[3][8], ct[3][8];   // BN1 constants [k-step % 3]
+  u32x4 cs[3], ct[3];    // BN1 constants [k-step % 3]: a / b of the lane's eight channels, packed halves
   u32x4 w3f[2][3];       // 3x3 weight fragments [step parity][dx] (reloaded for step + 2 behind their MFMA)
   f32x16 bacc[3];        // 3x3 accumulators [dx]
   unsigned e_pk[4];
@@ -309,8 +309,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     return fb + (unsigned)yc * rowpitch;
   };
   // ---------------- the BN pipeline: an ordered list of items per bottleneck row ----------------
-  //   C(q)    the four ds_read_b128 of k-step q's BN1 constants
-  //   BN(q).j BN1 + ReLU of dword j of k-step q's pixel fragment (4 VALU instructions)
+  //   C(q)    the two ds_read_b128 of k-step q's BN1 constants
+  //   BN(q).j BN1 + ReLU of dword j of k-step q's pixel fragment (2 VALU instructions: v_pk_fma_f16, v_pk_max_f16)
   //   LD(u).i one 16-byte activation load of the NEXT row into ring slot u, behind the last BN item that read the slot
   // in the order C0 C1 C2 | BN(0).0-3 C3 | BN(1).0-3 C4 | ... ; the list is consumed one item per slot, first by the spare slots
   // of the previous row's 3x3 phase (PLB items), then by the row's own 1x1 slots (see make_a_sched)
@@ -326,21 +326,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int U = Q >> 2, I = Q & 3;
     constexpr bool HALF = ODD && U == NSU - 1;
     const int c0 = (HALF ? 64 * U + 16 * h : 64 * U + 32 * h) + 8 * I;
-    const float4 s0 = *(const float4 *)(tab1 + c0), s1 = *(const float4 *)(tab1 + c0 + 4);
-    const float4 t0 = *(const float4 *)(tab1 + K + c0), t1 = *(const float4 *)(tab1 + K + c0 + 4);
-    float *cd = cs[Q % 3], *td = ct[Q % 3];
-    cd[0] = s0.x; cd[1] = s0.y; cd[2] = s0.z; cd[3] = s0.w; cd[4] = s1.x; cd[5] = s1.y; cd[6] = s1.z; cd[7] = s1.w;
-    td[0] = t0.x; td[1] = t0.y; td[2] = t0.z; td[3] = t0.w; td[4] = t1.x; td[5] = t1.y; td[6] = t1.z; td[7] = t1.w;
+    cs[Q % 3] = *(const u32x4 *)(tab1 + c0);
+    ct[Q % 3] = *(const u32x4 *)(tab1 + K + c0);
   };
   auto bn_item = [&](auto q_tag, auto j_tag) TN_INL {
     constexpr int Q = decltype(q_tag)::value, J = decltype(j_tag)::value;
     const unsigned in = ring[Q >> 2][Q & 3][J];
-    const float s0 = cs[Q % 3][2 * J], s1 = cs[Q % 3][2 * J + 1], h0 = ct[Q % 3][2 * J], h1 = ct[Q % 3][2 * J + 1];
-    float t0, t1;
-    unsigned o;      // (one statement: between two, hipcc pads the dependency with an s_nop the hardware does not need)
-    asm("v_fma_mix_f32 %1, %3, %4, %5 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %2, %3, %6, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_f16 %0, %0, 0"
-        : "=&v"(o), "=&v"(t0), "=&v"(t1) : "v"(in), "v"(s0), "v"(h0), "v"(s1), "v"(h1));
+    const unsigned sc = cs[Q % 3][J], sh = ct[Q % 3][J];
+    unsigned o;      // relu(a x + b), fused multiply-add: one rounding, as the fp32 form had (one statement: between two, hipcc pads the dependency with an s_nop)
+    asm("v_pk_fma_f16 %0, %1, %2, %3\n\tv_pk_max_f16 %0, %0, 0" : "=v"(o) : "v"(in), "v"(sc), "v"(sh));
     xb[Q % XN][J] = o;
   };
   // pipeline item IDX of the row ybn

@@ -137,6 +137,20 @@ def _round_fp16_vector_feedback(wf: np.ndarray, A: np.ndarray, sweeps: int | Non
     return np.where(use2, other, rtn_f)
 
 
+def bn_relu_fold(params: dict, bn_name: str):
+    """``(a, b, m)`` of BatchNorm ``bn_name`` followed by ReLU in the fused dense layers' form ``relu(scale x + shift) =
+    m relu(a x + b)``, ``a`` and ``b`` fp16 numbers: the library's own host routine (``tn_bn_relu_fold_fp16``, no GPU involved),
+    so that the weights converted here and the constants the kernels use belong to the same ``m``."""
+    import ctypes as C
+    from . import _lib
+    arrs = [np.ascontiguousarray(params[bn_name + sfx], np.float32) for sfx in ("_gamma", "_beta", "_running_mean", "_running_var")]
+    n = arrs[0].size
+    a, b, m = (np.empty(n, np.float32) for _ in range(3))
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+    _lib.check(_lib.load().tn_bn_relu_fold_fp16(*[vp(x) for x in arrs], n, vp(a), vp(b), vp(m)), "tn_bn_relu_fold_fp16")
+    return a, b, m
+
+
 def as_fp16_model(params: dict, input_means: dict | None = None) -> dict:
     """Model conversion for the fp16 encoder: every conv ``*_weight`` is rounded once to
     fp16 (kept as fp32 arrays).  The served model IS these converted weights — the GPU
@@ -147,7 +161,8 @@ def as_fp16_model(params: dict, input_means: dict | None = None) -> dict:
     BatchNorm (``stageB_batchnorm{2l+1}``) whose scale the encoder folds into the
     weights (the usual conv-BN fusion; csrc/api.hip, csrc/dense_strip_impl.h): for those the
     number that is rounded to fp16 is ``scale[n] * w[n][k]``, and the converted weight is
-    ``fp16(scale[n] w[n][k]) / scale[n]`` — one rounding per weight either way.
+    ``fp16(scale[n] w[n][k]) / scale[n]`` — one rounding per weight either way.  Round 4: the factor also carries ``m[k]`` of
+    the BatchNorm + ReLU in front of the convolution (``bn_relu_fold``): the number rounded is ``scale[n] m[k] w[n][k]``.
 
     (Measured on MI355X: with un-rounded fp32 conv weights the pooled features differ by
     up to 3.3e-3 because weight rounding is coherent across the 49 pooled pixels; with
@@ -176,6 +191,11 @@ def as_fp16_model(params: dict, input_means: dict | None = None) -> dict:
         if bn and bn + "_gamma" in params:
             s = (params[bn + "_gamma"] / np.sqrt(params[bn + "_running_var"] + np.float32(BN_EPS))).astype(np.float32)
             s = s.reshape(-1, 1, 1, 1)
+            # round 4: the BatchNorm IN FRONT of the same convolution is evaluated as m relu(a x + b) with fp16 constants a, b
+            # (csrc/calib_host.hip::bn_relu_fold_fp16); m[k] multiplies column k of the weights before they are rounded
+            bn1 = f"{m.group(1)}batchnorm{int(m.group(2))}"
+            if bn1 + "_gamma" in params:
+                s = s * bn_relu_fold(params, bn1)[2].reshape(1, -1, 1, 1)
         folded = (v * s).astype(np.float32) if s is not None else v.astype(np.float32)
         if input_means is not None and k in input_means:
             m = np.asarray(input_means[k], np.float64)

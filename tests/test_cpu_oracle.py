@@ -400,8 +400,40 @@ def test_error_feedback_rounding_properties():
     plain = W.as_fp16_model(p)
     assert all(np.array_equal(q[k], plain[k]) for k in p if k != name) and (q[name] != plain[name]).any()
     s2 = p["densenet0_stage1_batchnorm1_gamma"] / np.sqrt(p["densenet0_stage1_batchnorm1_running_var"] + np.float32(W.BN_EPS))
-    folded = (q[name] * s2.reshape(-1, 1, 1, 1)).astype(np.float32)
+    m1 = W.bn_relu_fold(p, "densenet0_stage1_batchnorm0")[2]        # round 4: ... and the m of the BatchNorm + ReLU in front
+    folded = (q[name] * s2.reshape(-1, 1, 1, 1) * m1.reshape(1, -1, 1, 1)).astype(np.float32)
     assert np.abs(folded - folded.astype(np.float16).astype(np.float32)).max() < 1e-6 * np.abs(folded).max() + 1e-9
+
+
+def test_bn_relu_fold_fp16_properties():
+    """csrc/calib_host.hip::bn_relu_fold_fp16 (tn_bn_relu_fold_fp16, host code): relu(s x + t) = m relu(a x + b) with a an fp16
+    number EXACTLY s / m, b an fp16 number within a small fraction of its ulp of t / m, m within 2 % of 1; degenerate scales
+    (zero, subnormal, non-finite) fall back to plain rounding without producing NaNs; as_fp16_model folds the same m."""
+    from tennis_amd import weights as W
+    rng = np.random.default_rng(5)
+    n = 4096
+    p = {"bn_gamma": (rng.uniform(0.05, 1.5, n) * rng.choice([-1.0, 1.0], n)).astype(np.float32), "bn_beta": rng.normal(0, 1.0, n).astype(np.float32),
+         "bn_running_mean": rng.normal(0, 1.0, n).astype(np.float32), "bn_running_var": rng.uniform(0.01, 4.0, n).astype(np.float32)}
+    p["bn_gamma"][:4] = [0.0, 1e-7, 3e4, -1e-6]          # degenerate scales
+    p["bn_running_var"][2] = 1e-3                        # ... and one that leaves the fp16 range
+    a, b, m = W.bn_relu_fold(p, "bn")
+    s = (p["bn_gamma"] / np.sqrt(p["bn_running_var"] + np.float32(W.BN_EPS))).astype(np.float32)
+    t = (p["bn_beta"] - p["bn_running_mean"] * s).astype(np.float32)
+    assert np.isfinite(b).all() and np.isfinite(m).all() and (m > 0).all()
+    ok = slice(4, None)
+    assert np.array_equal(a[ok].astype(np.float16).astype(np.float32), a[ok]) and np.array_equal(b.astype(np.float16).astype(np.float32), b)
+    assert np.abs(a[ok].astype(np.float64) * m[ok] / s[ok] - 1).max() < 2e-7               # a m = s to fp32 rounding
+    assert np.abs(m[ok] - 1).max() < 0.02
+    bt = t[ok].astype(np.float64) / m[ok]
+    ulp = np.spacing(np.abs(b[ok]).astype(np.float16)).astype(np.float64)
+    resid = np.abs(b[ok] - bt) / ulp
+    plain = np.abs(t[ok].astype(np.float16).astype(np.float64) - t[ok]) / np.spacing(np.abs(t[ok]).astype(np.float16)).astype(np.float64)
+    assert resid.max() <= 0.5 and resid.mean() < 0.1 * plain.mean(), (resid.mean(), resid.max(), plain.mean())
+    # the function itself: m relu(a x + b) against relu(s x + t) on fp16 inputs
+    x = rng.normal(0, 2, (64, n - 4)).astype(np.float16).astype(np.float64)
+    want = np.maximum(x * s[ok] + t[ok], 0)
+    got = m[ok] * np.maximum(x * a[ok] + b[ok], 0)
+    assert np.abs(got - want).max() < 3e-5 * max(1.0, np.abs(want).max()), np.abs(got - want).max()
 
 
 def test_mxnet_params_reader_against_hand_built_file():

@@ -18,7 +18,10 @@ pytestmark = pytest.mark.gpu
 # families without large perfectly flat regions (on a flat region every pixel makes the SAME fp16 activation-rounding error, which the
 # average pool cannot reduce: that part belongs to the fp16 activation path, not to the weight conversion - rows "kernels alone" /
 # "exact-weights mode" of the matrix)
-NATURAL = ["noise", "lowcontrast", "blobs", "scene", "dark", "bright", "tinted", "photo", "jpeg", "stripes", "checker"]
+# (round 4, second pass: "bright" - blobs compressed into the top tenth of the range - and "stripes" are piecewise flat as well; with
+# the packed-half BN1 the same conversion realised 1.1e-3 / 1.4e-3 there where the fp32-constant form had realised 7.4e-4 / 8.4e-4,
+# the exact-weights mode measuring 1.5e-3 / 1.0 - 1.3e-3 on them in both: they were inside the bar by the luck of one realisation)
+NATURAL = ["noise", "lowcontrast", "gradient", "blobs", "scene", "dark", "tinted", "photo", "jpeg", "checker"]
 
 
 def _jpeg_frames(n, size=224):
@@ -102,7 +105,7 @@ def test_calibration_matrix(world, report):
     # the bar holds on every family without large flat regions, held-out ones included ...
     for f in NATURAL:
         assert default[f] < 1e-3, (f, default[f])
-    # ... frames with large perfectly flat regions (constant colour, saturated patches, half-black, text on white, gradients) stay
+    # ... frames with large flat regions (constant colour, saturated patches, half-black, text on white, stripes, near-white blobs) stay
     # within 2e-3 - their measured values are what bench.py quotes - and no further from the bar than the exact-weights mode is
     # on the same frames plus 5e-4: what is left there is the fp16 activation path, not the conversion
     assert max(default.values()) < 2e-3, default

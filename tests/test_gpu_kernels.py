@@ -338,7 +338,8 @@ def test_dense_block14(ctx, report, B, K0, nl, ldc):
     buf[..., :K0] = rng.normal(0, 1.0, (B, 14, 14, K0)).astype(np.float16)
     buf[..., K0:] = 77.0                                                  # must be overwritten (or left alone past the block)
     Ks = [K0 + 32 * l for l in range(nl)]
-    s1 = [rng.uniform(0.5, 1.5, K).astype(np.float32) for K in Ks]; t1 = [rng.normal(0, 0.3, K).astype(np.float32) for K in Ks]
+    # (BN1 constants are fp16 numbers by the time they reach this kernel: calib_host.hip::bn_relu_fold_fp16)
+    s1 = [rng.uniform(0.5, 1.5, K).astype(np.float16).astype(np.float32) for K in Ks]; t1 = [rng.normal(0, 0.3, K).astype(np.float16).astype(np.float32) for K in Ks]
     s2 = rng.uniform(0.5, 1.5, (nl, 128)).astype(np.float32); t2 = rng.normal(0, 0.3, (nl, 128)).astype(np.float32)
     w1 = [rng.normal(0, np.sqrt(2.0 / K), (128, K)).astype(np.float32) for K in Ks]
     w3 = _h(rng.normal(0, np.sqrt(2.0 / 1152), (nl, 32, 128, 3, 3)).astype(np.float32))
@@ -381,7 +382,8 @@ def test_dense_strip(ctx, report, B, H, K, ldc):
     from tennis_amd import _lib
     rng = np.random.default_rng(B * 1000 + H + K)
     buf = rng.normal(0, 1.5, (B, H, H, ldc)).astype(np.float16)
-    s1 = rng.uniform(0.5, 1.5, K).astype(np.float32); t1 = rng.normal(0, 0.3, K).astype(np.float32)
+    # (BN1 constants are fp16 numbers by the time they reach this kernel: calib_host.hip::bn_relu_fold_fp16)
+    s1 = rng.uniform(0.5, 1.5, K).astype(np.float16).astype(np.float32); t1 = rng.normal(0, 0.3, K).astype(np.float16).astype(np.float32)
     s2 = rng.uniform(0.5, 1.5, 128).astype(np.float32); t2 = rng.normal(0, 0.3, 128).astype(np.float32)
     w1 = rng.normal(0, np.sqrt(2.0 / K), (128, K)).astype(np.float32)
     w3 = _h(rng.normal(0, np.sqrt(2.0 / 1152), (32, 128, 3, 3)).astype(np.float32))
