@@ -259,6 +259,13 @@ typedef struct tn_gnmt_trainer tn_gnmt_trainer;
 int tn_gnmt_trainer_create(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix, tn_rnn_kind cell_kind,
                            int input_size, int hidden, int embed, int vocab, int max_batch, int max_src_len,
                            int max_tgt_len, tn_gnmt_trainer **out);
+/* Any layer count the inference handle serves (tn_gnmt_create_ex): num_layers >= 2, 0 <= num_bi_layers < num_layers, flags =
+ * TN_GNMT_USE_RESIDUAL or 0 - the arguments the reference passes into the model it trains (train_gnmt.py:58-61,223-227;
+ * models/captioning/gnmt.py:71-111,153-157,393-396).  Parameter names: enc_rnn{i}_l_ / _r_ (bidirectional layers), enc_rnn{i}_,
+ * dec_rnn{j}_.  tn_gnmt_trainer_create = (2, 1, 0), the reference's flag defaults. */
+int tn_gnmt_trainer_create_ex(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix, tn_rnn_kind cell_kind,
+                              int input_size, int hidden, int embed, int vocab, int num_layers, int num_bi_layers, int flags,
+                              int max_batch, int max_src_len, int max_tgt_len, tn_gnmt_trainer **out);
 int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float *src, const int32_t *src_valid_len,
                                      const int32_t *tgt, int ld, const int32_t *tgt_valid_len, int batch, int steps,
                                      int tgt_len, float *loss, float *logits_out);
@@ -267,6 +274,9 @@ int tn_gnmt_trainer_buffers(tn_gnmt_trainer *t, float **params_dev, float **grad
  * dropout from a counter-based generator; 0 until set.  tn_gnmt_trainer_dropout_masks: the last step's masks (test hook). */
 int tn_gnmt_trainer_set_dropout(tn_gnmt_trainer *t, float p, uint64_t seed);
 int tn_gnmt_trainer_dropout_masks(tn_gnmt_trainer *t, float **m_enc0, float **m_enc1, float **m_dec);
+/* one mask of the last step (test hook): which = encoder layer 0 .. num_layers - 1 -> (B*T, dirs*H); num_layers + j -> decoder layer
+ * j >= 1, (L*B, H) step-major */
+int tn_gnmt_trainer_dropout_mask(tn_gnmt_trainer *t, int which, float **mask);
 int tn_gnmt_trainer_adam_step(tn_gnmt_trainer *t, float lr, float beta1, float beta2, float epsilon);
 int tn_gnmt_trainer_read_param(tn_gnmt_trainer *t, const char *name, int gradient, float *out_host, int64_t capacity,
                                int64_t *numel);

@@ -69,45 +69,74 @@ def _direction(x, w, pref, reverse, vl, cell="gru"):
     return torch.stack(outs, dim=1), h, c
 
 
-def forward_loss(params: dict, src, src_vl, tgt, tgt_vl, hidden, prefix="gnmt_", dtype=torch.float64, masks=None, cell="gru"):
-    """-> (loss scalar tensor, logits (B, L-1, V), leaf tensors dict).  masks = (m_enc0 (B,T,2H), m_enc1 (B,T,H), m_dec (L,B,H))
-    are the dropout masks (already scaled by 1/(1-p)) of gnmt.py:152,395; None = no dropout."""
+def forward_loss(params: dict, src, src_vl, tgt, tgt_vl, hidden, prefix="gnmt_", dtype=torch.float64, masks=None, cell="gru",
+                 num_layers=2, num_bi_layers=1, use_residual=False):
+    """-> (loss scalar tensor, logits (B, L-1, V), leaf tensors dict).
+
+    ``num_layers`` / ``num_bi_layers`` / ``use_residual``: GNMTEncoder.forward (gnmt.py:136-160: dropout on every layer's output,
+    ``outputs + inputs`` for layers ``i > num_bi_layers``, the backward direction's states of a bidirectional layer) and
+    GNMTDecoder.hybrid_forward (gnmt.py:369-404: every cell behind the first reads ``[output of the layer below, attention]``, its
+    output goes through dropout and, with ``use_residual``, gets the layer's input added).
+
+    masks: the dropout masks (already scaled by 1/(1-p)); None = no dropout.  Two-layer form (rounds 2-3): a tuple
+    ``(m_enc0 (B,T,2H), m_enc1 (B,T,H), m_dec (L,B,H))``; general form: a dict ``{"enc": [per encoder layer (B,T,dirs*H)],
+    "dec": {j: (L,B,H) for decoder layers j >= 1}}``."""
     w = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True) for k, v in params.items()}
     x = torch.tensor(np.asarray(src), dtype=dtype)
     vl = torch.tensor(np.asarray(src_vl), dtype=torch.long)
     B, T, _ = x.shape
     H = hidden
+    NL, NBI = num_layers, num_bi_layers
+    if masks is not None and not isinstance(masks, dict):
+        assert NL == 2
+        masks = {"enc": [masks[0], masks[1]], "dec": {1: masks[2]}}
+    tt = lambda a: torch.tensor(np.asarray(a), dtype=dtype)
     pe = prefix + "enc_"
-    fo, _, _ = _direction(x, w, pe + "rnn0_l_", False, vl, cell)
-    bo, bh0, bc0 = _direction(x, w, pe + "rnn0_r_", True, vl, cell)
-    seq0 = torch.cat([fo, bo], dim=2)
-    if masks is not None:
-        seq0 = seq0 * torch.tensor(np.asarray(masks[0]), dtype=dtype)      # dropout on the layer output (states are not dropped)
-    mem, h1, c1 = _direction(seq0, w, pe + "rnn1_", False, vl, cell)
-    if masks is not None:
-        mem = mem * torch.tensor(np.asarray(masks[1]), dtype=dtype)
+    inputs = x
+    h_init, c_init = [], []
+    for i in range(NL):
+        if i < NBI:
+            fo, _, _ = _direction(inputs, w, f"{pe}rnn{i}_l_", False, vl, cell)
+            bo, bh, bc = _direction(inputs, w, f"{pe}rnn{i}_r_", True, vl, cell)
+            out = torch.cat([fo, bo], dim=2)
+            h_init.append(bh); c_init.append(bc)
+        else:
+            out, hh, cc = _direction(inputs, w, f"{pe}rnn{i}_", False, vl, cell)
+            h_init.append(hh); c_init.append(cc)
+        if masks is not None:
+            out = out * tt(masks["enc"][i])            # dropout on the layer output (states are not dropped)
+        if use_residual and i > NBI:
+            out = out + inputs
+        inputs = out
+    mem = inputs
     keyproj = mem @ w[prefix + "dec_attention_key_weight"].T
     mask = (torch.arange(T)[None, :] < vl[:, None])
     tg = torch.tensor(np.asarray(tgt), dtype=torch.long)
     tvl = torch.tensor(np.asarray(tgt_vl), dtype=torch.long) - 1
     L = tg.shape[1] - 1
-    h0s, h1s, att = bh0, h1, torch.zeros((B, H), dtype=dtype)
-    c0s, c1s = bc0, c1
+    hs, cs = list(h_init), list(c_init)
+    att = torch.zeros((B, H), dtype=dtype)
     pd = prefix + "dec_"
+    cw = lambda j: (w[f"{pd}rnn{j}_i2h_weight"], w[f"{pd}rnn{j}_h2h_weight"], w[f"{pd}rnn{j}_i2h_bias"], w[f"{pd}rnn{j}_h2h_bias"])
     logits = []
     for i in range(L):
         emb = w[prefix + "tgt_embed_weight"][tg[:, i].clamp(min=0)]
-        h0s, c0s = _cell(cell, torch.cat([emb, att], dim=1), h0s, c0s, w[pd + "rnn0_i2h_weight"], w[pd + "rnn0_h2h_weight"],
-                         w[pd + "rnn0_i2h_bias"], w[pd + "rnn0_h2h_bias"])
-        q = h0s / np.sqrt(H)
+        hs[0], cs[0] = _cell(cell, torch.cat([emb, att], dim=1), hs[0], cs[0], *cw(0))
+        q = hs[0] / np.sqrt(H)
         score = torch.einsum("bh,bth->bt", q, keyproj)
         score = torch.where(mask, score, torch.full_like(score, -1e18))
         wts = torch.softmax(score, dim=1) * mask.to(dtype)
         att = torch.einsum("bt,bth->bh", wts, mem)
-        h1s, c1s = _cell(cell, torch.cat([h0s, att], dim=1), h1s, c1s, w[pd + "rnn1_i2h_weight"], w[pd + "rnn1_h2h_weight"],
-                         w[pd + "rnn1_i2h_bias"], w[pd + "rnn1_h2h_bias"])
-        top = h1s if masks is None else h1s * torch.tensor(np.asarray(masks[2][i]), dtype=dtype)
-        logits.append(top @ w[prefix + "tgt_proj_weight"].T + w[prefix + "tgt_proj_bias"])
+        rnn_out = hs[0]
+        for j in range(1, NL):
+            cur = rnn_out
+            hs[j], cs[j] = _cell(cell, torch.cat([cur, att], dim=1), hs[j], cs[j], *cw(j))
+            rnn_out = hs[j]
+            if masks is not None:
+                rnn_out = rnn_out * tt(masks["dec"][j][i])
+            if use_residual:
+                rnn_out = rnn_out + cur
+        logits.append(rnn_out @ w[prefix + "tgt_proj_weight"].T + w[prefix + "tgt_proj_bias"])
     logits = torch.stack(logits, dim=1)                                       # (B, L, V)
     logp = torch.log_softmax(logits, dim=2)
     nll = -torch.gather(logp, 2, tg[:, 1:, None]).squeeze(2)
@@ -117,8 +146,10 @@ def forward_loss(params: dict, src, src_vl, tgt, tgt_vl, hidden, prefix="gnmt_",
     return loss, logits, w
 
 
-def loss_and_grads(params, src, src_vl, tgt, tgt_vl, hidden, prefix="gnmt_", masks=None, cell="gru"):
-    loss, logits, w = forward_loss(params, src, src_vl, tgt, tgt_vl, hidden, prefix, masks=masks, cell=cell)
+def loss_and_grads(params, src, src_vl, tgt, tgt_vl, hidden, prefix="gnmt_", masks=None, cell="gru", num_layers=2, num_bi_layers=1,
+                   use_residual=False):
+    loss, logits, w = forward_loss(params, src, src_vl, tgt, tgt_vl, hidden, prefix, masks=masks, cell=cell, num_layers=num_layers,
+                                   num_bi_layers=num_bi_layers, use_residual=use_residual)
     loss.backward()
     return float(loss.detach()), logits.detach().numpy(), {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape)) for k, v in w.items()}
 

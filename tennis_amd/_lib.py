@@ -88,6 +88,9 @@ _SIGS = {
     "tn_finetune_destroy": (C.c_int, [_P]),
     "tn_gnmt_trainer_create": (C.c_int, [_P, C.POINTER(TnParam), C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "tn_gnmt_trainer_create_ex": (C.c_int, [_P, C.POINTER(TnParam), C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "tn_gnmt_trainer_dropout_mask": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
     "tn_gnmt_trainer_forward_backward": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "tn_gnmt_trainer_buffers": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int64)]),
     "tn_gnmt_trainer_set_dropout": (C.c_int, [_P, C.c_float, C.c_uint64]),

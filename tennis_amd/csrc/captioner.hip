@@ -1192,50 +1192,121 @@ extern "C" int tn_masked_softmax_ce(tn_ctx *ctx, const float *logits, const int3
 }
 
 // ---- captioner training handle ------------------------------------------------------------------------------------------
+// Round 4: any num_layers >= 2 with num_bi_layers < num_layers and use_residual, as the reference passes them into the model it
+// trains (train_gnmt.py:58-61,223-227; gnmt.py:71-111,136-160,369-404).  Every encoder / decoder layer is a record of its
+// parameter offsets, the forward state kept for the backward pass and its backward workspace; the step below walks the records.
+namespace {
+
+// a decoder cell behind the first one: gates on the stacked pre-activations g (R,4H) of x = [layer input, attention, h_prev];
+// the new state to hn (+ cn); the layer's OUTPUT = dropout(h) (+ the layer's input with use_residual, gnmt.py:393-396) to
+// out (row stride ldo: the next layer's step input, or the rows the projection reads); the attention vector is copied along
+__global__ void trn_cell_fwd_kernel(const float *__restrict__ g, const float *__restrict__ x, int lstm, const float *__restrict__ cprev,
+                                    float *__restrict__ hn, float *__restrict__ cn, const float *__restrict__ mask, int residual,
+                                    float *__restrict__ out, int ldo, float *__restrict__ att_dst, int R, int H) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)R * H) return;
+  const long r = id / H;
+  const int u = (int)(id - r * H);
+  const float *gr = g + r * 4 * H;
+  float h;
+  if (lstm) {
+    const float ig = sigm(gr[u]), fg = sigm(gr[H + u]), gg = tanhf(gr[2 * H + u]), og = sigm(gr[3 * H + u]);
+    const float c2 = fg * cprev[id] + ig * gg;
+    cn[id] = c2;
+    h = og * tanhf(c2);
+  } else {
+    const float rg = sigm(gr[u]), zg = sigm(gr[H + u]);
+    const float ng = tanhf(gr[2 * H + u] + rg * gr[3 * H + u]);
+    h = (1.f - zg) * ng + zg * x[r * 3 * H + 2 * H + u];
+  }
+  hn[id] = h;
+  out[r * ldo + u] = (mask ? h * mask[id] : h) + (residual ? x[r * 3 * H + u] : 0.f);
+  if (att_dst) att_dst[r * ldo + u] = x[r * 3 * H + H + u];
+}
+
+// out (R,H) = a[r * la + u] (* m[r * H + u]) (+ b[r * lb + u])
+__global__ void trn_combine_kernel(const float *__restrict__ a, int la, const float *__restrict__ m, const float *__restrict__ b, int lb,
+                                   float *__restrict__ out, int R, int H) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)R * H) return;
+  const long r = id / H;
+  const int u = (int)(id - r * H);
+  float v = a[r * la + u];
+  if (m) v *= m[id];
+  if (b) v += b[r * lb + u];
+  out[id] = v;
+}
+// dst[r * ld + u] = src[r * ls + u]
+__global__ void trn_copy_kernel(const float *__restrict__ src, int ls, float *__restrict__ dst, int ld, int R, int H) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)R * H) return;
+  const long r = id / H;
+  const int u = (int)(id - r * H);
+  dst[r * ld + u] = src[r * ls + u];
+}
+// y = x * m + r (element-wise over n; m / r optional)
+__global__ void trn_mul_add_kernel(const float *__restrict__ x, const float *__restrict__ m, const float *__restrict__ r,
+                                   float *__restrict__ y, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = x[i];
+  if (m) v *= m[i];
+  if (r) v += r[i];
+  y[i] = v;
+}
+
+struct TrnEnc {          // encoder layer i: bidirectional (i < num_bi_layers: in -> 2H) or uni-directional (in -> H)
+  int in, D, out;        // input width, directions, output width D * H
+  bool res;              // use_residual && i > num_bi_layers (gnmt.py:155-157)
+  long o_wi, o_bi, o_wh, o_bh;     // the directions adjacent per tensor kind: one GEMM / one recurrent launch serves both
+  float *whT, *wiT;      // per direction (H, GH); (in, D GH) [layers behind the first]
+  float *gi, *seq, *sav, *hl, *cl, *M, *xn;       // xn: what the next layer (or the attention) reads = dropout(seq) (+ input)
+  float *dxn, *dseq, *dgi, *dgh, *hp, *dhl, *dcl; // dxn: gradient w.r.t. xn
+};
+struct TrnDec {          // decoder cell j: step input x = [embedding | layer input, attention, h_prev], K = in + H columns
+  int in, K;
+  long o_wi, o_bi, o_wh, o_bh;
+  float *wc, *bc, *wcT;  // stacked (4H, K) step matrix, its bias, its transpose
+  float *X, *G, *C, *Hs, *M;       // per step (L, B, .): inputs, stacked pre-activations, cell states (LSTM), states h (j >= 1), dropout masks (j >= 1)
+  float *dG, *dX, *dhz, *dcz, *dW, *db;
+};
+
+}  // namespace
+
 struct tn_gnmt_trainer {
   tn_ctx *ctx;
   DevBuf pool;
-  int F, H, E, V, maxB, maxT, maxL;
+  int F, H, E, V, maxB, maxT, maxL, NL, NBI;
+  bool residual;
   int G;                          // gates per cell: 3 GRU, 4 LSTM
   std::string prefix;
-  // flat parameter / gradient / Adam-moment buffers; the two directions of the bi layer are adjacent per tensor kind so that
-  // one GEMM / one recurrent launch serves both
   long n, step;
-  long o_e0wi, o_e0bi, o_e0wh, o_e0bh, o_e1wi, o_e1bi, o_e1wh, o_e1bh, o_d0wi, o_d0bi, o_d0wh, o_d0bh, o_d1wi, o_d1bi,
-      o_d1wh, o_d1bh, o_wk, o_wp, o_bp, o_emb;
-  float *w, *g, *am, *av;
-  // derived forms of the weights, refreshed after every update
-  float *e0whT, *e1whT, *e1wiT, *w0c, *b0c, *w1c, *b1c, *w0cT, *w1cT, *wpT, *wkT;
-  // forward state kept for the backward pass
-  float *gi0, *seq0, *sav0, *gi1, *mem, *sav1, *hl0, *hl1, *keyproj, *keyprojT;
-  float *X0, *G0, *X1, *G1, *H1, *AW, *h0tmp, *ctxtmp, *logits, *lossrows;
+  long o_wk, o_wp, o_bp, o_emb;
+  float *w, *g, *am, *av;         // flat parameter / gradient / Adam-moment buffers
+  std::vector<TrnEnc> enc;
+  std::vector<TrnDec> dec;
+  float *wpT, *wkT;
+  float *keyproj, *keyprojT, *AW, *h0tmp, *ctxtmp, *logits, *lossrows, *Out, *dlog, *dOut, *dq, *dkp, *tmpA, *tmpB, *tmpM, *tmpAtt;
   int32_t *vl, *tvl;
-  // backward workspace
-  float *dlog, *dH1, *dG0, *dG1, *dX0, *dX1, *dhz0, *dhz1, *dq, *dmem, *dkp, *dW0c, *db0c, *dW1c, *db1c;
-  float *dhl0, *dhl1, *dgi1, *dgh1, *hp1, *dseq0, *dgi0, *dgh0, *hp0;
-  // dropout (gnmt.py:152,395: after each encoder layer and on the top decoder cell's output): masks and dropped copies
   float drop_p;
   unsigned long long drop_seed, drop_count;
-  float *M0, *M1, *M2, *seq0d, *memd, *H1d;
-  // LSTM cell states: encoder finals, decoder per step, and their gradients
-  float *cl0, *cl1, *C0, *C1, *dcz0, *dcz1, *dcl0, *dcl1;
 };
 
 static int trainer_refresh(tn_gnmt_trainer *t) {
   hipStream_t s = t->ctx->stream;
-  const int H = t->H, E = t->E, V = t->V, GH = t->G * H, K0 = E + 2 * H, K1 = 3 * H, lstm = t->G == 4;
+  const int H = t->H, V = t->V, GH = t->G * H, lstm = t->G == 4;
   int rc;
 #define TN_TRY(e) do { rc = (e); if (rc) return rc; } while (0)
-  for (int d = 0; d < 2; ++d)
-    TN_TRY(launch_transpose_f32(t->w + t->o_e0wh + (long)d * GH * H, GH, H, t->e0whT + (long)d * H * GH, s));
-  TN_TRY(launch_transpose_f32(t->w + t->o_e1wh, GH, H, t->e1whT, s));
-  TN_TRY(launch_transpose_f32(t->w + t->o_e1wi, GH, 2 * H, t->e1wiT, s));
-  hipLaunchKernelGGL(trn_stack_kernel, dim3(4 * H), dim3(256), 0, s, (const float *)(t->w + t->o_d0wi), (const float *)(t->w + t->o_d0wh),
-                     (const float *)(t->w + t->o_d0bi), (const float *)(t->w + t->o_d0bh), E + H, H, lstm, t->w0c, t->b0c);
-  hipLaunchKernelGGL(trn_stack_kernel, dim3(4 * H), dim3(256), 0, s, (const float *)(t->w + t->o_d1wi), (const float *)(t->w + t->o_d1wh),
-                     (const float *)(t->w + t->o_d1bi), (const float *)(t->w + t->o_d1bh), 2 * H, H, lstm, t->w1c, t->b1c);
-  TN_TRY(launch_transpose_f32(t->w0c, 4 * H, K0, t->w0cT, s));
-  TN_TRY(launch_transpose_f32(t->w1c, 4 * H, K1, t->w1cT, s));
+  for (size_t i = 0; i < t->enc.size(); ++i) {
+    TrnEnc &e = t->enc[i];
+    for (int d = 0; d < e.D; ++d) TN_TRY(launch_transpose_f32(t->w + e.o_wh + (long)d * GH * H, GH, H, e.whT + (long)d * H * GH, s));
+    if (i > 0) TN_TRY(launch_transpose_f32(t->w + e.o_wi, e.D * GH, e.in, e.wiT, s));
+  }
+  for (TrnDec &d : t->dec) {
+    hipLaunchKernelGGL(trn_stack_kernel, dim3(4 * H), dim3(256), 0, s, (const float *)(t->w + d.o_wi), (const float *)(t->w + d.o_wh),
+                       (const float *)(t->w + d.o_bi), (const float *)(t->w + d.o_bh), d.in, H, lstm, d.wc, d.bc);
+    TN_TRY(launch_transpose_f32(d.wc, 4 * H, d.K, d.wcT, s));
+  }
   TN_TRY(launch_transpose_f32(t->w + t->o_wp, V, H, t->wpT, s));
   TN_TRY(launch_transpose_f32(t->w + t->o_wk, H, H, t->wkT, s));
 #undef TN_TRY
@@ -1243,11 +1314,15 @@ static int trainer_refresh(tn_gnmt_trainer *t) {
   return TN_OK;
 }
 
-extern "C" int tn_gnmt_trainer_create(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix_c, tn_rnn_kind cell_kind,
-                                      int input_size, int hidden, int embed, int vocab, int max_batch, int max_src_len,
-                                      int max_tgt_len, tn_gnmt_trainer **out) {
+extern "C" int tn_gnmt_trainer_create_ex(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix_c, tn_rnn_kind cell_kind,
+                                         int input_size, int hidden, int embed, int vocab, int num_layers, int num_bi_layers, int flags,
+                                         int max_batch, int max_src_len, int max_tgt_len, tn_gnmt_trainer **out) {
   TN_REQUIRE(ctx && params && prefix_c && out, "tn_gnmt_trainer_create: null argument");
   TN_REQUIRE(cell_kind == TN_RNN_GRU || cell_kind == TN_RNN_LSTM, "tn_gnmt_trainer_create: cell_type must be 'gru' or 'lstm'");
+  TN_REQUIRE((flags & ~TN_GNMT_USE_RESIDUAL) == 0, "tn_gnmt_trainer_create_ex: unknown flag");
+  // the same shapes tn_gnmt_create_ex serves (gnmt.py:78-80; a memory of 2H columns does not fit the attention's key width)
+  TN_REQUIRE(num_layers >= 2 && num_layers <= 8 && num_bi_layers >= 0 && num_bi_layers < num_layers,
+             "tn_gnmt_trainer_create: need 2 <= num_layers <= 8 and 0 <= num_bi_layers < num_layers");
   const int G_ = cell_kind == TN_RNN_GRU ? 3 : 4;
   TN_REQUIRE(input_size > 0 && hidden > 0 && hidden % 4 == 0 && G_ * hidden <= 1024 && embed > 0 && vocab > 1 && max_batch > 0 &&
                  max_src_len > 0 && max_tgt_len > 1, "tn_gnmt_trainer_create: bad shape (gates*hidden <= 1024, hidden % 4 == 0)");
@@ -1257,14 +1332,24 @@ extern "C" int tn_gnmt_trainer_create(tn_ctx *ctx, const tn_param *params, int n
   for (int i = 0; i < n_params; ++i) pm[params[i].name] = &params[i];
   tn_gnmt_trainer *t = new tn_gnmt_trainer();
   t->ctx = ctx; t->F = input_size; t->H = hidden; t->E = embed; t->V = vocab; t->maxB = max_batch; t->maxT = max_src_len;
-  t->maxL = max_tgt_len - 1; t->prefix = pre; t->step = 0; t->G = G_;
-  const long F = input_size, H = hidden, E = embed, V = vocab, GH = (long)G_ * H;
+  t->maxL = max_tgt_len - 1; t->prefix = pre; t->step = 0; t->G = G_; t->NL = num_layers; t->NBI = num_bi_layers;
+  t->residual = (flags & TN_GNMT_USE_RESIDUAL) != 0;
+  const long H = hidden, E = embed, V = vocab, GH = (long)G_ * H;
   long o = 0;
   auto take = [&](long cnt) { const long r = o; o += cnt; return r; };
-  t->o_e0wi = take(2 * GH * F); t->o_e0bi = take(2 * GH); t->o_e0wh = take(2 * GH * H); t->o_e0bh = take(2 * GH);
-  t->o_e1wi = take(GH * 2 * H); t->o_e1bi = take(GH); t->o_e1wh = take(GH * H); t->o_e1bh = take(GH);
-  t->o_d0wi = take(GH * (E + H)); t->o_d0bi = take(GH); t->o_d0wh = take(GH * H); t->o_d0bh = take(GH);
-  t->o_d1wi = take(GH * 2 * H); t->o_d1bi = take(GH); t->o_d1wh = take(GH * H); t->o_d1bh = take(GH);
+  t->enc.resize(num_layers); t->dec.resize(num_layers);
+  int fin = input_size;
+  for (int i = 0; i < num_layers; ++i) {
+    TrnEnc &e = t->enc[i];
+    e.in = fin; e.D = i < num_bi_layers ? 2 : 1; e.out = e.D * hidden; e.res = t->residual && i > num_bi_layers;
+    e.o_wi = take(e.D * GH * e.in); e.o_bi = take(e.D * GH); e.o_wh = take(e.D * GH * H); e.o_bh = take(e.D * GH);
+    fin = e.out;
+  }
+  for (int j = 0; j < num_layers; ++j) {
+    TrnDec &d = t->dec[j];
+    d.in = j == 0 ? embed + hidden : 2 * hidden; d.K = d.in + hidden;
+    d.o_wi = take(GH * d.in); d.o_bi = take(GH); d.o_wh = take(GH * H); d.o_bh = take(GH);
+  }
   t->o_wk = take(H * H); t->o_wp = take(V * H); t->o_bp = take(V); t->o_emb = take(V * E);
   t->n = o;
   std::vector<float> w(t->n);
@@ -1276,41 +1361,51 @@ extern "C" int tn_gnmt_trainer_create(tn_ctx *ctx, const tn_param *params, int n
     if (it->second->numel != cnt) { tn_set_error("parameter " + pre + name + " has the wrong size"); ok = false; return; }
     memcpy(&w[off], it->second->data_host, sizeof(float) * cnt);
   };
-  for (int d = 0; d < 2 && ok; ++d) {
-    const std::string c = std::string("enc_rnn0_") + (d ? "r_" : "l_");
-    put(c + "i2h_weight", t->o_e0wi + d * GH * F, GH * F); put(c + "i2h_bias", t->o_e0bi + d * GH, GH);
-    put(c + "h2h_weight", t->o_e0wh + d * GH * H, GH * H); put(c + "h2h_bias", t->o_e0bh + d * GH, GH);
+  for (int i = 0; i < num_layers && ok; ++i) {
+    const TrnEnc &e = t->enc[i];
+    for (int d = 0; d < e.D && ok; ++d) {
+      const std::string c = "enc_rnn" + std::to_string(i) + (e.D == 2 ? (d ? "_r_" : "_l_") : "_");
+      put(c + "i2h_weight", e.o_wi + d * GH * e.in, GH * e.in); put(c + "i2h_bias", e.o_bi + d * GH, GH);
+      put(c + "h2h_weight", e.o_wh + d * GH * H, GH * H); put(c + "h2h_bias", e.o_bh + d * GH, GH);
+    }
   }
-  put("enc_rnn1_i2h_weight", t->o_e1wi, GH * 2 * H); put("enc_rnn1_i2h_bias", t->o_e1bi, GH);
-  put("enc_rnn1_h2h_weight", t->o_e1wh, GH * H); put("enc_rnn1_h2h_bias", t->o_e1bh, GH);
-  put("dec_rnn0_i2h_weight", t->o_d0wi, GH * (E + H)); put("dec_rnn0_i2h_bias", t->o_d0bi, GH);
-  put("dec_rnn0_h2h_weight", t->o_d0wh, GH * H); put("dec_rnn0_h2h_bias", t->o_d0bh, GH);
-  put("dec_rnn1_i2h_weight", t->o_d1wi, GH * 2 * H); put("dec_rnn1_i2h_bias", t->o_d1bi, GH);
-  put("dec_rnn1_h2h_weight", t->o_d1wh, GH * H); put("dec_rnn1_h2h_bias", t->o_d1bh, GH);
-  put("dec_attention_key_weight", t->o_wk, H * H); put("tgt_proj_weight", t->o_wp, V * H); put("tgt_proj_bias", t->o_bp, V);
-  put("tgt_embed_weight", t->o_emb, V * E);
+  for (int j = 0; j < num_layers && ok; ++j) {
+    const TrnDec &d = t->dec[j];
+    const std::string c = "dec_rnn" + std::to_string(j) + "_";
+    put(c + "i2h_weight", d.o_wi, GH * d.in); put(c + "i2h_bias", d.o_bi, GH);
+    put(c + "h2h_weight", d.o_wh, GH * H); put(c + "h2h_bias", d.o_bh, GH);
+  }
+  if (ok) {
+    put("dec_attention_key_weight", t->o_wk, H * H); put("tgt_proj_weight", t->o_wp, V * H); put("tgt_proj_bias", t->o_bp, V);
+    put("tgt_embed_weight", t->o_emb, V * E);
+  }
   if (!ok) return fail(TN_ERR_MISSING);
   t->w = t->pool.upload(w.data(), w.size());
   auto fl = [&](size_t n) { return t->pool.alloc<float>(n); };
   t->g = fl(t->n); t->am = fl(t->n); t->av = fl(t->n);
-  const size_t B = max_batch, T = max_src_len, L = t->maxL, BT = B * T, LB = L * B, K0 = E + 2 * H, K1 = 3 * H;
-  t->e0whT = fl(2 * H * GH); t->e1whT = fl(H * GH); t->e1wiT = fl(2 * H * GH);
-  t->w0c = fl(4 * H * K0); t->b0c = fl(4 * H); t->w1c = fl(4 * H * K1); t->b1c = fl(4 * H);
-  t->w0cT = fl(4 * H * K0); t->w1cT = fl(4 * H * K1); t->wpT = fl(V * H); t->wkT = fl(H * H);
-  t->gi0 = fl(BT * 2 * GH); t->seq0 = fl(BT * 2 * H); t->sav0 = fl(2 * BT * (G_ + 1) * H); t->gi1 = fl(BT * GH); t->mem = fl(BT * H);
-  t->sav1 = fl(BT * (G_ + 1) * H); t->hl0 = fl(2 * B * H); t->hl1 = fl(B * H); t->keyproj = fl(BT * H); t->keyprojT = fl(BT * H);
-  t->X0 = fl(LB * K0); t->G0 = fl(LB * 4 * H); t->X1 = fl(LB * K1); t->G1 = fl(LB * 4 * H); t->H1 = fl(LB * H); t->AW = fl(LB * T);
-  t->h0tmp = fl(B * H); t->ctxtmp = fl(B * H); t->logits = fl(LB * V); t->lossrows = fl(LB);
+  const size_t B = max_batch, T = max_src_len, L = t->maxL, BT = B * T, LB = L * B;
+  for (int i = 0; i < num_layers; ++i) {
+    TrnEnc &e = t->enc[i];
+    const size_t D = e.D, DG = D * GH, O = e.out;
+    e.whT = fl(D * H * GH); e.wiT = i ? fl((size_t)e.in * DG) : nullptr;
+    e.gi = fl(BT * DG); e.seq = fl(BT * O); e.sav = fl(D * BT * (G_ + 1) * H); e.hl = fl(D * B * H); e.cl = fl(D * B * H);
+    e.M = fl(BT * O); e.xn = fl(BT * O);
+    e.dxn = fl(BT * O); e.dseq = fl(BT * O); e.dgi = fl(BT * DG); e.dgh = fl(BT * DG); e.hp = fl(D * BT * H);
+    e.dhl = fl(D * B * H); e.dcl = fl(D * B * H);
+  }
+  for (int j = 0; j < num_layers; ++j) {
+    TrnDec &d = t->dec[j];
+    const size_t K = d.K;
+    d.wc = fl(4 * H * K); d.bc = fl(4 * H); d.wcT = fl(4 * H * K);
+    d.X = fl(LB * K); d.G = fl(LB * 4 * H); d.C = fl(LB * H); d.Hs = fl(LB * H); d.M = fl(LB * H);
+    d.dG = fl(LB * 4 * H); d.dX = fl(LB * K); d.dhz = fl(B * H); d.dcz = fl(B * H); d.dW = fl(4 * H * K); d.db = fl(4 * H);
+  }
+  t->wpT = fl(V * H); t->wkT = fl(H * H);
+  t->keyproj = fl(BT * H); t->keyprojT = fl(BT * H); t->AW = fl(LB * T); t->h0tmp = fl(B * H); t->ctxtmp = fl(B * H);
+  t->logits = fl(LB * V); t->lossrows = fl(LB); t->Out = fl(LB * H); t->dlog = fl(LB * V); t->dOut = fl(LB * H); t->dq = fl(B * H);
+  t->dkp = fl(BT * H); t->tmpA = fl(B * H); t->tmpB = fl(B * H); t->tmpM = fl(B * H); t->tmpAtt = fl(B * H);
   t->vl = t->pool.alloc<int32_t>(B); t->tvl = t->pool.alloc<int32_t>(B);
-  t->dlog = fl(LB * V); t->dH1 = fl(LB * H); t->dG0 = fl(LB * 4 * H); t->dG1 = fl(LB * 4 * H); t->dX0 = fl(LB * K0);
-  t->dX1 = fl(LB * K1); t->dhz0 = fl(B * H); t->dhz1 = fl(B * H); t->dq = fl(B * H); t->dmem = fl(BT * H); t->dkp = fl(BT * H);
-  t->dW0c = fl(4 * H * K0); t->db0c = fl(4 * H); t->dW1c = fl(4 * H * K1); t->db1c = fl(4 * H);
-  t->dhl0 = fl(2 * B * H); t->dhl1 = fl(B * H); t->dgi1 = fl(BT * GH); t->dgh1 = fl(BT * GH); t->hp1 = fl(BT * H);
-  t->dseq0 = fl(BT * 2 * H); t->dgi0 = fl(BT * 2 * GH); t->dgh0 = fl(BT * 2 * GH); t->hp0 = fl(2 * BT * H);
-  t->M0 = fl(BT * 2 * H); t->M1 = fl(BT * H); t->M2 = fl(LB * H); t->seq0d = fl(BT * 2 * H); t->memd = fl(BT * H); t->H1d = fl(LB * H);
   t->drop_p = 0.f; t->drop_seed = 0; t->drop_count = 0;
-  t->cl0 = fl(2 * B * H); t->cl1 = fl(B * H); t->C0 = fl(LB * H); t->C1 = fl(LB * H); t->dcz0 = fl(B * H); t->dcz1 = fl(B * H);
-  t->dcl0 = fl(2 * B * H); t->dcl1 = fl(B * H);
   if (t->pool.failed) { tn_set_error("device allocation failed"); return fail(TN_ERR_NOMEM); }
   TN_HIP_CHECK(hipMemsetAsync(t->g, 0, sizeof(float) * t->n, ctx->stream));
   TN_HIP_CHECK(hipMemsetAsync(t->am, 0, sizeof(float) * t->n, ctx->stream));
@@ -1319,6 +1414,14 @@ extern "C" int tn_gnmt_trainer_create(tn_ctx *ctx, const tn_param *params, int n
   if (rc) return fail(rc);
   *out = t;
   return TN_OK;
+}
+
+// the reference's flag defaults (train_gnmt.py:58-61): two layers, the first bidirectional, no residual connections
+extern "C" int tn_gnmt_trainer_create(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix_c, tn_rnn_kind cell_kind,
+                                      int input_size, int hidden, int embed, int vocab, int max_batch, int max_src_len,
+                                      int max_tgt_len, tn_gnmt_trainer **out) {
+  return tn_gnmt_trainer_create_ex(ctx, params, n_params, prefix_c, cell_kind, input_size, hidden, embed, vocab, 2, 1, 0, max_batch,
+                                   max_src_len, max_tgt_len, out);
 }
 
 __global__ void trn_dec_len_kernel(const int32_t *__restrict__ tgt_vl, int32_t *__restrict__ out, int B) {
@@ -1339,7 +1442,8 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
              "tn_gnmt_trainer_forward_backward: batch / source steps / target length exceed the handle");
   TN_ON_DEVICE(t->ctx->device);
   hipStream_t s = t->ctx->stream;
-  const int B = batch, T = steps, L = tgt_len - 1, F = t->F, H = t->H, E = t->E, V = t->V, G = t->G, GH = G * H, K0 = E + 2 * H, K1 = 3 * H;
+  const int B = batch, T = steps, L = tgt_len - 1, H = t->H, E = t->E, V = t->V, G = t->G, GH = G * H, NL = t->NL;
+  const int K0 = E + 2 * H, K1 = 3 * H;
   const int BT = B * T, LB = L * B;
   const bool lstm = G == 4;
   const size_t att_lds = ((size_t)(H + T) * 4 + (size_t)4 * (T > H ? T : H)) * sizeof(float);
@@ -1351,53 +1455,70 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
   int rc;
 #define TN_TRY(e) do { rc = (e); if (rc) return rc; } while (0)
   const int nbH = (B * H + 255) / 256;
-  // ---------------- forward ----------------
+  const float *nul = nullptr;
+  auto blocks = [](long n) { return dim3((unsigned)((n + 255) / 256)); };
+  // ---------------- forward: encoder (gnmt.py:136-160) ----------------
   TN_HIP_CHECK(hipMemcpyAsync(t->vl, src_valid_len, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, s));
   hipLaunchKernelGGL(trn_dec_len_kernel, dim3((B + 255) / 256), dim3(256), 0, s, tgt_valid_len, t->tvl, B);
-  TN_TRY(launch_linear_f32(src, F, w + t->o_e0wi, F, w + t->o_e0bi, t->gi0, 2 * GH, BT, 2 * GH, F, 0, s));
-  TN_HIP_CHECK(hipMemsetAsync(t->seq0, 0, sizeof(float) * (size_t)BT * 2 * H, s));
-  TN_TRY(launch_rnn_recurrent(G, t->gi0, 2 * GH, t->e0whT, w + t->o_e0bh, t->vl, t->seq0, 2 * H, t->hl0, lstm ? t->cl0 : nullptr, B, T, H, 2, s, t->sav0));
-  // dropout points of the reference (gnmt.py:152,395); the recurrences themselves keep the un-dropped outputs
   const bool drop = t->drop_p > 0.f;
-  const float *seq0d = t->seq0, *memd = t->mem, *H1d = t->H1;
-  if (drop) {
-    const unsigned long long key = t->drop_seed * 0x2545F4914F6CDD1Dull + (++t->drop_count) * 0xD1342543DE82EF95ull;
-    const long n0 = (long)BT * 2 * H, n1 = (long)BT * H, n2 = (long)LB * H;
-    hipLaunchKernelGGL(trn_dropout_mask_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, t->M0, n0, t->drop_p, key ^ 0x1111ull);
-    hipLaunchKernelGGL(trn_dropout_mask_kernel, dim3((n1 + 255) / 256), dim3(256), 0, s, t->M1, n1, t->drop_p, key ^ 0x2222ull);
-    hipLaunchKernelGGL(trn_dropout_mask_kernel, dim3((n2 + 255) / 256), dim3(256), 0, s, t->M2, n2, t->drop_p, key ^ 0x3333ull);
-    hipLaunchKernelGGL(trn_mul_kernel, dim3((n0 + 255) / 256), dim3(256), 0, s, (const float *)t->seq0, (const float *)t->M0, t->seq0d, n0);
-    seq0d = t->seq0d; memd = t->memd; H1d = t->H1d;
-  }
-  TN_TRY(launch_linear_f32(seq0d, 2 * H, w + t->o_e1wi, 2 * H, w + t->o_e1bi, t->gi1, GH, BT, GH, 2 * H, 0, s));
-  TN_HIP_CHECK(hipMemsetAsync(t->mem, 0, sizeof(float) * (size_t)BT * H, s));
-  TN_TRY(launch_rnn_recurrent(G, t->gi1, GH, t->e1whT, w + t->o_e1bh, t->vl, t->mem, H, t->hl1, lstm ? t->cl1 : nullptr, B, T, H, 1, s, t->sav1));
-  if (drop) hipLaunchKernelGGL(trn_mul_kernel, dim3(((long)BT * H + 255) / 256), dim3(256), 0, s, (const float *)t->mem, (const float *)t->M1, t->memd, (long)BT * H);
-  TN_TRY(launch_linear_f32(memd, H, w + t->o_wk, H, nullptr, t->keyproj, H, BT, H, H, 0, s));
-  hipLaunchKernelGGL(transpose_bth_kernel, dim3((H + 31) / 32, (T + 31) / 32, B), dim3(256), 0, s, (const float *)t->keyproj, t->keyprojT, T, H);
-  for (int i = 0; i < L; ++i) {
-    float *X0 = t->X0 + (size_t)i * B * K0, *X1 = t->X1 + (size_t)i * B * K1, *G0 = t->G0 + (size_t)i * B * 4 * H;
-    float *G1 = t->G1 + (size_t)i * B * 4 * H, *H1 = t->H1 + (size_t)i * B * H;
-    const float *X1p = t->X1 + (size_t)(i - 1) * B * K1, *H1p = t->H1 + (size_t)(i - 1) * B * H;
-    // decoder layer 0 starts from the encoder's BACKWARD layer-0 state, layer 1 from the uni layer (gnmt.py:146-150,224-252)
-    hipLaunchKernelGGL(trn_prep_kernel, dim3(B), dim3(256), 0, s, (const float *)(w + t->o_emb), tgt, ld, i,
-                       i ? X1p + H : (const float *)nullptr, K1, i ? X1p : (const float *)(t->hl0 + (size_t)B * H), i ? K1 : H,
-                       i ? H1p : (const float *)t->hl1, H, X0, X1, H, E);
-    TN_TRY(launch_linear_f32(X0, K0, t->w0c, K0, t->b0c, G0, 4 * H, B, 4 * H, K0, 0, s));
-    const float *c0p = !lstm ? nullptr : i ? t->C0 + (size_t)(i - 1) * B * H : t->cl0 + (size_t)B * H;
-    const float *c1p = !lstm ? nullptr : i ? t->C1 + (size_t)(i - 1) * B * H : t->cl1;
-    hipLaunchKernelGGL(dec_attention_kernel<1>, dim3(B), dim3(kBeamThreads), att_lds, s, (const float *)G0, (const float *)(X0 + E + H), K0,
-                       c0p, lstm ? 1 : 0, t->h0tmp, lstm ? t->C0 + (size_t)i * B * H : (float *)nullptr, X1, K1, (const float *)t->keyprojT, memd,
-                       (const int32_t *)t->vl, t->ctxtmp, 1, 1, T, H, t->AW + (size_t)i * B * T);
-    TN_TRY(launch_linear_f32(X1, K1, t->w1c, K1, t->b1c, G1, 4 * H, B, 4 * H, K1, 0, s));
-    hipLaunchKernelGGL(dec_tf_cell1_kernel, dim3(nbH), dim3(256), 0, s, (const float *)G1, (const float *)X1, lstm ? 1 : 0, c1p, H1,
-                       lstm ? t->C1 + (size_t)i * B * H : (float *)nullptr, B, H);
-    const float *H1p_ = H1;
-    if (drop) {
-      hipLaunchKernelGGL(trn_mul_kernel, dim3(nbH), dim3(256), 0, s, (const float *)H1, (const float *)(t->M2 + (size_t)i * B * H), t->H1d + (size_t)i * B * H, (long)B * H);
-      H1p_ = t->H1d + (size_t)i * B * H;
+  const unsigned long long key = drop ? t->drop_seed * 0x2545F4914F6CDD1Dull + (++t->drop_count) * 0xD1342543DE82EF95ull : 0ull;
+  std::vector<const float *> xin(NL + 1);     // layer i reads xin[i]; xin[NL] = the memory
+  xin[0] = src;
+  for (int i = 0; i < NL; ++i) {
+    TrnEnc &e = t->enc[i];
+    const int DG = e.D * GH;
+    TN_TRY(launch_linear_f32(xin[i], e.in, w + e.o_wi, e.in, w + e.o_bi, e.gi, DG, BT, DG, e.in, 0, s));
+    TN_HIP_CHECK(hipMemsetAsync(e.seq, 0, sizeof(float) * (size_t)BT * e.out, s));
+    TN_TRY(launch_rnn_recurrent(G, e.gi, DG, e.whT, w + e.o_bh, t->vl, e.seq, e.out, e.hl, lstm ? e.cl : nullptr, B, T, H, e.D, s, e.sav));
+    // dropout on the layer's output (the states are not dropped), then the residual connection (gnmt.py:152-157)
+    const long no = (long)BT * e.out;
+    if (drop) hipLaunchKernelGGL(trn_dropout_mask_kernel, blocks(no), dim3(256), 0, s, e.M, no, t->drop_p, key ^ (0x1111ull * (i + 1)));
+    if (drop || e.res) {
+      hipLaunchKernelGGL(trn_mul_add_kernel, blocks(no), dim3(256), 0, s, (const float *)e.seq, drop ? (const float *)e.M : nul,
+                         e.res ? xin[i] : nul, e.xn, no);
+      xin[i + 1] = e.xn;
+    } else {
+      xin[i + 1] = e.seq;
     }
-    TN_TRY(launch_linear_f32(H1p_, H, w + t->o_wp, H, w + t->o_bp, t->logits + (size_t)i * V, L * V, B, V, H, 0, s));
+  }
+  const float *mem = xin[NL];
+  TN_TRY(launch_linear_f32(mem, H, w + t->o_wk, H, nullptr, t->keyproj, H, BT, H, H, 0, s));
+  hipLaunchKernelGGL(transpose_bth_kernel, dim3((H + 31) / 32, (T + 31) / 32, B), dim3(256), 0, s, (const float *)t->keyproj, t->keyprojT, T, H);
+  // the decoder layer j starts from encoder layer j's final state: the BACKWARD direction's for a bidirectional layer (gnmt.py:146-150)
+  auto h_init = [&](int j) { return (const float *)(t->enc[j].hl + (size_t)(t->enc[j].D - 1) * B * H); };
+  auto c_init = [&](int j) { return (const float *)(t->enc[j].cl + (size_t)(t->enc[j].D - 1) * B * H); };
+  // ---------------- forward: decoder steps (gnmt.py:369-404) ----------------
+  if (drop)
+    for (int j = 1; j < NL; ++j)
+      hipLaunchKernelGGL(trn_dropout_mask_kernel, blocks((long)LB * H), dim3(256), 0, s, t->dec[j].M, (long)LB * H, t->drop_p, key ^ (0x3333ull * j));
+  TrnDec &d0 = t->dec[0], &d1 = t->dec[1];
+  for (int i = 0; i < L; ++i) {
+    const size_t so = (size_t)i * B, sp = (size_t)(i - 1) * B;
+    float *X0 = d0.X + so * K0, *X1 = d1.X + so * K1;
+    const float *X1p = d1.X + sp * K1;
+    hipLaunchKernelGGL(trn_prep_kernel, dim3(B), dim3(256), 0, s, (const float *)(w + t->o_emb), tgt, ld, i,
+                       i ? X1p + H : nul, K1, i ? X1p : h_init(0), i ? K1 : H,
+                       i ? (const float *)(d1.Hs + sp * H) : h_init(1), H, X0, X1, H, E);
+    for (int j = 2; j < NL; ++j)
+      hipLaunchKernelGGL(trn_copy_kernel, dim3(nbH), dim3(256), 0, s, i ? (const float *)(t->dec[j].Hs + sp * H) : h_init(j), H,
+                         t->dec[j].X + so * K1 + 2 * H, K1, B, H);
+    TN_TRY(launch_linear_f32(X0, K0, d0.wc, K0, d0.bc, d0.G + so * 4 * H, 4 * H, B, 4 * H, K0, 0, s));
+    const float *c0p = !lstm ? nul : i ? (const float *)(d0.C + sp * H) : c_init(0);
+    hipLaunchKernelGGL(dec_attention_kernel<1>, dim3(B), dim3(kBeamThreads), att_lds, s, (const float *)(d0.G + so * 4 * H), (const float *)(X0 + E + H), K0,
+                       c0p, lstm ? 1 : 0, t->h0tmp, lstm ? d0.C + so * H : (float *)nullptr, X1, K1, (const float *)t->keyprojT, mem,
+                       (const int32_t *)t->vl, t->ctxtmp, 1, 1, T, H, t->AW + so * T);
+    for (int j = 1; j < NL; ++j) {
+      TrnDec &d = t->dec[j];
+      const bool top = j == NL - 1;
+      float *Xj = d.X + so * K1;
+      TN_TRY(launch_linear_f32(Xj, K1, d.wc, K1, d.bc, d.G + so * 4 * H, 4 * H, B, 4 * H, K1, 0, s));
+      const float *cp = !lstm ? nul : i ? (const float *)(d.C + sp * H) : c_init(j);
+      float *outp = top ? t->Out + so * H : t->dec[j + 1].X + so * K1;
+      hipLaunchKernelGGL(trn_cell_fwd_kernel, dim3(nbH), dim3(256), 0, s, (const float *)(d.G + so * 4 * H), (const float *)Xj, lstm ? 1 : 0, cp,
+                         d.Hs + so * H, lstm ? d.C + so * H : (float *)nullptr, drop ? (const float *)(d.M + so * H) : nul, t->residual ? 1 : 0,
+                         outp, top ? H : K1, top ? (float *)nullptr : outp + H, B, H);
+    }
+    TN_TRY(launch_linear_f32(t->Out + so * H, H, w + t->o_wp, H, w + t->o_bp, t->logits + (size_t)i * V, L * V, B, V, H, 0, s));
   }
   // ---------------- loss and its gradient ----------------
   hipLaunchKernelGGL(trn_ce_bwd_kernel, dim3(L, B), dim3(256), 0, s, (const float *)t->logits, tgt + 1, ld, (const int32_t *)t->tvl, B, L, V,
@@ -1405,91 +1526,126 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
   TN_TRY(launch_colsum_f32(t->lossrows, 1, LB, 1, loss, s));
   if (logits_out) TN_HIP_CHECK(hipMemcpyAsync(logits_out, t->logits, sizeof(float) * (size_t)LB * V, hipMemcpyDeviceToDevice, s));
   // ---------------- backward: projection ----------------
-  TN_TRY(launch_linear_f32(t->dlog, V, t->wpT, V, nullptr, t->dH1, H, LB, H, V, 0, s));
-  if (drop) hipLaunchKernelGGL(trn_mul_kernel, dim3(((long)LB * H + 255) / 256), dim3(256), 0, s, (const float *)t->dH1, (const float *)t->M2, t->dH1, (long)LB * H);
-  TN_TRY(launch_gemm_tn_f32(t->dlog, V, H1d, H, g + t->o_wp, H, V, H, LB, s));
+  TN_TRY(launch_linear_f32(t->dlog, V, t->wpT, V, nullptr, t->dOut, H, LB, H, V, 0, s));
+  TN_TRY(launch_gemm_tn_f32(t->dlog, V, t->Out, H, g + t->o_wp, H, V, H, LB, s));
   TN_TRY(launch_colsum_f32(t->dlog, V, LB, V, g + t->o_bp, s));
-  TN_HIP_CHECK(hipMemsetAsync(t->dmem, 0, sizeof(float) * (size_t)BT * H, s));
+  float *dmem = t->enc[NL - 1].dxn;
+  TN_HIP_CHECK(hipMemsetAsync(dmem, 0, sizeof(float) * (size_t)BT * H, s));
   TN_HIP_CHECK(hipMemsetAsync(t->dkp, 0, sizeof(float) * (size_t)BT * H, s));
   // ---------------- backward: decoder steps, last to first ----------------
   for (int i = L - 1; i >= 0; --i) {
     const bool last = i == L - 1;
-    float *X0 = t->X0 + (size_t)i * B * K0, *X1 = t->X1 + (size_t)i * B * K1, *G0 = t->G0 + (size_t)i * B * 4 * H;
-    float *G1 = t->G1 + (size_t)i * B * 4 * H;
-    float *dG0 = t->dG0 + (size_t)i * B * 4 * H, *dG1 = t->dG1 + (size_t)i * B * 4 * H;
-    float *dX0 = t->dX0 + (size_t)i * B * K0, *dX1 = t->dX1 + (size_t)i * B * K1;
-    const float *dX0n = t->dX0 + (size_t)(i + 1) * B * K0, *dX1n = t->dX1 + (size_t)(i + 1) * B * K1;   // step i+1 (valid unless last)
-    const float *nul = nullptr;
-    const float *a1b = last ? nul : (const float *)t->dhz1, *a1c = last ? nul : dX1n + 2 * H;
+    const size_t so = (size_t)i * B, sp = (size_t)(i - 1) * B, sn = (size_t)(i + 1) * B;
+    // d (output of layer j), walking down from the rows the projection read: pointer + row stride
+    const float *dcur = t->dOut + so * H;
+    int ldcur = H;
+    float *pingpong[2] = {t->tmpA, t->tmpB};
+    int pp = 0;
+    for (int j = NL - 1; j >= 1; --j) {
+      TrnDec &d = t->dec[j];
+      const float *Xj = d.X + so * K1, *Gj = d.G + so * 4 * H;
+      float *dGj = d.dG + so * 4 * H, *dXj = d.dX + so * K1;
+      const float *dXjn = d.dX + sn * K1;
+      // through the dropout mask to the cell's h
+      const float *dh = dcur;
+      int ldh = ldcur;
+      if (drop) {
+        hipLaunchKernelGGL(trn_combine_kernel, dim3(nbH), dim3(256), 0, s, dcur, ldcur, (const float *)(d.M + so * H), nul, 0, t->tmpM, B, H);
+        dh = t->tmpM; ldh = H;
+      }
+      if (lstm)
+        hipLaunchKernelGGL(trn_lstm_bwd_kernel, dim3(nbH), dim3(256), 0, s, Gj, i ? (const float *)(d.C + sp * H) : c_init(j), (const float *)(d.C + so * H),
+                           dh, ldh, last ? nul : (const float *)d.dhz, H, last ? nul : dXjn + 2 * H, K1, nul, 0, last ? nul : (const float *)d.dcz,
+                           dGj, d.dhz, d.dcz, B, H);
+      else
+        hipLaunchKernelGGL(trn_gru_bwd_kernel, dim3(nbH), dim3(256), 0, s, Gj, Xj + 2 * H, K1, dh, ldh, last ? nul : (const float *)d.dhz, H,
+                           last ? nul : dXjn + 2 * H, K1, nul, 0, dGj, d.dhz, B, H);
+      TN_TRY(launch_linear_f32(dGj, 4 * H, d.wcT, 4 * H, nullptr, dXj, K1, B, K1, 4 * H, 0, s));
+      // d (the layer's input) = its column block of dX (+ the residual path)
+      if (t->residual) {
+        float *dst = pingpong[pp]; pp ^= 1;
+        hipLaunchKernelGGL(trn_combine_kernel, dim3(nbH), dim3(256), 0, s, (const float *)dXj, K1, nul, dcur, ldcur, dst, B, H);
+        dcur = dst; ldcur = H;
+      } else {
+        dcur = dXj; ldcur = K1;
+      }
+    }
+    // attention: d ctx = the attention columns of every layer's dX at this step + the first cell's at the next step
+    const float *datt = t->dec[1].dX + so * K1 + H;
+    int ldatt = K1;
+    if (NL > 2) {
+      hipLaunchKernelGGL(trn_combine_kernel, dim3(nbH), dim3(256), 0, s, datt, K1, nul, (const float *)(t->dec[2].dX + so * K1 + H), K1, t->tmpAtt, B, H);
+      for (int j = 3; j < NL; ++j)
+        hipLaunchKernelGGL(trn_combine_kernel, dim3(nbH), dim3(256), 0, s, (const float *)t->tmpAtt, H, nul, (const float *)(t->dec[j].dX + so * K1 + H), K1, t->tmpAtt, B, H);
+      datt = t->tmpAtt; ldatt = H;
+    }
+    const float *dX0n = d0.dX + sn * K0;
+    hipLaunchKernelGGL(trn_att_bwd_kernel, dim3(B), dim3(256), attb_lds, s, (const float *)(t->AW + so * T), mem, (const float *)t->keyproj,
+                       (const float *)(d1.X + so * K1), K1, datt, ldatt, last ? nul : dX0n + E, K0, (const int32_t *)t->vl, dmem, t->dkp, t->dq, T, H);
+    // first cell: d h0 = d (layer 1's input) + the query's gradient + the recurrent paths
+    const float *X0 = d0.X + so * K0, *G0 = d0.G + so * 4 * H;
+    float *dG0 = d0.dG + so * 4 * H, *dX0 = d0.dX + so * K0;
     if (lstm)
-      hipLaunchKernelGGL(trn_lstm_bwd_kernel, dim3(nbH), dim3(256), 0, s, (const float *)G1, i ? (const float *)(t->C1 + (size_t)(i - 1) * B * H) : (const float *)t->cl1,
-                         (const float *)(t->C1 + (size_t)i * B * H), (const float *)(t->dH1 + (size_t)i * B * H), H, a1b, H, a1c, K1, nul, 0,
-                         last ? nul : (const float *)t->dcz1, dG1, t->dhz1, t->dcz1, B, H);
+      hipLaunchKernelGGL(trn_lstm_bwd_kernel, dim3(nbH), dim3(256), 0, s, G0, i ? (const float *)(d0.C + sp * H) : c_init(0), (const float *)(d0.C + so * H),
+                         dcur, ldcur, (const float *)t->dq, H, last ? nul : (const float *)d0.dhz, H, last ? nul : dX0n + E + H, K0,
+                         last ? nul : (const float *)d0.dcz, dG0, d0.dhz, d0.dcz, B, H);
     else
-      hipLaunchKernelGGL(trn_gru_bwd_kernel, dim3(nbH), dim3(256), 0, s, (const float *)G1, (const float *)(X1 + 2 * H), K1,
-                         (const float *)(t->dH1 + (size_t)i * B * H), H, a1b, H, a1c, K1, nul, 0, dG1, t->dhz1, B, H);
-    TN_TRY(launch_linear_f32(dG1, 4 * H, t->w1cT, 4 * H, nullptr, dX1, K1, B, K1, 4 * H, 0, s));
-    hipLaunchKernelGGL(trn_att_bwd_kernel, dim3(B), dim3(256), attb_lds, s, (const float *)(t->AW + (size_t)i * B * T), memd,
-                       (const float *)t->keyproj, (const float *)X1, K1, (const float *)(dX1 + H), K1, last ? nul : dX0n + E, K0,
-                       (const int32_t *)t->vl, t->dmem, t->dkp, t->dq, T, H);
-    const float *a0c = last ? nul : (const float *)t->dhz0, *a0d = last ? nul : dX0n + E + H;
-    if (lstm)
-      hipLaunchKernelGGL(trn_lstm_bwd_kernel, dim3(nbH), dim3(256), 0, s, (const float *)G0,
-                         i ? (const float *)(t->C0 + (size_t)(i - 1) * B * H) : (const float *)(t->cl0 + (size_t)B * H),
-                         (const float *)(t->C0 + (size_t)i * B * H), (const float *)dX1, K1, (const float *)t->dq, H, a0c, H, a0d, K0,
-                         last ? nul : (const float *)t->dcz0, dG0, t->dhz0, t->dcz0, B, H);
-    else
-      hipLaunchKernelGGL(trn_gru_bwd_kernel, dim3(nbH), dim3(256), 0, s, (const float *)G0, (const float *)(X0 + E + H), K0,
-                         (const float *)dX1, K1, (const float *)t->dq, H, a0c, H, a0d, K0, dG0, t->dhz0, B, H);
-    TN_TRY(launch_linear_f32(dG0, 4 * H, t->w0cT, 4 * H, nullptr, dX0, K0, B, K0, 4 * H, 0, s));
+      hipLaunchKernelGGL(trn_gru_bwd_kernel, dim3(nbH), dim3(256), 0, s, G0, X0 + E + H, K0, dcur, ldcur, (const float *)t->dq, H,
+                         last ? nul : (const float *)d0.dhz, H, last ? nul : dX0n + E + H, K0, dG0, d0.dhz, B, H);
+    TN_TRY(launch_linear_f32(dG0, 4 * H, d0.wcT, 4 * H, nullptr, dX0, K0, B, K0, 4 * H, 0, s));
   }
-  // gradients reaching the encoder's final states: layer 0 backward direction and the uni layer (forward direction of layer 0: none)
-  TN_HIP_CHECK(hipMemsetAsync(t->dhl0, 0, sizeof(float) * (size_t)B * H, s));
-  hipLaunchKernelGGL(trn_add2_kernel, dim3(nbH), dim3(256), 0, s, (const float *)t->dhz0, H, (const float *)(t->dX0 + E + H), K0,
-                     t->dhl0 + (size_t)B * H, B, H);
-  hipLaunchKernelGGL(trn_add2_kernel, dim3(nbH), dim3(256), 0, s, (const float *)t->dhz1, H, (const float *)(t->dX1 + 2 * H), K1, t->dhl1, B, H);
-  if (lstm) {   // gradients reaching the encoder's final cell states
-    TN_HIP_CHECK(hipMemsetAsync(t->dcl0, 0, sizeof(float) * (size_t)B * H, s));
-    TN_HIP_CHECK(hipMemcpyAsync(t->dcl0 + (size_t)B * H, t->dcz0, sizeof(float) * (size_t)B * H, hipMemcpyDeviceToDevice, s));
-    TN_HIP_CHECK(hipMemcpyAsync(t->dcl1, t->dcz1, sizeof(float) * (size_t)B * H, hipMemcpyDeviceToDevice, s));
+  // gradients reaching the encoder's final states: decoder layer j's initial state is encoder layer j's (backward direction of a bi layer)
+  for (int j = 0; j < NL; ++j) {
+    TrnEnc &e = t->enc[j];
+    TrnDec &d = t->dec[j];
+    if (e.D == 2) {
+      TN_HIP_CHECK(hipMemsetAsync(e.dhl, 0, sizeof(float) * (size_t)B * H, s));
+      if (lstm) TN_HIP_CHECK(hipMemsetAsync(e.dcl, 0, sizeof(float) * (size_t)B * H, s));
+    }
+    const size_t off = (size_t)(e.D - 1) * B * H;
+    hipLaunchKernelGGL(trn_add2_kernel, dim3(nbH), dim3(256), 0, s, (const float *)d.dhz, H, (const float *)(d.dX + (j ? 2 * H : E + H)), d.K,
+                       e.dhl + off, B, H);
+    if (lstm) TN_HIP_CHECK(hipMemcpyAsync(e.dcl + off, d.dcz, sizeof(float) * (size_t)B * H, hipMemcpyDeviceToDevice, s));
   }
   // ---------------- backward: decoder weights, attention key projection, embedding ----------------
-  TN_TRY(launch_gemm_tn_f32(t->dG0, 4 * H, t->X0, K0, t->dW0c, K0, 4 * H, K0, LB, s));
-  TN_TRY(launch_colsum_f32(t->dG0, 4 * H, LB, 4 * H, t->db0c, s));
-  hipLaunchKernelGGL(trn_unstack_kernel, dim3(GH), dim3(256), 0, s, (const float *)t->dW0c, (const float *)t->db0c, E + H, H, lstm ? 1 : 0, g + t->o_d0wi,
-                     g + t->o_d0wh, g + t->o_d0bi, g + t->o_d0bh);
-  TN_TRY(launch_gemm_tn_f32(t->dG1, 4 * H, t->X1, K1, t->dW1c, K1, 4 * H, K1, LB, s));
-  TN_TRY(launch_colsum_f32(t->dG1, 4 * H, LB, 4 * H, t->db1c, s));
-  hipLaunchKernelGGL(trn_unstack_kernel, dim3(GH), dim3(256), 0, s, (const float *)t->dW1c, (const float *)t->db1c, 2 * H, H, lstm ? 1 : 0, g + t->o_d1wi,
-                     g + t->o_d1wh, g + t->o_d1bi, g + t->o_d1bh);
-  TN_TRY(launch_gemm_tn_f32(t->dkp, H, memd, H, g + t->o_wk, H, H, H, BT, s));
-  TN_TRY(launch_linear_f32(t->dkp, H, t->wkT, H, nullptr, t->dmem, H, BT, H, H, 1, s));
-  if (drop) hipLaunchKernelGGL(trn_mul_kernel, dim3(((long)BT * H + 255) / 256), dim3(256), 0, s, (const float *)t->dmem, (const float *)t->M1, t->dmem, (long)BT * H);
-  hipLaunchKernelGGL(trn_emb_grad_kernel, dim3(V), dim3(64), 0, s, (const float *)t->dX0, K0, tgt, ld, B, L, E, V, g + t->o_emb);
-  // ---------------- backward: encoder ----------------
-  TN_HIP_CHECK(hipMemsetAsync(t->dgi1, 0, sizeof(float) * (size_t)BT * GH, s));
-  TN_HIP_CHECK(hipMemsetAsync(t->dgh1, 0, sizeof(float) * (size_t)BT * GH, s));
-  TN_HIP_CHECK(hipMemsetAsync(t->hp1, 0, sizeof(float) * (size_t)BT * H, s));
-  if (lstm) TN_TRY(launch_lstm_train_bwd(t->mem, t->sav1, t->dmem, w + t->o_e1wh, t->dgi1, t->hp1, B, T, H, s, 1, t->vl, t->dhl1, t->dcl1));
-  else TN_TRY(launch_gru_train_bwd(t->mem, t->sav1, t->dmem, w + t->o_e1wh, t->dgi1, t->dgh1, t->hp1, B, T, H, s, 1, t->vl, t->dhl1));
-  const float *dgh1 = lstm ? t->dgi1 : t->dgh1;      // LSTM: one pre-activation gradient feeds both branches
-  TN_TRY(launch_gemm_tn_f32(t->dgi1, GH, seq0d, 2 * H, g + t->o_e1wi, 2 * H, GH, 2 * H, BT, s));
-  TN_TRY(launch_colsum_f32(t->dgi1, GH, BT, GH, g + t->o_e1bi, s));
-  TN_TRY(launch_gemm_tn_f32(dgh1, GH, t->hp1, H, g + t->o_e1wh, H, GH, H, BT, s));
-  TN_TRY(launch_colsum_f32(dgh1, GH, BT, GH, g + t->o_e1bh, s));
-  TN_TRY(launch_linear_f32(t->dgi1, GH, t->e1wiT, GH, nullptr, t->dseq0, 2 * H, BT, 2 * H, GH, 0, s));
-  if (drop) hipLaunchKernelGGL(trn_mul_kernel, dim3(((long)BT * 2 * H + 255) / 256), dim3(256), 0, s, (const float *)t->dseq0, (const float *)t->M0, t->dseq0, (long)BT * 2 * H);
-  TN_HIP_CHECK(hipMemsetAsync(t->dgi0, 0, sizeof(float) * (size_t)BT * 2 * GH, s));
-  TN_HIP_CHECK(hipMemsetAsync(t->dgh0, 0, sizeof(float) * (size_t)BT * 2 * GH, s));
-  TN_HIP_CHECK(hipMemsetAsync(t->hp0, 0, sizeof(float) * (size_t)2 * BT * H, s));
-  if (lstm) TN_TRY(launch_lstm_train_bwd(t->seq0, t->sav0, t->dseq0, w + t->o_e0wh, t->dgi0, t->hp0, B, T, H, s, 2, t->vl, t->dhl0, t->dcl0));
-  else TN_TRY(launch_gru_train_bwd(t->seq0, t->sav0, t->dseq0, w + t->o_e0wh, t->dgi0, t->dgh0, t->hp0, B, T, H, s, 2, t->vl, t->dhl0));
-  const float *dgh0 = lstm ? t->dgi0 : t->dgh0;
-  TN_TRY(launch_gemm_tn_f32(t->dgi0, 2 * GH, src, F, g + t->o_e0wi, F, 2 * GH, F, BT, s));
-  TN_TRY(launch_colsum_f32(t->dgi0, 2 * GH, BT, 2 * GH, g + t->o_e0bi, s));
-  for (int d = 0; d < 2; ++d)
-    TN_TRY(launch_gemm_tn_f32(dgh0 + d * GH, 2 * GH, t->hp0 + (size_t)d * BT * H, H, g + t->o_e0wh + (long)d * GH * H, H, GH, H, BT, s));
-  TN_TRY(launch_colsum_f32(dgh0, 2 * GH, BT, 2 * GH, g + t->o_e0bh, s));
+  for (int j = 0; j < NL; ++j) {
+    TrnDec &d = t->dec[j];
+    TN_TRY(launch_gemm_tn_f32(d.dG, 4 * H, d.X, d.K, d.dW, d.K, 4 * H, d.K, LB, s));
+    TN_TRY(launch_colsum_f32(d.dG, 4 * H, LB, 4 * H, d.db, s));
+    hipLaunchKernelGGL(trn_unstack_kernel, dim3(GH), dim3(256), 0, s, (const float *)d.dW, (const float *)d.db, d.in, H, lstm ? 1 : 0, g + d.o_wi,
+                       g + d.o_wh, g + d.o_bi, g + d.o_bh);
+  }
+  TN_TRY(launch_gemm_tn_f32(t->dkp, H, mem, H, g + t->o_wk, H, H, H, BT, s));
+  TN_TRY(launch_linear_f32(t->dkp, H, t->wkT, H, nullptr, dmem, H, BT, H, H, 1, s));
+  hipLaunchKernelGGL(trn_emb_grad_kernel, dim3(V), dim3(64), 0, s, (const float *)d0.dX, K0, tgt, ld, B, L, E, V, g + t->o_emb);
+  // ---------------- backward: encoder, last layer to first ----------------
+  for (int i = NL - 1; i >= 0; --i) {
+    TrnEnc &e = t->enc[i];
+    const int DG = e.D * GH;
+    const long no = (long)BT * e.out;
+    // e.dxn = d (what the next layer read); through the dropout mask to the recurrence's outputs
+    const float *dseq = e.dxn;
+    if (drop) {
+      hipLaunchKernelGGL(trn_mul_add_kernel, blocks(no), dim3(256), 0, s, (const float *)e.dxn, (const float *)e.M, nul, e.dseq, no);
+      dseq = e.dseq;
+    }
+    TN_HIP_CHECK(hipMemsetAsync(e.dgi, 0, sizeof(float) * (size_t)BT * DG, s));
+    TN_HIP_CHECK(hipMemsetAsync(e.dgh, 0, sizeof(float) * (size_t)BT * DG, s));
+    TN_HIP_CHECK(hipMemsetAsync(e.hp, 0, sizeof(float) * (size_t)e.D * BT * H, s));
+    if (lstm) TN_TRY(launch_lstm_train_bwd(e.seq, e.sav, dseq, w + e.o_wh, e.dgi, e.hp, B, T, H, s, e.D, t->vl, e.dhl, e.dcl));
+    else TN_TRY(launch_gru_train_bwd(e.seq, e.sav, dseq, w + e.o_wh, e.dgi, e.dgh, e.hp, B, T, H, s, e.D, t->vl, e.dhl));
+    const float *dgh = lstm ? e.dgi : e.dgh;      // LSTM: one pre-activation gradient feeds both branches
+    TN_TRY(launch_gemm_tn_f32(e.dgi, DG, xin[i], e.in, g + e.o_wi, e.in, DG, e.in, BT, s));
+    TN_TRY(launch_colsum_f32(e.dgi, DG, BT, DG, g + e.o_bi, s));
+    for (int d = 0; d < e.D; ++d)
+      TN_TRY(launch_gemm_tn_f32(dgh + (size_t)d * GH, DG, e.hp + (size_t)d * BT * H, H, g + e.o_wh + (long)d * GH * H, H, GH, H, BT, s));
+    TN_TRY(launch_colsum_f32(dgh, DG, BT, DG, g + e.o_bh, s));
+    if (i > 0) {       // d (this layer's input) = d (the layer below's xn): through the input weights (+ the residual path)
+      TrnEnc &below = t->enc[i - 1];
+      TN_TRY(launch_linear_f32(e.dgi, DG, e.wiT, DG, nullptr, below.dxn, e.in, BT, e.in, DG, 0, s));
+      if (e.res) hipLaunchKernelGGL(add_inplace_kernel, blocks((long)BT * e.in), dim3(256), 0, s, below.dxn, (const float *)e.dxn, (long)BT * e.in);
+    }
+  }
 #undef TN_TRY
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;
@@ -1504,10 +1660,18 @@ extern "C" int tn_gnmt_trainer_set_dropout(tn_gnmt_trainer *t, float p, uint64_t
   t->drop_p = p; t->drop_seed = seed; t->drop_count = 0;
   return TN_OK;
 }
-// the masks of the last forward_backward (device pointers; (B*T, 2H), (B*T, H), (L*B, H) step-major) - test hook
+// the masks of the last forward_backward (device pointers) - test hook.  which = 0 .. num_layers - 1: encoder layer's (B*T, D H);
+// num_layers + j, j = 1 .. num_layers - 1: decoder layer j's (L*B, H) step-major
+extern "C" int tn_gnmt_trainer_dropout_mask(tn_gnmt_trainer *t, int which, float **mask) {
+  TN_REQUIRE(t && mask, "tn_gnmt_trainer_dropout_mask: null argument");
+  TN_REQUIRE(which >= 0 && which < 2 * t->NL && which != t->NL, "tn_gnmt_trainer_dropout_mask: no such mask");
+  *mask = which < t->NL ? t->enc[which].M : t->dec[which - t->NL].M;
+  return TN_OK;
+}
+// (the two-layer form of round 2: encoder layers 0 / 1 and the top decoder layer)
 extern "C" int tn_gnmt_trainer_dropout_masks(tn_gnmt_trainer *t, float **m_enc0, float **m_enc1, float **m_dec) {
   TN_REQUIRE(t && m_enc0 && m_enc1 && m_dec, "tn_gnmt_trainer_dropout_masks: null argument");
-  *m_enc0 = t->M0; *m_enc1 = t->M1; *m_dec = t->M2;
+  *m_enc0 = t->enc[0].M; *m_enc1 = t->enc[1].M; *m_dec = t->dec[t->NL - 1].M;
   return TN_OK;
 }
 
@@ -1537,7 +1701,7 @@ extern "C" int tn_gnmt_trainer_read_param(tn_gnmt_trainer *t, const char *name_c
                                           int64_t *numel) {
   TN_REQUIRE(t && name_c && out_host && numel, "tn_gnmt_trainer_read_param: null argument");
   const std::string name(name_c), pre = t->prefix;
-  const long F = t->F, H = t->H, E = t->E, V = t->V, GH = (long)t->G * H;
+  const long H = t->H, E = t->E, V = t->V, GH = (long)t->G * H;
   long off = -1, cnt = 0;
   auto cell = [&](const std::string &c, long owi, long obi, long owh, long obh, long in) {
     if (name == pre + c + "i2h_weight") { off = owi; cnt = GH * in; }
@@ -1545,11 +1709,14 @@ extern "C" int tn_gnmt_trainer_read_param(tn_gnmt_trainer *t, const char *name_c
     if (name == pre + c + "h2h_weight") { off = owh; cnt = GH * H; }
     if (name == pre + c + "h2h_bias") { off = obh; cnt = GH; }
   };
-  for (int d = 0; d < 2; ++d)
-    cell(std::string("enc_rnn0_") + (d ? "r_" : "l_"), t->o_e0wi + d * GH * F, t->o_e0bi + d * GH, t->o_e0wh + d * GH * H, t->o_e0bh + d * GH, F);
-  cell("enc_rnn1_", t->o_e1wi, t->o_e1bi, t->o_e1wh, t->o_e1bh, 2 * H);
-  cell("dec_rnn0_", t->o_d0wi, t->o_d0bi, t->o_d0wh, t->o_d0bh, E + H);
-  cell("dec_rnn1_", t->o_d1wi, t->o_d1bi, t->o_d1wh, t->o_d1bh, 2 * H);
+  for (int i = 0; i < t->NL; ++i) {
+    const TrnEnc &e = t->enc[i];
+    for (int d = 0; d < e.D; ++d)
+      cell("enc_rnn" + std::to_string(i) + (e.D == 2 ? (d ? "_r_" : "_l_") : "_"), e.o_wi + d * GH * e.in, e.o_bi + d * GH, e.o_wh + d * GH * H,
+           e.o_bh + d * GH, e.in);
+    const TrnDec &dc = t->dec[i];
+    cell("dec_rnn" + std::to_string(i) + "_", dc.o_wi, dc.o_bi, dc.o_wh, dc.o_bh, dc.in);
+  }
   if (name == pre + "dec_attention_key_weight") { off = t->o_wk; cnt = H * H; }
   if (name == pre + "tgt_proj_weight") { off = t->o_wp; cnt = V * H; }
   if (name == pre + "tgt_proj_bias") { off = t->o_bp; cnt = V; }

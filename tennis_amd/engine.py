@@ -401,14 +401,17 @@ class TemporalHeadTrainer:
 class GNMTTrainer:
     """One training step of the captioner the way reference train_gnmt.py::train drives it (:328-337): teacher-forced
     ``NMTModel`` forward, token-averaged ``MaskedSoftmaxCELoss``, ``loss.backward()``, ``gluon.Trainer('adam').step(1)``.
-    GRU (the reference's flag default) or LSTM cells, ``num_layers=2, num_bi_layers=1``.  ``grads`` / ``params`` are flat device
-    views for a data-parallel all-reduce between ``forward_backward`` and ``step``."""
+    GRU (the reference's flag default) or LSTM cells; ``num_layers`` / ``num_bi_layers`` / ``use_residual`` as the reference's
+    flags pass them into the model it trains (train_gnmt.py:58-61,223-227; round 4: any ``num_layers >= 2`` with
+    ``num_bi_layers < num_layers``).  ``grads`` / ``params`` are flat device views for a data-parallel all-reduce between
+    ``forward_backward`` and ``step``."""
 
     def __init__(self, params: dict, input_size: int, hidden: int, embed: int, vocab: int, max_batch: int = 32,
                  max_src_len: int = 256, max_tgt_len: int = 64, prefix: str = "gnmt_", ctx: _lib.Context | None = None,
-                 cell_type: str = "gru"):
+                 cell_type: str = "gru", num_layers: int = 2, num_bi_layers: int = 1, use_residual: bool = False):
         if cell_type not in ("gru", "lstm"):
             raise ValueError(f"cell_type must be 'gru' or 'lstm', got {cell_type!r}")
+        self.num_layers, self.num_bi_layers, self.use_residual = num_layers, num_bi_layers, bool(use_residual)
         self.ctx = ctx or _lib.default_context()
         self.lib = self.ctx.lib
         self.input_size, self.hidden, self.embed, self.vocab, self.prefix = input_size, hidden, embed, vocab, prefix
@@ -417,9 +420,10 @@ class GNMTTrainer:
         self.shapes = {k: tuple(np.asarray(params[k]).shape) for k in self.names}
         arr, keep = _lib.make_params({k: params[k] for k in self.names})
         h = C.c_void_p()
-        check(self.lib.tn_gnmt_trainer_create(self.ctx.handle, arr, len(arr), prefix.encode(),
-                                              _lib.RNN_GRU if cell_type == "gru" else _lib.RNN_LSTM, input_size, hidden, embed, vocab,
-                                              max_batch, max_src_len, max_tgt_len, C.byref(h)), "tn_gnmt_trainer_create")
+        check(self.lib.tn_gnmt_trainer_create_ex(self.ctx.handle, arr, len(arr), prefix.encode(),
+                                                 _lib.RNN_GRU if cell_type == "gru" else _lib.RNN_LSTM, input_size, hidden, embed, vocab,
+                                                 num_layers, num_bi_layers, 1 if use_residual else 0,
+                                                 max_batch, max_src_len, max_tgt_len, C.byref(h)), "tn_gnmt_trainer_create_ex")
         del keep
         self.handle = h
         pw, pg, n = C.c_void_p(), C.c_void_p(), C.c_int64()
@@ -469,6 +473,16 @@ class GNMTTrainer:
                 __cuda_array_interface__ = {"shape": shape, "typestr": "<f4", "data": (addr, False), "version": 3}
             return torch.as_tensor(_Arr(), device=f"cuda:{self.ctx.device}")
         return (view(a.value, (batch, src_steps, 2 * h)), view(b.value, (batch, src_steps, h)), view(c.value, (tgt_steps, batch, h)))
+
+    def dropout_mask(self, which: int, shape) -> torch.Tensor:
+        """One mask of the last step: ``which`` = encoder layer ``i`` -> (B,T,dirs*H); ``num_layers + j`` -> decoder layer ``j >= 1``,
+        (L,B,H) step-major."""
+        a = C.c_void_p()
+        check(self.lib.tn_gnmt_trainer_dropout_mask(self.handle, which, C.byref(a)), "tn_gnmt_trainer_dropout_mask")
+
+        class _Arr:
+            __cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (a.value, False), "version": 3}
+        return torch.as_tensor(_Arr(), device=f"cuda:{self.ctx.device}")
 
     def step(self, lr: float, beta1: float = 0.9, beta2: float = 0.999, epsilon: float = 1e-8):
         check(self.lib.tn_gnmt_trainer_adam_step(self.handle, lr, beta1, beta2, epsilon), "tn_gnmt_trainer_adam_step")

@@ -2,8 +2,8 @@
 (itself derived from gluon-nlp) and of the NMTModel the reference builds from gluonnlp
 (train_gnmt.py:228-229).  The blocks hold configuration and Gluon-named parameters; the
 compute runs in libtennis_hip.so (tn_gnmt_*): cell_type 'gru' (flag default) or 'lstm', attention 'scaled_luong',
-num_layers >= 2 with num_bi_layers < num_layers, use_residual on or off (inference; the training step keeps the
-reference's flag defaults num_layers 2 / num_bi_layers 1 / no residual).
+num_layers >= 2 with num_bi_layers < num_layers, use_residual on or off - inference (tn_gnmt_create_ex) and, since round 4, the
+training step (tn_gnmt_trainer_create_ex).
 """
 from __future__ import annotations
 
@@ -176,6 +176,8 @@ class NMTModel(Block):
         if self._engine is None or self._engine[0] != key or self._engine[2] < max_batch or self._engine[3] < max_src_len:
             p = {k: v.data for k, v in self.collect_params().items()}
             enc = self.encoder
+            if bool(enc._use_residual) != bool(self.decoder._use_residual) or enc._num_layers != self.decoder._num_layers:
+                raise ValueError("encoder and decoder must agree on num_layers and use_residual (get_gnmt_encoder_decoder, gnmt.py:397-416)")
             cap = GNMTCaptioner(p, self._input_size, enc._hidden_size, self._embed_size, len(self.tgt_vocab), beam,
                                 max_length, max(max_batch, 32), max(max_src_len, 256), self.prefix, enc._cell_type,
                                 enc._num_layers, enc._num_bi_layers, bool(enc._use_residual))

@@ -1,5 +1,6 @@
-"""Host side of the captioner's training path — counterpart of reference train_gnmt.py::train (:305-470) for the
-configuration it ships as default (``--num_layers 2 --num_bi_layers 1``, ``--cell_type gru`` or ``lstm``):
+"""Host side of the captioner's training path — counterpart of reference train_gnmt.py::train (:305-470): ``--cell_type gru`` or
+``lstm``, ``--num_layers`` / ``--num_bi_layers`` as the reference's flags (:58-61; default 2 / 1), residual connections when the
+model was built with them:
 
     trainer = gluon.Trainer(model.collect_params(), 'adam', {'learning_rate': lr})                      :310
     for epoch: for batch in train loader (FixedBucketSampler over target lengths):                      :318
@@ -52,14 +53,19 @@ def train(data_train, data_val, data_test, model, translator, epochs: int, batch
           start_epoch: int = 0, save_dir: str | None = None, seed: int = 0, log=print):
     """-> history: one dict per epoch (train loss, valid / test loss and BLEU, learning rate)."""
     enc = model.encoder
-    if enc._cell_type not in ("gru", "lstm") or enc._num_layers != 2 or enc._num_bi_layers != 1:
-        raise NotImplementedError("the training step is built for num_layers=2, num_bi_layers=1 (the reference's flag defaults)")
+    if enc._cell_type not in ("gru", "lstm"):
+        raise NotImplementedError("the training step is built for GRU / LSTM cells")
+    dec = model.decoder
+    if bool(getattr(enc, "_use_residual", False)) != bool(getattr(dec, "_use_residual", False)) or enc._num_layers != dec._num_layers:
+        raise ValueError("encoder and decoder must agree on num_layers and use_residual (get_gnmt_encoder_decoder builds them that way, "
+                         "gnmt.py:397-416)")
     params = {k: v.data for k, v in model.collect_params().items()}
     max_t = max(l[0] for l in data_train.get_data_lens())
     max_l = max(l[-1] for l in data_train.get_data_lens())
     trainer = GNMTTrainer(params, model._input_size, enc._hidden_size, model._embed_size, len(model.tgt_vocab),
                           max_batch=batch_size, max_src_len=max_t, max_tgt_len=max_l, prefix=model.prefix,
-                          cell_type=enc._cell_type)
+                          cell_type=enc._cell_type, num_layers=enc._num_layers, num_bi_layers=enc._num_bi_layers,
+                          use_residual=bool(getattr(enc, "_use_residual", False)))
     if dropout > 0:
         trainer.set_dropout(dropout, seed)
     val_tgt = data_val.get_captions(split=True) if data_val is not None else None

@@ -646,6 +646,28 @@ def test_gnmt_train_oracle_forward_matches_numpy_oracle(cell):
     assert np.all(moved[np.abs(g[k]) > 1e-6] > 0.9e-3) and np.all(moved < 1.01e-3)
 
 
+@pytest.mark.parametrize("nl,nbi,res,cell", [(3, 1, False, "gru"), (4, 2, True, "gru"), (3, 0, True, "lstm"), (2, 1, True, "lstm")])
+def test_gnmt_train_oracle_layer_counts_match_numpy_oracle(nl, nbi, res, cell):
+    """the training oracle's general form (num_layers / num_bi_layers / use_residual, gnmt.py:136-160,369-404) against the numpy
+    restatement the inference tests use, which was written separately (oracle/gnmt_np.py::encoder / Decoder)."""
+    from oracle import gnmt_np as gn, gnmt_train_torch as gt
+    from tennis_amd import weights as W
+    B, T, F, H, E, V, L = 3, 9, 16, 8, 6, 14, 6
+    p = W.make_gnmt_weights(2, cell, F, H, E, V, num_layers=nl, num_bi_layers=nbi)
+    rng = np.random.default_rng(1)
+    src = (np.abs(rng.normal(0, 1, (B, T, F))) * 0.5).astype(np.float32)
+    vl = np.array([9, 5, 7], np.int32)
+    tgt = rng.integers(4, V, (B, L)).astype(np.int32)
+    tgt[:, 0] = 2
+    tvl = np.array([6, 4, 5], np.int32)
+    loss, logits, g = gt.loss_and_grads(p, src, vl, tgt, tvl, H, cell=cell, num_layers=nl, num_bi_layers=nbi, use_residual=res)
+    mem, states = gn.encoder(src, vl, p, cell, H, num_layers=nl, num_bi_layers=nbi, use_residual=res)
+    ref = gn.decode_seq(gn.Decoder(p, H, cell=cell, num_layers=nl, use_residual=res), mem, states, vl, tgt[:, :-1])
+    assert np.abs(logits - ref).max() < 1e-6
+    assert set(g) == set(p) and all(np.isfinite(v).all() for v in g.values())
+    assert all(np.abs(v).max() > 0 for k, v in g.items() if "enc_rnn0_l_" not in k or nbi > 0)
+
+
 def test_vector_feedback_rounding_library_vs_numpy():
     """tn_round_fp16_calibrated (csrc/calib_host.hip, host code) against its numpy reference: the same neighbour for every weight,
     every weight ON one of its two neighbours, representable weights untouched, and the property the method is for - the row
