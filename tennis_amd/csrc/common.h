@@ -1,5 +1,6 @@
 // Shared device/host helpers for libtennis_hip (gfx950 only).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
@@ -252,6 +253,28 @@ int launch_stem(const StemArgs &a, hipStream_t s);
 int launch_stem_pool(const StemArgs &a, f16 *out, int ldy, int Hp, int Wp, hipStream_t s);
 
 int launch_maxpool3x3s2(const f16 *x, int B, int H, int W, int C, f16 *y, int ldy, int Ho, int Wo, hipStream_t s);
+// hipFuncAttributeMaxDynamicSharedMemorySize is set per DEVICE: a process-wide `static bool` left the second GPU of a process
+// with the default limit.  One bit per device; the attribute call is idempotent, so two threads racing only repeat it.
+struct PerDeviceFlag {
+  std::atomic<unsigned long long> done{0};
+  bool is_set(int *dev_out) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    *dev_out = d;
+    return (done.load(std::memory_order_acquire) >> (d & 63)) & 1ull;
+  }
+  void set(int d) { done.fetch_or(1ull << (d & 63), std::memory_order_release); }
+};
+#define TN_SET_ATTR_ONCE_PER_DEVICE(...)                    \
+  do {                                                      \
+    static PerDeviceFlag tn_flag_;                          \
+    int tn_dev_;                                            \
+    if (!tn_flag_.is_set(&tn_dev_)) {                       \
+      __VA_ARGS__;                                          \
+      tn_flag_.set(tn_dev_);                                \
+    }                                                       \
+  } while (0)
+
 // BN1 + ReLU of the dense layers as two packed-half instructions: relu(s x + t) = m relu(a x + b) with a, b fp16 numbers and m folded
 // into the 1x1 weights (csrc/calib_host.hip)
 void bn_scale_shift(const float *gamma, const float *beta, const float *mean, const float *var, int n, float eps, float *scale, float *shift);

@@ -193,14 +193,10 @@ int launch_conv3x3(const Conv3x3Args &a, hipStream_t s) {
   TN_REQUIRE(a.W <= 240, "conv3x3: W too large for the LDS tile");
   const int lds_px = TILE_PX + 2 * a.W + 2;
   const size_t lds = conv3x3_lds_bytes(a.W);
-  static bool attr_set = false;
-  if (!attr_set) {
-    TN_HIP_CHECK(hipFuncSetAttribute((const void *)conv3x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  TN_SET_ATTR_ONCE_PER_DEVICE(TN_HIP_CHECK(hipFuncSetAttribute((const void *)conv3x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      160 * 1024));
     TN_HIP_CHECK(hipFuncSetAttribute((const void *)conv3x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024));
-    attr_set = true;
-  }
+                                     160 * 1024)));
   const dim3 grid((a.M + TILE_PX - 1) / TILE_PX), block(256);
   if (a.variant == 9)
     hipLaunchKernelGGL(conv3x3_kernel<0>, grid, block, lds, s, a, lds_px);

@@ -421,11 +421,7 @@ Block7Image pack_block7(const std::vector<Block7Layer> &layers, int K0) {
 int launch_dense_block7(const DenseBlock7Args &a, hipStream_t s) {
   TN_REQUIRE(dense_block7_supported(7, 7, a.K0, a.nl) && a.ldc % 8 == 0 && a.K0 + 32 * a.nl <= a.ldc && a.B > 0,
              "dense_block7: bad geometry");
-  static bool attr_set = false;
-  if (!attr_set) {
-    TN_HIP_CHECK(hipFuncSetAttribute((const void *)dense_block7_kernel<kRingDepth>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    attr_set = true;
-  }
+  TN_SET_ATTR_ONCE_PER_DEVICE(TN_HIP_CHECK(hipFuncSetAttribute((const void *)dense_block7_kernel<kRingDepth>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes)));
   hipLaunchKernelGGL((dense_block7_kernel<kRingDepth>), dim3(a.B), dim3(256), kLdsBytes, s, a);
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;

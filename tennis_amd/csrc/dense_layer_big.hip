@@ -794,12 +794,8 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
 template <int W, int ROUT, int BM, int BK, int PP, bool CHAIN = false, bool EX = false>
 int launch_geom(const DenseLayerArgs &a, hipStream_t s) {
   using G = DLGeom<W, ROUT, BM, BK>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    TN_HIP_CHECK(hipFuncSetAttribute((const void *)dense_layer_kernel<W, ROUT, BM, BK, PP, CHAIN, EX>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
-    attr_set = true;
-  }
+  TN_SET_ATTR_ONCE_PER_DEVICE(TN_HIP_CHECK(hipFuncSetAttribute((const void *)dense_layer_kernel<W, ROUT, BM, BK, PP, CHAIN, EX>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES)));
   static int ncu = 0;
   if (!ncu) {
     int dev = 0;

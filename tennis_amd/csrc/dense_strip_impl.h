@@ -556,11 +556,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 template <int W, int KS>
 int launch_strip(const DenseStripArgs &a, hipStream_t s) {
   using G = DSGeom<W, KS>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    TN_HIP_CHECK(hipFuncSetAttribute((const void *)dense_strip_kernel<W, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
-    attr_set = true;
-  }
+  TN_SET_ATTR_ONCE_PER_DEVICE(TN_HIP_CHECK(hipFuncSetAttribute((const void *)dense_strip_kernel<W, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES)));
   hipLaunchKernelGGL((dense_strip_kernel<W, KS>), dim3(a.B * G::WGS), dim3(256), G::LDS_BYTES, s, a);
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;
