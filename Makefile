@@ -27,12 +27,13 @@ $(CSRC)/$(1).o $(ISA_DIR)/$(1).s &: $(CSRC)/$(1).hip $(wildcard $(CSRC)/*.h) inc
 	@mv $(CSRC)/$(1)-hip-amdgcn-amd-amdhsa-gfx950.s $(ISA_DIR)/$(1).s
 	@rm -f $(CSRC)/$(1)-hip-amdgcn-amd-amdhsa-gfx950.* $(CSRC)/$(1)-host-x86_64-unknown-linux-gnu.* $(CSRC)/$(1).hip-hip-amdgcn-amd-amdhsa.hipfb
 endef
-$(foreach u,$(STRIP_UNITS) dense_block14,$(eval $(call STRIP_RULE,$(u))))
+$(foreach u,$(STRIP_UNITS) dense_block14 dense_block28,$(eval $(call STRIP_RULE,$(u))))
 
 # dense_block14.hip keeps its activation ring in literal registers v[192:255] and counts its own vmcnt: scripts/audit_block14_isa.py
-audit: $(STRIP_UNITS:%=$(ISA_DIR)/%.s) $(ISA_DIR)/dense_block14.s
+audit: $(STRIP_UNITS:%=$(ISA_DIR)/%.s) $(ISA_DIR)/dense_block14.s $(ISA_DIR)/dense_block28.s
 	python3 scripts/audit_strip_isa.py $(STRIP_UNITS:%=$(ISA_DIR)/%.s)
 	python3 scripts/audit_block14_isa.py $(ISA_DIR)/dense_block14.s
+	python3 scripts/audit_block14_isa.py $(ISA_DIR)/dense_block28.s
 
 $(OUT): $(OBJS)
 	@mkdir -p $(dir $(OUT))

@@ -406,6 +406,12 @@ int tn_dbg_block14_run(void *handle, void *buf_f16, int ldc, int B);
 int tn_dbg_block14_run_ts(void *handle, void *buf_f16, int ldc, int B,
                           unsigned long long *ts /* NULL or 64 per frame (160 in a -DTN_B14_STAMPS build): s_memtime stamps of wave 0, one per layer */);
 void tn_dbg_block14_destroy(void *handle);
+/* the streamed 28x28 dense block (csrc/dense_block28.hip), same operand convention */
+int tn_dbg_block28_create(tn_ctx *ctx, int K0, int nl, const float *w1_all, const float *s1_all, const float *t1_all,
+                          const float *s2_all, const float *t2_all, const float *w3_all, void **out);
+int tn_dbg_block28_run(void *handle, void *buf_f16, int ldc, int B);
+int tn_dbg_block28_run_ts(void *handle, void *buf_f16, int ldc, int B, unsigned long long *ts);
+void tn_dbg_block28_destroy(void *handle);
 
 #ifdef __cplusplus
 }

@@ -1,4 +1,4 @@
-"""Audit of dense_block14_kernel's ISA (no GPU needed): the kernel keeps its activation ring in literal registers v[192:255],
+"""Audit of dense_block14_kernel's / dense_block28_kernel's ISA (no GPU needed): the kernels keep their activation ring in literal registers v[192:255],
 whose loads are in flight for two super-step intervals; hipcc does not know those registers are live.  Fails if
 
   1. any instruction OUTSIDE an inline-asm region (;;#ASMSTART .. ;;#ASMEND) names a VGPR >= 192;
@@ -27,7 +27,7 @@ def vgprs(line):
 def main():
     text = "\n".join(open(p).read() for p in sys.argv[1:])
     bad = kernels = 0
-    for m in re.finditer(r"^(\S*dense_block14_kernel\S*):", text, re.M):
+    for m in re.finditer(r"^(\S*dense_block(?:14|28)_kernel\S*):", text, re.M):
         name = m.group(1)
         end = text.find(".end_amdhsa_kernel", m.end())
         body = text[m.end():text.rfind("s_endpgm", m.end(), end) + 8]

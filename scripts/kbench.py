@@ -253,5 +253,34 @@ for v in [int(s) for s in args.variants.split(",")]:
         res.append(dict(k="b14", us=round(us, 1), tf=round(fl / us / 1e6, 1)))
         print(res[-1], flush=True)
         lib.tn_dbg_block14_destroy(h)
+if "b28" in args.kernels:     # the streamed 28x28 dense block (dense_block28.hip)
+    K0, nl = 128, 12
+    Ks = [K0 + 32 * l for l in range(nl)]
+    cat = lambda xs: np.ascontiguousarray(np.concatenate([x.ravel() for x in xs]))
+    w1 = cat([rng.normal(0, (2.0 / K) ** 0.5, (128, K)).astype(np.float32) for K in Ks])
+    s1 = cat([(rng.random(K) + 0.5).astype(np.float32) for K in Ks]); t1 = cat([rng.normal(0, 0.3, K).astype(np.float32) for K in Ks])
+    s2 = (rng.random((nl, 128)) + 0.5).astype(np.float32); t2 = rng.normal(0, 0.3, (nl, 128)).astype(np.float32)
+    w3 = rng.normal(0, 0.03, (nl, 32, 128, 3, 3)).astype(np.float32)
+    vp = lambda a_: a_.ctypes.data_as(C.c_void_p)
+    h = C.c_void_p()
+    _lib.check(lib.tn_dbg_block28_create(ctx.handle, K0, nl, vp(w1), vp(s1), vp(t1), vp(s2), vp(t2), vp(w3), C.byref(h)))
+    buf = torch.randn((B * 784, 512), device="cuda", dtype=torch.float16)
+    fn = lambda: _lib.check(lib.tn_dbg_block28_run(h, _lib.ptr(buf), 512, B))
+    us = timed(fn, args.iters)
+    fl = sum(2.0 * B * 784 * (128 * K + 32 * 1152) for K in Ks)
+    if args.stamps:
+        ts = torch.zeros((B * 64,), dtype=torch.int64, device="cuda")
+        _lib.check(lib.tn_dbg_block28_run_ts(h, _lib.ptr(buf), 512, B, _lib.ptr(ts)))
+        torch.cuda.synchronize()
+        t = ts.cpu().numpy().astype(np.float64).reshape(B, 64)
+        d = np.diff(np.concatenate([t[:, 63:64], t[:, :nl]], axis=1), axis=1)
+        med = np.median(d, axis=0)
+        slots = [4 * (32 * ((K + 63) // 64) + 8 + 144) for K in Ks]
+        print("   per layer (ticks, median over frames): %s" % " ".join("%d" % x for x in med))
+        print("   ticks per MFMA slot: %s" % " ".join("%.1f" % (med[l] / slots[l]) for l in range(nl)))
+        print("   whole kernel %d ticks" % np.median(t[:, 62] - t[:, 63]), flush=True)
+    res.append(dict(k="b28", us=round(us, 1), tf=round(fl / us / 1e6, 1)))
+    print(res[-1], flush=True)
+    lib.tn_dbg_block28_destroy(h)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(res, open("gpurun_out/kbench.json", "w"), indent=1)

@@ -139,6 +139,10 @@ _SIGS = {
     "tn_dbg_block14_run": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "tn_dbg_block14_run_ts": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "tn_dbg_block14_destroy": (None, [_P]),
+    "tn_dbg_block28_create": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_void_p)]),
+    "tn_dbg_block28_run": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "tn_dbg_block28_run_ts": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "tn_dbg_block28_destroy": (None, [_P]),
 }
 
 _lib = None

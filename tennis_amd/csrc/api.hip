@@ -269,6 +269,9 @@ struct tn_encoder {
   bool block14 = true;        // a 14x14 block runs on the streamed kernel of dense_block14.hip (TN_NO_BLOCK14 disables)
   DenseBlock14Args b14[4] = {};
   f16 *b14_scratch[4] = {nullptr, nullptr, nullptr, nullptr};   // its k-step-major working copy of the block's frames
+  bool block28 = false;       // a 28x28 block runs on the streamed kernel of dense_block28.hip (TN_BLOCK28=1 enables: measured, not the default)
+  DenseBlock28Args b28[4] = {};
+  f16 *b28_scratch[4] = {nullptr, nullptr, nullptr, nullptr};
   hipStream_t side[4];
   hipEvent_t ev_in, ev_done[2][4];   // completion of the side streams, alternating per forward call
   bool pipelined = false;            // tn_densenet121_set_pipelined: the caller's stream is not made to wait inside forward
@@ -303,6 +306,7 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
   if (e->nsplit != 4) e->nsplit = 2;
   e->block7 = getenv("TN_NO_BLOCK7") == nullptr;
   e->block14 = getenv("TN_NO_BLOCK14") == nullptr;
+  e->block28 = getenv("TN_BLOCK28") != nullptr && atoi(getenv("TN_BLOCK28")) != 0;
   e->chain = getenv("TN_NO_CHAIN") == nullptr;   // measured: -20% on the 14x14 / 7x7 blocks, +2.8% end to end
   e->dl_variant = getenv("TN_DL_VARIANT") ? atoi(getenv("TN_DL_VARIANT")) : 0;
   e->exact = (flags & TN_ENC_EXACT_WEIGHTS) != 0;
@@ -350,7 +354,8 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
   for (int b = 0; b < 4; ++b) {
     const std::string sp = pre + "stage" + std::to_string(b + 1) + "_";
     const bool pack14 = e->fuse && e->block14 && !e->exact && dense_block14_supported(e->Hb[b], e->Wb[b], e->Cin[b], kBlockCfg[b]);
-    const bool pack7 = (e->fuse && e->block7 && !e->exact && dense_block7_supported(e->Hb[b], e->Wb[b], e->Cin[b], kBlockCfg[b])) || pack14;
+    const bool pack28 = e->fuse && e->block28 && !e->exact && dense_block28_supported(e->Hb[b], e->Wb[b], e->Cin[b], kBlockCfg[b]);
+    const bool pack7 = (e->fuse && e->block7 && !e->exact && dense_block7_supported(e->Hb[b], e->Wb[b], e->Cin[b], kBlockCfg[b])) || pack14 || pack28;
     std::vector<std::vector<float>> h7[4];     // host copies for pack_block7: folded 1x1 weights, s1, t1, t2 per layer
     std::vector<const float *> h7w3;
     for (int l = 0; l < kBlockCfg[b]; ++l) {
@@ -407,6 +412,14 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
       a14.stream = e->pool.upload(pack_block14(bl, e->Cin[b]));
       a14.total_units = dense_block14_units(e->Cin[b], kBlockCfg[b]);
       a14.ldc = e->Cb[b]; a14.K0 = e->Cin[b]; a14.nl = kBlockCfg[b];
+    } else if (pack28) {
+      std::vector<Block14Layer> bl;
+      for (int l = 0; l < kBlockCfg[b]; ++l)
+        bl.push_back(Block14Layer{h7[0][l].data(), h7w3[l], h7[1][l].data(), h7[2][l].data(), h7[3][l].data()});
+      DenseBlock28Args &a28 = e->b28[b];
+      a28.stream = e->pool.upload(pack_block28(bl, e->Cin[b]));
+      a28.total_units = dense_block28_units(e->Cin[b], kBlockCfg[b]);
+      a28.ldc = e->Cb[b]; a28.K0 = e->Cin[b]; a28.nl = kBlockCfg[b];
     } else if (pack7) {
       std::vector<Block7Layer> bl;
       for (int l = 0; l < kBlockCfg[b]; ++l)
@@ -444,6 +457,8 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
     e->blockbuf[b] = (f16 *)e->pool.alloc(B * e->Hb[b] * e->Wb[b] * e->Cb[b] * sizeof(f16));
   for (int b = 0; b < 4; ++b)
     if (e->b14[b].stream) e->b14_scratch[b] = (f16 *)e->pool.alloc(B * dense_block14_scratch_halfs() * sizeof(f16));
+  for (int b = 0; b < 4; ++b)
+    if (e->b28[b].stream) e->b28_scratch[b] = (f16 *)e->pool.alloc(B * dense_block28_scratch_halfs() * sizeof(f16));
   e->workspace_bytes = e->pool.bytes - weights_bytes;
   if (e->pool.failed) { tn_set_error("device allocation failed"); return fail(TN_ERR_NOMEM); }
   // dense_block14.hip reads the 32 channels a layer is about to write as the zero-weighted pad of its last 64-channel super-step:
@@ -451,6 +466,12 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
   for (int b = 0; b < 4; ++b)
     if (e->b14[b].stream && (hipMemset(e->blockbuf[b], 0, B * e->Hb[b] * e->Wb[b] * e->Cb[b] * sizeof(f16)) != hipSuccess ||
                              hipMemset(e->b14_scratch[b], 0, B * dense_block14_scratch_halfs() * sizeof(f16)) != hipSuccess)) {
+      tn_set_error("hipMemset failed");
+      return fail(TN_ERR_HIP);
+    }
+  for (int b = 0; b < 4; ++b)      // (dense_block28.hip reads rows 28 .. 31 of a plane and the zero-weighted pad of a last super-step)
+    if (e->b28[b].stream && (hipMemset(e->blockbuf[b], 0, B * e->Hb[b] * e->Wb[b] * e->Cb[b] * sizeof(f16)) != hipSuccess ||
+                             hipMemset(e->b28_scratch[b], 0, B * dense_block28_scratch_halfs() * sizeof(f16)) != hipSuccess)) {
       tn_set_error("hipMemset failed");
       return fail(TN_ERR_HIP);
     }
@@ -518,6 +539,20 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
       }
       tm.begin("dense_block_stream_14x14", fl, by);
       rc = launch_dense_block14(a14, s);
+      tm.end();
+      if (rc) return rc;
+    } else if (!cal && e->b28[b].stream && e->dl_variant == 0) {
+      // the 28x28 block in four passes of eight rows, all weights streamed once per pass (dense_block28.hip)
+      DenseBlock28Args a28 = e->b28[b];
+      a28.buf = bbuf[b]; a28.B = B;
+      a28.scratch = e->b28_scratch[b] + (size_t)b0 * dense_block28_scratch_halfs();
+      double fl = 0, by = 0;
+      for (auto &L : e->layers[b]) {
+        fl += 2.0 * M * (128.0 * L.cin + 32.0 * 1152);
+        by += (double)M * (L.cin + 32) * 2 + 128.0 * L.cin * 2 + 32.0 * 1152 * 2;
+      }
+      tm.begin("dense_block_stream_28x28", fl, by);
+      rc = launch_dense_block28(a28, s);
       tm.end();
       if (rc) return rc;
     } else if (!cal && e->b7[b].wa && e->dl_variant == 0) {

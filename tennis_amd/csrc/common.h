@@ -237,6 +237,21 @@ size_t dense_block14_scratch_halfs();   // per frame
 std::vector<unsigned char> pack_block14(const std::vector<Block14Layer> &layers, int K0);
 int launch_dense_block14(const DenseBlock14Args &a, hipStream_t s);
 
+// The 28x28 dense block as one launch: dense_block14.hip's recipe with the frame walked in four passes of eight rows (dense_block28.hip).
+struct DenseBlock28Args {
+  f16 *buf;                      // concat buffer [B][784][ldc]: reads channels [0,K0), appends [K0, K0 + 32 nl)
+  int ldc, K0, nl, B;
+  const unsigned char *stream;   // the block's weight stream (pack_block28)
+  int total_units;               // dense_block28_units(K0, nl)
+  f16 *scratch = nullptr;        // B x dense_block28_scratch_halfs(): the kernel's k-step-major working copy of the frames (zeroed once)
+  unsigned long long *ts = nullptr;   // tuning hook: s_memtime per layer (64 per workgroup)
+};
+bool dense_block28_supported(int H, int W, int K0, int nl);
+int dense_block28_units(int K0, int nl);
+size_t dense_block28_scratch_halfs();   // per frame
+std::vector<unsigned char> pack_block28(const std::vector<Block14Layer> &layers, int K0);
+int launch_dense_block28(const DenseBlock28Args &a, hipStream_t s);
+
 struct StemArgs {
   const void *x;
   int layout;         // tn_layout

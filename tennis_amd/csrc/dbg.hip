@@ -266,3 +266,70 @@ extern "C" void tn_dbg_block14_destroy(void *handle) {
   (void)hipFree(b->scratch);
   delete b;
 }
+
+// ---- the streamed 28x28 dense block (dense_block28.hip) ----
+// same operand convention as tn_dbg_block7_create
+struct tn_dbg_block28 {
+  tn_ctx *ctx;
+  void *stream = nullptr, *scratch = nullptr;
+  int scratch_frames = 0;
+  DenseBlock28Args args;
+};
+
+extern "C" int tn_dbg_block28_create(tn_ctx *ctx, int K0, int nl, const float *w1_all, const float *s1_all, const float *t1_all,
+                                     const float *s2_all, const float *t2_all, const float *w3_all, void **out) {
+  TN_REQUIRE(ctx && w1_all && s1_all && t1_all && s2_all && t2_all && w3_all && out, "tn_dbg_block28_create: null argument");
+  TN_REQUIRE(dense_block28_supported(28, 28, K0, nl), "tn_dbg_block28_create: unsupported geometry");
+  TN_ON_DEVICE(ctx->device);
+  std::vector<std::vector<float>> folded(nl);
+  std::vector<Block14Layer> layers(nl);
+  size_t o1 = 0, ok = 0;
+  for (int l = 0; l < nl; ++l) {
+    const int K = K0 + 32 * l;
+    folded[l].resize((size_t)128 * K);
+    for (int n = 0; n < 128; ++n)
+      for (int k = 0; k < K; ++k) folded[l][(size_t)n * K + k] = w1_all[o1 + (size_t)n * K + k] * s2_all[(size_t)l * 128 + n];
+    layers[l] = Block14Layer{folded[l].data(), w3_all + (size_t)l * 32 * 128 * 9, s1_all + ok, t1_all + ok, t2_all + (size_t)l * 128};
+    o1 += (size_t)128 * K;
+    ok += K;
+  }
+  const std::vector<unsigned char> img = pack_block28(layers, K0);
+  tn_dbg_block28 *b = new tn_dbg_block28();
+  b->ctx = ctx;
+  if (hipMalloc(&b->stream, img.size()) != hipSuccess || hipMemcpy(b->stream, img.data(), img.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    tn_set_error("tn_dbg_block28_create: device allocation failed");
+    delete b;
+    return TN_ERR_NOMEM;
+  }
+  b->args = DenseBlock28Args{nullptr, 0, K0, nl, 0, (const unsigned char *)b->stream, dense_block28_units(K0, nl)};
+  *out = b;
+  return TN_OK;
+}
+
+extern "C" int tn_dbg_block28_run_ts(void *handle, void *buf_f16, int ldc, int B, unsigned long long *ts) {
+  tn_dbg_block28 *b = (tn_dbg_block28 *)handle;
+  TN_REQUIRE(b && buf_f16, "tn_dbg_block28_run: null argument");
+  TN_ON_DEVICE(b->ctx->device);
+  if (b->scratch_frames < B) {
+    (void)hipFree(b->scratch);
+    b->scratch = nullptr; b->scratch_frames = 0;
+    if (hipMalloc(&b->scratch, (size_t)B * dense_block28_scratch_halfs() * sizeof(f16)) != hipSuccess) {
+      tn_set_error("tn_dbg_block28_run: device allocation failed");
+      return TN_ERR_NOMEM;
+    }
+    b->scratch_frames = B;
+    TN_HIP_CHECK(hipMemset(b->scratch, 0, (size_t)B * dense_block28_scratch_halfs() * sizeof(f16)));
+  }
+  DenseBlock28Args a = b->args;
+  a.buf = (f16 *)buf_f16; a.ldc = ldc; a.B = B; a.ts = ts; a.scratch = (f16 *)b->scratch;
+  return launch_dense_block28(a, b->ctx->stream);
+}
+extern "C" int tn_dbg_block28_run(void *handle, void *buf_f16, int ldc, int B) { return tn_dbg_block28_run_ts(handle, buf_f16, ldc, B, nullptr); }
+
+extern "C" void tn_dbg_block28_destroy(void *handle) {
+  tn_dbg_block28 *b = (tn_dbg_block28 *)handle;
+  if (!b) return;
+  (void)hipFree(b->stream);
+  (void)hipFree(b->scratch);
+  delete b;
+}

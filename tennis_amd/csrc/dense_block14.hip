@@ -485,7 +485,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       advance_dma();
     }
     // channels 0 .. K0 - 1 of this wave's pixels: NHWC -> the k-step-major copy (a wave only ever reads its own pixels' planes)
-    for (int q = 0; q < a.K0 / 16; ++q)
+    // (eight k-steps' loads in flight per round trip: one load - wait - store per k-step was 16 dependent round trips, 20 us of a
+    // 360 us launch)
+    const int nq = a.K0 / 16;
+    int q0 = 0;
+    for (; q0 + 8 <= nq; q0 += 8) {
+      u32x4 v[8][2];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) v[q][f] = *(const u32x4 *)(fb + noff[f] + 32 * (q0 + q) + 16 * h);
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+          if (valid[f]) *(u32x4 *)(scr + (size_t)(q0 + q) * kPlaneB + voff[f]) = v[q][f];
+    }
+    for (int q = q0; q < nq; ++q)
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
         const u32x4 v = *(const u32x4 *)(fb + noff[f] + 32 * q + 16 * h);

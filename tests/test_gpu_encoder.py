@@ -164,6 +164,25 @@ def test_lds_resident_7x7_block_vs_tile_kernel(setup, report, monkeypatch):
     assert torch.equal(big[:2], got) and torch.equal(big[32:], got)
 
 
+def test_streamed_28x28_block_route(setup, report, monkeypatch):
+    """TN_BLOCK28=1: the 28x28 block as ONE launch of dense_block28.hip (four passes of eight rows per layer, every layer's weights
+    streamed once per pass, K up to 480 - the layers the strip kernel cannot hold) instead of seven strip launches + five tile-kernel
+    launches.  Measured in round 4 at the same time per step as the default route and more energy: opt-in, but held to
+    the same bar, and a frame's features do not depend on the batch around it."""
+    from tennis_amd.engine import DenseNet121Features
+    x = torch.from_numpy(setup["x16"].astype(np.float32)).cuda()
+    dflt = DenseNet121Features(setup["p"], 224, max_batch=2)(x)
+    monkeypatch.setenv("TN_BLOCK28", "1")
+    got = DenseNet121Features(setup["p"], 224, max_batch=2)(x)
+    big = DenseNet121Features(setup["p"], 224, max_batch=34)(x[torch.arange(34, device="cuda") % 2])
+    monkeypatch.delenv("TN_BLOCK28")
+    e = float(np.abs(got.cpu().numpy() - setup["ref"]).max())
+    report["features_block28_maxabs_err"] = e
+    assert e < TOL, e
+    assert float((got - dflt).abs().max()) < 2e-3 and not torch.equal(got, dflt)      # (a different kernel did run)
+    assert torch.equal(big[:2], got) and torch.equal(big[32:], got)
+
+
 def test_unfused_fallback_path(setup, report, monkeypatch):
     """TN_NO_FUSE=1: the layer-wise kernels (conv1x1 / conv3x3 / stem / maxpool) that serve input sizes the fused
     tiles do not cover; same oracle, same tolerance."""

@@ -373,6 +373,54 @@ def test_dense_block14(ctx, report, B, K0, nl, ldc):
     assert np.array_equal(out[..., :K0], buf[..., :K0].astype(np.float32)) and np.all(out[..., end:] == 77.0)
 
 
+@pytest.mark.parametrize("B,K0,nl,ldc", [(2, 128, 1, 512), (3, 128, 3, 512), (2, 160, 2, 256), (1, 128, 12, 512), (2, 384, 4, 512),
+                                          (300, 256, 2, 512)])
+def test_dense_block28(ctx, report, B, K0, nl, ldc):
+    """The streamed 28x28 dense block (dense_block28.hip: one frame per workgroup walked in four passes of eight rows, all weights
+    through the LDS-DMA ring once per pass, rolling bottleneck tile, 3x3 output rows one above the pass' 1x1 rows) vs the oracle,
+    layer by layer: two-super-step layers (K = 128: the ring wraps through two passes), odd and even super-step counts, half-empty
+    last super-steps, the 12-layer block of a 224 x 224 input, K > 320 (what the strip kernel could not hold), more workgroups than CUs."""
+    from tennis_amd import _lib
+    rng = np.random.default_rng(B * 1000 + K0 + nl)
+    buf = np.zeros((B, 28, 28, ldc), np.float16)
+    buf[..., :K0] = rng.normal(0, 1.0, (B, 28, 28, K0)).astype(np.float16)
+    buf[..., K0:] = 77.0                                                  # must be overwritten (or left alone past the block)
+    Ks = [K0 + 32 * l for l in range(nl)]
+    s1 = [rng.uniform(0.5, 1.5, K).astype(np.float16).astype(np.float32) for K in Ks]; t1 = [rng.normal(0, 0.3, K).astype(np.float16).astype(np.float32) for K in Ks]
+    s2 = rng.uniform(0.5, 1.5, (nl, 128)).astype(np.float32); t2 = rng.normal(0, 0.3, (nl, 128)).astype(np.float32)
+    w1 = [rng.normal(0, np.sqrt(2.0 / K), (128, K)).astype(np.float32) for K in Ks]
+    w3 = _h(rng.normal(0, np.sqrt(2.0 / 1152), (nl, 32, 128, 3, 3)).astype(np.float32))
+    cat = lambda xs: np.ascontiguousarray(np.concatenate([x.ravel() for x in xs]))
+    w1_all, s1_all, t1_all = cat(w1), cat(s1), cat(t1)
+    h = C.c_void_p()
+    vp = lambda a_: a_.ctypes.data_as(C.c_void_p)
+    _lib.check(ctx.lib.tn_dbg_block28_create(ctx.handle, K0, nl, vp(w1_all), vp(s1_all), vp(t1_all), vp(s2), vp(t2), vp(w3), C.byref(h)), "block28_create")
+    try:
+        d = torch.from_numpy(buf).cuda()
+        _lib.check(ctx.lib.tn_dbg_block28_run(h, _lib.ptr(d), ldc, B), "block28_run")
+        out = d.cpu().numpy().astype(np.float32)
+        d2 = torch.from_numpy(buf).cuda()                                  # a second run on a fresh copy: same bits
+        _lib.check(ctx.lib.tn_dbg_block28_run(h, _lib.ptr(d2), ldc, B), "block28_run")
+        assert torch.equal(d2, d)
+    finally:
+        ctx.lib.tn_dbg_block28_destroy(h)
+    ref = buf.astype(np.float32)
+    worst = 0.0
+    for l, K in enumerate(Ks):
+        a1 = _bnrelu_h(ref[..., :K], s1[l], t1[l])
+        bott = (a1.reshape(-1, K) @ _h(w1[l] * s2[l][:, None]).T).reshape(B, 28, 28, 128)
+        a2 = _h(np.maximum(bott + t2[l], 0).astype(np.float32))
+        y = _h(dn.conv2d_nhwc(a2, w3[l], 1, 1))
+        err = np.abs(out[..., K:K + 32] - y)
+        e = float(err.max())
+        assert e < 2e-2, (l, K, e, np.argwhere(err > 2e-2)[:8].tolist())
+        worst = max(worst, e)
+        ref[..., K:K + 32] = out[..., K:K + 32]          # follow the device's own roundings into the next layer
+    report[f"dense_block28_{B}_K{K0}_nl{nl}"] = worst
+    end = K0 + 32 * nl
+    assert np.array_equal(out[..., :K0], buf[..., :K0].astype(np.float32)) and np.all(out[..., end:] == 77.0)
+
+
 @pytest.mark.parametrize("B,H,K,ldc", [(2, 56, 64, 256), (1, 56, 224, 256), (3, 56, 96, 256), (2, 56, 160, 256),
                                         (3, 28, 128, 512), (2, 28, 320, 512), (5, 28, 160, 512), (1, 28, 288, 512),
                                         (2, 128, 64, 256), (1, 128, 224, 256), (3, 64, 128, 512), (2, 64, 320, 512)])   # 512 x 512 input: 5 / 3 workgroups per frame, partly empty last strip pair
