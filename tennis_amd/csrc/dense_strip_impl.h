@@ -43,7 +43,7 @@
 #include "common.h"
 
 #ifndef TN_DS_EXP
-#define TN_DS_EXP 0   // timing experiments only (results wrong): bit 0 no activation loads inside the row loop, bit 1 no 3x3 phase, bit 2 no 1x1 phase
+#define TN_DS_EXP 0   // timing experiments only (results wrong): bit 0 no activation loads inside the row loop, bit 1 no 3x3 phase, bit 2 no 1x1 phase, bit 3 / 4 no weight-fragment reads in the 3x3 / 1x1 phase
 #endif
 
 namespace {
@@ -346,6 +346,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
   auto wa_item = [&](auto q_tag, auto mb_tag) TN_INL {
     constexpr int Q = decltype(q_tag)::value, MB = decltype(mb_tag)::value;
+    if ((TN_DS_EXP & 16) && Q >= 2) return;     // (timing experiment: the 1x1 phase keeps reusing its first eight weight fragments)
     wa[Q & 1][MB] = *(const u32x4 *)(w1l + (Q * 4 + MB) * 1024);
   };
   auto wa_group = [&](auto q_tag) TN_INL { static_for<4>([&](auto mb_tag) TN_INL { wa_item(q_tag, mb_tag); }); };
@@ -412,6 +413,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
   auto w3_item = [&](auto s_tag, auto dx_tag) TN_INL {
     constexpr int S = decltype(s_tag)::value, DX = decltype(dx_tag)::value;
+    if ((TN_DS_EXP & 8) && S >= 2) return;      // (timing experiment: the 3x3 phase keeps reusing its first six weight fragments)
     w3f[S & 1][DX] = *(const u32x4 *)(w3l + (S * 3 + DX) * 1024);
   };
 
