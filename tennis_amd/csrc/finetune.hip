@@ -46,7 +46,9 @@ __global__ void ft_im2col7_kernel(const float *__restrict__ x, int B, int H, int
   o[0] = v0; o[1] = v1; o[2] = v2;
 }
 // 3x3 pad 1 on (B,H,W,C) contiguous -> (B*H*W, 9*C), column order (ky, kx, c)
-__global__ void ft_im2col3_kernel(const float *__restrict__ a, int B, int H, int W, int C, float *__restrict__ col) {
+// sc / sh non-null: the source is a pre-activation, relu(a * sc[c] + sh[c]) is applied on the way (padding stays zero)
+__global__ void ft_im2col3_kernel(const float *__restrict__ a, int B, int H, int W, int C, float *__restrict__ col,
+                                  const float *__restrict__ sc = nullptr, const float *__restrict__ sh = nullptr) {
   const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int C4 = C / 4;
   if (id >= (long)B * H * W * 9 * C4) return;
@@ -56,7 +58,14 @@ __global__ void ft_im2col3_kernel(const float *__restrict__ a, int B, int H, int
   const int x = (int)(m % W), y = (int)((m / W) % H), b = (int)(m / ((long)W * H));
   const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *(const float4 *)(a + (((long)b * H + iy) * W + ix) * C + c4 * 4);
+  if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+    v = *(const float4 *)(a + (((long)b * H + iy) * W + ix) * C + c4 * 4);
+    if (sc) {
+      const float4 s4 = *(const float4 *)(sc + c4 * 4), h4 = *(const float4 *)(sh + c4 * 4);
+      v.x = fmaxf(fmaf(v.x, s4.x, h4.x), 0.f); v.y = fmaxf(fmaf(v.y, s4.y, h4.y), 0.f);
+      v.z = fmaxf(fmaf(v.z, s4.z, h4.z), 0.f); v.w = fmaxf(fmaf(v.w, s4.w, h4.w), 0.f);
+    }
+  }
   *(float4 *)(col + m * 9 * C + tap * C + c4 * 4) = v;
 }
 // transpose of im2col3 (gather form, deterministic): da[m][c] = sum over taps of dcol[neighbour(m, tap)][tap][c]
@@ -308,7 +317,9 @@ inline unsigned nblk(long n) { return (unsigned)((n + 255) / 256); }
 }  // namespace
 
 // One BatchNorm: offsets of gamma / beta in the flat parameter buffer, of the running statistics and batch statistics
-struct FtBn { long o_gamma, o_beta; long o_rm, o_rv; int C; float *mean, *var; std::string name; };
+struct FtBn { long o_gamma, o_beta; long o_rm, o_rv; int C; float *mean, *var; std::string name; float *sc = nullptr, *sh = nullptr; };
+// (sc, sh: the folded form relu(x * sc + sh) of the layer's training-mode BatchNorm + ReLU, refreshed in every forward - what the
+//  GEMMs' operand transforms and the fused im2col read instead of a stored activation)
 struct FtLayer { FtBn bn1, bn2; long o_w1, o_w3; int K; float *z1; std::string n1, n3; };
 struct FtTrans { FtBn bn; long o_w; int Cin, Cout; float *z; std::string nw; };
 
@@ -327,12 +338,24 @@ struct tn_finetune {
   int Cin[4], Ctot[4], Hb[4];
   // activations kept for backward
   float *x_in, *col7, *z0, *a0, *X[4], *dX[4], *feat, *logits, *loss, *dlog, *dfeat;
+  // batch statistics of every channel of a block's concat buffer, computed ONCE when the channel is produced: the BatchNorms in
+  // front of the block's 1x1 convolutions, of its transition and of the head all normalise prefixes of the same channels
+  float *Xmean[4], *Xvar[4];
   // temporaries
   float *ta, *tb, *col, *dcol, *tg, *tw, *ws;      // ws: split-K partial results / BatchNorm reduction slices
   long ws_floats;
   int32_t *labels;
 };
 
+// sc = gamma / sqrt(var + eps), sh = beta - mean * sc
+__global__ void ft_bn_fold_kernel(const float *__restrict__ mean, const float *__restrict__ var, const float *__restrict__ gamma,
+                                  const float *__restrict__ beta, int C, float *__restrict__ sc, float *__restrict__ sh) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float s = gamma[c] * rsqrtf(var[c] + kEps);
+  sc[c] = s;
+  sh[c] = fmaf(-mean[c], s, beta[c]);
+}
 static int ft_slices(long M, int C) {
   const int cb = (C + 63) / 64;
   int RS = (int)((M + 2047) / 2048);                 // >= 2048 rows per slice, <= 512 workgroups
@@ -346,6 +369,17 @@ static void ft_bn_forward(tn_finetune *f, const FtBn &bn, const float *x, int ld
                      bn.var);
   hipLaunchKernelGGL(ft_bn_relu_kernel, dim3(nblk(M * bn.C)), dim3(256), 0, s, x, ld, M, bn.C, (const float *)bn.mean,
                      (const float *)bn.var, (const float *)(f->w + bn.o_gamma), (const float *)(f->w + bn.o_beta), y);
+}
+// batch statistics of columns [0, C) of x into mean / var (no BatchNorm attached: the shared per-channel statistics of a block)
+static void ft_stats(tn_finetune *f, const float *x, int ld, long M, int C, float *mean, float *var, hipStream_t s) {
+  const int RS = ft_slices(M, C);
+  hipLaunchKernelGGL(ft_bn_stats_kernel, dim3((C + 63) / 64, RS), dim3(1024), 0, s, x, ld, M, C, f->ws);
+  hipLaunchKernelGGL(ft_bn_stats_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const float *)f->ws, RS, C, x, M, mean, var);
+}
+// relu(x * sc + sh) of a BatchNorm whose batch statistics are known (bn.mean / bn.var)
+static void ft_bn_fold(tn_finetune *f, const FtBn &bn, hipStream_t s) {
+  hipLaunchKernelGGL(ft_bn_fold_kernel, dim3((bn.C + 255) / 256), dim3(256), 0, s, (const float *)bn.mean, (const float *)bn.var,
+                     (const float *)(f->w + bn.o_gamma), (const float *)(f->w + bn.o_beta), bn.C, bn.sc, bn.sh);
 }
 static void ft_bn_recompute(tn_finetune *f, const FtBn &bn, const float *x, int ld, long M, float *y, hipStream_t s) {
   hipLaunchKernelGGL(ft_bn_relu_kernel, dim3(nblk(M * bn.C)), dim3(256), 0, s, x, ld, M, bn.C, (const float *)bn.mean,
@@ -487,11 +521,14 @@ extern "C" int tn_finetune_create(tn_ctx *ctx, const tn_param *params, int n_par
     if (hipMalloc(&lp, sizeof(int32_t) * B) != hipSuccess) P.failed = true; else P.ptrs.push_back(lp);
     f->labels = (int32_t *)lp;
   }
-  auto bnbuf = [&](FtBn &b) { b.mean = P.fl(b.C); b.var = P.fl(b.C); };
-  bnbuf(f->bn0); bnbuf(f->bnF);
+  auto bnbuf = [&](FtBn &b) { b.mean = P.fl(b.C); b.var = P.fl(b.C); b.sc = P.fl(b.C); b.sh = P.fl(b.C); };
+  // a BatchNorm over a prefix of a block's concat buffer reads the block's shared statistics
+  auto bnshared = [&](FtBn &b, int blk) { b.mean = f->Xmean[blk]; b.var = f->Xvar[blk]; b.sc = P.fl(b.C); b.sh = P.fl(b.C); };
+  for (int b = 0; b < 4; ++b) { f->Xmean[b] = P.fl(f->Ctot[b]); f->Xvar[b] = P.fl(f->Ctot[b]); }
+  bnbuf(f->bn0); bnshared(f->bnF, 3);
   for (int b = 0; b < 4; ++b) {
-    for (auto &L : f->layers[b]) { bnbuf(L.bn1); bnbuf(L.bn2); }
-    if (b < 3) bnbuf(f->trans[b].bn);
+    for (auto &L : f->layers[b]) { bnshared(L.bn1, b); bnbuf(L.bn2); }
+    if (b < 3) bnshared(f->trans[b].bn, b);
   }
   if (P.failed) { tn_set_error("device allocation failed"); return fail(TN_ERR_NOMEM); }
   TN_HIP_CHECK(hipMemcpy(f->w, w.data(), sizeof(float) * f->n, hipMemcpyHostToDevice));
@@ -523,27 +560,35 @@ extern "C" int tn_finetune_forward_backward(tn_finetune *f, const float *x, cons
   ft_bn_forward(f, f->bn0, f->z0, 64, M0, f->a0, s);
   hipLaunchKernelGGL(ft_maxpool_kernel, dim3(nblk((long)B * f->Hb[0] * f->Hb[0] * 64)), dim3(256), 0, s, (const float *)f->a0, B, H / 2, W / 2, 64,
                      f->X[0], f->Ctot[0]);
+  // Round 4: (a) a channel's batch statistics are computed once, when it is produced (64 / 32 / Cout new columns at a time) - every
+  // BatchNorm of the block that normalises it reads them; (b) BatchNorm + ReLU in front of a convolution is never stored: the 1x1
+  // GEMMs transform their X operand while staging it (launch_linear_f32_bnrelu), im2col transforms the bottleneck on the way
+  ft_stats(f, f->X[0], f->Ctot[0], (long)B * f->Hb[0] * f->Hb[0], f->Cin[0], f->Xmean[0], f->Xvar[0], s);
   for (int b = 0; b < 4; ++b) {
     const int Hh = f->Hb[b], Ct = f->Ctot[b];
     const long M = (long)B * Hh * Hh;
     for (auto &L : f->layers[b]) {
-      ft_bn_forward(f, L.bn1, f->X[b], Ct, M, f->ta, s);
-      TN_TRY(launch_linear_f32(f->ta, L.K, w + L.o_w1, L.K, nullptr, L.z1, 128, (int)M, 128, L.K, 0, s));
-      ft_bn_forward(f, L.bn2, L.z1, 128, M, f->tb, s);
-      hipLaunchKernelGGL(ft_im2col3_kernel, dim3(nblk(M * 9 * 32)), dim3(256), 0, s, (const float *)f->tb, B, Hh, Hh, 128, f->col);
+      ft_bn_fold(f, L.bn1, s);
+      TN_TRY(launch_linear_f32_bnrelu(f->X[b], Ct, L.bn1.sc, L.bn1.sh, w + L.o_w1, L.K, nullptr, L.z1, 128, (int)M, 128, L.K, 0, s));
+      ft_stats(f, L.z1, 128, M, 128, L.bn2.mean, L.bn2.var, s);
+      ft_bn_fold(f, L.bn2, s);
+      hipLaunchKernelGGL(ft_im2col3_kernel, dim3(nblk(M * 9 * 32)), dim3(256), 0, s, (const float *)L.z1, B, Hh, Hh, 128, f->col,
+                         (const float *)L.bn2.sc, (const float *)L.bn2.sh);
       TN_TRY(launch_linear_f32(f->col, 1152, w + L.o_w3, 1152, nullptr, f->X[b] + L.K, Ct, (int)M, 32, 1152, 0, s));
+      ft_stats(f, f->X[b] + L.K, Ct, M, 32, f->Xmean[b] + L.K, f->Xvar[b] + L.K, s);
     }
     if (b < 3) {
       FtTrans &T = f->trans[b];
-      ft_bn_forward(f, T.bn, f->X[b], Ct, M, f->ta, s);
-      TN_TRY(launch_linear_f32(f->ta, T.Cin, w + T.o_w, T.Cin, nullptr, T.z, T.Cout, (int)M, T.Cout, T.Cin, 0, s));
+      ft_bn_fold(f, T.bn, s);
+      TN_TRY(launch_linear_f32_bnrelu(f->X[b], Ct, T.bn.sc, T.bn.sh, w + T.o_w, T.Cin, nullptr, T.z, T.Cout, (int)M, T.Cout, T.Cin, 0, s));
       hipLaunchKernelGGL(ft_avgpool2_kernel, dim3(nblk(M / 4 * T.Cout)), dim3(256), 0, s, (const float *)T.z, B, Hh, Hh, T.Cout, f->X[b + 1],
                          f->Ctot[b + 1]);
+      ft_stats(f, f->X[b + 1], f->Ctot[b + 1], M / 4, T.Cout, f->Xmean[b + 1], f->Xvar[b + 1], s);
     }
   }
   const int CF = f->Ctot[3], P3 = f->Hb[3] * f->Hb[3];
   const long M3 = (long)B * P3;
-  ft_bn_forward(f, f->bnF, f->X[3], CF, M3, f->ta, s);
+  ft_bn_recompute(f, f->bnF, f->X[3], CF, M3, f->ta, s);
   hipLaunchKernelGGL(ft_gap_kernel, dim3(nblk((long)B * CF)), dim3(256), 0, s, (const float *)f->ta, B, P3, CF, f->feat);
   TN_TRY(launch_linear_f32(f->feat, CF, w + f->o_wd, CF, w + f->o_bd, f->logits, NC, B, NC, CF, 0, s));
   TN_HIP_CHECK(hipMemcpyAsync(f->labels, labels, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, s));
@@ -561,16 +606,15 @@ extern "C" int tn_finetune_forward_backward(tn_finetune *f, const float *x, cons
       FtLayer &L = f->layers[b][l];
       const float *dy = f->dX[b] + L.K;                      // (M, 32) view, row stride Ct
       // 3x3: dW3 = dy^T col ; dcol = dy W3 ; col2im
-      ft_bn_recompute(f, L.bn2, L.z1, 128, M, f->tb, s);
-      hipLaunchKernelGGL(ft_im2col3_kernel, dim3(nblk(M * 9 * 32)), dim3(256), 0, s, (const float *)f->tb, B, Hh, Hh, 128, f->col);
+      hipLaunchKernelGGL(ft_im2col3_kernel, dim3(nblk(M * 9 * 32)), dim3(256), 0, s, (const float *)L.z1, B, Hh, Hh, 128, f->col,
+                         (const float *)L.bn2.sc, (const float *)L.bn2.sh);
       TN_TRY(launch_gemm_tn_f32(dy, Ct, f->col, 1152, g + L.o_w3, 1152, 32, 1152, (int)M, s, f->ws, f->ws_floats));
       TN_TRY(launch_transpose_f32(w + L.o_w3, 32, 1152, f->tw, s));                      // (1152, 32)
       TN_TRY(launch_linear_f32(dy, Ct, f->tw, 32, nullptr, f->dcol, 1152, (int)M, 1152, 32, 0, s));
       hipLaunchKernelGGL(ft_col2im3_kernel, dim3(nblk(M * 32)), dim3(256), 0, s, (const float *)f->dcol, B, Hh, Hh, 128, f->tg);
       ft_bn_backward(f, L.bn2, f->tg, L.z1, 128, M, f->tb, 128, 0, s);                  // tb = d z1
       // 1x1: dW1 = dz1^T a ; da = dz1 W1
-      ft_bn_recompute(f, L.bn1, f->X[b], Ct, M, f->ta, s);
-      TN_TRY(launch_gemm_tn_f32(f->tb, 128, f->ta, L.K, g + L.o_w1, L.K, 128, L.K, (int)M, s, f->ws, f->ws_floats));
+      TN_TRY(launch_gemm_tn_f32_bnrelu(f->tb, 128, f->X[b], Ct, L.bn1.sc, L.bn1.sh, g + L.o_w1, L.K, 128, L.K, (int)M, s, f->ws, f->ws_floats));
       TN_TRY(launch_transpose_f32(w + L.o_w1, 128, L.K, f->tw, s));                     // (K, 128)
       TN_TRY(launch_linear_f32(f->tb, 128, f->tw, 128, nullptr, f->tg, L.K, (int)M, L.K, 128, 0, s));
       ft_bn_backward(f, L.bn1, f->tg, f->X[b], Ct, M, f->dX[b], Ct, 1, s);               // accumulate into channels [0, K)
@@ -580,8 +624,8 @@ extern "C" int tn_finetune_forward_backward(tn_finetune *f, const float *x, cons
       const int Hp = f->Hb[b - 1], Cp = f->Ctot[b - 1];
       const long Mp = (long)B * Hp * Hp;
       hipLaunchKernelGGL(ft_avgpool2_bwd_kernel, dim3(nblk(Mp * T.Cout)), dim3(256), 0, s, (const float *)f->dX[b], Ct, B, Hp, Hp, T.Cout, f->tb);
-      ft_bn_recompute(f, T.bn, f->X[b - 1], Cp, Mp, f->ta, s);
-      TN_TRY(launch_gemm_tn_f32(f->tb, T.Cout, f->ta, T.Cin, g + T.o_w, T.Cin, T.Cout, T.Cin, (int)Mp, s, f->ws, f->ws_floats));
+      TN_TRY(launch_gemm_tn_f32_bnrelu(f->tb, T.Cout, f->X[b - 1], Cp, T.bn.sc, T.bn.sh, g + T.o_w, T.Cin, T.Cout, T.Cin, (int)Mp, s, f->ws,
+                                       f->ws_floats));
       TN_TRY(launch_transpose_f32(w + T.o_w, T.Cout, T.Cin, f->tw, s));                  // (Cin, Cout)
       TN_TRY(launch_linear_f32(f->tb, T.Cout, f->tw, T.Cout, nullptr, f->tg, T.Cin, (int)Mp, T.Cin, T.Cout, 0, s));
       ft_bn_backward(f, T.bn, f->tg, f->X[b - 1], Cp, Mp, f->dX[b - 1], Cp, 0, s);

@@ -14,11 +14,14 @@ constexpr int kPD = 4;   // k-tiles of 16 in flight per thread (registers) ahead
 
 // F = 16x16 fragments per wave in each direction: tile = (32 F) x (32 F), 4 waves in a 2 x 2 arrangement (F = 2 is
 // what is launched; skinny problems go to linear_f32_skinny_kernel below).
-template <int F>
+// BN (round 4, the fine-tuning path): the X operand is transformed while it is staged, x -> relu(x * asc[k] + ash[k]) - a
+// training-mode BatchNorm + ReLU in front of a 1x1 convolution never materialises its output (finetune.hip).
+template <int F, bool BN = false>
 __global__ __launch_bounds__(256) void linear_f32_kernel(const float *__restrict__ X, int ldx,
                                                          const float *__restrict__ Wt, int ldw,
                                                          const float *__restrict__ bias, float *__restrict__ Y,
-                                                         int ldy, int M, int N, int K, int accumulate) {
+                                                         int ldy, int M, int N, int K, int accumulate,
+                                                         const float *__restrict__ asc = nullptr, const float *__restrict__ ash = nullptr) {
   constexpr int BT = 32 * F;             // tile rows (M) = tile columns (N)
   __shared__ float As[2][BT][17];
   __shared__ float Bs[2][BT][17];
@@ -47,12 +50,23 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float *__restrict
     for (int j = 0; j < 4; ++j) { a4[j] = 0.f; b4[j] = 0.f; }
     if (it >= nk) return;
     if (vec) {
-      if (doA && am < M && kk < K) { const float4 v = *(const float4 *)(xrow + kk); a4[0] = v.x; a4[1] = v.y; a4[2] = v.z; a4[3] = v.w; }
+      if (doA && am < M && kk < K) {
+        const float4 v = *(const float4 *)(xrow + kk);
+        a4[0] = v.x; a4[1] = v.y; a4[2] = v.z; a4[3] = v.w;
+        if constexpr (BN) {
+          const float4 sc = *(const float4 *)(asc + kk), sh = *(const float4 *)(ash + kk);
+          a4[0] = fmaxf(fmaf(a4[0], sc.x, sh.x), 0.f); a4[1] = fmaxf(fmaf(a4[1], sc.y, sh.y), 0.f);
+          a4[2] = fmaxf(fmaf(a4[2], sc.z, sh.z), 0.f); a4[3] = fmaxf(fmaf(a4[3], sc.w, sh.w), 0.f);
+        }
+      }
       if (doB && bn < N && kk < K) { const float4 v = *(const float4 *)(wrow + kk); b4[0] = v.x; b4[1] = v.y; b4[2] = v.z; b4[3] = v.w; }
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (doA && am < M && kk + j < K) a4[j] = xrow[kk + j];
+        if (doA && am < M && kk + j < K) {
+          a4[j] = xrow[kk + j];
+          if constexpr (BN) a4[j] = fmaxf(fmaf(a4[j], asc[kk + j], ash[kk + j]), 0.f);
+        }
         if (doB && bn < N && kk + j < K) b4[j] = wrow[kk + j];
       }
     }
@@ -112,10 +126,12 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float *__restrict
 
 // Skinny problems (fewer than two 64x64 tiles per CU): 32x32 tile, one 16x16 fragment per wave, BK = 32 so that a
 // k-tile carries 8 MFMAs per barrier.  Same k order per output element as linear_f32_kernel (one accumulator chain).
+template <bool BN = false>
 __global__ __launch_bounds__(256) void linear_f32_skinny_kernel(const float *__restrict__ X, int ldx,
                                                                 const float *__restrict__ Wt, int ldw,
                                                                 const float *__restrict__ bias, float *__restrict__ Y,
-                                                                int ldy, int M, int N, int K, int accumulate) {
+                                                                int ldy, int M, int N, int K, int accumulate,
+                                                                const float *__restrict__ asc = nullptr, const float *__restrict__ ash = nullptr) {
   __shared__ float As[2][32][33];
   __shared__ float Bs[2][32][33];
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
@@ -135,12 +151,23 @@ __global__ __launch_bounds__(256) void linear_f32_skinny_kernel(const float *__r
     for (int j = 0; j < 4; ++j) { a4[j] = 0.f; b4[j] = 0.f; }
     if (it >= nk) return;
     if (vec) {
-      if (am < M && kk < K) { const float4 v = *(const float4 *)(xrow + kk); a4[0] = v.x; a4[1] = v.y; a4[2] = v.z; a4[3] = v.w; }
+      if (am < M && kk < K) {
+        const float4 v = *(const float4 *)(xrow + kk);
+        a4[0] = v.x; a4[1] = v.y; a4[2] = v.z; a4[3] = v.w;
+        if constexpr (BN) {
+          const float4 sc = *(const float4 *)(asc + kk), sh = *(const float4 *)(ash + kk);
+          a4[0] = fmaxf(fmaf(a4[0], sc.x, sh.x), 0.f); a4[1] = fmaxf(fmaf(a4[1], sc.y, sh.y), 0.f);
+          a4[2] = fmaxf(fmaf(a4[2], sc.z, sh.z), 0.f); a4[3] = fmaxf(fmaf(a4[3], sc.w, sh.w), 0.f);
+        }
+      }
       if (bn < N && kk < K) { const float4 v = *(const float4 *)(wrow + kk); b4[0] = v.x; b4[1] = v.y; b4[2] = v.z; b4[3] = v.w; }
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (am < M && kk + j < K) a4[j] = xrow[kk + j];
+        if (am < M && kk + j < K) {
+          a4[j] = xrow[kk + j];
+          if constexpr (BN) a4[j] = fmaxf(fmaf(a4[j], asc[kk + j], ash[kk + j]), 0.f);
+        }
         if (bn < N && kk + j < K) b4[j] = wrow[kk + j];
       }
     }
@@ -255,10 +282,28 @@ int launch_linear_f32(const float *X, int ldx, const float *Wt, int ldw, const f
   const long big = (long)((N + 63) / 64) * ((M + 63) / 64);
   if (big >= 512) {
     const dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
-    hipLaunchKernelGGL(linear_f32_kernel<2>, grid, block, 0, s, X, ldx, Wt, ldw, bias, Y, ldy, M, N, K, accumulate);
+    hipLaunchKernelGGL((linear_f32_kernel<2, false>), grid, block, 0, s, X, ldx, Wt, ldw, bias, Y, ldy, M, N, K, accumulate, (const float *)nullptr,
+                       (const float *)nullptr);
   } else {   // fewer than two 64x64 tiles per CU: quarter-size tiles put four times as many CUs to work
     const dim3 grid((N + 31) / 32, (M + 31) / 32), block(256);
-    hipLaunchKernelGGL(linear_f32_skinny_kernel, grid, block, 0, s, X, ldx, Wt, ldw, bias, Y, ldy, M, N, K, accumulate);
+    hipLaunchKernelGGL(linear_f32_skinny_kernel<false>, grid, block, 0, s, X, ldx, Wt, ldw, bias, Y, ldy, M, N, K, accumulate, (const float *)nullptr,
+                       (const float *)nullptr);
+  }
+  TN_HIP_CHECK(hipGetLastError());
+  return TN_OK;
+}
+
+// Y = relu(X * asc + ash) W^T (+ bias): the X operand goes through a per-column scale / shift and a ReLU while it is staged
+int launch_linear_f32_bnrelu(const float *X, int ldx, const float *asc, const float *ash, const float *Wt, int ldw, const float *bias,
+                             float *Y, int ldy, int M, int N, int K, int accumulate, hipStream_t s) {
+  if (M <= 0 || N <= 0) return TN_OK;
+  const long big = (long)((N + 63) / 64) * ((M + 63) / 64);
+  if (big >= 512) {
+    const dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
+    hipLaunchKernelGGL((linear_f32_kernel<2, true>), grid, block, 0, s, X, ldx, Wt, ldw, bias, Y, ldy, M, N, K, accumulate, asc, ash);
+  } else {
+    const dim3 grid((N + 31) / 32, (M + 31) / 32), block(256);
+    hipLaunchKernelGGL(linear_f32_skinny_kernel<true>, grid, block, 0, s, X, ldx, Wt, ldw, bias, Y, ldy, M, N, K, accumulate, asc, ash);
   }
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;

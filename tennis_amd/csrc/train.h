@@ -17,6 +17,9 @@ int launch_lstm_train_bwd(const float *seq, const float *gates, const float *dse
                           const int32_t *valid_len = nullptr, const float *dh_last = nullptr, const float *dc_last = nullptr);
 int launch_gemm_tn_f32(const float *A, int lda, const float *Bm, int ldb, float *Cm, int ldc, int M, int N, int K,
                        hipStream_t s, float *workspace = nullptr, long workspace_floats = 0);   // workspace: enables split-K
+// ... with B -> relu(B * bsc[n] + bsh[n]) applied while the operand is staged
+int launch_gemm_tn_f32_bnrelu(const float *A, int lda, const float *Bm, int ldb, const float *bsc, const float *bsh, float *Cm, int ldc,
+                              int M, int N, int K, hipStream_t s, float *workspace = nullptr, long workspace_floats = 0);
 int launch_colsum_f32(const float *A, int lda, int rows, int cols, float *out, hipStream_t s);
 int launch_sgd_momentum(float *w, const float *g, float *mom, long n, float lr, float momentum, float wd,
                         float rescale, hipStream_t s);

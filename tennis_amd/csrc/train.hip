@@ -308,9 +308,11 @@ __global__ __launch_bounds__(MAXT) void lstm_train_bwd_kernel(const float *__res
 // fragments want (lane = (column, k)): rows of 64 columns are staged as they lie, no transposes.  kTnPD k-tiles of 16
 // stay in flight in registers (the compiler does not overlap a plain load -> LDS -> MFMA loop by itself).
 constexpr int kTnPD = 4;
+template <bool BNB = false>       // BNB: the B operand goes through relu(b * bsc[n] + bsh[n]) while it is staged (finetune.hip)
 __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const float *__restrict__ A, int lda,
                                                           const float *__restrict__ Bm, int ldb,
-                                                          float *__restrict__ Cm, int ldc, int M, int N, int K, int kchunk) {
+                                                          float *__restrict__ Cm, int ldc, int M, int N, int K, int kchunk,
+                                                          const float *__restrict__ bsc = nullptr, const float *__restrict__ bsh = nullptr) {
   // split-K: slice blockIdx.z covers rows [z*kchunk, (z+1)*kchunk) and writes its own (M, N) partial result
   A += (long)blockIdx.z * kchunk * lda;
   Bm += (long)blockIdx.z * kchunk * ldb;
@@ -337,11 +339,19 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const float *__restric
       const float4 va = *(const float4 *)(A + (long)k * lda + m0 + sc), vb = *(const float4 *)(Bm + (long)k * ldb + n0 + sc);
       a4[0] = va.x; a4[1] = va.y; a4[2] = va.z; a4[3] = va.w;
       b4[0] = vb.x; b4[1] = vb.y; b4[2] = vb.z; b4[3] = vb.w;
+      if constexpr (BNB) {
+        const float4 s4 = *(const float4 *)(bsc + n0 + sc), h4 = *(const float4 *)(bsh + n0 + sc);
+        b4[0] = fmaxf(fmaf(b4[0], s4.x, h4.x), 0.f); b4[1] = fmaxf(fmaf(b4[1], s4.y, h4.y), 0.f);
+        b4[2] = fmaxf(fmaf(b4[2], s4.z, h4.z), 0.f); b4[3] = fmaxf(fmaf(b4[3], s4.w, h4.w), 0.f);
+      }
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (m0 + sc + q < M) a4[q] = A[(long)k * lda + m0 + sc + q];
-        if (n0 + sc + q < N) b4[q] = Bm[(long)k * ldb + n0 + sc + q];
+        if (n0 + sc + q < N) {
+          b4[q] = Bm[(long)k * ldb + n0 + sc + q];
+          if constexpr (BNB) b4[q] = fmaxf(fmaf(b4[q], bsc[n0 + sc + q], bsh[n0 + sc + q]), 0.f);
+        }
       }
     }
   };
@@ -495,8 +505,9 @@ int launch_lstm_train_bwd(const float *seq, const float *gates, const float *dse
   TN_BPTT_DISPATCH(lstm_train_bwd_kernel, 4, dirs, seq, gates, dseq, wh, dgi, hprev, B, T, H, dirs, valid_len, dh_last, dc_last);
   TN_LAUNCH_CHECK();
 }
-int launch_gemm_tn_f32(const float *A, int lda, const float *Bm, int ldb, float *Cm, int ldc, int M, int N, int K,
-                       hipStream_t s, float *workspace, long workspace_floats) {
+// C (M,N) = A^T B over K rows; bsc / bsh non-null: B -> relu(B * bsc[n] + bsh[n]) on the way in (a BatchNorm + ReLU that is never stored)
+static int gemm_tn_dispatch(const float *A, int lda, const float *Bm, int ldb, const float *bsc, const float *bsh, float *Cm, int ldc, int M,
+                            int N, int K, hipStream_t s, float *workspace, long workspace_floats) {
   const int tiles = ((N + 63) / 64) * ((M + 63) / 64);
   // few output tiles and a long reduction (weight gradients over all pixels): split K over workgroups, partial results
   // in the caller's workspace, summed in slice order (deterministic)
@@ -506,17 +517,28 @@ int launch_gemm_tn_f32(const float *A, int lda, const float *Bm, int ldb, float 
     if (S > K / 512) S = K / 512;
     while (S > 1 && (long)S * M * N > workspace_floats) --S;
   }
+  const bool bn = bsc != nullptr;
   if (S <= 1) {
-    hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64, 1), dim3(256), 0, s, A, lda, Bm, ldb, Cm, ldc,
-                       M, N, K, K);
+    const dim3 grid((N + 63) / 64, (M + 63) / 64, 1);
+    if (bn) hipLaunchKernelGGL(gemm_tn_f32_kernel<true>, grid, dim3(256), 0, s, A, lda, Bm, ldb, Cm, ldc, M, N, K, K, bsc, bsh);
+    else hipLaunchKernelGGL(gemm_tn_f32_kernel<false>, grid, dim3(256), 0, s, A, lda, Bm, ldb, Cm, ldc, M, N, K, K, bsc, bsh);
     TN_LAUNCH_CHECK();
   }
   const int kchunk = (((K + S - 1) / S) + 15) / 16 * 16;
   S = (K + kchunk - 1) / kchunk;
-  hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64, S), dim3(256), 0, s, A, lda, Bm, ldb, workspace, N,
-                     M, N, K, kchunk);
+  const dim3 grid((N + 63) / 64, (M + 63) / 64, S);
+  if (bn) hipLaunchKernelGGL(gemm_tn_f32_kernel<true>, grid, dim3(256), 0, s, A, lda, Bm, ldb, workspace, N, M, N, K, kchunk, bsc, bsh);
+  else hipLaunchKernelGGL(gemm_tn_f32_kernel<false>, grid, dim3(256), 0, s, A, lda, Bm, ldb, workspace, N, M, N, K, kchunk, bsc, bsh);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(((long)M * N + 255) / 256), dim3(256), 0, s, (const float *)workspace, S, M, N, Cm, ldc);
   TN_LAUNCH_CHECK();
+}
+int launch_gemm_tn_f32(const float *A, int lda, const float *Bm, int ldb, float *Cm, int ldc, int M, int N, int K,
+                       hipStream_t s, float *workspace, long workspace_floats) {
+  return gemm_tn_dispatch(A, lda, Bm, ldb, nullptr, nullptr, Cm, ldc, M, N, K, s, workspace, workspace_floats);
+}
+int launch_gemm_tn_f32_bnrelu(const float *A, int lda, const float *Bm, int ldb, const float *bsc, const float *bsh, float *Cm, int ldc,
+                              int M, int N, int K, hipStream_t s, float *workspace, long workspace_floats) {
+  return gemm_tn_dispatch(A, lda, Bm, ldb, bsc, bsh, Cm, ldc, M, N, K, s, workspace, workspace_floats);
 }
 int launch_colsum_f32(const float *A, int lda, int rows, int cols, float *out, hipStream_t s) {
   hipLaunchKernelGGL(colsum_f32_kernel, dim3((cols + 63) / 64), dim3(1024), 0, s, A, lda, rows, cols, out);
