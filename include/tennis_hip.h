@@ -175,6 +175,21 @@ typedef struct tn_preproc tn_preproc;
 int tn_preproc_create(tn_ctx *ctx, int src_h, int src_w, int resize, int crop, tn_preproc **out);
 int tn_preproc_forward(tn_preproc *p, const uint8_t *src, int batch, uint8_t *dst);
 int tn_preproc_destroy(tn_preproc *p);
+/* Train-time augmentation of the frame classifier (reference train.py:127-136: transforms.RandomResizedCrop(data_shape),
+ * RandomFlipLeftRight(), RandomColorJitter(brightness, contrast, saturation), RandomLighting(alpha) in front of ToTensor / Normalize):
+ * the image arithmetic for a batch, one parameter record per frame.  The random draws are the caller's (MXNet's generator cannot be
+ * reproduced: tennis_amd/transforms.py draws them the way mx.image.random_size_crop / the image_random operators do).  src (batch,
+ * src_h, src_w, 3) uint8 RGB and every other buffer on the device, frames_host = the same records on the host (validated there);
+ * tmp batch * size * size * 3 bytes, gray_tmp batch floats; dst (batch, size, size, 3) uint8 - what ToTensor receives. */
+typedef struct tn_aug_frame {
+  int32_t x0, y0, cw, ch;        /* crop window (random_size_crop), resized to size x size with cv::resize(INTER_LINEAR) */
+  int32_t flip;                  /* RandomFlipLeftRight */
+  int32_t order;                 /* four 2-bit fields, first applied in the low bits: 0 brightness, 1 contrast, 2 saturation, 3 hue (= nothing) */
+  float brightness, contrast, saturation;   /* the operators' alphas: 1 + U(-p, p) */
+  float light[3];                /* RandomLighting: eigvec (alpha * eigval), per channel */
+} tn_aug_frame;
+int tn_augment_forward(tn_ctx *ctx, const uint8_t *src, int batch, int src_h, int src_w, const tn_aug_frame *frames_dev,
+                       const tn_aug_frame *frames_host, int size, uint8_t *tmp, float *gray_tmp, uint8_t *dst);
 /* ToTensor + Normalize (reference evaluate.py:96-97, train.py:138-139) for consumers of fp32 frames (the fine-tuning
  * step; the inference encoder fuses it into its stem load): dst[p][c] = (src[p][c] / 255 - mean[c]) / std[c],
  * src (pixels, 3) uint8 NHWC, dst (pixels, 3) float NHWC, both DEVICE; mean3 / std3 HOST arrays of 3 floats. */

@@ -57,3 +57,40 @@ def test_transform_u8(img, data_shape):
     """Resize(data_shape + 32) + CenterCrop(data_shape): (H, W, 3) uint8 -> (data_shape, data_shape, 3) uint8."""
     s = data_shape + 32
     return center_crop(resize_bilinear_u8(img, s, s), data_shape)
+
+
+# ---- the reference's train transform (train.py:127-136), image arithmetic only: the random parameters are inputs ----
+#   transforms.RandomResizedCrop -> mx.image.random_size_crop -> fixed_crop (crop, then imresize interp=1)        [EXT]
+#   transforms.RandomFlipLeftRight; RandomColorJitter -> the image_random operators (brightness / contrast / saturation, each
+#   saturate_cast to uint8, in a drawn order; contrast against the image's mean grey 0.299 R + 0.587 G + 0.114 B);
+#   RandomLighting -> in + eigvec (alpha * eigval)                                      [EXT: src/operator/image/image_random-inl.h]
+# PARITY UNPINNED (MXNet absent): saturate_cast is taken as clamp-then-truncate, the image's mean grey as the exact mean of the
+# per-pixel float32 grey values.
+
+def _sat_u8(v):
+    return np.clip(v, np.float32(0), np.float32(255)).astype(np.uint8)        # clamp, then truncate
+
+
+def _gray(img):
+    f = img.astype(np.float32)
+    return (f[..., 0] * np.float32(0.299) + f[..., 1] * np.float32(0.587)) + f[..., 2] * np.float32(0.114)
+
+
+def augment_u8(img, x0, y0, cw, ch, flip, order, brightness, contrast, saturation, light, size):
+    """(H, W, 3) uint8 -> (size, size, 3) uint8; ``order``: the four jitter operators (0 brightness, 1 contrast, 2 saturation,
+    3 hue = nothing) in the order they run; ``light``: the three per-channel offsets of RandomLighting."""
+    a = resize_bilinear_u8(img[y0:y0 + ch, x0:x0 + cw], size, size)
+    if flip:
+        a = a[:, ::-1]
+    b, c, s = np.float32(brightness), np.float32(contrast), np.float32(saturation)
+    for op in order:
+        f = a.astype(np.float32)
+        if op == 0:
+            a = _sat_u8(f * b)
+        elif op == 1:
+            gm = np.float32(_gray(a).astype(np.float64).sum() / (size * size))
+            a = _sat_u8(f * c + (np.float32(1) - c) * gm)
+        elif op == 2:
+            g = _gray(a) * (np.float32(1) - s)
+            a = _sat_u8(f * s + g[..., None])
+    return _sat_u8(a.astype(np.float32) + np.asarray(light, np.float32)[None, None, :])

@@ -63,6 +63,7 @@ _SIGS = {
     "tn_preproc_create": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "tn_preproc_forward": (C.c_int, [_P, _P, C.c_int, _P]),
     "tn_preproc_destroy": (C.c_int, [_P]),
+    "tn_augment_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P]),
     "tn_to_tensor_normalize": (C.c_int, [_P, _P, C.c_long, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "tn_jpeg_create": (C.c_int, [_P, C.POINTER(_P)]),
     "tn_jpeg_info": (C.c_int, [_P, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),

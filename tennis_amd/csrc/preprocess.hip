@@ -146,6 +146,176 @@ extern "C" int tn_to_tensor_normalize(tn_ctx *ctx, const uint8_t *src, long pixe
   return TN_OK;
 }
 
+// ---- train-time augmentation (reference train.py:127-136: RandomResizedCrop, RandomFlipLeftRight, RandomColorJitter,
+// RandomLighting in front of ToTensor / Normalize) ------------------------------------------------------------------------
+// The random draws are the host's (tennis_amd/transforms.py: MXNet's generator cannot be reproduced); what runs here is the
+// image arithmetic for a batch of frames with one parameter record each.  All of it stays uint8 between the operators, as
+// the Gluon transforms do on the uint8 HWC image ToTensor receives [EXT: mxnet src/operator/image/image_random-inl.h,
+// python/mxnet/image/image.py; unpinned]:
+//   random_size_crop -> fixed_crop: crop (x0, y0, cw, ch), cv::resize(INTER_LINEAR) to size x size (8-bit fixed point as above,
+//     the 2 x 2 box average for an exact 2x reduction); flip: mirror in x;
+//   colour jitter: brightness / contrast / saturation (/ hue = 0: nothing) in the record's order, each
+//     saturate_cast<uint8>(float): brightness v * a; contrast v * a + (1 - a) * mean over the image of
+//     0.299 R + 0.587 G + 0.114 B; saturation v * a + (1 - a) * (0.299 R + 0.587 G + 0.114 B) of the pixel;
+//   lighting: v + pca[c] (AlexNet's eigenvectors times the drawn alphas, worked out on the host).
+namespace {
+
+__device__ __forceinline__ uint8_t sat_u8(float v) { return (uint8_t)(v < 0.f ? 0.f : (v > 255.f ? 255.f : v)); }
+// Un-fused arithmetic: the host code these kernels restate rounds every product and every sum (HIP's __fmul_rn / __fadd_rn are
+// plain operators, which hipcc contracts into fmas: a grey pixel's saturation result 123.0 came out as 122.99999 here and 123.0
+// there).  Operations built under `fp contract(off)` carry no contract flag and stay separate after inlining.
+__device__ __forceinline__ float mul_nf(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float add_nf(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float sub_nf(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+__device__ __forceinline__ double dmul_nf(double a, double b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ double dsub_nf(double a, double b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+
+__device__ __forceinline__ void aug_tap(int d, int src, int dst, bool clamp_ofs, int &ofs, int &c0, int &c1) {
+  // (explicitly un-fused: hipcc contracts a * b - c into an fma, cv::resize's host code does not)
+  float f = (float)dsub_nf(dmul_nf((double)d + 0.5, (double)src / (double)dst), 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (clamp_ofs) {
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= src - 1) { f = 0.f; s = src - 1; }
+  }
+  ofs = s;
+  c0 = (int)max(-32768l, min(32767l, lrintf(mul_nf(sub_nf(1.f, f), 2048.f))));
+  c1 = (int)max(-32768l, min(32767l, lrintf(mul_nf(f, 2048.f))));
+}
+
+// crop + resize + flip: one thread per output pixel
+__global__ __launch_bounds__(256) void aug_crop_resize_kernel(const uint8_t *__restrict__ src, int Hs, int Ws,
+                                                              const tn_aug_frame *__restrict__ fr, int size, uint8_t *__restrict__ dst) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  if (x >= size) return;
+  const tn_aug_frame f = fr[b];
+  const uint8_t *img = src + ((size_t)b * Hs + f.y0) * Ws * 3 + (size_t)f.x0 * 3;      // the crop window, row pitch Ws * 3
+  const int xo = f.flip ? size - 1 - x : x;
+  uint8_t *o = dst + (((size_t)b * size + y) * size + xo) * 3;
+  const size_t pitch = (size_t)Ws * 3;
+  if (f.cw == 2 * size && f.ch == 2 * size) {      // exact 2x reduction: INTER_AREA fast path
+    const uint8_t *p = img + (size_t)(2 * y) * pitch + (size_t)(2 * x) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = (uint8_t)((p[c] + p[3 + c] + p[pitch + c] + p[pitch + 3 + c] + 2) >> 2);
+    return;
+  }
+  int tx, tx0, tx1, ty, ty0, ty1;
+  aug_tap(x, f.cw, size, true, tx, tx0, tx1);
+  aug_tap(y, f.ch, size, false, ty, ty0, ty1);
+  const int r0 = ty < 0 ? 0 : (ty < f.ch ? ty : f.ch - 1);
+  const int r1 = ty + 1 < 0 ? 0 : (ty + 1 < f.ch ? ty + 1 : f.ch - 1);
+  const int c1 = tx + 1 < f.cw ? tx + 1 : f.cw - 1;
+  const uint8_t *p0 = img + (size_t)r0 * pitch, *p1 = img + (size_t)r1 * pitch;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int S0 = p0[tx * 3 + c] * tx0 + p0[c1 * 3 + c] * tx1;
+    const int S1 = p1[tx * 3 + c] * tx0 + p1[c1 * 3 + c] * tx1;
+    o[c] = (uint8_t)((((ty0 * (S0 >> 4)) >> 16) + ((ty1 * (S1 >> 4)) >> 16) + 2) >> 2);
+  }
+}
+
+__device__ __forceinline__ float aug_gray(const uint8_t v[3]) {
+  return add_nf(add_nf(mul_nf((float)v[0], 0.299f), mul_nf((float)v[1], 0.587f)), mul_nf((float)v[2], 0.114f));
+}
+// operator `op` of the jitter on one pixel (0 brightness, 1 contrast, 2 saturation, 3 hue = nothing)
+__device__ __forceinline__ void aug_op(int op, const tn_aug_frame &f, float gray_mean, uint8_t v[3]) {
+  if (op == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = sat_u8(mul_nf((float)v[c], f.brightness));
+  } else if (op == 1) {
+    const float beta = mul_nf(sub_nf(1.f, f.contrast), gray_mean);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = sat_u8(add_nf(mul_nf((float)v[c], f.contrast), beta));
+  } else if (op == 2) {
+    const float g = mul_nf(aug_gray(v), sub_nf(1.f, f.saturation));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = sat_u8(add_nf(mul_nf((float)v[c], f.saturation), g));
+  }
+}
+
+// mean of 0.299 R + 0.587 G + 0.114 B over the image AS THE CONTRAST OPERATOR SEES IT (the operators in front of it applied):
+// one workgroup per frame; every per-pixel grey value is a float, their sum in double is exact in any order (multiples of 2^-27
+// below 2^26), so the result does not depend on how the reduction is arranged
+__global__ __launch_bounds__(256) void aug_gray_mean_kernel(const uint8_t *__restrict__ img, const tn_aug_frame *__restrict__ fr, int size,
+                                                            float *__restrict__ gray_mean) {
+  __shared__ double red[256];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const tn_aug_frame f = fr[b];
+  const long n = (long)size * size;
+  const uint8_t *p = img + (size_t)b * n * 3;
+  double acc = 0.0;
+  for (long i = t; i < n; i += 256) {
+    uint8_t v[3] = {p[i * 3], p[i * 3 + 1], p[i * 3 + 2]};
+    for (int k = 0; k < 4; ++k) {
+      const int op = (f.order >> (2 * k)) & 3;
+      if (op == 1) break;
+      aug_op(op, f, 0.f, v);
+    }
+    acc += (double)aug_gray(v);
+  }
+  red[t] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+  if (t == 0) gray_mean[b] = (float)(red[0] / (double)n);
+}
+
+__global__ __launch_bounds__(256) void aug_color_kernel(const uint8_t *__restrict__ img, const tn_aug_frame *__restrict__ fr, int size,
+                                                        const float *__restrict__ gray_mean, uint8_t *__restrict__ dst) {
+  const long n = (long)size * size;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (i >= n) return;
+  const tn_aug_frame f = fr[b];
+  const uint8_t *p = img + ((size_t)b * n + i) * 3;
+  uint8_t v[3] = {p[0], p[1], p[2]};
+  const float gm = gray_mean[b];
+  for (int k = 0; k < 4; ++k) aug_op((f.order >> (2 * k)) & 3, f, gm, v);
+  uint8_t *o = dst + ((size_t)b * n + i) * 3;
+  o[0] = sat_u8(add_nf((float)v[0], f.light[0]));
+  o[1] = sat_u8(add_nf((float)v[1], f.light[1]));
+  o[2] = sat_u8(add_nf((float)v[2], f.light[2]));
+}
+
+}  // namespace
+
+extern "C" int tn_augment_forward(tn_ctx *ctx, const uint8_t *src, int batch, int src_h, int src_w, const tn_aug_frame *frames_dev,
+                                  const tn_aug_frame *frames_host, int size, uint8_t *tmp, float *gray_tmp, uint8_t *dst) {
+  TN_REQUIRE(ctx && src && frames_dev && frames_host && tmp && gray_tmp && dst, "tn_augment_forward: null argument");
+  TN_REQUIRE(batch > 0 && batch <= 65535 && src_h > 0 && src_w > 0 && size > 0 && size <= 65535, "tn_augment_forward: bad shape");
+  for (int b = 0; b < batch; ++b) {
+    const tn_aug_frame &f = frames_host[b];
+    TN_REQUIRE(f.x0 >= 0 && f.y0 >= 0 && f.cw > 0 && f.ch > 0 && f.x0 + f.cw <= src_w && f.y0 + f.ch <= src_h,
+               "tn_augment_forward: a crop window leaves the frame");
+    int seen = 0;
+    for (int k = 0; k < 4; ++k) seen |= 1 << ((f.order >> (2 * k)) & 3);
+    TN_REQUIRE(seen == 15 && (f.order >> 8) == 0, "tn_augment_forward: order must be a permutation of the four jitter operators, two bits each");
+  }
+  TN_ON_DEVICE(ctx->device);
+  hipStream_t s = ctx->stream;
+  hipLaunchKernelGGL(aug_crop_resize_kernel, dim3((size + 255) / 256, size, batch), dim3(256), 0, s, src, src_h, src_w, frames_dev, size, tmp);
+  hipLaunchKernelGGL(aug_gray_mean_kernel, dim3(batch), dim3(256), 0, s, (const uint8_t *)tmp, frames_dev, size, gray_tmp);
+  hipLaunchKernelGGL(aug_color_kernel, dim3((unsigned)(((long)size * size + 255) / 256), batch), dim3(256), 0, s, (const uint8_t *)tmp,
+                     frames_dev, size, (const float *)gray_tmp, dst);
+  TN_HIP_CHECK(hipGetLastError());
+  return TN_OK;
+}
+
 extern "C" int tn_preproc_destroy(tn_preproc *p) {
   if (!p) return TN_OK;
   TnDeviceGuard tn_dg_(p->ctx->device);

@@ -145,6 +145,7 @@ def build_parser():
     p = argparse.ArgumentParser(description="tennis_amd train (flags of reference train.py:30-95)")
     p.add_argument("--backbone", default="DenseNet121")
     p.add_argument("--freeze_backbone", action="store_true")
+    p.add_argument("--no_augment", action="store_true", help="test transform for the train split too (not a reference flag)")
     p.add_argument("--model_id", default="0000")
     p.add_argument("--split_id", default="02")
     p.add_argument("--data_shape", type=int, default=224)
@@ -174,8 +175,9 @@ def main(argv=None):
     """reference train.py::main (:98-386) for the two trainable configurations on the hot path:
       * ``--feats_model <id> --window W --temp_pool gru|lstm``: the temporal head on pre-extracted features (backbone frozen);
       * ``--window 1`` without ``--feats_model``: the frame classifier end to end (BatchNorm in training mode).
-    Frames go through the TEST transform: the reference's train-time augmentation (RandomResizedCrop, flips, colour jitter,
-    lighting; train.py:127-136) is host-side image processing outside this path and is not mirrored."""
+    End-to-end training on frames from disk uses the reference's TRAIN transform for the train split (RandomResizedCrop,
+    RandomFlipLeftRight, RandomColorJitter(0.4, 0.4, 0.4), RandomLighting(0.1); train.py:125-139 - round 4: one GPU launch group per
+    batch, ``tennis_amd.transforms``), the test transform for validation; ``--no_augment`` keeps the test transform everywhere."""
     from . import transforms
     from .dataset import DataLoader, TennisSet
     from .engine import FrameModelTrainer, TemporalHeadTrainer
@@ -199,7 +201,13 @@ def main(argv=None):
     tf = transforms.Compose([transforms.Resize(flags.data_shape + 32), transforms.CenterCrop(flags.data_shape),
                              transforms.ToTensor(),
                              transforms.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])]) if on_disk else None
-    mk = lambda split, ev, bal: TennisSet(root=flags.root, transform=tf, split=split, every=ev, padding=flags.padding,
+    # train.py:125-139: jitter_param = 0.4, lighting_param = 0.1 (every rank draws from its own seed: the ranks train on different rows)
+    tf_train = transforms.Compose([transforms.RandomResizedCrop(flags.data_shape), transforms.RandomFlipLeftRight(),
+                                   transforms.RandomColorJitter(brightness=0.4, contrast=0.4, saturation=0.4),
+                                   transforms.RandomLighting(0.1), transforms.ToTensor(),
+                                   transforms.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])],
+                                  seed=1000 + rank) if on_disk and not flags.no_augment else tf
+    mk = lambda split, ev, bal: TennisSet(root=flags.root, transform=tf_train if split == "train" else tf, split=split, every=ev, padding=flags.padding,
                                           stride=flags.stride, window=flags.window, model_id=flags.model_id,
                                           split_id=flags.split_id, balance=bal, feats_model=flags.feats_model,
                                           data_shape=flags.data_shape, frames_per_video=flags.frames_per_video,

@@ -203,3 +203,49 @@ def test_caption_set_on_disk(tmp_path):
     assert src.shape == (2, 2, 24) and tgt.shape == (2, 4)
     with pytest.raises(ValueError):
         CaptionSet(root=root, split="test", split_id="02")
+
+
+def test_train_transform_oracle_and_parameter_draws():
+    """Round 4: the reference's TRAIN transform (train.py:125-139).  oracle/image_np.py::augment_u8 with neutral parameters is the
+    plain resize; the host-side draws of tennis_amd.transforms follow mx.image.random_size_crop / the image_random operators:
+    crop windows inside the frame with areas in ``scale`` and aspect ratios in ``ratio`` (the centre-crop fallback when ten
+    attempts fail), flips about half of the time, alphas in 1 +- p, orders = permutations of the four jitter operators."""
+    from oracle import image_np as im
+    from tennis_amd import transforms as T
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (90, 120, 3), dtype=np.uint8)
+    assert np.array_equal(im.augment_u8(img, 0, 0, 120, 90, 0, [0, 1, 2, 3], 1.0, 1.0, 1.0, [0, 0, 0], 64), im.resize_bilinear_u8(img, 64, 64))
+    flipped = im.augment_u8(img, 0, 0, 120, 90, 1, [3, 2, 1, 0], 1.0, 1.0, 1.0, [0, 0, 0], 64)
+    assert np.array_equal(flipped, im.resize_bilinear_u8(img, 64, 64)[:, ::-1])
+    bright = im.augment_u8(img, 0, 0, 120, 90, 0, [0, 1, 2, 3], 2.0, 1.0, 1.0, [0, 0, 0], 64)
+    assert bright.max() == 255 and (bright >= im.resize_bilinear_u8(img, 64, 64)).all()
+    grey = im.augment_u8(img, 0, 0, 120, 90, 0, [2, 0, 1, 3], 1.0, 1.0, 0.0, [0, 0, 0], 64)          # saturation 0: every channel = the grey value
+    assert np.abs(grey[..., 0].astype(int) - grey[..., 1].astype(int)).max() == 0 and np.array_equal(grey[..., 1], grey[..., 2])
+    flat = im.augment_u8(img, 0, 0, 120, 90, 0, [1, 0, 2, 3], 1.0, 0.0, 1.0, [0, 0, 0], 64)          # contrast 0: the mean grey everywhere
+    assert len(np.unique(flat)) == 1
+    # the draws
+    rrc, jit, lit = T.RandomResizedCrop(224), T.RandomColorJitter(0.4, 0.4, 0.4), T.RandomLighting(0.1)
+    g = np.random.default_rng(3)
+    wins = np.array([rrc.draw(g, 720, 1280) for _ in range(2000)])
+    assert (wins[:, 0] >= 0).all() and (wins[:, 1] >= 0).all() and (wins[:, 0] + wins[:, 2] <= 1280).all() and (wins[:, 1] + wins[:, 3] <= 720).all()
+    area = wins[:, 2] * wins[:, 3] / (720 * 1280)
+    ratio = wins[:, 2] / wins[:, 3]
+    # (a 16:9 frame rejects the large windows whose ratio <= 4/3 makes them taller than the frame: the accepted areas skew small)
+    assert 0.07 < area.min() and area.max() <= 1.0 and 0.25 < area.mean() < 0.45
+    sq = np.array([rrc.draw(g, 500, 500) for _ in range(2000)])
+    assert 0.45 < (sq[:, 2] * sq[:, 3] / 250000.0).mean() < 0.6
+    assert 0.74 < ratio.min() and ratio.max() < 1.35
+    tall = np.array([T.RandomResizedCrop(224, scale=(0.9, 1.0), ratio=(3.0, 3.0)).draw(g, 100, 100) for _ in range(20)])
+    assert (tall == np.array([0, 0, 100, 100])).all()                      # no 3:1 window of 90 % of a square frame: the centre crop
+    flips = np.mean([T.RandomFlipLeftRight().draw(g) for _ in range(4000)])
+    assert 0.45 < flips < 0.55
+    orders = set()
+    for _ in range(500):
+        o, a = jit.draw(g)
+        orders.add(tuple(o))
+        assert sorted(o) == [0, 1, 2, 3] and all(0.6 <= v <= 1.4 for v in a)
+    assert len(orders) == 24
+    l = np.array([lit.draw(g) for _ in range(2000)])
+    assert l.shape == (2000, 3) and abs(l.mean()) < 0.3 and 2.0 < l[:, 0].std() < 4.5      # 0.1 * 55.46 * 0.5675 = 3.1 on the first axis
+    with pytest.raises(NotImplementedError):
+        T.Compose([T.RandomResizedCrop(224), T.ToTensor()])

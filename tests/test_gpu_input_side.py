@@ -92,3 +92,47 @@ def test_frames_on_disk_to_features(tmp_path, report):
     e = float(np.abs(feats[pick] - ref).max())
     report["disk_frames_to_features_maxabs_err"] = e
     assert e < 5e-3, e          # u8 path: one extra fp16 rounding of the normalised pixel (as test_gpu_encoder's u8 case)
+
+
+def test_train_transform_matches_oracle_bit_for_bit():
+    """Round 4: the reference's train transform (train.py:125-139) on the device (tn_augment_forward: crop + cv::resize + flip, the
+    image's mean grey, jitter operators in the drawn order + lighting) against oracle/image_np.py::augment_u8 fed the SAME drawn
+    parameters - uint8, bit for bit: 720p sources, a 2x-reduction window (INTER_AREA fast path), every one of the 24 operator
+    orders, whole-frame windows, flips."""
+    import ctypes as C
+    from oracle import image_np as im
+    from tennis_amd import transforms as T
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:360, 0:640]
+    frames = np.stack([np.clip(np.stack([100 + 60 * np.sin(xx / (30.0 + i) + i), 90 + 50 * np.cos(yy / 25.0), 60 + (xx + yy + 13 * i) % 120], -1)
+                               + rng.normal(0, 12, (360, 640, 3)), 0, 255).astype(np.uint8) for i in range(26)])
+    tf = T.Compose([T.RandomResizedCrop(112), T.RandomFlipLeftRight(), T.RandomColorJitter(0.4, 0.4, 0.4), T.RandomLighting(0.1),
+                    T.ToTensor(), T.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])], seed=5)
+    rec = tf.draw_params(len(frames), 360, 640)
+    import itertools
+    for i, perm in enumerate(itertools.permutations(range(4))):              # every order once
+        rec[i].order = sum(o << (2 * k) for k, o in enumerate(perm))
+    rec[24].x0, rec[24].y0, rec[24].cw, rec[24].ch = 200, 100, 224, 224      # exact 2x reduction
+    rec[25].x0, rec[25].y0, rec[25].cw, rec[25].ch = 0, 0, 640, 360          # the whole frame
+    got = tf.augment(torch.from_numpy(frames).cuda(), rec).cpu().numpy()
+    for i in range(len(frames)):
+        r = rec[i]
+        want = im.augment_u8(frames[i], r.x0, r.y0, r.cw, r.ch, r.flip, [(r.order >> (2 * k)) & 3 for k in range(4)], r.brightness,
+                             r.contrast, r.saturation, list(r.light), 112)
+        assert np.array_equal(got[i], want), (i, int(np.abs(got[i].astype(int) - want.astype(int)).max()), (r.x0, r.y0, r.cw, r.ch, r.flip, r.order))
+    # the call path: a batch through Compose.__call__ (its own draws), shape / dtype / reproducibility from the seed
+    a = T.Compose([T.RandomResizedCrop(64), T.RandomFlipLeftRight(), T.RandomColorJitter(0.4, 0.4, 0.4), T.RandomLighting(0.1), T.ToTensor(),
+                   T.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])], seed=9)
+    b = T.Compose([T.RandomResizedCrop(64), T.RandomFlipLeftRight(), T.RandomColorJitter(0.4, 0.4, 0.4), T.RandomLighting(0.1), T.ToTensor(),
+                   T.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])], seed=9)
+    xa, xb = a(frames[:8]), b(frames[:8])
+    assert xa.shape == (8, 64, 64, 3) and xa.dtype == torch.uint8 and torch.equal(xa, xb) and not torch.equal(a(frames[:8]), xa)
+    # errors: a window outside the frame, a broken order
+    bad = tf.draw_params(1, 360, 640)
+    bad[0].cw = 700
+    with pytest.raises(RuntimeError, match="crop window"):
+        tf.augment(torch.from_numpy(frames[:1]).cuda(), bad)
+    bad = tf.draw_params(1, 360, 640)
+    bad[0].order = 0
+    with pytest.raises(RuntimeError, match="permutation"):
+        tf.augment(torch.from_numpy(frames[:1]).cuda(), bad)
