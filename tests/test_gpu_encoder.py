@@ -317,6 +317,34 @@ def test_full_batch_256_matches_small_batches(report, monkeypatch):
     assert float((ref - small).abs().max()) < 2e-3
 
 
+def test_full_batch_256_distinct_frames_vs_oracle(report):
+    """BASELINE.json configs[1] at FULL size with 256 DISTINCT frames against the fp32 oracle (oracle/torch_ref.py, 15 s of CPU on the
+    test box - cross-checked against oracle/densenet_np.py in tests/test_cpu_oracle.py).  262 144 feature values instead of the 2 048
+    - 4 096 of the small tests: the largest single error sits AT the bar (measured 1.03e-3 / 9.95e-4 for weight seeds 0 / 2), the
+    99.99th percentile at 6.4 - 7.6e-4, a frame's worst feature at 5.3 - 6.3e-4 in the median; the logits of FrameModel's Dense(11)
+    (what north_star's bar names first) stay inside 1e-3 with room.  The test pins that picture: it fails if the tail grows."""
+    from oracle.torch_ref import TorchDenseNet121
+    from tennis_amd import weights as W
+    from tennis_amd.engine import Dense, DenseNet121Features
+    p = W.make_densenet121_weights(0)
+    p.update(W.make_dense_weights(1, 11, 1024, "framemodel0_dense0_"))
+    x16 = W.normalize_to_nchw_f32(W.synthetic_frames_u8(256, 224, seed=77)).astype(np.float16)
+    ref = TorchDenseNet121(p)(torch.from_numpy(x16.astype(np.float32))).numpy()
+    ref_logits = dn.dense(ref, p, "framemodel0_dense0_")
+    xd = torch.from_numpy(np.ascontiguousarray(x16.transpose(0, 2, 3, 1))).cuda()
+    feat_d = DenseNet121Features(p, 224, max_batch=256)(xd)
+    logits = Dense(p["framemodel0_dense0_weight"], p["framemodel0_dense0_bias"])(feat_d).cpu().numpy()
+    e = np.abs(feat_d.cpu().numpy() - ref)
+    el = float(np.abs(logits - ref_logits).max())
+    report["features_b256_distinct_maxabs_err"] = float(e.max())
+    report["features_b256_distinct_p9999_err"] = float(np.quantile(e, 0.9999))
+    report["features_b256_distinct_over_bar"] = int((e > TOL).sum())
+    report["logits_b256_distinct_maxabs_err"] = el
+    assert el < TOL, el
+    assert np.quantile(e, 0.9999) < TOL and np.median(e.max(1)) < 7.5e-4
+    assert e.max() < 1.25e-3 and (e > TOL).sum() <= 8, (float(e.max()), int((e > TOL).sum()))
+
+
 def test_fp32_weights_exact_mode(report):
     """north_star: "logits within 1e-3 of the MXNet CPU reference", which evaluates fp32 parameters
     (reference models/vision/definitions.py:27-33).  With UN-rounded fp32 conv weights the default fp16 model carries
