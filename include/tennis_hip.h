@@ -132,6 +132,15 @@ int tn_densenet121_input_means(tn_encoder *enc, const void *x, tn_layout layout,
  * The reference evaluates fp32 parameters (models/vision/definitions.py:27-33): this keeps ONE fp16 number per weight within
  * the 1e-3 bar of that evaluation. */
 int tn_round_fp16_calibrated(const float *w, int rows, int cols, const double *A, int frames, int sweeps, double ridge, float *out);
+/* The `.npy` side of `evaluate.py --save_feats` (reference evaluate.py:306-321: np.save(feat_path, feat[i]) per frame unless the file
+ * exists): a pool of host threads that creates the directories and writes one NumPy-format-1.0 float32 file per row, byte for byte
+ * what np.save writes.  submit copies the rows (host memory) and returns; drain waits for everything submitted, returns the totals
+ * since creation and fails with the first file error.  Host code, no GPU involved (csrc/npy_host.hip). */
+typedef struct tn_npy_writer tn_npy_writer;
+int tn_npy_writer_create(int threads, tn_npy_writer **out);
+int tn_npy_writer_submit(tn_npy_writer *w, const float *rows_host, int n, int dim, const char *const *paths, int skip_existing);
+int tn_npy_writer_drain(tn_npy_writer *w, int64_t *written, int64_t *skipped);
+int tn_npy_writer_destroy(tn_npy_writer *w);
 /* BatchNorm -> ReLU in front of a dense layer's 1x1 convolution (gluoncv DenseNet _make_dense_layer, reference call site
  * models/vision/definitions.py:30) re-parametrised for the fused kernels' packed-half form: relu(scale x + shift) = m relu(a x + b)
  * with a and b fp16 numbers (a exactly scale / m, b the best of 33 candidates for shift / m); m[k] multiplies column k of the 1x1

@@ -50,20 +50,69 @@ def evaluate_model(net, loader, dataset, metrics, ctx=None):
     return results, ground_truths
 
 
+class NpyWriter:
+    """The ``.npy`` side of ``--save_feats``: ``tn_npy_writer_*`` (csrc/npy_host.hip), a pool of host threads behind the C ABI that
+    writes one NumPy-format-1.0 float32 file per feature row, byte for byte what ``np.save(path, row)`` writes, creating the
+    directories and skipping files that exist (reference evaluate.py:312-316).  ``submit`` returns as soon as the rows are copied:
+    the files of batch i are written while the GPU encodes batch i + 1 (the reference's np.save loop costs 13 ms of Python per 256
+    frames against 1.8 ms of GPU time for their features)."""
+
+    def __init__(self, threads: int | None = None):
+        import ctypes as C
+        from . import _lib
+        self._C, self._lib = C, _lib
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self.lib.tn_npy_writer_create(int(threads or min(16, os.cpu_count() or 4)), C.byref(h)), "tn_npy_writer_create")
+        self.handle = h
+        self._written = self._skipped = 0
+
+    def submit(self, rows: np.ndarray, paths, skip_existing: bool = True):
+        C = self._C
+        rows = np.ascontiguousarray(rows, np.float32)
+        assert rows.ndim == 2 and rows.shape[0] == len(paths)
+        arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+        self._lib.check(self.lib.tn_npy_writer_submit(self.handle, rows.ctypes.data_as(C.c_void_p), rows.shape[0], rows.shape[1], arr,
+                                                      1 if skip_existing else 0), "tn_npy_writer_submit")
+
+    def drain(self):
+        """waits for everything submitted; -> (files written, files skipped) since the last drain"""
+        C = self._C
+        w, s = C.c_int64(), C.c_int64()
+        self._lib.check(self.lib.tn_npy_writer_drain(self.handle, C.byref(w), C.byref(s)), "tn_npy_writer_drain")
+        out = (w.value - self._written, s.value - self._skipped)
+        self._written, self._skipped = w.value, s.value
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.tn_npy_writer_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def save_features(net, loader, dataset, ctx=None, verbose=True):
     """Reference evaluate.py:306-321: feat = net.backbone(x); one float32 ``.npy`` per
-    frame at save_feature_path(idx), skipped when the file already exists."""
-    written = 0
-    for data, _labels, idxs in loader:
-        feat = net.backbone(data).cpu().numpy()
-        for i, idx in enumerate(int(j) for j in idxs):
-            feat_path = dataset.save_feature_path(idx)
-            if not os.path.exists(feat_path):
-                os.makedirs(os.path.dirname(feat_path), exist_ok=True)
-                np.save(feat_path, feat[i])
-                written += 1
-                if verbose:
-                    print("Saving %s" % feat_path)
+    frame at save_feature_path(idx), skipped when the file already exists.  The files are written by ``NpyWriter``'s threads
+    behind the next batch's encode (round 4); the count returned is the number of files that did not exist."""
+    writer = NpyWriter()
+    try:
+        for data, _labels, idxs in loader:
+            feat = net.backbone(data).cpu().numpy()
+            paths = [dataset.save_feature_path(int(j)) for j in idxs]
+            if verbose:
+                for feat_path in paths:
+                    if not os.path.exists(feat_path):
+                        print("Saving %s" % feat_path)
+            writer.submit(feat, paths)
+        written, _skipped = writer.drain()
+    finally:
+        writer.close()
     return written
 
 
@@ -86,28 +135,30 @@ def save_features_sharded(net, loader, dataset, device=None, rank=None, world=No
     if rank is None or world is None:
         rank, world = sharding._rank(group), sharding._world(group)
     fdim = _backbone_dim(net, loader)
-    written = [0]
+    writer = NpyWriter() if write else None
 
     def encode(s, e):
         data, _labels, idxs = loader.collate(range(s, e))
         feat = net.backbone(data)
         if write:
-            host = feat.detach().cpu().numpy()
-            for i, idx in enumerate(int(j) for j in idxs):
-                feat_path = dataset.save_feature_path(idx)
-                if not os.path.exists(feat_path):
-                    os.makedirs(os.path.dirname(feat_path), exist_ok=True)
-                    np.save(feat_path, host[i])
-                    written[0] += 1
-                    if verbose:
+            paths = [dataset.save_feature_path(int(j)) for j in idxs]
+            if verbose:
+                for feat_path in paths:
+                    if not os.path.exists(feat_path):
                         print("Saving %s" % feat_path)
+            writer.submit(feat.detach().cpu().numpy(), paths)
         return feat
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     comm = sharding.feature_comm(device, group) if world > 1 else None
-    full = sharding.extract_features_sharded(encode, len(dataset), loader.batch_size, fdim, device, rank=rank, world=world,
-                                             group=group, block=block, stats=stats, comm=comm)
-    return full, written[0]
+    try:
+        full = sharding.extract_features_sharded(encode, len(dataset), loader.batch_size, fdim, device, rank=rank, world=world,
+                                                 group=group, block=block, stats=stats, comm=comm)
+        written = writer.drain()[0] if writer is not None else 0
+    finally:
+        if writer is not None:
+            writer.close()
+    return full, written
 
 
 class SyntheticCorpus:

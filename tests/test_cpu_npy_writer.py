@@ -1,0 +1,66 @@
+"""The ``.npy`` writer of ``evaluate.py --save_feats`` (csrc/npy_host.hip, reference evaluate.py:306-321): pure host code behind
+the C ABI, checked against np.save byte for byte."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from tennis_amd import _lib
+from tennis_amd.evaluate import NpyWriter
+
+
+def test_files_are_np_save_bytes_and_existing_files_are_kept(tmp_path):
+    rng = np.random.default_rng(5)
+    w = NpyWriter(threads=4)
+    for dim in (1, 7, 1024, 100003):            # header padding changes with the number of digits of the shape
+        rows = rng.standard_normal((5, dim)).astype(np.float32)
+        paths = [str(tmp_path / f"d{dim}" / f"v{i % 2}" / f"{i:05d}.npy") for i in range(5)]      # directories are created
+        w.submit(rows, paths)
+        assert w.drain() == (5, 0)
+        for i, p in enumerate(paths):
+            ref = tmp_path / "ref.npy"
+            np.save(ref, rows[i])
+            assert open(p, "rb").read() == open(ref, "rb").read()
+            np.testing.assert_array_equal(np.load(p), rows[i])
+    # evaluate.py:312: a file that exists is not rewritten
+    rows2 = rng.standard_normal((5, 100003)).astype(np.float32)
+    more = paths[:3] + [str(tmp_path / "new" / "a.npy"), str(tmp_path / "new" / "b.npy")]
+    w.submit(rows2, more)
+    assert w.drain() == (2, 3)
+    np.testing.assert_array_equal(np.load(paths[0]), rows[0])
+    np.testing.assert_array_equal(np.load(more[3]), rows2[3])
+    # skip_existing=False overwrites
+    w.submit(rows2[:1], paths[:1], skip_existing=False)
+    assert w.drain() == (1, 0)
+    np.testing.assert_array_equal(np.load(paths[0]), rows2[0])
+    w.close()
+
+
+def test_many_batches_in_flight(tmp_path):
+    rng = np.random.default_rng(6)
+    w = NpyWriter(threads=8)
+    feats = rng.standard_normal((40, 64, 1024)).astype(np.float32)
+    for b in range(40):                           # more jobs than the queue bound: submit blocks instead of piling up
+        w.submit(feats[b], [str(tmp_path / f"{b:03d}" / f"{i:03d}.npy") for i in range(64)])
+    assert w.drain() == (40 * 64, 0)
+    for b in (0, 17, 39):
+        for i in (0, 63):
+            np.testing.assert_array_equal(np.load(tmp_path / f"{b:03d}" / f"{i:03d}.npy"), feats[b, i])
+    w.close()
+
+
+def test_errors_surface_at_drain(tmp_path):
+    blocker = tmp_path / "file"
+    blocker.write_bytes(b"x")
+    w = NpyWriter(threads=2)
+    w.submit(np.zeros((1, 4), np.float32), [str(blocker / "sub" / "a.npy")])     # a directory below a regular file
+    with pytest.raises(RuntimeError, match="cannot create the directory"):
+        w.drain()
+    w.submit(np.ones((1, 4), np.float32), [str(tmp_path / "ok.npy")])            # the writer stays usable
+    assert w.drain() == (1, 0)
+    lib = _lib.load()
+    assert lib.tn_npy_writer_submit(w.handle, None, 1, 4, None, 1) != 0
+    h = C.c_void_p()
+    assert lib.tn_npy_writer_create(0, C.byref(h)) != 0
+    w.close()
