@@ -1,7 +1,7 @@
 """Tuning: phase durations of the beam-search step kernels (alt build with -DTN_DEC_STAMPS)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-os.environ["TENNIS_HIP_LIB"] = os.path.abspath("tennis_amd/lib/alt/libtennis_stamps.so")   # hipcc -DTN_DEC_STAMPS build of captioner.hip linked with the other objects
+os.environ["TENNIS_HIP_LIB"] = os.path.abspath("scripts/scratch/libs/stamps.so")   # hipcc -DTN_DEC_STAMPS build of captioner.hip linked with the other objects
 import numpy as np, torch
 from tennis_amd import weights as W, _lib
 from tennis_amd.engine import GNMTCaptioner
@@ -21,8 +21,8 @@ lib.tn_dbg_dec_stamps.restype = C.c_int
 lib.tn_dbg_dec_stamps(out)
 st = np.array(list(out), dtype=np.int64)
 names_a = ["gates0", "scores", "softmax", "context+write"]
-names_b = ["gates1", "proj", "lse", "cand", "topk", "bookkeeping", "samples", "prep"]
+names_b = [("gates1", 8, 9), ("proj", 9, 10), ("rows: logits+lse+cand+row top-k", 10, 12), ("merge top-k", 12, 13), ("bookkeeping", 13, 14), ("next inputs", 14, 16)]
 print("valid_len[0] =", int(vl[0]))
 print("attention (us):", {n: (st[i + 1] - st[i]) / 100.0 for i, n in enumerate(names_a)}, "total", (st[4] - st[0]) / 100.0)
-print("beam (us):", {n: (st[9 + i] - st[8 + i]) / 100.0 for i, n in enumerate(names_b)}, "total", (st[16] - st[8]) / 100.0)
+print("beam (us):", {n: (st[b] - st[a]) / 100.0 for n, a, b in names_b}, "total", (st[16] - st[8]) / 100.0)
 print("attention end -> beam start (lin1 + gaps):", (st[8] - st[4]) / 100.0)

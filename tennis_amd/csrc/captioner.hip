@@ -60,7 +60,12 @@ __global__ __launch_bounds__(kBeamThreads) void dec_attention_kernel(
     const float *__restrict__ g0, const float *__restrict__ hprev, int ldh, const float *__restrict__ cprev, int lstm,
     float *__restrict__ hn, float *__restrict__ cn, float *__restrict__ x1, int ldx1,
     const float *__restrict__ kpT, const float *__restrict__ mem, const int32_t *__restrict__ valid_len,
-    float *__restrict__ ctx, int beam, int rows, int T, int H, float *__restrict__ wsave = nullptr) {
+    float *__restrict__ ctx, int beam, int rows, int T, int H, float *__restrict__ wsave = nullptr,
+    const int32_t *__restrict__ tok = nullptr, const int32_t *__restrict__ par = nullptr, const float *__restrict__ ew = nullptr,
+    const float *__restrict__ p0 = nullptr) {
+  // ew != NULL (beam search, two decoder layers, from the second step on): the row's pre-activations are put together here,
+  // g = ew[tok[row]] + p0[parent row] (dec_beam_kernel), and h_prev / c_prev are the PARENT row's (hprev / cprev then hold
+  // the previous step's new states, one row per beam, pitch ldh / H)
   constexpr int NP = (NBM + 3) & ~3;
   extern __shared__ float sm[];   // q[H][NP] | w[T][NP] | part[4][rows][max(T,H)]
   float *q = sm, *w = q + H * NP, *part = w + T * NP;
@@ -74,16 +79,25 @@ __global__ __launch_bounds__(kBeamThreads) void dec_attention_kernel(
     float v = 0.f;
     if (k < rows) {
       const long r = (long)r0 + k;
-      const float *g = g0 + r * 4 * H;
+      const long rp = ew ? (long)b * beam + par[r] : r;
+      float ga, gb, gc, gd;
+      if (ew) {
+        const int word = tok[r];
+        const float *e = ew + (long)(word > 0 ? word : 0) * 4 * H, *q0 = p0 + rp * 4 * H;
+        ga = e[u] + q0[u]; gb = e[H + u] + q0[H + u]; gc = e[2 * H + u] + q0[2 * H + u]; gd = e[3 * H + u] + q0[3 * H + u];
+      } else {
+        const float *g = g0 + r * 4 * H;
+        ga = g[u]; gb = g[H + u]; gc = g[2 * H + u]; gd = g[3 * H + u];
+      }
       if (lstm) {
-        const float ig = sigm(g[u]), fg = sigm(g[H + u]), gg = tanhf(g[2 * H + u]), og = sigm(g[3 * H + u]);
-        const float c2 = fg * cprev[r * H + u] + ig * gg;
+        const float ig = sigm(ga), fg = sigm(gb), gg = tanhf(gc), og = sigm(gd);
+        const float c2 = fg * cprev[rp * H + u] + ig * gg;
         cn[r * H + u] = c2;
         v = og * tanhf(c2);
       } else {
-        const float rg = sigm(g[u]), zg = sigm(g[H + u]);
-        const float ng = tanhf(g[2 * H + u] + rg * g[3 * H + u]);
-        v = (1.f - zg) * ng + zg * hprev[r * ldh + u];
+        const float rg = sigm(ga), zg = sigm(gb);
+        const float ng = tanhf(gc + rg * gd);
+        v = (1.f - zg) * ng + zg * hprev[rp * ldh + u];
       }
       hn[r * H + u] = v;
       x1[r * ldx1 + u] = v;
@@ -202,32 +216,131 @@ __global__ void transpose_bth_kernel(const float *__restrict__ src, float *__res
     if (h0 + i < H && t0 + tx < T) dst[((long)b * H + h0 + i) * T + t0 + tx] = tile[tx][i];
 }
 
-// Beam-search step, launch 4 of 4, one workgroup per source clip:
-//   second decoder cell's gates on g1 (R,4H) (column layout as in dec_attention_kernel; h_prev / c_prev are
-//   the clip's rows of x1[:, 2H:3H] / c1cur) -> projection to the vocabulary (Wp^T streamed once for all
-//   beams, 4 partial sums over K) -> log_softmax -> length-penalised candidates -> top-`beam` over
-//   [beam*V | finished] -> bookkeeping -> the NEXT step's inputs, re-gathered by parent beam:
-//   x0 = [embed(word), ctx[parent], h0[parent]], x1[:, 2H:3H] = h1[parent], c0cur / c1cur (LSTM).
+// Wave-wide best of per-lane (value, index) pairs - value descending, then index ascending - in two DPP reductions of one
+// instruction per stage (row shifts + row broadcasts, result in lane 63): the maximum value, then the minimum index among the
+// lanes that hold it.  A lane without a candidate passes (-inf, 0xffffffff).
+__device__ __forceinline__ void wave_best(float v, unsigned ix, float &wv, unsigned &wi) {
+  float m = v;
+#define TN_DPP_F(ctrl, rmask) m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), ctrl, rmask, 0xf, false)));
+  TN_DPP_F(0x111, 0xf) TN_DPP_F(0x112, 0xf) TN_DPP_F(0x114, 0xf) TN_DPP_F(0x118, 0xf)   // row_shr:1,2,4,8 -> lane 15 of a row
+  TN_DPP_F(0x142, 0xa) TN_DPP_F(0x143, 0xc)                                             // row_bcast:15 / :31 -> lane 63
+#undef TN_DPP_F
+  wv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
+  unsigned c = v == wv ? ix : 0xffffffffu;
+#define TN_DPP_U(ctrl, rmask) c = min(c, (unsigned)__builtin_amdgcn_update_dpp((int)c, (int)c, ctrl, rmask, 0xf, false));
+  TN_DPP_U(0x111, 0xf) TN_DPP_U(0x112, 0xf) TN_DPP_U(0x114, 0xf) TN_DPP_U(0x118, 0xf)
+  TN_DPP_U(0x142, 0xa) TN_DPP_U(0x143, 0xc)
+#undef TN_DPP_U
+  wi = (unsigned)__builtin_amdgcn_readlane((int)c, 63);
+}
+
+// The `count` largest of arr[0..n) (LDS), descending, ties -> lowest index, where element p has index idx[p] (idx != NULL) or
+// base + p: one wave, no block barrier.  A lane owns the elements p = lane mod 64 and keeps the best of them; a round is
+// wave_best plus, in the winning lane only, dropping the element and looking at its own elements again.  REG: n <= 256, the
+// lane's four elements live in registers (nothing is re-read); otherwise the dropped element becomes -inf in LDS and the lane
+// rescans its stride.  out_val / out_idx (LDS) receive the winners.
+template <bool REG>
+__device__ __forceinline__ void wave_topk_impl(float *arr, const int *idx, int base, int n, int count, float *out_val, int *out_idx, int lane) {
+  float x[4];
+  unsigned xi[4];
+  if constexpr (REG) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = lane + 64 * i;
+      x[i] = p < n ? arr[p] : -INFINITY;
+      xi[i] = p < n ? (unsigned)(idx ? idx[p] : base + p) : 0xffffffffu;
+    }
+  }
+  float bv;
+  unsigned bix;
+  int bpos;
+  auto scan = [&]() {
+    bv = -INFINITY; bix = 0xffffffffu; bpos = -1;
+    if constexpr (REG) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (x[i] > bv || (x[i] == bv && xi[i] < bix)) { bv = x[i]; bix = xi[i]; bpos = i; }
+    } else {
+      for (int p = lane; p < n; p += 64) {
+        const float v = arr[p];
+        const unsigned ix = (unsigned)(idx ? idx[p] : base + p);
+        if (v > bv || (v == bv && ix < bix)) { bv = v; bix = ix; bpos = p; }
+      }
+    }
+  };
+  scan();
+  for (int k = 0; k < count; ++k) {
+    float wv;
+    unsigned wi;
+    wave_best(bv, bix, wv, wi);
+    if (bpos >= 0 && bix == wi && bv == wv) {       // this lane owned the winner: record, drop it, look again
+      out_idx[k] = (int)wi;
+      out_val[k] = wv;
+      if constexpr (REG) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i == bpos) { x[i] = -INFINITY; xi[i] = 0xffffffffu; }
+      } else {
+        arr[bpos] = -INFINITY;
+      }
+      scan();
+    }
+  }
+}
+__device__ __forceinline__ void wave_topk(float *arr, const int *idx, int base, int n, int count, float *out_val, int *out_idx, int lane) {
+  if (n <= 256) wave_topk_impl<true>(arr, idx, base, n, count, out_val, out_idx, lane);
+  else wave_topk_impl<false>(arr, idx, base, n, count, out_val, out_idx, lane);
+}
+
+// Beam-search step, last launch, one workgroup per source clip:
+//   last decoder cell's gates on g1 (R rows of ldg floats, the first 4H of a row; column layout as in dec_attention_kernel;
+//   h_prev / c_prev are the clip's rows of x1[:, 2H:3H] / c1cur) -> projection to the vocabulary (Wp^T streamed once for all
+//   beams, 4 partial sums over K) -> per beam row, inside one wave: logits, log-sum-exp, length-penalised candidates and the
+//   row's `beam` best -> top-`beam` over [the rows' bests | finished] (the same order as a top-`beam` over [beam*V | finished]:
+//   value descending, ties to the lowest index) -> bookkeeping, the step's (parent, word) back-pointers (the token prefixes are
+//   rebuilt once at the end, beam_samples_kernel) -> the NEXT step's inputs, re-gathered by parent beam.  Two forms:
+//     tok_out == NULL: x0 = [embed(word), ctx[parent], h0[parent]], c0cur; the first cell's gate GEMM is the next step's first launch;
+//     tok_out != NULL (two decoder layers): the first cell's pre-activations are linear in x0 and the next step's attention
+//       kernel puts them together itself, g0 = ew[word] + p0[parent] with ew = embed . W0[:, 0:E]^T (V,4H; once per model) and
+//       p0 = [h0, ctx] . W0[:, E:]^T + b0.  p0 only needs what the attention kernel left in x1, so it is computed by EXTRA
+//       workgroups of this launch (blockIdx >= nclips, four 16 x 16 tiles each, lat_tile_f32) on the CUs the clips do not use:
+//       3 launches per step, and the gate GEMM on the critical path stays the last cell's.  This kernel then only hands on
+//       the words and the parents.
+//   Always: x1[:, 2H:3H] = h1[parent], c1cur (LSTM).
+struct LatGemmArgs {
+  const float *X, *W, *bias;
+  float *Y;
+  int ldx, ldw, ldy, M, N, K;
+};
 template <int NBM>
 __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
-    const float *__restrict__ g1, float *__restrict__ x1, int lstm, float *__restrict__ c1cur,
+    const float *__restrict__ g1, int ldg, float *__restrict__ x1, int lstm, float *__restrict__ c1cur,
     const float *__restrict__ wpT, const float *__restrict__ bp, const float *__restrict__ h0n,
     const float *__restrict__ ctx, const float *__restrict__ c0n, float *__restrict__ x0, float *__restrict__ c0cur,
-    const float *__restrict__ emb, int H, int E, int V, int beam, int step, float alpha, float Kp, int eos,
+    const float *__restrict__ emb, int H, int E, int V, int beam, int step, float lp, float prev_lp, int eos,
     float *__restrict__ scores, int32_t *__restrict__ alive, int32_t *__restrict__ vlen,
-    const int32_t *__restrict__ samples_in, int32_t *__restrict__ samples_out, int L, int32_t *__restrict__ any_alive,
-    float *__restrict__ hstate = nullptr, int32_t *__restrict__ parent_out = nullptr) {
+    int32_t *__restrict__ bp_par, int32_t *__restrict__ bp_word, int R, int32_t *__restrict__ any_alive,
+    float *__restrict__ hstate, int32_t *__restrict__ parent_out, int32_t *__restrict__ tok_out, int nclips, LatGemmArgs gm) {
   // hstate != NULL: use_residual (gnmt.py:394-395) - the projection sees h + the cell's input x1[:, 0:H], the recurrent
   // state stays h and goes through this (R,H) scratch; parent_out: the chosen parent beam of every row, for the states of
   // the decoder layers between the first and the last one (num_layers > 2)
-  extern __shared__ float sm[];   // h1n[H][NP] | c1n[H][NP] | logits[beam*V] | part[4*beam*V] (cand aliases part) | lse[16]
-  const int b = blockIdx.x, t = threadIdx.x, NC = beam * V + beam, K0 = E + 2 * H, K1 = 3 * H;
+  extern __shared__ float sm[];   // h1n[H][NP] | c1n[H][NP] | logits[beam*V] (the candidates in place) | part[4*beam*V]
+  const int b = blockIdx.x, t = threadIdx.x, K0 = E + 2 * H, K1 = 3 * H;
   constexpr int NP = (NBM + 3) & ~3;   // LDS pitch of one k: NBM beam rows padded to 16-byte multiples
-  float *h1n = sm, *c1n = h1n + NP * H, *logits = c1n + NP * H, *part = logits + beam * V, *cand = part;
-  float *lse = part + 4 * beam * V;
-  __shared__ float sel_val[16], o_score[16], lps[2];
-  __shared__ int sel_idx[16], sel_par[16], sel_word[16], o_alive[16], o_vlen[16];
+  float *h1n = sm, *c1n = h1n + NP * H, *logits = c1n + NP * H, *part = logits + beam * V;
+  __shared__ float sel_val[16], o_score[16], m_val[16 * 16 + 16];
+  __shared__ int sel_idx[16], sel_par[16], sel_word[16], o_alive[16], o_vlen[16], m_idx[16 * 16 + 16];
   const int lane = t & 63, wid = t >> 6;
+  if (b >= nclips) {      // p0 tiles for the next step (see above); no output that this launch's clips read
+    const int tile = (b - nclips) * 4 + (wid >> 2), ntn = gm.N / 16;
+    lat_tile_f32(gm.X, gm.ldx, gm.W, gm.ldw, gm.bias, gm.Y, gm.ldy, gm.M, gm.N, gm.K, (tile / ntn) * 16, (tile % ntn) * 16, wid & 3, lane,
+                 (float (*)[64][4])(sm + (wid >> 2) * (4 * 64 * 4)));
+    return;
+  }
+  // the old state of the beam row this wave will own (loaded now, used after the projection)
+  const int rowk = wid < beam ? wid : 0;
+  const int al = alive[b * beam + rowk], ovl = vlen[b * beam + rowk];
+  const float osc = scores[b * beam + rowk];
   DEC_STAMP(8);
   // ---- cell 1 ----
   for (int idx = t; idx < NBM * H; idx += kBeamThreads) {
@@ -235,7 +348,7 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
     float v = 0.f, c2 = 0.f;
     if (k < beam) {
       const long r = (long)b * beam + k;
-      const float *g = g1 + r * 4 * H;
+      const float *g = g1 + r * ldg;
       if (lstm) {
         const float ig = sigm(g[u]), fg = sigm(g[H + u]), gg = tanhf(g[2 * H + u]), og = sigm(g[3 * H + u]);
         c2 = fg * c1cur[r * H + u] + ig * gg;
@@ -283,101 +396,38 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
     }
   }
   __syncthreads();
-  for (int c = t; c < beam * V; c += kBeamThreads) {
-    const int v = c % V;
-    logits[c] = bp[v] + ((part[c] + part[beam * V + c]) + (part[2 * beam * V + c] + part[3 * beam * V + c]));
-  }
-  __syncthreads();
   DEC_STAMP(10);
-  // ---- log-sum-exp: wave k owns beam row k; the old beam state moves to LDS meanwhile ----
+  // ---- wave k owns beam row k: logits, log-sum-exp, candidates (in place of the logits) and the row's `beam` best ----
   if (wid < beam) {
-    const float *z = logits + wid * V;
+    const int k = wid;
+    float *z = logits + k * V;
     float mx = -INFINITY;
-    for (int v = lane; v < V; v += 64) mx = fmaxf(mx, z[v]);
+    for (int v = lane; v < V; v += 64) {
+      const int c = k * V + v;
+      const float x = bp[v] + ((part[c] + part[beam * V + c]) + (part[2 * beam * V + c] + part[3 * beam * V + c]));
+      z[v] = x;
+      mx = fmaxf(mx, x);
+    }
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     float sum = 0.f;
     for (int v = lane; v < V; v += 64) sum += expf(z[v] - mx);
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    if (lane == 0) lse[wid] = mx + logf(sum);
-  } else if (wid == 15) {
-    if (lane < beam) { o_alive[lane] = alive[b * beam + lane]; o_vlen[lane] = vlen[b * beam + lane]; o_score[lane] = scores[b * beam + lane]; }
+    const float lse = mx + logf(sum);
+    for (int v = lane; v < V; v += 64) {
+      const float logp = z[v] - lse;
+      z[v] = al ? (osc * prev_lp + logp) / lp : kNeg;
+    }
+    wave_topk(z, nullptr, k * V, V, beam, m_val + k * beam, m_idx + k * beam, lane);
     if (lane == 0) {
-      lps[0] = powf(Kp + (float)step, alpha) / powf(Kp + 1.f, alpha);
-      lps[1] = step == 1 ? 1.f : powf(Kp + (float)(step - 1), alpha) / powf(Kp + 1.f, alpha);
+      o_alive[k] = al; o_vlen[k] = ovl; o_score[k] = osc;
+      m_val[beam * beam + k] = al ? kNeg : osc;           // a finished beam competes with its own score
+      m_idx[beam * beam + k] = beam * V + k;
     }
-  }
-  __syncthreads();
-  DEC_STAMP(11);
-  // ---- candidates (part is dead: cand aliases it) ----
-  const float lp = lps[0], prev_lp = lps[1];
-  for (int c = t; c < NC; c += kBeamThreads) {
-    float v;
-    if (c < beam * V) {
-      const int k = c / V;
-      const float logp = logits[c] - lse[k];
-      v = o_alive[k] ? (o_score[k] * prev_lp + logp) / lp : kNeg;
-    } else {
-      const int k = c - beam * V;
-      v = o_alive[k] ? kNeg : o_score[k];
-    }
-    cand[c] = v;
   }
   __syncthreads();
   DEC_STAMP(12);
-  // ---- top-`beam`, descending, ties -> lowest index: one wave, no block barriers.  A lane keeps the best of its
-  // strided candidates as a 64-bit key (order-preserving float bits | inverted index) and rescans only when it
-  // loses that best; the wave maximum is a DPP reduction (row shifts + row broadcasts), result in lane 63 ----
-  if (wid == 0) {
-    auto lane_best = [&](unsigned &hi, unsigned &lo) {
-      float bv = -INFINITY;
-      int bi = 0x7fffffff;
-      int c = lane;
-      for (; c + 7 * 64 < NC; c += 8 * 64) {          // LDS reads batched by hand, as the global ones above
-        float x[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) x[i] = cand[c + i * 64];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          if (x[i] > bv) { bv = x[i]; bi = c + i * 64; }   // ascending index: ties keep the lowest
-      }
-      for (; c < NC; c += 64) {
-        const float x = cand[c];
-        if (x > bv) { bv = x; bi = c; }
-      }
-      const unsigned u = __float_as_uint(bv);
-      hi = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-      lo = 0xffffffffu - (unsigned)bi;
-      if (bi == 0x7fffffff) { hi = 0u; lo = 0u; }          // no candidate left in this lane
-    };
-    unsigned hi, lo;
-    lane_best(hi, lo);
-    for (int k = 0; k < beam; ++k) {
-      unsigned h = hi, l = lo;
-#define TN_DPP_MAX(ctrl, rmask)                                                                       \
-  {                                                                                                   \
-    const unsigned l2 = (unsigned)__builtin_amdgcn_update_dpp((int)l, (int)l, ctrl, rmask, 0xf, false); \
-    const unsigned h2 = (unsigned)__builtin_amdgcn_update_dpp((int)h, (int)h, ctrl, rmask, 0xf, false); \
-    const bool gt = h2 > h || (h2 == h && l2 > l);                                                     \
-    l = gt ? l2 : l;                                                                                  \
-    h = gt ? h2 : h;                                                                                  \
-  }
-      TN_DPP_MAX(0x111, 0xf)   // row_shr:1
-      TN_DPP_MAX(0x112, 0xf)   // row_shr:2
-      TN_DPP_MAX(0x114, 0xf)   // row_shr:4
-      TN_DPP_MAX(0x118, 0xf)   // row_shr:8   -> lane 15 of every row holds the row maximum
-      TN_DPP_MAX(0x142, 0xa)   // row_bcast:15 into rows 1, 3
-      TN_DPP_MAX(0x143, 0xc)   // row_bcast:31 into rows 2, 3 -> lane 63 holds the wave maximum
-#undef TN_DPP_MAX
-      const unsigned wl = (unsigned)__builtin_amdgcn_readlane((int)l, 63);
-      const int i = (int)(0xffffffffu - wl);
-      if (lo == wl && (hi | lo) != 0u) {            // this lane owned the winner: record, drop it, rescan its stride
-        sel_idx[k] = i;
-        sel_val[k] = cand[i];
-        cand[i] = -INFINITY;
-        lane_best(hi, lo);
-      }
-    }
-  }
+  // ---- top-`beam` of the clip: the rows' bests and the finished beams ----
+  if (wid == 0) wave_topk(m_val, m_idx, 0, beam * beam + beam, beam, sel_val, sel_idx, lane);
   __syncthreads();
   DEC_STAMP(13);
   // ---- bookkeeping ----
@@ -393,28 +443,26 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
     sel_par[t] = bid;
     sel_word[t] = word;
     if (parent_out) parent_out[b * beam + t] = bid;
+    bp_par[(long)(step - 1) * R + b * beam + t] = bid;
+    bp_word[(long)(step - 1) * R + b * beam + t] = word;
     if (al) atomicOr(any_alive, 1);
   }
   __syncthreads();
   DEC_STAMP(14);
-  // ---- samples: copy the chosen parent's prefix (step entries: BOS + step-1 words), append the word ----
-  for (int k = 0; k < beam; ++k) {
-    const int32_t *src = samples_in + ((long)b * beam + sel_par[k]) * L;
-    int32_t *dst = samples_out + ((long)b * beam + k) * L;
-    for (int i = t; i < step; i += kBeamThreads) dst[i] = src[i];
-    if (t == 0) dst[step] = sel_word[k];
-  }
-  DEC_STAMP(15);
   // ---- next step's inputs, states re-gathered by parent beam ----
-  for (int idx = t; idx < beam * K0; idx += kBeamThreads) {
-    const int k = idx / K0, i = idx - k * K0;
-    const long r = (long)b * beam + k, pr = (long)b * beam + sel_par[k];
-    const int word = sel_word[k];
-    float v;
-    if (i < E) v = emb[(long)(word > 0 ? word : 0) * E + i];
-    else if (i < E + H) v = ctx[pr * H + i - E];
-    else v = h0n[pr * H + i - E - H];
-    x0[r * K0 + i] = v;
+  if (tok_out) {
+    if (t < beam) tok_out[b * beam + t] = sel_word[t];
+  } else {
+    for (int idx = t; idx < beam * K0; idx += kBeamThreads) {
+      const int k = idx / K0, i = idx - k * K0;
+      const long r = (long)b * beam + k, pr = (long)b * beam + sel_par[k];
+      const int word = sel_word[k];
+      float v;
+      if (i < E) v = emb[(long)(word > 0 ? word : 0) * E + i];
+      else if (i < E + H) v = ctx[pr * H + i - E];
+      else v = h0n[pr * H + i - E - H];
+      x0[r * K0 + i] = v;
+    }
   }
   for (int idx = t; idx < beam * H; idx += kBeamThreads) {
     const int k = idx / H, u = idx - k * H;
@@ -422,7 +470,7 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
     x1[r * K1 + 2 * H + u] = hstate ? hstate[pr * H + u] : h1n[u * NP + sel_par[k]];
     if (lstm) {
       c1cur[r * H + u] = c1n[u * NP + sel_par[k]];
-      c0cur[r * H + u] = c0n[pr * H + u];
+      if (!tok_out) c0cur[r * H + u] = c0n[pr * H + u];
     }
   }
   DEC_STAMP(16);
@@ -537,6 +585,35 @@ __global__ void beam_init_kernel(float *scores, int32_t *alive, int32_t *vlen, i
   vlen[id] = 1;
   tok[id] = bos;
   samples[(long)id * L] = bos;
+}
+
+// The token prefixes of the final beams from the steps' (parent, word) back-pointers: sample[row][s] for s = steps .. 1 is the
+// word chosen at step s by the row's ancestor of that step (-1 where a finished beam was carried over), sample[row][0] = bos -
+// what copying the parent's prefix and appending the word at every step (BeamSearchSampler [EXT]) leaves behind.  One
+// workgroup per clip; the clip's pointers pass through LDS in chunks of kSampChunk steps, newest first.
+constexpr int kSampChunk = 256;
+__global__ __launch_bounds__(256) void beam_samples_kernel(const int32_t *__restrict__ bp_par, const int32_t *__restrict__ bp_word,
+                                                           int32_t *__restrict__ samples, int L, int steps, int R, int beam, int bos) {
+  __shared__ int32_t par[kSampChunk * 16], word[kSampChunk * 16];
+  const int b = blockIdx.x, t = threadIdx.x;
+  int cur = t;
+  int32_t *dst = samples + ((long)b * beam + (t < beam ? t : 0)) * L;
+  for (int hi = steps; hi > 0; hi -= kSampChunk) {
+    const int lo = hi > kSampChunk ? hi - kSampChunk : 0, n = hi - lo;
+    __syncthreads();
+    for (int i = t; i < n * beam; i += 256) {
+      const int s = i / beam, k = i - s * beam;
+      par[i] = bp_par[(long)(lo + s) * R + b * beam + k];
+      word[i] = bp_word[(long)(lo + s) * R + b * beam + k];
+    }
+    __syncthreads();
+    if (t < beam)
+      for (int s = n - 1; s >= 0; --s) {
+        dst[lo + s + 1] = word[s * beam + cur];
+        cur = par[s * beam + cur];
+      }
+  }
+  if (t < beam) dst[0] = bos;
 }
 
 __global__ void beam_finalize_kernel(const int32_t *alive, int32_t *vlen, int32_t *samples, int L, int last, int R,
@@ -854,6 +931,14 @@ struct tn_gnmt {
   // fused beam-search step: stacked [i2h | h2h] weights (4H rows each), transposed projection, step buffers
   float *w0c, *b0c, *w1c, *b1c, *wpT;
   float *sx0, *sx1, *g0, *g1, *h0n, *ctxn, *c0n, *c0cur, *c1cur, *keyprojT, *h1n, *c1n;
+  // two decoder layers: the first cell's gate GEMM leaves the step's critical path (dec_beam_kernel, `tok_out`):
+  // w1x (4H, 3H) = the first cell's columns of h0 and ctx in the order of x1 = [h0, ctx, h1_prev] (the last H columns unused),
+  // b1x = b0, ew (V, 4H) = embedding . first cell's embedding columns (made on the first search), p0 (R, 4H) the [h0, ctx]
+  // share of the next step's pre-activations, h0n2 / c0n2 the second buffers of the first cell's states (a step reads the
+  // previous step's by parent row while it writes its own)
+  float *w1x, *b1x, *ew, *p0, *h0n2, *c0n2;
+  bool ew_ready;
+  int32_t *bp_par, *bp_word;   // (maxL, R) back-pointers of the search
   int B, T;
 };
 
@@ -931,6 +1016,7 @@ extern "C" int tn_gnmt_create_ex(tn_ctx *ctx, const tn_param *params, int n_para
     // one GEMM per decoder cell: rows of the stacked matrix = 4H gate columns over [cell input | h_prev].
     // LSTM: [Wi | Wh], bias bi + bh.  GRU: r and z likewise; the candidate keeps its two branches apart
     // (n = tanh(n_i2h + r * n_h2h)): rows 2H..3H = [Wi_n | 0], rows 3H..4H = [0 | Wh_n].
+    std::vector<float> last_w, last_b;      // host copies of the matrix stack() made last
     auto stack = [&](const std::string &cell, int in_dim, float **w_out, float **b_out) -> bool {
       const float *wi = get(pre + cell + "i2h_weight", (int64_t)G3 * in_dim), *wh = get(pre + cell + "h2h_weight", (int64_t)G3 * H);
       const float *bi = get(pre + cell + "i2h_bias", G3), *bh = get(pre + cell + "h2h_bias", G3);
@@ -953,10 +1039,26 @@ extern "C" int tn_gnmt_create_ex(tn_ctx *ctx, const tn_param *params, int n_para
       }
       *w_out = g->pool.upload(w.data(), w.size());
       *b_out = g->pool.upload(bv.data(), bv.size());
+      last_w.swap(w); last_b.swap(bv);
       return true;
     };
-    if (!stack("dec_rnn0_", embed + H, &g->w0c, &g->b0c) ||
-        !stack("dec_rnn" + std::to_string(num_layers - 1) + "_", 2 * H, &g->w1c, &g->b1c)) return fail(TN_ERR_MISSING);
+    if (!stack("dec_rnn0_", embed + H, &g->w0c, &g->b0c)) return fail(TN_ERR_MISSING);
+    std::vector<float> w0, b0;
+    w0.swap(last_w); b0.swap(last_b);
+    if (!stack("dec_rnn" + std::to_string(num_layers - 1) + "_", 2 * H, &g->w1c, &g->b1c)) return fail(TN_ERR_MISSING);
+    if (num_layers == 2) {
+      const int K0 = embed + 2 * H, K1 = 3 * H;
+      std::vector<float> wx((size_t)4 * H * K1, 0.f);
+      for (int row = 0; row < 4 * H; ++row) {
+        float *d = &wx[(size_t)row * K1];
+        const float *sw = &w0[(size_t)row * K0];
+        memcpy(d, sw + embed + H, sizeof(float) * H);        // x1[:, 0:H] = h0   <- x0[:, E+H:]
+        memcpy(d + H, sw + embed, sizeof(float) * H);        // x1[:, H:2H] = ctx <- x0[:, E:E+H]
+      }
+      g->w1x = g->pool.upload(wx.data(), wx.size());
+      g->b1x = g->pool.upload(b0.data(), b0.size());
+      g->ew = g->pool.alloc<float>((size_t)vocab * 4 * H);
+    }
     g->mid.resize(num_layers - 2);
     for (int i = 1; i + 1 < num_layers; ++i)
       if (!stack("dec_rnn" + std::to_string(i) + "_", 2 * H, &g->mid[i - 1].w, &g->mid[i - 1].b)) return fail(TN_ERR_MISSING);
@@ -978,14 +1080,18 @@ extern "C" int tn_gnmt_create_ex(tn_ctx *ctx, const tn_param *params, int n_para
     m.hn = g->pool.alloc<float>(R * H); m.cn = g->pool.alloc<float>(R * H); m.ccur = g->pool.alloc<float>(R * H);
   }
   g->hstate = g->residual ? g->pool.alloc<float>(R * H) : nullptr;
-  g->parent = g->mid.empty() ? nullptr : g->pool.alloc<int32_t>(R);
+  g->parent = g->pool.alloc<int32_t>(R);
   g->vl = g->pool.alloc<int32_t>(max_batch);
-  for (int i = 0; i < 2; ++i) g->samples[i] = g->pool.alloc<int32_t>(R * g->maxL);
+  g->samples[0] = g->pool.alloc<int32_t>(R * g->maxL);
+  g->bp_par = g->pool.alloc<int32_t>(R * g->maxL); g->bp_word = g->pool.alloc<int32_t>(R * g->maxL);
   g->scores = g->pool.alloc<float>(R); g->alive = g->pool.alloc<int32_t>(R); g->vlen = g->pool.alloc<int32_t>(R);
   g->tok = g->pool.alloc<int32_t>(R); g->flag = g->pool.alloc<int32_t>(1);
   g->h1n = g->pool.alloc<float>(R * H); g->c1n = g->pool.alloc<float>(R * H);
   g->sx0 = g->pool.alloc<float>(R * (embed + 2 * H)); g->sx1 = g->pool.alloc<float>(R * 3 * H);
   g->g0 = g->pool.alloc<float>(R * 4 * H); g->g1 = g->pool.alloc<float>(R * 4 * H);
+  if (num_layers == 2) {
+    g->p0 = g->pool.alloc<float>(R * 4 * H); g->h0n2 = g->pool.alloc<float>(R * H); g->c0n2 = g->pool.alloc<float>(R * H);
+  }
   g->h0n = g->pool.alloc<float>(R * H); g->ctxn = g->pool.alloc<float>(R * H); g->c0n = g->pool.alloc<float>(R * H);
   g->c0cur = g->pool.alloc<float>(R * H); g->c1cur = g->pool.alloc<float>(R * H); g->keyprojT = g->pool.alloc<float>(BT * H);
   if (g->pool.failed) { tn_set_error("device allocation failed"); return fail(TN_ERR_NOMEM); }
@@ -1049,7 +1155,6 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
   if (int rc = nbm == 4 ? allow_lds(dec_beam_kernel<4>, beam_lds) : nbm == 5 ? allow_lds(dec_beam_kernel<5>, beam_lds)
                : nbm == 8 ? allow_lds(dec_beam_kernel<8>, beam_lds) : allow_lds(dec_beam_kernel<16>, beam_lds)) return rc;
   TN_HIP_CHECK(hipMemsetAsync(g->samples[0], 0xff, sizeof(int32_t) * (size_t)R * L, s));
-  TN_HIP_CHECK(hipMemsetAsync(g->samples[1], 0xff, sizeof(int32_t) * (size_t)R * L, s));
   // decoder layer i starts from encoder layer i's state, the BACKWARD direction's for a bidirectional layer (gnmt.py:146-150,224-252)
   const int NL = g->NL, nmid = NL - 2;
   auto hinit = [&](int i) { return (const float *)(g->hl[i] + (i < g->NBI ? (size_t)B * H : 0)); };
@@ -1062,16 +1167,42 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
                        lstm ? cinit(j + 1) : (const float *)nullptr, g->mid[j].sx, g->mid[j].ccur, 1, beam, R, H);
   float *x_after0 = nmid ? g->mid[0].sx : g->sx1;       // input of the cell behind the attention
   hipLaunchKernelGGL(beam_init_kernel, dim3((R + 255) / 256), dim3(256), 0, s, g->scores, g->alive, g->vlen, g->tok, g->samples[0], L, B, beam, bos);
+  // Two decoder layers (the reference's default): 3 launches per step.  The first cell's pre-activations g0 are linear in
+  // x0 = [embed(word), ctx, h0]: step i + 1's attention kernel puts them together from ew[word] and the [h0, ctx] share p0 that
+  // extra workgroups of step i's beam launch computed beside the clips (dec_beam_kernel).  More layers: the cells between
+  // attention and the last one have their own operands, the first cell keeps its own GEMM (2 + 2 per layer launches).
+  const bool fused0 = nmid == 0;
+  LatGemmArgs gm{};
+  int gemm_wgs = 0;
+  size_t beam_lds_launch = beam_lds;
+  if (fused0) {
+    if (!g->ew_ready) {      // embed . W0[:, 0:E]^T: (V, E) x (4H rows of K0, the first E columns) -> (V, 4H)
+      if (int rc = launch_linear_f32(g->emb, E, g->w0c, K0, nullptr, g->ew, 4 * H, V, 4 * H, E, 0, s)) return rc;
+      g->ew_ready = true;
+    }
+    gm = LatGemmArgs{g->sx1, g->w1x, g->b1x, g->p0, K1, K1, 4 * H, R, 4 * H, 2 * H};
+    gemm_wgs = (((R + 15) / 16) * (4 * H / 16) + 3) / 4;
+    if (beam_lds_launch < 4 * 4 * 64 * 4 * sizeof(float)) beam_lds_launch = 4 * 4 * 64 * 4 * sizeof(float);   // the tiles' partial sums
+  }
+  float *h0buf[2] = {g->h0n, fused0 ? g->h0n2 : g->h0n}, *c0buf[2] = {g->c0n, fused0 ? g->c0n2 : g->c0n};
   int steps_done = 0, all_dead = 0;
-  // one step = 4 launches: the loop is bound by launch-to-launch dependency latency, not by arithmetic
+  // the loop is bound by launch-to-launch dependency latency, not by arithmetic
   for (int i = 0; i < max_length; ++i) {
-    const int step = i + 1;
+    const int step = i + 1, cur = step & 1;
     if ((i & 15) == 0) TN_HIP_CHECK(hipMemsetAsync(g->flag, 0, sizeof(int32_t), s));
-    int rc = launch_linear_f32_lat(g->sx0, K0, g->w0c, K0, g->b0c, g->g0, 4 * H, R, 4 * H, K0, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(dec_attention_kernel<1>, dim3(R), dim3(kBeamThreads), att_lds, s, (const float *)g->g0,
-                       (const float *)(g->sx0 + E + H), K0, (const float *)g->c0cur, lstm ? 1 : 0, g->h0n, g->c0n, x_after0, K1,
-                       (const float *)g->keyprojT, (const float *)g->mem, (const int32_t *)g->vl, g->ctxn, beam, 1, T, H);
+    int rc = TN_OK;
+    if (!fused0 || i == 0) {
+      rc = launch_linear_f32_lat(g->sx0, K0, g->w0c, K0, g->b0c, g->g0, 4 * H, R, 4 * H, K0, s);
+      if (rc) return rc;
+      hipLaunchKernelGGL(dec_attention_kernel<1>, dim3(R), dim3(kBeamThreads), att_lds, s, (const float *)g->g0,
+                         (const float *)(g->sx0 + E + H), K0, (const float *)g->c0cur, lstm ? 1 : 0, h0buf[cur], c0buf[cur], x_after0, K1,
+                         (const float *)g->keyprojT, (const float *)g->mem, (const int32_t *)g->vl, g->ctxn, beam, 1, T, H);
+    } else {
+      hipLaunchKernelGGL(dec_attention_kernel<1>, dim3(R), dim3(kBeamThreads), att_lds, s, (const float *)nullptr,
+                         (const float *)h0buf[cur ^ 1], H, (const float *)c0buf[cur ^ 1], lstm ? 1 : 0, h0buf[cur], c0buf[cur], x_after0, K1,
+                         (const float *)g->keyprojT, (const float *)g->mem, (const int32_t *)g->vl, g->ctxn, beam, 1, T, H,
+                         (float *)nullptr, (const int32_t *)g->tok, (const int32_t *)g->parent, (const float *)g->ew, (const float *)g->p0);
+    }
     for (int j = 0; j < nmid; ++j) {
       GnmtMid &m = g->mid[j];
       rc = launch_linear_f32_lat(m.sx, K1, m.w, K1, m.b, m.g, 4 * H, R, 4 * H, K1, s);
@@ -1081,12 +1212,16 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
     }
     rc = launch_linear_f32_lat(g->sx1, K1, g->w1c, K1, g->b1c, g->g1, 4 * H, R, 4 * H, K1, s);
     if (rc) return rc;
+    // BeamSearchScorer [EXT gluonnlp]: length penalty ((K + length) / (K + 1)) ^ alpha of this step and of the previous one
+    const float lp = powf(K + (float)step, alpha) / powf(K + 1.f, alpha);
+    const float prev_lp = step == 1 ? 1.f : powf(K + (float)(step - 1), alpha) / powf(K + 1.f, alpha);
 #define TN_BEAM_LAUNCH(NBM)                                                                                              \
-  hipLaunchKernelGGL(dec_beam_kernel<NBM>, dim3(B), dim3(kBeamThreads), beam_lds, s, (const float *)g->g1, g->sx1,       \
-                     lstm ? 1 : 0, g->c1cur, (const float *)g->wpT, (const float *)g->bp, (const float *)g->h0n,          \
-                     (const float *)g->ctxn, (const float *)g->c0n, g->sx0, g->c0cur, (const float *)g->emb, H, E, V,     \
-                     beam, step, alpha, K, eos, g->scores, g->alive, g->vlen, (const int32_t *)g->samples[0],             \
-                     g->samples[1], L, g->flag, g->hstate, g->parent)
+  hipLaunchKernelGGL(dec_beam_kernel<NBM>, dim3(B + gemm_wgs), dim3(kBeamThreads), beam_lds_launch, s,                   \
+                     (const float *)g->g1, 4 * H, g->sx1, lstm ? 1 : 0, g->c1cur, (const float *)g->wpT,                  \
+                     (const float *)g->bp, (const float *)g->h0n, (const float *)g->ctxn, (const float *)g->c0n, g->sx0,  \
+                     g->c0cur, (const float *)g->emb, H, E, V, beam, step, lp, prev_lp, eos, g->scores, g->alive,         \
+                     g->vlen, g->bp_par, g->bp_word, R, g->flag, g->hstate, g->parent,                                    \
+                     fused0 ? g->tok : (int32_t *)nullptr, B, gm)
     if (nbm == 4) TN_BEAM_LAUNCH(4);
     else if (nbm == 5) TN_BEAM_LAUNCH(5);
     else if (nbm == 8) TN_BEAM_LAUNCH(8);
@@ -1095,9 +1230,6 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
     for (int j = 0; j < nmid; ++j)      // the middle layers' states follow their rows' parent beams
       hipLaunchKernelGGL(dec_mid_state_kernel, dim3(nbm_), dim3(256), 0, s, (const int32_t *)g->parent, (const float *)g->mid[j].hn,
                          lstm ? (const float *)g->mid[j].cn : (const float *)nullptr, g->mid[j].sx, g->mid[j].ccur, 0, beam, R, H);
-    {
-      int32_t *tmp = g->samples[0]; g->samples[0] = g->samples[1]; g->samples[1] = tmp;
-    }
     TN_HIP_CHECK(hipGetLastError());
     steps_done = step;
     if ((i & 15) == 15 || i == max_length - 1) {   // look at the device flag every 16 steps
@@ -1107,7 +1239,9 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
       if (!f) { all_dead = 1; break; }
     }
   }
-  // g->samples[0] now holds the newest samples
+  // the token prefixes, from the back-pointers of the steps taken
+  hipLaunchKernelGGL(beam_samples_kernel, dim3(B), dim3(256), 0, s, (const int32_t *)g->bp_par, (const int32_t *)g->bp_word, g->samples[0], L,
+                     steps_done, R, beam, bos);
   if (!all_dead) {
     hipLaunchKernelGGL(beam_finalize_kernel, dim3((R + 255) / 256), dim3(256), 0, s, g->alive, g->vlen, g->samples[0], L, steps_done + 1, R, eos);
     *length_host = steps_done + 2;

@@ -219,59 +219,37 @@ __global__ __launch_bounds__(256) void linear_f32_skinny_kernel(const float *__r
 // walks - and the four partial tiles meet in LDS, added in wave order (deterministic).  A lane (r = lane & 15, q = lane >> 4)
 // holds X[m0 + r][16 j + 4 q + e] / W[n0 + r][same k] for e = 0..3: MFMA e of chunk j contracts the k-values 16 j + 4 q' + e over
 // q' = 0..3 - any bijection of k works as long as both operands use it.
-constexpr int kLatGroup = 6;
 __global__ __launch_bounds__(256) void linear_f32_lat_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw,
-                                                             const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int K) {
+                                                             const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int Kall,
+                                                             int nsplit, int K2) {
   __shared__ float red[4][64][4];
-  const int t = threadIdx.x, lane = t & 63, wid = t >> 6, r = lane & 15, q = lane >> 4;
-  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
-  const int nch = (K + 63) / 64;                     // 16-wide k chunks per wave
-  const int kbeg = wid * nch * 16;
-  const int xm = min(m0 + r, M - 1), wn = min(n0 + r, N - 1);
-  const float *xrow = X + (long)xm * ldx + 4 * q, *wrow = Wt + (long)wn * ldw + 4 * q;
-  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int c0 = 0; c0 < nch; c0 += kLatGroup) {
-    float4 xa[kLatGroup], wb[kLatGroup];
-#pragma unroll
-    for (int j = 0; j < kLatGroup; ++j) {
-      const int k = kbeg + (c0 + j) * 16 + 4 * q;
-      const bool ok = c0 + j < nch && k < K;        // (K % 4 == 0: a float4 is all inside or all outside)
-      xa[j] = ok ? *(const float4 *)(xrow + kbeg + (c0 + j) * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
-      wb[j] = ok ? *(const float4 *)(wrow + kbeg + (c0 + j) * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int j = 0; j < kLatGroup; ++j) {
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].x, wb[j].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].y, wb[j].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].z, wb[j].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j].w, wb[j].w, acc, 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) red[wid][lane][e] = acc[e];
-  __syncthreads();
-  if (wid == 0) {
-    const int n = n0 + r;
-    if (n < N) {
-      const float bz = bias ? bias[n] : 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int m = m0 + q * 4 + e;
-        if (m < M) Y[(long)m * ldy + n] = ((red[0][lane][e] + red[1][lane][e]) + (red[2][lane][e] + red[3][lane][e])) + bz;
-      }
-    }
-  }
+  const int n0 = blockIdx.x * 16;
+  const int K = n0 >= nsplit ? K2 : Kall;            // the output columns from nsplit on only contract the first K2 k-values
+  lat_tile_f32(X, ldx, Wt, ldw, bias, Y, ldy, M, N, K, blockIdx.y * 16, n0, threadIdx.x >> 6, threadIdx.x & 63, red);
 }
 
 }  // namespace
 
 int launch_linear_f32_lat(const float *X, int ldx, const float *Wt, int ldw, const float *bias, float *Y, int ldy, int M, int N, int K,
                           hipStream_t s) {
+  return launch_linear_f32_lat2(X, ldx, Wt, ldw, bias, Y, ldy, M, N, K, N, K, s);
+}
+
+// the same with two K ranges: the output columns n >= nsplit (a multiple of 16) contract only k < K2 (their weights beyond are
+// never read) - the captioner's step GEMM computes the last cell's gates over [h0, ctx, h1_prev] and the first cell's share
+// over [h0, ctx] in one launch
+int launch_linear_f32_lat2(const float *X, int ldx, const float *Wt, int ldw, const float *bias, float *Y, int ldy, int M, int N, int K,
+                           int nsplit, int K2, hipStream_t s) {
   if (M <= 0 || N <= 0) return TN_OK;
+  TN_REQUIRE(nsplit >= N || (nsplit % 16 == 0 && K2 > 0 && K2 <= K && K2 % 4 == 0), "linear_f32_lat2: bad column split");
   const bool vec = ((ldx | ldw | K) & 3) == 0 && (((uintptr_t)X | (uintptr_t)Wt) & 15) == 0;
-  if (!vec || K < 128 || (long)((N + 15) / 16) * ((M + 15) / 16) > 4096) return launch_linear_f32(X, ldx, Wt, ldw, bias, Y, ldy, M, N, K, 0, s);
+  if (!vec || K < 128 || (long)((N + 15) / 16) * ((M + 15) / 16) > 4096) {
+    if (nsplit >= N) return launch_linear_f32(X, ldx, Wt, ldw, bias, Y, ldy, M, N, K, 0, s);
+    if (int rc = launch_linear_f32(X, ldx, Wt, ldw, bias, Y, ldy, M, nsplit, K, 0, s)) return rc;
+    return launch_linear_f32(X, ldx, Wt + (long)nsplit * ldw, ldw, bias ? bias + nsplit : nullptr, Y + nsplit, ldy, M, N - nsplit, K2, 0, s);
+  }
   const dim3 grid((N + 15) / 16, (M + 15) / 16), block(256);
-  hipLaunchKernelGGL(linear_f32_lat_kernel, grid, block, 0, s, X, ldx, Wt, ldw, bias, Y, ldy, M, N, K);
+  hipLaunchKernelGGL(linear_f32_lat_kernel, grid, block, 0, s, X, ldx, Wt, ldw, bias, Y, ldy, M, N, K, nsplit, K2);
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;
 }
