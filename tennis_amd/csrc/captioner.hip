@@ -46,15 +46,24 @@ __device__ long long g_dec_stamps[24];
 #else
 #define DEC_STAMP(i)
 #endif
-// Beam-search step, launch 2 of 4, one workgroup (16 waves) per `rows` consecutive decoder rows of one clip (rows = 1:
-// the step is latency-bound — few workgroups, dependent L2 round trips — so it pays to spread the rows over CUs even
-// though each re-reads the clip's key projection and memory from L2):
+// Work split of the step kernels' three streaming loops (attention scores, attention context, vocabulary projection): a
+// thread owns FOUR consecutive outputs (one 16-byte load per operand row) and a slice of the contraction; n4 groups of four
+// outputs are dealt over 64 / 128 / 256 threads and the remaining factor of the 1024 threads (16 / 8 / 4) splits the
+// contraction, the partial sums meet in LDS.  Each of these loops used to be one scalar load + one LDS read per FMA row:
+// the LDS pipe (every lane reading the same broadcast value) and the number of loads in flight bound them, not the bytes.
+__device__ __host__ __forceinline__ int step_groups(int n4) { return n4 <= 64 ? 64 : n4 <= 128 ? 128 : 256; }
+static size_t att_lds_bytes(int T, int H) {      // q[H] | w[Tp] | part[16 * max(Tp, H)]
+  const int Tp = (T + 3) & ~3;
+  return ((size_t)H + Tp + (size_t)16 * (Tp > H ? Tp : H)) * sizeof(float);
+}
+// Beam-search step, first launch, one workgroup (16 waves) per decoder row (the step is latency-bound - few workgroups,
+// dependent L2 round trips - so it pays to spread the rows over CUs even though the beams of a clip each re-read the clip's key
+// projection and memory from L2):
 //   first decoder cell's gate arithmetic on the stacked pre-activations g0 (R,4H) — GRU columns
 //   [r, z, n_i2h, n_h2h] (r and z already summed over both branches), LSTM [i, f, g, o]; h_prev = last H columns
 //   of the step input x0 — the new state goes to hn (R,H) (+ cn) and to x1[:, 0:H];
-//   scaled-Luong scores against the TRANSPOSED key projection kpT (B,H,T) (thread = (quarter of H, source step):
-//   coalesced along T), masked softmax (one wave per beam row), context from mem (B,T,H) (thread = (quarter of
-//   the valid steps, unit)) -> ctx (R,H) and x1[:, H:2H].
+//   scaled-Luong scores against the TRANSPOSED key projection kpT (B,H,Tp) (Tp = T rounded up to 4), masked softmax (one
+//   wave), context from mem (B,T,H) -> ctx (R,H) and x1[:, H:2H].
 template <int NBM>
 __global__ __launch_bounds__(kBeamThreads) void dec_attention_kernel(
     const float *__restrict__ g0, const float *__restrict__ hprev, int ldh, const float *__restrict__ cprev, int lstm,
@@ -66,154 +75,153 @@ __global__ __launch_bounds__(kBeamThreads) void dec_attention_kernel(
   // ew != NULL (beam search, two decoder layers, from the second step on): the row's pre-activations are put together here,
   // g = ew[tok[row]] + p0[parent row] (dec_beam_kernel), and h_prev / c_prev are the PARENT row's (hprev / cprev then hold
   // the previous step's new states, one row per beam, pitch ldh / H)
-  constexpr int NP = (NBM + 3) & ~3;
-  extern __shared__ float sm[];   // q[H][NP] | w[T][NP] | part[4][rows][max(T,H)]
-  float *q = sm, *w = q + H * NP, *part = w + T * NP;
-  const int r0 = blockIdx.x * rows, b = r0 / beam, t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  static_assert(NBM == 1, "one decoder row per workgroup");
+  extern __shared__ float sm[];   // q[H] | w[Tp] | part[16 * max(Tp, H)]
+  const int Tp = (T + 3) & ~3;
+  float *q = sm, *w = q + H, *part = w + Tp;
+  const long r = blockIdx.x;
+  const int b = (int)(r / beam), t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int vl = min(max(valid_len[b], 0), T);
   const float inv = 1.0f / sqrtf((float)H);
   DEC_STAMP(0);
   // ---- cell 0 ----
-  for (int idx = t; idx < NBM * H; idx += kBeamThreads) {
-    const int k = idx / H, u = idx - k * H;
-    float v = 0.f;
-    if (k < rows) {
-      const long r = (long)r0 + k;
-      const long rp = ew ? (long)b * beam + par[r] : r;
-      float ga, gb, gc, gd;
-      if (ew) {
-        const int word = tok[r];
-        const float *e = ew + (long)(word > 0 ? word : 0) * 4 * H, *q0 = p0 + rp * 4 * H;
-        ga = e[u] + q0[u]; gb = e[H + u] + q0[H + u]; gc = e[2 * H + u] + q0[2 * H + u]; gd = e[3 * H + u] + q0[3 * H + u];
-      } else {
-        const float *g = g0 + r * 4 * H;
-        ga = g[u]; gb = g[H + u]; gc = g[2 * H + u]; gd = g[3 * H + u];
-      }
-      if (lstm) {
-        const float ig = sigm(ga), fg = sigm(gb), gg = tanhf(gc), og = sigm(gd);
-        const float c2 = fg * cprev[rp * H + u] + ig * gg;
-        cn[r * H + u] = c2;
-        v = og * tanhf(c2);
-      } else {
-        const float rg = sigm(ga), zg = sigm(gb);
-        const float ng = tanhf(gc + rg * gd);
-        v = (1.f - zg) * ng + zg * hprev[rp * ldh + u];
-      }
-      hn[r * H + u] = v;
-      x1[r * ldx1 + u] = v;
+  for (int u = t; u < H; u += kBeamThreads) {
+    const long rp = ew ? (long)b * beam + par[r] : r;
+    float ga, gb, gc, gd;
+    if (ew) {
+      const int word = tok[r];
+      const float *e = ew + (long)(word > 0 ? word : 0) * 4 * H, *q0 = p0 + rp * 4 * H;
+      ga = e[u] + q0[u]; gb = e[H + u] + q0[H + u]; gc = e[2 * H + u] + q0[2 * H + u]; gd = e[3 * H + u] + q0[3 * H + u];
+    } else {
+      const float *g = g0 + r * 4 * H;
+      ga = g[u]; gb = g[H + u]; gc = g[2 * H + u]; gd = g[3 * H + u];
     }
-    q[u * NP + k] = v * inv;
+    float v;
+    if (lstm) {
+      const float ig = sigm(ga), fg = sigm(gb), gg = tanhf(gc), og = sigm(gd);
+      const float c2 = fg * cprev[rp * H + u] + ig * gg;
+      cn[r * H + u] = c2;
+      v = og * tanhf(c2);
+    } else {
+      const float rg = sigm(ga), zg = sigm(gb);
+      const float ng = tanhf(gc + rg * gd);
+      v = (1.f - zg) * ng + zg * hprev[rp * ldh + u];
+    }
+    hn[r * H + u] = v;
+    x1[r * ldx1 + u] = v;
+    q[u] = v * inv;
   }
   __syncthreads();
   DEC_STAMP(1);
-  // ---- scores: 4 partial sums over H per (row, source step) ----
+  // ---- scores: thread = (slice of H, four source steps); HG partial sums per step ----
+  const int S4 = (vl + 3) >> 2, CG = step_groups(S4), HG = kBeamThreads / CG;
   {
-    const int hq = t >> 8, hn4 = H / 4, h0 = hq * hn4;
-    const float *kp = kpT + (long)b * H * T;
-    for (int s = t & 255; s < vl; s += 256) {
-      float acc[NBM];
-#pragma unroll
-      for (int j = 0; j < NBM; ++j) acc[j] = 0.f;
-      // loads are batched by hand (16 in flight): left to itself the compiler waits for each load before its fma
+    const int hg = t / CG, hn_ = (H + HG - 1) / HG, h0 = hg * hn_, h1 = min(H, h0 + hn_);
+    const float *kp = kpT + (long)b * H * Tp;
+    for (int s4 = t % CG; s4 < S4; s4 += CG) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       int h = h0;
-      for (; h + 16 <= h0 + hn4; h += 16) {
-        float kv[16];
+      for (; h + 16 <= h1; h += 16) {           // 16 x 16 bytes in flight
+        float4 kv[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) kv[i] = kp[(long)(h + i) * T + s];
+        for (int i = 0; i < 16; ++i) kv[i] = *(const float4 *)(kp + (long)(h + i) * Tp + 4 * s4);
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-#pragma unroll
-          for (int j = 0; j < NBM; ++j) acc[j] = fmaf(kv[i], q[(h + i) * NP + j], acc[j]);
+        for (int i = 0; i < 16; ++i) {
+          const float qv = q[h + i];
+          acc.x = fmaf(kv[i].x, qv, acc.x); acc.y = fmaf(kv[i].y, qv, acc.y); acc.z = fmaf(kv[i].z, qv, acc.z); acc.w = fmaf(kv[i].w, qv, acc.w);
+        }
       }
-      for (; h < h0 + hn4; ++h) {
-        const float kv = kp[(long)h * T + s];
-#pragma unroll
-        for (int j = 0; j < NBM; ++j) acc[j] = fmaf(kv, q[h * NP + j], acc[j]);
+      for (; h < h1; ++h) {
+        const float4 kv = *(const float4 *)(kp + (long)h * Tp + 4 * s4);
+        const float qv = q[h];
+        acc.x = fmaf(kv.x, qv, acc.x); acc.y = fmaf(kv.y, qv, acc.y); acc.z = fmaf(kv.z, qv, acc.z); acc.w = fmaf(kv.w, qv, acc.w);
       }
-#pragma unroll
-      for (int j = 0; j < NBM; ++j)
-        if (j < rows) part[(hq * rows + j) * T + s] = acc[j];
+      *(float4 *)(part + hg * Tp + 4 * s4) = acc;
     }
   }
   __syncthreads();
   DEC_STAMP(2);
-  // ---- masked softmax: wave k owns beam row k (masked -> -1e18, weights * mask) ----
-  if (wid < rows) {
-    const float *p0 = part + wid * T, *p1 = p0 + rows * T, *p2 = p1 + rows * T, *p3 = p2 + rows * T;
-    float mx = -INFINITY;
-    for (int s = lane; s < T; s += 64) {
-      const float a = s < vl ? (p0[s] + p1[s]) + (p2[s] + p3[s]) : kNeg;
-      w[s * NP + wid] = a;
-      mx = fmaxf(mx, a);
+  // ---- the HG partial sums of every step (all threads), then the masked softmax in one wave (masked -> -1e18, weights * mask) ----
+  for (int s = t; s < T; s += kBeamThreads) {
+    float a = kNeg;
+    if (s < vl) {
+      a = part[s];
+      for (int g = 1; g < HG; ++g) a += part[g * Tp + s];
     }
+    w[s] = a;
+  }
+  __syncthreads();
+  if (wid == 0) {
+    float mx = -INFINITY;
+    for (int s = lane; s < T; s += 64) mx = fmaxf(mx, w[s]);
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     float sum = 0.f;
     for (int s = lane; s < T; s += 64) {
-      const float e = expf(w[s * NP + wid] - mx);
-      w[s * NP + wid] = e;
+      const float e = expf(w[s] - mx);
+      w[s] = e;
       sum += e;
     }
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     const float rs = 1.0f / sum;
     for (int s = lane; s < T; s += 64) {
-      const float v = s < vl ? w[s * NP + wid] * rs : 0.f;
-      w[s * NP + wid] = v;
-      if (wsave) wsave[((long)r0 + wid) * T + s] = v;      // training keeps the attention weights
+      const float v = s < vl ? w[s] * rs : 0.f;
+      w[s] = v;
+      if (wsave) wsave[r * T + s] = v;      // training keeps the attention weights
     }
-  } else if (wid < NP) {
-    for (int s = lane; s < T; s += 64) w[s * NP + wid] = 0.f;      // padded rows feed unused accumulators
   }
   __syncthreads();
   DEC_STAMP(3);
-  // ---- context: 4 partial sums over the valid steps per (row, unit); weights beyond valid_len are exactly 0 ----
+  // ---- context: thread = (slice of the valid steps, four units); SG partial sums per unit; weights beyond valid_len are 0 ----
+  const int U4 = H >> 2, CG2 = step_groups(U4), SG = kBeamThreads / CG2;
   {
-    const int sq = t >> 8, sn = (vl + 3) / 4, s0 = sq * sn, s1 = min(vl, s0 + sn);
+    const int sg = t / CG2, sn = (vl + SG - 1) / SG, s0 = sg * sn, s1 = min(vl, s0 + sn);
     const float *mv = mem + (long)b * T * H;
-    for (int u = t & 255; u < H; u += 256) {
-      float acc[NBM];
-#pragma unroll
-      for (int j = 0; j < NBM; ++j) acc[j] = 0.f;
+    for (int u4 = t % CG2; u4 < U4; u4 += CG2) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       int s = s0;
       for (; s + 16 <= s1; s += 16) {
-        float m[16];
+        float4 m[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) m[i] = mv[(long)(s + i) * H + u];
+        for (int i = 0; i < 16; ++i) m[i] = *(const float4 *)(mv + (long)(s + i) * H + 4 * u4);
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-#pragma unroll
-          for (int j = 0; j < NBM; ++j) acc[j] = fmaf(w[(s + i) * NP + j], m[i], acc[j]);
+        for (int i = 0; i < 16; ++i) {
+          const float wv = w[s + i];
+          acc.x = fmaf(wv, m[i].x, acc.x); acc.y = fmaf(wv, m[i].y, acc.y); acc.z = fmaf(wv, m[i].z, acc.z); acc.w = fmaf(wv, m[i].w, acc.w);
+        }
       }
-      for (; s < s1; ++s) {
-        const float m = mv[(long)s * H + u];
+      if (s < s1) {                              // the rest of the slice, still all in flight at once
+        float4 m[16];
 #pragma unroll
-        for (int j = 0; j < NBM; ++j) acc[j] = fmaf(w[s * NP + j], m, acc[j]);
+        for (int i = 0; i < 16; ++i) m[i] = s + i < s1 ? *(const float4 *)(mv + (long)(s + i) * H + 4 * u4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float wv = s + i < s1 ? w[s + i] : 0.f;
+          acc.x = fmaf(wv, m[i].x, acc.x); acc.y = fmaf(wv, m[i].y, acc.y); acc.z = fmaf(wv, m[i].z, acc.z); acc.w = fmaf(wv, m[i].w, acc.w);
+        }
       }
-#pragma unroll
-      for (int j = 0; j < NBM; ++j)
-        if (j < rows) part[(sq * rows + j) * H + u] = acc[j];
+      *(float4 *)(part + sg * H + 4 * u4) = acc;
     }
   }
   __syncthreads();
-  for (int idx = t; idx < rows * H; idx += kBeamThreads) {
-    const int k = idx / H, u = idx - k * H;
-    const long r = (long)r0 + k;
-    const float a = (part[idx] + part[rows * H + idx]) + (part[2 * rows * H + idx] + part[3 * rows * H + idx]);
+  for (int u = t; u < H; u += kBeamThreads) {
+    float a = part[u];
+    for (int g = 1; g < SG; ++g) a += part[g * H + u];
     ctx[r * H + u] = a;
     x1[r * ldx1 + H + u] = a;
   }
   DEC_STAMP(4);
 }
 
-// (B,T,H) -> (B,H,T): the key projection as the per-clip attention kernel reads it
+// (B,T,H) -> (B,H,Tp), Tp = T rounded up to 4: the key projection as the attention kernel reads it (16-byte loads along T)
 __global__ void transpose_bth_kernel(const float *__restrict__ src, float *__restrict__ dst, int T, int H) {
   __shared__ float tile[32][33];
+  const int Tp = (T + 3) & ~3;
   const int b = blockIdx.z, t0 = blockIdx.y * 32, h0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int i = ty; i < 32; i += 8)
-    if (t0 + i < T && h0 + tx < H) tile[i][tx] = src[((long)b * T + t0 + i) * H + h0 + tx];
+  for (int i = ty; i < 32; i += 8) tile[i][tx] = (t0 + i < T && h0 + tx < H) ? src[((long)b * T + t0 + i) * H + h0 + tx] : 0.f;
   __syncthreads();
   for (int i = ty; i < 32; i += 8)
-    if (h0 + i < H && t0 + tx < T) dst[((long)b * H + h0 + i) * T + t0 + tx] = tile[tx][i];
+    if (h0 + i < H && t0 + tx < Tp) dst[((long)b * H + h0 + i) * Tp + t0 + tx] = tile[tx][i];
 }
 
 // Wave-wide best of per-lane (value, index) pairs - value descending, then index ascending - in two DPP reductions of one
@@ -234,39 +242,18 @@ __device__ __forceinline__ void wave_best(float v, unsigned ix, float &wv, unsig
   wi = (unsigned)__builtin_amdgcn_readlane((int)c, 63);
 }
 
-// The `count` largest of arr[0..n) (LDS), descending, ties -> lowest index, where element p has index idx[p] (idx != NULL) or
-// base + p: one wave, no block barrier.  A lane owns the elements p = lane mod 64 and keeps the best of them; a round is
-// wave_best plus, in the winning lane only, dropping the element and looking at its own elements again.  REG: n <= 256, the
-// lane's four elements live in registers (nothing is re-read); otherwise the dropped element becomes -inf in LDS and the lane
-// rescans its stride.  out_val / out_idx (LDS) receive the winners.
-template <bool REG>
-__device__ __forceinline__ void wave_topk_impl(float *arr, const int *idx, int base, int n, int count, float *out_val, int *out_idx, int lane) {
-  float x[4];
-  unsigned xi[4];
-  if constexpr (REG) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int p = lane + 64 * i;
-      x[i] = p < n ? arr[p] : -INFINITY;
-      xi[i] = p < n ? (unsigned)(idx ? idx[p] : base + p) : 0xffffffffu;
-    }
-  }
+// The `count` largest of n <= 256 elements held four per lane in registers (x[i], index xi[i]; -inf / 0xffffffff where the lane
+// has none), descending, ties -> lowest index: one wave, no barrier, nothing re-read.  A round is wave_best plus, in the
+// winning lane only, dropping the element.  out_val / out_idx (LDS) receive the winners.
+__device__ __forceinline__ void wave_topk_regs(float (&x)[4], unsigned (&xi)[4], int count, float *out_val, int *out_idx) {
   float bv;
   unsigned bix;
   int bpos;
   auto scan = [&]() {
     bv = -INFINITY; bix = 0xffffffffu; bpos = -1;
-    if constexpr (REG) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (x[i] > bv || (x[i] == bv && xi[i] < bix)) { bv = x[i]; bix = xi[i]; bpos = i; }
-    } else {
-      for (int p = lane; p < n; p += 64) {
-        const float v = arr[p];
-        const unsigned ix = (unsigned)(idx ? idx[p] : base + p);
-        if (v > bv || (v == bv && ix < bix)) { bv = v; bix = ix; bpos = p; }
-      }
-    }
+    for (int i = 0; i < 4; ++i)
+      if (x[i] > bv || (x[i] == bv && xi[i] < bix)) { bv = x[i]; bix = xi[i]; bpos = i; }
   };
   scan();
   for (int k = 0; k < count; ++k) {
@@ -276,20 +263,51 @@ __device__ __forceinline__ void wave_topk_impl(float *arr, const int *idx, int b
     if (bpos >= 0 && bix == wi && bv == wv) {       // this lane owned the winner: record, drop it, look again
       out_idx[k] = (int)wi;
       out_val[k] = wv;
-      if constexpr (REG) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (i == bpos) { x[i] = -INFINITY; xi[i] = 0xffffffffu; }
-      } else {
-        arr[bpos] = -INFINITY;
-      }
+      for (int i = 0; i < 4; ++i)
+        if (i == bpos) { x[i] = -INFINITY; xi[i] = 0xffffffffu; }
       scan();
     }
   }
 }
+// The same over arr[0..n) in LDS for any n, element p has index idx[p] (idx != NULL) or base + p: a lane owns the elements
+// p = lane mod 64 and rescans them when it has won (the dropped element becomes -inf in LDS).
 __device__ __forceinline__ void wave_topk(float *arr, const int *idx, int base, int n, int count, float *out_val, int *out_idx, int lane) {
-  if (n <= 256) wave_topk_impl<true>(arr, idx, base, n, count, out_val, out_idx, lane);
-  else wave_topk_impl<false>(arr, idx, base, n, count, out_val, out_idx, lane);
+  if (n <= 256) {
+    float x[4];
+    unsigned xi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = lane + 64 * i;
+      x[i] = p < n ? arr[p] : -INFINITY;
+      xi[i] = p < n ? (unsigned)(idx ? idx[p] : base + p) : 0xffffffffu;
+    }
+    wave_topk_regs(x, xi, count, out_val, out_idx);
+    return;
+  }
+  float bv;
+  unsigned bix;
+  int bpos;
+  auto scan = [&]() {
+    bv = -INFINITY; bix = 0xffffffffu; bpos = -1;
+    for (int p = lane; p < n; p += 64) {
+      const float v = arr[p];
+      const unsigned ix = (unsigned)(idx ? idx[p] : base + p);
+      if (v > bv || (v == bv && ix < bix)) { bv = v; bix = ix; bpos = p; }
+    }
+  };
+  scan();
+  for (int k = 0; k < count; ++k) {
+    float wv;
+    unsigned wi;
+    wave_best(bv, bix, wv, wi);
+    if (bpos >= 0 && bix == wi && bv == wv) {
+      out_idx[k] = (int)wi;
+      out_val[k] = wv;
+      arr[bpos] = -INFINITY;
+      scan();
+    }
+  }
 }
 
 // Beam-search step, last launch, one workgroup per source clip:
@@ -324,10 +342,10 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
   // hstate != NULL: use_residual (gnmt.py:394-395) - the projection sees h + the cell's input x1[:, 0:H], the recurrent
   // state stays h and goes through this (R,H) scratch; parent_out: the chosen parent beam of every row, for the states of
   // the decoder layers between the first and the last one (num_layers > 2)
-  extern __shared__ float sm[];   // h1n[H][NP] | c1n[H][NP] | logits[beam*V] (the candidates in place) | part[4*beam*V]
+  extern __shared__ float sm[];   // h1n[H][NP] | c1n[H][NP] | logits[beam*Vp] (the candidates in place) | part[KQ*beam*Vp]
   const int b = blockIdx.x, t = threadIdx.x, K0 = E + 2 * H, K1 = 3 * H;
   constexpr int NP = (NBM + 3) & ~3;   // LDS pitch of one k: NBM beam rows padded to 16-byte multiples
-  float *h1n = sm, *c1n = h1n + NP * H, *logits = c1n + NP * H, *part = logits + beam * V;
+  float *h1n = sm, *c1n = h1n + NP * H, *logits = c1n + NP * H, *part = logits + beam * ((V + 3) & ~3);
   __shared__ float sel_val[16], o_score[16], m_val[16 * 16 + 16];
   __shared__ int sel_idx[16], sel_par[16], sel_word[16], o_alive[16], o_vlen[16], m_idx[16 * 16 + 16];
   const int lane = t & 63, wid = t >> 6;
@@ -368,56 +386,93 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
   }
   __syncthreads();
   DEC_STAMP(9);
-  // ---- projection: thread = (quarter of K, vocabulary column) ----
+  // ---- projection: thread = (slice of K, four vocabulary columns), see step_groups; KQ partial sums per logit ----
+  const int Vp = (V + 3) & ~3, V4 = Vp >> 2, CGv = step_groups(V4), KQ = kBeamThreads / CGv;
   {
-    const int kq = t >> 8, tv = t & 255, kn = H / 4, k0 = kq * kn;
-    for (int v = tv; v < V; v += 256) {
-      float acc[NBM];
+    constexpr int NLD = NBM <= 5 ? 16 : NBM <= 8 ? 8 : 2;      // 16-byte loads in flight (registers: NBM float4 sums beside them)
+    const int kq = t / CGv, kn = (H + KQ - 1) / KQ, k0 = kq * kn, k1 = min(H, k0 + kn);
+    for (int v4 = t % CGv; v4 < V4; v4 += CGv) {
+      float4 acc[NBM];
 #pragma unroll
-      for (int q = 0; q < NBM; ++q) acc[q] = 0.f;
+      for (int q = 0; q < NBM; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
       int k = k0;
-      for (; k + 16 <= k0 + kn; k += 16) {      // 16 loads in flight (batched by hand, see dec_attention_kernel)
-        float w[16];
+      for (; k + NLD <= k1; k += NLD) {
+        float4 w[NLD];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) w[i] = wpT[(long)(k + i) * V + v];
+        for (int i = 0; i < NLD; ++i) w[i] = *(const float4 *)(wpT + (long)(k + i) * Vp + 4 * v4);
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
+        for (int i = 0; i < NLD; ++i)
 #pragma unroll
-          for (int q = 0; q < NBM; ++q) acc[q] = fmaf(w[i], h1n[(k + i) * NP + q], acc[q]);
+          for (int q = 0; q < NBM; ++q) {
+            const float hv = h1n[(k + i) * NP + q];
+            acc[q].x = fmaf(w[i].x, hv, acc[q].x); acc[q].y = fmaf(w[i].y, hv, acc[q].y);
+            acc[q].z = fmaf(w[i].z, hv, acc[q].z); acc[q].w = fmaf(w[i].w, hv, acc[q].w);
+          }
       }
-      for (; k < k0 + kn; ++k) {
-        const float w = wpT[(long)k * V + v];
+      for (; k < k1; ++k) {
+        const float4 w = *(const float4 *)(wpT + (long)k * Vp + 4 * v4);
 #pragma unroll
-        for (int q = 0; q < NBM; ++q) acc[q] = fmaf(w, h1n[k * NP + q], acc[q]);
+        for (int q = 0; q < NBM; ++q) {
+          const float hv = h1n[k * NP + q];
+          acc[q].x = fmaf(w.x, hv, acc[q].x); acc[q].y = fmaf(w.y, hv, acc[q].y);
+          acc[q].z = fmaf(w.z, hv, acc[q].z); acc[q].w = fmaf(w.w, hv, acc[q].w);
+        }
       }
 #pragma unroll
       for (int q = 0; q < NBM; ++q)
-        if (q < beam) part[(kq * beam + q) * V + v] = acc[q];
+        if (q < beam) *(float4 *)(part + (long)(kq * beam + q) * Vp + 4 * v4) = acc[q];
     }
   }
   __syncthreads();
   DEC_STAMP(10);
-  // ---- wave k owns beam row k: logits, log-sum-exp, candidates (in place of the logits) and the row's `beam` best ----
+  // ---- logits = bias + the KQ partial sums (all threads) ----
+  for (int c = t; c < beam * V; c += kBeamThreads) {
+    const int k = c / V, v = c - k * V;
+    float x = part[k * Vp + v];
+    for (int g = 1; g < KQ; ++g) x += part[(g * beam + k) * Vp + v];
+    logits[k * Vp + v] = x + bp[v];
+  }
+  __syncthreads();
+  // ---- wave k owns beam row k: log-sum-exp, length-penalised candidates and the row's `beam` best (V <= 256: in registers) ----
   if (wid < beam) {
     const int k = wid;
-    float *z = logits + k * V;
-    float mx = -INFINITY;
-    for (int v = lane; v < V; v += 64) {
-      const int c = k * V + v;
-      const float x = bp[v] + ((part[c] + part[beam * V + c]) + (part[2 * beam * V + c] + part[3 * beam * V + c]));
-      z[v] = x;
-      mx = fmaxf(mx, x);
+    float *z = logits + k * Vp;
+    if (V <= 256) {
+      float x[4];
+      unsigned xi[4];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int v = lane + 64 * i;
+        x[i] = v < V ? z[v] : -INFINITY;
+        xi[i] = v < V ? (unsigned)(k * V + v) : 0xffffffffu;
+        mx = fmaxf(mx, x[i]);
+      }
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (lane + 64 * i < V) sum += expf(x[i] - mx);
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      const float lse = mx + logf(sum);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (lane + 64 * i < V) x[i] = al ? (osc * prev_lp + (x[i] - lse)) / lp : kNeg;
+      wave_topk_regs(x, xi, beam, m_val + k * beam, m_idx + k * beam);
+    } else {
+      float mx = -INFINITY;
+      for (int v = lane; v < V; v += 64) mx = fmaxf(mx, z[v]);
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      float sum = 0.f;
+      for (int v = lane; v < V; v += 64) sum += expf(z[v] - mx);
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      const float lse = mx + logf(sum);
+      for (int v = lane; v < V; v += 64) {
+        const float logp = z[v] - lse;
+        z[v] = al ? (osc * prev_lp + logp) / lp : kNeg;
+      }
+      wave_topk(z, nullptr, k * V, V, beam, m_val + k * beam, m_idx + k * beam, lane);
     }
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    float sum = 0.f;
-    for (int v = lane; v < V; v += 64) sum += expf(z[v] - mx);
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    const float lse = mx + logf(sum);
-    for (int v = lane; v < V; v += 64) {
-      const float logp = z[v] - lse;
-      z[v] = al ? (osc * prev_lp + logp) / lp : kNeg;
-    }
-    wave_topk(z, nullptr, k * V, V, beam, m_val + k * beam, m_idx + k * beam, lane);
     if (lane == 0) {
       o_alive[k] = al; o_vlen[k] = ovl; o_score[k] = osc;
       m_val[beam * beam + k] = al ? kNeg : osc;           // a finished beam competes with its own score
@@ -426,9 +481,13 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
   }
   __syncthreads();
   DEC_STAMP(12);
-  // ---- top-`beam` of the clip: the rows' bests and the finished beams ----
-  if (wid == 0) wave_topk(m_val, m_idx, 0, beam * beam + beam, beam, sel_val, sel_idx, lane);
-  __syncthreads();
+  // ---- top-`beam` of the clip: the rows' bests and the finished beams; the same wave then does the bookkeeping ----
+  if (wid == 0) {
+    wave_topk(m_val, m_idx, 0, beam * beam + beam, beam, sel_val, sel_idx, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
   DEC_STAMP(13);
   // ---- bookkeeping ----
   if (t < beam) {
@@ -1063,9 +1122,10 @@ extern "C" int tn_gnmt_create_ex(tn_ctx *ctx, const tn_param *params, int n_para
     for (int i = 1; i + 1 < num_layers; ++i)
       if (!stack("dec_rnn" + std::to_string(i) + "_", 2 * H, &g->mid[i - 1].w, &g->mid[i - 1].b)) return fail(TN_ERR_MISSING);
     const float *wp = get(pre + "tgt_proj_weight", (int64_t)vocab * H);
-    std::vector<float> wt((size_t)H * vocab);
+    const int vp = (vocab + 3) & ~3;        // rows of Wp^T padded to 16 bytes (dec_beam_kernel loads four columns at a time)
+    std::vector<float> wt((size_t)H * vp, 0.f);
     for (int v = 0; v < vocab; ++v)
-      for (int k = 0; k < H; ++k) wt[(size_t)k * vocab + v] = wp[(size_t)v * H + k];
+      for (int k = 0; k < H; ++k) wt[(size_t)k * vp + v] = wp[(size_t)v * H + k];
     g->wpT = g->pool.upload(wt.data(), wt.size());
   }
   const size_t BT = (size_t)max_batch * max_src_len, R = (size_t)max_batch * beam;
@@ -1093,7 +1153,7 @@ extern "C" int tn_gnmt_create_ex(tn_ctx *ctx, const tn_param *params, int n_para
     g->p0 = g->pool.alloc<float>(R * 4 * H); g->h0n2 = g->pool.alloc<float>(R * H); g->c0n2 = g->pool.alloc<float>(R * H);
   }
   g->h0n = g->pool.alloc<float>(R * H); g->ctxn = g->pool.alloc<float>(R * H); g->c0n = g->pool.alloc<float>(R * H);
-  g->c0cur = g->pool.alloc<float>(R * H); g->c1cur = g->pool.alloc<float>(R * H); g->keyprojT = g->pool.alloc<float>(BT * H);
+  g->c0cur = g->pool.alloc<float>(R * H); g->c1cur = g->pool.alloc<float>(R * H); g->keyprojT = g->pool.alloc<float>((size_t)max_batch * ((max_src_len + 3) & ~3) * H);
   if (g->pool.failed) { tn_set_error("device allocation failed"); return fail(TN_ERR_NOMEM); }
   *out = g;
   return TN_OK;
@@ -1147,10 +1207,11 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
   const int K0 = E + 2 * H, K1 = 3 * H;
   const bool lstm = g->G == 4;
   const int nbm = beam <= 4 ? 4 : beam == 5 ? 5 : beam <= 8 ? 8 : 16;   // beam 5: the reference's flag default
-  const size_t att_lds = ((size_t)(H + T) * 4 + (size_t)4 * (T > H ? T : H)) * sizeof(float);   // one row per workgroup
-  const size_t beam_lds = ((size_t)2 * ((nbm + 3) & ~3) * H + (size_t)5 * beam * V + 16) * sizeof(float);
+  const size_t att_lds = att_lds_bytes(T, H);
+  const int Vp = (V + 3) & ~3;
+  const size_t beam_lds = ((size_t)2 * ((nbm + 3) & ~3) * H + (size_t)(1 + kBeamThreads / step_groups(Vp / 4)) * beam * Vp + 16) * sizeof(float);
   TN_REQUIRE(beam_lds <= kStepLdsMax && att_lds <= kStepLdsMax,
-             "tn_gnmt_beam_search: beam * (2*hidden + 5*vocab) or 8 * max(hidden, source length) exceeds the step kernels' 152 KiB of LDS");
+             "tn_gnmt_beam_search: beam * (2*hidden + 17*vocab) floats or 18 * max(hidden, source length) floats exceed the step kernels' 152 KiB of LDS");
   if (int rc = allow_lds(dec_attention_kernel<1>, att_lds)) return rc;
   if (int rc = nbm == 4 ? allow_lds(dec_beam_kernel<4>, beam_lds) : nbm == 5 ? allow_lds(dec_beam_kernel<5>, beam_lds)
                : nbm == 8 ? allow_lds(dec_beam_kernel<8>, beam_lds) : allow_lds(dec_beam_kernel<16>, beam_lds)) return rc;
@@ -1273,8 +1334,8 @@ extern "C" int tn_gnmt_decode_seq(tn_gnmt *g, const int32_t *tgt, int ld, int st
   const int B = g->B, T = g->T, H = g->H, E = g->E, V = g->V, R = B, K0 = E + 2 * H, K1 = 3 * H;
   const bool lstm = g->G == 4;
   const int nb = (R * H + 255) / 256;
-  const size_t att_lds = ((size_t)(H + T) * 4 + (size_t)4 * (T > H ? T : H)) * sizeof(float);
-  TN_REQUIRE(att_lds <= kStepLdsMax, "tn_gnmt_decode_seq: 8 * max(hidden, source length) exceeds the step kernel's 152 KiB of LDS");
+  const size_t att_lds = att_lds_bytes(T, H);
+  TN_REQUIRE(att_lds <= kStepLdsMax, "tn_gnmt_decode_seq: 18 * max(hidden, source length) floats exceed the step kernel's 152 KiB of LDS");
   if (int rc = allow_lds(dec_attention_kernel<1>, att_lds)) return rc;
   const int NL = g->NL, nmid = NL - 2;
   auto hinit = [&](int i) { return (const float *)(g->hl[i] + (i < g->NBI ? (size_t)B * H : 0)); };
@@ -1535,7 +1596,7 @@ extern "C" int tn_gnmt_trainer_create_ex(tn_ctx *ctx, const tn_param *params, in
     d.dG = fl(LB * 4 * H); d.dX = fl(LB * K); d.dhz = fl(B * H); d.dcz = fl(B * H); d.dW = fl(4 * H * K); d.db = fl(4 * H);
   }
   t->wpT = fl(V * H); t->wkT = fl(H * H);
-  t->keyproj = fl(BT * H); t->keyprojT = fl(BT * H); t->AW = fl(LB * T); t->h0tmp = fl(B * H); t->ctxtmp = fl(B * H);
+  t->keyproj = fl(BT * H); t->keyprojT = fl(B * ((T + 3) & ~(size_t)3) * H); t->AW = fl(LB * T); t->h0tmp = fl(B * H); t->ctxtmp = fl(B * H);
   t->logits = fl(LB * V); t->lossrows = fl(LB); t->Out = fl(LB * H); t->dlog = fl(LB * V); t->dOut = fl(LB * H); t->dq = fl(B * H);
   t->dkp = fl(BT * H); t->tmpA = fl(B * H); t->tmpB = fl(B * H); t->tmpM = fl(B * H); t->tmpAtt = fl(B * H);
   t->vl = t->pool.alloc<int32_t>(B); t->tvl = t->pool.alloc<int32_t>(B);
@@ -1580,9 +1641,9 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
   const int K0 = E + 2 * H, K1 = 3 * H;
   const int BT = B * T, LB = L * B;
   const bool lstm = G == 4;
-  const size_t att_lds = ((size_t)(H + T) * 4 + (size_t)4 * (T > H ? T : H)) * sizeof(float);
+  const size_t att_lds = att_lds_bytes(T, H);
   const size_t attb_lds = (size_t)(2 * H + T + 256) * sizeof(float);
-  TN_REQUIRE(att_lds <= kStepLdsMax && attb_lds <= kStepLdsMax, "tn_gnmt_trainer: 8 * max(hidden, source length) exceeds 152 KiB of LDS");
+  TN_REQUIRE(att_lds <= kStepLdsMax && attb_lds <= kStepLdsMax, "tn_gnmt_trainer: 18 * max(hidden, source length) floats exceed 152 KiB of LDS");
   if (int rc = allow_lds(dec_attention_kernel<1>, att_lds)) return rc;
   if (int rc = allow_lds(trn_att_bwd_kernel, attb_lds)) return rc;
   float *w = t->w, *g = t->g;
