@@ -26,3 +26,13 @@ print("valid_len[0] =", int(vl[0]))
 print("attention (us):", {n: (st[i + 1] - st[i]) / 100.0 for i, n in enumerate(names_a)}, "total", (st[4] - st[0]) / 100.0)
 print("beam (us):", {n: (st[b] - st[a]) / 100.0 for n, a, b in names_b}, "total", (st[16] - st[8]) / 100.0)
 print("attention end -> beam start (lin1 + gaps):", (st[8] - st[4]) / 100.0)
+try:
+    o2 = (C.c_longlong * 8)()
+    lib.tn_dbg_lat_stamps.restype = C.c_int
+    lib.tn_dbg_lat_stamps(o2)
+    l = np.array(list(o2), dtype=np.int64)
+    print("gate GEMM workgroups (us after the attention kernel's last stamp): first %.2f..%.2f, middle %.2f..%.2f, last %.2f..%.2f; beam kernel's first stamp at %.2f" % (
+        (l[0] - st[4]) / 100.0, (l[1] - st[4]) / 100.0, (l[2] - st[4]) / 100.0, (l[3] - st[4]) / 100.0, (l[4] - st[4]) / 100.0, (l[5] - st[4]) / 100.0, (st[8] - st[4]) / 100.0))
+    print("first workgroup: %d s_memtime ticks in %.2f us -> %.0f MHz" % (l[7] - l[6], (l[1] - l[0]) / 100.0, (l[7] - l[6]) / ((l[1] - l[0]) / 100.0)))
+except AttributeError:
+    pass

@@ -26,8 +26,26 @@
 namespace {
 
 constexpr float kNeg = -1e18f;
+constexpr int kGemmPitchPad = 16;   // floats; measured at config C5: 0 / 32 / 64 / 96: 44.2 us per step, 16 / 48 / 80: 42.2
 
 __device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// Wave-wide maximum / sum in six DPP stages (row shifts + row broadcasts, result in lane 63, handed to every lane through an SGPR)
+__device__ __forceinline__ float wave_max(float v) {
+  float m = v;
+#define TN_DPP_F(ctrl, rmask) m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(m), __float_as_int(m), ctrl, rmask, 0xf, false)));
+  TN_DPP_F(0x111, 0xf) TN_DPP_F(0x112, 0xf) TN_DPP_F(0x114, 0xf) TN_DPP_F(0x118, 0xf) TN_DPP_F(0x142, 0xa) TN_DPP_F(0x143, 0xc)
+#undef TN_DPP_F
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  float m = v;
+#define TN_DPP_F(ctrl, rmask) m += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), ctrl, rmask, 0xf, false));
+  TN_DPP_F(0x111, 0xf) TN_DPP_F(0x112, 0xf) TN_DPP_F(0x114, 0xf) TN_DPP_F(0x118, 0xf) TN_DPP_F(0x142, 0xa) TN_DPP_F(0x143, 0xc)
+#undef TN_DPP_F
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
+}
+
 
 // ---- beam-search step kernels: 1024 threads = 16 waves ----
 constexpr int kBeamThreads = 1024;
@@ -154,14 +172,14 @@ __global__ __launch_bounds__(kBeamThreads) void dec_attention_kernel(
   if (wid == 0) {
     float mx = -INFINITY;
     for (int s = lane; s < T; s += 64) mx = fmaxf(mx, w[s]);
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    mx = wave_max(mx);
     float sum = 0.f;
     for (int s = lane; s < T; s += 64) {
       const float e = expf(w[s] - mx);
       w[s] = e;
       sum += e;
     }
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    sum = wave_sum(sum);
     const float rs = 1.0f / sum;
     for (int s = lane; s < T; s += 64) {
       const float v = s < vl ? w[s] * rs : 0.f;
@@ -252,22 +270,28 @@ __device__ __forceinline__ void wave_topk_regs(float (&x)[4], unsigned (&xi)[4],
   auto scan = [&]() {
     bv = -INFINITY; bix = 0xffffffffu; bpos = -1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (x[i] > bv || (x[i] == bv && xi[i] < bix)) { bv = x[i]; bix = xi[i]; bpos = i; }
+    for (int i = 0; i < 4; ++i) {
+      const bool better = (x[i] > bv) | ((x[i] == bv) & (xi[i] < bix));     // (no short circuit: straight-line selects)
+      bv = better ? x[i] : bv; bix = better ? xi[i] : bix; bpos = better ? i : bpos;
+    }
   };
   scan();
   for (int k = 0; k < count; ++k) {
     float wv;
     unsigned wi;
     wave_best(bv, bix, wv, wi);
-    if (bpos >= 0 && bix == wi && bv == wv) {       // this lane owned the winner: record, drop it, look again
+    const bool won = (bpos >= 0) & (bix == wi) & (bv == wv);       // this lane owned the winner: record, drop it, look again
+    if (won) {
       out_idx[k] = (int)wi;
       out_val[k] = wv;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (i == bpos) { x[i] = -INFINITY; xi[i] = 0xffffffffu; }
-      scan();
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool drop = won & (i == bpos);
+      x[i] = drop ? -INFINITY : x[i];
+      xi[i] = drop ? 0xffffffffu : xi[i];
+    }
+    scan();
   }
 }
 // The same over arr[0..n) in LDS for any n, element p has index idx[p] (idx != NULL) or base + p: a lane owns the elements
@@ -332,7 +356,7 @@ struct LatGemmArgs {
 };
 template <int NBM>
 __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
-    const float *__restrict__ g1, int ldg, float *__restrict__ x1, int lstm, float *__restrict__ c1cur,
+    const float *__restrict__ g1, int ldg, float *__restrict__ x1, int K1, int lstm, float *__restrict__ c1cur,
     const float *__restrict__ wpT, const float *__restrict__ bp, const float *__restrict__ h0n,
     const float *__restrict__ ctx, const float *__restrict__ c0n, float *__restrict__ x0, float *__restrict__ c0cur,
     const float *__restrict__ emb, int H, int E, int V, int beam, int step, float lp, float prev_lp, int eos,
@@ -343,7 +367,7 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
   // state stays h and goes through this (R,H) scratch; parent_out: the chosen parent beam of every row, for the states of
   // the decoder layers between the first and the last one (num_layers > 2)
   extern __shared__ float sm[];   // h1n[H][NP] | c1n[H][NP] | logits[beam*Vp] (the candidates in place) | part[KQ*beam*Vp]
-  const int b = blockIdx.x, t = threadIdx.x, K0 = E + 2 * H, K1 = 3 * H;
+  const int b = blockIdx.x, t = threadIdx.x, K0 = E + 2 * H;     // (K1: pitch of x1 = [input of the last cell (2H) | h_prev])
   constexpr int NP = (NBM + 3) & ~3;   // LDS pitch of one k: NBM beam rows padded to 16-byte multiples
   float *h1n = sm, *c1n = h1n + NP * H, *logits = c1n + NP * H, *part = logits + beam * ((V + 3) & ~3);
   __shared__ float sel_val[16], o_score[16], m_val[16 * 16 + 16];
@@ -393,8 +417,9 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
     const int kq = t / CGv, kn = (H + KQ - 1) / KQ, k0 = kq * kn, k1 = min(H, k0 + kn);
     for (int v4 = t % CGv; v4 < V4; v4 += CGv) {
       float4 acc[NBM];
+      const float4 bz = kq == 0 ? *(const float4 *)(bp + 4 * v4) : make_float4(0.f, 0.f, 0.f, 0.f);   // (bp padded to Vp)
 #pragma unroll
-      for (int q = 0; q < NBM; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int q = 0; q < NBM; ++q) acc[q] = bz;
       int k = k0;
       for (; k + NLD <= k1; k += NLD) {
         float4 w[NLD];
@@ -425,12 +450,12 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
   }
   __syncthreads();
   DEC_STAMP(10);
-  // ---- logits = bias + the KQ partial sums (all threads) ----
+  // ---- logits = the KQ partial sums (the first one starts from the bias), all threads ----
   for (int c = t; c < beam * V; c += kBeamThreads) {
     const int k = c / V, v = c - k * V;
     float x = part[k * Vp + v];
     for (int g = 1; g < KQ; ++g) x += part[(g * beam + k) * Vp + v];
-    logits[k * Vp + v] = x + bp[v];
+    logits[k * Vp + v] = x;
   }
   __syncthreads();
   // ---- wave k owns beam row k: log-sum-exp, length-penalised candidates and the row's `beam` best (V <= 256: in registers) ----
@@ -448,12 +473,12 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
         xi[i] = v < V ? (unsigned)(k * V + v) : 0xffffffffu;
         mx = fmaxf(mx, x[i]);
       }
-      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      mx = wave_max(mx);
       float sum = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (lane + 64 * i < V) sum += expf(x[i] - mx);
-      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      sum = wave_sum(sum);
       const float lse = mx + logf(sum);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -462,10 +487,10 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
     } else {
       float mx = -INFINITY;
       for (int v = lane; v < V; v += 64) mx = fmaxf(mx, z[v]);
-      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      mx = wave_max(mx);
       float sum = 0.f;
       for (int v = lane; v < V; v += 64) sum += expf(z[v] - mx);
-      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      sum = wave_sum(sum);
       const float lse = mx + logf(sum);
       for (int v = lane; v < V; v += 64) {
         const float logp = z[v] - lse;
@@ -483,7 +508,33 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
   DEC_STAMP(12);
   // ---- top-`beam` of the clip: the rows' bests and the finished beams; the same wave then does the bookkeeping ----
   if (wid == 0) {
-    wave_topk(m_val, m_idx, 0, beam * beam + beam, beam, sel_val, sel_idx, lane);
+    // every candidate counts the candidates that beat it (value, then lower index): the ones beaten by fewer than `beam` are
+    // the winners and the count is their place - no dependent rounds.  Up to 64 candidates: one per lane, the others' values
+    // come through v_readlane (branch-free); more (beam >= 8): broadcast LDS reads.
+    const int n2 = beam * beam + beam;
+    if (n2 <= 64) {
+      const float v = lane < n2 ? m_val[lane] : -INFINITY;
+      const int ix = lane < n2 ? m_idx[lane] : 0x7fffffff;
+      int rank = 0;
+      for (int j = 0; j < n2; ++j) {
+        const float vj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+        const int ij = __builtin_amdgcn_readlane(ix, j);
+        rank += (int)(vj > v) | ((int)(vj == v) & (int)(ij < ix));
+      }
+      if (lane < n2 && rank < beam) { sel_val[rank] = v; sel_idx[rank] = ix; }
+    } else {
+      for (int p = lane; p < n2; p += 64) {
+        const float v = m_val[p];
+        const int ix = m_idx[p];
+        int rank = 0;
+        for (int j = 0; j < n2; ++j) {
+          const float vj = m_val[j];
+          const int ij = m_idx[j];
+          rank += (int)(vj > v) | ((int)(vj == v) & (int)(ij < ix));
+        }
+        if (rank < beam) { sel_val[rank] = v; sel_idx[rank] = ix; }
+      }
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -625,8 +676,8 @@ __global__ void add_inplace_kernel(float *__restrict__ y, const float *__restric
 __global__ void dec_init_kernel(const float *__restrict__ emb, int bos, const float *__restrict__ h0c,
                                 const float *__restrict__ h1c, const float *__restrict__ c0c,
                                 const float *__restrict__ c1c, float *__restrict__ x0, float *__restrict__ x1,
-                                float *__restrict__ c0cur, float *__restrict__ c1cur, int beam, int H, int E) {
-  const int r = blockIdx.x, b = r / beam, K0 = E + 2 * H, K1 = 3 * H;
+                                float *__restrict__ c0cur, float *__restrict__ c1cur, int beam, int H, int E, int K1) {
+  const int r = blockIdx.x, b = r / beam, K0 = E + 2 * H;
   for (int i = threadIdx.x; i < K0; i += blockDim.x)
     x0[(long)r * K0 + i] = i < E ? emb[(long)bos * E + i] : i < E + H ? 0.f : h0c[(long)b * H + i - E - H];
   for (int u = threadIdx.x; u < H; u += blockDim.x) {
@@ -988,14 +1039,15 @@ struct tn_gnmt {
   float *scores;
   int32_t *alive, *vlen, *tok, *samples[2], *flag;
   // fused beam-search step: stacked [i2h | h2h] weights (4H rows each), transposed projection, step buffers
-  float *w0c, *b0c, *w1c, *b1c, *wpT;
+  float *w0c, *b0c, *w1c, *b1c, *wpT, *bpp;   // (wpT, bpp: Wp^T and its bias with rows / length padded to a multiple of 4)
   float *sx0, *sx1, *g0, *g1, *h0n, *ctxn, *c0n, *c0cur, *c1cur, *keyprojT, *h1n, *c1n;
   // two decoder layers: the first cell's gate GEMM leaves the step's critical path (dec_beam_kernel, `tok_out`):
   // w1x (4H, 3H) = the first cell's columns of h0 and ctx in the order of x1 = [h0, ctx, h1_prev] (the last H columns unused),
   // b1x = b0, ew (V, 4H) = embedding . first cell's embedding columns (made on the first search), p0 (R, 4H) the [h0, ctx]
   // share of the next step's pre-activations, h0n2 / c0n2 the second buffers of the first cell's states (a step reads the
   // previous step's by parent row while it writes its own)
-  float *w1x, *b1x, *ew, *p0, *h0n2, *c0n2;
+  float *w1x, *b1x, *ew, *p0, *h0n2, *c0n2, *w1cp, *sx1p;
+  int K1p;                 // pitch of w1cp / w1x / sx1p, see kGemmPitchPad
   bool ew_ready;
   int32_t *bp_par, *bp_word;   // (maxL, R) back-pointers of the search
   int B, T;
@@ -1107,9 +1159,20 @@ extern "C" int tn_gnmt_create_ex(tn_ctx *ctx, const tn_param *params, int n_para
     if (!stack("dec_rnn" + std::to_string(num_layers - 1) + "_", 2 * H, &g->w1c, &g->b1c)) return fail(TN_ERR_MISSING);
     if (num_layers == 2) {
       const int K0 = embed + 2 * H, K1 = 3 * H;
-      std::vector<float> wx((size_t)4 * H * K1, 0.f);
+      // the step GEMMs read 16 operand rows per load instruction: with rows 3H floats apart (3 KiB at H = 256) the sixteen
+      // lines of an instruction fall into a quarter of the L2 channels; the rows of the beam search's operands get a pitch
+      // that spreads them (tuning: TN_GNMT_PAD=<floats>)
+      const char *pe = getenv("TN_GNMT_PAD");
+      const int K1p = K1 + (pe ? atoi(pe) : kGemmPitchPad);
+      g->K1p = K1p;
+      const std::vector<float> &w1 = last_w;
+      std::vector<float> w1p((size_t)4 * H * K1p, 0.f);
+      for (int row = 0; row < 4 * H; ++row) memcpy(&w1p[(size_t)row * K1p], &w1[(size_t)row * K1], sizeof(float) * K1);
+      g->w1cp = g->pool.upload(w1p.data(), w1p.size());
+      g->sx1p = g->pool.alloc<float>((size_t)max_batch * beam * K1p);
+      std::vector<float> wx((size_t)4 * H * K1p, 0.f);
       for (int row = 0; row < 4 * H; ++row) {
-        float *d = &wx[(size_t)row * K1];
+        float *d = &wx[(size_t)row * K1p];
         const float *sw = &w0[(size_t)row * K0];
         memcpy(d, sw + embed + H, sizeof(float) * H);        // x1[:, 0:H] = h0   <- x0[:, E+H:]
         memcpy(d + H, sw + embed, sizeof(float) * H);        // x1[:, H:2H] = ctx <- x0[:, E:E+H]
@@ -1127,6 +1190,10 @@ extern "C" int tn_gnmt_create_ex(tn_ctx *ctx, const tn_param *params, int n_para
     for (int v = 0; v < vocab; ++v)
       for (int k = 0; k < H; ++k) wt[(size_t)k * vp + v] = wp[(size_t)v * H + k];
     g->wpT = g->pool.upload(wt.data(), wt.size());
+    const float *bpv = get(pre + "tgt_proj_bias", vocab);
+    std::vector<float> bpad(vp, 0.f);
+    if (bpv) memcpy(bpad.data(), bpv, sizeof(float) * vocab);
+    g->bpp = g->pool.upload(bpad.data(), bpad.size());
   }
   const size_t BT = (size_t)max_batch * max_src_len, R = (size_t)max_batch * beam;
   g->seq0 = g->pool.alloc<float>(BT * 2 * H); g->mem = g->pool.alloc<float>(BT * H); g->keyproj = g->pool.alloc<float>(BT * H);
@@ -1220,19 +1287,22 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
   const int NL = g->NL, nmid = NL - 2;
   auto hinit = [&](int i) { return (const float *)(g->hl[i] + (i < g->NBI ? (size_t)B * H : 0)); };
   auto cinit = [&](int i) { return (const float *)(g->cl[i] + (i < g->NBI ? (size_t)B * H : 0)); };
+  const bool fused0 = NL == 2;
+  float *sx1 = fused0 ? g->sx1p : g->sx1;            // the last cell's step input, pitch ld1
+  const int ld1 = fused0 ? g->K1p : K1;
   hipLaunchKernelGGL(dec_init_kernel, dim3(R), dim3(256), 0, s, (const float *)g->emb, bos, hinit(0), hinit(NL - 1),
-                     lstm ? cinit(0) : (const float *)nullptr, cinit(NL - 1), g->sx0, g->sx1, g->c0cur, g->c1cur, beam, H, E);
+                     lstm ? cinit(0) : (const float *)nullptr, cinit(NL - 1), g->sx0, sx1, g->c0cur, g->c1cur, beam, H, E, ld1);
   const int nbm_ = (R * H + 255) / 256;
   for (int j = 0; j < nmid; ++j)
     hipLaunchKernelGGL(dec_mid_state_kernel, dim3(nbm_), dim3(256), 0, s, (const int32_t *)nullptr, hinit(j + 1),
                        lstm ? cinit(j + 1) : (const float *)nullptr, g->mid[j].sx, g->mid[j].ccur, 1, beam, R, H);
-  float *x_after0 = nmid ? g->mid[0].sx : g->sx1;       // input of the cell behind the attention
+  float *x_after0 = nmid ? g->mid[0].sx : sx1;          // input of the cell behind the attention
+  const int ld_after0 = nmid ? K1 : ld1;
   hipLaunchKernelGGL(beam_init_kernel, dim3((R + 255) / 256), dim3(256), 0, s, g->scores, g->alive, g->vlen, g->tok, g->samples[0], L, B, beam, bos);
   // Two decoder layers (the reference's default): 3 launches per step.  The first cell's pre-activations g0 are linear in
   // x0 = [embed(word), ctx, h0]: step i + 1's attention kernel puts them together from ew[word] and the [h0, ctx] share p0 that
   // extra workgroups of step i's beam launch computed beside the clips (dec_beam_kernel).  More layers: the cells between
   // attention and the last one have their own operands, the first cell keeps its own GEMM (2 + 2 per layer launches).
-  const bool fused0 = nmid == 0;
   LatGemmArgs gm{};
   int gemm_wgs = 0;
   size_t beam_lds_launch = beam_lds;
@@ -1241,7 +1311,7 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
       if (int rc = launch_linear_f32(g->emb, E, g->w0c, K0, nullptr, g->ew, 4 * H, V, 4 * H, E, 0, s)) return rc;
       g->ew_ready = true;
     }
-    gm = LatGemmArgs{g->sx1, g->w1x, g->b1x, g->p0, K1, K1, 4 * H, R, 4 * H, 2 * H};
+    gm = LatGemmArgs{sx1, g->w1x, g->b1x, g->p0, ld1, ld1, 4 * H, R, 4 * H, 2 * H};
     gemm_wgs = (((R + 15) / 16) * (4 * H / 16) + 3) / 4;
     if (beam_lds_launch < 4 * 4 * 64 * 4 * sizeof(float)) beam_lds_launch = 4 * 4 * 64 * 4 * sizeof(float);   // the tiles' partial sums
   }
@@ -1256,11 +1326,11 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
       rc = launch_linear_f32_lat(g->sx0, K0, g->w0c, K0, g->b0c, g->g0, 4 * H, R, 4 * H, K0, s);
       if (rc) return rc;
       hipLaunchKernelGGL(dec_attention_kernel<1>, dim3(R), dim3(kBeamThreads), att_lds, s, (const float *)g->g0,
-                         (const float *)(g->sx0 + E + H), K0, (const float *)g->c0cur, lstm ? 1 : 0, h0buf[cur], c0buf[cur], x_after0, K1,
+                         (const float *)(g->sx0 + E + H), K0, (const float *)g->c0cur, lstm ? 1 : 0, h0buf[cur], c0buf[cur], x_after0, ld_after0,
                          (const float *)g->keyprojT, (const float *)g->mem, (const int32_t *)g->vl, g->ctxn, beam, 1, T, H);
     } else {
       hipLaunchKernelGGL(dec_attention_kernel<1>, dim3(R), dim3(kBeamThreads), att_lds, s, (const float *)nullptr,
-                         (const float *)h0buf[cur ^ 1], H, (const float *)c0buf[cur ^ 1], lstm ? 1 : 0, h0buf[cur], c0buf[cur], x_after0, K1,
+                         (const float *)h0buf[cur ^ 1], H, (const float *)c0buf[cur ^ 1], lstm ? 1 : 0, h0buf[cur], c0buf[cur], x_after0, ld_after0,
                          (const float *)g->keyprojT, (const float *)g->mem, (const int32_t *)g->vl, g->ctxn, beam, 1, T, H,
                          (float *)nullptr, (const int32_t *)g->tok, (const int32_t *)g->parent, (const float *)g->ew, (const float *)g->p0);
     }
@@ -1271,15 +1341,16 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
       hipLaunchKernelGGL(dec_mid_cell_kernel, dim3(nbm_), dim3(256), 0, s, (const float *)m.g, (const float *)m.sx, lstm ? 1 : 0,
                          (const float *)m.ccur, m.hn, m.cn, j + 1 < nmid ? g->mid[j + 1].sx : g->sx1, g->residual ? 1 : 0, R, H);
     }
-    rc = launch_linear_f32_lat(g->sx1, K1, g->w1c, K1, g->b1c, g->g1, 4 * H, R, 4 * H, K1, s);
+    rc = fused0 ? launch_linear_f32_lat(sx1, ld1, g->w1cp, ld1, g->b1c, g->g1, 4 * H, R, 4 * H, K1, s)
+                : launch_linear_f32_lat(g->sx1, K1, g->w1c, K1, g->b1c, g->g1, 4 * H, R, 4 * H, K1, s);
     if (rc) return rc;
     // BeamSearchScorer [EXT gluonnlp]: length penalty ((K + length) / (K + 1)) ^ alpha of this step and of the previous one
     const float lp = powf(K + (float)step, alpha) / powf(K + 1.f, alpha);
     const float prev_lp = step == 1 ? 1.f : powf(K + (float)(step - 1), alpha) / powf(K + 1.f, alpha);
 #define TN_BEAM_LAUNCH(NBM)                                                                                              \
   hipLaunchKernelGGL(dec_beam_kernel<NBM>, dim3(B + gemm_wgs), dim3(kBeamThreads), beam_lds_launch, s,                   \
-                     (const float *)g->g1, 4 * H, g->sx1, lstm ? 1 : 0, g->c1cur, (const float *)g->wpT,                  \
-                     (const float *)g->bp, (const float *)g->h0n, (const float *)g->ctxn, (const float *)g->c0n, g->sx0,  \
+                     (const float *)g->g1, 4 * H, sx1, ld1, lstm ? 1 : 0, g->c1cur, (const float *)g->wpT,                \
+                     (const float *)g->bpp, (const float *)g->h0n, (const float *)g->ctxn, (const float *)g->c0n, g->sx0, \
                      g->c0cur, (const float *)g->emb, H, E, V, beam, step, lp, prev_lp, eos, g->scores, g->alive,         \
                      g->vlen, g->bp_par, g->bp_word, R, g->flag, g->hstate, g->parent,                                    \
                      fused0 ? g->tok : (int32_t *)nullptr, B, gm)

@@ -219,17 +219,36 @@ __global__ __launch_bounds__(256) void linear_f32_skinny_kernel(const float *__r
 // walks - and the four partial tiles meet in LDS, added in wave order (deterministic).  A lane (r = lane & 15, q = lane >> 4)
 // holds X[m0 + r][16 j + 4 q + e] / W[n0 + r][same k] for e = 0..3: MFMA e of chunk j contracts the k-values 16 j + 4 q' + e over
 // q' = 0..3 - any bijection of k works as long as both operands use it.
+#ifdef TN_LAT_STAMPS
+__device__ long long g_lat_stamps[8];
+#endif
 __global__ __launch_bounds__(256) void linear_f32_lat_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw,
                                                              const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int Kall,
                                                              int nsplit, int K2) {
   __shared__ float red[4][64][4];
   const int n0 = blockIdx.x * 16;
   const int K = n0 >= nsplit ? K2 : Kall;            // the output columns from nsplit on only contract the first K2 k-values
+#ifdef TN_LAT_STAMPS   // tuning builds only: when the first / middle / last workgroup start and end (100 MHz ticks)
+  const int wgid = blockIdx.y * gridDim.x + blockIdx.x, nwg = gridDim.x * gridDim.y;
+  const int slot = wgid == 0 ? 0 : wgid == nwg / 2 ? 1 : wgid == nwg - 1 ? 2 : -1;
+  if (slot >= 0 && threadIdx.x == 0) g_lat_stamps[2 * slot] = wall_clock64();
+  if (slot == 0 && threadIdx.x == 0) g_lat_stamps[6] = __builtin_amdgcn_s_memtime();
+#endif
   lat_tile_f32(X, ldx, Wt, ldw, bias, Y, ldy, M, N, K, blockIdx.y * 16, n0, threadIdx.x >> 6, threadIdx.x & 63, red);
+#ifdef TN_LAT_STAMPS
+  if (slot >= 0 && threadIdx.x == 0) g_lat_stamps[2 * slot + 1] = wall_clock64();
+  if (slot == 0 && threadIdx.x == 0) g_lat_stamps[7] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 }  // namespace
 
+#ifdef TN_LAT_STAMPS
+extern "C" int tn_dbg_lat_stamps(long long *out) {
+  TN_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lat_stamps), sizeof(long long) * 8));
+  return TN_OK;
+}
+#endif
 int launch_linear_f32_lat(const float *X, int ldx, const float *Wt, int ldw, const float *bias, float *Y, int ldy, int M, int N, int K,
                           hipStream_t s) {
   return launch_linear_f32_lat2(X, ldx, Wt, ldw, bias, Y, ldy, M, N, K, N, K, s);
