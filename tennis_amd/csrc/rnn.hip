@@ -152,6 +152,140 @@ __global__ __launch_bounds__(MAXT) void rnn_recurrent_kernel(
   }
 }
 
+// The same recurrence for the blocks whose weight columns do not fit the registers (G*H > 512: GRU / LSTM with H = 256, the
+// captioner's encoder), one batch row per workgroup.  What bounded the kernel above there, per step: the L1 fill of the streamed
+// weights (160 of 256 k-values x 768 rows x 4 B = 480 KB at 64 B/clk), the LDS pipe (every lane reading the same h values:
+// 64 ds_read_b128 per wave) and the latency of the step's gi loads behind the barrier.  Here
+//   * the k-values of a thread's column are split three ways: KR in registers, KL in LDS ([k/4][row][4]: conflict-free 16-byte
+//     reads; as much as the 160 KB hold), the rest streamed with 16 loads in flight;
+//   * h is not read per FMA: a lane reads 16 bytes per 16 k-values (lane l holds h[k0 + 4 (l mod 4) + e], e = 0..3) and the FMAs
+//     take their h operand through DPP quad_perm:[j,j,j,j] (v_fmac_f32_dpp: lane j of the quad, broadcast to the quad) -
+//     4 x fewer LDS instructions, no extra VALU work;
+//   * the step's gi values are requested before the dot product.
+// The dot product still runs over k in ascending order with one accumulator: results are bit-identical to the kernel above.
+#define TN_FMA_Q(ACC, HREG, W, J)                                                                              \
+  asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[" #J "," #J "," #J "," #J "] row_mask:0xf bank_mask:0xf"  \
+               : "+v"(ACC) : "v"(HREG), "v"(W))
+// 16 k-values k0 .. k0+15: WV(i) is the weight of k0 + i
+#define TN_DOT16(ACC, HQ, WV)                                                                                          \
+  do {                                                                                                                 \
+    TN_FMA_Q(ACC, HQ.x, WV(0), 0);  TN_FMA_Q(ACC, HQ.y, WV(1), 0);  TN_FMA_Q(ACC, HQ.z, WV(2), 0);  TN_FMA_Q(ACC, HQ.w, WV(3), 0);   \
+    TN_FMA_Q(ACC, HQ.x, WV(4), 1);  TN_FMA_Q(ACC, HQ.y, WV(5), 1);  TN_FMA_Q(ACC, HQ.z, WV(6), 1);  TN_FMA_Q(ACC, HQ.w, WV(7), 1);   \
+    TN_FMA_Q(ACC, HQ.x, WV(8), 2);  TN_FMA_Q(ACC, HQ.y, WV(9), 2);  TN_FMA_Q(ACC, HQ.z, WV(10), 2); TN_FMA_Q(ACC, HQ.w, WV(11), 2);  \
+    TN_FMA_Q(ACC, HQ.x, WV(12), 3); TN_FMA_Q(ACC, HQ.y, WV(13), 3); TN_FMA_Q(ACC, HQ.z, WV(14), 3); TN_FMA_Q(ACC, HQ.w, WV(15), 3);  \
+  } while (0)
+template <int G, int KR, int KL, int MAXT>
+__global__ __launch_bounds__(MAXT) void rnn_recurrent_big_kernel(
+    const float *__restrict__ gi, int ldgi, const float *__restrict__ whT, const float *__restrict__ bh,
+    const int32_t *__restrict__ valid_len, float *__restrict__ seq, int ldo, float *__restrict__ h_last,
+    float *__restrict__ c_last, float *__restrict__ save, int B, int T, int H) {
+  static_assert(KR % 16 == 0 && KL % 16 == 0, "whole 16-wide h chunks");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int GH = G * H;
+  float *hs = lds;                 // [H]
+  float *gh = hs + H;              // [GH]
+  float *cs = gh + GH;             // [H] (LSTM)
+  float *wl = cs + H;              // [KL/4][GH][4]
+  const int j = threadIdx.x, lane4 = (j & 3) * 4;
+  const int dir = blockIdx.y, bg = blockIdx.x;
+  const float *wcol = whT + (long)dir * H * GH + j;
+  const float bj = bh[dir * GH + j];
+  float wr[KR];
+#pragma unroll
+  for (int k = 0; k < KR; ++k) wr[k] = wcol[(long)k * GH];
+  for (int k4 = 0; k4 < KL / 4; ++k4) {
+    float4 v;
+    v.x = wcol[(long)(KR + 4 * k4 + 0) * GH]; v.y = wcol[(long)(KR + 4 * k4 + 1) * GH];
+    v.z = wcol[(long)(KR + 4 * k4 + 2) * GH]; v.w = wcol[(long)(KR + 4 * k4 + 3) * GH];
+    *(float4 *)(wl + ((long)k4 * GH + j) * 4) = v;
+  }
+  if (j < H) {
+    hs[j] = 0.f;
+    if (G == 4) cs[j] = 0.f;
+  }
+  const int vlen = valid_len ? valid_len[bg] : T;
+  __syncthreads();
+
+  for (int s = 0; s < T; ++s) {
+    // this step's input pre-activations of the units the thread finishes below (requested now, used after the barrier)
+    const bool live = j < H && s < vlen;
+    const int ti = dir ? (vlen - 1 - s) : s;
+    float gq[G];
+    if (live) {
+      const float *g = gi + ((long)bg * T + ti) * ldgi + dir * GH;
+#pragma unroll
+      for (int e = 0; e < G; ++e) gq[e] = g[e * H + j];
+    }
+    float acc = bj;
+#pragma unroll
+    for (int k = 0; k < KR; k += 16) {
+      const float4 hq = *(const float4 *)(hs + k + lane4);
+#define TN_WV(i) wr[k + (i)]
+      TN_DOT16(acc, hq, TN_WV);
+#undef TN_WV
+    }
+#pragma unroll
+    for (int k = 0; k < KL; k += 16) {
+      const float4 hq = *(const float4 *)(hs + KR + k + lane4);
+      float w[16];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 v = *(const float4 *)(wl + ((long)(k / 4 + i) * GH + j) * 4);
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+      }
+#define TN_WV(i) w[i]
+      TN_DOT16(acc, hq, TN_WV);
+#undef TN_WV
+    }
+    for (int k = KR + KL; k < H; k += 16) {         // (H % 16 == 0 for this kernel)
+      float w[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) w[i] = wcol[(long)(k + i) * GH];
+      const float4 hq = *(const float4 *)(hs + k + lane4);
+#define TN_WV(i) w[i]
+      TN_DOT16(acc, hq, TN_WV);
+#undef TN_WV
+    }
+    gh[j] = acc;
+    __syncthreads();
+    if (live) {
+      const int u = j;
+      float hn;
+      if (G == 3) {
+        const float r = sigmoidf_(gq[0] + gh[u]);
+        const float z = sigmoidf_(gq[1] + gh[H + u]);
+        const float n = tanhf(gq[2] + r * gh[2 * H + u]);
+        hn = (1.f - z) * n + z * hs[u];
+        if (save) {
+          float *sv = save + ((long)dir * B * T + (long)bg * T + ti) * (4 * H);
+          sv[u] = r; sv[H + u] = z; sv[2 * H + u] = n; sv[3 * H + u] = gh[2 * H + u];
+        }
+      } else {
+        const float ig = sigmoidf_(gq[0] + gh[u]);
+        const float fg = sigmoidf_(gq[1] + gh[H + u]);
+        const float gg = tanhf(gq[2] + gh[2 * H + u]);
+        const float og = sigmoidf_(gq[G - 1] + gh[3 * H + u]);
+        const float c2 = fg * cs[u] + ig * gg;
+        cs[u] = c2;
+        hn = og * tanhf(c2);
+        if (save) {
+          float *sv = save + ((long)dir * B * T + (long)bg * T + ti) * (5 * H);
+          sv[u] = ig; sv[H + u] = fg; sv[2 * H + u] = gg; sv[3 * H + u] = og; sv[4 * H + u] = c2;
+        }
+      }
+      hs[u] = hn;
+      seq[((long)bg * T + ti) * ldo + dir * H + u] = hn;
+    }
+    __syncthreads();
+  }
+  if (j < H) {
+    if (h_last) h_last[((long)dir * B + bg) * H + j] = hs[j];
+    if (c_last && G == 4) c_last[((long)dir * B + bg) * H + j] = cs[j];
+  }
+}
+#undef TN_DOT16
+#undef TN_FMA_Q
+
 __global__ void temporal_pool_kernel(const float *__restrict__ x, int B, int T, int F, int kind,
                                      float *__restrict__ y) {
   const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -203,6 +337,25 @@ int launch_rnn_recurrent(int gates, const float *gi, int ldgi, const float *whT,
     else if (kr == 64) TN_RNN_LAUNCH(G_, NB_, 64, 1024);       \
     else TN_RNN_LAUNCH(G_, NB_, 0, 1024);                      \
   } while (0)
+  // one row per workgroup and a column that does not fit the registers (H = 256): registers + LDS + stream, h through DPP
+  if (nb == 1 && H == 256) {
+    constexpr int KR3 = 96, KL3 = 48, KR4 = 64, KL4 = 32;
+    const int kl = gates == 3 ? KL3 : KL4;
+    const size_t lds2 = (size_t)(2 * H + gates * H + kl * gates * H) * sizeof(float);
+    if (gates == 3) {
+      TN_SET_ATTR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void *)rnn_recurrent_big_kernel<3, KR3, KL3, 768>,
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      hipLaunchKernelGGL((rnn_recurrent_big_kernel<3, KR3, KL3, 768>), grid, block, lds2, s, gi, ldgi, whT, bh, valid_len, seq, ldo, h_last,
+                         c_last, save, B, T, H);
+    } else {
+      TN_SET_ATTR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void *)rnn_recurrent_big_kernel<4, KR4, KL4, 1024>,
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      hipLaunchKernelGGL((rnn_recurrent_big_kernel<4, KR4, KL4, 1024>), grid, block, lds2, s, gi, ldgi, whT, bh, valid_len, seq, ldo, h_last,
+                         c_last, save, B, T, H);
+    }
+    TN_HIP_CHECK(hipGetLastError());
+    return TN_OK;
+  }
   // (register-resident weights only with one row per workgroup: with four the unrolled prefix spills)
   if (gates == 3) { if (nb == 4) TN_RNN_LAUNCH(3, 4, 0, 1024); else TN_RNN_PICK(3, 1); }
   else { if (nb == 4) TN_RNN_LAUNCH(4, 4, 0, 1024); else TN_RNN_PICK(4, 1); }
