@@ -97,7 +97,17 @@ __global__ __launch_bounds__(kBeamThreads) void dec_attention_kernel(
   extern __shared__ float sm[];   // q[H] | w[Tp] | part[16 * max(Tp, H)]
   const int Tp = (T + 3) & ~3;
   float *q = sm, *w = q + H, *part = w + Tp;
-  const long r = blockIdx.x;
+  // workgroup -> decoder row: workgroups go to the 8 XCDs round robin, and the `beam` rows of a clip read the same key projection
+  // and memory (2 T H floats): rows of one clip are given to workgroups of one XCD, so that a clip's data sits in one L2
+  // (4 MB each) instead of `beam` of them
+  long r = blockIdx.x;
+  {
+    const int nclips = (int)gridDim.x / beam, full = (nclips / 8) * 8 * beam, id = blockIdx.x;
+    if (id < full) {
+      const int slot = id >> 3;
+      r = (long)((id & 7) + 8 * (slot / beam)) * beam + slot % beam;
+    }
+  }
   const int b = (int)(r / beam), t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int vl = min(max(valid_len[b], 0), T);
   const float inv = 1.0f / sqrtf((float)H);
