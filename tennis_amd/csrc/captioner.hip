@@ -69,10 +69,23 @@ __device__ long long g_dec_stamps[24];
 // outputs are dealt over 64 / 128 / 256 threads and the remaining factor of the 1024 threads (16 / 8 / 4) splits the
 // contraction, the partial sums meet in LDS.  Each of these loops used to be one scalar load + one LDS read per FMA row:
 // the LDS pipe (every lane reading the same broadcast value) and the number of loads in flight bound them, not the bytes.
-__device__ __host__ __forceinline__ int step_groups(int n4) { return n4 <= 64 ? 64 : n4 <= 128 ? 128 : 256; }
-static size_t att_lds_bytes(int T, int H) {      // q[H] | w[Tp] | part[16 * max(Tp, H)]
+// `split` (16, 8, 4, 2 or 1) caps the number of partial sums: the host lowers it when 16 partial rows do not fit the LDS
+// (a wide beam with a large vocabulary, a very long source).
+__device__ __host__ __forceinline__ int step_groups(int n4, int split) {
+  const int g = n4 <= 64 ? 64 : n4 <= 128 ? 128 : 256, floor_g = 1024 / split;
+  return g > floor_g ? g : floor_g;
+}
+static size_t att_lds_bytes(int T, int H, int split) {      // q[H] | w[Tp] | part[partials * max(Tp, H)]
   const int Tp = (T + 3) & ~3;
-  return ((size_t)H + Tp + (size_t)16 * (Tp > H ? Tp : H)) * sizeof(float);
+  const int hg = 1024 / step_groups(Tp / 4, split), sg = 1024 / step_groups(H / 4, split);
+  const size_t a = (size_t)hg * Tp, b = (size_t)sg * H;
+  return ((size_t)H + Tp + (a > b ? a : b)) * sizeof(float);
+}
+// the largest split whose attention kernel fits the step kernels' LDS (0: not even one partial row does)
+static int att_split(int T, int H, size_t limit) {
+  for (int sp = 16; sp >= 1; sp >>= 1)
+    if (att_lds_bytes(T, H, sp) <= limit) return sp;
+  return 0;
 }
 // Beam-search step, first launch, one workgroup (16 waves) per decoder row (the step is latency-bound - few workgroups,
 // dependent L2 round trips - so it pays to spread the rows over CUs even though the beams of a clip each re-read the clip's key
@@ -89,7 +102,7 @@ __global__ __launch_bounds__(kBeamThreads) void dec_attention_kernel(
     const float *__restrict__ kpT, const float *__restrict__ mem, const int32_t *__restrict__ valid_len,
     float *__restrict__ ctx, int beam, int rows, int T, int H, float *__restrict__ wsave = nullptr,
     const int32_t *__restrict__ tok = nullptr, const int32_t *__restrict__ par = nullptr, const float *__restrict__ ew = nullptr,
-    const float *__restrict__ p0 = nullptr) {
+    const float *__restrict__ p0 = nullptr, int split = 16) {
   // ew != NULL (beam search, two decoder layers, from the second step on): the row's pre-activations are put together here,
   // g = ew[tok[row]] + p0[parent row] (dec_beam_kernel), and h_prev / c_prev are the PARENT row's (hprev / cprev then hold
   // the previous step's new states, one row per beam, pitch ldh / H)
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(kBeamThreads) void dec_attention_kernel(
   __syncthreads();
   DEC_STAMP(1);
   // ---- scores: thread = (slice of H, four source steps); HG partial sums per step ----
-  const int S4 = (vl + 3) >> 2, CG = step_groups(S4), HG = kBeamThreads / CG;
+  const int S4 = (vl + 3) >> 2, CG = step_groups(S4, split), HG = kBeamThreads / CG;
   {
     const int hg = t / CG, hn_ = (H + HG - 1) / HG, h0 = hg * hn_, h1 = min(H, h0 + hn_);
     const float *kp = kpT + (long)b * H * Tp;
@@ -200,7 +213,7 @@ __global__ __launch_bounds__(kBeamThreads) void dec_attention_kernel(
   __syncthreads();
   DEC_STAMP(3);
   // ---- context: thread = (slice of the valid steps, four units); SG partial sums per unit; weights beyond valid_len are 0 ----
-  const int U4 = H >> 2, CG2 = step_groups(U4), SG = kBeamThreads / CG2;
+  const int U4 = H >> 2, CG2 = step_groups(U4, split), SG = kBeamThreads / CG2;
   {
     const int sg = t / CG2, sn = (vl + SG - 1) / SG, s0 = sg * sn, s1 = min(vl, s0 + sn);
     const float *mv = mem + (long)b * T * H;
@@ -372,7 +385,7 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
     const float *__restrict__ emb, int H, int E, int V, int beam, int step, float lp, float prev_lp, int eos,
     float *__restrict__ scores, int32_t *__restrict__ alive, int32_t *__restrict__ vlen,
     int32_t *__restrict__ bp_par, int32_t *__restrict__ bp_word, int R, int32_t *__restrict__ any_alive,
-    float *__restrict__ hstate, int32_t *__restrict__ parent_out, int32_t *__restrict__ tok_out, int nclips, LatGemmArgs gm) {
+    float *__restrict__ hstate, int32_t *__restrict__ parent_out, int32_t *__restrict__ tok_out, int nclips, LatGemmArgs gm, int split) {
   // hstate != NULL: use_residual (gnmt.py:394-395) - the projection sees h + the cell's input x1[:, 0:H], the recurrent
   // state stays h and goes through this (R,H) scratch; parent_out: the chosen parent beam of every row, for the states of
   // the decoder layers between the first and the last one (num_layers > 2)
@@ -421,7 +434,7 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
   __syncthreads();
   DEC_STAMP(9);
   // ---- projection: thread = (slice of K, four vocabulary columns), see step_groups; KQ partial sums per logit ----
-  const int Vp = (V + 3) & ~3, V4 = Vp >> 2, CGv = step_groups(V4), KQ = kBeamThreads / CGv;
+  const int Vp = (V + 3) & ~3, V4 = Vp >> 2, CGv = step_groups(V4, split), KQ = kBeamThreads / CGv;
   {
     constexpr int NLD = NBM <= 5 ? 16 : NBM <= 8 ? 8 : 2;      // 16-byte loads in flight (registers: NBM float4 sums beside them)
     const int kq = t / CGv, kn = (H + KQ - 1) / KQ, k0 = kq * kn, k1 = min(H, k0 + kn);
@@ -1284,11 +1297,15 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
   const int K0 = E + 2 * H, K1 = 3 * H;
   const bool lstm = g->G == 4;
   const int nbm = beam <= 4 ? 4 : beam == 5 ? 5 : beam <= 8 ? 8 : 16;   // beam 5: the reference's flag default
-  const size_t att_lds = att_lds_bytes(T, H);
+  const int asplit = att_split(T, H, kStepLdsMax);
   const int Vp = (V + 3) & ~3;
-  const size_t beam_lds = ((size_t)2 * ((nbm + 3) & ~3) * H + (size_t)(1 + kBeamThreads / step_groups(Vp / 4)) * beam * Vp + 16) * sizeof(float);
-  TN_REQUIRE(beam_lds <= kStepLdsMax && att_lds <= kStepLdsMax,
-             "tn_gnmt_beam_search: beam * (2*hidden + 17*vocab) floats or 18 * max(hidden, source length) floats exceed the step kernels' 152 KiB of LDS");
+  auto beam_lds_of = [&](int sp) { return ((size_t)2 * ((nbm + 3) & ~3) * H + (size_t)(1 + kBeamThreads / step_groups(Vp / 4, sp)) * beam * Vp + 16) * sizeof(float); };
+  int bsplit = 16;
+  while (bsplit > 1 && beam_lds_of(bsplit) > kStepLdsMax) bsplit >>= 1;
+  const size_t beam_lds = beam_lds_of(bsplit);
+  TN_REQUIRE(beam_lds <= kStepLdsMax && asplit > 0,
+             "tn_gnmt_beam_search: beam * (2*hidden + 2*vocab) or 3 * max(hidden, source length) floats exceed the step kernels' 152 KiB of LDS");
+  const size_t att_lds = att_lds_bytes(T, H, asplit);
   if (int rc = allow_lds(dec_attention_kernel<1>, att_lds)) return rc;
   if (int rc = nbm == 4 ? allow_lds(dec_beam_kernel<4>, beam_lds) : nbm == 5 ? allow_lds(dec_beam_kernel<5>, beam_lds)
                : nbm == 8 ? allow_lds(dec_beam_kernel<8>, beam_lds) : allow_lds(dec_beam_kernel<16>, beam_lds)) return rc;
@@ -1337,12 +1354,13 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
       if (rc) return rc;
       hipLaunchKernelGGL(dec_attention_kernel<1>, dim3(R), dim3(kBeamThreads), att_lds, s, (const float *)g->g0,
                          (const float *)(g->sx0 + E + H), K0, (const float *)g->c0cur, lstm ? 1 : 0, h0buf[cur], c0buf[cur], x_after0, ld_after0,
-                         (const float *)g->keyprojT, (const float *)g->mem, (const int32_t *)g->vl, g->ctxn, beam, 1, T, H);
+                         (const float *)g->keyprojT, (const float *)g->mem, (const int32_t *)g->vl, g->ctxn, beam, 1, T, H,
+                         (float *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, (const float *)nullptr, (const float *)nullptr, asplit);
     } else {
       hipLaunchKernelGGL(dec_attention_kernel<1>, dim3(R), dim3(kBeamThreads), att_lds, s, (const float *)nullptr,
                          (const float *)h0buf[cur ^ 1], H, (const float *)c0buf[cur ^ 1], lstm ? 1 : 0, h0buf[cur], c0buf[cur], x_after0, ld_after0,
                          (const float *)g->keyprojT, (const float *)g->mem, (const int32_t *)g->vl, g->ctxn, beam, 1, T, H,
-                         (float *)nullptr, (const int32_t *)g->tok, (const int32_t *)g->parent, (const float *)g->ew, (const float *)g->p0);
+                         (float *)nullptr, (const int32_t *)g->tok, (const int32_t *)g->parent, (const float *)g->ew, (const float *)g->p0, asplit);
     }
     for (int j = 0; j < nmid; ++j) {
       GnmtMid &m = g->mid[j];
@@ -1363,7 +1381,7 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
                      (const float *)g->bpp, (const float *)g->h0n, (const float *)g->ctxn, (const float *)g->c0n, g->sx0, \
                      g->c0cur, (const float *)g->emb, H, E, V, beam, step, lp, prev_lp, eos, g->scores, g->alive,         \
                      g->vlen, g->bp_par, g->bp_word, R, g->flag, g->hstate, g->parent,                                    \
-                     fused0 ? g->tok : (int32_t *)nullptr, B, gm)
+                     fused0 ? g->tok : (int32_t *)nullptr, B, gm, bsplit)
     if (nbm == 4) TN_BEAM_LAUNCH(4);
     else if (nbm == 5) TN_BEAM_LAUNCH(5);
     else if (nbm == 8) TN_BEAM_LAUNCH(8);
@@ -1415,8 +1433,9 @@ extern "C" int tn_gnmt_decode_seq(tn_gnmt *g, const int32_t *tgt, int ld, int st
   const int B = g->B, T = g->T, H = g->H, E = g->E, V = g->V, R = B, K0 = E + 2 * H, K1 = 3 * H;
   const bool lstm = g->G == 4;
   const int nb = (R * H + 255) / 256;
-  const size_t att_lds = att_lds_bytes(T, H);
-  TN_REQUIRE(att_lds <= kStepLdsMax, "tn_gnmt_decode_seq: 18 * max(hidden, source length) floats exceed the step kernel's 152 KiB of LDS");
+  const int asplit = att_split(T, H, kStepLdsMax);
+  TN_REQUIRE(asplit > 0, "tn_gnmt_decode_seq: 3 * max(hidden, source length) floats exceed the step kernel's 152 KiB of LDS");
+  const size_t att_lds = att_lds_bytes(T, H, asplit);
   if (int rc = allow_lds(dec_attention_kernel<1>, att_lds)) return rc;
   const int NL = g->NL, nmid = NL - 2;
   auto hinit = [&](int i) { return (const float *)(g->hl[i] + (i < g->NBI ? (size_t)B * H : 0)); };
@@ -1436,7 +1455,8 @@ extern "C" int tn_gnmt_decode_seq(tn_gnmt *g, const int32_t *tgt, int ld, int st
     if (rc) return rc;
     hipLaunchKernelGGL(dec_attention_kernel<1>, dim3(R), dim3(kBeamThreads), att_lds, s, (const float *)g->g0,
                        (const float *)(g->sx0 + E + H), K0, (const float *)g->c0cur, lstm ? 1 : 0, g->h0n, g->c0n, x_after0, K1,
-                       (const float *)g->keyprojT, (const float *)g->mem, (const int32_t *)g->vl, g->ctxn, 1, 1, T, H);
+                       (const float *)g->keyprojT, (const float *)g->mem, (const int32_t *)g->vl, g->ctxn, 1, 1, T, H,
+                       (float *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, (const float *)nullptr, (const float *)nullptr, asplit);
     for (int j = 0; j < nmid; ++j) {
       GnmtMid &m = g->mid[j];
       rc = launch_linear_f32_lat(m.sx, K1, m.w, K1, m.b, m.g, 4 * H, R, 4 * H, K1, s);
@@ -1722,9 +1742,10 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
   const int K0 = E + 2 * H, K1 = 3 * H;
   const int BT = B * T, LB = L * B;
   const bool lstm = G == 4;
-  const size_t att_lds = att_lds_bytes(T, H);
+  const int asplit = att_split(T, H, kStepLdsMax);
   const size_t attb_lds = (size_t)(2 * H + T + 256) * sizeof(float);
-  TN_REQUIRE(att_lds <= kStepLdsMax && attb_lds <= kStepLdsMax, "tn_gnmt_trainer: 18 * max(hidden, source length) floats exceed 152 KiB of LDS");
+  TN_REQUIRE(asplit > 0 && attb_lds <= kStepLdsMax, "tn_gnmt_trainer: 3 * max(hidden, source length) floats exceed 152 KiB of LDS");
+  const size_t att_lds = att_lds_bytes(T, H, asplit);
   if (int rc = allow_lds(dec_attention_kernel<1>, att_lds)) return rc;
   if (int rc = allow_lds(trn_att_bwd_kernel, attb_lds)) return rc;
   float *w = t->w, *g = t->g;
@@ -1782,7 +1803,8 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
     const float *c0p = !lstm ? nul : i ? (const float *)(d0.C + sp * H) : c_init(0);
     hipLaunchKernelGGL(dec_attention_kernel<1>, dim3(B), dim3(kBeamThreads), att_lds, s, (const float *)(d0.G + so * 4 * H), (const float *)(X0 + E + H), K0,
                        c0p, lstm ? 1 : 0, t->h0tmp, lstm ? d0.C + so * H : (float *)nullptr, X1, K1, (const float *)t->keyprojT, mem,
-                       (const int32_t *)t->vl, t->ctxtmp, 1, 1, T, H, t->AW + so * T);
+                       (const int32_t *)t->vl, t->ctxtmp, 1, 1, T, H, t->AW + so * T, (const int32_t *)nullptr, (const int32_t *)nullptr,
+                       (const float *)nullptr, (const float *)nullptr, asplit);
     for (int j = 1; j < NL; ++j) {
       TrnDec &d = t->dec[j];
       const bool top = j == NL - 1;

@@ -93,6 +93,10 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
                                              const uint16_t *__restrict__ fast, int16_t *__restrict__ coef, uint32_t first_block,
                                              uint32_t max_blocks, int *__restrict__ err) {
   uint32_t nblk = 0;
+  // the Huffman tables of the MCU's slots, 4 bits each (DC id | AC id << 2), in one register pair: picking the symbol's table
+  // is then arithmetic instead of a dependent load from the frame record in every symbol's chain
+  uint64_t tabs = 0;
+  for (int i = 0; i < g.bpm; ++i) tabs |= (uint64_t)((f.slot_dc[i] & 3) | ((f.slot_ac[i] & 3) << 2)) << (4 * i);
   const uint16_t *lut_base = luts + (size_t)f.lut * 8 * LUT_SIZE;
   const uint16_t *fast_base = fast;      // this file's first-level tables (LDS copy when the workgroup staged its set)
   const uint32_t stop = sub_end < rd.end ? sub_end : rd.end;
@@ -141,7 +145,8 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
     // one symbol, DC difference (F.2.2.1) and AC coefficient (F.2.2.2) through the same straight-line code: the lanes of a
     // wave are at different places of their blocks, a branch per symbol kind would run both sides for every symbol
     const bool dc = k == 0;
-    const int table = dc ? f.slot_dc[slot] : 4 + f.slot_ac[slot];
+    const uint32_t tb = (uint32_t)(tabs >> (4 * slot));
+    const int table = dc ? (int)(tb & 3u) : 4 + (int)((tb >> 2) & 3u);
     uint16_t e = fast_base[table * FAST_SIZE + (uint32_t)(buf >> (64 - FAST_BITS))];
     if (e == 0) e = lut_base[(size_t)table * LUT_SIZE + (uint32_t)(buf >> 48)];
     int len = e >> 8;

@@ -48,6 +48,10 @@ def _case(seed, B, T, F, H, E, V, beam, max_length, eos_bias=0.0, proj_scale=1.0
     dict(seed=12, B=4, T=15, F=40, H=32, E=16, V=40, beam=4, max_length=24, proj_scale=30.0, nl=4, nbi=1, res=True),
     dict(seed=13, B=3, T=15, F=40, H=32, E=16, V=40, beam=4, max_length=24, proj_scale=30.0, nl=2, nbi=1, res=True, cell="lstm"),
     dict(seed=14, B=3, T=15, F=40, H=32, E=16, V=40, beam=3, max_length=20, proj_scale=30.0, nl=3, nbi=0, res=True),
+    # shapes whose 16-way partial sums do not fit the step kernels' LDS (the split is lowered): wide beam x full vocabulary x H = 256,
+    # a source of 2500 steps
+    dict(seed=15, B=2, T=30, F=64, H=256, E=100, V=254, beam=10, max_length=12, proj_scale=30.0),
+    dict(seed=16, B=1, T=2500, F=16, H=32, E=16, V=40, beam=3, max_length=8, proj_scale=30.0),
 ])
 def test_beam_search_matches_oracle(cfg, report):
     (mem, s, sc, vl), (rmem, rs, rsc, rvl) = _case(**cfg)
