@@ -892,20 +892,25 @@ __global__ void trn_lstm_bwd_kernel(const float *__restrict__ g, const float *__
   dcz[id] = dct * fg;
 }
 
-// attention backward for one decoder row per workgroup (256 threads): ctx = sum_t w_t mem_t, w = masked softmax of
-// s_t = q . kp_t, q = h0 / sqrt(H).  dctx = up to two addends.  Accumulates into dmem, dkp (B,T,H); writes dq / sqrt(H).
+// Backward of one decoder step's attention (scaled Luong: ctx = sum_t w_t mem_t, w = softmax(s), s_t = q . kp_t, q = h0 / sqrt(H)) for
+// one clip: dctx = up to two addends; dw_t = mem_t . dctx; ds = w (dw - w . dw); dq = sum_t ds_t kp_t -> dh0 = dq / sqrt(H).
+// The step's share of d mem and d keyproj is NOT accumulated here (that was a read-modify-write of 2 T H floats per clip and
+// step behind one workgroup, 123 us per step at config C5): the step only leaves ds (L,B,T) and dctx (L,B,H) behind, and
+// trn_att_outer_kernel forms d mem = sum over steps of w (x) dctx and d keyproj = sum of ds (x) q once after the loop.
 __global__ __launch_bounds__(256) void trn_att_bwd_kernel(const float *__restrict__ aw, const float *__restrict__ mem,
                                                           const float *__restrict__ keyproj, const float *__restrict__ h0,
                                                           int ldh, const float *c0, int lc0, const float *c1, int lc1,
-                                                          const int32_t *__restrict__ valid_len, float *__restrict__ dmem,
-                                                          float *__restrict__ dkp, float *__restrict__ dh0, int T, int H) {
+                                                          const int32_t *__restrict__ valid_len, float *__restrict__ ds_out,
+                                                          float *__restrict__ dctx_out, float *__restrict__ dh0, int T, int H) {
   extern __shared__ float sm[];    // dctx[H] | q[H] | ds[T] | red[256]
   float *dctx = sm, *q = sm + H, *ds = q + H, *red = ds + T;
   const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int vl = min(max(valid_len[b], 0), T);
   const float inv = 1.0f / sqrtf((float)H);
   for (int u = t; u < H; u += 256) {
-    dctx[u] = (c0 ? c0[(long)b * lc0 + u] : 0.f) + (c1 ? c1[(long)b * lc1 + u] : 0.f);
+    const float d = (c0 ? c0[(long)b * lc0 + u] : 0.f) + (c1 ? c1[(long)b * lc1 + u] : 0.f);
+    dctx[u] = d;
+    dctx_out[(long)b * H + u] = d;
     q[u] = h0[(long)b * ldh + u] * inv;
   }
   __syncthreads();
@@ -926,19 +931,47 @@ __global__ __launch_bounds__(256) void trn_att_bwd_kernel(const float *__restric
   for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
   const float dot = red[0];
   __syncthreads();
-  for (int s = t; s < vl; s += 256) ds[s] = w[s] * (ds[s] - dot);
+  for (int s = t; s < T; s += 256) {
+    const float v = s < vl ? w[s] * (ds[s] - dot) : 0.f;
+    ds[s] = v;
+    ds_out[(long)b * T + s] = v;
+  }
   __syncthreads();
-  // dmem_t += w_t dctx ; dkp_t += ds_t q ; dq = sum_t ds_t kp_t
+  // dq = sum_t ds_t kp_t, 16 loads in flight
   for (int u = t; u < H; u += 256) {
     float dq = 0.f;
-    const float dc = dctx[u], qu = q[u];
-    for (int s = 0; s < vl; ++s) {
-      const long o = ((long)b * T + s) * H + u;
-      dmem[o] += w[s] * dc;
-      dkp[o] += ds[s] * qu;
-      dq = fmaf(ds[s], kp[(long)s * H + u], dq);
+    int s = 0;
+    for (; s + 16 <= vl; s += 16) {
+      float kv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) kv[i] = kp[(long)(s + i) * H + u];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dq = fmaf(ds[s + i], kv[i], dq);
     }
+    for (; s < vl; ++s) dq = fmaf(ds[s], kp[(long)s * H + u], dq);
     dh0[(long)b * H + u] = dq * inv;
+  }
+}
+
+// d mem (B,T,H) = sum over the `steps` decoder steps of w_step (x) dctx_step, d keyproj = sum of ds_step (x) h0_step / sqrt(H):
+// thread = (source step, four units), the steps' factors are (steps, B, T) / (steps, B, H) arrays (h0: pitch ldh per row).
+__global__ __launch_bounds__(256) void trn_att_outer_kernel(const float *__restrict__ aw, const float *__restrict__ ds,
+                                                            const float *__restrict__ dctx, const float *__restrict__ h0, int ldh,
+                                                            float *__restrict__ dmem, float *__restrict__ dkp, int steps, int B, int T, int H) {
+  const int b = blockIdx.y, u4 = threadIdx.x & 63, s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= T) return;
+  const float inv = 1.0f / sqrtf((float)H);
+  for (int u = 4 * u4; u < H; u += 256) {
+    float4 am = make_float4(0.f, 0.f, 0.f, 0.f), ak = am;
+    for (int l = 0; l < steps; ++l) {
+      const long r = (long)l * B + b;
+      const float w = aw[r * T + s], d = ds[r * T + s] * inv;
+      const float4 c = *(const float4 *)(dctx + r * H + u), q = *(const float4 *)(h0 + r * ldh + u);
+      am.x = fmaf(w, c.x, am.x); am.y = fmaf(w, c.y, am.y); am.z = fmaf(w, c.z, am.z); am.w = fmaf(w, c.w, am.w);
+      ak.x = fmaf(d, q.x, ak.x); ak.y = fmaf(d, q.y, ak.y); ak.z = fmaf(d, q.z, ak.z); ak.w = fmaf(d, q.w, ak.w);
+    }
+    *(float4 *)(dmem + ((long)b * T + s) * H + u) = am;
+    *(float4 *)(dkp + ((long)b * T + s) * H + u) = ak;
   }
 }
 
@@ -1582,6 +1615,7 @@ struct tn_gnmt_trainer {
   std::vector<TrnEnc> enc;
   std::vector<TrnDec> dec;
   float *wpT, *wkT;
+  float *DS, *DCTX;          // per decoder step: the attention scores' gradient (L,B,T) and the context's (L,B,H)
   float *keyproj, *keyprojT, *AW, *h0tmp, *ctxtmp, *logits, *lossrows, *Out, *dlog, *dOut, *dq, *dkp, *tmpA, *tmpB, *tmpM, *tmpAtt;
   int32_t *vl, *tvl;
   float drop_p;
@@ -1697,7 +1731,7 @@ extern "C" int tn_gnmt_trainer_create_ex(tn_ctx *ctx, const tn_param *params, in
     d.dG = fl(LB * 4 * H); d.dX = fl(LB * K); d.dhz = fl(B * H); d.dcz = fl(B * H); d.dW = fl(4 * H * K); d.db = fl(4 * H);
   }
   t->wpT = fl(V * H); t->wkT = fl(H * H);
-  t->keyproj = fl(BT * H); t->keyprojT = fl(B * ((T + 3) & ~(size_t)3) * H); t->AW = fl(LB * T); t->h0tmp = fl(B * H); t->ctxtmp = fl(B * H);
+  t->keyproj = fl(BT * H); t->keyprojT = fl(B * ((T + 3) & ~(size_t)3) * H); t->AW = fl(LB * T); t->DS = fl(LB * T); t->DCTX = fl(LB * H); t->h0tmp = fl(B * H); t->ctxtmp = fl(B * H);
   t->logits = fl(LB * V); t->lossrows = fl(LB); t->Out = fl(LB * H); t->dlog = fl(LB * V); t->dOut = fl(LB * H); t->dq = fl(B * H);
   t->dkp = fl(BT * H); t->tmpA = fl(B * H); t->tmpB = fl(B * H); t->tmpM = fl(B * H); t->tmpAtt = fl(B * H);
   t->vl = t->pool.alloc<int32_t>(B); t->tvl = t->pool.alloc<int32_t>(B);
@@ -1827,9 +1861,7 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
   TN_TRY(launch_linear_f32(t->dlog, V, t->wpT, V, nullptr, t->dOut, H, LB, H, V, 0, s));
   TN_TRY(launch_gemm_tn_f32(t->dlog, V, t->Out, H, g + t->o_wp, H, V, H, LB, s));
   TN_TRY(launch_colsum_f32(t->dlog, V, LB, V, g + t->o_bp, s));
-  float *dmem = t->enc[NL - 1].dxn;
-  TN_HIP_CHECK(hipMemsetAsync(dmem, 0, sizeof(float) * (size_t)BT * H, s));
-  TN_HIP_CHECK(hipMemsetAsync(t->dkp, 0, sizeof(float) * (size_t)BT * H, s));
+  float *dmem = t->enc[NL - 1].dxn;      // (written, with t->dkp, by trn_att_outer_kernel after the loop)
   // ---------------- backward: decoder steps, last to first ----------------
   for (int i = L - 1; i >= 0; --i) {
     const bool last = i == L - 1;
@@ -1879,7 +1911,8 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
     }
     const float *dX0n = d0.dX + sn * K0;
     hipLaunchKernelGGL(trn_att_bwd_kernel, dim3(B), dim3(256), attb_lds, s, (const float *)(t->AW + so * T), mem, (const float *)t->keyproj,
-                       (const float *)(d1.X + so * K1), K1, datt, ldatt, last ? nul : dX0n + E, K0, (const int32_t *)t->vl, dmem, t->dkp, t->dq, T, H);
+                       (const float *)(d1.X + so * K1), K1, datt, ldatt, last ? nul : dX0n + E, K0, (const int32_t *)t->vl, t->DS + so * T,
+                       t->DCTX + so * H, t->dq, T, H);
     // first cell: d h0 = d (layer 1's input) + the query's gradient + the recurrent paths
     const float *X0 = d0.X + so * K0, *G0 = d0.G + so * 4 * H;
     float *dG0 = d0.dG + so * 4 * H, *dX0 = d0.dX + so * K0;
@@ -1913,6 +1946,8 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
     hipLaunchKernelGGL(trn_unstack_kernel, dim3(GH), dim3(256), 0, s, (const float *)d.dW, (const float *)d.db, d.in, H, lstm ? 1 : 0, g + d.o_wi,
                        g + d.o_wh, g + d.o_bi, g + d.o_bh);
   }
+  hipLaunchKernelGGL(trn_att_outer_kernel, dim3((T + 3) / 4, B), dim3(256), 0, s, (const float *)t->AW, (const float *)t->DS, (const float *)t->DCTX,
+                     (const float *)d1.X, K1, dmem, t->dkp, L, B, T, H);
   TN_TRY(launch_gemm_tn_f32(t->dkp, H, mem, H, g + t->o_wk, H, H, H, BT, s));
   TN_TRY(launch_linear_f32(t->dkp, H, t->wkT, H, nullptr, dmem, H, BT, H, H, 1, s));
   hipLaunchKernelGGL(trn_emb_grad_kernel, dim3(V), dim3(64), 0, s, (const float *)d0.dX, K0, tgt, ld, B, L, E, V, g + t->o_emb);
