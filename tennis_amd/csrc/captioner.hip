@@ -1501,7 +1501,7 @@ extern "C" int tn_gnmt_decode_seq(tn_gnmt *g, const int32_t *tgt, int ld, int st
     if (rc) return rc;
     hipLaunchKernelGGL(dec_tf_cell1_kernel, dim3(nb), dim3(256), 0, s, (const float *)g->g1, (const float *)g->sx1, lstm ? 1 : 0,
                        (const float *)g->c1cur, g->h1n, g->c1n, R, H, g->residual ? g->hstate : (float *)nullptr);
-    rc = launch_linear_f32(proj_in, H, g->wp, H, g->bp, logits + (size_t)i * V, steps * V, R, V, H, 0, s);
+    rc = launch_linear_f32_lat(proj_in, H, g->wp, H, g->bp, logits + (size_t)i * V, steps * V, R, V, H, s);
     if (rc) return rc;
   }
   TN_HIP_CHECK(hipGetLastError());
@@ -1833,7 +1833,7 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
     for (int j = 2; j < NL; ++j)
       hipLaunchKernelGGL(trn_copy_kernel, dim3(nbH), dim3(256), 0, s, i ? (const float *)(t->dec[j].Hs + sp * H) : h_init(j), H,
                          t->dec[j].X + so * K1 + 2 * H, K1, B, H);
-    TN_TRY(launch_linear_f32(X0, K0, d0.wc, K0, d0.bc, d0.G + so * 4 * H, 4 * H, B, 4 * H, K0, 0, s));
+    TN_TRY(launch_linear_f32_lat(X0, K0, d0.wc, K0, d0.bc, d0.G + so * 4 * H, 4 * H, B, 4 * H, K0, s));
     const float *c0p = !lstm ? nul : i ? (const float *)(d0.C + sp * H) : c_init(0);
     hipLaunchKernelGGL(dec_attention_kernel<1>, dim3(B), dim3(kBeamThreads), att_lds, s, (const float *)(d0.G + so * 4 * H), (const float *)(X0 + E + H), K0,
                        c0p, lstm ? 1 : 0, t->h0tmp, lstm ? d0.C + so * H : (float *)nullptr, X1, K1, (const float *)t->keyprojT, mem,
@@ -1843,14 +1843,14 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
       TrnDec &d = t->dec[j];
       const bool top = j == NL - 1;
       float *Xj = d.X + so * K1;
-      TN_TRY(launch_linear_f32(Xj, K1, d.wc, K1, d.bc, d.G + so * 4 * H, 4 * H, B, 4 * H, K1, 0, s));
+      TN_TRY(launch_linear_f32_lat(Xj, K1, d.wc, K1, d.bc, d.G + so * 4 * H, 4 * H, B, 4 * H, K1, s));
       const float *cp = !lstm ? nul : i ? (const float *)(d.C + sp * H) : c_init(j);
       float *outp = top ? t->Out + so * H : t->dec[j + 1].X + so * K1;
       hipLaunchKernelGGL(trn_cell_fwd_kernel, dim3(nbH), dim3(256), 0, s, (const float *)(d.G + so * 4 * H), (const float *)Xj, lstm ? 1 : 0, cp,
                          d.Hs + so * H, lstm ? d.C + so * H : (float *)nullptr, drop ? (const float *)(d.M + so * H) : nul, t->residual ? 1 : 0,
                          outp, top ? H : K1, top ? (float *)nullptr : outp + H, B, H);
     }
-    TN_TRY(launch_linear_f32(t->Out + so * H, H, w + t->o_wp, H, w + t->o_bp, t->logits + (size_t)i * V, L * V, B, V, H, 0, s));
+    TN_TRY(launch_linear_f32_lat(t->Out + so * H, H, w + t->o_wp, H, w + t->o_bp, t->logits + (size_t)i * V, L * V, B, V, H, s));
   }
   // ---------------- loss and its gradient ----------------
   hipLaunchKernelGGL(trn_ce_bwd_kernel, dim3(L, B), dim3(256), 0, s, (const float *)t->logits, tgt + 1, ld, (const int32_t *)t->tvl, B, L, V,
@@ -1890,7 +1890,7 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
       else
         hipLaunchKernelGGL(trn_gru_bwd_kernel, dim3(nbH), dim3(256), 0, s, Gj, Xj + 2 * H, K1, dh, ldh, last ? nul : (const float *)d.dhz, H,
                            last ? nul : dXjn + 2 * H, K1, nul, 0, dGj, d.dhz, B, H);
-      TN_TRY(launch_linear_f32(dGj, 4 * H, d.wcT, 4 * H, nullptr, dXj, K1, B, K1, 4 * H, 0, s));
+      TN_TRY(launch_linear_f32_lat(dGj, 4 * H, d.wcT, 4 * H, nullptr, dXj, K1, B, K1, 4 * H, s));
       // d (the layer's input) = its column block of dX (+ the residual path)
       if (t->residual) {
         float *dst = pingpong[pp]; pp ^= 1;
@@ -1923,7 +1923,7 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
     else
       hipLaunchKernelGGL(trn_gru_bwd_kernel, dim3(nbH), dim3(256), 0, s, G0, X0 + E + H, K0, dcur, ldcur, (const float *)t->dq, H,
                          last ? nul : (const float *)d0.dhz, H, last ? nul : dX0n + E + H, K0, dG0, d0.dhz, B, H);
-    TN_TRY(launch_linear_f32(dG0, 4 * H, d0.wcT, 4 * H, nullptr, dX0, K0, B, K0, 4 * H, 0, s));
+    TN_TRY(launch_linear_f32_lat(dG0, 4 * H, d0.wcT, 4 * H, nullptr, dX0, K0, B, K0, 4 * H, s));
   }
   // gradients reaching the encoder's final states: decoder layer j's initial state is encoder layer j's (backward direction of a bi layer)
   for (int j = 0; j < NL; ++j) {
