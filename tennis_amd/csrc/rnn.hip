@@ -17,6 +17,7 @@
 #include "common.h"
 #include "linear.h"
 #include "rnn.h"
+#include "rnn_dot.h"
 
 namespace {
 
@@ -163,17 +164,6 @@ __global__ __launch_bounds__(MAXT) void rnn_recurrent_kernel(
 //     4 x fewer LDS instructions, no extra VALU work;
 //   * the step's gi values are requested before the dot product.
 // The dot product still runs over k in ascending order with one accumulator: results are bit-identical to the kernel above.
-#define TN_FMA_Q(ACC, HREG, W, J)                                                                              \
-  asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[" #J "," #J "," #J "," #J "] row_mask:0xf bank_mask:0xf"  \
-               : "+v"(ACC) : "v"(HREG), "v"(W))
-// 16 k-values k0 .. k0+15: WV(i) is the weight of k0 + i
-#define TN_DOT16(ACC, HQ, WV)                                                                                          \
-  do {                                                                                                                 \
-    TN_FMA_Q(ACC, HQ.x, WV(0), 0);  TN_FMA_Q(ACC, HQ.y, WV(1), 0);  TN_FMA_Q(ACC, HQ.z, WV(2), 0);  TN_FMA_Q(ACC, HQ.w, WV(3), 0);   \
-    TN_FMA_Q(ACC, HQ.x, WV(4), 1);  TN_FMA_Q(ACC, HQ.y, WV(5), 1);  TN_FMA_Q(ACC, HQ.z, WV(6), 1);  TN_FMA_Q(ACC, HQ.w, WV(7), 1);   \
-    TN_FMA_Q(ACC, HQ.x, WV(8), 2);  TN_FMA_Q(ACC, HQ.y, WV(9), 2);  TN_FMA_Q(ACC, HQ.z, WV(10), 2); TN_FMA_Q(ACC, HQ.w, WV(11), 2);  \
-    TN_FMA_Q(ACC, HQ.x, WV(12), 3); TN_FMA_Q(ACC, HQ.y, WV(13), 3); TN_FMA_Q(ACC, HQ.z, WV(14), 3); TN_FMA_Q(ACC, HQ.w, WV(15), 3);  \
-  } while (0)
 template <int G, int KR, int KL, int MAXT>
 __global__ __launch_bounds__(MAXT) void rnn_recurrent_big_kernel(
     const float *__restrict__ gi, int ldgi, const float *__restrict__ whT, const float *__restrict__ bh,
@@ -193,12 +183,7 @@ __global__ __launch_bounds__(MAXT) void rnn_recurrent_big_kernel(
   float wr[KR];
 #pragma unroll
   for (int k = 0; k < KR; ++k) wr[k] = wcol[(long)k * GH];
-  for (int k4 = 0; k4 < KL / 4; ++k4) {
-    float4 v;
-    v.x = wcol[(long)(KR + 4 * k4 + 0) * GH]; v.y = wcol[(long)(KR + 4 * k4 + 1) * GH];
-    v.z = wcol[(long)(KR + 4 * k4 + 2) * GH]; v.w = wcol[(long)(KR + 4 * k4 + 3) * GH];
-    *(float4 *)(wl + ((long)k4 * GH + j) * 4) = v;
-  }
+  rnn_dot_fill_lds<KR, KL>(wl, GH, j, wcol, GH);
   if (j < H) {
     hs[j] = 0.f;
     if (G == 4) cs[j] = 0.f;
@@ -216,36 +201,7 @@ __global__ __launch_bounds__(MAXT) void rnn_recurrent_big_kernel(
 #pragma unroll
       for (int e = 0; e < G; ++e) gq[e] = g[e * H + j];
     }
-    float acc = bj;
-#pragma unroll
-    for (int k = 0; k < KR; k += 16) {
-      const float4 hq = *(const float4 *)(hs + k + lane4);
-#define TN_WV(i) wr[k + (i)]
-      TN_DOT16(acc, hq, TN_WV);
-#undef TN_WV
-    }
-#pragma unroll
-    for (int k = 0; k < KL; k += 16) {
-      const float4 hq = *(const float4 *)(hs + KR + k + lane4);
-      float w[16];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float4 v = *(const float4 *)(wl + ((long)(k / 4 + i) * GH + j) * 4);
-        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
-      }
-#define TN_WV(i) w[i]
-      TN_DOT16(acc, hq, TN_WV);
-#undef TN_WV
-    }
-    for (int k = KR + KL; k < H; k += 16) {         // (H % 16 == 0 for this kernel)
-      float w[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) w[i] = wcol[(long)(k + i) * GH];
-      const float4 hq = *(const float4 *)(hs + k + lane4);
-#define TN_WV(i) w[i]
-      TN_DOT16(acc, hq, TN_WV);
-#undef TN_WV
-    }
+    const float acc = rnn_dot_big<KR, KL>(bj, wr, wl, GH, j, wcol, GH, hs, H, lane4);
     gh[j] = acc;
     __syncthreads();
     if (live) {
@@ -283,8 +239,6 @@ __global__ __launch_bounds__(MAXT) void rnn_recurrent_big_kernel(
     if (c_last && G == 4) c_last[((long)dir * B + bg) * H + j] = cs[j];
   }
 }
-#undef TN_DOT16
-#undef TN_FMA_Q
 
 __global__ void temporal_pool_kernel(const float *__restrict__ x, int B, int T, int F, int kind,
                                      float *__restrict__ y) {

@@ -9,6 +9,7 @@
 // weight gradients are three transposed GEMMs over all B*T rows afterwards.
 #include "common.h"
 #include "train.h"
+#include "rnn_dot.h"
 
 namespace {
 
@@ -84,7 +85,7 @@ __global__ void scatter_pool_grad_kernel(const float *__restrict__ dpooled, cons
 // BPTT of one direction for NB batch rows: thread j = (gate block g, unit u).  As in rnn.hip's forward kernel the
 // first KR values of the thread's W_hh column (loop-invariant over the steps) stay in registers, the rest is streamed
 // 16 loads at a time, and small batches run one row per workgroup.
-template <int NB, int KR, int MAXT>
+template <int NB, int KR, int MAXT, int KL = 0>   // KL > 0 (NB = 1, H % 16 == 0): KL more weights in LDS, x through DPP (rnn_dot.h)
 __global__ __launch_bounds__(MAXT) void gru_train_bwd_kernel(const float *__restrict__ seq, const float *__restrict__ gates,
                                      const float *__restrict__ dseq, const float *__restrict__ wh,   // [dirs][3H][H]
                                      float *__restrict__ dgi, float *__restrict__ dgh,               // [B*T][dirs*3H]
@@ -97,12 +98,14 @@ __global__ __launch_bounds__(MAXT) void gru_train_bwd_kernel(const float *__rest
   float *dh = lds;                  // [NB][H]   gradient flowing into h_t from the later step
   float *dgs = dh + NB * H;         // [NB][3H]  this step's h2h pre-activation gradients
   float *part = dgs + NB * GH;      // [NB][3][H]
+  float *wl = part + NB * GH;       // [KL/4][3H][4] (KL > 0)
   const int j = threadIdx.x, dir = blockIdx.y, b0 = blockIdx.x * NB;
   const int g = j / H, u = j - g * H;
   const float *wrow = wh + (long)dir * GH * H + (long)g * H * H + u;   // W_hh[g*H + jj][u], jj = 0..H-1
   float wr[KR > 0 ? KR : 1];
 #pragma unroll
   for (int k = 0; k < KR; ++k) wr[k] = wrow[(long)k * H];
+  if constexpr (KL > 0) rnn_dot_fill_lds<KR, KL>(wl, GH, j, wrow, H);
   for (int i = j; i < NB * H; i += GH) dh[i] = 0.f;
   __syncthreads();
   for (int s = T - 1; s >= 0; --s) {          // reverse of the direction's own walking order
@@ -137,6 +140,10 @@ __global__ __launch_bounds__(MAXT) void gru_train_bwd_kernel(const float *__rest
     float acc[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+    if constexpr (KL > 0) {
+      static_assert(KL == 0 || NB == 1, "the LDS share is built for one row per workgroup");
+      acc[0] = rnn_dot_big<KR, KL>(0.f, wr, wl, GH, j, wrow, H, dgs + g * H, H, (j & 3) * 4);
+    } else {
 #pragma unroll
     for (int jj = 0; jj < KR; jj += 4) {
 #pragma unroll
@@ -177,6 +184,7 @@ __global__ __launch_bounds__(MAXT) void gru_train_bwd_kernel(const float *__rest
         acc[b] = fmaf(w3, dv.w, acc[b]);
       }
     }
+    }
 #pragma unroll
     for (int b = 0; b < NB; ++b) part[(b * 3 + g) * H + u] = acc[b];
     __syncthreads();
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(MAXT) void gru_train_bwd_kernel(const float *__rest
 // ---- LSTM (gate order [i, f, g, o], mx.gluon.rnn.LSTM); saved per step: i | f | g | o | c_t ----
 // BPTT of one LSTM direction for NB batch rows: thread j = (gate block g of 4, unit u).  The pre-activation
 // gradient is the same for the i2h and the h2h branch, so only dgi is written (the caller uses it for both).
-template <int NB, int KR, int MAXT>
+template <int NB, int KR, int MAXT, int KL = 0>   // KL > 0 (NB = 1, H % 16 == 0): KL more weights in LDS, x through DPP (rnn_dot.h)
 __global__ __launch_bounds__(MAXT) void lstm_train_bwd_kernel(const float *__restrict__ seq, const float *__restrict__ gates,
                                       const float *__restrict__ dseq, const float *__restrict__ wh,   // [dirs][4H][H]
                                       float *__restrict__ dgi,                                        // [B*T][dirs*4H]
@@ -206,12 +214,14 @@ __global__ __launch_bounds__(MAXT) void lstm_train_bwd_kernel(const float *__res
   float *dc = dh + NB * H;          // [NB][H]   ... into c_t
   float *dgs = dc + NB * H;         // [NB][4H]  this step's pre-activation gradients
   float *part = dgs + NB * GH;      // [NB][4][H]
+  float *wl = part + NB * GH;       // [KL/4][4H][4] (KL > 0)
   const int j = threadIdx.x, dir = blockIdx.y, b0 = blockIdx.x * NB;
   const int g = j / H, u = j - g * H;
   const float *wrow = wh + (long)dir * GH * H + (long)g * H * H + u;   // W_hh[g*H + jj][u], jj = 0..H-1
   float wr[KR > 0 ? KR : 1];
 #pragma unroll
   for (int k = 0; k < KR; ++k) wr[k] = wrow[(long)k * H];
+  if constexpr (KL > 0) rnn_dot_fill_lds<KR, KL>(wl, GH, j, wrow, H);
   for (int i = j; i < NB * H; i += GH) { dh[i] = 0.f; dc[i] = 0.f; }
   __syncthreads();
   for (int s = T - 1; s >= 0; --s) {
@@ -251,6 +261,10 @@ __global__ __launch_bounds__(MAXT) void lstm_train_bwd_kernel(const float *__res
     float acc[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+    if constexpr (KL > 0) {
+      static_assert(KL == 0 || NB == 1, "the LDS share is built for one row per workgroup");
+      acc[0] = rnn_dot_big<KR, KL>(0.f, wr, wl, GH, j, wrow, H, dgs + g * H, H, (j & 3) * 4);
+    } else {
 #pragma unroll
     for (int jj = 0; jj < KR; jj += 4) {
 #pragma unroll
@@ -290,6 +304,7 @@ __global__ __launch_bounds__(MAXT) void lstm_train_bwd_kernel(const float *__res
         acc[b] = fmaf(w2, dv.z, acc[b]);
         acc[b] = fmaf(w3, dv.w, acc[b]);
       }
+    }
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) part[(b * 4 + g) * H + u] = acc[b];
@@ -487,6 +502,13 @@ int launch_scatter_pool_grad(const float *dpooled, const int32_t *arg, int B, in
     const int kr = (threads <= 512 && H >= 128) ? 128 : (threads <= 768 && H >= 96) ? 96 : H >= 64 ? 64 : 0;      \
     const dim3 grid((B + nb - 1) / nb, DIRS), block(threads);                                                     \
     const size_t lds = (size_t)(nb * H * (GATES == 4 ? 2 : 1) + 2 * nb * GATES * H) * sizeof(float);              \
+    if (nb == 1 && H == 256) {   /* the column does not fit the registers: registers + LDS + stream (rnn_dot.h) */       \
+      constexpr int KRb = GATES == 3 ? 96 : 64, KLb = GATES == 3 ? 48 : 32, MTb = GATES == 3 ? 768 : 1024;              \
+      const size_t lds2 = lds + (size_t)KLb * GATES * H * sizeof(float);                                                 \
+      TN_SET_ATTR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void *)KERNEL<1, KRb, MTb, KLb>,                      \
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));    \
+      hipLaunchKernelGGL((KERNEL<1, KRb, MTb, KLb>), grid, block, lds2, s, __VA_ARGS__);                                 \
+    } else                                                                                                              \
     if (nb == 4) hipLaunchKernelGGL((KERNEL<4, 0, 1024>), grid, block, lds, s, __VA_ARGS__);                      \
     else if (kr == 128) hipLaunchKernelGGL((KERNEL<1, 128, 512>), grid, block, lds, s, __VA_ARGS__);              \
     else if (kr == 96) hipLaunchKernelGGL((KERNEL<1, 96, 768>), grid, block, lds, s, __VA_ARGS__);                \

@@ -32,7 +32,10 @@ def _case(seed, B, T, F, H, E, V, L, cell="gru", nl=2, nbi=1, res=False):
                                  dict(seed=3, B=4, T=40, F=128, H=128, E=100, V=254, L=9),    # config-C5 widths
                                  dict(seed=6, B=3, T=9, F=16, H=8, E=6, V=14, L=6, cell="lstm"),
                                  dict(seed=7, B=5, T=23, F=64, H=32, E=20, V=40, L=11, cell="lstm"),
-                                 dict(seed=8, B=4, T=40, F=128, H=128, E=100, V=254, L=9, cell="lstm")])
+                                 dict(seed=8, B=4, T=40, F=128, H=128, E=100, V=254, L=9, cell="lstm"),
+                                 # H = 256, the --num_hidden of model 0102: the recurrent kernels' registers + LDS + stream form
+                                 dict(seed=9, B=3, T=14, F=48, H=256, E=24, V=40, L=6),
+                                 dict(seed=10, B=3, T=14, F=48, H=256, E=24, V=40, L=6, cell="lstm")])
 def test_loss_and_gradients_match_autograd(cfg, report):
     from tennis_amd.engine import GNMTTrainer
     p, src, svl, tgt, tvl = _case(**cfg)
