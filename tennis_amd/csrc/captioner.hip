@@ -897,59 +897,85 @@ __global__ void trn_lstm_bwd_kernel(const float *__restrict__ g, const float *__
 // The step's share of d mem and d keyproj is NOT accumulated here (that was a read-modify-write of 2 T H floats per clip and
 // step behind one workgroup, 123 us per step at config C5): the step only leaves ds (L,B,T) and dctx (L,B,H) behind, and
 // trn_att_outer_kernel forms d mem = sum over steps of w (x) dctx and d keyproj = sum of ds (x) q once after the loop.
-__global__ __launch_bounds__(256) void trn_att_bwd_kernel(const float *__restrict__ aw, const float *__restrict__ mem,
-                                                          const float *__restrict__ keyproj, const float *__restrict__ h0,
-                                                          int ldh, const float *c0, int lc0, const float *c1, int lc1,
-                                                          const int32_t *__restrict__ valid_len, float *__restrict__ ds_out,
-                                                          float *__restrict__ dctx_out, float *__restrict__ dh0, int T, int H) {
-  extern __shared__ float sm[];    // dctx[H] | q[H] | ds[T] | red[256]
-  float *dctx = sm, *q = sm + H, *ds = q + H, *red = ds + T;
+__global__ __launch_bounds__(kBeamThreads) void trn_att_bwd_kernel(const float *__restrict__ aw, const float *__restrict__ mem,
+                                                                   const float *__restrict__ keyproj, const float *c0, int lc0, const float *c1, int lc1,
+                                                                   const int32_t *__restrict__ valid_len, float *__restrict__ ds_out,
+                                                                   float *__restrict__ dctx_out, float *__restrict__ dh0, int T, int H) {
+  extern __shared__ float sm[];    // dctx[H] | ds[T] | part[16][H] | red[16]
+  float *dctx = sm, *ds = dctx + H, *part = ds + T, *red = part + 16 * H;
   const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int vl = min(max(valid_len[b], 0), T);
   const float inv = 1.0f / sqrtf((float)H);
-  for (int u = t; u < H; u += 256) {
+  for (int u = t; u < H; u += kBeamThreads) {
     const float d = (c0 ? c0[(long)b * lc0 + u] : 0.f) + (c1 ? c1[(long)b * lc1 + u] : 0.f);
     dctx[u] = d;
     dctx_out[(long)b * H + u] = d;
-    q[u] = h0[(long)b * ldh + u] * inv;
   }
   __syncthreads();
   const float *w = aw + (long)b * T;
   const float *mv = mem + (long)b * T * H, *kp = keyproj + (long)b * T * H;
-  // dw_t = mem_t . dctx  (one wave per source step)
-  for (int s = wid; s < vl; s += 4) {
-    float a = 0.f;
-    for (int u = lane; u < H; u += 64) a = fmaf(mv[(long)s * H + u], dctx[u], a);
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-    if (lane == 0) ds[s] = a;
-  }
-  __syncthreads();
-  float part = 0.f;
-  for (int s = t; s < vl; s += 256) part += w[s] * ds[s];
-  red[t] = part;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
-  const float dot = red[0];
-  __syncthreads();
-  for (int s = t; s < T; s += 256) {
-    const float v = s < vl ? w[s] * (ds[s] - dot) : 0.f;
-    ds[s] = v;
-    ds_out[(long)b * T + s] = v;
-  }
-  __syncthreads();
-  // dq = sum_t ds_t kp_t, 16 loads in flight
-  for (int u = t; u < H; u += 256) {
-    float dq = 0.f;
-    int s = 0;
-    for (; s + 16 <= vl; s += 16) {
-      float kv[16];
+  // dw_t = mem_t . dctx: wave `wid` takes the steps wid, wid + 16, ...; a lane owns four units per 256 (16-byte loads along H),
+  // eight steps in flight
+  for (int s0 = wid; s0 < vl; s0 += 16 * 8) {
+    float a[8];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) kv[i] = kp[(long)(s + i) * H + u];
+    for (int i = 0; i < 8; ++i) a[i] = 0.f;
+    for (int u = 4 * lane; u < H; u += 256) {
+      const float4 d = *(const float4 *)(dctx + u);
+      float4 m[8];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) dq = fmaf(ds[s + i], kv[i], dq);
+      for (int i = 0; i < 8; ++i) {
+        const int s = s0 + 16 * i;
+        m[i] = s < vl ? *(const float4 *)(mv + (long)s * H + u) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] = fmaf(m[i].x, d.x, fmaf(m[i].y, d.y, fmaf(m[i].z, d.z, fmaf(m[i].w, d.w, a[i]))));
     }
-    for (; s < vl; ++s) dq = fmaf(ds[s], kp[(long)s * H + u], dq);
-    dh0[(long)b * H + u] = dq * inv;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float v = wave_sum(a[i]);
+      if (lane == 0 && s0 + 16 * i < vl) ds[s0 + 16 * i] = v;
+    }
+  }
+  __syncthreads();
+  float pw = 0.f;
+  for (int s = t; s < vl; s += kBeamThreads) pw += w[s] * ds[s];
+  pw = wave_sum(pw);
+  if (lane == 0) red[wid] = pw;
+  __syncthreads();
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dot += red[i];
+  for (int s = t; s < T; s += kBeamThreads) {
+    const float v = s < vl ? w[s] * (ds[s] - dot) : 0.f;
+    ds_out[(long)b * T + s] = v;
+    ds[s] = v;                  // each element is read (above) and written by the same thread
+  }
+  __syncthreads();
+  // dq = sum_t ds_t kp_t: thread = (slice of the valid steps, four units), 16 partial sums per unit
+  const int U4 = H >> 2, CG = step_groups(U4, 16), SG = kBeamThreads / CG;
+  {
+    const int sg = t / CG, sn = (vl + SG - 1) / SG, sa = sg * sn, sb = min(vl, sa + sn);
+    for (int u4 = t % CG; u4 < U4; u4 += CG) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s = sa; s < sb; s += 16) {
+        float4 m[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m[i] = s + i < sb ? *(const float4 *)(kp + (long)(s + i) * H + 4 * u4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float dv = s + i < sb ? ds[s + i] : 0.f;
+          acc.x = fmaf(dv, m[i].x, acc.x); acc.y = fmaf(dv, m[i].y, acc.y); acc.z = fmaf(dv, m[i].z, acc.z); acc.w = fmaf(dv, m[i].w, acc.w);
+        }
+      }
+      *(float4 *)(part + sg * H + 4 * u4) = acc;
+    }
+  }
+  __syncthreads();
+  for (int u = t; u < H; u += kBeamThreads) {
+    float a = part[u];
+    for (int g = 1; g < SG; ++g) a += part[g * H + u];
+    dh0[(long)b * H + u] = a * inv;
   }
 }
 
@@ -1777,7 +1803,7 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
   const int BT = B * T, LB = L * B;
   const bool lstm = G == 4;
   const int asplit = att_split(T, H, kStepLdsMax);
-  const size_t attb_lds = (size_t)(2 * H + T + 256) * sizeof(float);
+  const size_t attb_lds = (size_t)(17 * H + T + 16) * sizeof(float);
   TN_REQUIRE(asplit > 0 && attb_lds <= kStepLdsMax, "tn_gnmt_trainer: 3 * max(hidden, source length) floats exceed 152 KiB of LDS");
   const size_t att_lds = att_lds_bytes(T, H, asplit);
   if (int rc = allow_lds(dec_attention_kernel<1>, att_lds)) return rc;
@@ -1910,9 +1936,8 @@ extern "C" int tn_gnmt_trainer_forward_backward(tn_gnmt_trainer *t, const float 
       datt = t->tmpAtt; ldatt = H;
     }
     const float *dX0n = d0.dX + sn * K0;
-    hipLaunchKernelGGL(trn_att_bwd_kernel, dim3(B), dim3(256), attb_lds, s, (const float *)(t->AW + so * T), mem, (const float *)t->keyproj,
-                       (const float *)(d1.X + so * K1), K1, datt, ldatt, last ? nul : dX0n + E, K0, (const int32_t *)t->vl, t->DS + so * T,
-                       t->DCTX + so * H, t->dq, T, H);
+    hipLaunchKernelGGL(trn_att_bwd_kernel, dim3(B), dim3(kBeamThreads), attb_lds, s, (const float *)(t->AW + so * T), mem, (const float *)t->keyproj,
+                       datt, ldatt, last ? nul : dX0n + E, K0, (const int32_t *)t->vl, t->DS + so * T, t->DCTX + so * H, t->dq, T, H);
     // first cell: d h0 = d (layer 1's input) + the query's gradient + the recurrent paths
     const float *X0 = d0.X + so * K0, *G0 = d0.G + so * 4 * H;
     float *dG0 = d0.dG + so * 4 * H, *dX0 = d0.dX + so * K0;
