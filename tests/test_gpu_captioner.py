@@ -52,6 +52,8 @@ def _case(seed, B, T, F, H, E, V, beam, max_length, eos_bias=0.0, proj_scale=1.0
     # a source of 2500 steps
     dict(seed=15, B=2, T=30, F=64, H=256, E=100, V=254, beam=10, max_length=12, proj_scale=30.0),
     dict(seed=16, B=1, T=2500, F=16, H=32, E=16, V=40, beam=3, max_length=8, proj_scale=30.0),
+    # 12 clips: eight of them through the XCD-aware workgroup -> row mapping of the attention kernel, four behind it
+    dict(seed=17, B=12, T=21, F=32, H=32, E=16, V=40, beam=5, max_length=14, proj_scale=30.0),
 ])
 def test_beam_search_matches_oracle(cfg, report):
     (mem, s, sc, vl), (rmem, rs, rsc, rvl) = _case(**cfg)
