@@ -38,6 +38,9 @@ namespace {
 #ifndef TN_JPEG_SUBSEQ
 #define TN_JPEG_SUBSEQ 256
 #endif
+#ifndef TN_JPEG_RUNIN
+#define TN_JPEG_RUNIN 1
+#endif
 constexpr int SUBSEQ = TN_JPEG_SUBSEQ;     // bytes of entropy-coded data per decoding thread
 constexpr int MAX_SLOTS = 10;   // blocks per MCU (T.81 B.2.3: sum of Hi x Vi <= 10)
 constexpr int LUT_SIZE = 65536; // 16-bit prefix -> (code length << 8) | symbol, 0 = no such code
@@ -231,6 +234,22 @@ __global__ __launch_bounds__(256) void jpeg_sync_kernel(const uint8_t *__restric
   const uint32_t sub_start = live ? sg.byte_start + t * SUBSEQ : 0u, sub_end = sub_start + SUBSEQ;
   if (pass == 0) {
     if (!live) return;
+#if TN_JPEG_RUNIN
+    // run-in: start one subsequence EARLIER with the guessed state, so that the decoder has usually fallen into step with the
+    // true one when it crosses into its own subsequence; the crossing state is recorded as the start of the record (the fix-up
+    // pass decodes again only where the predecessor's end differs from it)
+    if (t > 0) {
+      uint32_t cp = sub_start - SUBSEQ;
+      if (t > 1 && rd.ld(cp - 1) == 0xFFu && rd.ld(cp) == 0u) cp += 1;
+      const SubRec r0 = t > 1 ? decode_sub<false>(rd, cp, 0, sub_start, 0, 0, g, f, luts, fast, nullptr, 0, 0, nullptr)
+                              : decode_sub<false>(rd, sg.byte_start, 0, sub_start, 0, 0, g, f, luts, fast, nullptr, 0, 0, nullptr);   // (the segment's first: true state)
+      SubRec r1 = decode_sub<false>(rd, r0.pos >> 3, r0.pos & 7, sub_end, r0.state >> 6, r0.state & 63, g, f, luts, fast, nullptr, 0, 0, nullptr);
+      r1.in_pos = r0.pos;
+      r1.in_state = r0.state;
+      rec[sub] = r1;
+      return;
+    }
+#endif
     uint32_t cp = sub_start;
     if (t > 0 && rd.ld(cp - 1) == 0xFFu && rd.ld(cp) == 0u) cp += 1;     // a stuffed byte is not data
     rec[sub] = decode_sub<false>(rd, cp, 0, sub_end, 0, 0, g, f, luts, fast, nullptr, 0, 0, nullptr);
