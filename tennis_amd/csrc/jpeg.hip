@@ -93,7 +93,8 @@ struct SubRec { uint32_t pos; uint16_t state; uint16_t in_state; uint32_t nblk; 
 template <bool WRITE>
 __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint32_t cb, uint32_t sub_end, int slot, int k,
                                              const Geom &g, const FrameDev &f, const uint16_t *__restrict__ luts,
-                                             const uint16_t *__restrict__ fast, int16_t *__restrict__ coef, uint32_t first_block,
+                                             const uint16_t *__restrict__ fast, const uint16_t *sh_fast, bool in_lds,
+                                             int16_t *__restrict__ coef, uint32_t first_block,
                                              uint32_t max_blocks, int *__restrict__ err) {
   uint32_t nblk = 0;
   // the Huffman tables of the MCU's slots, 4 bits each (DC id | AC id << 2), in one register pair: picking the symbol's table
@@ -101,7 +102,8 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
   uint64_t tabs = 0;
   for (int i = 0; i < g.bpm; ++i) tabs |= (uint64_t)((f.slot_dc[i] & 3) | ((f.slot_ac[i] & 3) << 2)) << (4 * i);
   const uint16_t *lut_base = luts + (size_t)f.lut * 8 * LUT_SIZE;
-  const uint16_t *fast_base = fast;      // this file's first-level tables (LDS copy when the workgroup staged its set)
+  // this file's first-level tables: the workgroup's LDS copy (in_lds: a real ds_read - through one generic pointer the lookup
+  // was a FLAT load that waits for every outstanding global load as well) or, for a thread of another table set, global memory
   const uint32_t stop = sub_end < rd.end ? sub_end : rd.end;
   uint64_t buf = 0;
   int nb = 0;
@@ -150,7 +152,9 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
     const bool dc = k == 0;
     const uint32_t tb = (uint32_t)(tabs >> (4 * slot));
     const int table = dc ? (int)(tb & 3u) : 4 + (int)((tb >> 2) & 3u);
-    uint16_t e = fast_base[table * FAST_SIZE + (uint32_t)(buf >> (64 - FAST_BITS))];
+    const uint32_t fidx = table * FAST_SIZE + (uint32_t)(buf >> (64 - FAST_BITS));
+    uint16_t e;
+    if (in_lds) e = ((const __attribute__((address_space(3))) uint16_t *)sh_fast)[fidx]; else e = fast[fidx];
     if (e == 0) e = lut_base[(size_t)table * LUT_SIZE + (uint32_t)(buf >> 48)];
     int len = e >> 8;
     const int sym = e & 255;
@@ -191,12 +195,10 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
 // The first-level tables (8 x 1024 entries, 16 KiB) of the table set most of a workgroup's threads need are staged in
 // LDS: one dependent load per symbol then costs an LDS round trip instead of an L2 one.  Threads of another set (a
 // workgroup that straddles two files with different Huffman tables) read theirs from global memory.
-__device__ __forceinline__ const uint16_t *stage_fast(const uint16_t *__restrict__ fast, uint32_t block_set, uint32_t my_set,
-                                                      uint16_t *sh_fast) {
+__device__ __forceinline__ void stage_fast(const uint16_t *__restrict__ fast, uint32_t block_set, uint16_t *sh_fast) {
   const uint4 *src = (const uint4 *)(fast + (size_t)block_set * 8 * FAST_SIZE);
   for (int i = threadIdx.x; i < 8 * FAST_SIZE / 8; i += 256) ((uint4 *)sh_fast)[i] = src[i];
   __syncthreads();
-  return my_set == block_set ? sh_fast : fast + (size_t)my_set * 8 * FAST_SIZE;
 }
 
 __device__ __forceinline__ int find_seg(const Seg *__restrict__ segs, int nseg, uint32_t sub) {
@@ -229,7 +231,9 @@ __global__ __launch_bounds__(256) void jpeg_sync_kernel(const uint8_t *__restric
   __shared__ uint32_t sh_set;
   if (threadIdx.x == 0) sh_set = f.lut;      // (thread 0 of a launched workgroup is always live)
   __syncthreads();
-  fast = stage_fast(fast, sh_set, f.lut, sh_fast);
+  stage_fast(fast, sh_set, sh_fast);
+  const bool in_lds = f.lut == sh_set;
+  fast += (size_t)f.lut * 8 * FAST_SIZE;
   Reader rd{scan + f.scan_off, live ? sg.byte_end : 0u};
   const uint32_t sub_start = live ? sg.byte_start + t * SUBSEQ : 0u, sub_end = sub_start + SUBSEQ;
   if (pass == 0) {
@@ -241,9 +245,9 @@ __global__ __launch_bounds__(256) void jpeg_sync_kernel(const uint8_t *__restric
     if (t > 0) {
       uint32_t cp = sub_start - SUBSEQ;
       if (t > 1 && rd.ld(cp - 1) == 0xFFu && rd.ld(cp) == 0u) cp += 1;
-      const SubRec r0 = t > 1 ? decode_sub<false>(rd, cp, 0, sub_start, 0, 0, g, f, luts, fast, nullptr, 0, 0, nullptr)
-                              : decode_sub<false>(rd, sg.byte_start, 0, sub_start, 0, 0, g, f, luts, fast, nullptr, 0, 0, nullptr);   // (the segment's first: true state)
-      SubRec r1 = decode_sub<false>(rd, r0.pos >> 3, r0.pos & 7, sub_end, r0.state >> 6, r0.state & 63, g, f, luts, fast, nullptr, 0, 0, nullptr);
+      const SubRec r0 = t > 1 ? decode_sub<false>(rd, cp, 0, sub_start, 0, 0, g, f, luts, fast, sh_fast, in_lds, nullptr, 0, 0, nullptr)
+                              : decode_sub<false>(rd, sg.byte_start, 0, sub_start, 0, 0, g, f, luts, fast, sh_fast, in_lds, nullptr, 0, 0, nullptr);   // (the segment's first: true state)
+      SubRec r1 = decode_sub<false>(rd, r0.pos >> 3, r0.pos & 7, sub_end, r0.state >> 6, r0.state & 63, g, f, luts, fast, sh_fast, in_lds, nullptr, 0, 0, nullptr);
       r1.in_pos = r0.pos;
       r1.in_state = r0.state;
       rec[sub] = r1;
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(256) void jpeg_sync_kernel(const uint8_t *__restric
 #endif
     uint32_t cp = sub_start;
     if (t > 0 && rd.ld(cp - 1) == 0xFFu && rd.ld(cp) == 0u) cp += 1;     // a stuffed byte is not data
-    rec[sub] = decode_sub<false>(rd, cp, 0, sub_end, 0, 0, g, f, luts, fast, nullptr, 0, 0, nullptr);
+    rec[sub] = decode_sub<false>(rd, cp, 0, sub_end, 0, 0, g, f, luts, fast, sh_fast, in_lds, nullptr, 0, 0, nullptr);
     return;
   }
   volatile SubRec *vrec = rec;
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(256) void jpeg_sync_kernel(const uint8_t *__restric
       if (ppos != in_pos || pstate != in_state) {     // decode again only from a start this thread has not decoded from yet
         in_pos = ppos;
         in_state = pstate;
-        const SubRec r = decode_sub<false>(rd, ppos >> 3, ppos & 7, sub_end, pstate >> 6, pstate & 63, g, f, luts, fast, nullptr, 0, 0, nullptr);
+        const SubRec r = decode_sub<false>(rd, ppos >> 3, ppos & 7, sub_end, pstate >> 6, pstate & 63, g, f, luts, fast, sh_fast, in_lds, nullptr, 0, 0, nullptr);
         ch = (vrec[sub].pos != r.pos || vrec[sub].state != r.state || vrec[sub].nblk != r.nblk) ? 1 : 0;
         vrec[sub].pos = r.pos; vrec[sub].state = (uint16_t)r.state; vrec[sub].nblk = r.nblk;
         vrec[sub].in_pos = in_pos; vrec[sub].in_state = (uint16_t)in_state;
@@ -313,7 +317,9 @@ __global__ __launch_bounds__(256) void jpeg_write_kernel(const uint8_t *__restri
   __shared__ uint32_t sh_set;
   if (threadIdx.x == 0) sh_set = f.lut;
   __syncthreads();
-  fast = stage_fast(fast, sh_set, f.lut, sh_fast);
+  stage_fast(fast, sh_set, sh_fast);
+  const bool in_lds = f.lut == sh_set;
+  fast += (size_t)f.lut * 8 * FAST_SIZE;
   if (!live) return;
   const uint32_t t = sub - sg.first_sub;
   Reader rd{scan + f.scan_off, sg.byte_end};
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(256) void jpeg_write_kernel(const uint8_t *__restri
   }
   if (b0 >= sg.nblocks) return;
   int16_t *cf = coef + ((size_t)sg.frame * g.blocks_per_frame + sg.block_base) * 64;
-  const SubRec r = decode_sub<true>(rd, cp, cb, sub_end, slot, k, g, f, luts, fast, cf, b0, sg.nblocks, err);
+  const SubRec r = decode_sub<true>(rd, cp, cb, sub_end, slot, k, g, f, luts, fast, sh_fast, in_lds, cf, b0, sg.nblocks, err);
   if (t + 1 == sg.nsub && b0 + r.nblk < sg.nblocks) atomicExch(err, 1);    // data ran out before the last block
 }
 
