@@ -545,6 +545,80 @@ __global__ __launch_bounds__(256) void jpeg_color420_kernel(Geom g, const uint8_
   }
 }
 
+// The same for a PAIR of rows and eight pixels per thread (the frames of a video: 4:2:0, W a multiple of 8): the rows 2 cy and
+// 2 cy + 1 share the near chroma row cy (far rows cy - 1 / cy + 1), a thread needs the chroma columns c0 - 1 .. c0 + 4 of three
+// rows (a dword and two bytes each instead of eight byte loads per four pixels), luma comes as two 8-byte loads and the 2 x 24
+// output bytes leave as 8-byte stores that are contiguous across the wave.  Threads are dealt over (row pair, column group)
+// linearly, so that no lane idles at widths that are not multiples of 2048.  jpeg_color420_kernel had one row and 1024 pixels
+// per workgroup: 0.93 ms per 256 720p frames for 1.06 GB of traffic.
+__global__ __launch_bounds__(256) void jpeg_color420x2_kernel(Geom g, const uint8_t *__restrict__ planes, uint8_t *__restrict__ rgb) {
+  const int tpp = g.W >> 3, pairs = (g.H + 1) >> 1;            // threads per row pair (W % 8 == 0)
+  const int idx = blockIdx.x * 256 + threadIdx.x, frame = blockIdx.y;
+  if (idx >= tpp * pairs) return;
+  const int cy = idx / tpp, tx = idx - cy * tpp, x0 = tx * 8, c0 = tx * 4;
+  const uint8_t *pl = planes + (size_t)frame * g.planes_per_frame;
+  const int cw = g.cw[1], ch = g.ch[1];
+  const int ym = cy > 0 ? cy - 1 : 0, yp = cy + 1 < ch ? cy + 1 : ch - 1;
+  // chroma column sums 3 * near + far of the six columns, for the even row (far = cy - 1) and the odd row (far = cy + 1)
+  int cs[2][2][6];          // [component][row parity][column]
+#pragma unroll
+  for (int comp = 0; comp < 2; ++comp) {
+    const uint8_t *p = pl + g.plane_off[1 + comp];
+    const int pw = g.plane_w[1 + comp];
+    int v[3][6];            // rows cy - 1, cy, cy + 1
+    const int rows[3] = {ym, cy, yp};
+    if (c0 + 4 <= cw - 1 && c0 >= 1) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const uint8_t *q = p + (size_t)rows[r] * pw + c0;
+        const uint32_t d = *(const uint32_t *)q;
+        v[r][0] = q[-1]; v[r][1] = d & 255; v[r][2] = (d >> 8) & 255; v[r][3] = (d >> 16) & 255; v[r][4] = d >> 24; v[r][5] = q[4];
+      }
+    } else {                 // the plane's edges: columns clamp to 0 .. cw - 1
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const int c = c0 - 1 + i;
+          v[r][i] = p[(size_t)rows[r] * pw + (c < 0 ? 0 : c > cw - 1 ? cw - 1 : c)];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      cs[comp][0][i] = 3 * v[1][i] + v[0][i];
+      cs[comp][1][i] = 3 * v[1][i] + v[2][i];
+    }
+  }
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int y = 2 * cy + par;
+    if (y >= g.H) break;
+    const uint2 y8 = *(const uint2 *)(pl + g.plane_off[0] + (size_t)y * g.plane_w[0] + x0);
+    uint8_t px[24];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ci = 1 + (j >> 1);             // the pixel's chroma column c0 + (j >> 1) in cs[..][..][0..5] (index 0 = c0 - 1)
+      const int Y = ((j < 4 ? y8.x : y8.y) >> (8 * (j & 3))) & 255;
+      const int cb = ((j & 1) ? (3 * cs[0][par][ci] + cs[0][par][ci + 1] + 7) >> 4 : (3 * cs[0][par][ci] + cs[0][par][ci - 1] + 8) >> 4) - 128;
+      const int cr = ((j & 1) ? (3 * cs[1][par][ci] + cs[1][par][ci + 1] + 7) >> 4 : (3 * cs[1][par][ci] + cs[1][par][ci - 1] + 8) >> 4) - 128;
+      const int r = Y + ((91881 * cr + 32768) >> 16);
+      const int b = Y + ((116130 * cb + 32768) >> 16);
+      const int gg = Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
+      px[3 * j] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+      px[3 * j + 1] = (uint8_t)(gg < 0 ? 0 : gg > 255 ? 255 : gg);
+      px[3 * j + 2] = (uint8_t)(b < 0 ? 0 : b > 255 ? 255 : b);
+    }
+    uint8_t *o = rgb + (((size_t)frame * g.H + y) * g.W + x0) * 3;
+    if ((((size_t)o) & 7) == 0) {
+      uint2 w[3];
+      __builtin_memcpy(w, px, 24);
+      ((uint2 *)o)[0] = w[0]; ((uint2 *)o)[1] = w[1]; ((uint2 *)o)[2] = w[2];
+    } else {
+      for (int i = 0; i < 24; ++i) o[i] = px[i];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host: markers
 struct HuffSpec { uint8_t counts[16]; uint8_t syms[256]; int nsym; bool present; };
 
@@ -957,7 +1031,9 @@ extern "C" int tn_jpeg_decode(tn_jpeg *j, const uint8_t *const *data_host, const
   // ---- IDCT, upsampling, colour ----
   hipLaunchKernelGGL(jpeg_idct_kernel, dim3((g.blocks_per_frame + 63) / 64, n), dim3(64), 0, st, g, j->d_frames.p, j->d_coef.p, j->d_planes.p);
   const bool is420 = g.ncomp == 3 && g.hmax == 2 && g.vmax == 2 && g.hs[1] == 1 && g.vs[1] == 1 && g.hs[2] == 1 && g.vs[2] == 1 && g.cw[1] > 2;
-  if (is420)
+  if (is420 && g.W % 8 == 0)
+    hipLaunchKernelGGL(jpeg_color420x2_kernel, dim3(((g.W >> 3) * ((g.H + 1) >> 1) + 255) / 256, n), dim3(256), 0, st, g, j->d_planes.p, rgb);
+  else if (is420)
     hipLaunchKernelGGL(jpeg_color420_kernel, dim3((g.W + 1023) / 1024, g.H, n), dim3(256), 0, st, g, j->d_planes.p, rgb);
   else
     hipLaunchKernelGGL(jpeg_color_kernel, dim3((g.W + 255) / 256, g.H, n), dim3(256), 0, st, g, j->d_planes.p, rgb);
