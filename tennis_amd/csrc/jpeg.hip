@@ -25,8 +25,12 @@
 //      is at most 2 samples wide, as jinit_upsampler chooses) fused with jdcolor.c's fixed-point YCbCr -> RGB.
 // Bit-exact against Pillow / libjpeg-turbo (tests/test_gpu_jpeg.py) and against oracle/jpeg_np.py.
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -780,8 +784,47 @@ struct PinBuf {
 
 }  // namespace
 
+// Persistent host workers for the staging copy (spawning 8 threads per call costs as much as the copy they do)
+struct HostPool {
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  std::function<void(int)> fn;
+  int n_items = 0, next = 0, pending = 0;
+  bool stop = false;
+  explicit HostPool(int nthreads) {
+    for (int t = 0; t < nthreads; ++t) th.emplace_back([this] { work(); });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> g(mu); stop = true; }
+    cv_work.notify_all();
+    for (auto &t : th) t.join();
+  }
+  void work() {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv_work.wait(lk, [&] { return stop || next < n_items; });
+      if (stop) return;
+      const int i = next++;
+      lk.unlock();
+      fn(i);
+      lk.lock();
+      if (--pending == 0) cv_done.notify_all();
+    }
+  }
+  void run(int n, std::function<void(int)> f) {       // f(0) .. f(n-1) on the workers; returns when all are done
+    if (n <= 0) return;
+    std::unique_lock<std::mutex> lk(mu);
+    fn = std::move(f); n_items = n; next = 0; pending = n;
+    cv_work.notify_all();
+    cv_done.wait(lk, [&] { return pending == 0; });
+    n_items = 0;
+  }
+};
+
 struct tn_jpeg {
   tn_ctx *ctx;
+  std::unique_ptr<HostPool> pool;
   PinBuf<uint8_t> h_scan;
   PinBuf<FrameDev> h_frames;
   PinBuf<Seg> h_segs;
@@ -972,22 +1015,27 @@ extern "C" int tn_jpeg_decode(tn_jpeg *j, const uint8_t *const *data_host, const
       if (interval != nint) { tn_set_error("tn_jpeg_decode: file " + std::to_string(i) + ": restart markers do not match the restart interval"); return TN_ERR_INVALID; }
     }
   }
-  {   // entropy-coded bytes -> pinned staging buffer
-    auto copy_range = [&](int a, int b) {
-      for (int i = a; i < b; ++i) {
-        const FrameDev &f = j->h_frames.p[i];
-        const size_t len = f.scan_len, padded = ((len + SUBSEQ - 1) / SUBSEQ) * SUBSEQ + 16;
-        memcpy(j->h_scan.p + f.scan_off, data_host[i] + hd[i].scan_begin, len);
-        memset(j->h_scan.p + f.scan_off + len, 0, padded - len);
-      }
+  {   // entropy-coded bytes -> pinned staging buffer -> device, in groups of frames: the H2D copy of a group runs while the
+      // pool's threads stage the next one (the staging copy and the H2D used to run one after the other: 2.0 + 1.4 ms per
+      // 78 MB batch)
+    auto copy_one = [&](int i) {
+      const FrameDev &f = j->h_frames.p[i];
+      const size_t len = f.scan_len, padded = ((len + SUBSEQ - 1) / SUBSEQ) * SUBSEQ + 16;
+      memcpy(j->h_scan.p + f.scan_off, data_host[i] + hd[i].scan_begin, len);
+      memset(j->h_scan.p + f.scan_off + len, 0, padded - len);
     };
-    const int nthr = so > (4u << 20) ? std::min(8, n) : 1;
-    if (nthr <= 1) {
-      copy_range(0, n);
-    } else {
-      std::vector<std::thread> th;
-      for (int t = 0; t < nthr; ++t) th.emplace_back(copy_range, (int)((long)n * t / nthr), (int)((long)n * (t + 1) / nthr));
-      for (auto &t : th) t.join();
+    const bool big = so > (4u << 20) && n >= 8;
+    if (big && !j->pool) {
+      const unsigned hw = std::thread::hardware_concurrency();
+      j->pool.reset(new HostPool(std::max(2, std::min(16, (int)(hw ? hw / 4 : 8)))));
+    }
+    const int ngroups = big && so > (16u << 20) ? 4 : 1;
+    for (int gi = 0; gi < ngroups; ++gi) {
+      const int ga = (int)((long)n * gi / ngroups), gb = (int)((long)n * (gi + 1) / ngroups);
+      if (big) j->pool->run(gb - ga, [&](int k) { copy_one(ga + k); });
+      else for (int i = ga; i < gb; ++i) copy_one(i);
+      const size_t off_a = j->h_frames.p[ga].scan_off, off_b = gb < n ? (size_t)j->h_frames.p[gb].scan_off : so;
+      TN_HIP_CHECK(hipMemcpyAsync(j->d_scan.p + off_a, j->h_scan.p + off_a, off_b - off_a, hipMemcpyHostToDevice, st));
     }
   }
   const int nseg = (int)segs.size();
@@ -1003,7 +1051,6 @@ extern "C" int tn_jpeg_decode(tn_jpeg *j, const uint8_t *const *data_host, const
     TN_HIP_CHECK(hipMemcpyAsync(j->d_fast.p, j->fast_host.data(), j->fast_host.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
     TN_HIP_CHECK(hipStreamSynchronize(st));       // (pageable source)
   }
-  TN_HIP_CHECK(hipMemcpyAsync(j->d_scan.p, j->h_scan.p, so, hipMemcpyHostToDevice, st));
   TN_HIP_CHECK(hipMemcpyAsync(j->d_frames.p, j->h_frames.p, n * sizeof(FrameDev), hipMemcpyHostToDevice, st));
   TN_HIP_CHECK(hipMemcpyAsync(j->d_segs.p, j->h_segs.p, nseg * sizeof(Seg), hipMemcpyHostToDevice, st));
   TN_HIP_CHECK(hipMemsetAsync(j->d_flags.p, 0, 2 * sizeof(int), st));
