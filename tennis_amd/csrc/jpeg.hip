@@ -118,6 +118,11 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
   uint64_t buf = 0;
   int nb = 0;
   uint32_t pn = cp;
+  // pb: the data byte that holds the first unread bit; sm: bit i set = the i-th buffered byte (from the top) is an FF with a
+  // stuffed 00 behind it.  Kept up to date as bytes enter and leave the buffer, so that the position of the next symbol is
+  // arithmetic (it used to be worked out by walking back over the buffered bytes - two byte loads and a branch per byte, in
+  // every symbol step of every lane whose reader had run past the end of its subsequence).
+  uint32_t pb = cp, sm = 0;
   auto refill = [&]() {
     while (nb <= 32) {
       if (pn + 4 <= rd.end) {
@@ -132,30 +137,26 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
         }
       }
       const uint32_t b = rd.ld(pn);
+      const uint32_t stuffed = (b == 0xFFu && rd.ld(pn + 1) == 0u) ? 1u : 0u;
+      sm |= stuffed << ((nb + 7) >> 3);
       buf |= (uint64_t)b << (56 - nb);
       nb += 8;
-      pn += 1 + ((b == 0xFFu && rd.ld(pn + 1) == 0u) ? 1u : 0u);
+      pn += 1 + stuffed;
     }
   };
-  auto position = [&](uint32_t &pb, uint32_t &bit) {      // data byte and bit of the first unread bit
-    uint32_t q = pn;
-    for (int i = 0; i < (nb >> 3); ++i) q = rd.prev(q);
-    bit = 0;
-    if (nb & 7) {
-      q = rd.prev(q);
-      bit = 8 - (nb & 7);
-    }
-    pb = q;
+  auto consume = [&](int nbits) {      // drop nbits from the top of the buffer
+    const int before = (nb + 7) >> 3;
+    buf <<= nbits;
+    nb -= nbits;
+    const int c = before - ((nb + 7) >> 3);          // bytes that left the buffer
+    pb += (uint32_t)c + (uint32_t)__builtin_popcount(sm & ((1u << c) - 1u));
+    sm >>= c;
   };
   refill();
-  buf <<= cb;
-  nb -= (int)cb;
+  consume((int)cb);
   for (;;) {
-    if (pn >= stop) {
-      position(cp, cb);
-      if (cp >= stop) break;
-    }
-    if (WRITE && first_block + nblk >= max_blocks) { position(cp, cb); break; }     // the rest of the segment is padding
+    if (pb >= stop) break;
+    if (WRITE && first_block + nblk >= max_blocks) break;     // the rest of the segment is padding
     if (nb < 32) refill();
     // one symbol, DC difference (F.2.2.1) and AC coefficient (F.2.2.2) through the same straight-line code: the lanes of a
     // wave are at different places of their blocks, a branch per symbol kind would run both sides for every symbol
@@ -208,9 +209,10 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
     k = block_end ? 0 : kn;
     slot = block_end ? (slot + 1 == g.bpm ? 0 : slot + 1) : slot;
     nblk += block_end ? 1u : 0u;
-    buf <<= nbits;            // <= 27 bits, nb >= 32
-    nb -= nbits;
+    consume(nbits);           // <= 27 bits, nb >= 32
   }
+  cp = pb;
+  cb = (8u - ((uint32_t)nb & 7u)) & 7u;
   if (WRITE && own) {      // the last block began here and ends in the next subsequence: its values so far, one by one
     for (uint32_t h = 0; h < 64; ++h) {
       const uint32_t w = h >> 1, phys = (((w >> 2) ^ sw) << 2) | (w & 3u);
