@@ -123,25 +123,34 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
   // arithmetic (it used to be worked out by walking back over the buffered bytes - two byte loads and a branch per byte, in
   // every symbol step of every lane whose reader had run past the end of its subsequence).
   uint32_t pb = cp, sm = 0;
+  // nx: the four bytes at pn, requested when pn last moved - a refill then appends from a register and only ASKS for the next
+  // dword; the dependent load (and its wait, which stalls the whole wave) is out of the symbols' chain
+  uint32_t nx = 0;
+  auto fetch = [&]() {
+    if (pn + 4 <= rd.end) __builtin_memcpy(&nx, rd.s + pn, 4);
+  };
+  fetch();
   auto refill = [&]() {
     while (nb <= 32) {
-      if (pn + 4 <= rd.end) {
-        uint32_t x;
-        __builtin_memcpy(&x, rd.s + pn, 4);
-        const uint32_t y = ~x;
+      const bool have4 = pn + 4 <= rd.end;
+      if (have4) {
+        const uint32_t x = nx, y = ~x;
         if ((((y - 0x01010101u) & ~y) & 0x80808080u) == 0) {      // no FF among the four bytes
           buf |= (uint64_t)__builtin_bswap32(x) << (32 - nb);
           nb += 32;
           pn += 4;
+          fetch();
           continue;
         }
       }
-      const uint32_t b = rd.ld(pn);
-      const uint32_t stuffed = (b == 0xFFu && rd.ld(pn + 1) == 0u) ? 1u : 0u;
+      const uint32_t b = have4 ? (nx & 0xFFu) : rd.ld(pn);
+      const uint32_t b1 = have4 ? ((nx >> 8) & 0xFFu) : rd.ld(pn + 1);
+      const uint32_t stuffed = (b == 0xFFu && b1 == 0u) ? 1u : 0u;
       sm |= stuffed << ((nb + 7) >> 3);
       buf |= (uint64_t)b << (56 - nb);
       nb += 8;
       pn += 1 + stuffed;
+      fetch();
     }
   };
   auto consume = [&](int nbits) {      // drop nbits from the top of the buffer
