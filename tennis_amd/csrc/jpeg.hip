@@ -43,7 +43,7 @@ namespace {
 #define TN_JPEG_SUBSEQ 256
 #endif
 #ifndef TN_JPEG_RUNIN
-#define TN_JPEG_RUNIN 1
+#define TN_JPEG_RUNIN 0      // sync pass 0 with a run-in of this many subsequences (measured round 4: 0 / 1 / 2 -> 8.35 / 8.47 / 8.55 ms per batch)
 #endif
 constexpr int SUBSEQ = TN_JPEG_SUBSEQ;     // bytes of entropy-coded data per decoding thread
 constexpr int MAX_SLOTS = 10;   // blocks per MCU (T.81 B.2.3: sum of Hi x Vi <= 10)
@@ -285,14 +285,14 @@ __global__ __launch_bounds__(256) void jpeg_sync_kernel(const uint8_t *__restric
   if (pass == 0) {
     if (!live) return;
 #if TN_JPEG_RUNIN
-    // run-in: start one subsequence EARLIER with the guessed state, so that the decoder has usually fallen into step with the
-    // true one when it crosses into its own subsequence; the crossing state is recorded as the start of the record (the fix-up
-    // pass decodes again only where the predecessor's end differs from it)
+    // run-in: start TN_JPEG_RUNIN subsequences EARLIER with the guessed state, so that the decoder has usually fallen into step
+    // with the true one when it crosses into its own subsequence; the crossing state is recorded as the start of the record (the
+    // fix-up pass decodes again only where the predecessor's end differs from it)
     if (t > 0) {
-      uint32_t cp = sub_start - SUBSEQ;
-      if (t > 1 && rd.ld(cp - 1) == 0xFFu && rd.ld(cp) == 0u) cp += 1;
-      const SubRec r0 = t > 1 ? decode_sub<false>(rd, cp, 0, sub_start, 0, 0, g, f, luts, fast, sh_fast, in_lds, nullptr, 0, 0, nullptr)
-                              : decode_sub<false>(rd, sg.byte_start, 0, sub_start, 0, 0, g, f, luts, fast, sh_fast, in_lds, nullptr, 0, 0, nullptr);   // (the segment's first: true state)
+      const bool from_start = t <= (uint32_t)TN_JPEG_RUNIN;        // the segment's first byte: the true state
+      uint32_t cp = from_start ? sg.byte_start : sub_start - (uint32_t)TN_JPEG_RUNIN * SUBSEQ;
+      if (!from_start && rd.ld(cp - 1) == 0xFFu && rd.ld(cp) == 0u) cp += 1;
+      const SubRec r0 = decode_sub<false>(rd, cp, 0, sub_start, 0, 0, g, f, luts, fast, sh_fast, in_lds, nullptr, 0, 0, nullptr);
       SubRec r1 = decode_sub<false>(rd, r0.pos >> 3, r0.pos & 7, sub_end, r0.state >> 6, r0.state & 63, g, f, luts, fast, sh_fast, in_lds, nullptr, 0, 0, nullptr);
       r1.in_pos = r0.pos;
       r1.in_state = r0.state;
