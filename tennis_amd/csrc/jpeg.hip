@@ -25,6 +25,9 @@
 //      is at most 2 samples wide, as jinit_upsampler chooses) fused with jdcolor.c's fixed-point YCbCr -> RGB.
 // Bit-exact against Pillow / libjpeg-turbo (tests/test_gpu_jpeg.py) and against oracle/jpeg_np.py.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <condition_variable>
 #include <cstring>
 #include <functional>
@@ -927,6 +930,11 @@ extern "C" int tn_jpeg_decode(tn_jpeg *j, const uint8_t *const *data_host, const
   TN_REQUIRE(n > 0 && n <= 65535, "tn_jpeg_decode: batch must be in 1..65535");
   TN_ON_DEVICE(j->ctx->device);
   hipStream_t st = j->ctx->stream;
+  static const bool timing = getenv("TN_JPEG_TIMING") != nullptr;      // tuning: host wall clock of the call's phases on stderr
+  const auto tnow = [] { return std::chrono::steady_clock::now(); };
+  auto t_prev = tnow();
+  double t_phase[6] = {0, 0, 0, 0, 0, 0};
+  auto lap = [&](int i) { if (timing) { const auto t = tnow(); t_phase[i] += std::chrono::duration<double, std::milli>(t - t_prev).count(); t_prev = t; } };
 
   // ---- headers ----
   std::vector<Header> hd(n);
@@ -1059,6 +1067,7 @@ extern "C" int tn_jpeg_decode(tn_jpeg *j, const uint8_t *const *data_host, const
       if (interval != nint) { tn_set_error("tn_jpeg_decode: file " + std::to_string(i) + ": restart markers do not match the restart interval"); return TN_ERR_INVALID; }
     }
   }
+  lap(0);       // headers, tables, segments
   {   // entropy-coded bytes -> pinned staging buffer -> device, in groups of frames: the H2D copy of a group runs while the
       // pool's threads stage the next one (the staging copy and the H2D used to run one after the other: 2.0 + 1.4 ms per
       // 78 MB batch)
@@ -1071,7 +1080,8 @@ extern "C" int tn_jpeg_decode(tn_jpeg *j, const uint8_t *const *data_host, const
     const bool big = so > (4u << 20) && n >= 8;
     if (big && !j->pool) {
       const unsigned hw = std::thread::hardware_concurrency();
-      j->pool.reset(new HostPool(std::max(2, std::min(16, (int)(hw ? hw / 4 : 8)))));
+      const char *pe = getenv("TN_JPEG_THREADS");
+      j->pool.reset(new HostPool(pe ? std::max(1, atoi(pe)) : std::max(2, std::min(16, (int)(hw ? hw / 4 : 8)))));
     }
     const int ngroups = big && so > (16u << 20) ? 4 : 1;
     for (int gi = 0; gi < ngroups; ++gi) {
@@ -1100,6 +1110,8 @@ extern "C" int tn_jpeg_decode(tn_jpeg *j, const uint8_t *const *data_host, const
   TN_HIP_CHECK(hipMemsetAsync(j->d_flags.p, 0, 2 * sizeof(int), st));
   TN_HIP_CHECK(hipMemsetAsync(j->d_coef.p, 0, (size_t)n * g.blocks_per_frame * 64 * sizeof(int16_t), st));
 
+  lap(1);       // staging + issue of the copies
+  if (timing) { (void)hipStreamSynchronize(st); lap(2); }      // what of the H2D was still outstanding
   // ---- Huffman decode ----
   const unsigned gsub = (total_sub + 255) / 256;
   hipLaunchKernelGGL(jpeg_sync_kernel, dim3(gsub), dim3(256), 0, st, j->d_scan.p, j->d_frames.p, j->d_segs.p, nseg, g, j->d_luts.p, j->d_fast.p, j->d_rec.p,
@@ -1115,6 +1127,7 @@ extern "C" int tn_jpeg_decode(tn_jpeg *j, const uint8_t *const *data_host, const
     if (!j->h_flags.p[0]) break;
   }
   j->last_sync_passes = pass;
+  lap(3);       // sync passes (each ends in a host round trip)
   hipLaunchKernelGGL(jpeg_block_scan_kernel, dim3(nseg), dim3(256), 0, st, j->d_segs.p, j->d_rec.p, j->d_base.p);
   hipLaunchKernelGGL(jpeg_write_kernel, dim3(gsub), dim3(256), 0, st, j->d_scan.p, j->d_frames.p, j->d_segs.p, nseg, g, j->d_luts.p, j->d_fast.p, j->d_rec.p,
                      j->d_base.p, total_sub, j->d_coef.p, j->d_flags.p + 1);
@@ -1131,6 +1144,9 @@ extern "C" int tn_jpeg_decode(tn_jpeg *j, const uint8_t *const *data_host, const
   TN_HIP_CHECK(hipGetLastError());
   TN_HIP_CHECK(hipMemcpyAsync(j->h_flags.p + 1, j->d_flags.p + 1, sizeof(int), hipMemcpyDeviceToHost, st));
   TN_HIP_CHECK(hipStreamSynchronize(st));
+  lap(4);       // write pass, DC scan, IDCT, colour
+  if (timing) fprintf(stderr, "tn_jpeg_decode: host %.2f | staging %.2f | H2D tail %.2f | sync passes %.2f | rest %.2f ms\n", t_phase[0], t_phase[1],
+                      t_phase[2], t_phase[3], t_phase[4]);
   if (j->h_flags.p[1]) { tn_set_error("tn_jpeg_decode: corrupt entropy-coded data (bad Huffman code, coefficient index or block count)"); return TN_ERR_INVALID; }
   if (width) *width = g.W;
   if (height) *height = g.H;
