@@ -1245,7 +1245,7 @@ extern "C" int tn_gnmt_create_ex(tn_ctx *ctx, const tn_param *params, int n_para
       // lines of an instruction fall into a quarter of the L2 channels; the rows of the beam search's operands get a pitch
       // that spreads them (tuning: TN_GNMT_PAD=<floats>)
       const char *pe = getenv("TN_GNMT_PAD");
-      const int K1p = K1 + (pe ? atoi(pe) : kGemmPitchPad);
+      const int K1p = K1 + (((pe ? std::max(0, atoi(pe)) : kGemmPitchPad) + 3) & ~3);      // (rows stay 16-byte aligned)
       g->K1p = K1p;
       const std::vector<float> &w1 = last_w;
       std::vector<float> w1p((size_t)4 * H * K1p, 0.f);
