@@ -29,13 +29,23 @@ def paths(tag, b):
     return [os.path.join(args.dir, tag, "V%03d" % b, "%05d.npy" % i) for i in range(args.frames)]
 
 
-def run(tag, save):
+def run(tag, save, defer=False):
+    """defer: the batch before is copied to the host and saved after this batch's forward has been queued (what
+    tennis_amd.evaluate.save_features does since round 4)"""
     shutil.rmtree(os.path.join(args.dir, tag), ignore_errors=True)
     t0 = time.perf_counter()
+    pending = None
     for b in range(args.batches):
         f = net(x)
         if save is not None:
-            save(f.cpu().numpy(), paths(tag, b))
+            if defer:
+                if pending is not None:
+                    save(pending[0].cpu().numpy(), pending[1])
+                pending = (f, paths(tag, b))
+            else:
+                save(f.cpu().numpy(), paths(tag, b))
+    if pending is not None:
+        save(pending[0].cpu().numpy(), pending[1])
     torch.cuda.synchronize()
     return time.perf_counter() - t0
 
@@ -53,7 +63,7 @@ out["encode_only_fps"] = n / run("none", None)
 out["np_save_loop_fps"] = n / run("py", np_save)
 w = NpyWriter(threads=args.threads or None)
 t0 = time.perf_counter()
-dt = run("native", w.submit)
+dt = run("native", w.submit, defer=True)
 written, skipped = w.drain()
 dt_total = dt + 0.0
 dt_total = time.perf_counter() - t0

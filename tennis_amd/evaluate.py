@@ -101,15 +101,25 @@ def save_features(net, loader, dataset, ctx=None, verbose=True):
     frame at save_feature_path(idx), skipped when the file already exists.  The files are written by ``NpyWriter``'s threads
     behind the next batch's encode (round 4); the count returned is the number of files that did not exist."""
     writer = NpyWriter()
+    pending = None          # (features on the device, paths) of the batch before: copied to the host and handed to the writer
+                            # AFTER the next batch's forward has been queued, so that the copy waits for nothing but its own batch
+
+    def flush(item):
+        feat, paths = item
+        if verbose:
+            for feat_path in paths:
+                if not os.path.exists(feat_path):
+                    print("Saving %s" % feat_path)
+        writer.submit(feat.cpu().numpy(), paths)
+
     try:
         for data, _labels, idxs in loader:
-            feat = net.backbone(data).cpu().numpy()
-            paths = [dataset.save_feature_path(int(j)) for j in idxs]
-            if verbose:
-                for feat_path in paths:
-                    if not os.path.exists(feat_path):
-                        print("Saving %s" % feat_path)
-            writer.submit(feat, paths)
+            feat = net.backbone(data)
+            if pending is not None:
+                flush(pending)
+            pending = (feat, [dataset.save_feature_path(int(j)) for j in idxs])
+        if pending is not None:
+            flush(pending)
         written, _skipped = writer.drain()
     finally:
         writer.close()
@@ -136,17 +146,23 @@ def save_features_sharded(net, loader, dataset, device=None, rank=None, world=No
         rank, world = sharding._rank(group), sharding._world(group)
     fdim = _backbone_dim(net, loader)
     writer = NpyWriter() if write else None
+    pending = []            # the batch before this one: written out once this one's forward is queued (see save_features)
 
-    def encode(s, e):
-        data, _labels, idxs = loader.collate(range(s, e))
-        feat = net.backbone(data)
-        if write:
-            paths = [dataset.save_feature_path(int(j)) for j in idxs]
+    def flush():
+        while pending:
+            feat, paths = pending.pop(0)
             if verbose:
                 for feat_path in paths:
                     if not os.path.exists(feat_path):
                         print("Saving %s" % feat_path)
             writer.submit(feat.detach().cpu().numpy(), paths)
+
+    def encode(s, e):
+        data, _labels, idxs = loader.collate(range(s, e))
+        feat = net.backbone(data)
+        if write:
+            flush()
+            pending.append((feat, [dataset.save_feature_path(int(j)) for j in idxs]))
         return feat
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
@@ -154,6 +170,8 @@ def save_features_sharded(net, loader, dataset, device=None, rank=None, world=No
     try:
         full = sharding.extract_features_sharded(encode, len(dataset), loader.batch_size, fdim, device, rank=rank, world=world,
                                                  group=group, block=block, stats=stats, comm=comm)
+        if writer is not None:
+            flush()
         written = writer.drain()[0] if writer is not None else 0
     finally:
         if writer is not None:
