@@ -293,7 +293,7 @@ int launch_rnn_recurrent(int gates, const float *gi, int ldgi, const float *whT,
   } while (0)
   // one row per workgroup and a column that does not fit the registers (H = 256): registers + LDS + stream, h through DPP
   if (nb == 1 && H == 256) {
-    constexpr int KR3 = 96, KL3 = 48, KR4 = 64, KL4 = 32;
+    constexpr int KR3 = 112, KL3 = 48, KR4 = 64, KL4 = 32;
     const int kl = gates == 3 ? KL3 : KL4;
     const size_t lds2 = (size_t)(2 * H + gates * H + kl * gates * H) * sizeof(float);
     if (gates == 3) {
