@@ -503,7 +503,7 @@ int launch_scatter_pool_grad(const float *dpooled, const int32_t *arg, int B, in
     const dim3 grid((B + nb - 1) / nb, DIRS), block(threads);                                                     \
     const size_t lds = (size_t)(nb * H * (GATES == 4 ? 2 : 1) + 2 * nb * GATES * H) * sizeof(float);              \
     if (nb == 1 && H == 256) {   /* the column does not fit the registers: registers + LDS + stream (rnn_dot.h) */       \
-      constexpr int KRb = GATES == 3 ? 96 : 64, KLb = GATES == 3 ? 48 : 32, MTb = GATES == 3 ? 768 : 1024;              \
+      constexpr int KRb = GATES == 3 ? 112 : 64, KLb = GATES == 3 ? 48 : 32, MTb = GATES == 3 ? 768 : 1024;              \
       const size_t lds2 = lds + (size_t)KLb * GATES * H * sizeof(float);                                                 \
       TN_SET_ATTR_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void *)KERNEL<1, KRb, MTb, KLb>,                      \
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));    \
