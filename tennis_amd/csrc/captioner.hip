@@ -1128,7 +1128,7 @@ struct tn_gnmt {
   // b1x = b0, ew (V, 4H) = embedding . first cell's embedding columns (made on the first search), p0 (R, 4H) the [h0, ctx]
   // share of the next step's pre-activations, h0n2 / c0n2 the second buffers of the first cell's states (a step reads the
   // previous step's by parent row while it writes its own)
-  float *w1x, *b1x, *ew, *p0, *h0n2, *c0n2, *w1cp, *sx1p;
+  float *w1x, *b1x, *ew, *p0, *h0n2, *c0n2, *w1cp, *sx1p, *w1k4;
   int K1p;                 // pitch of w1cp / w1x / sx1p, see kGemmPitchPad
   bool ew_ready;
   int32_t *bp_par, *bp_word;   // (maxL, R) back-pointers of the search
@@ -1251,6 +1251,12 @@ extern "C" int tn_gnmt_create_ex(tn_ctx *ctx, const tn_param *params, int n_para
       std::vector<float> w1p((size_t)4 * H * K1p, 0.f);
       for (int row = 0; row < 4 * H; ++row) memcpy(&w1p[(size_t)row * K1p], &w1[(size_t)row * K1], sizeof(float) * K1);
       g->w1cp = g->pool.upload(w1p.data(), w1p.size());
+      {   // the same weights k-group-major for the step's gate GEMM (lat_tile_f32<true>)
+        std::vector<float> wk((size_t)K1 * 4 * H);
+        for (int row = 0; row < 4 * H; ++row)
+          for (int k = 0; k < K1; ++k) wk[((size_t)(k >> 2) * 4 * H + row) * 4 + (k & 3)] = w1[(size_t)row * K1 + k];
+        g->w1k4 = g->pool.upload(wk.data(), wk.size());
+      }
       g->sx1p = g->pool.alloc<float>((size_t)max_batch * beam * K1p);
       std::vector<float> wx((size_t)4 * H * K1p, 0.f);
       for (int row = 0; row < 4 * H; ++row) {
@@ -1428,7 +1434,7 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
       hipLaunchKernelGGL(dec_mid_cell_kernel, dim3(nbm_), dim3(256), 0, s, (const float *)m.g, (const float *)m.sx, lstm ? 1 : 0,
                          (const float *)m.ccur, m.hn, m.cn, j + 1 < nmid ? g->mid[j + 1].sx : g->sx1, g->residual ? 1 : 0, R, H);
     }
-    rc = fused0 ? launch_linear_f32_lat(sx1, ld1, g->w1cp, ld1, g->b1c, g->g1, 4 * H, R, 4 * H, K1, s)
+    rc = fused0 ? launch_linear_f32_lat_wk4(sx1, ld1, g->w1k4, g->b1c, g->g1, 4 * H, R, 4 * H, K1, s)
                 : launch_linear_f32_lat(g->sx1, K1, g->w1c, K1, g->b1c, g->g1, 4 * H, R, 4 * H, K1, s);
     if (rc) return rc;
     // BeamSearchScorer [EXT gluonnlp]: length penalty ((K + length) / (K + 1)) ^ alpha of this step and of the previous one
