@@ -26,6 +26,9 @@
 namespace {
 
 constexpr float kNeg = -1e18f;
+// element (row r, column k) of a decoder cell's step-input matrix: row-major with pitch ld > 0, or k-group-major
+// ([k/4][rows][4], the operand form of lat_tile_f32<.., true>) with -ld rows
+__device__ __forceinline__ long xidx(long r, int k, int ld) { return ld > 0 ? r * ld + k : ((long)(k >> 2) * (-ld) + r) * 4 + (k & 3); }
 constexpr int kGemmPitchPad = 16;   // floats; measured at config C5: 0 / 32 / 64 / 96: 44.2 us per step, 16 / 48 / 80: 42.2
 
 __device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(kBeamThreads) void dec_attention_kernel(
       v = (1.f - zg) * ng + zg * hprev[rp * ldh + u];
     }
     hn[r * H + u] = v;
-    x1[r * ldx1 + u] = v;
+    x1[xidx(r, u, ldx1)] = v;
     q[u] = v * inv;
   }
   __syncthreads();
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(kBeamThreads) void dec_attention_kernel(
     float a = part[u];
     for (int g = 1; g < SG; ++g) a += part[g * H + u];
     ctx[r * H + u] = a;
-    x1[r * ldx1 + H + u] = a;
+    x1[xidx(r, H + u, ldx1)] = a;
   }
   DEC_STAMP(4);
 }
@@ -398,8 +401,12 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
   const int lane = t & 63, wid = t >> 6;
   if (b >= nclips) {      // p0 tiles for the next step (see above); no output that this launch's clips read
     const int tile = (b - nclips) * 4 + (wid >> 2), ntn = gm.N / 16;
-    lat_tile_f32(gm.X, gm.ldx, gm.W, gm.ldw, gm.bias, gm.Y, gm.ldy, gm.M, gm.N, gm.K, (tile / ntn) * 16, (tile % ntn) * 16, wid & 3, lane,
-                 (float (*)[64][4])(sm + (wid >> 2) * (4 * 64 * 4)));
+    if (gm.ldx < 0)
+      lat_tile_f32<false, true>(gm.X, -4 * gm.ldx, gm.W, gm.ldw, gm.bias, gm.Y, gm.ldy, gm.M, gm.N, gm.K, (tile / ntn) * 16, (tile % ntn) * 16, wid & 3,
+                                lane, (float (*)[64][4])(sm + (wid >> 2) * (4 * 64 * 4)));
+    else
+      lat_tile_f32(gm.X, gm.ldx, gm.W, gm.ldw, gm.bias, gm.Y, gm.ldy, gm.M, gm.N, gm.K, (tile / ntn) * 16, (tile % ntn) * 16, wid & 3, lane,
+                   (float (*)[64][4])(sm + (wid >> 2) * (4 * 64 * 4)));
     return;
   }
   // the old state of the beam row this wave will own (loaded now, used after the projection)
@@ -421,11 +428,11 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
       } else {
         const float rg = sigm(g[u]), zg = sigm(g[H + u]);
         const float ng = tanhf(g[2 * H + u] + rg * g[3 * H + u]);
-        v = (1.f - zg) * ng + zg * x1[r * K1 + 2 * H + u];
+        v = (1.f - zg) * ng + zg * x1[xidx(r, 2 * H + u, K1)];
       }
       if (hstate) {
         hstate[r * H + u] = v;
-        v += x1[r * K1 + u];
+        v += x1[xidx(r, u, K1)];
       }
     }
     h1n[u * NP + k] = v;       // k-major: a projection thread reads its NBM rows with one or two wide LDS loads
@@ -600,7 +607,7 @@ __global__ __launch_bounds__(kBeamThreads) void dec_beam_kernel(
   for (int idx = t; idx < beam * H; idx += kBeamThreads) {
     const int k = idx / H, u = idx - k * H;
     const long r = (long)b * beam + k, pr = (long)b * beam + sel_par[k];
-    x1[r * K1 + 2 * H + u] = hstate ? hstate[pr * H + u] : h1n[u * NP + sel_par[k]];
+    x1[xidx(r, 2 * H + u, K1)] = hstate ? hstate[pr * H + u] : h1n[u * NP + sel_par[k]];
     if (lstm) {
       c1cur[r * H + u] = c1n[u * NP + sel_par[k]];
       if (!tok_out) c0cur[r * H + u] = c0n[pr * H + u];
@@ -704,7 +711,7 @@ __global__ void dec_init_kernel(const float *__restrict__ emb, int bos, const fl
   for (int i = threadIdx.x; i < K0; i += blockDim.x)
     x0[(long)r * K0 + i] = i < E ? emb[(long)bos * E + i] : i < E + H ? 0.f : h0c[(long)b * H + i - E - H];
   for (int u = threadIdx.x; u < H; u += blockDim.x) {
-    x1[(long)r * K1 + 2 * H + u] = h1c[(long)b * H + u];
+    x1[xidx(r, 2 * H + u, K1)] = h1c[(long)b * H + u];
     if (c0c) { c0cur[(long)r * H + u] = c0c[(long)b * H + u]; c1cur[(long)r * H + u] = c1c[(long)b * H + u]; }
   }
 }
@@ -1257,7 +1264,7 @@ extern "C" int tn_gnmt_create_ex(tn_ctx *ctx, const tn_param *params, int n_para
           for (int k = 0; k < K1; ++k) wk[((size_t)(k >> 2) * 4 * H + row) * 4 + (k & 3)] = w1[(size_t)row * K1 + k];
         g->w1k4 = g->pool.upload(wk.data(), wk.size());
       }
-      g->sx1p = g->pool.alloc<float>((size_t)max_batch * beam * K1p);
+      g->sx1p = g->pool.alloc<float>((size_t)max_batch * beam * K1p);      // (k-group-major in the beam search: K1 x rows floats)
       std::vector<float> wx((size_t)4 * H * K1p, 0.f);
       for (int row = 0; row < 4 * H; ++row) {
         float *d = &wx[(size_t)row * K1p];
@@ -1381,7 +1388,7 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
   auto cinit = [&](int i) { return (const float *)(g->cl[i] + (i < g->NBI ? (size_t)B * H : 0)); };
   const bool fused0 = NL == 2;
   float *sx1 = fused0 ? g->sx1p : g->sx1;            // the last cell's step input, pitch ld1
-  const int ld1 = fused0 ? g->K1p : K1;
+  const int ld1 = fused0 ? -(g->maxB * beam) : K1;      // two layers: k-group-major, the form the gate GEMM reads (xidx)
   hipLaunchKernelGGL(dec_init_kernel, dim3(R), dim3(256), 0, s, (const float *)g->emb, bos, hinit(0), hinit(NL - 1),
                      lstm ? cinit(0) : (const float *)nullptr, cinit(NL - 1), g->sx0, sx1, g->c0cur, g->c1cur, beam, H, E, ld1);
   const int nbm_ = (R * H + 255) / 256;
@@ -1403,7 +1410,7 @@ extern "C" int tn_gnmt_beam_search(tn_gnmt *g, int bos, int eos, float alpha, fl
       if (int rc = launch_linear_f32(g->emb, E, g->w0c, K0, nullptr, g->ew, 4 * H, V, 4 * H, E, 0, s)) return rc;
       g->ew_ready = true;
     }
-    gm = LatGemmArgs{sx1, g->w1x, g->b1x, g->p0, ld1, ld1, 4 * H, R, 4 * H, 2 * H};
+    gm = LatGemmArgs{sx1, g->w1x, g->b1x, g->p0, ld1, g->K1p, 4 * H, R, 4 * H, 2 * H};
     gemm_wgs = (((R + 15) / 16) * (4 * H / 16) + 3) / 4;
     if (beam_lds_launch < 4 * 4 * 64 * 4 * sizeof(float)) beam_lds_launch = 4 * 4 * 64 * 4 * sizeof(float);   // the tiles' partial sums
   }

@@ -14,7 +14,8 @@
 constexpr int kLatGroup = 6;
 // WK4: the weights are stored k-group-major, Wt[(k / 4) * ldw + n * 4 + k % 4] with ldw = 4 * (rows of W): the 16 lanes of a
 // quarter wave then read 256 contiguous bytes instead of 16 bytes from each of 16 rows 3 KiB apart.
-template <bool WK4 = false>
+// XK4: the same for X, X[(k / 4) * ldx + m * 4 + k % 4] with ldx = 4 * (rows of X).
+template <bool WK4 = false, bool XK4 = false>
 __device__ __forceinline__ void lat_tile_f32(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw,
                                              const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int K,
                                              int m0, int n0, int wq, int lane, float (*red)[64][4]) {
@@ -22,9 +23,9 @@ __device__ __forceinline__ void lat_tile_f32(const float *__restrict__ X, int ld
   const int nch = (K + 63) / 64;                     // 16-wide k chunks per wave
   const int kbeg = wq * nch * 16;
   const int xm = min(m0 + r, M - 1), wn = min(n0 + r, N - 1);
-  const float *xrow = X + (long)xm * ldx + 4 * q;
+  const float *xrow = XK4 ? X + (long)q * ldx + 4 * xm : X + (long)xm * ldx + 4 * q;
   const float *wrow = WK4 ? Wt + (long)q * ldw + 4 * wn : Wt + (long)wn * ldw + 4 * q;
-  const long wstep = WK4 ? (long)ldw / 4 : 1;      // floats per k in the weights' addressing (16 k = 4 k-groups)
+  const long wstep = WK4 ? (long)ldw / 4 : 1, xstep = XK4 ? (long)ldx / 4 : 1;      // floats per k in an operand's addressing
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int c0 = 0; c0 < nch; c0 += kLatGroup) {
     float4 xa[kLatGroup], wb[kLatGroup];
@@ -32,7 +33,7 @@ __device__ __forceinline__ void lat_tile_f32(const float *__restrict__ X, int ld
     for (int j = 0; j < kLatGroup; ++j) {
       const int k = kbeg + (c0 + j) * 16 + 4 * q;
       const bool ok = c0 + j < nch && k < K;        // (K % 4 == 0: a float4 is all inside or all outside)
-      xa[j] = ok ? *(const float4 *)(xrow + kbeg + (c0 + j) * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+      xa[j] = ok ? *(const float4 *)(xrow + (long)(kbeg + (c0 + j) * 16) * xstep) : make_float4(0.f, 0.f, 0.f, 0.f);
       wb[j] = ok ? *(const float4 *)(wrow + (long)(kbeg + (c0 + j) * 16) * wstep) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
@@ -67,6 +68,7 @@ int launch_linear_f32_lat(const float *X, int ldx, const float *Wt, int ldw, con
                           hipStream_t s);
 // the weights k-group-major (see lat_tile_f32<true>): Wk4[(k / 4) * 4 N + n * 4 + k % 4], K % 4 == 0, X float4-aligned
 int launch_linear_f32_lat_wk4(const float *X, int ldx, const float *Wk4, const float *bias, float *Y, int ldy, int M, int N, int K, hipStream_t s);
+// (ldx < 0: X k-group-major too, with -ldx rows: X[(k / 4) * 4 (-ldx) + m * 4 + k % 4])
 int launch_linear_f32_lat2(const float *X, int ldx, const float *Wt, int ldw, const float *bias, float *Y, int ldy, int M, int N, int K,
                            int nsplit, int K2, hipStream_t s);
 // Y = relu(X * asc[k] + ash[k]) W^T (+ bias): a BatchNorm + ReLU in front of the GEMM applied to the X operand while it is staged

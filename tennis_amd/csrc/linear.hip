@@ -244,7 +244,10 @@ __global__ __launch_bounds__(256) void linear_f32_lat_kernel(const float *__rest
 __global__ __launch_bounds__(256) void linear_f32_lat_wk4_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ Wk4,
                                                                  const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int K) {
   __shared__ float red[4][64][4];
-  lat_tile_f32<true>(X, ldx, Wk4, 4 * N, bias, Y, ldy, M, N, K, blockIdx.y * 16, blockIdx.x * 16, threadIdx.x >> 6, threadIdx.x & 63, red);
+  if (ldx < 0)
+    lat_tile_f32<true, true>(X, -4 * ldx, Wk4, 4 * N, bias, Y, ldy, M, N, K, blockIdx.y * 16, blockIdx.x * 16, threadIdx.x >> 6, threadIdx.x & 63, red);
+  else
+    lat_tile_f32<true>(X, ldx, Wk4, 4 * N, bias, Y, ldy, M, N, K, blockIdx.y * 16, blockIdx.x * 16, threadIdx.x >> 6, threadIdx.x & 63, red);
 }
 
 }  // namespace
@@ -257,7 +260,7 @@ extern "C" int tn_dbg_lat_stamps(long long *out) {
 #endif
 int launch_linear_f32_lat_wk4(const float *X, int ldx, const float *Wk4, const float *bias, float *Y, int ldy, int M, int N, int K, hipStream_t s) {
   if (M <= 0 || N <= 0) return TN_OK;
-  TN_REQUIRE(((ldx | K) & 3) == 0 && (((uintptr_t)X | (uintptr_t)Wk4) & 15) == 0, "linear_f32_lat_wk4: operands must be float4-aligned");
+  TN_REQUIRE((ldx < 0 || (ldx & 3) == 0) && (K & 3) == 0 && (((uintptr_t)X | (uintptr_t)Wk4) & 15) == 0, "linear_f32_lat_wk4: operands must be float4-aligned");
   const dim3 grid((N + 15) / 16, (M + 15) / 16), block(256);
   hipLaunchKernelGGL(linear_f32_lat_wk4_kernel, grid, block, 0, s, X, ldx, Wk4, bias, Y, ldy, M, N, K);
   TN_HIP_CHECK(hipGetLastError());
