@@ -1536,7 +1536,8 @@ extern "C" int tn_gnmt_decode_seq(tn_gnmt *g, const int32_t *tgt, int ld, int st
       hipLaunchKernelGGL(dec_mid_cell_kernel, dim3(nb), dim3(256), 0, s, (const float *)m.g, (const float *)m.sx, lstm ? 1 : 0,
                          (const float *)m.ccur, m.hn, m.cn, j + 1 < nmid ? g->mid[j + 1].sx : g->sx1, g->residual ? 1 : 0, R, H);
     }
-    rc = launch_linear_f32_lat(g->sx1, K1, g->w1c, K1, g->b1c, g->g1, 4 * H, R, 4 * H, K1, s);
+    rc = g->w1k4 ? launch_linear_f32_lat_wk4(g->sx1, K1, g->w1k4, g->b1c, g->g1, 4 * H, R, 4 * H, K1, s)      // (two layers: the k-group-major copy)
+                 : launch_linear_f32_lat(g->sx1, K1, g->w1c, K1, g->b1c, g->g1, 4 * H, R, 4 * H, K1, s);
     if (rc) return rc;
     hipLaunchKernelGGL(dec_tf_cell1_kernel, dim3(nb), dim3(256), 0, s, (const float *)g->g1, (const float *)g->sx1, lstm ? 1 : 0,
                        (const float *)g->c1cur, g->h1n, g->c1n, R, H, g->residual ? g->hstate : (float *)nullptr);
