@@ -148,3 +148,23 @@ def test_cnnrnn_full_size_c3(report):
         e = float(np.abs(got - ref).max())
         report[f"CNNRNN_{mode}_C3_full_size_logits_maxabs_err"] = e
         assert got.shape == (32, 11) and e < 1e-4
+
+
+@pytest.mark.parametrize("mode", ["gru", "lstm"])
+def test_recurrence_h256_does_not_depend_on_the_kernel(mode):
+    """H = 256: three clips run on ``rnn_recurrent_big_kernel`` (one row per workgroup; weights in registers + LDS + stream, h
+    through DPP), the same clips inside a batch of 520 on the four-rows-per-workgroup kernel.  Both sum a gate's dot product over
+    k in ascending order with one accumulator, so the outputs must be bit-identical (csrc/rnn_dot.h)."""
+    from tennis_amd import weights as W
+    from tennis_amd.engine import BiRNN
+    rng = np.random.default_rng(3)
+    F, H, T, B = 32, 256, 9, 520
+    p = W.make_rnn_weights(5, mode, F, H, "r_")
+    rnn = BiRNN(mode, F, H, p, "r_", max_rows=B * T)
+    x = torch.from_numpy(rng.normal(0, 1, (B, T, F)).astype(np.float32)).cuda()
+    vl = torch.from_numpy(rng.integers(1, T + 1, B).astype(np.int32)).cuda()
+    big_seq, big_h, big_c = rnn(x, vl, return_state=True)
+    seq, h, c = rnn(x[:3].contiguous(), vl[:3].contiguous(), return_state=True)
+    assert torch.equal(seq, big_seq[:3]) and torch.equal(h, big_h[:, :3])
+    if mode == "lstm":
+        assert torch.equal(c, big_c[:, :3])
