@@ -142,12 +142,13 @@ int tn_npy_writer_submit(tn_npy_writer *w, const float *rows_host, int n, int di
 int tn_npy_writer_drain(tn_npy_writer *w, int64_t *written, int64_t *skipped);
 int tn_npy_writer_destroy(tn_npy_writer *w);
 /* BatchNorm -> ReLU in front of a dense layer's 1x1 convolution (gluoncv DenseNet _make_dense_layer, reference call site
- * models/vision/definitions.py:30) re-parametrised for the fused kernels' packed-half form: relu(scale x + shift) = m relu(a x + b)
- * with a and b fp16 numbers (a exactly scale / m, b the best of 33 candidates for shift / m); m[k] multiplies column k of the 1x1
- * weights before they are rounded to fp16, which is part of how the fp16 model is defined (weights.as_fp16_model calls this so
- * that the host and the library agree on m bit for bit).  Host code, no GPU involved (csrc/calib_host.hip). */
-int tn_bn_relu_fold_fp16(const float *gamma, const float *beta, const float *running_mean, const float *running_var, int channels,
-                         float *a, float *b, float *m);
+ * models/vision/definitions.py:30) in the fused kernels' rounding-free form: relu(scale x + shift) = sw clamp(x, lo, hi) + tc with
+ * lo / hi fp16 numbers (the ReLU threshold -shift / scale on the side the scale's sign says, +-65504 on the other); sw[k]
+ * multiplies column k of the 1x1 weights before they are rounded to fp16 - part of how the fp16 model is defined
+ * (weights.as_fp16_model calls this so that the host and the library agree bit for bit) - and sum_k w[n][k] tc[k] joins the shift
+ * of the BatchNorm behind the convolution.  Host code, no GPU involved (csrc/calib_host.hip). */
+int tn_bn_relu_clamp_fold(const float *gamma, const float *beta, const float *running_mean, const float *running_var, int channels,
+                          float *lo, float *hi, float *sw, float *tc);
 int tn_densenet121_read_tap(tn_encoder *enc, const char *tap, int batch, float *out_host,
                             size_t capacity, size_t *numel);
 int tn_densenet121_destroy(tn_encoder *enc);

@@ -134,7 +134,7 @@ _SIGS = {
     "tn_npy_writer_submit": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.c_int]),
     "tn_npy_writer_drain": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "tn_npy_writer_destroy": (C.c_int, [_P]),
-    "tn_bn_relu_fold_fp16": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, _P]),
+    "tn_bn_relu_clamp_fold": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, _P, _P]),
     "tn_round_fp16_calibrated": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_double, _P]),
     "tn_dbg_block7_create": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_void_p)]),
     "tn_dbg_block7_run": (C.c_int, [_P, _P, C.c_int, C.c_int]),

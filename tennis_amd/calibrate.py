@@ -38,8 +38,9 @@ def frame_means(params: dict, frames_u8: np.ndarray | torch.Tensor, size=224, pr
         for k, v in enc.input_means(dev[i:i + 1], prefix=prefix).items():
             rows.setdefault(k, []).append(v)
     out = {k: np.stack(v).astype(np.float64) for k, v in rows.items()}
-    x = dev.float().mean((1, 2)).cpu().numpy().astype(np.float64) / 255.0
-    out[prefix + "conv0_weight"] = (x - W.IMAGENET_MEAN.astype(np.float64)) / W.IMAGENET_STD.astype(np.float64)
+    # the stem's operand is x - 255 mean_c (its weights carry 1 / (255 std_c): csrc/common.h "the stem's operand")
+    x = dev.float().mean((1, 2)).cpu().numpy().astype(np.float64)
+    out[prefix + "conv0_weight"] = x - 255.0 * np.array([0.485, 0.456, 0.406])
     del enc
     return out
 

@@ -244,7 +244,7 @@ struct tn_encoder {
   int Cin[4], Cb[4];       // block input / total channels
   int PH, PW;
   f16 *stem_wp, *stem_wp_zf;
-  float *stem_scale, *stem_shift;
+  float *stem_scale, *stem_shift, *stem_shift_u8;
   struct DenseLayer { float *s1, *t1; f16 *w1; float *s2, *t2; f16 *w3p; int cin; f16 *w1s = nullptr, *w3s = nullptr; };   // w1s / w3s: fragment images of the strip kernel
   std::vector<DenseLayer> layers[4];
   struct Trans { float *s, *t; f16 *w; int cin, cout; } trans[3];
@@ -343,10 +343,24 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
   {  // stem: conv0 + batchnorm0
     const float *w0 = pm.get(pre + "conv0_weight", 64 * 3 * 7 * 7);
     if (!w0 || !fold_bn(pm, pre + "batchnorm0", 64, s, t)) return fail(TN_ERR_MISSING);
-    e->stem_wp = e->pool.upload(pack_stem(w0, false));
-    e->stem_wp_zf = e->pool.upload(pack_stem(w0, true));
+    // the input normalisation's 1 / (255 std_c) goes into the weights before they are rounded (common.h "the stem's operand")
+    std::vector<float> w0s((size_t)64 * 3 * 49), tu(64);
+    for (int n = 0; n < 64; ++n) {
+      double bias = 0.0;
+      for (int c = 0; c < 3; ++c)
+        for (int k = 0; k < 49; ++k) {
+          const size_t i = ((size_t)n * 3 + c) * 49 + k;
+          w0s[i] = w0[i] * stem_wfactor(c);
+          bias -= (double)(float)(f16)w0s[i] * stem_pad(c);
+        }
+      s[n] = (float)((double)s[n] / kStemWScale);
+      tu[n] = (float)((double)t[n] + (double)s[n] * bias);
+    }
+    e->stem_wp = e->pool.upload(pack_stem(w0s.data(), false));
+    e->stem_wp_zf = e->pool.upload(pack_stem(w0s.data(), true));
     e->stem_scale = e->pool.upload(s);
     e->stem_shift = e->pool.upload(t);
+    e->stem_shift_u8 = e->pool.upload(tu);
   }
   e->zeros128 = e->pool.upload(std::vector<float>(128, 0.0f));
   e->ones128 = e->pool.upload(std::vector<float>(128, 1.0f));
@@ -365,10 +379,11 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
       const float *w3 = pm.get(sp + "conv" + std::to_string(2 * l + 1) + "_weight", 32 * 128 * 9);
       if (!w1 || !w3) return fail(TN_ERR_MISSING);
       if (!fold_bn(pm, sp + "batchnorm" + std::to_string(2 * l), L.cin, s, t)) return fail(TN_ERR_MISSING);
-      // BN1 + ReLU as relu(s x + t) = m relu(a x + b) with a, b fp16 numbers (calib_host.hip: what the strip / streamed-block kernels'
-      // packed-half BN needs); every kernel of the layer gets (a, b) as its constants and m[k] w[n][k] as its weights
-      std::vector<float> m1(L.cin);
-      bn_relu_fold_fp16(std::vector<float>(s).data(), std::vector<float>(t).data(), L.cin, s.data(), t.data(), m1.data());
+      // BN1 + ReLU as relu(s x + t) = sw clamp(x, lo, hi) + tc with lo, hi fp16 numbers (calib_host.hip::bn_relu_clamp_fold: no
+      // arithmetic and no rounding in front of the 1x1); every kernel of the layer gets (lo, hi) as its constants, sw[k] w[n][k] as
+      // its weights and sum_k w[n][k] tc[k] inside BN2's shift
+      std::vector<float> sw1(L.cin), tc1(L.cin);
+      bn_relu_clamp_fold(std::vector<float>(s).data(), std::vector<float>(t).data(), L.cin, s.data(), t.data(), sw1.data(), tc1.data());
       L.s1 = e->pool.upload(s); L.t1 = e->pool.upload(t);
       if (pack7) { h7[1].push_back(s); h7[2].push_back(t); h7w3.push_back(w3); }
       // The scale of the BatchNorm BEHIND the 1x1 convolution is folded into its weights before they are rounded to fp16
@@ -377,8 +392,18 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
       // still apply a scale get ones.
       if (!fold_bn(pm, sp + "batchnorm" + std::to_string(2 * l + 1), 128, s, t)) return fail(TN_ERR_MISSING);
       std::vector<float> w1f((size_t)128 * L.cin);
-      for (int n = 0; n < 128; ++n)
-        for (int k = 0; k < L.cin; ++k) w1f[(size_t)n * L.cin + k] = s[n] * m1[k] * w1[(size_t)n * L.cin + k];
+      bool in_range = true;
+      for (int n = 0; n < 128; ++n) {
+        double bias = 0.0;
+        for (int k = 0; k < L.cin; ++k) {
+          const float wf = s[n] * sw1[k] * w1[(size_t)n * L.cin + k];
+          w1f[(size_t)n * L.cin + k] = wf;
+          in_range = in_range && std::fabs(wf) <= 65504.0f;
+          bias += (double)w1[(size_t)n * L.cin + k] * (double)tc1[k];
+        }
+        t[n] = (float)((double)t[n] + (double)s[n] * bias);
+      }
+      if (!in_range) { tn_set_error("a 1x1 weight leaves the fp16 range once its BatchNorm scales are folded in (" + sp + "conv" + std::to_string(2 * l) + ")"); return fail(TN_ERR_INVALID); }
       if (e->exact) {
         const int bk = e->Hb[b] >= 28 ? 32 : 64;          // k-tile of the block's fused kernel (dense_layer_big.hip)
         L.w1 = e->pool.upload(split_hi_lo_rows(w1f.data(), 128, L.cin, (L.cin + bk - 1) / bk * bk));
@@ -497,6 +522,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
   for (int b = 0; b < 4; ++b) bbuf[b] = e->blockbuf[b] + (size_t)b0 * e->Hb[b] * e->Wb[b] * e->Cb[b];
   {
     StemArgs a{x, (int)layout, B, e->H, e->W, e->stem_wp, e->stem_wp_zf, e->stem_scale, e->stem_shift, stem_out, e->Hs, e->Ws};
+    a.shift_u8 = e->stem_shift_u8;
     const double px = fB * e->Hs * e->Ws;
     if (e->fuse) {
       tm.begin("stem_conv_bn_relu_maxpool", 2.0 * px * 64 * 147, fB * e->H * e->W * 3 * 2 + fB * e->Hb[0] * e->Wb[0] * 64 * 2);
@@ -518,8 +544,8 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
   // convolution the per-channel mean of that input, in execution order
   const bool cal = e->calib_dev != nullptr;
   float *cal_out = e->calib_dev;
-  auto cal_mean = [&](const f16 *xin, int ld, int K, const float *sc, const float *sh, long rows) {
-    const int rc2 = launch_channel_mean(xin, ld, K, sc, sh, rows, e->calib_scratch, cal_out, s);
+  auto cal_mean = [&](const f16 *xin, int ld, int K, const float *sc, const float *sh, long rows, int clamp = 0) {
+    const int rc2 = launch_channel_mean(xin, ld, K, sc, sh, rows, e->calib_scratch, cal_out, s, clamp);
     cal_out += K;
     return rc2;
   };
@@ -609,9 +635,11 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
         continue;
       }
       // un-fused: BN2 (scale folded into the weights) adds its shift in the 1x1's epilogue, the 3x3 only applies the ReLU
-      if (cal && (rc = cal_mean(bbuf[b], e->Cb[b], L.cin, L.s1, L.t1, M))) return rc;
+      // (the 1x1's operand is clamp(x, lo, hi): that is what its folded weights multiply, and what the calibration averages)
+      if (cal && (rc = cal_mean(bbuf[b], e->Cb[b], L.cin, L.s1, L.t1, M, 1))) return rc;
       Conv1x1Args a1{bbuf[b], e->Cb[b], L.cin, L.s1, L.t1, L.w1, 128, bott, 128, 0, M, 0, Hh, Ww};
       a1.bias = L.t2;
+      a1.clamp = 1;
       tm.begin("conv1x1_bnrelu", 2.0 * M * 128.0 * L.cin, (double)M * (L.cin + 128) * 2 + 128.0 * L.cin * 2);
       rc = launch_conv1x1(a1, s);
       tm.end();

@@ -81,17 +81,21 @@ extern "C" int tn_round_fp16_calibrated(const float *w, int N, int K, const doub
   return TN_OK;
 }
 
-// ---- BatchNorm + ReLU in front of a dense layer's 1x1 convolution as TWO packed-half instructions (round 4) ----
-// The strip / streamed-block kernels are issue-bound: one wave per SIMD, and every 32-cycle MFMA of the 1x1 phase carried one
-// BN1 + ReLU item of four VALU instructions (two v_fma_mix_f32, v_cvt_pk_f16_f32, v_pk_max_f16: fp32 constants).  With fp16
-// constants the item is v_pk_fma_f16 + v_pk_max_f16 - measured 10 - 17 % on the layers with K >= 192 - but rounding s and t to
-// fp16 is an error that is the same in every pixel (the average pool does not reduce it, like a weight-rounding error).  So
-// the constants are not rounded, the layer is re-parametrised: for m > 0
-//     relu(s x + t) = m relu(a x + b),   a = s / m,  b = t / m,
-// and m goes into column k of the 1x1 weights BEFORE they are rounded to fp16 (where BN2's scale already goes).  m is chosen
-// so that a is an fp16 number exactly (a = fp16(s) moved by j ulps, |j| <= 16, m = s / a) and b = t / m is as close to one as
-// the 33 candidates allow (the fraction of b's ulp moves by ~ |b / a| per step: expected residual 1/33 of half an ulp).
-// v_pk_fma_f16 is fused, so a x + b is rounded once - as the fp32 path rounded it.
+// ---- BatchNorm + ReLU in front of a dense layer's 1x1 convolution WITHOUT a rounding (round 5) ----
+// Rounds 1 - 4 evaluated relu(s x + t) per element and rounded the result to fp16 as the MFMA operand: one more rounding per
+// consumed activation, and on flat image regions the SAME error in every pixel (scripts/round_study.py: this
+// rounding alone is 9e-4 on a constant frame).  ReLU commutes with a positive scale:
+//     s > 0:  relu(s x + t) = s max(x, c) + t,   c = -t / s         s < 0:  relu(s x + t) = s min(x, c) + t
+// so the operand of the MFMA is u = clamp(x, lo, hi) - x itself (an fp16 number, stored by the producer) or the threshold: no
+// arithmetic, no rounding, v_pk_max_f16 + v_pk_min_f16 - and the affine part leaves the element-wise path: s goes into column k
+// of the 1x1 weights before they are rounded (where BN2's scale already goes), sum_k w[n][k] t[k] into BN2's shift.
+// What is left of an error is the threshold's own rounding, c16 = fp16(c): pixels on the clipped side get s (c16 - c) instead
+// of 0, at most 2^-11 |t| (the unclipped side is exact; scripts/round_study.py: 1.6e-4 on the features, every frame family).
+//   out: lo, hi  fp16 numbers (as floats);  sw  the factor for column k of the weights;  tc  the constant of channel k
+//   relu(scale x + shift) ~= sw * clamp(x, lo, hi) + tc
+// Degenerate channels: scale 0 / not finite -> the constant relu(shift); a threshold beyond the fp16 range -> the channel is
+// always clipped (constant 0) or never (lo = -65504 / hi = 65504: x is an fp16 number, the clamp does nothing).  A tiny scale
+// (gamma 5e-6, beta 1) is nothing special here: sw = s, tc = t, the threshold far outside the range.
 void bn_scale_shift(const float *gamma, const float *beta, const float *mean, const float *var, int n, float eps, float *scale, float *shift) {
   for (int i = 0; i < n; ++i) {
     const float s = gamma[i] / std::sqrt(var[i] + eps);
@@ -100,51 +104,32 @@ void bn_scale_shift(const float *gamma, const float *beta, const float *mean, co
   }
 }
 
-void bn_relu_fold_fp16(const float *scale, const float *shift, int n, float *a_out, float *b_out, float *m_out) {
-  auto half_clamped = [](double v) {          // nearest fp16 number, +-65504 beyond the range, 0 for a NaN
-    if (!(v == v)) return 0.f;
-    if (v > 65504.0) return 65504.f;
-    if (v < -65504.0) return -65504.f;
-    return (float)(f16)(float)v;
-  };
+void bn_relu_clamp_fold(const float *scale, const float *shift, int n, float *lo, float *hi, float *sw, float *tc) {
+  constexpr double kMax = 65504.0;
   for (int i = 0; i < n; ++i) {
-    double s = scale[i], t = std::isfinite(shift[i]) ? (double)shift[i] : 0.0;
-    if (!std::isfinite(scale[i]) || s == 0.0) {     // relu(t): a constant
-      a_out[i] = 0.f; b_out[i] = half_clamped(t); m_out[i] = 1.f;
-      continue;
+    const double s = scale[i], t = std::isfinite(shift[i]) ? (double)shift[i] : 0.0;
+    auto constant = [&](double v) { lo[i] = 0.f; hi[i] = 0.f; sw[i] = 0.f; tc[i] = (float)v; };
+    if (!std::isfinite(scale[i]) || s == 0.0) { constant(t > 0 ? t : 0.0); continue; }
+    const double c = -t / s;
+    if (s > 0) {
+      if (c > kMax) { constant(0.0); continue; }                // never above the threshold
+      lo[i] = (float)(f16)(float)(c < -kMax ? -kMax : c);
+      hi[i] = (float)kMax;
+    } else {
+      if (c < -kMax) { constant(0.0); continue; }
+      lo[i] = (float)-kMax;
+      hi[i] = (float)(f16)(float)(c > kMax ? kMax : c);
     }
-    // a scale outside fp16's comfortable range: a power of two of it goes into m first (exact)
-    double m0 = 1.0;
-    if (std::fabs(s) < 0x1p-10 || std::fabs(s) > 0x1p12) {
-      int e;
-      (void)std::frexp(s, &e);
-      m0 = std::ldexp(1.0, e);
-      s /= m0; t /= m0;
-    }
-    const f16 a0 = (f16)(float)s;
-    const unsigned short bits0 = __builtin_bit_cast(unsigned short, a0);
-    double best = 1e300;
-    int bj = 0;
-    for (int k = 0; k <= 32; ++k) {
-      const int j = (k & 1) ? -((k + 1) >> 1) : (k >> 1);          // 0, -1, 1, -2, 2, ...: ties go to the smallest |j|
-      const unsigned short bj_bits = (unsigned short)(bits0 + j);    // same sign, exponent stays normal (|s| in [2^-10, 2^12], |j| <= 16 < 1024)
-      const double aj = (double)(float)__builtin_bit_cast(f16, bj_bits);
-      const double bt = t * aj / s;
-      const double err = std::fabs((double)half_clamped(bt) - bt);
-      if (err < best) { best = err; bj = j; }
-    }
-    const unsigned short ab = (unsigned short)(bits0 + bj);
-    const float a = (float)__builtin_bit_cast(f16, ab);
-    a_out[i] = a;
-    m_out[i] = (float)(m0 * s / (double)a);
-    b_out[i] = half_clamped(t * (double)a / s);
+    sw[i] = scale[i];
+    tc[i] = (float)t;
   }
 }
 
-extern "C" int tn_bn_relu_fold_fp16(const float *gamma, const float *beta, const float *mean, const float *var, int n, float *a, float *b, float *m) {
-  TN_REQUIRE(gamma && beta && mean && var && a && b && m && n > 0, "tn_bn_relu_fold_fp16: null argument");
+extern "C" int tn_bn_relu_clamp_fold(const float *gamma, const float *beta, const float *mean, const float *var, int n, float *lo, float *hi,
+                                     float *sw, float *tc) {
+  TN_REQUIRE(gamma && beta && mean && var && lo && hi && sw && tc && n > 0, "tn_bn_relu_clamp_fold: null argument");
   std::vector<float> s(n), t(n);
   bn_scale_shift(gamma, beta, mean, var, n, 1e-5f, s.data(), t.data());
-  bn_relu_fold_fp16(s.data(), t.data(), n, a, b, m);
+  bn_relu_clamp_fold(s.data(), t.data(), n, lo, hi, sw, tc);
   return TN_OK;
 }

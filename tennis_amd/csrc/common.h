@@ -76,27 +76,30 @@ __device__ __forceinline__ f16x8 bn_relu8(f16x8 v, const float *__restrict__ s, 
   return r;
 }
 
-// Same result (fp32 fma, one rounding, ReLU) with the instructions that issue fastest (scripts/scratch/valubench.hip, ns per
-// wave-instruction and SIMD at two waves: v_fma_f32 1.2, v_fma_mix_f32 / v_cvt_pk_f16_f32 / v_pk_max_f16 2.0,
-// v_fma_mixlo/hi_f16 3.6 - 4.2 plus a wait state after every partial write).  fp16 in: v_fma_mix_f32 takes the element
-// straight from the packed register; the pair is rounded by one v_cvt_pk_f16_f32 and the ReLU runs on packed halves
-// (max(round(f), 0) == round(max(f, 0))): 4 instructions / 8.0 ns per dword against 3 / 10.2 ns through mixlo + mixhi.
-__device__ __forceinline__ unsigned bn_relu2_mix(unsigned in, float s0, float s1, float t0, float t1) {
-  float a0, a1;
-  unsigned d, o;
-  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(a0) : "v"(in), "v"(s0), "v"(t0));
-  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(a1) : "v"(in), "v"(s1), "v"(t1));
-  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d) : "v"(a0), "v"(a1));
-  asm("v_pk_max_f16 %0, %1, 0" : "=v"(o) : "v"(d));
+// The dense layers' BN1 + ReLU in its rounding-free form (calib_host.hip::bn_relu_clamp_fold): the operand is clamp(x, lo, hi),
+// lo / hi fp16 numbers handed over as floats.
+__device__ __forceinline__ f16x8 clamp8(f16x8 v, const float *__restrict__ lo, const float *__restrict__ hi) {
+  f16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (f16)fminf(fmaxf((float)v[j], lo[j]), hi[j]);
+  return r;
+}
+// two channels (a packed dword): the constants as floats -> packed halves (exact: they are fp16 numbers), v_pk_max_f16 + v_pk_min_f16.
+// The result usually goes straight into an MFMA as its B operand, and hipcc pads ONE wait state behind an asm statement where a
+// VALU-written MFMA operand needs two (cdna_hip_programming.md 5.7 item 2; seen in round 5 as one stale dword of the first
+// fragment on the waves whose schedule put the MFMA right behind the statement): the statement carries the other one itself.
+__device__ __forceinline__ unsigned clamp2_pk(unsigned in, float lo0, float lo1, float hi0, float hi1) {
+  unsigned l, h, o;
+  asm("v_cvt_pk_f16_f32 %1, %4, %5\n\tv_cvt_pk_f16_f32 %2, %6, %7\n\tv_pk_max_f16 %0, %3, %1\n\tv_pk_min_f16 %0, %0, %2\n\ts_nop 0"
+      : "=&v"(o), "=&v"(l), "=&v"(h) : "v"(in), "v"(lo0), "v"(lo1), "v"(hi0), "v"(hi1));
   return o;
 }
-
-__device__ __forceinline__ f16x8 bn_relu8_mix(f16x8 v, const float *__restrict__ s, const float *__restrict__ t) {
+__device__ __forceinline__ f16x8 clamp8_pk(f16x8 v, const float *__restrict__ lo, const float *__restrict__ hi) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const u32x4 in = __builtin_bit_cast(u32x4, v);
   u32x4 out;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) out[j] = bn_relu2_mix(in[j], s[2 * j], s[2 * j + 1], t[2 * j], t[2 * j + 1]);
+  for (int j = 0; j < 4; ++j) out[j] = clamp2_pk(in[j], lo[2 * j], lo[2 * j + 1], hi[2 * j], hi[2 * j + 1]);
   return __builtin_bit_cast(f16x8, out);
 }
 
@@ -147,6 +150,7 @@ struct Conv1x1Args {
   int variant = 0;    // tuning hook: 0 = default kernel choice
   int exact = 0;      // weights as hi + lo fp16 pairs: w [N][2 K] = [hi | lo] (K % 64 == 0)
   const float *bias = nullptr;   // [N] added to the fp32 result before the rounding to fp16 (no pooling)
+  int clamp = 0;      // the dense layers' BN1 form: scale / shift hold lo / hi, the operand is clamp(x, lo, hi) (no arithmetic, no rounding)
 };
 int launch_conv1x1(const Conv1x1Args &a, hipStream_t s);
 
@@ -252,6 +256,23 @@ size_t dense_block28_scratch_halfs();   // per frame
 std::vector<unsigned char> pack_block28(const std::vector<Block14Layer> &layers, int K0);
 int launch_dense_block28(const DenseBlock28Args &a, hipStream_t s);
 
+// ---- the stem's operand (round 5) -------------------------------------------------------------------------------
+// The reference hands the network ToTensor + Normalize of a decoded frame, v = (x / 255 - mean_c) / std_c (evaluate.py:96-97).
+// Rounding v to fp16 as the MFMA operand was the largest single error on flat frames (scripts/round_study.py: 8e-4 .. 1.3e-3 on
+// the features, the same error in every pixel of a flat region).  The stem therefore works on (x - 255 mean_c): the factor
+// 1 / (255 std_c) is folded into the conv0 weights BEFORE they are rounded (weights.as_fp16_model defines the fp16 model that
+// way; kStemWScale keeps the small weights out of fp16's subnormals and comes out again through the BatchNorm scale).  For
+// uint8 frames the staged operand is the INTEGER x - q_c (q_c = 255 mean_c rounded: exact in fp16, two packed-half
+// instructions per two values), out-of-frame taps are staged as 255 mean_c - q_c (= the normalised zero), and the constant
+// sum w (255 mean_c - q_c) sits in the BatchNorm shift (StemArgs::shift_u8).  Normalised inputs (fp32 NCHW / fp16 NHWC) are
+// staged as v * 255 std_c, rounded once, padding 0.
+constexpr double kStemMean[3] = {0.485, 0.456, 0.406}, kStemStd[3] = {0.229, 0.224, 0.225};
+constexpr float kStemQ[3] = {124.f, 116.f, 104.f};
+constexpr double kStemWScale = 64.0;
+constexpr float stem_unscale(int c) { return (float)(255.0 * kStemStd[c]); }                     // v -> x - 255 mean_c
+constexpr float stem_wfactor(int c) { return (float)(kStemWScale / (255.0 * kStemStd[c])); }     // conv0 weight of input channel c
+constexpr double stem_pad(int c) { return 255.0 * kStemMean[c] - (double)kStemQ[c]; }            // staged value of an out-of-frame tap (u8)
+
 struct StemArgs {
   const void *x;
   int layout;         // tn_layout
@@ -262,6 +283,7 @@ struct StemArgs {
   const float *shift; // [64]
   f16 *y;             // [B][Ho][Wo][64]
   int Ho, Wo;
+  const float *shift_u8 = nullptr;   // the shift for TN_LAYOUT_NHWC_U8 input (carries the constant of the integer staging, see above)
 };
 int launch_stem(const StemArgs &a, hipStream_t s);
 // fused stem + maxpool: writes the pooled map (Hp x Wp x 64) at row stride ldy
@@ -290,11 +312,11 @@ struct PerDeviceFlag {
     }                                                       \
   } while (0)
 
-// BN1 + ReLU of the dense layers as two packed-half instructions: relu(s x + t) = m relu(a x + b) with a, b fp16 numbers and m folded
-// into the 1x1 weights (csrc/calib_host.hip)
+// BN1 + ReLU of the dense layers without a rounding: relu(s x + t) = sw clamp(x, lo, hi) + tc, lo / hi fp16 numbers, sw folded into
+// the 1x1 weights, sum_k w[n][k] tc[k] into BN2's shift (csrc/calib_host.hip)
 void bn_scale_shift(const float *gamma, const float *beta, const float *mean, const float *var, int n, float eps, float *scale, float *shift);
-void bn_relu_fold_fp16(const float *scale, const float *shift, int n, float *a, float *b, float *m);
+void bn_relu_clamp_fold(const float *scale, const float *shift, int n, float *lo, float *hi, float *sw, float *tc);
 int launch_channel_mean(const f16 *x, int ld, int K, const float *scale, const float *shift, long rows, double *scratch /* 32 * K doubles */,
-                        float *out, hipStream_t s);
+                        float *out, hipStream_t s, int clamp = 0 /* scale / shift are lo / hi of the clamp form */);
 int launch_head(const f16 *x, int B, int H, int W, int C, const float *scale, const float *shift,
                 float *feat, int PH, int PW, hipStream_t s);

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
             v[j] = (f16)(0.25f * acc);
           }
         } else {
-          v = bn_relu8(xr[i][0], sc, sh);
+          v = a.clamp ? clamp8(xr[i][0], sc, sh) : bn_relu8(xr[i][0], sc, sh);
         }
       } else {
 #pragma unroll

@@ -221,14 +221,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int J = decltype(j_tag)::value, REG = decltype(reg_tag)::value;
     const u32x4 c = cb[J & 1];
     unsigned o;
-    asm volatile("v_pk_fma_f16 %0, v%c3, %1, %2\n\tv_pk_max_f16 %0, %0, 0" : "=v"(o) : "v"(c.x), "v"(c.y), "n"(REG) : TN_RING_CLOBBER);
+    asm volatile("v_pk_max_f16 %0, v%c3, %1\n\tv_pk_min_f16 %0, %0, %2" : "=&v"(o) : "v"(c.x), "v"(c.y), "n"(REG) : TN_RING_CLOBBER);
     return o;
   };
   auto bn_dword = [&](const unsigned in, auto j_tag) TN_INL -> unsigned {
     constexpr int J = decltype(j_tag)::value;
     const u32x4 c = cb[J & 1];
     unsigned o;
-    asm("v_pk_fma_f16 %0, %1, %2, %3\n\tv_pk_max_f16 %0, %0, 0" : "=v"(o) : "v"(in), "v"(c.x), "v"(c.y));
+    asm("v_pk_max_f16 %0, %1, %2\n\tv_pk_min_f16 %0, %0, %3" : "=&v"(o) : "v"(in), "v"(c.x), "v"(c.y));
     return o;
   };
   // constants of dword J of k-step KQ of the unit at vc: halves (a[2J], a[2J+1]), (b[2J], b[2J+1]), 8 B unused - 16 B per lane

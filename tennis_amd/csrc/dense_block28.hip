@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int J = decltype(j_tag)::value, REG = decltype(reg_tag)::value;
     const u32x4 c = cb[J & 1];
     unsigned o;
-    asm volatile("v_pk_fma_f16 %0, v%c3, %1, %2\n\tv_pk_max_f16 %0, %0, 0" : "=v"(o) : "v"(c.x), "v"(c.y), "n"(REG) : TN_RING_CLOBBER);
+    asm volatile("v_pk_max_f16 %0, v%c3, %1\n\tv_pk_min_f16 %0, %0, %2" : "=&v"(o) : "v"(c.x), "v"(c.y), "n"(REG) : TN_RING_CLOBBER);
     return o;
   };
   auto consts_read = [&](const unsigned vc, auto kq_tag, auto j_tag) TN_INL {

@@ -58,7 +58,7 @@ constexpr int kZeroSlot = 49, kDumpSlot = 50;
 constexpr int kTileOff = kActBytes, kTileBytes = 51 * kSlotPitch;
 constexpr int kRedOff = kTileOff + kTileBytes, kRedBytes = 4 * 8192;
 constexpr int kTabOff = kRedOff + kRedBytes;
-constexpr int kTabFloats = 1024 + 1024 + 128;        // s1 | t1 | t2 of one layer
+constexpr int kTabFloats = 512 + 512 + 128;          // lo1[1024] | hi1[1024] as fp16 (BN1 + ReLU as a clamp: calib_host.hip) | t2[128] fp32 of one layer
 constexpr int kLdsBytes = kTabOff + kTabFloats * 4;
 static_assert(kLdsBytes <= 160 * 1024, "LDS");
 constexpr int kStepUnits = 256;                      // a k-step of the 1x1 stream: 4 fragments x 64 lanes, in 16-byte units
@@ -99,14 +99,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const f32x4 *tb = (const f32x4 *)a.tab;
     f32x4 *tl = (f32x4 *)(smem + kTabOff);
     tl[tid] = tb[tid];
-    tl[256 + tid] = tb[256 + tid];
-    if (tid < 32) tl[512 + tid] = tb[512 + tid];
+    if (tid < 32) tl[256 + tid] = tb[256 + tid];
   }
   __syncthreads();
 
   // ---- lane geometry (the same for every layer) ----
   const unsigned aaddr0 = (unsigned)(h * kPix + n) * 16;                 // pixel fragment of tile 0, chunk h; tile 1: + 512
-  const unsigned caddr0 = kTabOff + h * 32;                              // s1 of channels 8h .. 8h+7; t1: + 4096
+  const unsigned caddr0 = kTabOff + h * 16;                              // lo1 of channels 8h .. 8h+7 (packed halves); hi1: + 2048
   unsigned waddr[2], offb[9][2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -127,30 +126,25 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   // (the LDS reads run TWO steps ahead of the MFMAs, BatchNorm one step ahead: a read issued in step P is consumed by the
   // element-wise work in the shadow of step P+1's MFMAs)
   u32x4 raw[2][2], x[2][2];
-  f32x4 cs[2][4];
+  u32x4 cs[2][2];
   auto read_step = [&](unsigned aad, unsigned cad, auto i_tag) TN_INL {     // step I (relative to aad / cad) -> buffers I & 1
     constexpr int I = decltype(i_tag)::value, Bf = I & 1;
     raw[Bf][0] = __builtin_bit_cast(u32x4, lds_h8(aad + I * 2 * kChunkRow));
     raw[Bf][1] = __builtin_bit_cast(u32x4, lds_h8(aad + I * 2 * kChunkRow + 512));
-    cs[Bf][0] = lds_f4(cad + I * 64);
-    cs[Bf][1] = lds_f4(cad + I * 64 + 16);
-    cs[Bf][2] = lds_f4(cad + I * 64 + 4096);
-    cs[Bf][3] = lds_f4(cad + I * 64 + 4096 + 16);
+    cs[Bf][0] = __builtin_bit_cast(u32x4, lds_h8(cad + I * 32));
+    cs[Bf][1] = __builtin_bit_cast(u32x4, lds_h8(cad + I * 32 + 2048));
   };
-  // BatchNorm + ReLU of two dwords (four channels) of one tile: fp32 fma, one rounding, packed ReLU.  Two independent chains
-  // interleaved in ONE statement: with a single wave on the SIMD nothing else hides the VALU result latency between
-  // fma -> convert -> max, and between two statements hipcc pads the dependency with an s_nop the hardware does not need.
+  // BatchNorm + ReLU of two dwords (four channels) of one tile as a clamp against the channels' thresholds (round 5: no
+  // arithmetic, no rounding - the scale is in the 1x1 weights, the shift in BN2's; calib_host.hip::bn_relu_clamp_fold): two
+  // independent chains in ONE statement (between two statements hipcc pads the dependency with an s_nop the hardware does not
+  // need).  Four packed-half instructions where the fp32 form had eight.
   auto bn_pair = [&](auto u_tag, auto par_tag) TN_INL {
     constexpr int U = decltype(u_tag)::value, T = U >> 1, D0 = 2 * (U & 1), D1 = D0 + 1, PAR = decltype(par_tag)::value;
     const unsigned in0 = raw[PAR][T][D0], in1 = raw[PAR][T][D1];
-    const f32x4 sc = cs[PAR][U & 1], sh = cs[PAR][2 + (U & 1)];     // channels 4 (U & 1) .. + 3 of the lane's eight
-    float t0, t1, t2, t3;
+    const unsigned l0 = cs[PAR][0][D0], l1 = cs[PAR][0][D1], h0 = cs[PAR][1][D0], h1 = cs[PAR][1][D1];
     unsigned o0, o1;
-    asm("v_fma_mix_f32 %2, %6, %8, %12 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %3, %6, %9, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %4, %7, %10, %14 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %5, %7, %11, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5\n\tv_pk_max_f16 %0, %0, 0\n\tv_pk_max_f16 %1, %1, 0"
-        : "=&v"(o0), "=&v"(o1), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-        : "v"(in0), "v"(in1), "v"(sc[0]), "v"(sc[1]), "v"(sc[2]), "v"(sc[3]), "v"(sh[0]), "v"(sh[1]), "v"(sh[2]), "v"(sh[3]));
+    asm("v_pk_max_f16 %0, %2, %4\n\tv_pk_max_f16 %1, %3, %5\n\tv_pk_min_f16 %0, %0, %6\n\tv_pk_min_f16 %1, %1, %7"
+        : "=&v"(o0), "=&v"(o1) : "v"(in0), "v"(in1), "v"(l0), "v"(l1), "v"(h0), "v"(h1));
     x[PAR][T][D0] = o0;
     x[PAR][T][D1] = o1;
   };
@@ -205,7 +199,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), expcnt / lgkmcnt untouched
 
     // ======================= 1x1: partial bottleneck over this wave's k-steps =======================
-    unsigned aad = aaddr0 + (unsigned)g0 * (2 * kChunkRow), cad = caddr0 + (unsigned)g0 * 64;
+    unsigned aad = aaddr0 + (unsigned)g0 * (2 * kChunkRow), cad = caddr0 + (unsigned)g0 * 32;
     read_step(aad, cad, ic<0>{});
     read_step(aad, cad, ic<1>{});
     static_for<4>([&](auto u_tag) TN_INL { bn_pair(u_tag, ic<0>{}); });
@@ -218,7 +212,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     while (b + 2 * D + 1 <= nA) {
       static_for<D>([&](auto i_tag) TN_INL { step(ic<decltype(i_tag)::value + 1>{}, ic<1>{}, ic<0>{}, aad, cad); });
       aad += D * 2 * kChunkRow;
-      cad += D * 64;
+      cad += D * 32;
       b += D;
     }
 #ifdef TN_B7_STAMPS_A
@@ -245,7 +239,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 
     // ======================= reduce the four partial tiles: wave w keeps M-tile w = accumulator set 0 =======================
     const float *tbn = a.tab + (size_t)(l + 1) * kTabFloats;
-    f32x4 tv0, tv1, tv2;
+    f32x4 tv0, tv2;
     static_for<3>([&](auto rd_tag) TN_INL {
       constexpr int RD = decltype(rd_tag)::value + 1;
       {
@@ -260,8 +254,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
       if constexpr (RD == 1) {
         if (l + 1 < a.nl) {        // the next layer's tables: requested now, stored behind the 3x3
           tv0 = ((const f32x4 *)tbn)[tid];
-          tv1 = ((const f32x4 *)tbn)[256 + tid];
-          if (tid < 32) tv2 = ((const f32x4 *)tbn)[512 + tid];
+          if (tid < 32) tv2 = ((const f32x4 *)tbn)[256 + tid];
         }
       }
       {
@@ -281,7 +274,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     stamp();
     // ======================= BN2 shift + ReLU + fp16 -> this wave's 32 channels of the pixel-slot tile =======================
     {
-      const unsigned t2ad = kTabOff + 8192 + (unsigned)(32 * w + 4 * h) * 4;
+      const unsigned t2ad = kTabOff + 4096 + (unsigned)(32 * w + 4 * h) * 4;
       f32x4 sh[4];
       static_for<4>([&](auto g_tag) TN_INL { sh[g_tag.value] = lds_f4(t2ad + g_tag.value * 32); });
       static_for<2>([&](auto t_tag) TN_INL {
@@ -350,8 +343,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
       if (l + 1 < a.nl) {
         f32x4 *tl = (f32x4 *)(smem + kTabOff);
         tl[tid] = tv0;
-        tl[256 + tid] = tv1;
-        if (tid < 32) tl[512 + tid] = tv2;
+        if (tid < 32) tl[256 + tid] = tv2;
       }
     }
     __syncthreads();
@@ -374,7 +366,7 @@ bool dense_block7_supported(int H, int W, int K0, int nl) {
 //      kRingDepth zero steps (the last layer's "next layer" refill).
 //  wb: for wave w, layer l, tap, s: one A fragment of the 3x3: row r = output channel 16 (r >> 4) + 8 ((r >> 2) & 1) + (r & 3) +
 //      4 ((r >> 3) & 1); k = 8 h + i = bottleneck channel 32 w + (i & 3) + 8 (2 s + (i >> 2)) + 4 h.
-//  tab: per layer s1[1024] | t1[1024] | t2[128], zero-padded.
+//  tab: per layer lo1[1024] | hi1[1024] as fp16 (zero-padded: a padding channel clamps to 0) | t2[128] fp32.
 Block7Image pack_block7(const std::vector<Block7Layer> &layers, int K0) {
   Block7Image img;
   const int nl = (int)layers.size();
@@ -404,9 +396,12 @@ Block7Image pack_block7(const std::vector<Block7Layer> &layers, int K0) {
     }
     img.tab.resize((size_t)(l + 1) * kTabFloats, 0.f);
     float *tb = img.tab.data() + (size_t)l * kTabFloats;
-    memcpy(tb, L.s1, sizeof(float) * K);
-    memcpy(tb + 1024, L.t1, sizeof(float) * K);
-    memcpy(tb + 2048, L.t2, sizeof(float) * 128);
+    f16 *th = (f16 *)tb;
+    for (int k = 0; k < K; ++k) {
+      th[k] = (f16)L.s1[k];           // (fp16 numbers: bn_relu_clamp_fold)
+      th[1024 + k] = (f16)L.t1[k];
+    }
+    memcpy(tb + 1024, L.t2, sizeof(float) * 128);
   }
   for (int w = 0; w < 4; ++w) {
     wave_a[w].resize(wave_a[w].size() + (size_t)kRingDepth * kStepUnits * 8, (f16)0.f);

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
 #pragma unroll
     for (int mi = 0; mi < MIW; ++mi) {
       if (mrow0 + mi * 16 < MA) {                  // wave-uniform: fragments past the frame's rows are skipped
-        const f16x8 xb = bn_relu8_mix(o.x[mi], o.sc, o.sh);
+        const f16x8 xb = clamp8_pk(o.x[mi], o.sc, o.sh);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.wa[ni], xb, acc[ni][mi], 0, 0, 0);
       }
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
           const float sh[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
           u32x4 xb, xn;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) xb[j] = bn_relu2_mix(xraw[0][j], sc[2 * j], sc[2 * j + 1], sh[2 * j], sh[2 * j + 1]);
+          for (int j = 0; j < 4; ++j) xb[j] = clamp2_pk(xraw[0][j], sc[2 * j], sc[2 * j + 1], sh[2 * j], sh[2 * j + 1]);
 #pragma unroll
           for (int mi = 0; mi < NF; ++mi) {
             const f16x8 xf = __builtin_bit_cast(f16x8, xb);
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(512) void dense_layer_kernel(DenseLayerArgs a) {
             for (int ni = 0; ni < NI; ++ni) {
               acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ni], xf, acc[ni][mi], 0, 0, 0);
               if (mi + 1 < NF && ni < 4) {
-                xn[ni] = bn_relu2_mix(xraw[mi + 1][ni], sc[2 * ni], sc[2 * ni + 1], sh[2 * ni], sh[2 * ni + 1]);
+                xn[ni] = clamp2_pk(xraw[mi + 1][ni], sc[2 * ni], sc[2 * ni + 1], sh[2 * ni], sh[2 * ni + 1]);
                 __builtin_amdgcn_sched_barrier(0);
               }
             }

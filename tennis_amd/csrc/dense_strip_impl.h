@@ -333,8 +333,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int Q = decltype(q_tag)::value, J = decltype(j_tag)::value;
     const unsigned in = ring[Q >> 2][Q & 3][J];
     const unsigned sc = cs[Q % 3][J], sh = ct[Q % 3][J];
-    unsigned o;      // relu(a x + b), fused multiply-add: one rounding, as the fp32 form had (one statement: between two, hipcc pads the dependency with an s_nop)
-    asm("v_pk_fma_f16 %0, %1, %2, %3\n\tv_pk_max_f16 %0, %0, 0" : "=v"(o) : "v"(in), "v"(sc), "v"(sh));
+    unsigned o;      // clamp(x, lo, hi): BN1 + ReLU without arithmetic or rounding (calib_host.hip::bn_relu_clamp_fold; one statement: between two, hipcc pads the dependency with an s_nop)
+    asm("v_pk_max_f16 %0, %1, %2\n\tv_pk_min_f16 %0, %0, %3" : "=&v"(o) : "v"(in), "v"(sc), "v"(sh));
     xb[Q % XN][J] = o;
   };
   // pipeline item IDX of the row ybn

@@ -96,13 +96,15 @@ int launch_maxpool3x3s2(const f16 *x, int B, int H, int W, int C, f16 *y, int ld
 // sums in double, then one pass over the chunks in index order.
 constexpr int kMeanChunks = 32;
 __global__ __launch_bounds__(256) void channel_mean_partial_kernel(const f16 *__restrict__ x, int ld, int K, const float *__restrict__ scale,
-                                                                   const float *__restrict__ shift, long rows, double *__restrict__ part) {
+                                                                   const float *__restrict__ shift, long rows, double *__restrict__ part, int clamp) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
   const long per = (rows + kMeanChunks - 1) / kMeanChunks, r0 = blockIdx.y * per, r1 = r0 + per < rows ? r0 + per : rows;
   double acc = 0.0;
   if (c < K) {
     const float sc = scale[c], sh = shift[c];
-    for (long r = r0 + sub; r < r1; r += 4) acc += (double)fmaxf(fmaf((float)x[r * ld + c], sc, sh), 0.f);
+    // clamp: the operand of a fused dense layer's 1x1, clamp(x, lo = scale[c], hi = shift[c]) (calib_host.hip::bn_relu_clamp_fold)
+    if (clamp) for (long r = r0 + sub; r < r1; r += 4) acc += (double)fminf(fmaxf((float)x[r * ld + c], sc), sh);
+    else for (long r = r0 + sub; r < r1; r += 4) acc += (double)fmaxf(fmaf((float)x[r * ld + c], sc, sh), 0.f);
   }
   __shared__ double red[4][64];
   red[sub][threadIdx.x & 63] = acc;
@@ -118,9 +120,9 @@ __global__ void channel_mean_final_kernel(const double *__restrict__ part, int K
 }
 
 int launch_channel_mean(const f16 *x, int ld, int K, const float *scale, const float *shift, long rows, double *scratch /* 32 * K */,
-                        float *out, hipStream_t s) {
+                        float *out, hipStream_t s, int clamp) {
   TN_REQUIRE(K > 0 && rows > 0, "channel_mean: empty input");
-  hipLaunchKernelGGL(channel_mean_partial_kernel, dim3((K + 63) / 64, kMeanChunks), dim3(256), 0, s, x, ld, K, scale, shift, rows, scratch);
+  hipLaunchKernelGGL(channel_mean_partial_kernel, dim3((K + 63) / 64, kMeanChunks), dim3(256), 0, s, x, ld, K, scale, shift, rows, scratch, clamp);
   hipLaunchKernelGGL(channel_mean_final_kernel, dim3((K + 255) / 256), dim3(256), 0, s, (const double *)scratch, K, rows, out);
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;

@@ -9,7 +9,8 @@
 // zero weights), so a lane's 8 operand values are 2 adjacent NHWC4 pixels =
 // one aligned ds_read_b128 from the staged input patch.  BN (fp32 scale and
 // shift per output channel) and ReLU are applied to the fp32 accumulators in
-// the epilogue, so the fp16 weights are exactly the model's weights.
+// the epilogue.  The staged operand is x - 255 mean (uint8 frames: an exact integer),
+// the weights carry 1 / (255 std): common.h "the stem's operand".
 // A workgroup owns 8 output rows of one frame and walks the row in 16-column
 // tiles, keeping all 28 weight fragments in registers.
 #include "common.h"
@@ -19,25 +20,29 @@ namespace {
 constexpr int PITCH = 320;        // bytes per patch row: 40 px * 8 B
 constexpr int PROWS = 21, PCOLS = 38;
 
+// one staged operand pixel (common.h "the stem's operand"): x - q_c for uint8 frames (integers, exact), v * 255 std_c for
+// normalised input; outside the frame the normalised zero
 __device__ __forceinline__ f16x4 load_px(const StemArgs &a, int b, int iy, int ix) {
+  const bool u8 = a.layout == TN_LAYOUT_NHWC_U8;
   f16x4 v = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+  if (u8) { v[0] = (f16)(float)stem_pad(0); v[1] = (f16)(float)stem_pad(1); v[2] = (f16)(float)stem_pad(2); }
   if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
     if (a.layout == TN_LAYOUT_NCHW_F32) {
       const float *x = (const float *)a.x;
       const long plane = (long)a.H * a.W;
       const long o = ((long)b * 3) * plane + (long)iy * a.W + ix;
-      v[0] = (f16)x[o];
-      v[1] = (f16)x[o + plane];
-      v[2] = (f16)x[o + 2 * plane];
+      v[0] = (f16)(x[o] * stem_unscale(0));
+      v[1] = (f16)(x[o + plane] * stem_unscale(1));
+      v[2] = (f16)(x[o + 2 * plane] * stem_unscale(2));
     } else if (a.layout == TN_LAYOUT_NHWC_F16) {
       const f16 *x = (const f16 *)a.x + (((long)b * a.H + iy) * a.W + ix) * 3;
-      v[0] = x[0]; v[1] = x[1]; v[2] = x[2];
+      v[0] = (f16)((float)x[0] * stem_unscale(0)); v[1] = (f16)((float)x[1] * stem_unscale(1)); v[2] = (f16)((float)x[2] * stem_unscale(2));
     } else {
       const uint8_t *x = (const uint8_t *)a.x + (((long)b * a.H + iy) * a.W + ix) * 3;
-      // ToTensor (/255) then Normalize (mean,std) — reference evaluate.py:96-97
-      v[0] = (f16)(((float)x[0] / 255.0f - 0.485f) / 0.229f);
-      v[1] = (f16)(((float)x[1] / 255.0f - 0.456f) / 0.224f);
-      v[2] = (f16)(((float)x[2] / 255.0f - 0.406f) / 0.225f);
+      // ToTensor (/255) then Normalize (mean,std) - reference evaluate.py:96-97 - with 1 / (255 std) in the weights
+      v[0] = (f16)((float)x[0] - kStemQ[0]);
+      v[1] = (f16)((float)x[1] - kStemQ[1]);
+      v[2] = (f16)((float)x[2] - kStemQ[2]);
     }
   }
   return v;
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       sc[nf][r] = a.scale[nf * 16 + kc * 4 + r];
-      sh[nf][r] = a.shift[nf * 16 + kc * 4 + r];
+      sh[nf][r] = (a.layout == TN_LAYOUT_NHWC_U8 ? a.shift_u8 : a.shift)[nf * 16 + kc * 4 + r];
     }
 
   const int ntiles = (a.Wo + 15) / 16;
@@ -117,6 +122,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
 
 int launch_stem(const StemArgs &a, hipStream_t s) {
   TN_REQUIRE(a.layout >= 0 && a.layout <= 2, "stem: unknown input layout");
+  TN_REQUIRE(a.shift_u8 != nullptr, "stem: the uint8 shift is missing");
   const dim3 grid((a.Ho + 7) / 8, a.B), block(256);
   hipLaunchKernelGGL(stem_kernel, grid, block, 0, s, a);
   TN_HIP_CHECK(hipGetLastError());

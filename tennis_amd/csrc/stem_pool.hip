@@ -15,8 +15,8 @@
 //    output channels: patch row p feeds the conv rows r with ky = p - 2r in [0,7), so one
 //    16-byte operand read serves up to eight MFMAs (23 reads per tile instead of 63);
 //  * accumulators live in VGPRs (three waves per SIMD requested, so no AGPR copies), BN +
-//    fp16 conversion is v_fma_f32 + v_cvt_pk_f16_f32 by hand, the vertical max is two v_pk_max_f16 per
-//    row half, border masking is a separate instantiation taken by border tiles only;
+//    v_fma_f32 by hand, the vertical max is four v_max_f32 per row half (fp32: the one rounding to fp16 comes after the
+//    pool, dithered - dither_pack), border masking is a separate instantiation taken by border tiles only;
 //  * the patch is staged as aligned 64-byte blocks (the k-slot layout starts with the zero
 //    tap, which makes the operand reads 16-byte aligned at that offset);
 //  * workgroups are persistent over a contiguous range of tiles: weights and BN constants are
@@ -44,7 +44,7 @@ constexpr int CR = 2 * PR + 1, CC = 32;   // conv tile (rows, cols; 29 of the 32
 constexpr int IR = 2 * CR + 5;            // 23 input rows
 constexpr int IPX = 80;                   // patch row: input pixels ix0 - 3 ... ix0 + 76 (slot = pixel - (ix0 - 3))
 constexpr int IPITCH = IPX * 8;           // bytes per patch row (NHWC4 fp16)
-constexpr int CPX = 136;                  // bytes per pixel of the row-max tile: 64 ch fp16 + 8 pad (bank spread)
+constexpr int CPX = 272;                  // bytes per pixel of the row-max tile: 64 ch fp32 + 16 pad (bank spread)
 constexpr int GPR = IPX / 8;              // 8-pixel groups per patch row (vector path)
 
 // workgroup barrier that orders LDS traffic only: __syncthreads() would also wait for the global loads of the next patch
@@ -55,29 +55,58 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
-// packed fp16 max without the canonicalising max(x, x) the IEEE builtin puts in front of every operand
-__device__ __forceinline__ unsigned pk_max(unsigned x, unsigned y) {
-  unsigned d;
-  asm("v_pk_max_f16 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y));
+// fp32 max / three-way max without the canonicalising max(x, x) the IEEE builtins put in front of every operand
+__device__ __forceinline__ float fmax_raw(float x, float y) {
+  float d;
+  asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y));
   return d;
 }
+__device__ __forceinline__ float fmax3_raw(float x, float y, float z) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+  return d;
+}
+// The ONE rounding of the stem's output, fp32 -> fp16, is DITHERED by position (round 5): on a flat image region every pixel of
+// a channel holds the same value, round-to-nearest makes the same error at every one of them, and no average downstream
+// reduces it (scripts/round_study.py: 9e-4 on the features of a constant frame from this rounding alone, 2e-5 dithered; it also
+// de-correlates the roundings of the layers behind it).  A 13-bit number keyed on (pooled row, pooled column, channel) - NOT on
+// the frame: a frame's features do not depend on its neighbours in the batch - is added below the fp16 mantissa and the sum is
+// truncated (v_cvt_pkrtz_f16_f32): stochastic rounding with a deterministic random number, unbiased for every value.  The
+// values are post-ReLU (>= 0); it has to happen AFTER the max pool (a max over differently dithered values is biased upwards),
+// which is why the row maxima travel through LDS as fp32.
+__device__ __forceinline__ unsigned dither_pack(float a, float b, unsigned h, int i) {
+  const unsigned ta = __builtin_amdgcn_ubfe(h, 2 * i, 13), tb = __builtin_amdgcn_ubfe(h, 2 * i + 2, 13);
+  const float da = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) + ta);
+  const float db = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) + tb);
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, (h2)__builtin_amdgcn_cvt_pkrtz(da, db));
+}
 
-// raw channel triple of one input pixel (address clamped by the caller, always in bounds)
+// staged channel triple of one input pixel (address clamped by the caller, always in bounds): x - 255 mean_c in the form
+// common.h "the stem's operand" describes - the integer x - q_c for uint8 frames, v * 255 std_c for normalised input
 template <int LAY>
 __device__ __forceinline__ void load_raw(const StemArgs &a, long pix, long plane, float (&v)[3]) {
   if constexpr (LAY == TN_LAYOUT_NCHW_F32) {
     const float *x = (const float *)a.x + pix;      // pix = b*3*plane + iy*W + ix
-    v[0] = x[0]; v[1] = x[plane]; v[2] = x[2 * plane];
+    v[0] = x[0] * stem_unscale(0); v[1] = x[plane] * stem_unscale(1); v[2] = x[2 * plane] * stem_unscale(2);
   } else if constexpr (LAY == TN_LAYOUT_NHWC_F16) {
     const f16 *x = (const f16 *)a.x + pix * 3;      // pix = (b*H + iy)*W + ix
-    v[0] = (float)x[0]; v[1] = (float)x[1]; v[2] = (float)x[2];
+    v[0] = (float)x[0] * stem_unscale(0); v[1] = (float)x[1] * stem_unscale(1); v[2] = (float)x[2] * stem_unscale(2);
   } else {
     const uint8_t *x = (const uint8_t *)a.x + pix * 3;
-    // ToTensor (/255) then Normalize (mean,std) — reference evaluate.py:96-97
-    v[0] = ((float)x[0] / 255.0f - 0.485f) / 0.229f;
-    v[1] = ((float)x[1] / 255.0f - 0.456f) / 0.224f;
-    v[2] = ((float)x[2] / 255.0f - 0.406f) / 0.225f;
+    // ToTensor (/255) then Normalize (mean,std) - reference evaluate.py:96-97 - with 1 / (255 std) in the weights
+    v[0] = (float)x[0] - kStemQ[0];
+    v[1] = (float)x[1] - kStemQ[1];
+    v[2] = (float)x[2] - kStemQ[2];
   }
+}
+// what an out-of-frame tap is staged as: the normalised zero (packed halves: {c0 c1}, {c2 0})
+template <int LAY>
+__device__ __forceinline__ unsigned stem_pad_dword(int odd) {
+  if constexpr (LAY != TN_LAYOUT_NHWC_U8) return 0u;
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 a = {(f16)(float)stem_pad(0), (f16)(float)stem_pad(1)}, b = {(f16)(float)stem_pad(2), (f16)0.f};
+  return odd ? __builtin_bit_cast(unsigned, b) : __builtin_bit_cast(unsigned, a);
 }
 
 struct Tile { int b, pr0, pc0; };
@@ -116,7 +145,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       sc[nf][r] = a.scale[(2 * nh + nf) * 16 + kc * 4 + r];
-      sh[nf][r] = a.shift[(2 * nh + nf) * 16 + kc * 4 + r];
+      sh[nf][r] = (LAY == TN_LAYOUT_NHWC_U8 ? a.shift_u8 : a.shift)[(2 * nh + nf) * 16 + kc * 4 + r];
     }
 
   // input patch staging, split in two halves so the loads of the next tile fly during the MFMAs of this one:
@@ -183,18 +212,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
           o[2 * i + 2] = __builtin_amdgcn_alignbit(d[e + 2], d[e + 1], 16);
           o[2 * i + 3] = d[e + 2] >> 16;
         }
+        // v -> v * 255 std_c in fp32, one rounding (the weights carry 1 / (255 std_c))
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const h2 q = __builtin_bit_cast(h2, o[i]);
+          const h2 r = {(f16)((float)q[0] * stem_unscale((i & 1) ? 2 : 0)), (i & 1) ? (f16)0.f : (f16)((float)q[1] * stem_unscale(1))};
+          o[i] = __builtin_bit_cast(unsigned, r);
+        }
+      } else if constexpr (LAY == TN_LAYOUT_NHWC_U8) {
+        // x - q_c as packed halves without a conversion: byte b -> 0x6400 | b = the fp16 number 1024 + b (exact), minus
+        // 1024 + q_c (exact: integers below 2048) - v_perm_b32, v_or_b32, v_pk_add_f16 per dword
+        const unsigned w[7] = {vq[0].x, vq[0].y, vq[0].z, vq[0].w, vq[1].x, vq[1].y, 0u};
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 k01 = {(f16)(-1024.f - kStemQ[0]), (f16)(-1024.f - kStemQ[1])}, k2 = {(f16)(-1024.f - kStemQ[2]), (f16)-1024.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int b = 3 * i, d = b >> 2, bo = b & 3;          // bytes b, b + 1, b + 2 of the 24: in dwords d, d + 1
+          const unsigned s01 = (unsigned)bo | (0x0cu << 8) | ((unsigned)(bo + 1) << 16) | (0x0cu << 24);
+          const unsigned s2 = (unsigned)(bo + 2) | 0x0c0c0c00u;
+          const unsigned p01 = __builtin_amdgcn_perm(w[d + 1], w[d], s01) | 0x64006400u;
+          const unsigned p2 = __builtin_amdgcn_perm(w[d + 1], w[d], s2) | 0x64006400u;
+          o[2 * i] = __builtin_bit_cast(unsigned, __builtin_bit_cast(h2, p01) + k01);
+          o[2 * i + 1] = __builtin_bit_cast(unsigned, __builtin_bit_cast(h2, p2) + k2);
+        }
       } else {
         f16 v[8][3];
-        if constexpr (LAY == TN_LAYOUT_NHWC_U8) {
-          const unsigned w[6] = {vq[0].x, vq[0].y, vq[0].z, vq[0].w, vq[1].x, vq[1].y};
-          const float mean[3] = {0.485f, 0.456f, 0.406f}, sdev[3] = {0.229f, 0.224f, 0.225f};
-#pragma unroll
-          for (int i = 0; i < 24; ++i) {
-            const float u = (float)((w[i >> 2] >> ((i & 3) * 8)) & 255u);
-            // ToTensor (/255) then Normalize (mean,std) -- reference evaluate.py:96-97 (same arithmetic as load_raw)
-            v[i / 3][i % 3] = (f16)((u / 255.0f - mean[i % 3]) / sdev[i % 3]);
-          }
-        } else {
+        {
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             const float fl[8] = {__builtin_bit_cast(float, vq[2 * c].x), __builtin_bit_cast(float, vq[2 * c].y),
@@ -202,7 +246,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
                                  __builtin_bit_cast(float, vq[2 * c + 1].x), __builtin_bit_cast(float, vq[2 * c + 1].y),
                                  __builtin_bit_cast(float, vq[2 * c + 1].z), __builtin_bit_cast(float, vq[2 * c + 1].w)};
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i][c] = (f16)fl[i];
+            for (int i = 0; i < 8; ++i) v[i][c] = (f16)(fl[i] * stem_unscale(c));
           }
         }
 #pragma unroll
@@ -216,7 +260,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
       const bool border = iy0 < 0 || iy0 + IR > a.H || gx0 < 0 || gx0 + IPX > a.W;
       if (border) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o[i] = in ? o[i] : 0u;
+        for (int i = 0; i < 16; ++i) o[i] = in ? o[i] : stem_pad_dword<LAY>(i & 1);
       }
       if (t < IR * GPR) {
         uint4 *dst = (uint4 *)(patch + vpr * IPITCH + vg * 64);
@@ -231,10 +275,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
       const int pr = p / IPX, pc = p - pr * IPX;
       const int iy = iy0 + pr, ix = gx0 + pc;
       const bool in = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      const float pd[3] = {LAY == TN_LAYOUT_NHWC_U8 ? (float)stem_pad(0) : 0.f, LAY == TN_LAYOUT_NHWC_U8 ? (float)stem_pad(1) : 0.f,
+                           LAY == TN_LAYOUT_NHWC_U8 ? (float)stem_pad(2) : 0.f};
       f16x4 v;
-      v[0] = in ? (f16)raw[i][0] : (f16)0.f;
-      v[1] = in ? (f16)raw[i][1] : (f16)0.f;
-      v[2] = in ? (f16)raw[i][2] : (f16)0.f;
+      v[0] = (f16)(in ? raw[i][0] : pd[0]);
+      v[1] = (f16)(in ? raw[i][1] : pd[1]);
+      v[2] = (f16)(in ? raw[i][2] : pd[2]);
       v[3] = (f16)0.f;
       if (p < IR * IPX) *(f16x4 *)(patch + pr * IPITCH + pc * 8) = v;
     }
@@ -243,13 +289,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
   // horizontal 3-max + store: item = (pooled row, pooled column, 8-channel group); 448 items, two rounds.  The item
   // geometry does not depend on the tile: LDS offset and output offset (relative to the tile's first pixel) are fixed
   int p_lds[2], p_pr[2], p_pc[2];
+  unsigned p_hash[2];                     // the item's share of the dither key (the tile adds its origin)
   long p_out[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int id = t + 256 * k, pr = id / (PC * 8), r2 = id - pr * (PC * 8), pc = r2 >> 3, cg = r2 & 7;
     p_pr[k] = id < PR * PC * 8 ? pr : 1 << 20;            // out of range: never valid
     p_pc[k] = pc;
-    p_lds[k] = (pr * CC + 2 * pc) * CPX + cg * 16;
+    p_lds[k] = (pr * CC + 2 * pc) * CPX + cg * 32;
+    p_hash[k] = (unsigned)pr * 0x85EBCA77u + (unsigned)pc * 0x9E3779B1u + (unsigned)cg * 0xC2B2AE3Du;
     p_out[k] = ((long)pr * Wp + pc) * ldy + cg * 8;
   }
 
@@ -279,40 +327,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
       const unsigned char *prow = patch + (ch * 16 + pl + kc + 1) * 16;
       const int c = ch * 16 + pl;
       const bool cvalid = (unsigned)(cx0 + c) < (unsigned)a.Wo;
-      unsigned m[2][2];                             // running maximum of the pooled row in progress, per channel fragment
-      // conv row r (complete after patch row 2r + 6): BN in fp32, fp16, max into the pooled rows it belongs to
+      float m[2][4];                                // running maximum of the pooled row in progress, per channel fragment (fp32: the rounding comes after the pool)
+      // conv row r (complete after patch row 2r + 6): BN in fp32, max into the pooled rows it belongs to
       // (r = 2 pr + {0,1,2}); an even row closes pooled row r/2 - 1 (ReLU on the maximum, then LDS) and opens row r/2
       // The hazard recogniser does not count wait states in front of inline asm that reads an MFMA result (seen in round 2
       // as garbage in the low halves of the last pooled row, depending on where the scheduler put the row's last MFMA): the
       // statement OPENS with the 12 wait states an 8-pass MFMA result needs and is ONE statement, so nothing can come
       // between the wait and the reads - correctness does not depend on MFMA placement (the tail calls keep the plain C++ form)
       auto finish_half = [&](int r, int nf, auto tail_tag) {
-        uint2 u;
+        float b[4];
         if constexpr (decltype(tail_tag)::value) {
-          f16x4 h;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) h[j] = (f16)fmaf(acc[r][nf][j], sc[nf][j], sh[nf][j]);
-          u = __builtin_bit_cast(uint2, h);
+          for (int j = 0; j < 4; ++j) b[j] = fmaf(acc[r][nf][j], sc[nf][j], sh[nf][j]);
         } else {
-          // fp32 fma, one rounding to fp16: four v_fma_f32 + two v_cvt_pk_f16_f32 (9 ns per SIMD; four v_fma_mixlo/hi_f16
-          // would be 14, and left to itself the compiler SLP-packs pairs into v_pk_fma_f32 + moves + converts)
-          float b0, b1, b2, b3;
           asm("s_nop 11\n\t"
-              "v_fma_f32 %2, %6, %10, %14\n\tv_fma_f32 %3, %7, %11, %15\n\tv_fma_f32 %4, %8, %12, %16\n\tv_fma_f32 %5, %9, %13, %17\n\t"
-              "v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5"
-              : "=&v"(u.x), "=&v"(u.y), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+              "v_fma_f32 %0, %4, %8, %12\n\tv_fma_f32 %1, %5, %9, %13\n\tv_fma_f32 %2, %6, %10, %14\n\tv_fma_f32 %3, %7, %11, %15"
+              : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
               : "v"(acc[r][nf][0]), "v"(acc[r][nf][1]), "v"(acc[r][nf][2]), "v"(acc[r][nf][3]),
                 "v"(sc[nf][0]), "v"(sc[nf][1]), "v"(sc[nf][2]), "v"(sc[nf][3]), "v"(sh[nf][0]), "v"(sh[nf][1]), "v"(sh[nf][2]), "v"(sh[nf][3]));
         }
         if constexpr (BORDER) {
           const bool valid = cvalid && (unsigned)(cy0 + r) < (unsigned)a.Ho;
-          u.x = valid ? u.x : 0u; u.y = valid ? u.y : 0u;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b[j] = valid ? b[j] : 0.f;
         }
-        if (r == 0) { m[nf][0] = u.x; m[nf][1] = u.y; return; }
-        const unsigned x = pk_max(m[nf][0], u.x), y = pk_max(m[nf][1], u.y);
-        if (r & 1) { m[nf][0] = x; m[nf][1] = y; return; }
-        *(uint2 *)(vtile + ((r / 2 - 1) * CC + c) * CPX + nh * 64 + nf * 32 + kc * 8) = make_uint2(pk_max(x, 0u), pk_max(y, 0u));
-        m[nf][0] = u.x; m[nf][1] = u.y;
+        if (r == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) m[nf][j] = b[j];
+          return;
+        }
+        float x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = fmax_raw(m[nf][j], b[j]);
+        if (r & 1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) m[nf][j] = x[j];
+          return;
+        }
+        *(float4 *)(vtile + ((r / 2 - 1) * CC + c) * CPX + nh * 128 + nf * 64 + kc * 16) =
+            make_float4(fmax_raw(x[0], 0.f), fmax_raw(x[1], 0.f), fmax_raw(x[2], 0.f), fmax_raw(x[3], 0.f));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[nf][j] = b[j];
       };
       // operand ring of three: the read of patch row p + 2 is requested before the MFMAs of row p are issued (the
       // compiler would otherwise place every read right in front of its first consumer and wait for it)
@@ -346,14 +401,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
     if (more) commit(nxt);
     [[maybe_unused]] const unsigned long long st3 = ST_NOW();
     f16 *obase = out + (((long)cur.b * Hp + cur.pr0) * Wp + cur.pc0) * ldy;
+    const unsigned tile_hash = (unsigned)cur.pr0 * 0x85EBCA77u + (unsigned)cur.pc0 * 0x9E3779B1u;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       if (cur.pr0 + p_pr[k] < Hp && cur.pc0 + p_pc[k] < Wp) {
-        const uint4 q0 = *(const uint4 *)(vtile + p_lds[k]), q1 = *(const uint4 *)(vtile + p_lds[k] + CPX),
-                    q2 = *(const uint4 *)(vtile + p_lds[k] + 2 * CPX);
+        const float4 *q = (const float4 *)(vtile + p_lds[k]);
+        const float4 a0 = q[0], a1 = q[1], b0 = q[CPX / 16], b1 = q[CPX / 16 + 1], c0 = q[2 * (CPX / 16)], c1 = q[2 * (CPX / 16) + 1];
+        // the dither key of (pooled row, pooled column, channel group): a multiplicative hash, two bits further on per channel
+        unsigned h = tile_hash + p_hash[k];
+        h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
         uint4 o;
-        o.x = pk_max(pk_max(q0.x, q1.x), q2.x); o.y = pk_max(pk_max(q0.y, q1.y), q2.y);
-        o.z = pk_max(pk_max(q0.z, q1.z), q2.z); o.w = pk_max(pk_max(q0.w, q1.w), q2.w);
+        o.x = dither_pack(fmax3_raw(a0.x, b0.x, c0.x), fmax3_raw(a0.y, b0.y, c0.y), h, 0);
+        o.y = dither_pack(fmax3_raw(a0.z, b0.z, c0.z), fmax3_raw(a0.w, b0.w, c0.w), h, 2);
+        o.z = dither_pack(fmax3_raw(a1.x, b1.x, c1.x), fmax3_raw(a1.y, b1.y, c1.y), h, 4);
+        o.w = dither_pack(fmax3_raw(a1.z, b1.z, c1.z), fmax3_raw(a1.w, b1.w, c1.w), h, 6);
         *(uint4 *)(obase + p_out[k]) = o;
       }
     }
@@ -377,7 +438,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
 int launch_stem_pool(const StemArgs &a, f16 *out, int ldy, int Hp, int Wp, hipStream_t s) {
   TN_REQUIRE(a.layout >= 0 && a.layout <= 2, "stem: unknown input layout");
   TN_REQUIRE(ldy % 8 == 0, "stem: output stride must be a multiple of 8");
-  TN_REQUIRE(a.wp_zf != nullptr, "stem: packed weights missing");
+  TN_REQUIRE(a.wp_zf != nullptr && a.shift_u8 != nullptr, "stem: packed weights / uint8 shift missing");
   static int slots = 0;
   if (!slots) {
     int dev = 0;

@@ -137,18 +137,40 @@ def _round_fp16_vector_feedback(wf: np.ndarray, A: np.ndarray, sweeps: int | Non
     return np.where(use2, other, rtn_f)
 
 
-def bn_relu_fold(params: dict, bn_name: str):
-    """``(a, b, m)`` of BatchNorm ``bn_name`` followed by ReLU in the fused dense layers' form ``relu(scale x + shift) =
-    m relu(a x + b)``, ``a`` and ``b`` fp16 numbers: the library's own host routine (``tn_bn_relu_fold_fp16``, no GPU involved),
-    so that the weights converted here and the constants the kernels use belong to the same ``m``."""
-    import ctypes as C
-    from . import _lib
-    arrs = [np.ascontiguousarray(params[bn_name + sfx], np.float32) for sfx in ("_gamma", "_beta", "_running_mean", "_running_var")]
-    n = arrs[0].size
-    a, b, m = (np.empty(n, np.float32) for _ in range(3))
-    vp = lambda x: x.ctypes.data_as(C.c_void_p)
-    _lib.check(_lib.load().tn_bn_relu_fold_fp16(*[vp(x) for x in arrs], n, vp(a), vp(b), vp(m)), "tn_bn_relu_fold_fp16")
-    return a, b, m
+def bn_relu_clamp_fold(params: dict, bn_name: str, use_library: bool = False):
+    """``(lo, hi, sw, tc)`` of BatchNorm ``bn_name`` followed by ReLU in the fused dense layers' rounding-free form
+    ``relu(scale x + shift) = sw clamp(x, lo, hi) + tc`` (csrc/calib_host.hip::bn_relu_clamp_fold): ``lo`` / ``hi`` fp16 numbers -
+    the ReLU threshold ``-shift / scale`` on the side the scale's sign says, +-65504 on the other - ``sw`` the factor that goes
+    into column k of the 1x1 weights before they are rounded, ``tc`` the constant whose weighted sum joins the next BatchNorm's
+    shift.  The numpy code is the reference; ``use_library`` runs the library's own host routine (``tn_bn_relu_clamp_fold``, no GPU
+    involved) - tests/test_cpu_oracle.py holds the two together bit for bit."""
+    g, b, mu, var = (np.ascontiguousarray(params[bn_name + sfx], np.float32) for sfx in ("_gamma", "_beta", "_running_mean", "_running_var"))
+    n = g.size
+    if use_library:
+        import ctypes as C
+        from . import _lib
+        lo, hi, sw, tc = (np.empty(n, np.float32) for _ in range(4))
+        vp = lambda x: x.ctypes.data_as(C.c_void_p)
+        _lib.check(_lib.load().tn_bn_relu_clamp_fold(vp(g), vp(b), vp(mu), vp(var), n, vp(lo), vp(hi), vp(sw), vp(tc)), "tn_bn_relu_clamp_fold")
+        return lo, hi, sw, tc
+    with np.errstate(all="ignore"):
+        scale = (g / np.sqrt(var + np.float32(BN_EPS))).astype(np.float32)
+        shift = (b - (mu * scale).astype(np.float32)).astype(np.float32)
+        s = scale.astype(np.float64)
+        t = np.where(np.isfinite(shift), shift, 0).astype(np.float64)
+        c = -t / np.where(s != 0, s, 1.0)
+        kmax = 65504.0
+        const = ~np.isfinite(scale) | (s == 0)
+        dead = (~const) & (((s > 0) & (c > kmax)) | ((s < 0) & (c < -kmax)))          # always on the clipped side
+        c16 = np.clip(c, -kmax, kmax).astype(np.float32).astype(np.float16).astype(np.float32)
+        lo = np.where(s > 0, c16, np.float32(-kmax)).astype(np.float32)
+        hi = np.where(s > 0, np.float32(kmax), c16).astype(np.float32)
+        sw, tc = scale.copy(), t.astype(np.float32)
+        off = const | dead
+        lo[off] = 0; hi[off] = 0; sw[off] = 0
+        tc[dead] = 0
+        tc[const] = np.maximum(t[const], 0).astype(np.float32)
+    return lo, hi, sw, tc
 
 
 def as_fp16_model(params: dict, input_means: dict | None = None) -> dict:
@@ -161,8 +183,10 @@ def as_fp16_model(params: dict, input_means: dict | None = None) -> dict:
     BatchNorm (``stageB_batchnorm{2l+1}``) whose scale the encoder folds into the
     weights (the usual conv-BN fusion; csrc/api.hip, csrc/dense_strip_impl.h): for those the
     number that is rounded to fp16 is ``scale[n] * w[n][k]``, and the converted weight is
-    ``fp16(scale[n] w[n][k]) / scale[n]`` — one rounding per weight either way.  Round 4: the factor also carries ``m[k]`` of
-    the BatchNorm + ReLU in front of the convolution (``bn_relu_fold``): the number rounded is ``scale[n] m[k] w[n][k]``.
+    ``fp16(scale[n] w[n][k]) / scale[n]`` — one rounding per weight either way.  Round 5: the factor also carries the SCALE
+    ``sw[k]`` of the BatchNorm in front of the convolution, whose ReLU the kernels evaluate as a clamp of the stored activation
+    (``bn_relu_clamp_fold``): the number rounded is ``scale[n] sw[k] w[n][k]`` (a channel with ``sw[k] = 0`` - a constant -
+    keeps its weight as it is; the kernels never multiply it).
 
     (Measured on MI355X: with un-rounded fp32 conv weights the pooled features differ by
     up to 3.3e-3 because weight rounding is coherent across the 49 pooled pixels; with
@@ -191,20 +215,24 @@ def as_fp16_model(params: dict, input_means: dict | None = None) -> dict:
         if bn and bn + "_gamma" in params:
             s = (params[bn + "_gamma"] / np.sqrt(params[bn + "_running_var"] + np.float32(BN_EPS))).astype(np.float32)
             s = s.reshape(-1, 1, 1, 1)
-            # round 4: the BatchNorm IN FRONT of the same convolution is evaluated as m relu(a x + b) with fp16 constants a, b
-            # (csrc/calib_host.hip::bn_relu_fold_fp16); m[k] multiplies column k of the weights before they are rounded
+            # round 5: the BatchNorm IN FRONT of the same convolution is evaluated as sw clamp(x, lo, hi) + tc
+            # (csrc/calib_host.hip::bn_relu_clamp_fold); sw[k] multiplies column k of the weights before they are rounded
             bn1 = f"{m.group(1)}batchnorm{int(m.group(2))}"
             if bn1 + "_gamma" in params:
-                s = s * bn_relu_fold(params, bn1)[2].reshape(1, -1, 1, 1)
+                s = s * bn_relu_clamp_fold(params, bn1)[2].reshape(1, -1, 1, 1)
+        if s is None and k.endswith("conv0_weight") and v.shape[1:] == (3, 7, 7):
+            # round 5: the stem works on x - 255 mean_c (an exact integer for uint8 frames), the input normalisation's
+            # 1 / (255 std_c) is part of the weight that is rounded (csrc/common.h "the stem's operand")
+            s = STEM_WFACTOR.reshape(1, 3, 1, 1)
         folded = (v * s).astype(np.float32) if s is not None else v.astype(np.float32)
         if input_means is not None and k in input_means:
-            m = np.asarray(input_means[k], np.float64)
+            am = np.asarray(input_means[k], np.float64)     # mean of the convolution's operand per input channel (per frame)
             taps = v.shape[2] * v.shape[3]
-            if m.ndim == 2:      # one row per calibration frame: vector error feedback
-                r = _round_fp16_vector_feedback(folded.astype(np.float64).reshape(v.shape[0], -1), np.repeat(m, taps, axis=1),
+            if am.ndim == 2:      # one row per calibration frame: vector error feedback
+                r = _round_fp16_vector_feedback(folded.astype(np.float64).reshape(v.shape[0], -1), np.repeat(am, taps, axis=1),
                                                 use_library=_USE_LIBRARY_ROUNDING)
             else:                # (cin, kh, kw) flattening
-                r = _round_fp16_error_feedback(folded.astype(np.float64).reshape(v.shape[0], -1), np.repeat(m, taps))
+                r = _round_fp16_error_feedback(folded.astype(np.float64).reshape(v.shape[0], -1), np.repeat(am, taps))
             r = r.reshape(v.shape).astype(np.float32)
         else:
             r = folded.astype(np.float16).astype(np.float32)
@@ -316,6 +344,8 @@ def synthetic_frames_u8(n: int, size: int = 224, seed: int = 1234) -> np.ndarray
 
 IMAGENET_MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32)
 IMAGENET_STD = np.array([0.229, 0.224, 0.225], dtype=np.float32)
+# csrc/common.h::stem_wfactor: what multiplies conv0's weights of input channel c before they are rounded to fp16
+STEM_WFACTOR = np.array([64.0 / (255.0 * 0.229), 64.0 / (255.0 * 0.224), 64.0 / (255.0 * 0.225)]).astype(np.float32)
 
 
 def normalize_to_nchw_f32(frames_u8: np.ndarray) -> np.ndarray:

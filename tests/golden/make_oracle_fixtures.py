@@ -24,7 +24,7 @@ from tennis_amd import weights as W           # noqa: E402
 def densenet_inputs():
     p = W.make_densenet121_weights(0)
     p.update(W.make_dense_weights(1, 11, 1024, "framemodel0_dense0_"))
-    x = W.normalize_to_nchw_f32(W.synthetic_frames_u8(2, 224, 1234)).astype(np.float16).astype(np.float32)
+    x = W.normalize_to_nchw_f32(W.synthetic_frames_u8(2, 224, 1234))      # ToTensor + Normalize in fp32, un-rounded: what the reference's network sees (evaluate.py:96-97)
     return p, x
 
 

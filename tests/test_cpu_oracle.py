@@ -400,40 +400,67 @@ def test_error_feedback_rounding_properties():
     plain = W.as_fp16_model(p)
     assert all(np.array_equal(q[k], plain[k]) for k in p if k != name) and (q[name] != plain[name]).any()
     s2 = p["densenet0_stage1_batchnorm1_gamma"] / np.sqrt(p["densenet0_stage1_batchnorm1_running_var"] + np.float32(W.BN_EPS))
-    m1 = W.bn_relu_fold(p, "densenet0_stage1_batchnorm0")[2]        # round 4: ... and the m of the BatchNorm + ReLU in front
+    m1 = W.bn_relu_clamp_fold(p, "densenet0_stage1_batchnorm0")[2]  # round 5: ... and the scale of the BatchNorm + ReLU in front
     folded = (q[name] * s2.reshape(-1, 1, 1, 1) * m1.reshape(1, -1, 1, 1)).astype(np.float32)
     assert np.abs(folded - folded.astype(np.float16).astype(np.float32)).max() < 1e-6 * np.abs(folded).max() + 1e-9
 
 
-def test_bn_relu_fold_fp16_properties():
-    """csrc/calib_host.hip::bn_relu_fold_fp16 (tn_bn_relu_fold_fp16, host code): relu(s x + t) = m relu(a x + b) with a an fp16
-    number EXACTLY s / m, b an fp16 number within a small fraction of its ulp of t / m, m within 2 % of 1; degenerate scales
-    (zero, subnormal, non-finite) fall back to plain rounding without producing NaNs; as_fp16_model folds the same m."""
+def test_bn_relu_clamp_fold_properties():
+    """csrc/calib_host.hip::bn_relu_clamp_fold (tn_bn_relu_clamp_fold, host code) and its numpy reference
+    (weights.bn_relu_clamp_fold): relu(s x + t) = sw clamp(x, lo, hi) + tc with lo / hi fp16 numbers.  Exact on the unclipped side of
+    every channel, within 2^-11 |t| on the clipped side; degenerate channels (zero / tiny / huge / non-finite scale: ADVICE r4 - the
+    round-4 form saturated its shift there) give the right VALUES, not just finite ones; the library and numpy agree bit for bit."""
     from tennis_amd import weights as W
     rng = np.random.default_rng(5)
     n = 4096
     p = {"bn_gamma": (rng.uniform(0.05, 1.5, n) * rng.choice([-1.0, 1.0], n)).astype(np.float32), "bn_beta": rng.normal(0, 1.0, n).astype(np.float32),
          "bn_running_mean": rng.normal(0, 1.0, n).astype(np.float32), "bn_running_var": rng.uniform(0.01, 4.0, n).astype(np.float32)}
-    p["bn_gamma"][:4] = [0.0, 1e-7, 3e4, -1e-6]          # degenerate scales
-    p["bn_running_var"][2] = 1e-3                        # ... and one that leaves the fp16 range
-    a, b, m = W.bn_relu_fold(p, "bn")
+    # degenerate scales: zero, tiny with a positive / negative shift (ADVICE r4: gamma 5e-6 beta 1; gamma 1e-7 beta 0.1; gamma 1e-5 beta 2),
+    # negative tiny, one that leaves the fp16 range, non-finite
+    p["bn_gamma"][:10] = [0.0, 1e-7, 3e4, -1e-6, 5e-6, 1e-7, 1e-5, 1e-6, -1e-6, np.inf]
+    p["bn_beta"][:10] = [0.7, 0.1, 0.3, 0.5, 1.0, 0.1, 2.0, -1.0, -1.0, 0.4]
+    p["bn_running_mean"][:10] = 0.0
+    p["bn_running_var"][:10] = 1.0
+    p["bn_running_var"][2] = 1e-3
+    lo, hi, sw, tc = W.bn_relu_clamp_fold(p, "bn")
+    lib = W.bn_relu_clamp_fold(p, "bn", use_library=True)
+    for a_, b_ in zip((lo, hi, sw, tc), lib):
+        assert np.array_equal(a_, b_)
     s = (p["bn_gamma"] / np.sqrt(p["bn_running_var"] + np.float32(W.BN_EPS))).astype(np.float32)
     t = (p["bn_beta"] - p["bn_running_mean"] * s).astype(np.float32)
-    assert np.isfinite(b).all() and np.isfinite(m).all() and (m > 0).all()
-    ok = slice(4, None)
-    assert np.array_equal(a[ok].astype(np.float16).astype(np.float32), a[ok]) and np.array_equal(b.astype(np.float16).astype(np.float32), b)
-    assert np.abs(a[ok].astype(np.float64) * m[ok] / s[ok] - 1).max() < 2e-7               # a m = s to fp32 rounding
-    assert np.abs(m[ok] - 1).max() < 0.02
-    bt = t[ok].astype(np.float64) / m[ok]
-    ulp = np.spacing(np.abs(b[ok]).astype(np.float16)).astype(np.float64)
-    resid = np.abs(b[ok] - bt) / ulp
-    plain = np.abs(t[ok].astype(np.float16).astype(np.float64) - t[ok]) / np.spacing(np.abs(t[ok]).astype(np.float16)).astype(np.float64)
-    assert resid.max() <= 0.5 and resid.mean() < 0.1 * plain.mean(), (resid.mean(), resid.max(), plain.mean())
-    # the function itself: m relu(a x + b) against relu(s x + t) on fp16 inputs
-    x = rng.normal(0, 2, (64, n - 4)).astype(np.float16).astype(np.float64)
-    want = np.maximum(x * s[ok] + t[ok], 0)
-    got = m[ok] * np.maximum(x * a[ok] + b[ok], 0)
-    assert np.abs(got - want).max() < 3e-5 * max(1.0, np.abs(want).max()), np.abs(got - want).max()
+    assert np.isfinite(lo).all() and np.isfinite(hi).all() and np.isfinite(sw).all() and np.isfinite(tc).all() and (lo <= hi).all()
+    assert np.array_equal(lo.astype(np.float16).astype(np.float32), lo) and np.array_equal(hi.astype(np.float16).astype(np.float32), hi)
+    # the function itself on fp16 inputs (what the concat buffer holds), every channel, the degenerate ones included
+    x = np.concatenate([rng.normal(0, 2, (64, n)), rng.normal(0, 300, (8, n)), np.full((1, n), 2.0)]).astype(np.float16).astype(np.float64)
+    sd, td = s.astype(np.float64), t.astype(np.float64)
+    sd[9] = 0.0; td[9] = 0.0                               # (a non-finite scale - its shift is NaN - is served as the constant 0)
+    want = np.maximum(x * sd + td, 0)
+    got = sw.astype(np.float64) * np.clip(x, lo, hi) + tc
+    err = np.abs(got - want)
+    # clipped side: |s| times the rounding of the threshold (half an fp16 ulp of it: <= 2^-11 |t|, except where the threshold is an
+    # fp16 subnormal - a scale of 1e6 - whose ulp is absolute)
+    thr_ulp = np.spacing(np.abs(np.where(sd > 0, lo, hi)).astype(np.float16)).astype(np.float64)
+    assert (err <= np.abs(sd) * 0.5 * thr_ulp + 1e-6 * np.abs(want) + 1e-30).all(), err.max()
+    normal = np.abs(td) > 6.2e-5 * np.abs(sd)
+    assert (err[:, normal] <= 2.0 ** -11 * np.abs(td[normal]) + 1e-6 * np.abs(want[:, normal]) + 1e-30).all()
+    unclipped = want > 2.0 ** -10 * np.abs(td)              # away from the threshold on the open side: exact up to fp32 constants
+    assert (err[unclipped] <= 1e-6 * np.abs(want[unclipped]) + 1e-7).all()
+    # ADVICE r4's three cases at x = 2: 1.0, 0.1, 2.0 (round 4 gave 0.506, 0.0079, 1.01)
+    assert np.allclose(got[-1, [4, 5, 6]], [1.0, 0.1, 2.0], rtol=0, atol=3e-5), got[-1, 4:7]
+    assert got[-1, 7] == 0.0 and got[-1, 8] == 0.0 and got[-1, 0] == np.float32(0.7)
+    # as_fp16_model folds the same sw: conv weights behind this BatchNorm are fp16 numbers once sw (and BN2's scale) are multiplied in
+    q = {"densenet0_stage1_conv0_weight": rng.normal(0, 0.1, (128, n, 1, 1)).astype(np.float32)}
+    q.update({k.replace("bn_", "densenet0_stage1_batchnorm0_"): v for k, v in p.items()})
+    q.update({"densenet0_stage1_batchnorm1_gamma": rng.uniform(0.5, 1.5, 128).astype(np.float32), "densenet0_stage1_batchnorm1_beta": np.zeros(128, np.float32),
+              "densenet0_stage1_batchnorm1_running_mean": np.zeros(128, np.float32), "densenet0_stage1_batchnorm1_running_var": rng.uniform(0.5, 2, 128).astype(np.float32)})
+    conv = W.as_fp16_model(q)["densenet0_stage1_conv0_weight"]
+    s2 = (q["densenet0_stage1_batchnorm1_gamma"] / np.sqrt(q["densenet0_stage1_batchnorm1_running_var"] + np.float32(W.BN_EPS))).astype(np.float32)
+    folded = (conv * s2.reshape(-1, 1, 1, 1) * sw.reshape(1, -1, 1, 1)).astype(np.float32)
+    live = sw != 0
+    rel = np.abs(folded - folded.astype(np.float16).astype(np.float32))[:, live] / (np.abs(folded[:, live]) + 1e-30)
+    big = (np.abs(folded[:, live]) > 1e-4) & (np.abs(folded[:, live]) < 6e4)     # (fp16 subnormals keep fewer bits; beyond the range the library refuses the layer)
+    assert rel[big].max() < 1e-6
+    assert np.array_equal(conv[:, ~live], q["densenet0_stage1_conv0_weight"][:, ~live])
 
 
 def test_mxnet_params_reader_against_hand_built_file():

@@ -23,9 +23,10 @@ def mk():
 def test_densenet_features_and_logits(mk, report):
     from tennis_amd.engine import Dense, DenseNet121Features
     d = np.load(os.path.join(GOLD, "oracle_densenet121_224_b2.npz"))
-    p, x = mk.densenet_inputs()
+    from tennis_amd import weights as W
+    p, _ = mk.densenet_inputs()
     enc = DenseNet121Features(p, 224, max_batch=2)
-    feats = enc(torch.from_numpy(x).cuda())
+    feats = enc(torch.from_numpy(W.synthetic_frames_u8(2, 224, 1234)).cuda())      # the decoded frames the fixture's normalised input was made from
     logits = Dense(p["framemodel0_dense0_weight"], p["framemodel0_dense0_bias"])(feats).cpu().numpy()
     ef, el = float(np.abs(feats.cpu().numpy() - d["feats"]).max()), float(np.abs(logits - d["logits"]).max())
     report["golden_densenet_feat_maxabs_err"], report["golden_densenet_logit_maxabs_err"] = ef, el

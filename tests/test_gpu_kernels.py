@@ -32,6 +32,22 @@ def _bnrelu_h(x, s, t):
     return _h(np.maximum(x * s + t, 0.0).astype(np.float32))
 
 
+def _clamp_consts(rng, K):
+    """(lo, hi) of a dense layer's BN1 + ReLU in the kernels' form (csrc/calib_host.hip::bn_relu_clamp_fold): the operand of the
+    1x1 is clamp(x, lo, hi), fp16 numbers; most channels have a positive scale (lo = threshold, hi = 65504), some a negative one
+    (lo = -65504, hi = threshold) and a few are constants (lo = hi = 0)"""
+    thr = rng.normal(0, 0.6, K).astype(np.float16).astype(np.float32)
+    kind = rng.random(K)
+    lo = np.where(kind < 0.82, thr, np.float32(-65504.0)).astype(np.float32)
+    hi = np.where(kind < 0.82, np.float32(65504.0), thr).astype(np.float32)
+    lo[kind > 0.97] = 0.0; hi[kind > 0.97] = 0.0
+    return lo, hi
+
+
+def _clamp(x, lo, hi):
+    return np.clip(x, lo, hi).astype(np.float32)       # exact: no arithmetic, no rounding
+
+
 @pytest.mark.parametrize("M,K,ldx,N,yoff,ldy", [
     (1000, 64, 256, 128, 0, 128),      # ragged M, block-1 first layer
     (128 * 600, 96, 256, 128, 0, 128),  # BM=128 path, K tail (96 = 64+32)
@@ -187,7 +203,7 @@ def test_dense_layer_fused(ctx, report, B, H, K, ldc, variant):
     W_ = H
     rng = np.random.default_rng(B * 1000 + H + K)
     buf = rng.normal(0, 1.5, (B, H, W_, ldc)).astype(np.float16)
-    s1 = rng.uniform(0.5, 1.5, K).astype(np.float32); t1 = rng.normal(0, 0.3, K).astype(np.float32)
+    s1, t1 = _clamp_consts(rng, K)      # (lo, hi)
     s2 = rng.uniform(0.5, 1.5, 128).astype(np.float32); t2 = rng.normal(0, 0.3, 128).astype(np.float32)
     w1 = rng.normal(0, np.sqrt(2.0 / K), (128, K)).astype(np.float16)
     w3 = rng.normal(0, np.sqrt(2.0 / 1152), (32, 128, 3, 3)).astype(np.float32)
@@ -200,7 +216,7 @@ def test_dense_layer_fused(ctx, report, B, H, K, ldc, variant):
                                               _lib.ptr(d["t1"]), _lib.ptr(d["w1"]), _lib.ptr(d["s2"]),
                                               _lib.ptr(d["t2"]), _lib.ptr(d["wp"]), B, H, W_, None, variant), "dense_layer")
     out = d["buf"].cpu().numpy().astype(np.float32)
-    a1 = _bnrelu_h(buf[..., :K].astype(np.float32), s1, t1)
+    a1 = _clamp(buf[..., :K].astype(np.float32), s1, t1)
     bott = (a1.reshape(-1, K) @ w1.astype(np.float32).T).reshape(B, H, W_, 128)
     a2 = _h(np.maximum(bott * s2 + t2, 0).astype(np.float32))
     ref = dn.conv2d_nhwc(a2, _h(w3), 1, 1)
@@ -230,7 +246,7 @@ def test_dense_layer_exact_weights(ctx, report, B, H, K, ldc):
     from tennis_amd import _lib
     rng = np.random.default_rng(B * 1000 + H + K)
     buf = rng.normal(0, 1.5, (B, H, H, ldc)).astype(np.float16)
-    s1 = rng.uniform(0.5, 1.5, K).astype(np.float32); t1 = rng.normal(0, 0.3, K).astype(np.float32)
+    s1, t1 = _clamp_consts(rng, K)      # (lo, hi)
     s2 = rng.uniform(0.5, 1.5, 128).astype(np.float32); t2 = rng.normal(0, 0.3, 128).astype(np.float32)
     w1 = rng.normal(0, np.sqrt(2.0 / K), (128, K)).astype(np.float32)
     w3 = rng.normal(0, np.sqrt(2.0 / 1152), (32, 128, 3, 3)).astype(np.float32)
@@ -248,7 +264,7 @@ def test_dense_layer_exact_weights(ctx, report, B, H, K, ldc):
     _lib.check(ctx.lib.tn_dbg_dense_layer_dev(ctx.handle, _lib.ptr(d["buf"]), ldc, K, _lib.ptr(d["s1"]), _lib.ptr(d["t1"]), _lib.ptr(d["w1"]),
                                               _lib.ptr(d["s2"]), _lib.ptr(d["t2"]), _lib.ptr(d["wp"]), B, H, H, None, 1 << 17), "dense_layer")
     out = d["buf"].cpu().numpy().astype(np.float32)
-    a1 = _bnrelu_h(buf[..., :K].astype(np.float32), s1, t1)
+    a1 = _clamp(buf[..., :K].astype(np.float32), s1, t1)
     bott = (a1.reshape(-1, K).astype(np.float64) @ w1.astype(np.float64).T).reshape(B, H, H, 128).astype(np.float32)
     a2 = _h(np.maximum(bott * s2 + t2, 0).astype(np.float32))
     ref = dn.conv2d_nhwc(a2, w3, 1, 1)                                      # fp32 weights, un-rounded
@@ -295,7 +311,7 @@ def test_dense_block7(ctx, report, B, K0, nl, ldc):
     buf[..., :K0] = rng.normal(0, 1.0, (B, 7, 7, K0)).astype(np.float16)
     buf[..., K0:] = 77.0                                                  # must be overwritten (or left alone past the block)
     Ks = [K0 + 32 * l for l in range(nl)]
-    s1 = [rng.uniform(0.5, 1.5, K).astype(np.float32) for K in Ks]; t1 = [rng.normal(0, 0.3, K).astype(np.float32) for K in Ks]
+    s1, t1 = map(list, zip(*[_clamp_consts(rng, K) for K in Ks]))      # (lo, hi) per layer
     s2 = rng.uniform(0.5, 1.5, (nl, 128)).astype(np.float32); t2 = rng.normal(0, 0.3, (nl, 128)).astype(np.float32)
     w1 = [rng.normal(0, np.sqrt(2.0 / K), (128, K)).astype(np.float32) for K in Ks]
     w3 = _h(rng.normal(0, np.sqrt(2.0 / 1152), (nl, 32, 128, 3, 3)).astype(np.float32))
@@ -313,7 +329,7 @@ def test_dense_block7(ctx, report, B, K0, nl, ldc):
     ref = buf.astype(np.float32)
     worst = 0.0
     for l, K in enumerate(Ks):
-        a1 = _bnrelu_h(ref[..., :K], s1[l], t1[l])
+        a1 = _clamp(ref[..., :K], s1[l], t1[l])
         bott = (a1.reshape(-1, K) @ _h(w1[l] * s2[l][:, None]).T).reshape(B, 7, 7, 128)
         a2 = _h(np.maximum(bott + t2[l], 0).astype(np.float32))
         y = _h(dn.conv2d_nhwc(a2, w3[l], 1, 1))
@@ -338,8 +354,7 @@ def test_dense_block14(ctx, report, B, K0, nl, ldc):
     buf[..., :K0] = rng.normal(0, 1.0, (B, 14, 14, K0)).astype(np.float16)
     buf[..., K0:] = 77.0                                                  # must be overwritten (or left alone past the block)
     Ks = [K0 + 32 * l for l in range(nl)]
-    # (BN1 constants are fp16 numbers by the time they reach this kernel: calib_host.hip::bn_relu_fold_fp16)
-    s1 = [rng.uniform(0.5, 1.5, K).astype(np.float16).astype(np.float32) for K in Ks]; t1 = [rng.normal(0, 0.3, K).astype(np.float16).astype(np.float32) for K in Ks]
+    s1, t1 = map(list, zip(*[_clamp_consts(rng, K) for K in Ks]))      # (lo, hi) per layer
     s2 = rng.uniform(0.5, 1.5, (nl, 128)).astype(np.float32); t2 = rng.normal(0, 0.3, (nl, 128)).astype(np.float32)
     w1 = [rng.normal(0, np.sqrt(2.0 / K), (128, K)).astype(np.float32) for K in Ks]
     w3 = _h(rng.normal(0, np.sqrt(2.0 / 1152), (nl, 32, 128, 3, 3)).astype(np.float32))
@@ -360,7 +375,7 @@ def test_dense_block14(ctx, report, B, K0, nl, ldc):
     ref = buf.astype(np.float32)
     worst = 0.0
     for l, K in enumerate(Ks):
-        a1 = _bnrelu_h(ref[..., :K], s1[l], t1[l])
+        a1 = _clamp(ref[..., :K], s1[l], t1[l])
         bott = (a1.reshape(-1, K) @ _h(w1[l] * s2[l][:, None]).T).reshape(B, 14, 14, 128)
         a2 = _h(np.maximum(bott + t2[l], 0).astype(np.float32))
         y = _h(dn.conv2d_nhwc(a2, w3[l], 1, 1))
@@ -386,7 +401,7 @@ def test_dense_block28(ctx, report, B, K0, nl, ldc):
     buf[..., :K0] = rng.normal(0, 1.0, (B, 28, 28, K0)).astype(np.float16)
     buf[..., K0:] = 77.0                                                  # must be overwritten (or left alone past the block)
     Ks = [K0 + 32 * l for l in range(nl)]
-    s1 = [rng.uniform(0.5, 1.5, K).astype(np.float16).astype(np.float32) for K in Ks]; t1 = [rng.normal(0, 0.3, K).astype(np.float16).astype(np.float32) for K in Ks]
+    s1, t1 = map(list, zip(*[_clamp_consts(rng, K) for K in Ks]))      # (lo, hi) per layer
     s2 = rng.uniform(0.5, 1.5, (nl, 128)).astype(np.float32); t2 = rng.normal(0, 0.3, (nl, 128)).astype(np.float32)
     w1 = [rng.normal(0, np.sqrt(2.0 / K), (128, K)).astype(np.float32) for K in Ks]
     w3 = _h(rng.normal(0, np.sqrt(2.0 / 1152), (nl, 32, 128, 3, 3)).astype(np.float32))
@@ -407,7 +422,7 @@ def test_dense_block28(ctx, report, B, K0, nl, ldc):
     ref = buf.astype(np.float32)
     worst = 0.0
     for l, K in enumerate(Ks):
-        a1 = _bnrelu_h(ref[..., :K], s1[l], t1[l])
+        a1 = _clamp(ref[..., :K], s1[l], t1[l])
         bott = (a1.reshape(-1, K) @ _h(w1[l] * s2[l][:, None]).T).reshape(B, 28, 28, 128)
         a2 = _h(np.maximum(bott + t2[l], 0).astype(np.float32))
         y = _h(dn.conv2d_nhwc(a2, w3[l], 1, 1))
@@ -430,8 +445,7 @@ def test_dense_strip(ctx, report, B, H, K, ldc):
     from tennis_amd import _lib
     rng = np.random.default_rng(B * 1000 + H + K)
     buf = rng.normal(0, 1.5, (B, H, H, ldc)).astype(np.float16)
-    # (BN1 constants are fp16 numbers by the time they reach this kernel: calib_host.hip::bn_relu_fold_fp16)
-    s1 = rng.uniform(0.5, 1.5, K).astype(np.float16).astype(np.float32); t1 = rng.normal(0, 0.3, K).astype(np.float16).astype(np.float32)
+    s1, t1 = _clamp_consts(rng, K)      # (lo, hi)
     s2 = rng.uniform(0.5, 1.5, 128).astype(np.float32); t2 = rng.normal(0, 0.3, 128).astype(np.float32)
     w1 = rng.normal(0, np.sqrt(2.0 / K), (128, K)).astype(np.float32)
     w3 = _h(rng.normal(0, np.sqrt(2.0 / 1152), (32, 128, 3, 3)).astype(np.float32))
@@ -443,7 +457,7 @@ def test_dense_strip(ctx, report, B, H, K, ldc):
     _lib.check(ctx.lib.tn_dbg_dense_strip_dev(ctx.handle, _lib.ptr(d["buf"]), ldc, K, _lib.ptr(d["s1"]), _lib.ptr(d["t1"]),
                                               _lib.ptr(d["w1s"]), _lib.ptr(d["w3s"]), B, H, H, None), "dense_strip")
     out = d["buf"].cpu().numpy().astype(np.float32)
-    a1 = _bnrelu_h(buf[..., :K].astype(np.float32), s1, t1)
+    a1 = _clamp(buf[..., :K].astype(np.float32), s1, t1)
     bott = (a1.reshape(-1, K) @ _h(w1 * s2[:, None]).T).reshape(B, H, H, 128)      # BN2's scale is folded into the weights before the fp16 rounding
     a2 = _h(np.maximum(bott + t2, 0).astype(np.float32))
     ref = dn.conv2d_nhwc(a2, w3, 1, 1)
