@@ -36,27 +36,33 @@ HBM_PEAK_TBS = 8.0                # MI355X HBM3E (MI355X_MICROARCH.md)
 MIN_TOTAL_STEPS = 1000        # (~2 s of GPU time at the default batch: a median over >= 5 regions of 200 steps, and long enough for a 1 Hz power / utilisation sampler to see it)
 
 
-def calibration_note():
-    """What tests/test_gpu_calibration.py measured on MI355X for the conversion the headline model uses (the committed matrix
-    profiles/r04_calibration_matrix.json: feature max-abs error vs the fp32 oracle on the un-rounded weights, per frame family)."""
-    path = os.path.join(ROOT, "profiles", "r04_calibration_matrix.json")
+def parity_note():
+    """What tests/test_gpu_calibration.py measured on MI355X for the model this line times (the newest committed matrix
+    profiles/r*_calibration_matrix.json: max-abs error of features and of the Dense(11) logits vs the fp32 oracle on the UN-rounded
+    weights and un-rounded input, per frame family).  One mode: the timed configuration is the one that is graded for parity."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_calibration_matrix.json")))
+    if not files:
+        return {"source": None, "note": "see tests/test_gpu_calibration.py (no committed matrix in this tree)"}
     try:
-        m = json.load(open(path))["feature_max_abs_error"]
-        d, ex, pl, ker = (m[k] for k in ("built-in set, 72 frames", "exact-weights mode (hi + lo pairs)", "plain rounding",
-                                         "kernels alone (oracle on the converted weights)"))
-        inside = sorted(f for f in d if d[f] < 1e-3)
-        outside = sorted(f for f in d if d[f] >= 1e-3)
-        rng = lambda fs, row: "%.2e .. %.2e" % (min(row[f] for f in fs), max(row[f] for f in fs)) if fs else "-"
-        return (f"within 1e-3 on {len(inside)} of {len(d)} families ({rng(inside, d)}: {', '.join(inside)}); {rng(outside, d)} on frames with large "
-                f"flat regions ({', '.join(outside)}), where the fp16 activation path alone measures {rng(outside, ker)} and the "
-                f"exact-weights mode {rng(outside, ex)} (every pixel of a flat region makes the same activation-rounding error, which the average "
-                f"pool cannot reduce: not a property of the weight conversion); plain rounding {rng(list(pl), pl)}; worst case {max(d.values()):.2e}")
-    except Exception as e:      # (a tree without the committed matrix)
-        return f"see tests/test_gpu_calibration.py ({type(e).__name__}: profiles/r04_calibration_matrix.json not readable)"
+        m = json.load(open(files[-1]))
+        feats, logits = m["feature_max_abs_error"], m.get("logit_max_abs_error", {})
+        key = [k for k in feats if k.startswith("built-in set, ")][-1]        # the default conversion (the largest built-in set)
+        d, ker, pl = feats[key], feats["kernels alone (oracle on the converted weights)"], feats["plain rounding"]
+        out = {"source": os.path.relpath(files[-1], ROOT), "conversion": key, "bar": 1e-3, "families": len(d),
+               "families_within_bar": sum(v < 1e-3 for v in d.values()),
+               "feature_err_worst": max(d.values()), "feature_err_worst_family": max(d, key=d.get),
+               "feature_err_by_family": {f: round(v, 6) for f, v in d.items()},
+               "kernels_alone_worst": max(ker.values()), "plain_rounding_worst": max(pl.values())}
+        if key in logits:
+            out["logit_err_worst"] = max(logits[key].values())
+        return out
+    except Exception as e:
+        return {"source": os.path.relpath(files[-1], ROOT), "note": f"{type(e).__name__}: matrix not readable"}
 
-# compulsory HBM bytes per frame if every intermediate stayed on chip (SURVEY §8d): fp16 NHWC frame in, fp32
+# compulsory HBM bytes per frame if every intermediate stayed on chip (SURVEY §8d): uint8 NHWC frame in, fp32
 # features out (+ 13.7 MB of fp16 weights per batch)
-COMPULSORY_BYTES_PER_FRAME = 301056 + 4096
+COMPULSORY_BYTES_PER_FRAME = 150528 + 4096
 WEIGHT_BYTES = 13.7e6
 # profile family (tn_densenet121_profile) -> kernel family key of profiles/*_pmc_traffic.json
 PMC_KEYS = {"dense_layer_strip_56x56": ("dense_strip_56x56", "dense_strip_kernel<56"),
@@ -72,13 +78,18 @@ PMC_KEYS = {"dense_layer_strip_56x56": ("dense_strip_56x56", "dense_strip_kernel
 
 
 def make_frames(batch, size, seed, device):
-    """uint8 uniform frames -> ToTensor+Normalize -> NHWC fp16, generated on the device."""
+    """uint8 uniform frames, NHWC, generated on the device: decoded frames as the loader (JPEG decode + Resize + CenterCrop on the
+    device) hands them to the encoder, which applies ToTensor + Normalize itself (reference evaluate.py:93-98)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    u8 = torch.randint(0, 256, (batch, size, size, 3), generator=g, device=device, dtype=torch.uint8)
-    mean = torch.tensor([0.485, 0.456, 0.406], device=device)
-    std = torch.tensor([0.229, 0.224, 0.225], device=device)
-    return ((u8.float() / 255.0 - mean) / std).half().contiguous()
+    return torch.randint(0, 256, (batch, size, size, 3), generator=g, device=device, dtype=torch.uint8).contiguous()
+
+
+def normalize_nchw_f32(u8):
+    """ToTensor + Normalize of the reference's test transform (evaluate.py:96-97) for the CPU baseline's input"""
+    mean = torch.tensor([0.485, 0.456, 0.406])
+    std = torch.tensor([0.229, 0.224, 0.225])
+    return ((u8.cpu().float() / 255.0 - mean) / std).permute(0, 3, 1, 2).contiguous()
 
 
 def pmc_traffic(kernel_family):
@@ -107,7 +118,7 @@ def _median_rate(fn, n, runs):
     return n / float(np.median(ts)), ts
 
 
-def cpu_baseline(params, frames_nhwc_f16, full=False):
+def cpu_baseline(params, frames_u8, full=False):
     """The reference CPU path stand-ins of SURVEY §8(d) on this box's host cores, on bounded samples (MXNet's CPU
     path cannot be installed: both are restatements, kind "port"):
       (i)  oracle/torch_ref.py — the same graph through torch-CPU / oneDNN, fp32, all cores: config C1's 32 frames,
@@ -117,7 +128,7 @@ def cpu_baseline(params, frames_nhwc_f16, full=False):
     from oracle.torch_ref import TorchDenseNet121
     threads = torch.get_num_threads()
     net = TorchDenseNet121(params)
-    x32 = frames_nhwc_f16[:32].float().permute(0, 3, 1, 2).contiguous().cpu()
+    x32 = normalize_nchw_f32(frames_u8[:32])
     net(x32[:2])
     fps32, ts32 = _median_rate(lambda: net(x32), 32, 5)
     out = {"value": round(fps32, 2), "unit": "frames/sec", "cores": threads, "kind": "port",
@@ -130,8 +141,8 @@ def cpu_baseline(params, frames_nhwc_f16, full=False):
                            "sample": "2 frames 224x224 fp32 through oracle/densenet_np.py, median of 3 runs",
                            "runs_s": [round(t, 3) for t in ts_np]}
     if full:
-        n = min(256, frames_nhwc_f16.shape[0])
-        x256 = frames_nhwc_f16[:n].float().permute(0, 3, 1, 2).contiguous().cpu()
+        n = min(256, frames_u8.shape[0])
+        x256 = normalize_nchw_f32(frames_u8[:n])
         fps256, ts256 = _median_rate(lambda: net(x256), n, 5)
         out["batch256"] = {"value": round(fps256, 2), "unit": "frames/sec", "cores": threads,
                            "sample": f"{n}-frame batch through oracle/torch_ref.py, median of 5 runs",
@@ -189,7 +200,7 @@ def build_parser():
     ap.add_argument("--no-pipeline", action="store_true", help="join the encoder's two half-batch streams inside every forward (A/B against the pipelined default)")
     ap.add_argument("--plain-rounding", action="store_true", help="seeded weights that are fp16-representable (rounds 1-2's model) instead of "
                     "the calibrated conversion of fp32 weights")
-    ap.add_argument("--no-exact-line", action="store_true", help="skip the extra fenced region that times the exact-weights mode")
+    ap.add_argument("--exact-line", action="store_true", help="also time the exact-weights mode in one more fenced region (not part of the default line any more: the timed configuration itself meets the bar)")
     ap.add_argument("--exact-weights", action="store_true",
                     help="NOT the headline configuration: un-rounded fp32 conv weights evaluated as hi + lo fp16 pairs "
                          "(TN_ENC_EXACT_WEIGHTS), to state what the 1e-3-vs-fp32-weights mode costs")
@@ -281,7 +292,7 @@ def run(argv):
     # parameters - the exact-weights mode (hi + lo fp16 weight pairs: twice the MFMA work of the dense layers and transitions)
     # - on the same box: one more fenced region of exactly K steps with a second encoder
     fps_exact = None
-    if not args.exact_weights and not args.single_region and not args.no_exact_line:
+    if not args.exact_weights and not args.single_region and args.exact_line:
         params_x = params32
         enc_f16 = enc
         enc = DenseNet121Features(params_x, SIZE, max_batch=args.batch, ctx=ctx, exact_weights=True)
@@ -344,22 +355,22 @@ def run(argv):
                "vs_baseline": None, "dtype": "f16", "data": "synthetic",
                "config": {"workload": "DenseNet-121 frame feature-extract, batch 256 synthetic 224x224x3 "
                                       "(BASELINE.json configs[1])",
-                          "frames_per_step_per_gpu": args.batch, "input": "NHWC fp16 normalised, HBM-resident",
+                          "frames_per_step_per_gpu": args.batch,
+                          "input": "NHWC uint8 decoded frames, HBM-resident (ToTensor + Normalize inside the stem); every step re-reads the SAME "
+                                   f"{args.batch * SIZE * SIZE * 3 / 1e6:.1f} MB buffer, which fits the 256 MB Infinity Cache: the stem's HBM read is not exercised (about 1 % of the step)",
                           "output": "fp32 features (B,1024)" + ("; RCCL all-gather of feature rows" if world > 1 else ""),
                           "weights": ("seeded random-init, fp32 conv weights as hi + lo fp16 pairs (exact-weights mode, 2x MFMA work "
                                       "in the dense layers / transitions)") if args.exact_weights
                                      else ("seeded random-init, conv weights fp16-representable" if args.plain_rounding else
-                                           "seeded random-init fp32 conv weights (not fp16-representable), converted to one fp16 number per weight by "
-                                           "calibrated rounding (vector error feedback against the 72 built-in calibration frames of 12 families, "
-                                           "tennis_amd/calibrate.py).  Feature error vs the fp32 oracle on the UN-rounded weights, measured per frame family "
-                                           "(tests/test_gpu_calibration.py, profiles/r04_calibration_matrix.json): " + calibration_note()),
+                                           "seeded random-init fp32 conv weights (not fp16-representable: what a trained checkpoint looks like), converted to ONE fp16 "
+                                           "number per weight by calibrated rounding against the library's built-in calibration frames with bias correction "
+                                           "(tennis_amd/calibrate.py, weights.as_fp16_model)"),
+                          "parity": (parity_note() if not (args.exact_weights or args.plain_rounding) else None),
                           "exchange": (comm.transport + f", all-gather of {args.batch} x {enc.feature_dim} fp32 rows per rank and step") if comm is not None else "none (1 rank)",
                           "timing": f"median of {repeats} fenced regions of exactly {args.steps} steps" + (", forwards pipelined (results joined one step behind, all joined before the closing fence)" if pipelined else ""),
                           "region_ms": [round(t * 1e3, 2) for t in times],
                           "frames_per_sec_forwards_joined": (round(world * args.batch * args.steps / dt_joined, 1) if dt_joined else None),
-                          "exact_weights_frames_per_sec": (round(fps_exact, 1) if fps_exact else None),
-                          "exact_weights_note": "un-rounded fp32 conv weights as hi + lo fp16 pairs (features within 1e-3 of the fp32 oracle on fp32 "
-                                                "weights: tests/test_gpu_encoder.py::test_fp32_weights_exact_mode); 2x the MFMA work of the dense layers"},
+                          **({"exact_weights_frames_per_sec": round(fps_exact, 1)} if fps_exact else {})},
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params32, x, full=args.cpu_baseline_full)

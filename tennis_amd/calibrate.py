@@ -46,7 +46,7 @@ def frame_means(params: dict, frames_u8: np.ndarray | torch.Tensor, size=224, pr
 
 
 def calibrated_fp16_model(params: dict, frames: torch.Tensor | np.ndarray | None = None, size=224, prefix: str = "densenet0_", ctx=None,
-                          builtin_frames: int = 72) -> dict:
+                          builtin_frames: int = 144) -> dict:
     """``params``: fp32 parameters (Gluon names).  The calibration set is the built-in one (``builtin_frames`` frames dealt over
     ``calib_frames.FAMILIES``, the same on every rank) plus, if given, ``frames``: NHWC uint8 frames of the material to be
     processed (host or device).  Returns the converted parameter dict (conv weights fp16-representable after the BN2 fold,

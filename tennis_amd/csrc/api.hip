@@ -251,6 +251,7 @@ struct tn_encoder {
   float *head_s, *head_t;
   float *zeros128 = nullptr;   // a BatchNorm shift of zeros (un-fused dense layers: the shift was added by the 1x1)
   f16 *stem_out, *bott, *blockbuf[4];
+  float *head32 = nullptr;     // the last block's map once more in fp32 (what the head reads): written by the last transition and the 7x7 block kernel
   size_t workspace_bytes;
   int last_batch;
   bool fuse, split;
@@ -480,6 +481,7 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
   e->bott = (f16 *)e->pool.alloc(B * e->Hb[0] * e->Wb[0] * 128 * sizeof(f16));
   for (int b = 0; b < 4; ++b)
     e->blockbuf[b] = (f16 *)e->pool.alloc(B * e->Hb[b] * e->Wb[b] * e->Cb[b] * sizeof(f16));
+  if (e->b7[3].wa) e->head32 = (float *)e->pool.alloc(B * e->Hb[3] * e->Wb[3] * e->Cb[3] * sizeof(float));
   for (int b = 0; b < 4; ++b)
     if (e->b14[b].stream) e->b14_scratch[b] = (f16 *)e->pool.alloc(B * dense_block14_scratch_halfs() * sizeof(f16));
   for (int b = 0; b < 4; ++b)
@@ -520,6 +522,10 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
   f16 *bott = e->bott + (size_t)b0 * e->Hb[0] * e->Wb[0] * 128;
   f16 *bbuf[4];
   for (int b = 0; b < 4; ++b) bbuf[b] = e->blockbuf[b] + (size_t)b0 * e->Hb[b] * e->Wb[b] * e->Cb[b];
+  // the head reads the last block un-rounded when the kernels that produce it write the fp32 side copy: the LDS-resident 7x7
+  // block kernel and the transition in front of it (not in the layer-wise calibration pass, not with a tuning variant)
+  float *h32 = (e->head32 && e->calib_dev == nullptr && e->dl_variant == 0)
+                   ? e->head32 + (size_t)b0 * e->Hb[3] * e->Wb[3] * e->Cb[3] : nullptr;
   {
     StemArgs a{x, (int)layout, B, e->H, e->W, e->stem_wp, e->stem_wp_zf, e->stem_scale, e->stem_shift, stem_out, e->Hs, e->Ws};
     a.shift_u8 = e->stem_shift_u8;
@@ -585,6 +591,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
       // the frame's concat buffer stays in LDS for the whole block; only the weights stream (dense_block7.hip)
       DenseBlock7Args a7 = e->b7[b];
       a7.buf = bbuf[b]; a7.B = B;
+      a7.side = b == 3 ? h32 : nullptr;
       double fl = 0, by = 0;
       for (auto &L : e->layers[b]) {
         fl += 2.0 * M * (128.0 * L.cin + 32.0 * 1152);
@@ -657,6 +664,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
       if (cal && (rc = cal_mean(bbuf[b], e->Cb[b], T.cin, T.s, T.t, M))) return rc;
       Conv1x1Args at{bbuf[b], e->Cb[b], T.cin, T.s, T.t, T.w, T.cout, bbuf[b + 1], e->Cb[b + 1], 0, Mo, 1, Hh, Ww};
       at.exact = e->exact;
+      if (b == 2 && h32) { at.y32 = h32; at.ld32 = e->Cb[3]; }
       tm.begin("transition_conv1x1_avgpool", 2.0 * M * (double)T.cout * T.cin,
                (double)M * T.cin * 2 + (double)Mo * T.cout * 2 + (double)T.cout * T.cin * 2);
       rc = launch_conv1x1(at, s);
@@ -665,7 +673,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
     }
   }
   tm.begin("head_bnrelu_avgpool7", 0.0, fB * e->Hb[3] * e->Wb[3] * e->Cb[3] * 2 + fB * e->feat_dim * 4);
-  rc = launch_head(bbuf[3], B, e->Hb[3], e->Wb[3], e->Cb[3], e->head_s, e->head_t, feat, e->PH, e->PW, s);
+  rc = launch_head(bbuf[3], B, e->Hb[3], e->Wb[3], e->Cb[3], e->head_s, e->head_t, feat, e->PH, e->PW, s, h32);
   tm.end();
   return rc;
 }

@@ -151,6 +151,8 @@ struct Conv1x1Args {
   int exact = 0;      // weights as hi + lo fp16 pairs: w [N][2 K] = [hi | lo] (K % 64 == 0)
   const float *bias = nullptr;   // [N] added to the fp32 result before the rounding to fp16 (no pooling)
   int clamp = 0;      // the dense layers' BN1 form: scale / shift hold lo / hi, the operand is clamp(x, lo, hi) (no arithmetic, no rounding)
+  float *y32 = nullptr;   // [M][ld32] fp32: the result once more, un-rounded (the last transition: what the head reads), columns [0, N)
+  int ld32 = 0;
 };
 int launch_conv1x1(const Conv1x1Args &a, hipStream_t s);
 
@@ -214,6 +216,7 @@ struct DenseBlock7Args {
   const float *tab;      // per layer s1[1024] | t1[1024] | t2[128]
   unsigned a_off[4], b_off[4];   // start of each wave's streams, in 16-byte units
   unsigned long long *ts = nullptr;
+  float *side = nullptr;         // [B][49][ldc] fp32: the appended channels once more, un-rounded, for the head
 };
 struct Block7Layer { const float *w1f /*[128][K], BN2 scale folded in*/, *w3 /*(32,128,3,3)*/, *s1, *t1 /*[K]*/, *t2 /*[128]*/; };
 struct Block7Image {
@@ -319,4 +322,4 @@ void bn_relu_clamp_fold(const float *scale, const float *shift, int n, float *lo
 int launch_channel_mean(const f16 *x, int ld, int K, const float *scale, const float *shift, long rows, double *scratch /* 32 * K doubles */,
                         float *out, hipStream_t s, int clamp = 0 /* scale / shift are lo / hi of the clamp form */);
 int launch_head(const f16 *x, int B, int H, int W, int C, const float *scale, const float *shift,
-                float *feat, int PH, int PW, hipStream_t s);
+                float *feat, int PH, int PW, hipStream_t s, const float *x32 = nullptr /* the same map un-rounded: read instead of x */);

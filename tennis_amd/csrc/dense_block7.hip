@@ -339,6 +339,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
       if (p < kPix) {
         *(f16x8 *)(smem + (unsigned)((K >> 3) + 2 * sf + h) * kChunkRow + p * 16) = ov;
         *(f16x8 *)(xb + (size_t)p * a.ldc + K + 16 * sf + 8 * h) = ov;
+        // the head (BN + ReLU + 7x7 average -> the features) reads the block's output UN-rounded from a side buffer: a feature
+        // of magnitude 8 otherwise carries the fp16 rounding of its 49 stored values directly (round 5; the later layers of the
+        // block go on consuming the fp16 copy: that is their MFMA operand)
+        if (a.side) {
+          float *sp = a.side + ((size_t)blockIdx.x * kPix + p) * a.ldc + K + 16 * sf + 8 * h;
+          *(f32x4 *)sp = o0;
+          *(f32x4 *)(sp + 4) = o1;
+        }
       }
       if (l + 1 < a.nl) {
         f32x4 *tl = (f32x4 *)(smem + kTabOff);

@@ -45,7 +45,9 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const f16 *__restrict__ x,
   }
 }
 
-__global__ __launch_bounds__(256) void head_kernel(const f16 *__restrict__ x, int B, int H, int W, int C,
+// X32: the map comes un-rounded from the fp32 side buffer the last transition and the 7x7 block kernel write (round 5)
+template <bool X32>
+__global__ __launch_bounds__(256) void head_kernel(const f16 *__restrict__ x, const float *__restrict__ x32, int B, int H, int W, int C,
                                                    const float *__restrict__ scale, const float *__restrict__ shift,
                                                    float *__restrict__ feat, int PH, int PW) {
   const int cpp = C >> 3;
@@ -68,9 +70,17 @@ __global__ __launch_bounds__(256) void head_kernel(const f16 *__restrict__ x, in
   for (int ky = 0; ky < 7; ++ky)
     for (int kx = 0; kx < 7; ++kx) {
       const int iy = ph * 7 + ky, ix = pw * 7 + kx;
-      const f16x8 v = *(const f16x8 *)(x + (((long)b * H + iy) * W + ix) * C + ch * 8);
+      if constexpr (X32) {
+        const float4 *q = (const float4 *)(x32 + (((long)b * H + iy) * W + ix) * C + ch * 8);
+        const float4 v0 = q[0], v1 = q[1];
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += fmaxf(fmaf((float)v[j], sc[j], sh[j]), 0.f);
+        for (int j = 0; j < 8; ++j) acc[j] += fmaxf(fmaf(v[j], sc[j], sh[j]), 0.f);
+      } else {
+        const f16x8 v = *(const f16x8 *)(x + (((long)b * H + iy) * W + ix) * C + ch * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += fmaxf(fmaf((float)v[j], sc[j], sh[j]), 0.f);
+      }
     }
   // Flatten of (B, C, PH, PW): index c*PH*PW + ph*PW + pw
   const int F = C * PH * PW;
@@ -129,11 +139,11 @@ int launch_channel_mean(const f16 *x, int ld, int K, const float *scale, const f
 }
 
 int launch_head(const f16 *x, int B, int H, int W, int C, const float *scale, const float *shift, float *feat,
-                int PH, int PW, hipStream_t s) {
+                int PH, int PW, hipStream_t s, const float *x32) {
   TN_REQUIRE(C % 8 == 0, "head: channels must be a multiple of 8");
   const long total = (long)B * PH * PW * (C / 8);
-  hipLaunchKernelGGL(head_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, B, H, W, C, scale,
-                     shift, feat, PH, PW);
+  if (x32) hipLaunchKernelGGL(head_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, x32, B, H, W, C, scale, shift, feat, PH, PW);
+  else hipLaunchKernelGGL(head_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, x32, B, H, W, C, scale, shift, feat, PH, PW);
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;
 }

@@ -48,14 +48,30 @@ def default_transform(img_hwc_u8: np.ndarray) -> np.ndarray:
 
 
 class TennisSet:
+    def __new__(cls, root="data", captions=False, *args, **kwargs):
+        """``TennisSet(captions=True, ...)`` (reference dataset.py:17-19,52-74,154-183; train_gnmt.py:196-203) IS the caption-mode
+        dataset: one sample per point - the clip's frame features and the caption's token ids.  It is served by
+        ``tennis_amd.captions.CaptionSet`` (same arguments, same sample tuple); the frame / window branch is this class."""
+        if captions and cls is TennisSet:
+            from .captions import CaptionSet
+            names = ("transform", "split", "every", "balance", "padding", "stride", "window", "model_id", "split_id", "flow",
+                     "max_cap_len", "vocab", "inference", "feats_model", "save_feats")
+            kw = dict(zip(names, args))
+            kw.update(kwargs)
+            if kw.get("flow"):
+                raise NotImplementedError("optical-flow input is outside the accelerated hot path (SURVEY §2a)")
+            return CaptionSet(split=kw.get("split", "train"), every=kw.get("every", 1), max_cap_len=kw.get("max_cap_len", -1),
+                              vocab=kw.get("vocab"), inference=kw.get("inference", False), root=root,
+                              split_id=kw.get("split_id", "02"), feats_model=kw.get("feats_model"),
+                              **{k: kw[k] for k in ("n_points", "feature_dim", "mean_frames", "seed") if k in kw})
+        return super().__new__(cls)
+
     def __init__(self, root="data", captions=False, transform=None, split="train", every=1, balance=True,
                  padding=1, stride=1, window=1, model_id="0000", split_id="02", flow=False, max_cap_len=-1,
                  vocab=None, inference=False, feats_model=None, save_feats=False,
                  # synthetic-source knobs (not in the reference):
                  data_shape=224, videos=("V006", "V007"), frames_per_video=16, seed=1234, split_first=0,
                  video_length=None, decode="host"):
-        if captions:
-            raise NotImplementedError("caption mode (dataset.py:154-183) is served by tennis_amd.captions.CaptionSet")
         if flow:
             raise NotImplementedError("optical-flow input is outside the accelerated hot path (SURVEY §2a)")
         self._root = root

@@ -12,7 +12,7 @@ import numpy as np
 from ... import weights as W
 from ...block import Block, Parameter
 
-__all__ = ["GNMTEncoder", "GNMTDecoder", "get_gnmt_encoder_decoder", "NMTModel", "Vocab"]
+__all__ = ["GNMTEncoder", "GNMTDecoder", "get_gnmt_encoder_decoder", "NMTModel", "Vocab", "TokenEmbedding"]
 
 
 _CELL = ("i2h_weight", "h2h_weight", "i2h_bias", "h2h_bias")
@@ -98,6 +98,54 @@ def get_gnmt_encoder_decoder(cell_type="lstm", attention_cell="scaled_luong", nu
     return encoder, decoder
 
 
+class TokenEmbedding:
+    """``gluonnlp.embedding.TokenEmbedding.from_file(file_path)`` (reference train_gnmt.py:212; the file is written by
+    train_embeddings.py: ``data/embeddings-ex.txt``, 250 lines of ``token v1 ... v100``) [EXT]: one token per line followed by its
+    vector, elements separated by ``elem_delim``; a first line of two elements is a header (word2vec / fastText) and skipped; a
+    token seen twice keeps its first vector; a line whose vector length differs from the first one's is an error."""
+
+    def __init__(self, idx_to_token, idx_to_vec):
+        self.idx_to_token = list(idx_to_token)
+        self.token_to_idx = {t: i for i, t in enumerate(self.idx_to_token)}
+        self.idx_to_vec = np.ascontiguousarray(idx_to_vec, dtype=np.float32)
+        self.dim = int(self.idx_to_vec.shape[1]) if self.idx_to_vec.ndim == 2 else 0
+
+    def __len__(self):
+        return len(self.idx_to_token)
+
+    def __contains__(self, token):
+        return token in self.token_to_idx
+
+    def __getitem__(self, token):
+        if isinstance(token, str):
+            j = self.token_to_idx.get(token)
+            return self.idx_to_vec[j] if j is not None else np.zeros(self.dim, np.float32)
+        return np.stack([self[t] for t in token])
+
+    @classmethod
+    def from_file(cls, file_path, elem_delim=" ", encoding="utf8"):
+        toks, vecs, seen, dim = [], [], set(), None
+        with open(file_path, "r", encoding=encoding) as f:
+            for line_num, line in enumerate(f):
+                elems = line.rstrip().split(elem_delim)
+                if len(elems) < 2 or (line_num == 0 and len(elems) == 2):
+                    continue                      # blank line / "<count> <dim>" header
+                token, vals = elems[0], [e for e in elems[1:] if e != ""]
+                if token in seen:
+                    continue
+                vec = np.array([float(v) for v in vals], np.float32)
+                if dim is None:
+                    dim = vec.size
+                elif vec.size != dim:
+                    raise ValueError(f"{file_path}:{line_num + 1}: vector of {vec.size} elements, the file's first one has {dim}")
+                seen.add(token)
+                toks.append(token)
+                vecs.append(vec)
+        if not toks:
+            raise ValueError(f"{file_path}: no embedding vectors")
+        return cls(toks, np.stack(vecs))
+
+
 class Vocab:
     """gluonnlp.Vocab(counter) as the reference uses it (dataset.py:57-58): indices 0..3 are
     <unk>, <pad>, <bos>, <eos>; then tokens by descending frequency, ties alphabetical [EXT]."""
@@ -107,9 +155,29 @@ class Vocab:
         toks = sorted(counter.items(), key=lambda kv: (-kv[1], kv[0]))
         self.idx_to_token = [self.unknown_token, self.padding_token, self.bos_token, self.eos_token] + [t for t, _ in toks]
         self.token_to_idx = {t: i for i, t in enumerate(self.idx_to_token)}
+        self.embedding = None
 
     def __len__(self):
         return len(self.idx_to_token)
+
+    def set_embedding(self, *embeddings):
+        """``gluonnlp.Vocab.set_embedding(word_embs)`` as the reference calls it (train_gnmt.py:211-213) [EXT]: ``self.embedding``
+        gets ``idx_to_vec`` (len(vocab), dim): the file's vector for every vocabulary token the file holds, the embedding's
+        unknown vector - zeros unless the file itself defines ``<unk>`` - for every other one, the special tokens included
+        (SURVEY App. B); several embeddings are concatenated along the vector."""
+        if not embeddings or any(e is None for e in embeddings):
+            self.embedding = None
+            return
+        cols = []
+        for e in embeddings:
+            unk = e.idx_to_vec[e.token_to_idx[self.unknown_token]] if self.unknown_token in e.token_to_idx else np.zeros(e.dim, np.float32)
+            tab = np.tile(unk.astype(np.float32), (len(self), 1))
+            for i, t in enumerate(self.idx_to_token):
+                j = e.token_to_idx.get(t)
+                if j is not None:
+                    tab[i] = e.idx_to_vec[j]
+            cols.append(tab)
+        self.embedding = TokenEmbedding(list(self.idx_to_token), np.concatenate(cols, axis=1))
 
     def __getitem__(self, tokens):
         if isinstance(tokens, str):
@@ -134,8 +202,12 @@ class NMTModel(Block):
         for n in ("tgt_proj_weight", "tgt_proj_bias", "tgt_embed_weight"):
             self._own_params[prefix + n] = Parameter(prefix + n)
         self._tgt_embed_given = tgt_embed is not None
-        if tgt_embed is not None:                      # train_gnmt.py:211-218: preloaded embedding table
-            self._own_params[prefix + "tgt_embed_weight"].data = np.ascontiguousarray(tgt_embed, dtype=np.float32)
+        if tgt_embed is not None:                      # train_gnmt.py:211-218: preloaded embedding table (its width IS the embed size)
+            tab = np.ascontiguousarray(getattr(tgt_embed, "idx_to_vec", tgt_embed), dtype=np.float32)
+            if tab.ndim != 2 or (tgt_vocab is not None and tab.shape[0] != len(tgt_vocab)):
+                raise ValueError(f"tgt_embed: a (len(tgt_vocab), dim) table is expected, got {tab.shape}")
+            self._embed_size = int(tab.shape[1])
+            self._own_params[prefix + "tgt_embed_weight"].data = tab
 
     def _structural_params(self, path=""):
         """[EXT, gluonnlp NMTModel.__init__] children ``src_embed``, ``tgt_embed``, ``encoder``, ``decoder``,

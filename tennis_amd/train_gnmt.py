@@ -132,27 +132,61 @@ def build_parser():
     p.add_argument("--lr", type=float, default=1e-3)
     p.add_argument("--lr_update_factor", type=float, default=0.5)
     p.add_argument("--every", type=int, default=1)
+    p.add_argument("--feats_model", default=None, help="load CNN features as npy files from this model: <data_root>/features/<feats_model>/, "
+                   "what `python -m tennis_amd.evaluate --save_feats --model_id <feats_model>` wrote (train_gnmt.py:116-117)")
+    p.add_argument("--emb_file", default="embeddings-ex.txt", help="the word embedding file generated by train_embeddings.py, under "
+                   "--data_root (train_gnmt.py:118; '' = a learned embedding of --emb_size)")
+    p.add_argument("--data_root", default=None, help="the dataset directory (the reference's 'data': splits/, annotations/, features/, "
+                   "the embedding file); without it the captions and features are synthetic")
+    p.add_argument("--split_id", default="02")
     p.add_argument("--feature_dim", type=int, default=1024, help="width of the pre-extracted frame features (feats_model)")
     p.add_argument("--n_points", type=int, default=64, help="synthetic source: points per split")
     p.add_argument("--root", default="models/captioning/experiments")
     return p
 
 
+def load_target_embedding(flags, vocab, log=print):
+    """reference train_gnmt.py:210-220: ``TokenEmbedding.from_file(data/<emb_file>)`` + ``vocab.set_embedding`` -> the table the
+    target ``nn.Embedding`` is initialised with, or None (no file asked for, or a synthetic run whose directory has none)."""
+    from .models.captioning.gnmt import TokenEmbedding
+    if not flags.emb_file:
+        return None
+    path = flags.emb_file if os.path.isabs(flags.emb_file) else os.path.join(flags.data_root or "data", flags.emb_file)
+    if not os.path.exists(path):
+        if flags.data_root is not None:
+            raise FileNotFoundError(f"--emb_file: {path} does not exist (pass --emb_file '' for a learned embedding)")
+        return None                            # synthetic source: nothing on disk to read
+    vocab.set_embedding(TokenEmbedding.from_file(path))
+    tab = vocab.embedding.idx_to_vec
+    known = int((np.abs(tab).sum(1) > 0).sum())
+    log("Loaded {} x {} target embedding from {} ({} of {} vocabulary tokens found)".format(tab.shape[0], tab.shape[1], path, known, len(vocab)))
+    return tab
+
+
 def build(flags):
-    """Datasets, model and translator as reference train_gnmt.py:120-256 assembles them (feature mode)."""
-    from .captions import CaptionSet
+    """Datasets, model and translator as reference train_gnmt.py:120-256 assembles them (feature mode, ``--feats_model``): with
+    ``--data_root`` the points, captions and per-frame ``.npy`` features come from disk (``TennisSet(captions=True, ...)``), the
+    target embedding from ``--emb_file``; without it everything is synthetic."""
+    from .dataset import TennisSet
     from .models.captioning.gnmt import NMTModel, get_gnmt_encoder_decoder
     from .utils.translation import BeamSearchScorer, BeamSearchTranslator
-    data_train = CaptionSet(split="train", every=flags.every, max_cap_len=flags.tgt_max_len, n_points=flags.n_points,
-                            feature_dim=flags.feature_dim)
-    data_val = CaptionSet(split="val", every=flags.every, vocab=data_train.vocab, inference=True,
-                          n_points=max(4, flags.n_points // 4), feature_dim=flags.feature_dim)
-    data_test = CaptionSet(split="test", every=flags.every, vocab=data_train.vocab, inference=True,
-                           n_points=max(4, flags.n_points // 4), feature_dim=flags.feature_dim)
+    if flags.data_root is not None and flags.feats_model is None:
+        raise NotImplementedError("train_gnmt on raw frames (no --feats_model) needs the frames of every point on disk and the backbone "
+                                  "inside the step; the accelerated path is the reference's feature mode (evaluate --save_feats first)")
+    src = dict(root=flags.data_root, split_id=flags.split_id, feats_model=flags.feats_model) if flags.data_root is not None else dict(root=None)
+    syn = {} if flags.data_root is not None else dict(feature_dim=flags.feature_dim)
+    data_train = TennisSet(captions=True, split="train", every=flags.every, max_cap_len=flags.tgt_max_len,
+                           **src, **syn, **({} if flags.data_root is not None else dict(n_points=flags.n_points)))
+    data_val = TennisSet(captions=True, split="val", every=flags.every, vocab=data_train.vocab, inference=True,
+                         **src, **syn, **({} if flags.data_root is not None else dict(n_points=max(4, flags.n_points // 4))))
+    data_test = TennisSet(captions=True, split="test", every=flags.every, vocab=data_train.vocab, inference=True,
+                          **src, **syn, **({} if flags.data_root is not None else dict(n_points=max(4, flags.n_points // 4))))
+    feature_dim = data_train[0][0].shape[1] if len(data_train) else flags.feature_dim      # the width evaluate --save_feats wrote
+    tgt_embed = load_target_embedding(flags, data_train.vocab)
     enc, dec = get_gnmt_encoder_decoder(cell_type=flags.cell_type, hidden_size=flags.num_hidden, dropout=flags.dropout,
                                         num_layers=flags.num_layers, num_bi_layers=flags.num_bi_layers)
     model = NMTModel(src_vocab=None, tgt_vocab=data_train.vocab, encoder=enc, decoder=dec, embed_size=flags.emb_size,
-                     prefix="gnmt_", input_size=flags.feature_dim)
+                     prefix="gnmt_", input_size=feature_dim, tgt_embed=tgt_embed)                  # train_gnmt.py:228-229
     model.initialize()
     translator = BeamSearchTranslator(model=model, beam_size=flags.beam_size,
                                       scorer=BeamSearchScorer(alpha=flags.lp_alpha, K=flags.lp_k),
@@ -164,6 +198,10 @@ def main(argv=None):
     flags = build_parser().parse_args(argv)
     data_train, data_val, data_test, model, translator = build(flags)
     save_dir = os.path.join(flags.root, flags.model_id)
+    os.makedirs(save_dir, exist_ok=True)
+    from .captions import write_sentences
+    write_sentences(data_val.get_captions(split=True), os.path.join(save_dir, "val_gt.txt"))         # train_gnmt.py:205-208
+    write_sentences(data_test.get_captions(split=True), os.path.join(save_dir, "test_gt.txt"))
     hist = train(data_train, data_val, data_test, model, translator, flags.epochs, flags.batch_size, lr=flags.lr,
                  lr_update_factor=flags.lr_update_factor, dropout=flags.dropout, num_buckets=flags.num_buckets,
                  test_batch_size=flags.test_batch_size, save_dir=save_dir)

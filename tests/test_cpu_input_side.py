@@ -205,6 +205,81 @@ def test_caption_set_on_disk(tmp_path):
         CaptionSet(root=root, split="test", split_id="02")
 
 
+def test_captioning_drivers_read_real_inputs(tmp_path):
+    """the captioning drivers on the reference's inputs (train_gnmt.py:116-118,196-218).  ``TennisSet(captions=
+    True, feats_model=...)`` IS the caption dataset (dataset.py:17-19,154-183); ``--emb_file`` is read with
+    TokenEmbedding.from_file and attached with Vocab.set_embedding (tokens the file does not hold, the specials included, get the
+    zero vector); ``train_gnmt.build`` assembles datasets, vocabulary, target embedding and model from ``--data_root``."""
+    from tennis_amd import train_gnmt as tg
+    from tennis_amd.captions import CaptionSet
+    from tennis_amd.dataset import TennisSet
+    from tennis_amd.models.captioning.gnmt import TokenEmbedding, Vocab
+    from tools import tiny_dataset as td
+    root = str(tmp_path / "data")
+    info = td.write(root, np.random.default_rng(4))
+    rng = np.random.default_rng(1)
+    feats = {}
+    for split, pts in info["points"].items():
+        for pid, v, a, b, cap in pts:
+            for fr in range(a, b):
+                path = TennisSet.get_feature_path(os.path.join(root, "features", "0042"), v, fr)
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                feats[(v, fr)] = rng.normal(0, 1, 20).astype(np.float32)
+                np.save(path, feats[(v, fr)])
+    # the reference's constructor call (train_gnmt.py:196-203)
+    data_train = TennisSet(root=root, split="train", transform=None, captions=True, max_cap_len=50, every=1, feats_model="0042")
+    data_test = TennisSet(root=root, split="test", transform=None, captions=True, vocab=data_train.vocab, every=1, inference=True, feats_model="0042")
+    assert isinstance(data_train, CaptionSet) and len(data_train) == 5 and len(data_test) == 2 and data_test.vocab is data_train.vocab
+    assert data_test.get_captions() == td.CAPTIONS["test"]
+    x, cap, tl, cl, idx = data_test[1]
+    pid, v, a, b, _ = info["points"]["test"][1]
+    assert x.shape == (4, 20) and np.array_equal(x[2], feats[(v, a + 2)])
+    assert [data_train.vocab.idx_to_token[i] for i in cap[1:-1]] == ["far", "player", "hits", "a", "backhand", "return", "wide"]
+    # the embedding file and Vocab.set_embedding
+    emb = TokenEmbedding.from_file(os.path.join(root, "embeddings-ex.txt"))
+    assert len(emb) == len(info["emb"]) and emb.dim == 12 and "court" in emb and np.array_equal(emb["near"], info["emb"]["near"])
+    vocab = data_train.vocab
+    vocab.set_embedding(emb)
+    tab = vocab.embedding.idx_to_vec
+    assert tab.shape == (len(vocab), 12) and tab.dtype == np.float32
+    assert not tab[:4].any() and not tab[vocab["winner"]].any()             # <unk> <pad> <bos> <eos> and a word the file lacks
+    assert np.array_equal(tab[vocab["player"]], info["emb"]["player"])
+    assert np.allclose(np.linalg.norm(tab[vocab["serves"]]), 1.0, atol=1e-6)
+    with open(os.path.join(root, "hdr.txt"), "w") as f:                        # word2vec-style header + a repeated token
+        f.write("3 2\na 1 2\nb 3 4\na 9 9\n")
+    h = TokenEmbedding.from_file(os.path.join(root, "hdr.txt"))
+    assert h.idx_to_token == ["a", "b"] and np.array_equal(h["a"], [1, 2])
+    v2 = Vocab({"a": 2, "zz": 1})
+    v2.set_embedding(h)
+    assert np.array_equal(v2.embedding.idx_to_vec, [[0, 0]] * 4 + [[1, 2], [0, 0]])
+    # the driver's assembly (train_gnmt.py:120-256) from --data_root / --feats_model / --emb_file
+    flags = tg.build_parser().parse_args(["--data_root", root, "--feats_model", "0042", "--num_hidden", "8", "--tgt_max_len", "6", "--emb_size", "100"])
+    assert flags.emb_file == "embeddings-ex.txt" and flags.split_id == "02"
+    d_tr, d_va, d_te, model, tr = tg.build(flags)
+    assert len(d_tr) == 5 and len(d_va) == 2 and len(d_te) == 2 and model._input_size == 20
+    assert model._embed_size == 12                                            # the file's width, not --emb_size (train_gnmt.py:214-218)
+    w = model.collect_params()["gnmt_tgt_embed_weight"].data
+    assert np.array_equal(w, d_tr.vocab.embedding.idx_to_vec) and w.shape == (len(d_tr.vocab), 12)
+    assert len(d_tr[0][1]) == 2 + 5 and max(len(s[1]) for s in (d_tr[i] for i in range(5))) == 2 + 6      # max_cap_len cuts the 10-word caption
+    with pytest.raises(FileNotFoundError):
+        tg.build(tg.build_parser().parse_args(["--data_root", root, "--feats_model", "0042", "--emb_file", "nope.txt"]))
+    flags = tg.build_parser().parse_args(["--data_root", root, "--feats_model", "0042", "--emb_file", "", "--emb_size", "10", "--num_hidden", "8"])
+    assert tg.build(flags)[3]._embed_size == 10
+    # synthetic source (no --data_root): unchanged
+    flags = tg.build_parser().parse_args(["--n_points", "8", "--feature_dim", "16", "--num_hidden", "8"])
+    assert tg.build(flags)[3]._input_size == 16
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/data/embeddings-ex.txt"), reason="build container only: the reference's own embedding file")
+def test_reference_embedding_file_parses():
+    """data/embeddings-ex.txt (BASELINE config 5's "250-word embedding"): 250 tokens x 100, rows L2-normalised."""
+    from tennis_amd.models.captioning.gnmt import TokenEmbedding
+    emb = TokenEmbedding.from_file("/root/reference/data/embeddings-ex.txt")
+    assert len(emb) == 250 and emb.idx_to_vec.shape == (250, 100)
+    assert np.allclose(np.linalg.norm(emb.idx_to_vec, axis=1), 1.0, atol=1e-4)
+    assert emb.idx_to_token[:3] == ["a", "np", "fp"]
+
+
 def test_train_transform_oracle_and_parameter_draws():
     """Round 4: the reference's TRAIN transform (train.py:125-139).  oracle/image_np.py::augment_u8 with neutral parameters is the
     plain resize; the host-side draws of tennis_amd.transforms follow mx.image.random_size_crop / the image_random operators:

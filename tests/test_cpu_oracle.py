@@ -721,4 +721,14 @@ def test_vector_feedback_rounding_library_vs_numpy():
     name = "densenet0_stage1_conv0_weight"
     q = W.as_fp16_model(p, input_means={name: np.abs(rng.normal(0.5, 0.2, (6, p[name].shape[1])))})
     plain = W.as_fp16_model(p)
-    assert all(np.array_equal(q[k], plain[k]) for k in p if k != name) and (q[name] != plain[name]).any()
+    rm = "densenet0_stage1_batchnorm1_running_mean"
+    assert all(np.array_equal(q[k], plain[k]) for k in p if k not in (name, rm)) and (q[name] != plain[name]).any()
+    # round 5, bias correction: the mean conversion error of the 1x1's output over the calibration rows sits in the running mean
+    # of the BatchNorm behind it (the only consumer), in the model's own units: sum_k (w_conv - w)[n, k] E[relu(bn1(x))[k]]
+    q2 = W.as_fp16_model(p, input_means={name: np.abs(np.random.default_rng(11).normal(0.5, 0.2, (6, p[name].shape[1])))})
+    q2n = W.as_fp16_model(p, input_means={name: np.abs(np.random.default_rng(11).normal(0.5, 0.2, (6, p[name].shape[1])))}, bias_correction=False)
+    assert np.array_equal(q2n[rm], p[rm]) and not np.array_equal(q2[rm], p[rm])
+    _, _, sw1, tc1 = W.bn_relu_clamp_fold(p, "densenet0_stage1_batchnorm0")
+    ybar = sw1.astype(np.float64) * np.abs(np.random.default_rng(11).normal(0.5, 0.2, (6, p[name].shape[1]))).mean(0) + tc1
+    want = (q2[name].astype(np.float64) - p[name]).sum((2, 3)) @ ybar
+    assert np.allclose(q2[rm].astype(np.float64) - p[rm], want, rtol=1e-3, atol=1e-7)

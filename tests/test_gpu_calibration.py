@@ -15,13 +15,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-# families without large perfectly flat regions (on a flat region every pixel makes the SAME fp16 activation-rounding error, which the
-# average pool cannot reduce: that part belongs to the fp16 activation path, not to the weight conversion - rows "kernels alone" /
-# "exact-weights mode" of the matrix)
-# (round 4, second pass: "bright" - blobs compressed into the top tenth of the range - and "stripes" are piecewise flat as well; with
-# the packed-half BN1 the same conversion realised 1.1e-3 / 1.4e-3 there where the fp32-constant form had realised 7.4e-4 / 8.4e-4,
-# the exact-weights mode measuring 1.5e-3 / 1.0 - 1.3e-3 on them in both: they were inside the bar by the luck of one realisation)
-NATURAL = ["noise", "lowcontrast", "gradient", "blobs", "scene", "dark", "tinted", "photo", "jpeg", "checker"]
+# (rounds 3 - 4 held the bar on the "natural" families only: on frames with large flat regions the fp16 activation path made the
+# same rounding error in every pixel.  Round 5 removed those roundings - exact stem operand, BN1 as a clamp, dithered stem
+# output - and the bar is asserted on ALL sixteen families again, features and logits: VERDICT r4 item 1)
 
 
 def _jpeg_frames(n, size=224):
@@ -48,10 +44,11 @@ def world():
     frames = {f: (CF.frames(f, 2, 224, seed=99) if f != "jpeg" else _jpeg_frames(2)) for f in fams}
     net = TorchDenseNet121(p)
     ref = {f: net(torch.from_numpy(W.normalize_to_nchw_f32(frames[f]))).numpy() for f in fams}      # fp32 graph, fp32 weights, un-rounded input
-    return dict(p=p, fams=fams, frames=frames, ref=ref)
+    dense = W.make_dense_weights(1, 11, 1024, "framemodel0_dense0_")        # the frame classifier's Dense(11) (definitions.py:25)
+    return dict(p=p, fams=fams, frames=frames, ref=ref, wd=dense["framemodel0_dense0_weight"].astype(np.float64))
 
 
-def _errors(world, q, ref=None, exact=False):
+def _errors(world, q, ref=None, exact=False, logits=None):
     from tennis_amd.engine import DenseNet121Features
     enc = DenseNet121Features(q, 224, max_batch=2, exact_weights=exact)
     ref = world["ref"] if ref is None else ref
@@ -59,6 +56,8 @@ def _errors(world, q, ref=None, exact=False):
     for f in world["fams"]:
         feat = enc(torch.from_numpy(world["frames"][f]).cuda()).cpu().numpy()
         out[f] = float(np.abs(feat - ref[f]).max())
+        if logits is not None:          # the same error through the classifier's Dense(11): what north_star names first
+            logits[f] = float(np.abs((feat.astype(np.float64) - ref[f]) @ world["wd"].T).max())
     del enc
     return out
 
@@ -82,8 +81,10 @@ def test_calibration_matrix(world, report):
     fm = frame_means(p, W.synthetic_frames_u8(8, 224, seed=4321))
     matrix["round 3: mean of 8 noise frames"] = _errors(world, W.as_fp16_model(p, input_means={k: v.mean(0) for k, v in fm.items()}))
     # the built-in calibration set at three sizes (72 is the default)
-    for n in (12, 24, 72):
-        matrix[f"built-in set, {n} frames"] = _errors(world, calibrated_fp16_model(p, None, 224, builtin_frames=n))
+    lmatrix = {}
+    for n in (12, 24, 72, 144):
+        lmatrix[f"built-in set, {n} frames"] = {}
+        matrix[f"built-in set, {n} frames"] = _errors(world, calibrated_fp16_model(p, None, 224, builtin_frames=n), logits=lmatrix[f"built-in set, {n} frames"])
     # ... plus eight frames of a family the set does not contain (a user who adds frames of the footage)
     for extra in ("text", "jpeg"):
         add = CF.frames(extra, 8, 224, seed=7) if extra != "jpeg" else _jpeg_frames(8)[::-1].copy()
@@ -92,25 +93,26 @@ def test_calibration_matrix(world, report):
     matrix["vector feedback, 8 noise frames only"] = _errors(world, calibrated_fp16_model(p, W.synthetic_frames_u8(8, 224, seed=4321), 224, builtin_frames=0))
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump({"bar": 1e-3, "oracle": "oracle/torch_ref.py (fp32 graph, un-rounded fp32 weights, un-rounded normalised input), 2 frames per family",
-               "held_out_families": CF.HELD_OUT + ["jpeg"], "feature_max_abs_error": matrix}, open("gpurun_out/calibration_matrix.json", "w"), indent=1)
+               "held_out_families": CF.HELD_OUT + ["jpeg"], "feature_max_abs_error": matrix, "logit_max_abs_error": lmatrix,
+               "logits": "Dense(11) of the frame classifier (weights.make_dense_weights(1, 11, 1024)) applied to the feature error"},
+              open("gpurun_out/calibration_matrix.json", "w"), indent=1)
     for k, row in matrix.items():
         print("%-40s " % k + " ".join("%s %.1e" % (f[:5], row[f]) for f in world["fams"]) + "  worst %.2e" % max(row.values()))
         report["calibration_worst_" + k.replace(" ", "_")] = max(row.values())
-    default = matrix["built-in set, 72 frames"]
+    default = matrix["built-in set, 144 frames"]          # calibrated_fp16_model's default
+    dlog = lmatrix["built-in set, 144 frames"]
     plain = matrix["plain rounding"]
+    kern = matrix["kernels alone (oracle on the converted weights)"]
     report["calibrated_default_worst_family_err"] = max(default.values())
-    report["calibrated_default_worst_natural_err"] = max(default[f] for f in NATURAL)
-    exact = matrix["exact-weights mode (hi + lo pairs)"]
-    report["exact_mode_worst_family_err"] = max(exact.values())
-    # the bar holds on every family without large flat regions, held-out ones included ...
-    for f in NATURAL:
+    report["calibrated_default_worst_family_logit_err"] = max(dlog.values())
+    report["kernels_alone_worst_family_err"] = max(kern.values())
+    report["exact_mode_worst_family_err"] = max(matrix["exact-weights mode (hi + lo pairs)"].values())
+    # THE bar (north_star: features / logits within 1e-3 of the fp32 reference), on every family, held-out ones included
+    for f in world["fams"]:
         assert default[f] < 1e-3, (f, default[f])
-    # ... frames with large flat regions (constant colour, saturated patches, half-black, text on white, stripes, near-white blobs) stay
-    # within 2e-3 - their measured values are what bench.py quotes - and no further from the bar than the exact-weights mode is
-    # on the same frames plus 5e-4: what is left there is the fp16 activation path, not the conversion
-    assert max(default.values()) < 2e-3, default
-    assert all(default[f] < max(1e-3, exact[f] + 5e-4) for f in world["fams"]), (default, exact)
-    assert max(default.values()) < 0.45 * max(plain.values()) and all(default[f] < plain[f] for f in world["fams"]), (default, plain)
+        assert dlog[f] < 1e-3, (f, dlog[f])
+        assert kern[f] < 1e-3, (f, kern[f])
+    assert max(default.values()) < 0.3 * max(plain.values()) and all(default[f] < plain[f] for f in world["fams"]), (default, plain)
     # and the set matters: one family of calibration frames leaves the others outside (the round-3 hole, now measured)
     assert max(matrix["round 3: mean of 8 noise frames"].values()) > 1.5 * max(default.values())
 

@@ -164,6 +164,39 @@ def test_captioning_evaluate_driver():
         assert sents[i] == gn.ids_to_sentences(rs, rvl, train.vocab.idx_to_token)[0]
 
 
+def test_captioning_pipeline_from_disk_through_the_drivers(tmp_path, report):
+    """the pipeline the reference runs (train_gnmt.py:116-118,196-218; evaluate.py --save_feats) started from
+    the drivers' command lines on a tiny copy of the reference's data/ directory:
+        python -m tennis_amd.evaluate --save_feats --model_id 0042 --split {train,val,test}     frames (JPEG) -> features (.npy)
+        python -m tennis_amd.train_gnmt --data_root data --feats_model 0042                       features + captions + embeddings -> captioner
+        python -m tennis_amd.evaluate_gnmt ...                                                    best parameters -> loss / BLEU / sentences"""
+    import os
+    from tennis_amd import evaluate as ev, evaluate_gnmt as eg, train_gnmt as tg
+    from tennis_amd.dataset import TennisSet
+    from tools import tiny_dataset as td
+    root, exp = str(tmp_path / "data"), str(tmp_path / "exp")
+    info = td.write(root, np.random.default_rng(8))
+    for split in ("train", "val", "test"):
+        assert ev.main(["--root", root, "--model_id", "0042", "--save_feats", "--split", split, "--batch_size", "16",
+                        "--exp_root", str(tmp_path / "vexp"), "--num_workers", "0"]) == 0
+    pid, v, a, b, cap = info["points"]["test"][0]
+    f = np.load(TennisSet.get_feature_path(os.path.join(root, "features", "0042"), v, a))
+    assert f.shape == (1024,) and f.dtype == np.float32 and np.isfinite(f).all() and f.std() > 0
+    common = ["--data_root", root, "--feats_model", "0042", "--model_id", "cap1", "--root", exp, "--num_hidden", "16",
+              "--tgt_max_len", "12", "--beam_size", "2", "--test_batch_size", "2", "--num_buckets", "2"]
+    assert tg.main(common + ["--epochs", "3", "--batch_size", "2", "--dropout", "0.0", "--lr", "0.01"]) == 0
+    files = sorted(os.listdir(os.path.join(exp, "cap1")))
+    assert {"0000.params", "0002.params", "val_gt.txt", "test_gt.txt", "epoch0_valid_out.txt", "epoch2_test_out.txt"} <= set(files), files
+    assert open(os.path.join(exp, "cap1", "test_gt.txt")).read().split("\n")[:2] == td.CAPTIONS["test"]
+    out = eg.main(common)
+    assert set(out) == {"valid", "test"} and all(np.isfinite(l) and 0.0 <= bl <= 1.0 for l, bl in out.values())
+    assert open(os.path.join(exp, "cap1", "best_test_out.txt")).read().count("\n") == 2       # one line per test point (a barely trained model may emit <eos> at once)
+    # the model the drivers built: 1024-d frame features in, the embedding file's width as embed size, its rows as the table's start
+    d_tr, _, _, model, _ = tg.build(tg.build_parser().parse_args(common))
+    assert model._input_size == 1024 and model._embed_size == 12 and len(d_tr.vocab) == 4 + len({w for c in td.CAPTIONS["train"] for w in c.split()})
+    report["captioning_pipeline_test_loss"] = float(out["test"][0])
+
+
 def test_frame_mode_source_embedding(report):
     """Frame-mode captioner (reference train_gnmt.py:148-170): ``src_embed = TimeDistributed(FrameModel(...).backbone)`` -
     the clip's FRAMES go into the model; translations and teacher-forced logits equal those of the feature-mode model
