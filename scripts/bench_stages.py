@@ -43,6 +43,36 @@ def c3t():
 s = timed(c3t, 50)
 out["C3_train_step"] = {"ms_per_clip_batch": round(s * 1e3, 3), "clips_per_s": round(B / s, 1),
                         "note": "forward + softmax CE + BPTT + weight-gradient GEMMs + SGD momentum update, fp32"}
+# ---- C3 end to end, IMAGE mode: 32 clips x 64 frames = 2 048 decoded frames -> DenseNet-121 encoder ->
+# bi-GRU(128) -> max over T -> Dense(11), the whole CNNRNN of reference models/vision/definitions.py:75-110 on frames -----------
+if os.environ.get("TN_STAGES_SKIP_C3_IMAGE") is None:
+    from tennis_amd.calibrate import calibrated_fp16_model
+    from tennis_amd.engine import DenseNet121Features
+    B3, T3 = 32, 64
+    pe = calibrated_fp16_model(W.make_densenet121_weights(0, fp16_model=False), None, 224)
+    enc = DenseNet121Features(pe, 224, max_batch=256)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    frames = torch.randint(0, 256, (B3 * T3, 224, 224, 3), generator=g, device=dev, dtype=torch.uint8)
+    feats = torch.empty((B3 * T3, 1024), dtype=torch.float32, device=dev)
+    enc.set_pipelined(True)
+    def c3_image():
+        for i in range(0, B3 * T3, 256):
+            enc(frames[i:i + 256], out=feats[i:i + 256])
+        enc.join(0); enc.join(1)
+        seq = rnn(feats.view(B3, T3, 1024))
+        return fc(temporal_pool(seq, "max"))
+    s = timed(c3_image, 10)
+    def c3_enc_only():
+        for i in range(0, B3 * T3, 256):
+            enc(frames[i:i + 256], out=feats[i:i + 256])
+        enc.join(0); enc.join(1)
+    s_e = timed(c3_enc_only, 10)
+    enc.set_pipelined(False)
+    out["C3_image_mode_end_to_end"] = {"clips": B3, "frames_per_clip": T3, "ms_per_clip_batch": round(s * 1e3, 3), "clips_per_s": round(B3 / s, 1),
+                                       "frames_per_s": round(B3 * T3 / s, 1), "encoder_only_ms": round(s_e * 1e3, 3),
+                                       "temporal_head_ms": round((s - s_e) * 1e3, 3),
+                                       "note": "2 048 uint8 224x224 frames resident in HBM -> encoder in 8 pipelined batches of 256 -> bi-GRU -> max -> Dense(11); logits (32, 11)"}
+    del enc, frames
 # ---- C5 -------------------------------------------------------------------------------------------------------
 B, T, F, H, E, V, beam, ml = 32, 214, 1024, 256, 100, 254, 5, 150
 p = W.make_gnmt_weights(0, "gru", F, H, E, V)

@@ -1,5 +1,5 @@
 // Does the instruction offset of global_load_lds_dwordx4 apply to the LDS address as well as to the global address?  (gfx950)
-// hipcc --offload-arch=gfx950 -O2 scripts/scratch/dmaoff.hip -o /tmp/dmaoff && /tmp/dmaoff
+// hipcc --offload-arch=gfx950 -O2 scripts/microbench/dmaoff.hip -o /tmp/dmaoff && /tmp/dmaoff
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

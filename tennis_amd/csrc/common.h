@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/tennis_hip.h"
+#include "../../include/tennis_hip_debug.h"
 
 typedef _Float16 f16;
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));

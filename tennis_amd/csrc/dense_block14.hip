@@ -83,7 +83,7 @@ __device__ __forceinline__ float dpp_f32(float v) {
 }
 
 // LDS-DMA: global (wave-uniform base in SGPRs + per-lane 32-bit offset) -> LDS (M0 + lane * size).  The instruction offset
-// applies to the global AND the LDS address (scripts/scratch/dmaoff.hip), so two 1-KiB pieces share one M0.
+// applies to the global AND the LDS address (scripts/microbench/dmaoff.hip), so two 1-KiB pieces share one M0.
 template <int OFF>
 __device__ __forceinline__ void dma16x2(const void *gbase, unsigned voff16, unsigned lds_dst) {
   unsigned keep;

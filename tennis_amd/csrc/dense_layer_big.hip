@@ -98,7 +98,7 @@ __device__ __forceinline__ int stage_swz(int row, int chunk) {
 // chunk bits 1-3 is conflict-free for every start slot, k-step and lane group (exhaustive search over the GF(2)-linear
 // maps, scripts/lds_swizzle_search.py); the price is paid by epilogue A's ds_write_b64: a 16-lane store group then covers
 // only four of the eight chunk positions.
-// ALL16 = the first form, `chunk ^ (slot & 15)`: 2-way on the epilogue's stores (153 B/ns/CU in scripts/scratch/ldsstore.hip
+// ALL16 = the first form, `chunk ^ (slot & 15)`: 2-way on the epilogue's stores (153 B/ns/CU in scripts/microbench/ldsstore.hip
 // against 76 for the second form, 195 for contiguous stores) but two lane pairs per group collide in the dx = +-1 taps.
 // Measured per geometry (r2-g, phase stamps and rocprof on one box): at 56x56 the first form wins (epilogue A 5 270 -> 3 970
 // cycles per tile, phase B 11 310 -> 12 160, kernel -1.7 %) and at 28x28 too (-1.1 %); the chained 14x14 block is 0.6 %

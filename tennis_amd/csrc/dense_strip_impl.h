@@ -11,7 +11,7 @@
 //   prologue.  A wave owns a pair of adjacent 14-pixel column strips (2 x 16 slots with their halo columns = the N = 32 of
 //   one v_mfma_f32_32x32x16_f16) and walks DOWN its rows one image row at a time.  One wave per SIMD issues one instruction
 //   per ~4 cycles: a 32-cycle 32x32x16 MFMA hides ~6 other instructions, a 16-cycle 16x16x32 only one
-//   (scripts/scratch/slotbench.hip) - and this layer needs ~3.5 element-wise / LDS / load instructions per 16x16x32's worth
+//   (scripts/microbench/slotbench.hip) - and this layer needs ~3.5 element-wise / LDS / load instructions per 16x16x32's worth
 //   of MFMA work, so the kernel is built on the 32x32 shape.
 // * the 128-channel bottleneck never touches LDS: with the weights as the A operand, the accumulator layout of the 1x1 GEMM
 //   (lane = slot l & 31, rows (r & 3) + 8 (r >> 2) + 4 (l >> 5)) IS the B-operand layout of the 3x3's MFMAs once the 3x3

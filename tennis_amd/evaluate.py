@@ -252,6 +252,9 @@ def extract_corpus(backbone, n_frames, batch, size, device, rank, world, block=4
     dt = time.perf_counter() - t0
     stats.update(seconds=dt, frames_per_sec=n_frames / dt, feature_dim=fdim,
                  gather_GBps_per_rank=(stats["gather_bytes_per_rank"] * max(world - 1, 0) / dt / 1e9))
+    if device.type == "cuda":        # HBM in use on this rank's device when the corpus is done (everything: the library's workspace, torch's pool, the feature matrix)
+        free_b, total_b = torch.cuda.mem_get_info(device)
+        stats.update(hbm_used_GB=(total_b - free_b) / 1e9, hbm_total_GB=total_b / 1e9)
     return full, stats
 
 
@@ -338,6 +341,7 @@ def _main_rank(flags, rank, world, dev):
                               "frames_per_sec": round(st["frames_per_sec"], 1), "seconds": round(st["seconds"], 3),
                               "feature_matrix_MB": round(full.numel() * 4 / 1e6, 1),
                               "gather_GBps_per_rank": round(st["gather_GBps_per_rank"], 3),
+                              "hbm_used_GB": round(st.get("hbm_used_GB", 0.0), 2), "hbm_total_GB": round(st.get("hbm_total_GB", 0.0), 1),
                               "checksum": float(full.double().sum().item())}))
         return 0
     # evaluate.py:91-98: Resize(s + 32) / CenterCrop(s) / ToTensor / Normalize, here one GPU launch per batch; the

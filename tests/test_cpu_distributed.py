@@ -311,3 +311,42 @@ def test_bench_step_loop_world2():
                 want = [[1000.0 * r + i for r in range(2) for _ in range(3)] for i in range(k)]
                 for r in range(2):
                     assert ret[r] == want, (pipelined, k, ret[r])
+
+
+class _StandInBackbone:
+    """What ``evaluate.extract_corpus`` needs of a backbone: frames (n, s, s, 3) uint8 -> (n, F) float32, a function of the frame's
+    pixels only (so the gathered matrix cannot depend on which rank encoded a frame)."""
+
+    def __call__(self, x):
+        v = x.reshape(x.shape[0], -1).to(torch.float64)
+        cols = [v.mean(1), v[:, ::7].sum(1) * 1e-3, v.std(1), v[:, 5], v.max(1).values]
+        return torch.stack(cols, 1).to(torch.float32)
+
+
+def _corpus_worker(rank, world, port, n_frames, batch, ret):
+    from tennis_amd import evaluate as ev
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    full, st = ev.extract_corpus(_StandInBackbone(), n_frames, batch, 8, torch.device("cpu"), rank, world, block=2)
+    ret[(world, rank)] = (full.numpy(), float(full.double().sum().item()), st["rounds"])
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_corpus_extract_world2_reproduces_the_world1_checksum():
+    """``evaluate --corpus_frames N`` (BASELINE config C4) on two ranks gathers the matrix - and therefore the
+    checksum - that one rank computes: frames are synthesised from their global index, batches are dealt to ranks in blocks,
+    the chunked all-gather puts every block back at its rows (ragged last batch, uneven number of blocks per rank)."""
+    n_frames, batch = 157, 16                 # 10 batches, the last one of 13 frames; 5 blocks of 2 batches over 2 ranks
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        _corpus_worker(0, 1, 0, n_frames, batch, ret)
+        mp.spawn(_corpus_worker, args=(2, 29547, n_frames, batch, ret), nprocs=2, join=True)
+        one, cs1, _ = ret[(1, 0)]
+        assert one.shape == (n_frames, 5) and np.isfinite(one).all()
+        for r in (0, 1):
+            full, cs, rounds = ret[(2, r)]
+            assert np.array_equal(full, one) and cs == cs1 and rounds >= 2

@@ -153,11 +153,16 @@ def test_dataset_paths_and_windows():
 def test_abi_library_exports_every_declared_symbol():
     from tennis_amd import _lib
     header = open(os.path.join(ROOT, "include", "tennis_hip.h")).read()
-    declared = sorted(set(re.findall(r"\b(tn_[a-z0-9_]+)\s*\(", header)))
-    assert len(declared) >= 24
+    debug = open(os.path.join(ROOT, "include", "tennis_hip_debug.h")).read()
+    public = sorted(set(re.findall(r"\b(tn_[a-z0-9_]+)\s*\(", header)))
+    hooks = sorted(set(re.findall(r"\b(tn_[a-z0-9_]+)\s*\(", debug)))
+    # the drop-in header carries the reference's surface only: test / tuning hooks live in tennis_hip_debug.h
+    assert not [n for n in public if n.startswith("tn_dbg_") or n in ("tn_densenet121_profile", "tn_densenet121_read_tap", "tn_jpeg_sync_passes")]
+    assert len(public) >= 60 and len(hooks) >= 20 and not set(public) & set(hooks)
+    declared = sorted(public + hooks)
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
-        assert hasattr(lib, name), f"{name} declared in include/tennis_hip.h but not exported"
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
     assert sorted(_lib.declared_symbols()) == declared            # the ctypes table covers the whole header
     assert _lib.load().tn_version() >= 100
 
