@@ -84,13 +84,17 @@ struct tn_npy_writer {
     std::lock_guard<std::mutex> g(err_mu);
     if (error.empty()) error = what;
   }
+  // A file appears under its name only when it is complete: the bytes go to "<path>.tmp.<pid>.<thread>" and the
+  // file is then renamed (atomic within a directory).  A short write (ENOSPC, EIO) or a killed run leaves no truncated .npy
+  // that the next --save_feats run would count as "exists" and the temporal head's training would read.
   void write_row(Job &j, int i, const std::string &header) {
     const std::string &path = j.paths[i];
     if (!make_dirs(path)) { fail("cannot create the directory of " + path + ": " + strerror(errno)); return; }
-    const int fd = open(path.c_str(), O_WRONLY | O_CREAT | (j.skip_existing ? O_EXCL : O_TRUNC), 0666);
+    if (j.skip_existing && access(path.c_str(), F_OK) == 0) { ++skipped; return; }          // evaluate.py:312: `if not os.path.exists(feat_path)`
+    const std::string tmp = path + ".tmp." + std::to_string((long)getpid()) + "." + std::to_string((unsigned long)std::hash<std::thread::id>{}(std::this_thread::get_id()));
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
     if (fd < 0) {
-      if (errno == EEXIST && j.skip_existing) { ++skipped; return; }       // evaluate.py:312: `if not os.path.exists(feat_path)`
-      fail("cannot open " + path + ": " + strerror(errno));
+      fail("cannot open " + tmp + ": " + strerror(errno));
       return;
     }
     std::string buf = header;
@@ -100,13 +104,33 @@ struct tn_npy_writer {
       const ssize_t n = write(fd, buf.data() + off, buf.size() - off);
       if (n < 0) {
         if (errno == EINTR) continue;
-        fail("write to " + path + " failed: " + strerror(errno));
+        fail("write to " + tmp + " failed: " + strerror(errno));
         break;
       }
       off += (size_t)n;
     }
-    close(fd);
-    if (off == buf.size()) ++written;
+    const bool closed = close(fd) == 0;
+    if (off != buf.size() || !closed) {
+      if (off == buf.size()) fail("close of " + tmp + " failed: " + strerror(errno));
+      unlink(tmp.c_str());
+      return;
+    }
+    if (j.skip_existing) {
+      // another writer may have completed the same file meanwhile: link() fails with EEXIST instead of replacing it
+      if (link(tmp.c_str(), path.c_str()) != 0) {
+        const int e = errno;
+        unlink(tmp.c_str());
+        if (e == EEXIST) { ++skipped; return; }
+        fail("cannot publish " + path + ": " + strerror(e));
+        return;
+      }
+      unlink(tmp.c_str());
+    } else if (rename(tmp.c_str(), path.c_str()) != 0) {
+      fail("cannot rename " + tmp + " to " + path + ": " + strerror(errno));
+      unlink(tmp.c_str());
+      return;
+    }
+    ++written;
   }
   void worker() {
     std::string header;

@@ -64,3 +64,33 @@ def test_errors_surface_at_drain(tmp_path):
     h = C.c_void_p()
     assert lib.tn_npy_writer_create(0, C.byref(h)) != 0
     w.close()
+
+
+def test_a_file_appears_under_its_name_only_when_complete(tmp_path):
+    """the writer publishes a file by renaming a finished temporary, so a failed or interrupted write cannot leave a
+    truncated .npy that the next ``--save_feats`` run would skip as 'exists'.  No temporaries are left behind; a file the writer
+    cannot finish (its temporary cannot be created: the name is taken by a directory) does not appear at all."""
+    rng = np.random.default_rng(7)
+    w = NpyWriter(threads=4)
+    rows = rng.standard_normal((32, 257)).astype(np.float32)
+    paths = [str(tmp_path / "a" / f"{i:03d}.npy") for i in range(32)]
+    w.submit(rows, paths)
+    w.submit(rows, paths)                      # the same files again while the first batch may still be in flight: kept, not rewritten
+    written, skipped = w.drain()
+    assert written + skipped == 64 and written >= 32
+    assert sorted(os.listdir(tmp_path / "a")) == [f"{i:03d}.npy" for i in range(32)]       # no *.tmp.* left
+    for i in (0, 31):
+        np.testing.assert_array_equal(np.load(paths[i]), rows[i])
+    ro = tmp_path / "ro"
+    ro.mkdir()
+    os.chmod(ro, 0o555)
+    try:
+        if os.access(ro, os.W_OK):             # (root ignores the mode bits: nothing to provoke then)
+            return
+        w.submit(rows[:1], [str(ro / "x.npy")])
+        with pytest.raises(RuntimeError):
+            w.drain()
+        assert os.listdir(ro) == []
+    finally:
+        os.chmod(ro, 0o755)
+        w.close()

@@ -275,8 +275,9 @@ def test_full_size_c5_against_the_oracle(cell, report):
     """BASELINE.json config C5 at FULL size (32 clips, T = 214, F = 1024, H = 256, E = 100, V = 254, beam 5, 150 steps) against the numpy
     oracle (4 - 8 s of CPU: the oracle was thought too slow for this until round 4 timed it).  GRU (the reference's flag default):
     every token id of every beam of every clip, every length, scores to 1e-4.  LSTM: the same for the best beam of every clip and
-    for every beam whose rank the oracle decides by more than 1e-4 - on one clip the fourth / fifth beams are a near tie (scores
-    3e-5 apart on the device and in the oracle) that float32 summation order decides; the test names the beam and checks the gap."""
+    for every other beam unless the oracle itself is undecided there at float32 precision (on one clip the fifth beam is a near
+    tie at an intermediate step: the oracle run on float64 copies of its inputs picks the device's hypothesis, the float32 run the
+    other one) - every beam of the device equals one of the oracle's two runs."""
     from tennis_amd import weights as W
     from tennis_amd.engine import GNMTCaptioner
     B, T, F, H, E, V, beam, ml = 32, 214, 1024, 256, 100, 254, 5, 150
@@ -299,14 +300,17 @@ def test_full_size_c5_against_the_oracle(cell, report):
     if cell == "gru":
         assert eq.all()
     else:
-        # No allowance by count.  Ids are exact wherever the ORACLE's own ranking is decided by more than
-        # float32 summation noise: a beam may differ only where the oracle's score of that rank lies within 1e-4 of a
-        # neighbouring rank's (a near tie that the projection's accumulation order decides - gluonnlp's topk has no tie rule to
-        # mirror beyond "larger score first", which both sides implement), and then its score still matches to 1e-4 (above).
-        for b, k in zip(*np.nonzero(~eq.all(axis=2))):
-            gaps = [abs(float(rsc[b, k] - rsc[b, j])) for j in (k - 1, k + 1) if 0 <= j < beam]
-            assert min(gaps) < 1e-4, (int(b), int(k), rsc[b].tolist(), sc[b].tolist())
+        # No allowance by count.  A beam may differ from the oracle only where the ORACLE ITSELF is undecided at
+        # float32 precision: the same oracle fed float64 copies of the parameters and features (its matrix products then
+        # accumulate in double before the cast) ranks one hypothesis of one clip differently from its float32 run - a near tie at
+        # an intermediate step that the projection's accumulation order decides; gluonnlp's topk has no tie rule to mirror beyond
+        # "larger score first", which both sides implement.  Every beam of the device must equal one of the two runs, ids and all.
+        p64 = {k: v.astype(np.float64) for k, v in p.items()}
+        mem64, states64 = gn.encoder(src.astype(np.float64), vl, p64, cell, H)
+        rs64, rsc64, rv64 = gn.beam_search(gn.Decoder(p64, H, cell=cell), mem64, states64, vl, 2, 3, beam=beam, max_length=ml)
+        either = eq.all(axis=2) | (s == rs64).all(axis=2)
         report[f"gnmt_c5_full_size_{cell}_near_tie_beams"] = int((~eq.all(axis=2)).sum())
+        assert either.all(), list(zip(*np.nonzero(~either)))
         assert eq.mean() > 0.999
 
 

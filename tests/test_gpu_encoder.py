@@ -521,3 +521,22 @@ def test_pipelined_forwards_match_joined_ones():
     again = enc(xs[1])
     torch.cuda.synchronize()
     assert torch.equal(again, ref[1])
+
+
+def test_a_nan_batch_does_not_poison_the_next_one():
+    """the streamed 14x14 block reads the 32 channels a layer is about to write as the zero-weighted pad of its last
+    super-step, and those hold whatever the previous forward of the frame slot left there.  With BN1 as a clamp the pad's
+    constants are lo = hi = 0 and v_pk_max_f16(NaN, 0) = 0: a forward whose input was NaN / inf (a corrupt frame handed over as
+    fp32) leaves nothing behind - the next batch through the same encoder gives the bits a fresh encoder gives."""
+    from tennis_amd import weights as W
+    from tennis_amd.engine import DenseNet121Features
+    p = W.make_densenet121_weights(0)
+    good = torch.from_numpy(W.synthetic_frames_u8(4, 224, seed=21)).cuda()
+    want = DenseNet121Features(p, 224, max_batch=4)(good).cpu().numpy()
+    enc = DenseNet121Features(p, 224, max_batch=4)
+    bad = torch.full((4, 3, 224, 224), float("nan"), dtype=torch.float32, device="cuda")
+    bad[1] = float("inf")
+    bad[2] = -60000.0
+    enc(bad)               # (v_pk_max_f16 / v_max_f32 return the non-NaN operand: even these frames' features come out finite)
+    got = enc(good).cpu().numpy()
+    assert np.isfinite(got).all() and np.array_equal(got, want)
