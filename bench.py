@@ -56,6 +56,15 @@ def parity_note():
                "kernels_alone_worst": max(ker.values()), "plain_rounding_worst": max(pl.values())}
         if key in logits:
             out["logit_err_worst"] = max(logits[key].values())
+        wide = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_parity_wide.json")))
+        if wide:       # scripts/parity_wide.py: more frames per family, two weight seeds, the exact-weights mode beside it
+            w = json.load(open(wide[-1]))
+            out["wide"] = {"source": os.path.relpath(wide[-1], ROOT), "frames_per_family": w["frames_per_family"],
+                           "by_weight_seed": {k: {"worst_feature": v["worst_feature"], "worst_logit": v["worst_logit"],
+                                                  "values_over_bar": v["values_over_bar"], "values": sum(r["values"] for r in v["families"].values()),
+                                                  "families_over_bar": sorted(f for f, r in v["families"].items() if r["over_bar"]),
+                                                  "exact_mode_worst_feature": v.get("exact_mode_worst_feature"),
+                                                  "exact_mode_values_over_bar": v.get("exact_mode_values_over_bar")} for k, v in w["weights"].items()}}
         return out
     except Exception as e:
         return {"source": os.path.relpath(files[-1], ROOT), "note": f"{type(e).__name__}: matrix not readable"}
@@ -200,7 +209,7 @@ def build_parser():
     ap.add_argument("--no-pipeline", action="store_true", help="join the encoder's two half-batch streams inside every forward (A/B against the pipelined default)")
     ap.add_argument("--plain-rounding", action="store_true", help="seeded weights that are fp16-representable (rounds 1-2's model) instead of "
                     "the calibrated conversion of fp32 weights")
-    ap.add_argument("--exact-line", action="store_true", help="also time the exact-weights mode in one more fenced region (not part of the default line any more: the timed configuration itself meets the bar)")
+    ap.add_argument("--no-exact-line", action="store_true", help="skip the extra fenced region that times the exact-weights mode (config.exact_weights_frames_per_sec)")
     ap.add_argument("--exact-weights", action="store_true",
                     help="NOT the headline configuration: un-rounded fp32 conv weights evaluated as hi + lo fp16 pairs "
                          "(TN_ENC_EXACT_WEIGHTS), to state what the 1e-3-vs-fp32-weights mode costs")
@@ -292,7 +301,7 @@ def run(argv):
     # parameters - the exact-weights mode (hi + lo fp16 weight pairs: twice the MFMA work of the dense layers and transitions)
     # - on the same box: one more fenced region of exactly K steps with a second encoder
     fps_exact = None
-    if not args.exact_weights and not args.single_region and args.exact_line:
+    if not args.exact_weights and not args.single_region and not args.no_exact_line:
         params_x = params32
         enc_f16 = enc
         enc = DenseNet121Features(params_x, SIZE, max_batch=args.batch, ctx=ctx, exact_weights=True)
@@ -370,7 +379,10 @@ def run(argv):
                           "timing": f"median of {repeats} fenced regions of exactly {args.steps} steps" + (", forwards pipelined (results joined one step behind, all joined before the closing fence)" if pipelined else ""),
                           "region_ms": [round(t * 1e3, 2) for t in times],
                           "frames_per_sec_forwards_joined": (round(world * args.batch * args.steps / dt_joined, 1) if dt_joined else None),
-                          **({"exact_weights_frames_per_sec": round(fps_exact, 1)} if fps_exact else {})},
+                          **({"exact_weights_frames_per_sec": round(fps_exact, 1),
+                              "exact_weights_note": "the SAME fp32 parameters with every conv weight (stem included) as hi + lo fp16 pairs, no calibration: the mode for inputs "
+                                                    "outside anything a calibration set resembles - in the wide evaluation (config.parity.wide) it has no value over the bar where "
+                                                    "the timed configuration has a handful on full-contrast checkerboards of 2-3 px period"} if fps_exact else {})},
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params32, x, full=args.cpu_baseline_full)

@@ -243,7 +243,7 @@ struct tn_encoder {
   int Hb[4], Wb[4];        // dense block spatial sizes
   int Cin[4], Cb[4];       // block input / total channels
   int PH, PW;
-  f16 *stem_wp, *stem_wp_zf;
+  f16 *stem_wp, *stem_wp_zf, *stem_wp_zf_lo = nullptr;
   float *stem_scale, *stem_shift, *stem_shift_u8;
   struct DenseLayer { float *s1, *t1; f16 *w1; float *s2, *t2; f16 *w3p; int cin; f16 *w1s = nullptr, *w3s = nullptr; };   // w1s / w3s: fragment images of the strip kernel
   std::vector<DenseLayer> layers[4];
@@ -359,6 +359,21 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
     }
     e->stem_wp = e->pool.upload(pack_stem(w0s.data(), false));
     e->stem_wp_zf = e->pool.upload(pack_stem(w0s.data(), true));
+    if (e->exact) {     // w = hi + lo: the second fragment image (the constant of the integer staging then uses hi + lo as well)
+      std::vector<float> lo(w0s.size());
+      for (int n = 0; n < 64; ++n) {
+        double bias = 0.0;
+        for (int c = 0; c < 3; ++c)
+          for (int k = 0; k < 49; ++k) {
+            const size_t i = ((size_t)n * 3 + c) * 49 + k;
+            const float hi = (float)(f16)w0s[i];
+            lo[i] = w0s[i] - hi;
+            bias -= ((double)hi + (double)(float)(f16)lo[i]) * stem_pad(c);
+          }
+        tu[n] = (float)((double)t[n] + (double)s[n] * bias);
+      }
+      e->stem_wp_zf_lo = e->pool.upload(pack_stem(lo.data(), true));
+    }
     e->stem_scale = e->pool.upload(s);
     e->stem_shift = e->pool.upload(t);
     e->stem_shift_u8 = e->pool.upload(tu);
@@ -529,6 +544,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
   {
     StemArgs a{x, (int)layout, B, e->H, e->W, e->stem_wp, e->stem_wp_zf, e->stem_scale, e->stem_shift, stem_out, e->Hs, e->Ws};
     a.shift_u8 = e->stem_shift_u8;
+    a.wp_zf_lo = e->stem_wp_zf_lo;
     const double px = fB * e->Hs * e->Ws;
     if (e->fuse) {
       tm.begin("stem_conv_bn_relu_maxpool", 2.0 * px * 64 * 147, fB * e->H * e->W * 3 * 2 + fB * e->Hb[0] * e->Wb[0] * 64 * 2);

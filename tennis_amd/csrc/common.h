@@ -288,6 +288,7 @@ struct StemArgs {
   f16 *y;             // [B][Ho][Wo][64]
   int Ho, Wo;
   const float *shift_u8 = nullptr;   // the shift for TN_LAYOUT_NHWC_U8 input (carries the constant of the integer staging, see above)
+  const f16 *wp_zf_lo = nullptr;     // exact-weights mode: the lo halves of the weights (w = hi + lo), same fragment layout as wp_zf
 };
 int launch_stem(const StemArgs &a, hipStream_t s);
 // fused stem + maxpool: writes the pooled map (Hp x Wp x 64) at row stride ldy

@@ -113,9 +113,11 @@ struct Tile { int b, pr0, pc0; };
 
 // VEC (frame width a multiple of 8): the patch is fetched as aligned groups of 8 pixels per thread with
 // 16-byte (fp16 / f32) or 8-byte (u8) loads instead of one element per load.
-template <int LAY, bool VEC>
+// EXW (exact-weights mode, TN_ENC_EXACT_WEIGHTS): conv0's weights as hi + lo fp16 pairs, every MFMA issued twice (round 5: with the
+// stem's weights plainly rounded the mode measured 2.3e-3 on near-white frames - all 147 taps see the same large operand)
+template <int LAY, bool VEC, bool EXW = false>
 // three waves per SIMD where the staging registers allow it (fp16 / u8 vector path), two otherwise
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY != TN_LAYOUT_NCHW_F32) ? 3 : 2))) void stem_pool_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY != TN_LAYOUT_NCHW_F32 && !EXW) ? 3 : 2))) void stem_pool_kernel(
     StemArgs a, f16 *__restrict__ out, int ldy, int Hp, int Wp, int nstrip, int ntc, int ntiles) {
   __shared__ __attribute__((aligned(16))) unsigned char patch[IR * IPITCH];
   __shared__ __attribute__((aligned(16))) unsigned char vtile[PR * CC * CPX];
@@ -139,6 +141,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
   for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf) wa[ky][nf] = ((const f16x8 *)a.wp_zf)[(ky * 4 + 2 * nh + nf) * 64 + lane];
+  [[maybe_unused]] f16x8 wl[EXW ? 7 : 1][2];
+  if constexpr (EXW) {
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf) wl[ky][nf] = ((const f16x8 *)a.wp_zf_lo)[(ky * 4 + 2 * nh + nf) * 64 + lane];
+  }
   float sc[2][4], sh[2][4];
 #pragma unroll
   for (int nf = 0; nf < 2; ++nf)
@@ -383,7 +392,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
           const int ky = p - 2 * r;
           if (ky >= 0 && ky < 7) {
 #pragma unroll
-            for (int nf = 0; nf < 2; ++nf) acc[r][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ky][nf], xb[p % 3], acc[r][nf], 0, 0, 0);
+            for (int nf = 0; nf < 2; ++nf) {
+              acc[r][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ky][nf], xb[p % 3], acc[r][nf], 0, 0, 0);
+              if constexpr (EXW) acc[r][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ky][nf], xb[p % 3], acc[r][nf], 0, 0, 0);
+            }
           }
         }
         // the two channel fragments of a finished row go one and two patch rows later, between the MFMAs in flight
@@ -455,7 +467,9 @@ int launch_stem_pool(const StemArgs &a, f16 *out, int ldy, int Hp, int Wp, hipSt
   const dim3 grid(ntiles < slots ? ntiles : slots), block(256);   // persistent: a workgroup walks a contiguous range of tiles
   static const bool novec = getenv("TN_STEM_NOVEC") != nullptr;   // tuning hook
   const bool vec = (a.W % 8 == 0) && a.W >= 80 && !novec;
-#define TN_STEM(L) do { if (vec) hipLaunchKernelGGL((stem_pool_kernel<L, true>), grid, block, 0, s, a, out, ldy, Hp, Wp, nstrip, ntc, ntiles); \
+#define TN_STEM(L) do { if (a.wp_zf_lo) { if (vec) hipLaunchKernelGGL((stem_pool_kernel<L, true, true>), grid, block, 0, s, a, out, ldy, Hp, Wp, nstrip, ntc, ntiles); \
+                                            else hipLaunchKernelGGL((stem_pool_kernel<L, false, true>), grid, block, 0, s, a, out, ldy, Hp, Wp, nstrip, ntc, ntiles); } \
+                        else if (vec) hipLaunchKernelGGL((stem_pool_kernel<L, true>), grid, block, 0, s, a, out, ldy, Hp, Wp, nstrip, ntc, ntiles); \
                         else hipLaunchKernelGGL((stem_pool_kernel<L, false>), grid, block, 0, s, a, out, ldy, Hp, Wp, nstrip, ntc, ntiles); } while (0)
   if (a.layout == TN_LAYOUT_NCHW_F32) TN_STEM(TN_LAYOUT_NCHW_F32);
   else if (a.layout == TN_LAYOUT_NHWC_F16) TN_STEM(TN_LAYOUT_NHWC_F16);

@@ -108,10 +108,12 @@ def test_calibration_matrix(world, report):
     report["kernels_alone_worst_family_err"] = max(kern.values())
     report["exact_mode_worst_family_err"] = max(matrix["exact-weights mode (hi + lo pairs)"].values())
     # THE bar (north_star: features / logits within 1e-3 of the fp32 reference), on every family, held-out ones included
+    exact = matrix["exact-weights mode (hi + lo pairs)"]
     for f in world["fams"]:
         assert default[f] < 1e-3, (f, default[f])
         assert dlog[f] < 1e-3, (f, dlog[f])
         assert kern[f] < 1e-3, (f, kern[f])
+        assert exact[f] < 1e-3, (f, exact[f])       # (round 5: the mode's stem weights are hi + lo as well; 2.3e-3 on "bright" before)
     assert max(default.values()) < 0.3 * max(plain.values()) and all(default[f] < plain[f] for f in world["fams"]), (default, plain)
     # and the set matters: one family of calibration frames leaves the others outside (the round-3 hole, now measured)
     assert max(matrix["round 3: mean of 8 noise frames"].values()) > 1.5 * max(default.values())
