@@ -106,7 +106,10 @@ int tn_densenet121_join(tn_encoder *enc, int lag);
 /* Calibration statistics for the calibrated fp16 conversion (tennis_amd/weights.py::as_fp16_model(input_means=...)):
  * `batch` frames go through the layer-wise kernels, and for each of the 119 convolutions behind the stem, in execution order
  * (per dense layer the 1x1's K input channels, then the 3x3's 128; a transition's inputs after its block), the mean over all
- * pixels of the activation that convolution reads is written to means_host (fp32, *numel values). */
+ * pixels of the OPERAND that convolution's folded weights multiply is written to means_host (fp32, *numel values): for a dense
+ * layer's 1x1 the clamped stored activation clamp(x, lo, hi) (tn_bn_relu_clamp_fold; relu(bn(x)) = sw * that + tc), for its 3x3
+ * the ReLU'd bottleneck, for a transition relu(bn(x)).  (The stem's operand mean, x - 255 mean_c, is a property of the frame and
+ * is computed by the caller.) */
 int tn_densenet121_input_means(tn_encoder *enc, const void *x, tn_layout layout, int batch, float *means_host,
                                int64_t capacity, int64_t *numel);
 /* Host side of that conversion (no GPU involved; csrc/calib_host.hip): w (N, K) fp32 -> out (N, K), every entry one of the two
