@@ -737,3 +737,46 @@ def test_vector_feedback_rounding_library_vs_numpy():
     ybar = sw1.astype(np.float64) * np.abs(np.random.default_rng(11).normal(0.5, 0.2, (6, p[name].shape[1]))).mean(0) + tc1
     want = (q2[name].astype(np.float64) - p[name]).sum((2, 3)) @ ybar
     assert np.allclose(q2[rm].astype(np.float64) - p[rm], want, rtol=1e-3, atol=1e-7)
+
+
+def test_bias_correction_reaches_exactly_the_consumers_of_a_channel():
+    """weights._apply_bias_correction (round 5): the mean conversion error of a convolution's output channels is added to the
+    running mean of EVERY BatchNorm that reads those channels and of no other - DenseNet's concat topology (reference call site
+    models/vision/definitions.py:30 -> gluoncv DenseNet: a dense layer's 32 new channels are read by every later layer of its block
+    and by the block's closing BatchNorm; a transition's outputs by every layer of the next block and its closing BatchNorm; a 1x1
+    by the BatchNorm behind it; the stem by batchnorm0)."""
+    from tennis_amd import weights as W
+    p = W.make_densenet121_weights(2, fp16_model=False)
+    pre = "densenet0_"
+
+    def changed(bias):
+        out = dict(p)
+        W._apply_bias_correction(out, bias, pre)
+        ch = {}
+        for k in p:
+            if k.endswith("_running_mean") and not np.array_equal(out[k], p[k]):
+                idx = np.nonzero(out[k] != p[k])[0]
+                ch[k[len(pre):-len("_running_mean")]] = (int(idx[0]), int(idx[-1]) + 1, out[k][idx] - p[k][idx])
+        return ch
+    # the 3x3 of layer 2 in block 2 (K0 = 128): channels [128 + 64, 128 + 96) of the block's buffer
+    b = np.linspace(0.01, 0.32, 32)
+    ch = changed({pre + "stage2_conv5_weight": b})
+    want = {f"stage2_batchnorm{2 * l}" for l in range(3, 12)} | {"batchnorm2"}
+    assert set(ch) == want
+    for lo, hi, d in ch.values():
+        assert (lo, hi) == (192, 224) and np.allclose(d, b, rtol=1e-5)
+    # a 1x1: the BatchNorm behind it only
+    ch = changed({pre + "stage3_conv10_weight": np.full(128, 0.5)})
+    assert set(ch) == {"stage3_batchnorm11"} and ch["stage3_batchnorm11"][:2] == (0, 128)
+    # transition 2 (conv2: 512 -> 256): every BN1 of block 3 and the block's closing BatchNorm, channels [0, 256)
+    ch = changed({pre + "conv2_weight": np.full(256, -0.25)})
+    assert set(ch) == {f"stage3_batchnorm{2 * l}" for l in range(24)} | {"batchnorm3"}
+    assert all(v[:2] == (0, 256) for v in ch.values())
+    # the last block closes with the head's BatchNorm; the stem feeds batchnorm0 (the stem's own BatchNorm) only
+    ch = changed({pre + "stage4_conv31_weight": np.full(32, 1.0)})
+    assert set(ch) == {"batchnorm4"} and ch["batchnorm4"][:2] == (512 + 15 * 32, 1024)
+    ch = changed({pre + "conv0_weight": np.full(64, 1.0)})
+    assert set(ch) == {"batchnorm0"}
+    # and through as_fp16_model: no 2-D means, no correction (the plain conversion of rounds 1 - 4 is unchanged)
+    q = W.as_fp16_model(p)
+    assert all(np.array_equal(q[k], p[k]) for k in p if k.endswith("_running_mean"))
