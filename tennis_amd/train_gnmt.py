@@ -202,9 +202,19 @@ def main(argv=None):
     from .captions import write_sentences
     write_sentences(data_val.get_captions(split=True), os.path.join(save_dir, "val_gt.txt"))         # train_gnmt.py:205-208
     write_sentences(data_test.get_captions(split=True), os.path.join(save_dir, "test_gt.txt"))
+    # resume (train_gnmt.py:232-244): the newest NNNN.params of the model id, valid_best.params aside
+    start_epoch = 0
+    files = sorted((f for f in os.listdir(save_dir) if f.endswith(".params") and f != "valid_best.params"), reverse=True)
+    if files:
+        start_epoch = int(files[0].split(".")[0]) + 1
+        model.load_parameters(os.path.join(save_dir, files[0]))
+        print("Loaded model params: {}".format(os.path.join(save_dir, files[0])))
     hist = train(data_train, data_val, data_test, model, translator, flags.epochs, flags.batch_size, lr=flags.lr,
                  lr_update_factor=flags.lr_update_factor, dropout=flags.dropout, num_buckets=flags.num_buckets,
-                 test_batch_size=flags.test_batch_size, save_dir=save_dir)
+                 test_batch_size=flags.test_batch_size, start_epoch=start_epoch, save_dir=save_dir)
+    if not hist:
+        print("[Finished] nothing to do: {} epochs are on disk".format(start_epoch))
+        return 0
     print("[Finished] best valid bleu={:.2f}".format(100 * max(h.get("valid_bleu", 0.0) for h in hist)))
     return 0
 

@@ -188,6 +188,9 @@ def test_captioning_pipeline_from_disk_through_the_drivers(tmp_path, report):
     files = sorted(os.listdir(os.path.join(exp, "cap1")))
     assert {"0000.params", "0002.params", "val_gt.txt", "test_gt.txt", "epoch0_valid_out.txt", "epoch2_test_out.txt"} <= set(files), files
     assert open(os.path.join(exp, "cap1", "test_gt.txt")).read().split("\n")[:2] == td.CAPTIONS["test"]
+    # a second call resumes behind the newest epoch file (train_gnmt.py:232-244): one more epoch, not three
+    assert tg.main(common + ["--epochs", "4", "--batch_size", "2", "--dropout", "0.0", "--lr", "0.01"]) == 0
+    assert "0003.params" in os.listdir(os.path.join(exp, "cap1")) and "epoch3_test_out.txt" in os.listdir(os.path.join(exp, "cap1"))
     out = eg.main(common)
     assert set(out) == {"valid", "test"} and all(np.isfinite(l) and 0.0 <= bl <= 1.0 for l, bl in out.values())
     assert open(os.path.join(exp, "cap1", "best_test_out.txt")).read().count("\n") == 2       # one line per test point (a barely trained model may emit <eos> at once)
