@@ -57,7 +57,7 @@ def parity_note():
         if key in logits:
             out["logit_err_worst"] = max(logits[key].values())
         wide = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_parity_wide.json")))
-        if wide:       # scripts/parity_wide.py: more frames per family, two weight seeds, the exact-weights mode beside it
+        if wide:       # tests/tools/parity_wide.py: more frames per family, two weight seeds, the exact-weights mode beside it
             w = json.load(open(wide[-1]))
             out["wide"] = {"source": os.path.relpath(wide[-1], ROOT), "frames_per_family": w["frames_per_family"],
                            "by_weight_seed": {k: {"worst_feature": v["worst_feature"], "worst_logit": v["worst_logit"],

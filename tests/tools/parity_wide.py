@@ -1,9 +1,10 @@
-"""The parity of the timed configuration on MORE frames than tests/test_gpu_calibration.py looks at (round 5): `--frames` frames
+"""(test infrastructure: imports oracle/, like everything under tests/)  The parity of the timed configuration on MORE frames than tests/test_gpu_calibration.py looks at (round 5): `--frames` frames
 of each of the 16 families (other seeds than the test's and the calibration set's), features and Dense(11) logits of the default
 calibrated conversion against the fp32 oracle (oracle/torch_ref.py) on the un-rounded weights and un-rounded input; also a second
-weight seed.  Writes gpurun_out/parity_wide.json.     python scripts/parity_wide.py [--frames 8]"""
+weight seed.  Writes gpurun_out/parity_wide.json.     python tests/tools/parity_wide.py [--frames 8]"""
 import argparse, json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 import numpy as np, torch
 from oracle.torch_ref import TorchDenseNet121
 from tennis_amd import calib_frames as CF, weights as W
@@ -11,7 +12,7 @@ from tennis_amd.calibrate import calibrated_fp16_model
 from tennis_amd.engine import DenseNet121Features
 
 ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=8); a = ap.parse_args()
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from test_gpu_calibration import _jpeg_frames
 torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
 out = {"frames_per_family": a.frames, "bar": 1e-3, "weights": {}}
