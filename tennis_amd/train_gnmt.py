@@ -139,6 +139,18 @@ def build_parser():
     p.add_argument("--data_root", default=None, help="the dataset directory (the reference's 'data': splits/, annotations/, features/, "
                    "the embedding file); without it the captions and features are synthetic")
     p.add_argument("--split_id", default="02")
+    # the reference's remaining flags (train_gnmt.py:48-118), accepted so that its documented command lines run unchanged, e.g.
+    # `python evaluate_gnmt.py --model_id 0102 --num_hidden 256 --backbone_from_id 0006 --feats_model 0006` (models/README.md:68)
+    p.add_argument("--bucket_scheme", default="constant", choices=["constant"], help="bucket widths (only the reference's default is built)")
+    p.add_argument("--bucket_ratio", type=float, default=0.0)
+    p.add_argument("--optimizer", default="adam", choices=["adam"])
+    p.add_argument("--clip", type=float, default=5.0, help="accepted; the reference defines the flag and never applies it (train_gnmt.py:305-470)")
+    p.add_argument("--log_interval", type=int, default=100)
+    p.add_argument("--num_gpus", type=int, default=1, help="the reference's captioner is single-GPU (train_gnmt.py:126-127); data parallelism here comes from torch.distributed")
+    p.add_argument("--backbone", default="DenseNet121")
+    p.add_argument("--backbone_from_id", default=None, help="frame mode only (the CNN inside the model); ignored with --feats_model, as in the reference")
+    p.add_argument("--freeze_backbone", action="store_true")
+    p.add_argument("--data_shape", type=int, default=512)
     p.add_argument("--feature_dim", type=int, default=1024, help="width of the pre-extracted frame features (feats_model)")
     p.add_argument("--n_points", type=int, default=64, help="synthetic source: points per split")
     p.add_argument("--root", default="models/captioning/experiments")
@@ -170,6 +182,8 @@ def build(flags):
     from .dataset import TennisSet
     from .models.captioning.gnmt import NMTModel, get_gnmt_encoder_decoder
     from .utils.translation import BeamSearchScorer, BeamSearchTranslator
+    if flags.data_root is None and flags.feats_model is not None and os.path.isdir(os.path.join("data", "splits")):
+        flags.data_root = "data"           # the reference's layout relative to the working directory (dataset.py:17: root='data')
     if flags.data_root is not None and flags.feats_model is None:
         raise NotImplementedError("train_gnmt on raw frames (no --feats_model) needs the frames of every point on disk and the backbone "
                                   "inside the step; the accelerated path is the reference's feature mode (evaluate --save_feats first)")
