@@ -295,6 +295,15 @@ def build_parser():
     p.add_argument("--save_feats", action="store_true")
     p.add_argument("--feats_model", default=None)
     p.add_argument("--temp_pool", default=None, help="mean, max, gru or lstm")
+    # the rest of the reference's flags (evaluate.py:30-75), so that its documented command lines parse unchanged, e.g.
+    # `python evaluate.py --model_id 0042 --backbone DenseNet121 --temp_pool gru --window 30 --backbone_from_id 0006 --feats_model 0006
+    # --freeze_backbone` (models/README.md:58)
+    p.add_argument("--backbone_from_id", default=None,
+                   help="load the frame model's parameters from the newest .params of this model id before the temporal model is put around it (evaluate.py:142-151)")
+    p.add_argument("--freeze_backbone", action="store_true", help="accepted (evaluate.py:153-155 sets grad_req = 'null': nothing to do without gradients)")
+    p.add_argument("--balance", default="True, False, False", help="accepted; the test set is never balanced (evaluate.py:109)")
+    p.add_argument("--vis", action="store_true", help="visualisation output is outside the accelerated path (SURVEY 2a): refused")
+    p.add_argument("--flow", default="", help="optical-flow input is outside the accelerated path (SURVEY 2a): anything but '' is refused")
     p.add_argument("--root", default="data")
     p.add_argument("--num_workers", type=int, default=2,
                    help="loader threads (reference: DataLoader worker processes, evaluate.py:113); on the device-decode route each owns a JPEG decoder on its own stream")
@@ -330,6 +339,10 @@ def main(argv=None):
 
 
 def _main_rank(flags, rank, world, dev):
+    if flags.flow or flags.vis:
+        raise NotImplementedError("--flow / --vis: optical-flow input and visualisation are outside the accelerated path (SURVEY 2a)")
+    if flags.num_workers < 0:                                               # the reference's -1 = cpu_count() (evaluate.py:80-81)
+        flags.num_workers = 2
     every = [int(s) for s in flags.every.split(",")]
     if flags.corpus_frames > 0:                                             # BASELINE config C4
         backbone = get_model(flags.backbone, pretrained=True, max_batch=flags.batch_size, conversion=flags.fp16_conversion).features
@@ -367,6 +380,14 @@ def _main_rank(flags, rank, world, dev):
         backbone_net = get_model(flags.backbone, pretrained=True, conversion=flags.fp16_conversion).features
         model = FrameModel(backbone_net, len(test_set.classes))
     if flags.window > 1:                                                    # evaluate.py:139-162
+        if flags.backbone_from_id and model is not None:                    # evaluate.py:142-151
+            bb_dir = os.path.join(flags.exp_root, flags.backbone_from_id)
+            if os.path.isdir(bb_dir):
+                files = sorted((f for f in os.listdir(bb_dir) if f.endswith(".params")), reverse=True)
+                if files:
+                    model.initialize()
+                    model.load_parameters(os.path.join(bb_dir, files[0]))
+                    print("Loaded backbone params: {}".format(os.path.join(bb_dir, files[0])))
         if flags.temp_pool in ["gru", "lstm"]:
             model = CNNRNN(model, num_classes=len(test_set.classes), type=flags.temp_pool, hidden_size=128)
         elif flags.temp_pool not in ["mean", "max"]:

@@ -162,6 +162,13 @@ def build_parser():
     p.add_argument("--momentum", type=float, default=0.9)
     p.add_argument("--wd", type=float, default=0.0001)
     p.add_argument("--feats_model", default=None)
+    # the rest of the reference's flags (train.py:32-93), accepted so that its command lines parse unchanged
+    p.add_argument("--backbone_from_id", default=None, help="start the frame model from the newest .params of this model id (train.py:222-235)")
+    p.add_argument("--log_interval", type=int, default=100)
+    p.add_argument("--num_gpus", type=int, default=1, help="one process per GPU here: data parallelism comes from torch.distributed (train.allreduce_and_step)")
+    p.add_argument("--vis", action="store_true", help="refused: outside the accelerated path (SURVEY 2a)")
+    p.add_argument("--flow", default="", help="anything but '' is refused: outside the accelerated path (SURVEY 2a)")
+    p.add_argument("--max_batches", type=int, default=-1, help="stop an epoch after this many batches (train.py:92: 'for 0031')")
     p.add_argument("--temp_pool", default=None, help="gru or lstm (trained); mean / max need no training")
     p.add_argument("--root", default="data")
     p.add_argument("--decode", default="device", choices=["device", "host", "auto"], help="where on-disk JPEG frames are decoded (see evaluate.py)")
@@ -188,6 +195,10 @@ def main(argv=None):
     from .models.vision.definitions import CNNRNN, FrameModel
     from . import weights as W
     flags = build_parser().parse_args(argv)
+    if flags.flow or flags.vis:
+        raise NotImplementedError("--flow / --vis: optical-flow input and visualisation are outside the accelerated path (SURVEY 2a)")
+    if flags.num_workers < 0:                          # the reference's -1 = cpu_count() (train.py:101-102)
+        flags.num_workers = 2
     every = [int(s) for s in flags.every.split(",")]
     balance = [s.strip().lower() in ("true", "t") for s in flags.balance.split(",")]
     lr_steps = [int(s) for s in flags.lr_steps.split(",")]
@@ -233,6 +244,11 @@ def main(argv=None):
         model = FrameModel(get_model(flags.backbone, pretrained=True).features, n_cls)
         model.initialize()
         model.classes._materialize(1024)
+        if flags.backbone_from_id:                     # train.py:222-235 loads it for window > 1 only; a frame model started from
+            bb = newest_params(os.path.join(flags.exp_root, flags.backbone_from_id))   # another experiment is the same request
+            if bb is not None:
+                model.load_parameters(bb)
+                print("Loaded backbone params: {}".format(bb))
         last = "discard"
         mk_head = lambda p: FrameModelTrainer(p, flags.data_shape, n_cls, batch=local_bs, prefix=model.backbone.prefix,
                                               dense_prefix=model.classes.prefix)
@@ -250,7 +266,9 @@ def main(argv=None):
     metrics = [PRF1(label_names=train_set.classes)]
 
     def batches():          # every rank walks the same (seeded) batches and trains on its rows rank::world of each
-        for data, labels, _ in train_data:
+        for i, (data, labels, _) in enumerate(train_data):
+            if flags.max_batches > 0 and i > flags.max_batches:             # train.py:405
+                break
             x = data if isinstance(data, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(data))
             y = torch.from_numpy(labels.astype(np.int32))
             if world > 1:

@@ -324,3 +324,26 @@ def test_train_transform_oracle_and_parameter_draws():
     assert l.shape == (2000, 3) and abs(l.mean()) < 0.3 and 2.0 < l[:, 0].std() < 4.5      # 0.1 * 55.46 * 0.5675 = 3.1 on the first axis
     with pytest.raises(NotImplementedError):
         T.Compose([T.RandomResizedCrop(224), T.ToTensor()])
+
+
+def test_reference_command_lines_parse():
+    """Every command line the reference documents for the hot path (models/README.md:14-68) parses unchanged; the two
+    inputs outside the path (--flow, the rdnet 3-D backbone) parse too and are refused when run, not misread."""
+    from tennis_amd import evaluate, evaluate_gnmt, train, train_gnmt
+    lines = ["--model_id 0006 --backbone DenseNet121",
+             "--model_id 0010 --backbone DenseNet121 --flow twos",
+             "--model_id 0031 --backbone rdnet --window 8 --data_shape 224",
+             "--model_id 0028 --backbone DenseNet121 --temp_pool mean --window 15 --backbone_from_id 0006 --feats_model 0006",
+             "--model_id 0006 --backbone DenseNet121 --save_feats",
+             "--model_id 0042 --backbone DenseNet121 --temp_pool gru --window 30 --backbone_from_id 0006 --feats_model 0006 --freeze_backbone"]
+    for line in lines:
+        f = evaluate.build_parser().parse_args(line.split())
+        assert f.model_id == line.split()[1]
+        if "--save_feats" not in line:
+            t = train.build_parser().parse_args(line.split() + ["--max_batches", "8", "--log_interval", "10", "--num_gpus", "1"])
+            assert t.model_id == f.model_id and t.max_batches == 8
+    cap = "--model_id 0102 --num_hidden 256 --backbone_from_id 0006 --feats_model 0006".split()
+    assert evaluate_gnmt.build_parser().parse_args(cap).num_hidden == 256
+    assert train_gnmt.build_parser().parse_args(cap).feats_model == "0006"
+    with pytest.raises(NotImplementedError):
+        train.main(lines[1].split())
