@@ -97,7 +97,10 @@ struct SubRec { uint32_t pos; uint16_t state; uint16_t in_state; uint32_t nblk; 
 // them is FF; pn is the next byte to load, nb the unread bits buffered.  The exact position of the next symbol - the
 // data byte that holds its first bit - is only worked out (walking back over the buffered bytes) once pn has passed
 // the end of the subsequence.
-template <bool WRITE>
+// UNST: the segment's bytes have been through jpeg_unstuff_kernel - no FF 00 pairs left, the position of a bit is arithmetic and a
+// refill is one unaligned dword (the stuffed form's reader takes a byte-wise path whenever ONE lane of the wave has an FF among its
+// next four bytes, and keeps a mask of the buffered stuffed bytes to know where a symbol starts).
+template <bool WRITE, bool UNST>
 __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint32_t cb, uint32_t sub_end, int slot, int k,
                                              const Geom &g, const FrameDev &f, const uint16_t *__restrict__ luts,
                                              const uint16_t *__restrict__ fast, const uint16_t *sh_fast, bool in_lds,
@@ -131,9 +134,22 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
   uint32_t nx = 0;
   auto fetch = [&]() {
     if (pn + 4 <= rd.end) __builtin_memcpy(&nx, rd.s + pn, 4);
+    else if (UNST) {              // the segment's last bytes: zeros behind the end, as Reader::ld reads them
+      nx = 0;
+      for (uint32_t i = 0; i < 4; ++i) nx |= rd.ld(pn + i) << (8 * i);
+    }
   };
   fetch();
   auto refill = [&]() {
+    if constexpr (UNST) {
+      if (nb <= 32) {
+        buf |= (uint64_t)__builtin_bswap32(nx) << (32 - nb);
+        nb += 32;
+        pn += 4;
+        fetch();
+      }
+      return;
+    }
     while (nb <= 32) {
       const bool have4 = pn + 4 <= rd.end;
       if (have4) {
@@ -157,6 +173,7 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
     }
   };
   auto consume = [&](int nbits) {      // drop nbits from the top of the buffer
+    if constexpr (UNST) { buf <<= nbits; nb -= nbits; return; }
     const int before = (nb + 7) >> 3;
     buf <<= nbits;
     nb -= nbits;
@@ -165,8 +182,10 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
     sm >>= c;
   };
   refill();
+  if constexpr (UNST) refill();      // (64 bits buffered, as the stuffed form's loop leaves them)
   consume((int)cb);
   for (;;) {
+    if constexpr (UNST) pb = (pn * 8u - (uint32_t)nb) >> 3;      // the byte that holds the first unread bit
     if (pb >= stop) break;
     if (WRITE && first_block + nblk >= max_blocks) break;     // the rest of the segment is padding
     if (nb < 32) refill();
@@ -223,6 +242,7 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
     nblk += block_end ? 1u : 0u;
     consume(nbits);           // <= 27 bits, nb >= 32
   }
+  if constexpr (UNST) pb = (pn * 8u - (uint32_t)nb) >> 3;
   cp = pb;
   cb = (8u - ((uint32_t)nb & 7u)) & 7u;
   if (WRITE && own) {      // the last block began here and ends in the next subsequence: its values so far, one by one
@@ -259,10 +279,131 @@ __device__ __forceinline__ int find_seg(const Seg *__restrict__ segs, int nseg, 
   return lo;
 }
 
+// ------------------------------------------------------------------------------------------------ un-stuffing (round 5)
+// FF 00 -> FF over every segment, in three launches: (1) one thread per 256 input bytes counts the bytes it keeps (a 00 goes iff the
+// byte before it is FF - the pairs cannot overlap); (2) exclusive sum of the counts inside each segment (jpeg_block_scan_kernel's
+// loop); (3) the same threads write their kept bytes behind each other, from the segment's own first byte on - the un-stuffed
+// segment is shorter than the stuffed one, so the copy keeps the batch buffer's layout and a segment's subsequences (counted from
+// the stuffed length) cover it with room to spare; the new end goes into a second Seg array, which the decode kernels read.
+// 0x80 in every byte of x that is zero (exact: no borrow between bytes)
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t x) {
+  const uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+  return ~(t | x | 0x7F7F7F7Fu);
+}
+// flags (0x80 per byte) of the stuffed zeros among the four bytes of x; ff = 0x80 if the byte before x is an FF (updated)
+__device__ __forceinline__ uint32_t stuffed_bytes(uint32_t x, uint32_t &ff) {
+  const uint32_t isff = zero_bytes(~x);
+  const uint32_t st = zero_bytes(x) & ((isff << 8) | ff);
+  ff = (isff >> 24) & 0x80u;
+  return st;
+}
+// sixteen lanes per 256-byte subsequence, 16 bytes each: a wave reads 1 KiB of the stream per instruction.  (One thread per
+// subsequence walking its 256 bytes touched 64 lines per load: 0.15 + 0.49 ms per 256 frames for the two kernels, most of what
+// the un-stuffed reader saves.)
+constexpr int UL = SUBSEQ / 16;      // lanes per subsequence in the un-stuffing kernels (a power of two, 4 .. 64)
+static_assert(UL >= 4 && UL <= 64 && (UL & (UL - 1)) == 0, "TN_JPEG_SUBSEQ");
+struct UnstLane { uint32_t x[4]; uint32_t st[4]; uint32_t n; bool live; };
+__device__ __forceinline__ UnstLane unstuff_lane(const uint8_t *__restrict__ s, const Seg &sg, uint32_t sub, uint32_t part) {
+  UnstLane r;
+  r.n = 0;
+  const uint32_t p0 = sg.byte_start + (sub - sg.first_sub) * SUBSEQ + part * 16u;
+  r.live = p0 < sg.byte_end;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { r.x[i] = 0; r.st[i] = 0; }
+  if (!r.live) return r;
+  uint32_t ff = (p0 > sg.byte_start && s[p0 - 1] == 0xFFu) ? 0x80u : 0u;
+  if (p0 + 16 <= sg.byte_end) {
+    __builtin_memcpy(r.x, s + p0, 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      r.st[i] = stuffed_bytes(r.x[i], ff);
+      r.n += 4u - (uint32_t)__builtin_popcount(r.st[i]);
+    }
+  } else {                         // the segment's last bytes: what lies behind the end counts as stuffed (= not kept)
+    for (uint32_t q = 0; q < 16; ++q) {
+      const uint32_t p = p0 + q;
+      const uint32_t b = p < sg.byte_end ? s[p] : 0u;
+      const bool drop = p >= sg.byte_end || (b == 0u && ff);
+      r.x[q >> 2] |= b << (8 * (q & 3));
+      r.st[q >> 2] |= drop ? 0x80u << (8 * (q & 3)) : 0u;
+      r.n += drop ? 0u : 1u;
+      ff = b == 0xFFu ? 0x80u : 0u;
+    }
+  }
+  return r;
+}
+__global__ __launch_bounds__(256) void jpeg_unstuff_count_kernel(const uint8_t *__restrict__ scan, const FrameDev *__restrict__ frames,
+                                                                 const Seg *__restrict__ segs, int nseg, uint32_t total_sub, uint32_t *__restrict__ kept) {
+  const uint32_t gid = blockIdx.x * 256u + threadIdx.x, sub = gid / UL, part = gid % UL;
+  uint32_t n = 0;
+  if (sub < total_sub) {
+    const Seg sg = segs[find_seg(segs, nseg, sub)];
+    n = unstuff_lane(scan + frames[sg.frame].scan_off, sg, sub, part).n;
+  }
+#pragma unroll
+  for (int d = 1; d < UL; d <<= 1) n += __shfl_xor(n, d, UL);
+  if (sub < total_sub && part == 0) kept[sub] = n;
+}
+// exclusive sum of kept[] inside each segment (one workgroup per segment) and the segment with its new end
+__global__ __launch_bounds__(256) void jpeg_unstuff_scan_kernel(const Seg *__restrict__ segs, const uint32_t *__restrict__ kept,
+                                                                uint32_t *__restrict__ base, Seg *__restrict__ segs_out) {
+  __shared__ uint32_t sh[256];
+  const Seg sg = segs[blockIdx.x];
+  uint32_t carry = 0;
+  for (uint32_t c0 = 0; c0 < sg.nsub; c0 += 256) {
+    const uint32_t i = c0 + threadIdx.x;
+    const uint32_t v = i < sg.nsub ? kept[sg.first_sub + i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      const uint32_t a = threadIdx.x >= (unsigned)d ? sh[threadIdx.x - d] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += a;
+      __syncthreads();
+    }
+    if (i < sg.nsub) base[sg.first_sub + i] = carry + sh[threadIdx.x] - v;
+    carry += sh[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    Seg r = sg;
+    r.byte_end = sg.byte_start + carry;
+    segs_out[blockIdx.x] = r;
+  }
+}
+__global__ __launch_bounds__(256) void jpeg_unstuff_write_kernel(const uint8_t *__restrict__ scan, const FrameDev *__restrict__ frames,
+                                                                 const Seg *__restrict__ segs, int nseg, uint32_t total_sub,
+                                                                 const uint32_t *__restrict__ base, uint8_t *__restrict__ out) {
+  const uint32_t gid = blockIdx.x * 256u + threadIdx.x, sub = gid / UL, part = gid % UL;
+  const bool in = sub < total_sub;
+  Seg sg;
+  UnstLane r;
+  r.n = 0; r.live = false;
+  if (in) {
+    sg = segs[find_seg(segs, nseg, sub)];
+    r = unstuff_lane(scan + frames[sg.frame].scan_off, sg, sub, part);
+  }
+  uint32_t pre = r.n;                                    // inclusive sum over the sixteen lanes of the subsequence
+#pragma unroll
+  for (int d = 1; d < UL; d <<= 1) {
+    const uint32_t v = __shfl_up(pre, d, UL);
+    if (part >= (uint32_t)d) pre += v;
+  }
+  if (!in || !r.live || r.n == 0) return;
+  uint8_t *o = out + frames[sg.frame].scan_off + sg.byte_start + base[sub] + (pre - r.n);
+  if (r.n == 16) {                                       // nothing stuffed among the lane's bytes (dword stores need no alignment here)
+    __builtin_memcpy(o, r.x, 16);
+    return;
+  }
+  for (uint32_t q = 0; q < 16; ++q)
+    if (!((r.st[q >> 2] >> (8 * (q & 3))) & 0x80u)) *o++ = (uint8_t)(r.x[q >> 2] >> (8 * (q & 3)));
+}
+
 // pass 0: from the subsequence's own first byte with a guessed state; pass > 0: from the predecessor's record, repeated
 // inside the workgroup (its 256 subsequences are neighbours) until a round changes nothing there, at most INNER times;
 // the host launches passes until one stores nothing at all.
 constexpr int INNER = 32;
+template <bool UNST>
 __global__ __launch_bounds__(256) void jpeg_sync_kernel(const uint8_t *__restrict__ scan, const FrameDev *__restrict__ frames,
                                                         const Seg *__restrict__ segs, int nseg, Geom g,
                                                         const uint16_t *__restrict__ luts, const uint16_t *__restrict__ fast, SubRec *rec, uint32_t total_sub, int pass,
@@ -294,9 +435,9 @@ __global__ __launch_bounds__(256) void jpeg_sync_kernel(const uint8_t *__restric
     if (t > 0) {
       const bool from_start = t <= (uint32_t)TN_JPEG_RUNIN;        // the segment's first byte: the true state
       uint32_t cp = from_start ? sg.byte_start : sub_start - (uint32_t)TN_JPEG_RUNIN * SUBSEQ;
-      if (!from_start && rd.ld(cp - 1) == 0xFFu && rd.ld(cp) == 0u) cp += 1;
-      const SubRec r0 = decode_sub<false>(rd, cp, 0, sub_start, 0, 0, g, f, luts, fast, sh_fast, in_lds, nullptr, 0, 0, nullptr);
-      SubRec r1 = decode_sub<false>(rd, r0.pos >> 3, r0.pos & 7, sub_end, r0.state >> 6, r0.state & 63, g, f, luts, fast, sh_fast, in_lds, nullptr, 0, 0, nullptr);
+      if (!UNST && !from_start && rd.ld(cp - 1) == 0xFFu && rd.ld(cp) == 0u) cp += 1;
+      const SubRec r0 = decode_sub<false, UNST>(rd, cp, 0, sub_start, 0, 0, g, f, luts, fast, sh_fast, in_lds, nullptr, 0, 0, nullptr);
+      SubRec r1 = decode_sub<false, UNST>(rd, r0.pos >> 3, r0.pos & 7, sub_end, r0.state >> 6, r0.state & 63, g, f, luts, fast, sh_fast, in_lds, nullptr, 0, 0, nullptr);
       r1.in_pos = r0.pos;
       r1.in_state = r0.state;
       rec[sub] = r1;
@@ -304,8 +445,8 @@ __global__ __launch_bounds__(256) void jpeg_sync_kernel(const uint8_t *__restric
     }
 #endif
     uint32_t cp = sub_start;
-    if (t > 0 && rd.ld(cp - 1) == 0xFFu && rd.ld(cp) == 0u) cp += 1;     // a stuffed byte is not data
-    rec[sub] = decode_sub<false>(rd, cp, 0, sub_end, 0, 0, g, f, luts, fast, sh_fast, in_lds, nullptr, 0, 0, nullptr);
+    if (!UNST && t > 0 && rd.ld(cp - 1) == 0xFFu && rd.ld(cp) == 0u) cp += 1;     // a stuffed byte is not data
+    rec[sub] = decode_sub<false, UNST>(rd, cp, 0, sub_end, 0, 0, g, f, luts, fast, sh_fast, in_lds, nullptr, 0, 0, nullptr);
     return;
   }
   volatile SubRec *vrec = rec;
@@ -318,7 +459,7 @@ __global__ __launch_bounds__(256) void jpeg_sync_kernel(const uint8_t *__restric
       if (ppos != in_pos || pstate != in_state) {     // decode again only from a start this thread has not decoded from yet
         in_pos = ppos;
         in_state = pstate;
-        const SubRec r = decode_sub<false>(rd, ppos >> 3, ppos & 7, sub_end, pstate >> 6, pstate & 63, g, f, luts, fast, sh_fast, in_lds, nullptr, 0, 0, nullptr);
+        const SubRec r = decode_sub<false, UNST>(rd, ppos >> 3, ppos & 7, sub_end, pstate >> 6, pstate & 63, g, f, luts, fast, sh_fast, in_lds, nullptr, 0, 0, nullptr);
         ch = (vrec[sub].pos != r.pos || vrec[sub].state != r.state || vrec[sub].nblk != r.nblk) ? 1 : 0;
         vrec[sub].pos = r.pos; vrec[sub].state = (uint16_t)r.state; vrec[sub].nblk = r.nblk;
         vrec[sub].in_pos = in_pos; vrec[sub].in_state = (uint16_t)in_state;
@@ -352,6 +493,7 @@ __global__ __launch_bounds__(256) void jpeg_block_scan_kernel(const Seg *__restr
   }
 }
 
+template <bool UNST>
 __global__ __launch_bounds__(256) void jpeg_write_kernel(const uint8_t *__restrict__ scan, const FrameDev *__restrict__ frames,
                                                          const Seg *__restrict__ segs, int nseg, Geom g,
                                                          const uint16_t *__restrict__ luts, const uint16_t *__restrict__ fast,
@@ -392,7 +534,7 @@ __global__ __launch_bounds__(256) void jpeg_write_kernel(const uint8_t *__restri
   }
   if (b0 >= sg.nblocks) return;
   int16_t *cf = coef + ((size_t)sg.frame * g.blocks_per_frame + sg.block_base) * 64;
-  const SubRec r = decode_sub<true>(rd, cp, cb, sub_end, slot, k, g, f, luts, fast, sh_fast, in_lds, cf, b0, sg.nblocks, err, sh_blk + threadIdx.x * 32);
+  const SubRec r = decode_sub<true, UNST>(rd, cp, cb, sub_end, slot, k, g, f, luts, fast, sh_fast, in_lds, cf, b0, sg.nblocks, err, sh_blk + threadIdx.x * 32);
   if (t + 1 == sg.nsub && b0 + r.nblk < sg.nblocks) atomicExch(err, 1);    // data ran out before the last block
 }
 
@@ -877,10 +1019,11 @@ struct tn_jpeg {
   PinBuf<Seg> h_segs;
   PinBuf<int> h_flags;                  // [0] changed, [1] error
   DevBuf<uint8_t> d_scan, d_planes;
+  DevBuf<uint8_t> d_scan_u;             // the batch's entropy-coded bytes without their FF 00 stuffing (same layout)
   DevBuf<FrameDev> d_frames;
-  DevBuf<Seg> d_segs;
+  DevBuf<Seg> d_segs, d_segs_u;         // segments as uploaded / with the un-stuffed ends
   DevBuf<SubRec> d_rec;
-  DevBuf<uint32_t> d_base;
+  DevBuf<uint32_t> d_base, d_kept;
   DevBuf<int16_t> d_coef;
   DevBuf<uint16_t> d_luts, d_fast;
   DevBuf<int> d_flags;
@@ -918,6 +1061,7 @@ extern "C" int tn_jpeg_destroy(tn_jpeg *j) {
   (void)hipStreamSynchronize(j->ctx->stream);
   j->h_scan.release(); j->h_frames.release(); j->h_segs.release(); j->h_flags.release();
   j->d_scan.release(); j->d_planes.release(); j->d_frames.release(); j->d_segs.release(); j->d_rec.release();
+  j->d_scan_u.release(); j->d_segs_u.release(); j->d_kept.release();
   j->d_base.release(); j->d_coef.release(); j->d_luts.release(); j->d_fast.release(); j->d_flags.release();
   delete j;
   return TN_OK;
@@ -1114,23 +1258,38 @@ extern "C" int tn_jpeg_decode(tn_jpeg *j, const uint8_t *const *data_host, const
   if (timing) { (void)hipStreamSynchronize(st); lap(2); }      // what of the H2D was still outstanding
   // ---- Huffman decode ----
   const unsigned gsub = (total_sub + 255) / 256;
-  hipLaunchKernelGGL(jpeg_sync_kernel, dim3(gsub), dim3(256), 0, st, j->d_scan.p, j->d_frames.p, j->d_segs.p, nseg, g, j->d_luts.p, j->d_fast.p, j->d_rec.p,
-                     total_sub, 0, j->d_flags.p);
+  static const bool no_unstuff = getenv("TN_JPEG_NO_UNSTUFF") != nullptr;      // A/B runs: the reader that skips FF 00 itself
+  const uint8_t *scan_d = j->d_scan.p;
+  const Seg *segs_d = j->d_segs.p;
+  if (!no_unstuff) {
+    if ((rc = j->d_scan_u.ensure(scan_total)) || (rc = j->d_segs_u.ensure(nseg)) || (rc = j->d_kept.ensure(total_sub))) return rc;
+    hipLaunchKernelGGL(jpeg_unstuff_count_kernel, dim3((total_sub + 256 / UL - 1) / (256 / UL)), dim3(256), 0, st, j->d_scan.p, j->d_frames.p, j->d_segs.p, nseg, total_sub, j->d_kept.p);
+    hipLaunchKernelGGL(jpeg_unstuff_scan_kernel, dim3(nseg), dim3(256), 0, st, j->d_segs.p, j->d_kept.p, j->d_base.p, j->d_segs_u.p);
+    hipLaunchKernelGGL(jpeg_unstuff_write_kernel, dim3((total_sub + 256 / UL - 1) / (256 / UL)), dim3(256), 0, st, j->d_scan.p, j->d_frames.p, j->d_segs.p, nseg, total_sub, j->d_base.p, j->d_scan_u.p);
+    scan_d = j->d_scan_u.p;
+    segs_d = j->d_segs_u.p;
+  }
+  auto launch_sync = [&](int ps) {
+    if (no_unstuff) hipLaunchKernelGGL(jpeg_sync_kernel<false>, dim3(gsub), dim3(256), 0, st, scan_d, j->d_frames.p, segs_d, nseg, g, j->d_luts.p, j->d_fast.p, j->d_rec.p, total_sub, ps, j->d_flags.p);
+    else hipLaunchKernelGGL(jpeg_sync_kernel<true>, dim3(gsub), dim3(256), 0, st, scan_d, j->d_frames.p, segs_d, nseg, g, j->d_luts.p, j->d_fast.p, j->d_rec.p, total_sub, ps, j->d_flags.p);
+  };
+  launch_sync(0);
   int pass = 1;
   for (;; ++pass) {
     if (pass > MAX_SYNC) { tn_set_error("tn_jpeg_decode: the Huffman streams did not synchronise (corrupt data)"); return TN_ERR_INVALID; }
     TN_HIP_CHECK(hipMemsetAsync(j->d_flags.p, 0, sizeof(int), st));
-    hipLaunchKernelGGL(jpeg_sync_kernel, dim3(gsub), dim3(256), 0, st, j->d_scan.p, j->d_frames.p, j->d_segs.p, nseg, g, j->d_luts.p, j->d_fast.p, j->d_rec.p,
-                       total_sub, pass, j->d_flags.p);
+    launch_sync(pass);
     TN_HIP_CHECK(hipMemcpyAsync(j->h_flags.p, j->d_flags.p, sizeof(int), hipMemcpyDeviceToHost, st));
     TN_HIP_CHECK(hipStreamSynchronize(st));
     if (!j->h_flags.p[0]) break;
   }
   j->last_sync_passes = pass;
   lap(3);       // sync passes (each ends in a host round trip)
-  hipLaunchKernelGGL(jpeg_block_scan_kernel, dim3(nseg), dim3(256), 0, st, j->d_segs.p, j->d_rec.p, j->d_base.p);
-  hipLaunchKernelGGL(jpeg_write_kernel, dim3(gsub), dim3(256), 0, st, j->d_scan.p, j->d_frames.p, j->d_segs.p, nseg, g, j->d_luts.p, j->d_fast.p, j->d_rec.p,
-                     j->d_base.p, total_sub, j->d_coef.p, j->d_flags.p + 1);
+  hipLaunchKernelGGL(jpeg_block_scan_kernel, dim3(nseg), dim3(256), 0, st, segs_d, j->d_rec.p, j->d_base.p);
+  if (no_unstuff) hipLaunchKernelGGL(jpeg_write_kernel<false>, dim3(gsub), dim3(256), 0, st, scan_d, j->d_frames.p, segs_d, nseg, g, j->d_luts.p, j->d_fast.p, j->d_rec.p,
+                                     j->d_base.p, total_sub, j->d_coef.p, j->d_flags.p + 1);
+  else hipLaunchKernelGGL(jpeg_write_kernel<true>, dim3(gsub), dim3(256), 0, st, scan_d, j->d_frames.p, segs_d, nseg, g, j->d_luts.p, j->d_fast.p, j->d_rec.p,
+                          j->d_base.p, total_sub, j->d_coef.p, j->d_flags.p + 1);
   hipLaunchKernelGGL(jpeg_dc_scan_kernel, dim3(n * g.ncomp), dim3(256), 0, st, g, j->d_coef.p);
   // ---- IDCT, upsampling, colour ----
   hipLaunchKernelGGL(jpeg_idct_kernel, dim3((g.blocks_per_frame + 63) / 64, n), dim3(64), 0, st, g, j->d_frames.p, j->d_coef.p, j->d_planes.p);
