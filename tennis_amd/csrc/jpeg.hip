@@ -132,20 +132,27 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
   // nx: the four bytes at pn, requested when pn last moved - a refill then appends from a register and only ASKS for the next
   // dword; the dependent load (and its wait, which stalls the whole wave) is out of the symbols' chain
   uint32_t nx = 0;
+  // UNST: the dword is requested unconditionally (a file's bytes are followed by 16 bytes of padding and the reader never gets
+  // further than 12 bytes past a segment's end) and nm masks what lies behind the end to zero when the dword is USED - a branch
+  // around the load, or a mask applied to it here, makes hipcc wait for it on the spot.
+  uint32_t nm = 0;
   auto fetch = [&]() {
-    if (pn + 4 <= rd.end) __builtin_memcpy(&nx, rd.s + pn, 4);
-    else if (UNST) {              // the segment's last bytes: zeros behind the end, as Reader::ld reads them
-      nx = 0;
-      for (uint32_t i = 0; i < 4; ++i) nx |= rd.ld(pn + i) << (8 * i);
+    if constexpr (UNST) {
+      const int valid = (int)rd.end - (int)pn;
+      nm = valid >= 4 ? 0xFFFFFFFFu : (valid <= 0 ? 0u : ((1u << (8 * valid)) - 1u));
+      __builtin_memcpy(&nx, rd.s + pn, 4);
+    } else {
+      if (pn + 4 <= rd.end) __builtin_memcpy(&nx, rd.s + pn, 4);
     }
   };
   fetch();
   auto refill = [&]() {
     if constexpr (UNST) {
       if (nb <= 32) {
-        buf |= (uint64_t)__builtin_bswap32(nx) << (32 - nb);
+        buf |= (uint64_t)__builtin_bswap32(nx & nm) << (32 - nb);
         nb += 32;
         pn += 4;
+        __builtin_amdgcn_sched_barrier(0);      // the old dword is dead before the new one is requested: one register, no copy (and no wait) behind the load
         fetch();
       }
       return;
@@ -195,9 +202,20 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
     const uint32_t tb = (uint32_t)(tabs >> (4 * slot));
     const int table = dc ? (int)(tb & 3u) : 4 + (int)((tb >> 2) & 3u);
     const uint32_t fidx = table * FAST_SIZE + (uint32_t)(buf >> (64 - FAST_BITS));
-    uint16_t e;
-    if (in_lds) e = ((const __attribute__((address_space(3))) uint16_t *)sh_fast)[fidx]; else e = fast[fidx];
-    if (e == 0) e = lut_base[(size_t)table * LUT_SIZE + (uint32_t)(buf >> 48)];
+    // The two lookups in GLOBAL memory (a thread of another table set; a code longer than FAST_BITS) are waited for inside
+    // their branches: left to hipcc the wait sits behind the join as vmcnt(0), in every symbol step, and also waits for the
+    // dword that the last refill requested for the NEXT refill - the one load that is meant to stay in flight.
+    uint32_t e;
+    if (in_lds) {
+      e = ((const __attribute__((address_space(3))) uint16_t *)sh_fast)[fidx];
+    } else {
+      e = fast[fidx];
+      asm volatile("" : "+v"(e));
+    }
+    if (e == 0) {
+      e = lut_base[(size_t)table * LUT_SIZE + (uint32_t)(buf >> 48)];
+      asm volatile("" : "+v"(e));
+    }
     int len = e >> 8;
     const int sym = e & 255;
     if (len == 0) {           // no such code: a wrong-state decoder steps on one bit, the true decode is corrupt
