@@ -560,11 +560,14 @@ __global__ __launch_bounds__(256) void jpeg_write_kernel(const uint8_t *__restri
 // differences in scan order, restarting at every restart interval.  One workgroup per (file, component), one MCU per
 // thread and round.
 __global__ __launch_bounds__(256) void jpeg_dc_scan_kernel(Geom g, int16_t *__restrict__ coef) {
-  __shared__ int sh_s[256];
-  __shared__ int sh_f[256];
+  // (round 5: the segmented scan runs inside the waves - six shuffles, no barrier - and crosses them through four LDS entries;
+  // the Hillis-Steele form over 256 LDS entries spent sixteen barriers per 256 MCUs: 267 us per 256 720p frames, all latency)
+  __shared__ int sh_s[4];
+  __shared__ int sh_f[4];
   const int frame = blockIdx.x / g.ncomp, comp = blockIdx.x % g.ncomp;
   int16_t *cf = coef + (size_t)frame * g.blocks_per_frame * 64;
   const int nmcu = g.mcux * g.mcuy;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int carry = 0;
   for (int c0 = 0; c0 < nmcu; c0 += 256) {
     const int m = c0 + threadIdx.x;
@@ -573,23 +576,26 @@ __global__ __launch_bounds__(256) void jpeg_dc_scan_kernel(Geom g, int16_t *__re
       for (int sl = 0; sl < g.bpm; ++sl)
         if (g.slot_comp[sl] == comp) sum += cf[((size_t)m * g.bpm + sl) * 64];
     const int flag = (m < nmcu && g.ri > 0 && m % g.ri == 0) ? 1 : 0;
-    if (threadIdx.x == 0 && !flag) sum += carry;
-    sh_s[threadIdx.x] = sum;
-    sh_f[threadIdx.x] = flag;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {      // inclusive segmented scan (Hillis-Steele)
-      int as = 0, af = 0;
-      const bool has = threadIdx.x >= (unsigned)d;
-      if (has) { as = sh_s[threadIdx.x - d]; af = sh_f[threadIdx.x - d]; }
-      __syncthreads();
-      if (has) {
-        if (!sh_f[threadIdx.x]) sh_s[threadIdx.x] += as;
-        sh_f[threadIdx.x] |= af;
+    // inclusive segmented scan over the wave: (s, f) of the lanes before this one; a flag stops the sum
+    int s = sum, f = flag;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int as = __shfl_up(s, d, 64), af = __shfl_up(f, d, 64);
+      if (lane >= d) {
+        if (!f) s += as;
+        f |= af;
       }
-      __syncthreads();
     }
+    if (lane == 63) { sh_s[wv] = s; sh_f[wv] = f; }
+    __syncthreads();
+    // what enters this wave: the carry of the previous rounds through the waves before it
+    int in = carry;
+    for (int w = 0; w < wv; ++w) in = sh_f[w] ? sh_s[w] : in + sh_s[w];
+    int tot = carry;                                     // ... and through all four: the next round's carry
+    for (int w = 0; w < 4; ++w) tot = sh_f[w] ? sh_s[w] : tot + sh_s[w];
+    const int incl = f ? s : s + in;                     // inclusive value of this MCU
     if (m < nmcu) {
-      int run = flag ? 0 : (threadIdx.x ? sh_s[threadIdx.x - 1] : carry);
+      int run = flag ? 0 : incl - sum;                   // what precedes this MCU's own blocks
       for (int sl = 0; sl < g.bpm; ++sl)
         if (g.slot_comp[sl] == comp) {
           int16_t *b = cf + ((size_t)m * g.bpm + sl) * 64;
@@ -597,7 +603,7 @@ __global__ __launch_bounds__(256) void jpeg_dc_scan_kernel(Geom g, int16_t *__re
           b[0] = (int16_t)run;
         }
     }
-    carry = sh_s[255];
+    carry = tot;
     __syncthreads();
   }
 }
