@@ -50,7 +50,7 @@ namespace {
 #endif
 constexpr int SUBSEQ = TN_JPEG_SUBSEQ;     // bytes of entropy-coded data per decoding thread
 constexpr int MAX_SLOTS = 10;   // blocks per MCU (T.81 B.2.3: sum of Hi x Vi <= 10)
-constexpr int LUT_SIZE = 65536; // 16-bit prefix -> (code length << 8) | symbol, 0 = no such code
+constexpr int LUT_SIZE = 65536; // 16-bit prefix -> lut_entry (code length, value size, zig-zag advance), 0 = no such code
 constexpr int FAST_BITS = 10, FAST_SIZE = 1 << FAST_BITS;   // first-level table: codes of up to 10 bits (the rest: 0 -> full table)
 constexpr int MAX_SYNC = 4096;  // fix-up passes before the stream is declared corrupt
 
@@ -76,6 +76,17 @@ struct Geom {                   // common to all files of a call
 struct Seg {                    // a stretch of one file's scan between restart markers (the whole scan without them)
   uint32_t frame, byte_start, byte_end, block_base, nblocks, first_sub, nsub;
 };
+
+// ------------------------------------------------------------------------------------------------ table entries
+// One decoding-table entry (first level, full table): bits 0-4 code length (0: no such code), 5-8 SSSS = the bits of the value
+// behind the code, 9-15 how far the zig-zag index moves: 1 for a DC difference, RRRR + 1 for an AC coefficient, 16 for ZRL,
+// 64 (= the block ends) for EOB and the undefined run / size pairs.  The symbol loop then needs no DC / AC case.
+__host__ __device__ constexpr uint16_t lut_entry(int len, int size, int advance) { return (uint16_t)(len | (size << 5) | (advance << 9)); }
+// the tables of MCU slot `slot`: DC table | (4 + AC table) << 8, from the packed per-slot nibbles (DC id | AC id << 2)
+__device__ __forceinline__ uint32_t slot_tables(uint64_t tabs, int slot) {
+  const uint32_t tb = (uint32_t)(tabs >> (4 * slot));
+  return (tb & 3u) | ((4u + ((tb >> 2) & 3u)) << 8);
+}
 
 // ------------------------------------------------------------------------------------------------ bit reader
 struct Reader {
@@ -117,6 +128,7 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
   // is then arithmetic instead of a dependent load from the frame record in every symbol's chain
   uint64_t tabs = 0;
   for (int i = 0; i < g.bpm; ++i) tabs |= (uint64_t)((f.slot_dc[i] & 3) | ((f.slot_ac[i] & 3) << 2)) << (4 * i);
+  uint32_t ctab = slot_tables(tabs, slot);      // the current slot's tables: DC | AC << 8
   const uint16_t *lut_base = luts + (size_t)f.lut * 8 * LUT_SIZE;
   // this file's first-level tables: the workgroup's LDS copy (in_lds: a real ds_read - through one generic pointer the lookup
   // was a FLAT load that waits for every outstanding global load as well) or, for a thread of another table set, global memory
@@ -199,8 +211,7 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
     // one symbol, DC difference (F.2.2.1) and AC coefficient (F.2.2.2) through the same straight-line code: the lanes of a
     // wave are at different places of their blocks, a branch per symbol kind would run both sides for every symbol
     const bool dc = k == 0;
-    const uint32_t tb = (uint32_t)(tabs >> (4 * slot));
-    const int table = dc ? (int)(tb & 3u) : 4 + (int)((tb >> 2) & 3u);
+    const int table = (int)(dc ? (ctab & 255u) : (ctab >> 8));
     const uint32_t fidx = table * FAST_SIZE + (uint32_t)(buf >> (64 - FAST_BITS));
     // The two lookups in GLOBAL memory (a thread of another table set; a code longer than FAST_BITS) are waited for inside
     // their branches: left to hipcc the wait sits behind the join as vmcnt(0), in every symbol step, and also waits for the
@@ -215,16 +226,15 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
     if (e == 0) {
       e = lut_base[(size_t)table * LUT_SIZE + (uint32_t)(buf >> 48)];
       asm volatile("" : "+v"(e));
+      if (e == 0) {           // no such code: a wrong-state decoder steps on one bit (as an empty DC / an EOB), the true decode is corrupt
+        if (WRITE) atomicExch(err, 1);
+        e = lut_entry(1, 0, dc ? 1 : 64);
+      }
     }
-    int len = e >> 8;
-    const int sym = e & 255;
-    if (len == 0) {           // no such code: a wrong-state decoder steps on one bit, the true decode is corrupt
-      if (WRITE) atomicExch(err, 1);
-      len = 1;
-    }
-    const int s = sym & 15, r = dc ? 0 : sym >> 4;
+    // entry = code length | size of the value | advance of the zig-zag index (lut_entry): nothing below depends on the symbol kind
+    const int len = (int)(e & 31u), s = (int)((e >> 5) & 15u), d = (int)(e >> 9);
     const int nbits = len + s;
-    const int kk = dc ? 0 : k + r;                                  // zig-zag index the value (if any) belongs to
+    const int kk = k + d - 1;                                       // zig-zag index the value (if any) belongs to
     if (WRITE && s) {
       if (kk > 63) {
         atomicExch(err, 1);
@@ -240,8 +250,8 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
         }
       }
     }
-    // next index: behind the value; ZRL (r = 15, s = 0) skips 16; EOB (s = 0 otherwise) ends the block
-    const int kn = dc ? 1 : (s ? kk + 1 : (r == 15 ? k + 16 : 64));
+    // next index: behind the value; ZRL skips 16; EOB ends the block (advance 64)
+    const int kn = k + d;
     const bool block_end = kn > 63;
     if (WRITE) {
       own = own || dc;
@@ -257,6 +267,7 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
     }
     k = block_end ? 0 : kn;
     slot = block_end ? (slot + 1 == g.bpm ? 0 : slot + 1) : slot;
+    ctab = slot_tables(tabs, slot);          // (off the lookup's dependency chain: the next symbol only selects one of its two bytes)
     nblk += block_end ? 1u : 0u;
     consume(nbits);           // <= 27 bits, nb >= 32
   }
@@ -945,7 +956,7 @@ std::string parse_header(const uint8_t *d, size_t n, Header &h) {
 }
 
 // T.81 Annex C code assignment -> 16-bit prefix table
-void build_lut(const HuffSpec &hs, uint16_t *lut) {
+void build_lut(const HuffSpec &hs, bool is_dc, uint16_t *lut) {
   memset(lut, 0, LUT_SIZE * sizeof(uint16_t));
   if (!hs.present) return;
   unsigned code = 0;
@@ -954,7 +965,8 @@ void build_lut(const HuffSpec &hs, uint16_t *lut) {
     for (int i = 0; i < hs.counts[len - 1]; ++i, ++k, ++code) {
       if (code >= (1u << len)) return;     // over-subscribed table: the remaining codes do not exist
       const unsigned first = code << (16 - len), cnt = 1u << (16 - len);
-      const uint16_t e = (uint16_t)((len << 8) | hs.syms[k]);
+      const int sym = hs.syms[k], sz = sym & 15, run = sym >> 4;
+      const uint16_t e = lut_entry(len, sz, is_dc ? 1 : (sz ? run + 1 : (run == 15 ? 16 : 64)));
       for (unsigned j = 0; j < cnt; ++j) lut[first + j] = e;
     }
     code <<= 1;
@@ -1185,8 +1197,8 @@ extern "C" int tn_jpeg_decode(tn_jpeg *j, const uint8_t *const *data_host, const
       const int idx = (int)j->lut_index.size();
       j->lut_host.resize((size_t)(idx + 1) * 8 * LUT_SIZE);
       for (int t = 0; t < 4; ++t) {
-        build_lut(h.dc[t], j->lut_host.data() + ((size_t)idx * 8 + t) * LUT_SIZE);
-        build_lut(h.ac[t], j->lut_host.data() + ((size_t)idx * 8 + 4 + t) * LUT_SIZE);
+        build_lut(h.dc[t], true, j->lut_host.data() + ((size_t)idx * 8 + t) * LUT_SIZE);
+        build_lut(h.ac[t], false, j->lut_host.data() + ((size_t)idx * 8 + 4 + t) * LUT_SIZE);
       }
       j->fast_host.resize((size_t)(idx + 1) * 8 * FAST_SIZE);
       for (int t = 0; t < 8; ++t) {       // first level: the full table's entry where the code fits into FAST_BITS bits
@@ -1194,7 +1206,7 @@ extern "C" int tn_jpeg_decode(tn_jpeg *j, const uint8_t *const *data_host, const
         uint16_t *fs = j->fast_host.data() + ((size_t)idx * 8 + t) * FAST_SIZE;
         for (int q = 0; q < FAST_SIZE; ++q) {
           const uint16_t e = full[(size_t)q << (16 - FAST_BITS)];
-          fs[q] = (e >> 8) <= FAST_BITS ? e : 0;
+          fs[q] = (e & 31) <= FAST_BITS ? e : 0;
         }
       }
       it = j->lut_index.emplace(key, idx).first;
