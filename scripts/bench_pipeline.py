@@ -89,8 +89,43 @@ for i in range(args.batches):
     torch.cuda.synchronize()      # (bufs4[i % 4] is free again only after its encode: 4 buffers, 2 decoders -> safe)
 for th in ths: th.join()
 two = (time.perf_counter() - t0) / args.batches
+# N decoders, N streams, N host threads, and the main thread waits for ITS OWN stream only (an event behind the encode) - a
+# device-wide synchronize after every encode, as above, also waits for the decoders' kernels of the next batches and puts the
+# encoder in lock step with them
+def many(nd, nb):
+    decs = [dec, dec2] + [image.JpegDecoder(_lib.Context(stream=torch.cuda.Stream())) for _ in range(nd - 2)]
+    free = [queue.Queue() for _ in range(nd)]
+    done = [queue.Queue() for _ in range(nd)]
+    for d in range(nd):
+        for _ in range(2): free[d].put(torch.empty_like(bufs[0]))
+    def work(d):
+        for i in range(d, nb, nd):
+            b = free[d].get()
+            decs[d].decode(batch, out=b)
+            done[d].put((i, b))
+    ths = [threading.Thread(target=work, args=(d,)) for d in range(nd)]
+    t0 = time.perf_counter()
+    for th in ths: th.start()
+    pending = None
+    for i in range(nb):
+        j, b = done[i % nd].get()
+        assert j == i
+        f = encode(b)
+        ev = torch.cuda.Event(); ev.record()
+        if pending is not None:
+            pending[0].synchronize(); free[pending[1]].put(pending[2])
+        pending = (ev, i % nd, b)
+    pending[0].synchronize()
+    for th in ths: th.join()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / nb
+nb = max(args.batches, 12)
+three = many(3, nb)
+four = many(4, nb)
 res = dict(two_decoders_ms_per_batch=round(two * 1e3, 2), two_decoders_frames_per_s=round(args.frames / two, 1), frames=args.frames, size=[H, W], serial_ms_per_batch=round(serial * 1e3, 2), serial_frames_per_s=round(args.frames / serial, 1),
            overlapped_ms_per_batch=round(overl * 1e3, 2), overlapped_frames_per_s=round(args.frames / overl, 1),
+           three_decoders_own_stream_wait_ms_per_batch=round(three * 1e3, 2), three_decoders_own_stream_wait_frames_per_s=round(args.frames / three, 1),
+           four_decoders_own_stream_wait_ms_per_batch=round(four * 1e3, 2), four_decoders_own_stream_wait_frames_per_s=round(args.frames / four, 1),
            decode_on_own_stream=True)
 print(json.dumps(res))
 os.makedirs("gpurun_out", exist_ok=True)
