@@ -214,6 +214,33 @@ def test_device_decode_random_sweep():
             assert np.array_equal(out[i], _pillow(f)), (h, w, kw, i)
 
 
+def test_device_decode_stuffing_heavy_streams():
+    """Round 5: the FF 00 stuffing is removed on the device before the Huffman passes.  Streams with MANY stuffed bytes
+    (quality 100 noise: long codes, runs of one-bits), with restart markers between stuffed bytes, multi-megabyte scans
+    (thousands of 256-byte subsequences per file, un-stuffed ends far from the stuffed ones) and every alignment of the
+    scan's first byte - all identical to libjpeg's output, and the stuffed-reader route (TN_JPEG_NO_UNSTUFF) is not needed."""
+    pytest.importorskip("PIL")
+    from tennis_amd import image
+    rng = np.random.default_rng(77)
+    dec = image.JpegDecoder()
+    worst = 0.0
+    for (h, w, kw) in [(256, 320, dict(quality=100, subsampling=0)), (240, 352, dict(quality=100, subsampling=2, restart_marker_blocks=3)),
+                       (1080, 1920, dict(quality=98, subsampling=2)), (64, 64, dict(quality=100, subsampling=1, restart_marker_rows=1)),
+                       (333, 517, dict(quality=100, subsampling=0, optimize=True))]:
+        files = []
+        for i in range(3):
+            a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            a[:: 7 + i] = 255                                         # saturated rows: long runs of one-bits in the DC / AC values
+            f = _encode(a, **kw)
+            files.append(f if i != 1 else f[:2] + b"\xff\xfe" + (4 + i).to_bytes(2, "big") + b"ab" + b"c" * i + f[2:])   # a COM segment shifts the scan's alignment
+        scan = files[0][files[0].rfind(b"\xff\xda"):]
+        worst = max(worst, scan.count(b"\xff\x00") / max(1, len(scan)))
+        out = dec.decode(files).cpu().numpy()
+        for i, f in enumerate(files):
+            assert np.array_equal(out[i], _pillow(f)), (h, w, kw, i)
+    assert worst > 0.003          # the streams really are stuffing-heavy (random data: 1 / 256 of the bytes)
+
+
 def test_evaluate_save_feats_from_jpeg_frames(tmp_path):
     """``evaluate.py --save_feats`` on a dataset of JPEG frames on disk (reference evaluate.py:306-321 over the frames of
     dataset.py:204): the driver's default route - device decode, two loader threads - writes the same .npy feature files as
