@@ -36,6 +36,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -203,9 +204,17 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
   refill();
   if constexpr (UNST) refill();      // (64 bits buffered, as the stuffed form's loop leaves them)
   consume((int)cb);
+  // UNST: rem = bits between the first unread bit and the end of the subsequence (the loop's exit test is one subtraction and a
+  // sign test per symbol instead of rebuilding the byte position).  The loop exists twice: when every lane of the wave has its
+  // tables in the workgroup's LDS copy - nearly always - the per-lane choice between the LDS and the global lookup (two exec-mask
+  // branches per symbol) is not in it.
+  int rem = UNST ? (int)(stop * 8u) - (int)(pn * 8u - (uint32_t)nb) : 0;
+  const bool wave_lds = __all(in_lds ? 1 : 0) != 0;
+  auto symbols = [&](auto lds_only_tag) __attribute__((always_inline)) {
+  constexpr bool LDS_ONLY = decltype(lds_only_tag)::value;
   for (;;) {
-    if constexpr (UNST) pb = (pn * 8u - (uint32_t)nb) >> 3;      // the byte that holds the first unread bit
-    if (pb >= stop) break;
+    if constexpr (UNST) { if (rem <= 0) break; }
+    else if (pb >= stop) break;
     if (WRITE && first_block + nblk >= max_blocks) break;     // the rest of the segment is padding
     if (nb < 32) refill();
     // one symbol, DC difference (F.2.2.1) and AC coefficient (F.2.2.2) through the same straight-line code: the lanes of a
@@ -217,7 +226,7 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
     // their branches: left to hipcc the wait sits behind the join as vmcnt(0), in every symbol step, and also waits for the
     // dword that the last refill requested for the NEXT refill - the one load that is meant to stay in flight.
     uint32_t e;
-    if (in_lds) {
+    if (LDS_ONLY || in_lds) {
       e = ((const __attribute__((address_space(3))) uint16_t *)sh_fast)[fidx];
     } else {
       e = fast[fidx];
@@ -270,7 +279,10 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
     ctab = slot_tables(tabs, slot);          // (off the lookup's dependency chain: the next symbol only selects one of its two bytes)
     nblk += block_end ? 1u : 0u;
     consume(nbits);           // <= 27 bits, nb >= 32
+    if constexpr (UNST) rem -= nbits;
   }
+  };
+  if (wave_lds) symbols(std::true_type{}); else symbols(std::false_type{});
   if constexpr (UNST) pb = (pn * 8u - (uint32_t)nb) >> 3;
   cp = pb;
   cb = (8u - ((uint32_t)nb & 7u)) & 7u;
