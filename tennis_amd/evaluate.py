@@ -305,7 +305,7 @@ def build_parser():
     p.add_argument("--vis", action="store_true", help="visualisation output is outside the accelerated path (SURVEY 2a): refused")
     p.add_argument("--flow", default="", help="optical-flow input is outside the accelerated path (SURVEY 2a): anything but '' is refused")
     p.add_argument("--root", default="data")
-    p.add_argument("--num_workers", type=int, default=2,
+    p.add_argument("--num_workers", type=int, default=3,
                    help="loader threads (reference: DataLoader worker processes, evaluate.py:113); on the device-decode route each owns a JPEG decoder on its own stream")
     p.add_argument("--decode", default="device", choices=["device", "host", "auto"],
                    help="where on-disk JPEG frames are decoded: on the GPU (tennis_amd.image), on the host (Pillow), or device with a host fallback for files the device decoder refuses")
@@ -342,7 +342,7 @@ def _main_rank(flags, rank, world, dev):
     if flags.flow or flags.vis:
         raise NotImplementedError("--flow / --vis: optical-flow input and visualisation are outside the accelerated path (SURVEY 2a)")
     if flags.num_workers < 0:                                               # the reference's -1 = cpu_count() (evaluate.py:80-81)
-        flags.num_workers = 2
+        flags.num_workers = 3                                               # (files -> features peaks at three decoder threads: scripts/bench_pipeline.py, profiles/r05_c_*)
     every = [int(s) for s in flags.every.split(",")]
     if flags.corpus_frames > 0:                                             # BASELINE config C4
         backbone = get_model(flags.backbone, pretrained=True, max_batch=flags.batch_size, conversion=flags.fp16_conversion).features

@@ -172,7 +172,7 @@ def build_parser():
     p.add_argument("--temp_pool", default=None, help="gru or lstm (trained); mean / max need no training")
     p.add_argument("--root", default="data")
     p.add_argument("--decode", default="device", choices=["device", "host", "auto"], help="where on-disk JPEG frames are decoded (see evaluate.py)")
-    p.add_argument("--num_workers", type=int, default=2, help="loader threads (train.py:101-102), see evaluate.py")
+    p.add_argument("--num_workers", type=int, default=3, help="loader threads (train.py:101-102), see evaluate.py")
     p.add_argument("--frames_per_video", type=int, default=16)
     p.add_argument("--exp_root", default=os.path.join("models", "vision", "experiments"))
     return p
@@ -198,7 +198,7 @@ def main(argv=None):
     if flags.flow or flags.vis:
         raise NotImplementedError("--flow / --vis: optical-flow input and visualisation are outside the accelerated path (SURVEY 2a)")
     if flags.num_workers < 0:                          # the reference's -1 = cpu_count() (train.py:101-102)
-        flags.num_workers = 2
+        flags.num_workers = 3                                               # (files -> features peaks at three decoder threads: scripts/bench_pipeline.py, profiles/r05_c_*)
     every = [int(s) for s in flags.every.split(",")]
     balance = [s.strip().lower() in ("true", "t") for s in flags.balance.split(",")]
     lr_steps = [int(s) for s in flags.lr_steps.split(",")]

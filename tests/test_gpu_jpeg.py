@@ -243,7 +243,7 @@ def test_device_decode_stuffing_heavy_streams():
 
 def test_evaluate_save_feats_from_jpeg_frames(tmp_path):
     """``evaluate.py --save_feats`` on a dataset of JPEG frames on disk (reference evaluate.py:306-321 over the frames of
-    dataset.py:204): the driver's default route - device decode, two loader threads - writes the same .npy feature files as
+    dataset.py:204): the driver's default route - device decode, three loader threads - writes the same .npy feature files as
     the host-decode route"""
     pytest.importorskip("PIL")
     from test_cpu_input_side import _write_dataset
