@@ -241,6 +241,39 @@ def test_device_decode_stuffing_heavy_streams():
     assert worst > 0.003          # the streams really are stuffing-heavy (random data: 1 / 256 of the bytes)
 
 
+def test_device_decode_with_a_poisoned_coefficient_array():
+    """Round 5: the coefficient array is no longer cleared per call - whole blocks leave the write pass as eight rows, and only
+    the blocks that straddle a subsequence boundary are cleared first (jpeg_zero_straddle_kernel).  With TN_JPEG_POISON=1 the
+    array is filled with 0x55 before every decode: any coefficient that nobody writes or clears would show as a wrong pixel.
+    (The flag is read once per process: a child process.)"""
+    pytest.importorskip("PIL")
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import io, sys, numpy as np
+        sys.path.insert(0, REPO_ROOT)
+        from PIL import Image
+        from tennis_amd import image
+        rng = np.random.default_rng(5)
+        dec = image.JpegDecoder()
+        for (h, w, kw) in [(720, 1280, dict(quality=90, subsampling=2)), (97, 131, dict(quality=35, subsampling=1)),
+                           (256, 256, dict(quality=100, subsampling=0)), (200, 333, dict(quality=75, subsampling=2, restart_marker_blocks=5))]:
+            files = []
+            for i in range(5):
+                yy, xx = np.mgrid[0:h, 0:w]
+                a = np.stack([127 + 100 * np.sin(xx / 23.0 + i), 127 + 100 * np.cos(yy / 17.0), (xx + yy * 3) % 256], -1)
+                a[: h // 3] = rng.integers(0, 256, (h // 3, w, 3))
+                if i == 4: a[:] = 37                       # a flat frame: blocks of one DC value
+                b = io.BytesIO(); Image.fromarray(np.clip(a, 0, 255).astype(np.uint8)).save(b, "JPEG", **kw); files.append(b.getvalue())
+            for rep in range(2):                          # the second call finds the first one's coefficients under the poison
+                out = dec.decode(files).cpu().numpy()
+                for i, f in enumerate(files):
+                    assert np.array_equal(out[i], np.asarray(Image.open(io.BytesIO(f)).convert("RGB"))), (h, w, kw, i, rep)
+        print("ok")
+    """).replace("REPO_ROOT", repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TN_JPEG_POISON="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
 def test_evaluate_save_feats_from_jpeg_frames(tmp_path):
     """``evaluate.py --save_feats`` on a dataset of JPEG frames on disk (reference evaluate.py:306-321 over the frames of
     dataset.py:204): the driver's default route - device decode, three loader threads - writes the same .npy feature files as
