@@ -83,12 +83,6 @@ struct Seg {                    // a stretch of one file's scan between restart 
 // behind the code, 9-15 how far the zig-zag index moves: 1 for a DC difference, RRRR + 1 for an AC coefficient, 16 for ZRL,
 // 64 (= the block ends) for EOB and the undefined run / size pairs.  The symbol loop then needs no DC / AC case.
 __host__ __device__ constexpr uint16_t lut_entry(int len, int size, int advance) { return (uint16_t)(len | (size << 5) | (advance << 9)); }
-// the tables of MCU slot `slot`: DC table | (4 + AC table) << 8, from the packed per-slot nibbles (DC id | AC id << 2)
-__device__ __forceinline__ uint32_t slot_tables(uint64_t tabs, int slot) {
-  const uint32_t tb = (uint32_t)(tabs >> (4 * slot));
-  return (tb & 3u) | ((4u + ((tb >> 2) & 3u)) << 8);
-}
-
 // ------------------------------------------------------------------------------------------------ bit reader
 struct Reader {
   const uint8_t *s;   // the file's scan bytes
@@ -129,7 +123,16 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
   // is then arithmetic instead of a dependent load from the frame record in every symbol's chain
   uint64_t tabs = 0;
   for (int i = 0; i < g.bpm; ++i) tabs |= (uint64_t)((f.slot_dc[i] & 3) | ((f.slot_ac[i] & 3) << 2)) << (4 * i);
-  uint32_t ctab = slot_tables(tabs, slot);      // the current slot's tables: DC | AC << 8
+  // rot: the slots' table nibbles (DC id | AC id << 2) ROTATED so that the current slot's sits in bits 0-3 (the accepted chroma layouts
+  // have at most 8 blocks per MCU: 32 bits) - it turns by one nibble at a block end, and the symbol loop carries neither the slot
+  // number nor a shift by it (the slot of the end record is (first slot + blocks completed) mod blocks per MCU)
+  const int slot0 = slot;
+  const uint32_t rot_sh = 4u * (uint32_t)(g.bpm - 1);
+  uint32_t rot = 0;
+  for (int i = 0; i < g.bpm; ++i) {
+    const int sl = slot + i < g.bpm ? slot + i : slot + i - g.bpm;
+    rot |= (uint32_t)((tabs >> (4 * sl)) & 15u) << (4 * i);
+  }
   const uint16_t *lut_base = luts + (size_t)f.lut * 8 * LUT_SIZE;
   // this file's first-level tables: the workgroup's LDS copy (in_lds: a real ds_read - through one generic pointer the lookup
   // was a FLAT load that waits for every outstanding global load as well) or, for a thread of another table set, global memory
@@ -220,7 +223,7 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
     // one symbol, DC difference (F.2.2.1) and AC coefficient (F.2.2.2) through the same straight-line code: the lanes of a
     // wave are at different places of their blocks, a branch per symbol kind would run both sides for every symbol
     const bool dc = k == 0;
-    const int table = (int)(dc ? (ctab & 255u) : (ctab >> 8));
+    const int table = (int)(dc ? (rot & 3u) : (4u | ((rot >> 2) & 3u)));
     const uint32_t fidx = table * FAST_SIZE + (uint32_t)(buf >> (64 - FAST_BITS));
     // The two lookups in GLOBAL memory (a thread of another table set; a code longer than FAST_BITS) are waited for inside
     // their branches: left to hipcc the wait sits behind the join as vmcnt(0), in every symbol step, and also waits for the
@@ -275,8 +278,7 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
       if (block_end) own = false;
     }
     k = block_end ? 0 : kn;
-    slot = block_end ? (slot + 1 == g.bpm ? 0 : slot + 1) : slot;
-    ctab = slot_tables(tabs, slot);          // (off the lookup's dependency chain: the next symbol only selects one of its two bytes)
+    rot = block_end ? ((rot >> 4) | ((rot & 15u) << rot_sh)) : rot;
     nblk += block_end ? 1u : 0u;
     consume(nbits);           // <= 27 bits, nb >= 32
     if constexpr (UNST) rem -= nbits;
@@ -293,6 +295,7 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
       if (v) coef[(size_t)(first_block + nblk) * 64 + h] = (int16_t)v;
     }
   }
+  slot = (int)(((uint32_t)slot0 + nblk) % (uint32_t)g.bpm);
   SubRec r;
   r.pos = cp * 8 + cb;
   r.state = (uint16_t)(slot * 64 + k);
@@ -1179,7 +1182,7 @@ extern "C" int tn_jpeg_decode(tn_jpeg *j, const uint8_t *const *data_host, const
   for (int c = 0; c < g.ncomp; ++c)
     for (int by = 0; by < g.vs[c]; ++by)
       for (int bx = 0; bx < g.hs[c]; ++bx) {
-        if (g.bpm >= MAX_SLOTS) { tn_set_error("tn_jpeg_decode: more than 10 blocks per MCU"); return TN_ERR_INVALID; }
+        if (g.bpm >= 8) { tn_set_error("tn_jpeg_decode: more than 8 blocks per MCU"); return TN_ERR_INVALID; }      // (decode_sub keeps the slots' table ids in 32 bits; no accepted chroma layout has more)
         g.slot_comp[g.bpm] = c; g.slot_by[g.bpm] = by; g.slot_bx[g.bpm] = bx;
         ++g.bpm;
       }
