@@ -79,10 +79,10 @@ struct Seg {                    // a stretch of one file's scan between restart 
 };
 
 // ------------------------------------------------------------------------------------------------ table entries
-// One decoding-table entry (first level, full table): bits 0-4 code length (0: no such code), 5-8 SSSS = the bits of the value
+// One decoding-table entry (first level, full table): bits 0-4 code length + SSSS = the bits the symbol takes (0: no such code), 5-8 SSSS = the bits of the value
 // behind the code, 9-15 how far the zig-zag index moves: 1 for a DC difference, RRRR + 1 for an AC coefficient, 16 for ZRL,
 // 64 (= the block ends) for EOB and the undefined run / size pairs.  The symbol loop then needs no DC / AC case.
-__host__ __device__ constexpr uint16_t lut_entry(int len, int size, int advance) { return (uint16_t)(len | (size << 5) | (advance << 9)); }
+__host__ __device__ constexpr uint16_t lut_entry(int len, int size, int advance) { return (uint16_t)((len + size) | (size << 5) | (advance << 9)); }
 // ------------------------------------------------------------------------------------------------ bit reader
 struct Reader {
   const uint8_t *s;   // the file's scan bytes
@@ -127,12 +127,14 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
   // have at most 8 blocks per MCU: 32 bits) - it turns by one nibble at a block end, and the symbol loop carries neither the slot
   // number nor a shift by it (the slot of the end record is (first slot + blocks completed) mod blocks per MCU)
   const int slot0 = slot;
+  uint32_t tbl;
   const uint32_t rot_sh = 4u * (uint32_t)(g.bpm - 1);
   uint32_t rot = 0;
   for (int i = 0; i < g.bpm; ++i) {
     const int sl = slot + i < g.bpm ? slot + i : slot + i - g.bpm;
     rot |= (uint32_t)((tabs >> (4 * sl)) & 15u) << (4 * i);
   }
+  tbl = k == 0 ? (rot & 3u) : (4u | ((rot >> 2) & 3u));
   const uint16_t *lut_base = luts + (size_t)f.lut * 8 * LUT_SIZE;
   // this file's first-level tables: the workgroup's LDS copy (in_lds: a real ds_read - through one generic pointer the lookup
   // was a FLAT load that waits for every outstanding global load as well) or, for a thread of another table set, global memory
@@ -223,7 +225,7 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
     // one symbol, DC difference (F.2.2.1) and AC coefficient (F.2.2.2) through the same straight-line code: the lanes of a
     // wave are at different places of their blocks, a branch per symbol kind would run both sides for every symbol
     const bool dc = k == 0;
-    const int table = (int)(dc ? (rot & 3u) : (4u | ((rot >> 2) & 3u)));
+    const int table = (int)tbl;
     const uint32_t fidx = table * FAST_SIZE + (uint32_t)(buf >> (64 - FAST_BITS));
     // The two lookups in GLOBAL memory (a thread of another table set; a code longer than FAST_BITS) are waited for inside
     // their branches: left to hipcc the wait sits behind the join as vmcnt(0), in every symbol step, and also waits for the
@@ -244,8 +246,8 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
       }
     }
     // entry = code length | size of the value | advance of the zig-zag index (lut_entry): nothing below depends on the symbol kind
-    const int len = (int)(e & 31u), s = (int)((e >> 5) & 15u), d = (int)(e >> 9);
-    const int nbits = len + s;
+    const int nbits = (int)(e & 31u), s = (int)((e >> 5) & 15u), d = (int)(e >> 9);
+    [[maybe_unused]] const int len = nbits - s;
     const int kk = k + d - 1;                                       // zig-zag index the value (if any) belongs to
     if (WRITE && s) {
       if (kk > 63) {
@@ -279,6 +281,7 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
     }
     k = block_end ? 0 : kn;
     rot = block_end ? ((rot >> 4) | ((rot & 15u) << rot_sh)) : rot;
+    tbl = block_end ? (rot & 3u) : (4u | ((rot >> 2) & 3u));      // the NEXT symbol's table, known before its lookup address is formed
     nblk += block_end ? 1u : 0u;
     consume(nbits);           // <= 27 bits, nb >= 32
     if constexpr (UNST) rem -= nbits;
@@ -1239,7 +1242,7 @@ extern "C" int tn_jpeg_decode(tn_jpeg *j, const uint8_t *const *data_host, const
         uint16_t *fs = j->fast_host.data() + ((size_t)idx * 8 + t) * FAST_SIZE;
         for (int q = 0; q < FAST_SIZE; ++q) {
           const uint16_t e = full[(size_t)q << (16 - FAST_BITS)];
-          fs[q] = (e & 31) <= FAST_BITS ? e : 0;
+          fs[q] = (e & 31) - ((e >> 5) & 15) <= FAST_BITS ? e : 0;      // (code length = bits taken - value bits)
         }
       }
       it = j->lut_index.emplace(key, idx).first;
