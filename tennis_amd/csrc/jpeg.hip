@@ -55,9 +55,6 @@ constexpr int LUT_SIZE = 65536; // 16-bit prefix -> lut_entry (code length, valu
 constexpr int FAST_BITS = 10, FAST_SIZE = 1 << FAST_BITS;   // first-level table: codes of up to 10 bits (the rest: 0 -> full table)
 constexpr int MAX_SYNC = 4096;  // fix-up passes before the stream is declared corrupt
 
-__constant__ uint8_t c_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
-                                     41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
-                                     30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
 struct FrameDev {               // per file
   uint32_t scan_off, scan_len;  // its entropy-coded bytes in the batch buffer
@@ -255,7 +252,8 @@ __device__ __forceinline__ SubRec decode_sub(const Reader &rd, uint32_t cp, uint
       } else {
         const int x = (int)((buf << len) >> (64 - s));
         const int val = x < (1 << (s - 1)) ? x - (1 << s) + 1 : x;   // EXTEND (F.2.2.1)
-        const uint32_t nat = c_zigzag[kk];
+        const uint32_t nat = (uint32_t)kk;      // (the coefficient array is in ZIG-ZAG order since round 5: the IDCT undoes it with compile-time indices;
+                                                // the table lookup here was a vector load from constant memory - and its wait - per value)
         if (own || dc) {
           const uint32_t w = nat >> 1, phys = (((w >> 2) ^ sw) << 2) | (w & 3u);
           ((uint16_t *)blk)[phys * 2 + (nat & 1u)] = (uint16_t)(int16_t)val;
@@ -693,12 +691,20 @@ __global__ __launch_bounds__(64) void jpeg_idct_kernel(Geom g, const FrameDev *_
   const int brow = g.ncomp == 1 ? my : my * g.vs[comp] + g.slot_by[sl], bcol = g.ncomp == 1 ? mx : mx * g.hs[comp] + g.slot_bx[sl];
   const int16_t *c = coef + ((size_t)frame * g.blocks_per_frame + blk) * 64;
   const uint16_t *q = frames[frame].q[comp];
+  // the block as the write pass left it: 128 bytes in zig-zag order (T.81 figure A.6); kZzInv[natural position] = zig-zag index
+  constexpr int kZzInv[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30, 41, 43, 9,  11, 18, 24, 31, 40, 44, 53,
+                              10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+  uint4 rows[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) rows[r] = ((const uint4 *)c)[r];
+  int16_t cz[64];
+  __builtin_memcpy(cz, rows, 128);
   int ws[64];
 #pragma unroll
   for (int col = 0; col < 8; ++col) {
     int in[8], o[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) in[r] = (int)c[r * 8 + col] * (int)q[r * 8 + col];
+    for (int r = 0; r < 8; ++r) in[r] = (int)cz[kZzInv[r * 8 + col]] * (int)q[r * 8 + col];
     idct8(in, o, 13 - 2);
 #pragma unroll
     for (int r = 0; r < 8; ++r) ws[r * 8 + col] = o[r];
