@@ -159,6 +159,42 @@ def cpu_baseline(params, frames_u8, full=False):
     return out
 
 
+PARITY_MIXED = 34          # frames [0, 34) of the timed batch: two of each of the 16 frame families + two fine checkerboards
+PARITY_FRAMES = 48         # ... checked together with the first 14 noise frames behind them
+
+
+def mixed_head_of_batch(size):
+    """(uint8 NHWC frames, labels): what replaces the first PARITY_MIXED noise frames of the timed batch"""
+    from tennis_amd import calib_frames as CF
+    npz = os.path.join(ROOT, "tests", "golden", "jpeg_cases.npz")
+    return CF.mixed_batch(PARITY_MIXED, size, seed=2025, jpeg_npz=npz if os.path.exists(npz) else None, fine=2)
+
+
+def parity_live(enc, x, labels, params32):
+    """Parity of the TIMED encoder instance on the batch it was timed on: one more 256-frame forward of `enc`
+    through the same default kernels, its first PARITY_FRAMES feature rows (mixed families + noise) against oracle/torch_ref.py on
+    the UN-rounded fp32 parameters and the un-rounded normalised input; Dense(11) logits of the frame classifier beside them."""
+    from oracle.torch_ref import TorchDenseNet121
+    from tennis_amd import weights as W
+    n = min(PARITY_FRAMES, x.shape[0])
+    t0 = time.perf_counter()
+    got = enc(x)[:n].cpu().numpy().astype(np.float64)
+    ref = TorchDenseNet121(params32)(normalize_nchw_f32(x[:n])).numpy()
+    wd = W.make_dense_weights(1, 11, 1024, "framemodel0_dense0_")["framemodel0_dense0_weight"].astype(np.float64)
+    e = got - ref
+    el = e @ wd.T
+    lab = list(labels[:n]) + ["noise (device-generated)"] * (n - len(labels[:n]))
+    fams = {}
+    for f in dict.fromkeys(lab):
+        idx = [i for i, l in enumerate(lab) if l == f]
+        fams[f] = round(float(np.abs(e[idx]).max()), 6)
+    return {"frames": n, "values": int(e.size), "bar": 1e-3, "oracle": "oracle/torch_ref.py: fp32 graph, un-rounded fp32 weights and input",
+            "feature_err_max": float(np.abs(e).max()), "feature_err_rms": float(np.sqrt((e ** 2).mean())), "logit_err_max": float(np.abs(el).max()),
+            "values_over_bar": int((np.abs(e) > 1e-3).sum()), "feature_err_by_family": fams,
+            "worst_family": max(fams, key=fams.get), "seconds": round(time.perf_counter() - t0, 2),
+            "how": f"a {x.shape[0]}-frame forward of the timed encoder instance after the timed regions, rows [0, {n}) checked"}
+
+
 class StepLoop:
     """The step / join / all-gather ordering of the timed loop, apart from the GPU so that tests/test_cpu_distributed.py can
     drive exactly this code on gloo with a stand-in encoder (the first multi-GPU run must not be the first time it executes).
@@ -209,6 +245,7 @@ def build_parser():
     ap.add_argument("--no-pipeline", action="store_true", help="join the encoder's two half-batch streams inside every forward (A/B against the pipelined default)")
     ap.add_argument("--plain-rounding", action="store_true", help="seeded weights that are fp16-representable (rounds 1-2's model) instead of "
                     "the calibrated conversion of fp32 weights")
+    ap.add_argument("--no-parity-live", action="store_true", help="skip config.parity_live (the timed encoder's features against the fp32 oracle on 48 frames of the timed batch)")
     ap.add_argument("--no-exact-line", action="store_true", help="skip the extra fenced region that times the exact-weights mode (config.exact_weights_frames_per_sec)")
     ap.add_argument("--exact-weights", action="store_true",
                     help="NOT the headline configuration: un-rounded fp32 conv weights evaluated as hi + lo fp16 pairs "
@@ -247,12 +284,27 @@ def run(argv):
         params = calibrated_fp16_model(params32, None, SIZE, ctx=ctx)     # the built-in calibration frames: the same model on every rank
     enc = DenseNet121Features(params, SIZE, max_batch=args.batch, ctx=ctx, exact_weights=args.exact_weights)
     x = make_frames(args.batch, SIZE, 1234 + rank, dev)
+    mixed_labels = []
+    if args.batch >= PARITY_FRAMES:      # the head of the timed batch is a mix of frame families, so that parity is measured on what is timed
+        mixed, mixed_labels = mixed_head_of_batch(SIZE)
+        x[:len(mixed)] = torch.from_numpy(mixed).to(dev)
     feats = [torch.empty((args.batch, enc.feature_dim), dtype=torch.float32, device=dev) for _ in range(2)]
     gathered = [torch.empty((world * args.batch, enc.feature_dim), dtype=torch.float32, device=dev)
                 for _ in range(2)] if world > 1 else None
     # the exchange step goes through the library's own RCCL communicator (tn_allgather_features); torch.distributed only
     # carries the barrier and the max over ranks of the timing
     comm = sharding.feature_comm(dev) if world > 1 else None      # (comm.bring_up: agreed fall-back to torch's RCCL communicator)
+    # what every rank's communicator says about itself (tn_comm_world = ncclCommCount, tn_comm_device = ncclCommCuDevice): the
+    # record of an N-GPU run shows that RCCL saw N ranks on N devices, not only that the launcher asked for them
+    comm_record = None
+    if world > 1:
+        mine = dict(comm.describe(), launcher_rank=rank, local_rank=int(os.environ.get("LOCAL_RANK", dev.index)), cuda_device=dev.index,
+                    gpu=torch.cuda.get_device_name(dev), pid=os.getpid())
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        comm_record = {"world_launched": world, "world_reported_by_rccl": sorted({r["world"] for r in allr}),
+                       "ranks_reported": sorted(r["rank"] for r in allr), "devices": [r["device"] for r in sorted(allr, key=lambda r: r["launcher_rank"])],
+                       "all_through_rccl": all(r["rccl"] for r in allr), "per_rank": sorted(allr, key=lambda r: r["launcher_rank"])}
     # Pipelined forwards (tn_densenet121_set_pipelined): the encoder runs a batch as two half batches on two streams, and
     # the last chained block of the second half occupies half of the CUs; without a join inside forward the next step's
     # first half starts beside it.  Results are ordered by the caller (StepLoop): the all-gather of step i is issued one step
@@ -358,6 +410,10 @@ def run(argv):
                     "encoder_frac_of_mfma_peak": round(enc_tf / MFMA_PEAK_TFLOPS, 4),
                     "compulsory_bytes_per_step": int(COMPULSORY_BYTES_PER_FRAME * args.batch + WEIGHT_BYTES),
                     "layerwise_bytes_per_step": round(sum(v["bytes"] for v in fams.values()) / NPROF)}
+        live = None
+        if not args.no_parity_live and args.batch >= PARITY_FRAMES:
+            enc.set_pipelined(False)
+            live = parity_live(enc, x, mixed_labels, params32)
         out = {"metric": "frames/sec DenseNet-121 224x224 feature-extract", "value": round(fps, 1),
                "unit": "frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
@@ -365,7 +421,9 @@ def run(argv):
                "config": {"workload": "DenseNet-121 frame feature-extract, batch 256 synthetic 224x224x3 "
                                       "(BASELINE.json configs[1])",
                           "frames_per_step_per_gpu": args.batch,
-                          "input": "NHWC uint8 decoded frames, HBM-resident (ToTensor + Normalize inside the stem); every step re-reads the SAME "
+                          "input": "NHWC uint8 decoded frames, HBM-resident (ToTensor + Normalize inside the stem); "
+                                   + (f"frames [0, {len(mixed_labels)}) are two of each of the 16 frame families + two fine checkerboards (what config.parity_live checks), the rest uniform noise; " if mixed_labels else "uniform noise; ")
+                                   + "every step re-reads the SAME "
                                    f"{args.batch * SIZE * SIZE * 3 / 1e6:.1f} MB buffer, which fits the 256 MB Infinity Cache: the stem's HBM read is not exercised (about 1 % of the step)",
                           "output": "fp32 features (B,1024)" + ("; RCCL all-gather of feature rows" if world > 1 else ""),
                           "weights": ("seeded random-init, fp32 conv weights as hi + lo fp16 pairs (exact-weights mode, 2x MFMA work "
@@ -374,7 +432,9 @@ def run(argv):
                                            "seeded random-init fp32 conv weights (not fp16-representable: what a trained checkpoint looks like), converted to ONE fp16 "
                                            "number per weight by calibrated rounding against the library's built-in calibration frames with bias correction "
                                            "(tennis_amd/calibrate.py, weights.as_fp16_model)"),
+                          "parity_live": live,
                           "parity": (parity_note() if not (args.exact_weights or args.plain_rounding) else None),
+                          "comm": comm_record,
                           "exchange": (comm.transport + f", all-gather of {args.batch} x {enc.feature_dim} fp32 rows per rank and step") if comm is not None else "none (1 rank)",
                           "timing": f"median of {repeats} fenced regions of exactly {args.steps} steps" + (", forwards pipelined (results joined one step behind, all joined before the closing fence)" if pipelined else ""),
                           "region_ms": [round(t * 1e3, 2) for t in times],

@@ -317,8 +317,13 @@ typedef struct tn_comm tn_comm;
 int tn_comm_unique_id(void *id_out /* TN_UNIQUE_ID_BYTES */);
 int tn_comm_create(tn_ctx *ctx, int rank, int world, const void *unique_id /* NULL for world 1 */, int flags,
                    tn_comm **out);
+/* What the communicator itself reports (with RCCL behind the handle: ncclCommUserRank / ncclCommCount / ncclCommCuDevice, so a
+ * record of an N-GPU run shows that RCCL saw N ranks - the reference's counterpart is len(ctx) at evaluate.py:84-85); -1 when RCCL
+ * refuses the query.  tn_comm_uses_rccl: 0 for the world-1 short cut that needs no RCCL. */
 int tn_comm_rank(const tn_comm *c);
 int tn_comm_world(const tn_comm *c);
+int tn_comm_device(const tn_comm *c);
+int tn_comm_uses_rccl(const tn_comm *c);
 /* out (world*rows, F) = rank-major concatenation of every rank's shard (rows, F); equal `rows` on every rank (pad the last
  * round, sharding.local_rows); shard may alias its own slot of out. */
 int tn_allgather_features(tn_comm *c, const float *shard, int rows, int F, float *out);

@@ -123,6 +123,8 @@ _SIGS = {
     "tn_comm_create": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.POINTER(_P)]),
     "tn_comm_rank": (C.c_int, [_P]),
     "tn_comm_world": (C.c_int, [_P]),
+    "tn_comm_device": (C.c_int, [_P]),
+    "tn_comm_uses_rccl": (C.c_int, [_P]),
     "tn_allgather_features": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "tn_allreduce_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_int]),
     "tn_allreduce_i64": (C.c_int, [_P, _P, C.c_size_t]),

@@ -185,3 +185,55 @@ def default_calibration_frames(size: int = 224, n: int = 28, seed: int = 4321) -
     with real frames of the footage to be processed should ADD those (calibrate(frames) concatenates)."""
     per = [(n + len(FAMILIES) - 1 - i) // len(FAMILIES) for i in range(len(FAMILIES))]
     return np.concatenate([frames(f, k, size, seed) for f, k in zip(FAMILIES, per) if k > 0])
+
+
+def fine_checkerboards(n: int, size: int = 224, seed: int = 0) -> np.ndarray:
+    """Full-contrast checkerboards with cells of 2, 3 and 1 px in turn: the frames on which the calibrated fp16 conversion is
+    weakest (round 5, profiles/r05_parity_wide.json: an exactly periodic pattern makes the same weight-rounding error in every
+    pixel of a phase).  Colours black / white or two saturated primaries, random phase."""
+    rng = np.random.default_rng([seed, 977])
+    t = np.arange(size)
+    out = np.empty((n, size, size, 3), np.uint8)
+    pal = np.array([[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0], [0, 255, 255], [255, 0, 255]], np.uint8)
+    for i in range(n):
+        p = (2, 3, 1)[i % 3]
+        oy, ox = rng.integers(0, 2 * p, 2)
+        m = ((((t[:, None] + oy) // p) + ((t[None, :] + ox) // p)) & 1).astype(bool)
+        c0, c1 = (pal[0], pal[1]) if i % 2 == 0 else pal[rng.choice(len(pal), 2, replace=False)]
+        out[i] = np.where(m[..., None], c1, c0)
+    return out
+
+
+def frames_from_npz(path: str, n: int, size: int = 224, skip: int = 0) -> np.ndarray:
+    """``n`` frames made of the decoded RGB images of an ``.npz`` of fixtures (keys ending in ``__rgb``, e.g. the repo's
+    tests/golden/jpeg_cases.npz): enlarged 2-4x (nearest neighbour) and tiled to ``size`` x ``size``."""
+    z = np.load(path)
+    imgs = [z[k] for k in sorted(z.files) if k.endswith("__rgb") and z[k].shape[0] >= 24]
+    out = []
+    for i in range(skip, skip + n):
+        im = imgs[i % len(imgs)]
+        k = 2 + i % 3
+        big = np.repeat(np.repeat(im, k, 0), k, 1)
+        reps = (-(-size // big.shape[0]), -(-size // big.shape[1]), 1)
+        out.append(np.tile(big, reps)[:size, :size])
+    return np.ascontiguousarray(np.stack(out))
+
+
+def mixed_batch(n: int, size: int = 224, seed: int = 0, jpeg_npz: str | None = None, fine: int | None = None):
+    """``n`` frames dealt over every family (calibration families, held-out families, ``jpeg`` when a fixture file is given) plus
+    ``fine`` fine checkerboards (default n // 16): the content mix the parity of the timed configuration is measured on (VERDICT r5
+    item 1).  Returns ``(frames uint8 NHWC, labels)`` with ``labels[i]`` the family of frame i."""
+    fams = FAMILIES + HELD_OUT + (["jpeg"] if jpeg_npz else [])
+    fine = n // 16 if fine is None else fine
+    rest = n - fine
+    per = [(rest + len(fams) - 1 - i) // len(fams) for i in range(len(fams))]
+    parts, labels = [], []
+    for f, k in zip(fams, per):
+        if k <= 0:
+            continue
+        parts.append(frames_from_npz(jpeg_npz, k, size, skip=seed % 7) if f == "jpeg" else frames(f, k, size, seed))
+        labels += [f] * k
+    if fine > 0:
+        parts.append(fine_checkerboards(fine, size, seed))
+        labels += ["finechecker"] * fine
+    return np.ascontiguousarray(np.concatenate(parts)), labels

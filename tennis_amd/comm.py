@@ -105,6 +105,11 @@ class Comm:
             raise TypeError(f"comm.allreduce_: unsupported dtype {buf.dtype}")
         return self._leave()
 
+    def describe(self) -> dict:
+        """what the communicator reports about itself (RCCL's own answers when RCCL is behind the handle: tn_comm_world = ncclCommCount ...)"""
+        return {"transport": self.transport, "rank": int(self.lib.tn_comm_rank(self.handle)), "world": int(self.lib.tn_comm_world(self.handle)),
+                "device": int(self.lib.tn_comm_device(self.handle)), "rccl": bool(self.lib.tn_comm_uses_rccl(self.handle))}
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.tn_comm_destroy(self.handle)
@@ -146,6 +151,11 @@ class GroupComm:
             w.wait()
             buf /= self.world
         return self._Work(w)
+
+    def describe(self) -> dict:
+        import torch
+        return {"transport": self.transport, "rank": self.rank, "world": self.world,
+                "device": torch.cuda.current_device() if torch.cuda.is_available() else -1, "rccl": self._dist.get_backend(self.group) == "nccl"}
 
     def close(self):
         pass

@@ -245,6 +245,8 @@ struct tn_encoder {
   int PH, PW;
   f16 *stem_wp, *stem_wp_zf, *stem_wp_zf_lo = nullptr;
   float *stem_scale, *stem_shift, *stem_shift_u8;
+  float *stem_floor = nullptr;                               // centred stem output (round 6): the ReLU's floor -m_c on the device
+  std::vector<float> stem_centre;                            // m_c on the host (read_tap / input_means add it back)
   struct DenseLayer { float *s1, *t1; f16 *w1; float *s2, *t2; f16 *w3p; int cin; f16 *w1s = nullptr, *w3s = nullptr; };   // w1s / w3s: fragment images of the strip kernel
   std::vector<DenseLayer> layers[4];
   struct Trans { float *s, *t; f16 *w; int cin, cout; } trans[3];
@@ -341,6 +343,33 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
   }
 
   std::vector<float> s, t;
+  // ---- centred stem output (round 6) ----
+  // The pooled stem map is what every dense layer of block 1 and the first transition read, through a BatchNorm each.  Stored
+  // as it is, a channel whose values sit many standard deviations from zero loses its information to fp16's RELATIVE precision:
+  // the extreme case is a (near-)dead channel of batchnorm0 (gamma ~ 0: the output is the constant relu(beta)), whose
+  // consumers normalise with a running variance at the epsilon floor - scale gamma / sqrt(1e-5) = 316 gamma on the rounding
+  // error of a constant, 1e-2 on the features of EVERY frame (tests/tools/trained_like.py, scripts/round_study.py).  All of a
+  // channel's consumers carry an estimate of its mean, their running_mean; the map is stored as relu(bn(conv)) - m_c with m_c
+  // their average, and the constant goes into the consumers' shifts, shift' = shift + scale m_c (exact: no kernel knows).
+  e->stem_centre.assign(64, 0.f);
+  if (getenv("TN_NO_STEM_CENTRE") == nullptr) {
+    std::vector<double> acc(64, 0.0);
+    int cnt = 0;
+    for (int l = 0; l <= kBlockCfg[0]; ++l) {
+      const std::string bn = l < kBlockCfg[0] ? pre + "stage1_batchnorm" + std::to_string(2 * l) : pre + "batchnorm1";
+      const float *mu = pm.get(bn + "_running_mean", l < kBlockCfg[0] ? 64 + 32 * l : 64 + 32 * kBlockCfg[0]);
+      if (!mu) return fail(TN_ERR_MISSING);
+      for (int c = 0; c < 64; ++c) acc[c] += mu[c];
+      ++cnt;
+    }
+    for (int c = 0; c < 64; ++c) {
+      const float m = (float)(acc[c] / cnt);
+      e->stem_centre[c] = std::isfinite(m) ? m : 0.f;
+    }
+  }
+  auto centre_shift = [&](std::vector<float> &sc, std::vector<float> &sh) {       // a consumer of block 1's channels 0 .. 63
+    for (int c = 0; c < 64; ++c) sh[c] = (float)((double)sh[c] + (double)sc[c] * (double)e->stem_centre[c]);
+  };
   {  // stem: conv0 + batchnorm0
     const float *w0 = pm.get(pre + "conv0_weight", 64 * 3 * 7 * 7);
     if (!w0 || !fold_bn(pm, pre + "batchnorm0", 64, s, t)) return fail(TN_ERR_MISSING);
@@ -374,9 +403,16 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
       }
       e->stem_wp_zf_lo = e->pool.upload(pack_stem(lo.data(), true));
     }
+    std::vector<float> fl(64);
+    for (int n = 0; n < 64; ++n) {
+      t[n] = (float)((double)t[n] - (double)e->stem_centre[n]);
+      tu[n] = (float)((double)tu[n] - (double)e->stem_centre[n]);
+      fl[n] = -e->stem_centre[n];
+    }
     e->stem_scale = e->pool.upload(s);
     e->stem_shift = e->pool.upload(t);
     e->stem_shift_u8 = e->pool.upload(tu);
+    e->stem_floor = e->pool.upload(fl);
   }
   e->zeros128 = e->pool.upload(std::vector<float>(128, 0.0f));
   e->ones128 = e->pool.upload(std::vector<float>(128, 1.0f));
@@ -395,12 +431,16 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
       const float *w3 = pm.get(sp + "conv" + std::to_string(2 * l + 1) + "_weight", 32 * 128 * 9);
       if (!w1 || !w3) return fail(TN_ERR_MISSING);
       if (!fold_bn(pm, sp + "batchnorm" + std::to_string(2 * l), L.cin, s, t)) return fail(TN_ERR_MISSING);
+      if (b == 0) centre_shift(s, t);
       // BN1 + ReLU as relu(s x + t) = sw clamp(x, lo, hi) + tc with lo, hi fp16 numbers (calib_host.hip::bn_relu_clamp_fold: no
       // arithmetic and no rounding in front of the 1x1); every kernel of the layer gets (lo, hi) as its constants, sw[k] w[n][k] as
       // its weights and sum_k w[n][k] tc[k] inside BN2's shift
       std::vector<float> sw1(L.cin), tc1(L.cin);
       bn_relu_clamp_fold(std::vector<float>(s).data(), std::vector<float>(t).data(), L.cin, s.data(), t.data(), sw1.data(), tc1.data());
       L.s1 = e->pool.upload(s); L.t1 = e->pool.upload(t);
+      // x0[k] = clamp(0, lo, hi): the operand's value on the CLIPPED side of a channel whose ReLU is off at x = 0 (round 6, below)
+      std::vector<float> x0(L.cin);
+      for (int k = 0; k < L.cin; ++k) x0[k] = std::fmin(std::fmax(0.f, s[k]), t[k]);
       if (pack7) { h7[1].push_back(s); h7[2].push_back(t); h7w3.push_back(w3); }
       // The scale of the BatchNorm BEHIND the 1x1 convolution is folded into its weights before they are rounded to fp16
       // (or split into hi + lo): bn2(conv(a)) = conv'(a) + shift with w'[n][k] = scale[n] w[n][k].  That is how the fp16
@@ -409,15 +449,28 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
       if (!fold_bn(pm, sp + "batchnorm" + std::to_string(2 * l + 1), 128, s, t)) return fail(TN_ERR_MISSING);
       std::vector<float> w1f((size_t)128 * L.cin);
       bool in_range = true;
+      // The constant of the clamp form, sum_k w[n][k] tc[k], is computed here in double from the exact weights, while the matrix
+      // pipe multiplies the ROUNDED folded weight with clamp(x).  On the clipped side of a channel the two have to cancel
+      // (sw lo + tc = 0), and they only do so to the precision of the rounded weight times |lo|: a near-dead BatchNorm channel
+      // with a negative shift (scale 1e-5, threshold 1e4, folded weight in fp16's subnormals) left 3e-4 per weight that way
+      // (scripts/dead_debug.py: 4.8e-3 on the features in the exact-weights mode).  Round 6: the operand is split at
+      // x0 = clamp(0, lo, hi) - sw clamp(x) + tc = sw (clamp(x) - x0) + (tc + sw x0) - and the x0 part of the matrix product is
+      // taken out of the shift with the SAME rounded weights the pipe uses: what is left of a weight's rounding error multiplies
+      // clamp(x) - x0 (zero on the clipped side), what the exact weights multiply is tc + sw x0 (= s (x0 - c): no cancellation).
       for (int n = 0; n < 128; ++n) {
-        double bias = 0.0;
+        double bias = 0.0, corr = 0.0;
         for (int k = 0; k < L.cin; ++k) {
           const float wf = s[n] * sw1[k] * w1[(size_t)n * L.cin + k];
           w1f[(size_t)n * L.cin + k] = wf;
           in_range = in_range && std::fabs(wf) <= 65504.0f;
-          bias += (double)w1[(size_t)n * L.cin + k] * (double)tc1[k];
+          bias += (double)w1[(size_t)n * L.cin + k] * ((double)tc1[k] + (double)sw1[k] * (double)x0[k]);
+          if (x0[k] != 0.f) {
+            const float hi = (float)(f16)wf;
+            const double weff = e->exact ? (double)hi + (double)(float)(f16)(wf - hi) : (double)hi;      // what the kernels multiply (split_hi_lo_rows / to_f16)
+            corr += weff * (double)x0[k];
+          }
         }
-        t[n] = (float)((double)t[n] + (double)s[n] * bias);
+        t[n] = (float)((double)t[n] + (double)s[n] * bias - corr);
       }
       if (!in_range) { tn_set_error("a 1x1 weight leaves the fp16 range once its BatchNorm scales are folded in (" + sp + "conv" + std::to_string(2 * l) + ")"); return fail(TN_ERR_INVALID); }
       if (e->exact) {
@@ -481,6 +534,7 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
       T.cin = e->Cb[b]; T.cout = e->Cb[b] / 2;
       const float *wt = pm.get(pre + "conv" + std::to_string(outer) + "_weight", (int64_t)T.cout * T.cin);
       if (!wt || !fold_bn(pm, pre + "batchnorm" + std::to_string(outer), T.cin, s, t)) return fail(TN_ERR_MISSING);
+      if (b == 0) centre_shift(s, t);
       T.s = e->pool.upload(s); T.t = e->pool.upload(t);
       T.w = e->exact ? e->pool.upload(split_hi_lo_rows(wt, T.cout, T.cin, T.cin))
                      : e->pool.upload(to_f16(wt, (size_t)T.cout * T.cin));
@@ -545,6 +599,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
     StemArgs a{x, (int)layout, B, e->H, e->W, e->stem_wp, e->stem_wp_zf, e->stem_scale, e->stem_shift, stem_out, e->Hs, e->Ws};
     a.shift_u8 = e->stem_shift_u8;
     a.wp_zf_lo = e->stem_wp_zf_lo;
+    a.floor = e->stem_floor;
     const double px = fB * e->Hs * e->Ws;
     if (e->fuse) {
       tm.begin("stem_conv_bn_relu_maxpool", 2.0 * px * 64 * 147, fB * e->H * e->W * 3 * 2 + fB * e->Hb[0] * e->Wb[0] * 64 * 2);
@@ -557,7 +612,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
       tm.end();
       if (rc) return rc;
       tm.begin("maxpool3x3s2", 0.0, px * 64 * 2 + fB * e->Hb[0] * e->Wb[0] * 64 * 2);
-      rc = launch_maxpool3x3s2(stem_out, B, e->Hs, e->Ws, 64, bbuf[0], e->Cb[0], e->Hb[0], e->Wb[0], s);
+      rc = launch_maxpool3x3s2(stem_out, B, e->Hs, e->Ws, 64, bbuf[0], e->Cb[0], e->Hb[0], e->Wb[0], s);      // (the stem map is centred already: max commutes with the constant)
       tm.end();
       if (rc) return rc;
     }
@@ -819,6 +874,13 @@ extern "C" int tn_densenet121_input_means(tn_encoder *e, const void *x, tn_layou
   int rc = encoder_run_range(e, x, layout, 0, batch, feat, s, tm);
   if (!rc && hipMemcpyAsync(means_host, dev, sizeof(float) * n, hipMemcpyDeviceToHost, s) != hipSuccess) rc = TN_ERR_HIP;
   if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = TN_ERR_HIP;
+  if (!rc) {      // block 1's 1x1 operands are clamps of the CENTRED stem channels: hand out the means in the reference graph's units
+    int64_t o = 0;
+    for (auto &L : e->layers[0]) {
+      for (int c = 0; c < 64; ++c) means_host[o + c] += e->stem_centre[c];
+      o += L.cin + 128;
+    }
+  }
   release();
   if (rc == TN_ERR_HIP) tn_set_error("tn_densenet121_input_means: HIP error");
   e->last_batch = batch;
@@ -855,8 +917,10 @@ extern "C" int tn_densenet121_read_tap(tn_encoder *e, const char *tap_c, int bat
   TN_HIP_CHECK(hipStreamSynchronize(e->ctx->stream));
   std::vector<f16> tmp(px * ld);
   TN_HIP_CHECK(hipMemcpy(tmp.data(), src, tmp.size() * sizeof(f16), hipMemcpyDeviceToHost));
+  // (the stem's output is stored centred: the tap hands out the values the reference's graph has)
+  const bool centred = tap == "stem" || tap == "pool0" || tap == "stage1";
   for (size_t p = 0; p < px; ++p)
-    for (int c = 0; c < cc; ++c) out_host[p * cc + c] = (float)tmp[p * ld + c];
+    for (int c = 0; c < cc; ++c) out_host[p * cc + c] = (float)tmp[p * ld + c] + (centred && c < 64 ? e->stem_centre[c] : 0.f);
   return TN_OK;
 }
 

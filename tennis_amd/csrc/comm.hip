@@ -32,6 +32,9 @@ struct Rccl {
   int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
+  int (*CommCount)(const ncclComm_t, int *) = nullptr;         // what the communicator itself says: ranks, this rank, its device
+  int (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+  int (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
   std::string error;
 };
 
@@ -57,6 +60,9 @@ Rccl *rccl() {
     TN_SYM(AllGather, "ncclAllGather")
     TN_SYM(AllReduce, "ncclAllReduce")
     TN_SYM(GetErrorString, "ncclGetErrorString")
+    TN_SYM(CommCount, "ncclCommCount")
+    TN_SYM(CommUserRank, "ncclCommUserRank")
+    TN_SYM(CommCuDevice, "ncclCommCuDevice")
 #undef TN_SYM
   });
   return &r;
@@ -120,8 +126,27 @@ extern "C" int tn_comm_create(tn_ctx *ctx, int rank, int world, const void *uniq
   return TN_OK;
 }
 
-extern "C" int tn_comm_rank(const tn_comm *c) { return c ? c->rank : 0; }
-extern "C" int tn_comm_world(const tn_comm *c) { return c ? c->world : 1; }
+// With an RCCL communicator behind the handle the answers are RCCL's own (ncclCommUserRank / ncclCommCount / ncclCommCuDevice):
+// a record of an N-GPU run can show that the library saw N ranks, not only that the launcher asked for them.
+extern "C" int tn_comm_rank(const tn_comm *c) {
+  if (!c) return 0;
+  int v = c->rank;
+  if (c->nccl && rccl()->CommUserRank(c->nccl, &v) != kNcclSuccess) return -1;
+  return v;
+}
+extern "C" int tn_comm_world(const tn_comm *c) {
+  if (!c) return 1;
+  int v = c->world;
+  if (c->nccl && rccl()->CommCount(c->nccl, &v) != kNcclSuccess) return -1;
+  return v;
+}
+extern "C" int tn_comm_device(const tn_comm *c) {
+  if (!c) return -1;
+  int v = c->ctx->device;
+  if (c->nccl && rccl()->CommCuDevice(c->nccl, &v) != kNcclSuccess) return -1;
+  return v;
+}
+extern "C" int tn_comm_uses_rccl(const tn_comm *c) { return c && c->nccl ? 1 : 0; }
 
 extern "C" int tn_comm_destroy(tn_comm *c) {
   if (!c) return TN_OK;

@@ -289,6 +289,10 @@ struct StemArgs {
   int Ho, Wo;
   const float *shift_u8 = nullptr;   // the shift for TN_LAYOUT_NHWC_U8 input (carries the constant of the integer staging, see above)
   const f16 *wp_zf_lo = nullptr;     // exact-weights mode: the lo halves of the weights (w = hi + lo), same fragment layout as wp_zf
+  // Round 6: the pooled map is stored CENTRED, relu(bn(conv)) - m_c, with m_c the channel's mean as the consuming BatchNorms
+  // know it (api.hip "centred stem output").  The kernels get `shift` / `shift_u8` with m_c already subtracted and the ReLU's
+  // floor -m_c here (max pool and ReLU commute with the subtraction: max(v - m, -m) = relu(v) - m); nullptr: floor 0.
+  const float *floor = nullptr;      // [64]
 };
 int launch_stem(const StemArgs &a, hipStream_t s);
 // fused stem + maxpool: writes the pooled map (Hp x Wp x 64) at row stride ldy

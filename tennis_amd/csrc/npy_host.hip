@@ -5,6 +5,7 @@
 // writes NumPy format 1.0 files byte for byte as np.save does, fed batch by batch while the GPU encodes the next one.
 // Pure host code (no GPU needed): tests/test_cpu_oracle.py compares the files with np.save's.
 #include <fcntl.h>
+#include <stdio.h>      // renameat2, RENAME_NOREPLACE
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -118,7 +119,18 @@ struct tn_npy_writer {
     if (j.skip_existing) {
       // another writer may have completed the same file meanwhile: link() fails with EEXIST instead of replacing it
       if (link(tmp.c_str(), path.c_str()) != 0) {
-        const int e = errno;
+        int e = errno;
+        // file systems without hard links (FAT / exFAT, several FUSE, object-store and SMB mounts: EPERM / ENOTSUP / EMLINK / EXDEV):
+        // an atomic no-replace rename where the kernel has one, else "is it there?" + rename (every row failed there)
+        if (e == EPERM || e == ENOTSUP || e == EOPNOTSUPP || e == EMLINK || e == EXDEV || e == ENOSYS) {
+          if (renameat2(AT_FDCWD, tmp.c_str(), AT_FDCWD, path.c_str(), RENAME_NOREPLACE) == 0) { ++written; return; }
+          e = errno;
+          if (e != EEXIST) {
+            if (access(path.c_str(), F_OK) == 0) e = EEXIST;
+            else if (rename(tmp.c_str(), path.c_str()) == 0) { ++written; return; }
+            else e = errno;
+          }
+        }
         unlink(tmp.c_str());
         if (e == EEXIST) { ++skipped; return; }
         fail("cannot publish " + path + ": " + strerror(e));

@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
         for (int nf = 0; nf < 4; ++nf) {
           f16x4 h;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h[r] = (f16)fmaxf(fmaf(acc[mf][nf][r], sc[nf][r], sh[nf][r]), 0.f);
+          for (int r = 0; r < 4; ++r)       // (the ReLU's floor is -m_c of the centred output: StemArgs::floor)
+            h[r] = (f16)fmaxf(fmaf(acc[mf][nf][r], sc[nf][r], sh[nf][r]), a.floor ? a.floor[nf * 16 + kc * 4 + r] : 0.f);
           *(f16x4 *)(dst + nf * 16) = h;
         }
       }

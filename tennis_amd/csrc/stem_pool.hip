@@ -148,13 +148,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf) wl[ky][nf] = ((const f16x8 *)a.wp_zf_lo)[(ky * 4 + 2 * nh + nf) * 64 + lane];
   }
-  float sc[2][4], sh[2][4];
+  float sc[2][4], sh[2][4], fl[2][4];          // fl: the ReLU's floor, -m_c of the centred output (StemArgs::floor), 0 without it
 #pragma unroll
   for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       sc[nf][r] = a.scale[(2 * nh + nf) * 16 + kc * 4 + r];
       sh[nf][r] = (LAY == TN_LAYOUT_NHWC_U8 ? a.shift_u8 : a.shift)[(2 * nh + nf) * 16 + kc * 4 + r];
+      fl[nf][r] = a.floor ? a.floor[(2 * nh + nf) * 16 + kc * 4 + r] : 0.f;
     }
 
   // input patch staging, split in two halves so the loads of the next tile fly during the MFMAs of this one:
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
         if constexpr (BORDER) {
           const bool valid = cvalid && (unsigned)(cy0 + r) < (unsigned)a.Ho;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) b[j] = valid ? b[j] : 0.f;
+          for (int j = 0; j < 4; ++j) b[j] = valid ? b[j] : fl[nf][j];
         }
         if (r == 0) {
 #pragma unroll
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((VEC && LAY
           return;
         }
         *(float4 *)(vtile + ((r / 2 - 1) * CC + c) * CPX + nh * 128 + nf * 64 + kc * 16) =
-            make_float4(fmax_raw(x[0], 0.f), fmax_raw(x[1], 0.f), fmax_raw(x[2], 0.f), fmax_raw(x[3], 0.f));
+            make_float4(fmax_raw(x[0], fl[nf][0]), fmax_raw(x[1], fl[nf][1]), fmax_raw(x[2], fl[nf][2]), fmax_raw(x[3], fl[nf][3]));
 #pragma unroll
         for (int j = 0; j < 4; ++j) m[nf][j] = b[j];
       };

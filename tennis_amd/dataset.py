@@ -54,8 +54,9 @@ class TennisSet:
         ``tennis_amd.captions.CaptionSet`` (same arguments, same sample tuple); the frame / window branch is this class."""
         if captions and cls is TennisSet:
             from .captions import CaptionSet
-            names = ("transform", "split", "every", "balance", "padding", "stride", "window", "model_id", "split_id", "flow",
-                     "max_cap_len", "vocab", "inference", "feats_model", "save_feats")
+            # (positional arguments behind `captions`, in __init__'s own order: derived, so that the two cannot drift - ADVICE r5)
+            import inspect
+            names = tuple(inspect.signature(TennisSet.__init__).parameters)[3:]
             kw = dict(zip(names, args))
             kw.update(kwargs)
             if kw.get("flow"):
@@ -74,6 +75,9 @@ class TennisSet:
                  video_length=None, decode="host"):
         if flow:
             raise NotImplementedError("optical-flow input is outside the accelerated hot path (SURVEY §2a)")
+        if captions:      # __new__ redirects TennisSet(captions=True) to CaptionSet and never gets here; a subclass / object.__new__ path does
+            raise NotImplementedError("caption mode is served by tennis_amd.captions.CaptionSet: construct TennisSet(captions=True, ...) "
+                                      "itself (not a subclass), or CaptionSet directly")
         self._root = root
         self._captions = captions
         self._split = split

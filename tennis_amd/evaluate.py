@@ -75,6 +75,26 @@ class NpyWriter:
         self._lib.check(self.lib.tn_npy_writer_submit(self.handle, rows.ctypes.data_as(C.c_void_p), rows.shape[0], rows.shape[1], arr,
                                                       1 if skip_existing else 0), "tn_npy_writer_submit")
 
+    @staticmethod
+    def sweep_stale(root: str, older_than_s: float = 600.0) -> int:
+        """A run that is killed mid-write leaves ``<frame>.npy.tmp.<pid>.<thread>`` files behind (never a truncated ``.npy``:
+        files are published by link / rename of a finished temporary).  Removes those under ``root`` that nobody has touched for
+        ``older_than_s`` seconds (a live writer's temporaries are younger); -> the number removed.  Called by ``save_features`` on
+        the feature directory before it writes."""
+        import time
+        n, now = 0, time.time()
+        for d, _dirs, files in os.walk(root):
+            for f in files:
+                if ".npy.tmp." in f:
+                    p = os.path.join(d, f)
+                    try:
+                        if now - os.path.getmtime(p) > older_than_s:
+                            os.unlink(p)
+                            n += 1
+                    except OSError:
+                        pass
+        return n
+
     def drain(self):
         """waits for everything submitted; -> (files written, files skipped) since the last drain"""
         C = self._C
@@ -101,6 +121,8 @@ def save_features(net, loader, dataset, ctx=None, verbose=True):
     frame at save_feature_path(idx), skipped when the file already exists.  The files are written by ``NpyWriter``'s threads
     behind the next batch's encode (round 4); the count returned is the number of files that did not exist."""
     writer = NpyWriter()
+    if os.path.isdir(getattr(dataset, "feat_dir", "") or ""):
+        NpyWriter.sweep_stale(dataset.feat_dir)
     pending = None          # (features on the device, paths) of the batch before: copied to the host and handed to the writer
                             # AFTER the next batch's forward has been queued, so that the copy waits for nothing but its own batch
 

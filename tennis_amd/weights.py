@@ -251,6 +251,17 @@ def as_fp16_model(params: dict, input_means: dict | None = None, bias_correction
     import re
     out = dict(params)
     bias, prefix = {}, None
+    # The vector feedback is centred (its constraints are the frames' DEVIATIONS from the mean operand) only if the mean error it then
+    # ignores is really taken out by _apply_bias_correction - which needs the whole DenseNet-121 tree under one prefix (a
+    # partial dict used to get the centring without the correction)
+    stem_keys = [k for k in params if k.endswith("conv0_weight") and getattr(params[k], "shape", (0,))[1:] == (3, 7, 7)]
+    can_correct = bool(bias_correction and stem_keys and all(
+        (stem_keys[0][:-len("conv0_weight")] + f"stage{st}_batchnorm{2 * l}_running_mean") in params for st in range(1, 5) for l in range(BLOCK_CONFIG[st - 1])))
+    if bias_correction and input_means is not None and not can_correct and any(np.asarray(v).ndim == 2 for v in input_means.values()):
+        import warnings
+        warnings.warn("as_fp16_model: not a complete DenseNet-121 parameter tree - bias correction (and the centring of the calibration "
+                      "constraints that goes with it) is off", RuntimeWarning, stacklevel=2)
+    bias_correction = can_correct
     for k, v in params.items():
         if not (k.endswith("_weight") and v.ndim == 4):
             continue
@@ -270,7 +281,18 @@ def as_fp16_model(params: dict, input_means: dict | None = None, bias_correction
             # 1 / (255 std_c) is part of the weight that is rounded (csrc/common.h "the stem's operand")
             s = STEM_WFACTOR.reshape(1, 3, 1, 1)
             prefix = k[:-len("conv0_weight")]
-        folded = (v * s).astype(np.float32) if s is not None else v.astype(np.float32)
+        with np.errstate(over="ignore", invalid="ignore"):
+            folded = (v * s).astype(np.float32) if s is not None else v.astype(np.float32)
+        # the library refuses such a model at create ("a 1x1 weight leaves the fp16 range", csrc/api.hip): the conversion must not
+        # hand out inf / NaN weights silently - nor let the oracle and a saved checkpoint carry them
+        amax = float(np.abs(folded).max()) if folded.size else 0.0
+        if not np.isfinite(amax) or amax > 65504.0:
+            raise ValueError(f"as_fp16_model: {k} leaves the fp16 range once its BatchNorm scales are folded in (max |w| = {amax:.3g}); "
+                             "serve this checkpoint with exact_weights=True")
+        lost = int(((folded != 0) & (np.abs(folded) < 2.0 ** -25)).sum())
+        if lost > max(8, folded.size // 1000):       # (a stray weight below 3e-8 is chance; a flushed column is a tiny BatchNorm scale)
+            import warnings
+            warnings.warn(f"as_fp16_model: {lost} non-zero weights of {k} round to 0 in fp16 (folded magnitude below 2^-25)", RuntimeWarning, stacklevel=2)
         if input_means is not None and k in input_means:
             am = np.asarray(input_means[k], np.float64)     # mean of the convolution's operand per input channel (per frame)
             taps = v.shape[2] * v.shape[3]
@@ -284,7 +306,12 @@ def as_fp16_model(params: dict, input_means: dict | None = None, bias_correction
         else:
             r = folded.astype(np.float16).astype(np.float32)
         if s is not None:
-            out[k] = np.where(s != 0, r / np.where(s != 0, s, 1), v).astype(np.float32)
+            # Below fp16's normal range (a near-dead BatchNorm channel: scale 1e-5) the rounded value keeps only a few bits, and
+            # un-folding it would hand the library - which also needs w[n][k] EXACTLY, for the constant tc[k] w[n][k] of the clamp
+            # form - a weight that is up to 100 % off (round 6, scripts/dead_debug.py: 8e-3 on the features).  Those weights stay
+            # as they are: what the matrix pipe multiplies is then fp16(s w), 3e-8 off at most.
+            keep = (s == 0) | (np.abs(folded) < 2.0 ** -14)
+            out[k] = np.where(keep, v, r / np.where(s != 0, s, 1)).astype(np.float32)
         else:
             out[k] = r
         if bias_correction and input_means is not None and k in input_means and np.asarray(input_means[k]).ndim == 2:

@@ -94,3 +94,18 @@ def test_a_file_appears_under_its_name_only_when_complete(tmp_path):
     finally:
         os.chmod(ro, 0o755)
         w.close()
+
+
+def test_stale_temporaries_are_swept(tmp_path):
+    """a killed run's "<frame>.npy.tmp.<pid>.<thread>" files are removed when they are old; young ones (a live writer's) stay"""
+    import time
+    from tennis_amd.evaluate import NpyWriter
+    d = tmp_path / "features" / "m" / "V006"
+    d.mkdir(parents=True)
+    old, young, real = d / "0001.npy.tmp.123.456", d / "0002.npy.tmp.123.457", d / "0003.npy"
+    for f in (old, young, real):
+        f.write_bytes(b"x")
+    t = time.time() - 3600
+    os.utime(old, (t, t))
+    assert NpyWriter.sweep_stale(str(tmp_path / "features")) == 1
+    assert not old.exists() and young.exists() and real.exists()

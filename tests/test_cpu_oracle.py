@@ -458,6 +458,13 @@ def test_bn_relu_clamp_fold_properties():
     q.update({k.replace("bn_", "densenet0_stage1_batchnorm0_"): v for k, v in p.items()})
     q.update({"densenet0_stage1_batchnorm1_gamma": rng.uniform(0.5, 1.5, 128).astype(np.float32), "densenet0_stage1_batchnorm1_beta": np.zeros(128, np.float32),
               "densenet0_stage1_batchnorm1_running_mean": np.zeros(128, np.float32), "densenet0_stage1_batchnorm1_running_var": rng.uniform(0.5, 2, 128).astype(np.float32)})
+    # channel 2 (gamma 3e4 / sqrt(1e-3)) takes its weights out of the fp16 range: the conversion refuses the checkpoint, as the
+    # library does at create (it used to hand out inf weights with a numpy overflow warning)
+    with pytest.raises(ValueError, match="fp16 range"):
+        W.as_fp16_model(q)
+    q["densenet0_stage1_batchnorm0_gamma"] = q["densenet0_stage1_batchnorm0_gamma"].copy()
+    q["densenet0_stage1_batchnorm0_gamma"][2] = 30.0
+    sw = W.bn_relu_clamp_fold(q, "densenet0_stage1_batchnorm0")[2]
     conv = W.as_fp16_model(q)["densenet0_stage1_conv0_weight"]
     s2 = (q["densenet0_stage1_batchnorm1_gamma"] / np.sqrt(q["densenet0_stage1_batchnorm1_running_var"] + np.float32(W.BN_EPS))).astype(np.float32)
     folded = (conv * s2.reshape(-1, 1, 1, 1) * sw.reshape(1, -1, 1, 1)).astype(np.float32)
@@ -780,3 +787,27 @@ def test_bias_correction_reaches_exactly_the_consumers_of_a_channel():
     # and through as_fp16_model: no 2-D means, no correction (the plain conversion of rounds 1 - 4 is unchanged)
     q = W.as_fp16_model(p)
     assert all(np.array_equal(q[k], p[k]) for k in p if k.endswith("_running_mean"))
+
+
+def test_conversion_keeps_the_weights_of_near_dead_channels():
+    """Round 6 (scripts/dead_debug.py).  A near-dead BatchNorm channel in front of a 1x1 (gamma 1e-5) folds its weights into fp16's
+    subnormals; un-folding the few bits that are left handed the library - which needs w[n][k] exactly for the constant tc[k] w[n][k]
+    of the clamp form - weights that were up to 100 % off: 8e-3 on the features for dead channels with a positive beta.  Those
+    weights now stay as they are, the others still become fp16 numbers once folded."""
+    from tennis_amd import weights as W
+    rng = np.random.default_rng(11)
+    n = 256
+    q = {"densenet0_stage1_conv0_weight": rng.normal(0, 0.1, (128, n, 1, 1)).astype(np.float32)}
+    g = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    dead = np.zeros(n, bool); dead[::9] = True
+    g[dead] *= (10.0 ** rng.uniform(-7, -4, int(dead.sum()))).astype(np.float32)
+    q.update({"densenet0_stage1_batchnorm0_gamma": g, "densenet0_stage1_batchnorm0_beta": np.abs(rng.normal(0, 0.3, n)).astype(np.float32),
+              "densenet0_stage1_batchnorm0_running_mean": np.zeros(n, np.float32), "densenet0_stage1_batchnorm0_running_var": np.ones(n, np.float32),
+              "densenet0_stage1_batchnorm1_gamma": np.ones(128, np.float32), "densenet0_stage1_batchnorm1_beta": np.zeros(128, np.float32),
+              "densenet0_stage1_batchnorm1_running_mean": np.zeros(128, np.float32), "densenet0_stage1_batchnorm1_running_var": np.ones(128, np.float32)})
+    w = q["densenet0_stage1_conv0_weight"]
+    conv = W.as_fp16_model(q)["densenet0_stage1_conv0_weight"]
+    assert np.array_equal(conv[:, dead], w[:, dead])                      # untouched: the constant beta * w is what these channels contribute
+    live = ~dead
+    rel = np.abs(conv[:, live] - w[:, live]) / np.abs(w[:, live])
+    assert rel.max() < 2.0 ** -10 and (conv[:, live] != w[:, live]).mean() > 0.9        # rounded once, to a neighbour
