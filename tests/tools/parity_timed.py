@@ -39,26 +39,27 @@ def make_weights(kind: str, seed: int = 0) -> dict:
     raise ValueError(kind)
 
 
-def batch(n: int = 256, seed: int = 5):
+def batch(n: int = 256, seed: int = 5, size: int = 224):
     from tennis_amd import calib_frames as CF
-    return CF.mixed_batch(n, 224, seed, JPEG_NPZ)
+    return CF.mixed_batch(n, size, seed, JPEG_NPZ)
 
 
 def oracle_features(params32: dict, frames_u8: np.ndarray) -> np.ndarray:
     from oracle.torch_ref import TorchDenseNet121
     from tennis_amd import weights as W
     net = TorchDenseNet121(params32)
-    out = [net(torch.from_numpy(W.normalize_to_nchw_f32(frames_u8[i:i + 64]))).numpy() for i in range(0, len(frames_u8), 64)]
+    step = 64 if frames_u8.shape[1] <= 256 else 8
+    out = [net(torch.from_numpy(W.normalize_to_nchw_f32(frames_u8[i:i + step]))).numpy() for i in range(0, len(frames_u8), step)]
     return np.concatenate(out)
 
 
-def encoder_for(params32: dict, mode: str, max_batch: int = 256, ctx=None):
+def encoder_for(params32: dict, mode: str, max_batch: int = 256, ctx=None, size: int = 224):
     from tennis_amd.calibrate import calibrated_fp16_model
     from tennis_amd.engine import DenseNet121Features
     if mode == "exact":
-        return DenseNet121Features(params32, 224, max_batch=max_batch, exact_weights=True, ctx=ctx)
+        return DenseNet121Features(params32, size, max_batch=max_batch, exact_weights=True, ctx=ctx)
     if mode == "calibrated":
-        return DenseNet121Features(calibrated_fp16_model(params32, None, 224, ctx=ctx), 224, max_batch=max_batch, ctx=ctx)
+        return DenseNet121Features(calibrated_fp16_model(params32, None, size, ctx=ctx), size, max_batch=max_batch, ctx=ctx)
     raise ValueError(mode)
 
 
@@ -86,21 +87,21 @@ def summarize(feat: np.ndarray, ref: np.ndarray, labels, dense_w: np.ndarray) ->
             "worst_family": max(fams, key=lambda f: fams[f]["feature_max_scaled"]), "families": fams}
 
 
-def measure(kind: str, mode: str, n: int = 256, seed: int = 5, wseed: int = 0, ref=None):
+def measure(kind: str, mode: str, n: int = 256, seed: int = 5, wseed: int = 0, ref=None, size: int = 224):
     from tennis_amd import weights as W
     p = make_weights(kind, wseed)
-    frames, labels = batch(n, seed)
+    frames, labels = batch(n, seed, size)
     if ref is None:
         ref = oracle_features(p, frames)
-    enc = encoder_for(p, mode, max_batch=n)
+    enc = encoder_for(p, mode, max_batch=n, size=size)
     x = torch.from_numpy(frames).cuda()
     feat = enc(x).cpu().numpy()
     stats, _ = enc.profile(x)
     ran = sorted(s["name"] for s in stats)
-    wd = W.make_dense_weights(1, 11, 1024, "framemodel0_dense0_")["framemodel0_dense0_weight"]
+    wd = W.make_dense_weights(1, 11, ref.shape[1], "framemodel0_dense0_")["framemodel0_dense0_weight"]
     out = summarize(feat, ref, labels, wd)
     out["kernel_families"] = ran
-    out["timed_kernels_ran"] = all(f in ran for f in TIMED_FAMILIES) if mode == "calibrated" else None
+    out["timed_kernels_ran"] = all(f in ran for f in TIMED_FAMILIES) if (mode == "calibrated" and size == 224) else None
     del enc
     return out, ref
 
@@ -111,6 +112,7 @@ if __name__ == "__main__":
     ap.add_argument("--weights", default="seeded,trained")
     ap.add_argument("--modes", default="calibrated,exact")
     ap.add_argument("--frames", type=int, default=256)
+    ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--out", default="gpurun_out/parity_timed.json")
     a = ap.parse_args()
     torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
@@ -118,7 +120,7 @@ if __name__ == "__main__":
     for kind in a.weights.split(","):
         ref = None
         for mode in a.modes.split(","):
-            r, ref = measure(kind, mode, a.frames, ref=ref)
+            r, ref = measure(kind, mode, a.frames, ref=ref, size=a.size)
             res["runs"][f"{kind} / {mode}"] = r
             print(kind, mode, {k: r[k] for k in ("feature_max", "logit_max", "over_bar", "feature_max_scaled", "over_bar_scaled", "worst_family", "timed_kernels_ran")}, flush=True)
             for f, v in r["families"].items():
