@@ -2,7 +2,7 @@
 # SQ-level PMC passes over one bench run (on the GPU box); per-kernel averages printed by scripts/pmc_sq_fmt.py
 set -u
 R=$PWD; export TMPDIR=/tmp
-B="python $R/bench.py --no-cpu-baseline --no-exact-line --single-region --plain-rounding --steps 2 --warmup 1"
+B="python $R/bench.py --no-cpu-baseline --no-exact-line --no-parity-live --single-region --plain-rounding --steps 2 --warmup 1"
 cd /tmp
 i=0
 for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" \

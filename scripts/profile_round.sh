@@ -4,7 +4,7 @@
 # 10-15 % slower than the steady state (clocks still ramping: 143.9 us against 128.1 us for the 56x56 layers on one box).
 set -u
 R=$PWD; export TMPDIR=/tmp
-B="python $R/bench.py --no-cpu-baseline --no-exact-line --single-region"
+B="python $R/bench.py --no-cpu-baseline --no-exact-line --no-parity-live --single-region"
 # the PMC passes run the fp16-representable seeded weights (--plain-rounding: the same kernels on the same shapes, no 144 calibration
 # forwards through the layer-wise kernels mixing into the per-family averages)
 P="$B --plain-rounding"

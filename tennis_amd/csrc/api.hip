@@ -278,6 +278,9 @@ struct tn_encoder {
   hipStream_t side[4];
   hipEvent_t ev_in, ev_done[2][4];   // completion of the side streams, alternating per forward call
   bool pipelined = false;            // tn_densenet121_set_pipelined: the caller's stream is not made to wait inside forward
+  bool last_interleaved = false;     // the previous split call took the whole-batch form
+  int last_ws0 = 0;                  // first workspace frame slot of the last forward (read_tap)
+  bool interleave = false;           // pipelined calls run WHOLE batches on alternating side streams (round 6, encoder_run), on two workspace sets
   long calls = 0;                    // forward calls so far
   int split_of[2] = {0, 0};          // side streams the call of each parity used (0: it ran on the caller's stream)
   int split_batch = 0;               // batch size of the last split call (pipelined calls share the workspace by row range)
@@ -545,7 +548,12 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
   e->head_s = e->pool.upload(s); e->head_t = e->pool.upload(t);
 
   const size_t weights_bytes = e->pool.bytes;
-  const size_t B = (size_t)max_batch;
+  // Round 6: with pipelined forwards a batch is no longer cut in two halves that run side by side - consecutive WHOLE batches run
+  // side by side on the two side streams (encoder_run), each in its own workspace set: twice the frames per launch
+  // (bench.py --batch 512 measured what that is worth before it was built: +2.1 %, the per-launch drain / fill of the chip
+  // amortised over two frames per CU).  TN_NO_INTERLEAVE: the half-batch form of rounds 1 - 5.
+  e->interleave = getenv("TN_NO_INTERLEAVE") == nullptr && e->split && max_batch >= 64;
+  const size_t B = (size_t)max_batch * (e->interleave ? 2 : 1);
   e->stem_out = (f16 *)e->pool.alloc(B * e->Hs * e->Ws * 64 * sizeof(f16));
   e->bott = (f16 *)e->pool.alloc(B * e->Hb[0] * e->Wb[0] * 128 * sizeof(f16));
   for (int b = 0; b < 4; ++b)
@@ -581,20 +589,21 @@ extern "C" size_t tn_densenet121_workspace_bytes(const tn_encoder *enc) { return
 // Frames [b0, b0+B) of the batch on stream s.  Every buffer is per-frame contiguous, so a
 // sub-batch is just a pointer offset; weights are shared read-only.
 static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, int b0, int B, float *feat0,
-                             hipStream_t s, EventTimer &tm) {
+                             hipStream_t s, EventTimer &tm, int ws0 = -1) {
   int rc;
   const double fB = (double)B;
   const size_t frame_bytes = (size_t)e->H * e->W * 3 * (layout == TN_LAYOUT_NCHW_F32 ? 4 : layout == TN_LAYOUT_NHWC_F16 ? 2 : 1);
   const void *x = (const unsigned char *)x0 + (size_t)b0 * frame_bytes;
   float *feat = feat0 + (size_t)b0 * e->feat_dim;
-  f16 *stem_out = e->stem_out + (size_t)b0 * e->Hs * e->Ws * 64;
-  f16 *bott = e->bott + (size_t)b0 * e->Hb[0] * e->Wb[0] * 128;
+  const int w0 = ws0 >= 0 ? ws0 : b0;        // first frame slot of the workspace (the second workspace set starts at maxB)
+  f16 *stem_out = e->stem_out + (size_t)w0 * e->Hs * e->Ws * 64;
+  f16 *bott = e->bott + (size_t)w0 * e->Hb[0] * e->Wb[0] * 128;
   f16 *bbuf[4];
-  for (int b = 0; b < 4; ++b) bbuf[b] = e->blockbuf[b] + (size_t)b0 * e->Hb[b] * e->Wb[b] * e->Cb[b];
+  for (int b = 0; b < 4; ++b) bbuf[b] = e->blockbuf[b] + (size_t)w0 * e->Hb[b] * e->Wb[b] * e->Cb[b];
   // the head reads the last block un-rounded when the kernels that produce it write the fp32 side copy: the LDS-resident 7x7
   // block kernel and the transition in front of it (not in the layer-wise calibration pass, not with a tuning variant)
   float *h32 = (e->head32 && e->calib_dev == nullptr && e->dl_variant == 0)
-                   ? e->head32 + (size_t)b0 * e->Hb[3] * e->Wb[3] * e->Cb[3] : nullptr;
+                   ? e->head32 + (size_t)w0 * e->Hb[3] * e->Wb[3] * e->Cb[3] : nullptr;
   {
     StemArgs a{x, (int)layout, B, e->H, e->W, e->stem_wp, e->stem_wp_zf, e->stem_scale, e->stem_shift, stem_out, e->Hs, e->Ws};
     a.shift_u8 = e->stem_shift_u8;
@@ -634,7 +643,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
       // pixel-owning waves, all weights streamed through an LDS ring (dense_block14.hip)
       DenseBlock14Args a14 = e->b14[b];
       a14.buf = bbuf[b]; a14.B = B;
-      a14.scratch = e->b14_scratch[b] + (size_t)b0 * dense_block14_scratch_halfs();
+      a14.scratch = e->b14_scratch[b] + (size_t)w0 * dense_block14_scratch_halfs();
       double fl = 0, by = 0;
       for (auto &L : e->layers[b]) {
         fl += 2.0 * M * (128.0 * L.cin + 32.0 * 1152);
@@ -648,7 +657,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
       // the 28x28 block in four passes of eight rows, all weights streamed once per pass (dense_block28.hip)
       DenseBlock28Args a28 = e->b28[b];
       a28.buf = bbuf[b]; a28.B = B;
-      a28.scratch = e->b28_scratch[b] + (size_t)b0 * dense_block28_scratch_halfs();
+      a28.scratch = e->b28_scratch[b] + (size_t)w0 * dense_block28_scratch_halfs();
       double fl = 0, by = 0;
       for (auto &L : e->layers[b]) {
         fl += 2.0 * M * (128.0 * L.cin + 32.0 * 1152);
@@ -762,6 +771,7 @@ static int encoder_run(tn_encoder *e, const void *x, tn_layout layout, int B, fl
   const bool split = e->split && !tm.on && B >= 32 * ns && (B % (8 * ns)) == 0;
   const int par = (int)(e->calls & 1);
   e->calls++;
+  e->last_ws0 = 0;
   if (!split) {
     // (a pipelined encoder: earlier calls may still run on the side streams and share the workspace)
     if (e->pipelined) {
@@ -770,6 +780,29 @@ static int encoder_run(tn_encoder *e, const void *x, tn_layout layout, int B, fl
     }
     e->split_of[par] = 0;
     return encoder_run_range(e, x, layout, 0, B, feat, s, tm);
+  }
+  if (e->pipelined && e->interleave && B / ns >= e->strip_min_batch) {      // (a batch whose halves would run the small-batch kernels keeps them: one kernel family per batch size, pipelined or not)
+    // Whole batch on side stream `par`, workspace set `par`: the call before runs on the other stream in the other set, the
+    // call before that was on this stream (stream order separates the two users of a set).  A call of the half-batch form
+    // may still be in flight on either stream (the mode was switched, or a small batch came in between): wait for it.
+    TN_HIP_CHECK(hipEventRecord(e->ev_in, s));
+    TN_HIP_CHECK(hipStreamWaitEvent(e->side[par], e->ev_in, 0));
+    if (!e->last_interleaved)
+      for (int p2 = 0; p2 < 2; ++p2)
+        for (int g = 0; g < e->split_of[p2]; ++g) TN_HIP_CHECK(hipStreamWaitEvent(e->side[par], e->ev_done[p2][g], 0));
+    e->last_interleaved = true;
+    e->last_ws0 = par * e->maxB;
+    const int r = encoder_run_range(e, x, layout, 0, B, feat, e->side[par], tm, par * e->maxB);
+    TN_HIP_CHECK(hipEventRecord(e->ev_done[par][0], e->side[par]));
+    e->split_of[par] = 1;
+    e->split_batch = 0;
+    return r;
+  }
+  if (e->last_interleaved) {      // back to the half-batch form: its row ranges cut across both workspace sets' users
+    for (int h = 0; h < ns; ++h)
+      for (int p2 = 0; p2 < 2; ++p2)
+        for (int g = 0; g < e->split_of[p2]; ++g) TN_HIP_CHECK(hipStreamWaitEvent(e->side[h], e->ev_done[p2][g], 0));
+    e->last_interleaved = false;
   }
   TN_HIP_CHECK(hipEventRecord(e->ev_in, s));
   // Pipelined calls overlap on the side streams, and half h of every call works in workspace rows [h B / ns, (h + 1) B / ns):
@@ -859,6 +892,7 @@ extern "C" int tn_densenet121_input_means(tn_encoder *e, const void *x, tn_layou
   *numel = n;
   TN_REQUIRE(capacity >= n, "tn_densenet121_input_means: host buffer too small");
   if (int rc = encoder_join(e, 0)) return rc;
+  if (int rc = encoder_join(e, 1)) return rc;     // (the call before the last one may still run, in the workspace set this pass uses)
   hipStream_t s = e->ctx->stream;
   float *dev = nullptr, *feat = nullptr;
   double *scratch = nullptr;
@@ -913,7 +947,9 @@ extern "C" int tn_densenet121_read_tap(tn_encoder *e, const char *tap_c, int bat
   const size_t px = (size_t)batch * hh * ww;
   *numel = px * cc;
   TN_REQUIRE(capacity >= *numel, "read_tap: host buffer too small");
+  src += (size_t)e->last_ws0 * hh * ww * ld;      // (the workspace set the last forward ran in)
   if (int rc = encoder_join(e, 0)) return rc;
+  if (int rc = encoder_join(e, 1)) return rc;
   TN_HIP_CHECK(hipStreamSynchronize(e->ctx->stream));
   std::vector<f16> tmp(px * ld);
   TN_HIP_CHECK(hipMemcpy(tmp.data(), src, tmp.size() * sizeof(f16), hipMemcpyDeviceToHost));

@@ -350,3 +350,19 @@ def test_corpus_extract_world2_reproduces_the_world1_checksum():
         for r in (0, 1):
             full, cs, rounds = ret[(2, r)]
             assert np.array_equal(full, one) and cs == cs1 and rounds >= 2
+
+
+def test_corpus_extract_world4_ragged_last_round():
+    """the same on FOUR ranks with a ragged last round - 11 batches in blocks of 2 are 6 blocks over 4 ranks: the
+    second round has two ranks with a block (one of them the corpus' 13-frame tail in a half-empty block) and two with none, which
+    still take part in the round's collective with padding rows.  Every rank ends with the world-1 matrix and checksum."""
+    n_frames, batch = 173, 16                 # 11 batches (the last one of 13 frames) = 6 blocks of 2 batches (the last block holds one)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        _corpus_worker(0, 1, 0, n_frames, batch, ret)
+        mp.spawn(_corpus_worker, args=(4, 29571, n_frames, batch, ret), nprocs=4, join=True)
+        one, cs1, _ = ret[(1, 0)]
+        assert one.shape == (n_frames, 5)
+        for r in range(4):
+            full, cs, rounds = ret[(4, r)]
+            assert np.array_equal(full, one) and cs == cs1 and rounds == 2, (r, rounds)

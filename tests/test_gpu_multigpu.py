@@ -124,6 +124,8 @@ def _comm_rank_main(rank, world, idfile, outfile):
     counts = torch.arange(121, dtype=torch.int64, device="cuda") * (rank + 1)
     comm.allreduce_(counts).wait()
     torch.cuda.synchronize()
+    d = comm.describe()          # RCCL's own answers when world > 1 (ncclCommCount / ncclCommUserRank / ncclCommCuDevice)
+    assert d["world"] == world and d["rank"] == rank and d["device"] == rank and d["rccl"] == (world > 1), d
     torch.save({"out": out.cpu(), "grads": grads.cpu(), "counts": counts.cpu()}, outfile % rank)
     comm.close()
 
@@ -144,6 +146,10 @@ def test_comm_single_rank_through_the_abi(force_rccl):
     comm.allreduce_(c).wait()
     torch.cuda.synchronize()
     assert torch.equal(out, shard) and torch.equal(g, g0) and torch.equal(c, torch.arange(50, dtype=torch.int64, device="cuda"))
+    # what the communicator says about itself (round 6: tn_comm_world / _rank / _device are RCCL's own answers - ncclCommCount,
+    # ncclCommUserRank, ncclCommCuDevice - when RCCL is behind the handle; bench.py prints them per rank in config.comm)
+    d = comm.describe()
+    assert d["world"] == 1 and d["rank"] == 0 and d["rccl"] == bool(force_rccl) and d["device"] == torch.cuda.current_device(), d
     comm.close()
 
 

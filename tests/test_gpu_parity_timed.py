@@ -122,16 +122,26 @@ def test_near_dead_batchnorm_channels(report):
 
 
 def test_a_frame_does_not_depend_on_its_batch():
-    """the 256-frame call and a 64-frame call (still the strip / streamed kernels: 64 frames per launch is where they switch in)
-    give the same bits for the same frame"""
+    """the 256-frame call and a 128-frame call (two half batches of 64: still the strip / streamed kernels - 64 frames per launch is
+    where they switch in) give the same bits for the same frame, and so does the pipelined whole-batch form (round 6)"""
     from tennis_amd import weights as W
     p = W.make_densenet121_weights(0)
     frames, _ = PT.batch(256)
     x = torch.from_numpy(frames).cuda()
     from tennis_amd.engine import DenseNet121Features
-    big = DenseNet121Features(p, 224, max_batch=256)(x)
-    small = DenseNet121Features(p, 224, max_batch=64)(x[192:256].contiguous())
-    assert torch.equal(big[192:256], small)
+    enc = DenseNet121Features(p, 224, max_batch=256)
+    big = enc(x)
+    small = DenseNet121Features(p, 224, max_batch=128)(x[128:256].contiguous())
+    assert torch.equal(big[128:256], small)
+    enc.set_pipelined(True)
+    outs = [torch.empty_like(big) for _ in range(3)]
+    for o in outs:
+        enc(x, out=o)
+    enc.join(0); enc.join(1)
+    enc.set_pipelined(False)
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, big)
 
 
 def test_family_parity_at_the_reference_default_input_size(report):
