@@ -100,7 +100,10 @@ int tn_densenet121_forward(tn_encoder *enc, const void *x, tn_layout layout, int
  * tn_densenet121_join(enc, 0) makes the ctx's stream wait for the last forward, join(enc, 1) for the one before it
  * (results consumed one call behind).  Until its join, a forward's input x must not be overwritten and its feat not
  * read; set_pipelined(enc, 0) joins everything outstanding.  Replaces nothing in the reference (MXNet's engine
- * overlaps independent ops by itself); it exists for streaming a corpus through the encoder (config C4). */
+ * overlaps independent ops by itself); it exists for streaming a corpus through the encoder (config C4).
+ * (Round 6: from 128 frames per call on, a pipelined forward runs its WHOLE batch on one of the two streams, consecutive calls
+ * alternating, each in its own workspace set - at most two forwards are in flight, as before; same results bit for bit,
+ * same join contract; TN_NO_INTERLEAVE=1 in the environment keeps the half-batch form.) */
 int tn_densenet121_set_pipelined(tn_encoder *enc, int on);
 int tn_densenet121_join(tn_encoder *enc, int lag);
 /* Calibration statistics for the calibrated fp16 conversion (tennis_amd/weights.py::as_fp16_model(input_means=...)):
