@@ -339,10 +339,9 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
   auto fail = [&](int code) { e->pool.release(); delete e; return code; };
   if (e->PH < 1 || e->PW < 1) { tn_set_error("input too small for AvgPool2D(7)"); return fail(TN_ERR_INVALID); }
   if (e->Wb[0] > 240) { tn_set_error("input too wide for the conv3x3 LDS tile"); return fail(TN_ERR_INVALID); }
-  if (e->exact) {      // the hi + lo weight passes exist in the 8-wave fused layer and the transition kernel only
-    bool ok = e->fuse && (e->dl_variant & ~256) == 0;
-    for (int b = 0; b < 4; ++b) ok = ok && dense_layer_big_supported(e->Hb[b], e->Wb[b]) && e->Cb[b] - 32 <= dense_layer_kmax(e->Wb[b]);
-    if (!ok) { tn_set_error("TN_ENC_EXACT_WEIGHTS needs the fused 224x224 path (56/28/14/7 blocks, default kernels)"); return fail(TN_ERR_INVALID); }
+  if (e->exact) {      // the hi + lo weight passes: the 8-wave fused layer, the transition kernel and (round 6) the un-fused layer kernels
+    const bool ok = e->fuse && (e->dl_variant & ~256) == 0;
+    if (!ok) { tn_set_error("TN_ENC_EXACT_WEIGHTS needs the default kernels (no TN_NO_FUSE, no TN_DL_VARIANT)"); return fail(TN_ERR_INVALID); }
   }
 
   std::vector<float> s, t;
@@ -477,7 +476,11 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
       }
       if (!in_range) { tn_set_error("a 1x1 weight leaves the fp16 range once its BatchNorm scales are folded in (" + sp + "conv" + std::to_string(2 * l) + ")"); return fail(TN_ERR_INVALID); }
       if (e->exact) {
-        const int bk = e->Hb[b] >= 28 ? 32 : 64;          // k-tile of the block's fused kernel (dense_layer_big.hip)
+        // k-tile of the kernel that will run the layer (the row pitch of [hi | lo] is twice K rounded up to it): the block's
+        // fused kernel (dense_layer_big.hip: 64 channels at 14 x 14 and 7 x 7, 32 elsewhere), or conv1x1.hip's 64 where no fused
+        // kernel tiles the map or holds the layer's K (encoder_run takes the same decision)
+        const bool tile = dense_layer_supported(e->Hb[b], e->Wb[b]) && L.cin <= dense_layer_kmax(e->Wb[b]);
+        const int bk = !tile ? 64 : (e->Hb[b] == 14 || e->Hb[b] == 7) ? 64 : 32;
         L.w1 = e->pool.upload(split_hi_lo_rows(w1f.data(), 128, L.cin, (L.cin + bk - 1) / bk * bk));
       } else {
         L.w1 = e->pool.upload(to_f16(w1f.data(), (size_t)128 * L.cin));
@@ -727,12 +730,14 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
       Conv1x1Args a1{bbuf[b], e->Cb[b], L.cin, L.s1, L.t1, L.w1, 128, bott, 128, 0, M, 0, Hh, Ww};
       a1.bias = L.t2;
       a1.clamp = 1;
+      a1.exact = e->exact;
       tm.begin("conv1x1_bnrelu", 2.0 * M * 128.0 * L.cin, (double)M * (L.cin + 128) * 2 + 128.0 * L.cin * 2);
       rc = launch_conv1x1(a1, s);
       tm.end();
       if (rc) return rc;
       if (cal && (rc = cal_mean(bott, 128, 128, e->ones128, e->zeros128, M))) return rc;
       Conv3x3Args a3{bott, L.s2, e->zeros128, L.w3p, bbuf[b], e->Cb[b], L.cin, M, Hh, Ww};
+      a3.exact = e->exact;
       tm.begin("conv3x3_bnrelu", 2.0 * M * 32.0 * 1152, (double)M * (128 + 32) * 2 + 32.0 * 1152 * 2);
       rc = launch_conv3x3(a3, s);
       tm.end();

@@ -149,7 +149,7 @@ struct Conv1x1Args {
   int pool;           // 0: Ho=H ; 1: 2x2 average of BN+ReLU'd input before the GEMM
   int H, W;           // input spatial size (used when pool)
   int variant = 0;    // tuning hook: 0 = default kernel choice
-  int exact = 0;      // weights as hi + lo fp16 pairs: w [N][2 K] = [hi | lo] (K % 64 == 0)
+  int exact = 0;      // weights as hi + lo fp16 pairs: w [N][2 Kp] = [hi | lo], Kp = K rounded up to 64 (pool: K % 64 == 0)
   const float *bias = nullptr;   // [N] added to the fp32 result before the rounding to fp16 (no pooling)
   int clamp = 0;      // the dense layers' BN1 form: scale / shift hold lo / hi, the operand is clamp(x, lo, hi) (no arithmetic, no rounding)
   float *y32 = nullptr;   // [M][ld32] fp32: the result once more, un-rounded (the last transition: what the head reads), columns [0, N)
@@ -166,6 +166,7 @@ struct Conv3x3Args {
   int ldy, yoff;
   int M, H, W;        // M = B*H*W
   int variant = 0;    // tuning hook: 0 = default kernel choice
+  int exact = 0;      // weights as hi + lo: wp holds the hi image (both MFMA layouts, pack_conv3x3) and then the lo image
 };
 int launch_conv3x3(const Conv3x3Args &a, hipStream_t s);
 size_t conv3x3_lds_bytes(int W);

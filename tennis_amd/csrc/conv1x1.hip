@@ -35,8 +35,10 @@ constexpr int smem_bytes() {
 
 // NB = output channels per workgroup (128, or 256 for the transitions with N >= 256: every column tile streams
 // the pixel tile again and repeats its BN+ReLU+average, so wider tiles cut both)
-// EX (exact-weights mode): w = hi + lo as two fp16 numbers, rows [hi (K) | lo (K)]; the k-tile loop
-// runs over 2 K, the activation side (and its BatchNorm constants) wrapping around after the hi half.
+// EX (exact-weights mode): w = hi + lo as two fp16 numbers, rows [hi (Kp) | lo (Kp)], Kp = K rounded up to the
+// k-tile (zero-padded; api.hip::split_hi_lo_rows); the k-tile loop runs over 2 Kp, the activation side (and its BatchNorm
+// constants) wrapping around after the hi half.  Round 6: also without POOL (the un-fused dense layers of map sizes no fused
+// kernel tiles - the 128 x 128 block of a 512 x 512 input - in the exact-weights mode).
 // ONCE (a transition with a single column tile): the activations are read exactly once, through non-temporal loads.
 template <int MI, bool POOL, int NB, bool EX = false, bool ONCE = false>
 __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
@@ -98,14 +100,14 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
       xsrc[i][0] = a.x + (long)m * a.ldx;
     }
   }
-  const int WLD = EX ? 2 * K : K;          // weight row pitch
+  const int nkc = (K + BK - 1) / BK;
+  const int WLD = EX ? 2 * nkc * BK : K;   // weight row pitch
   const f16 *wsrc = a.w + (long)(n0 + r0) * WLD;
 
   f16x8 xr[MI][NSRC];
   f16x8 wr[NI];
   float sc[8], sh[8];
 
-  const int nkc = (K + BK - 1) / BK;
   auto load_tile = [&](int kt) {
     const int kc = ((EX && kt >= nkc) ? kt - nkc : kt) * BK + c * 8;     // activation channels of this k-tile
     const int kw = kt * BK + c * 8;                                      // weight columns
@@ -256,7 +258,6 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1x1Args a) {
 int launch_conv1x1(const Conv1x1Args &a, hipStream_t s) {
   TN_REQUIRE(a.K % 32 == 0 && a.N % BN_TILE == 0, "conv1x1: K%32 or N%128");
   TN_REQUIRE(a.ldx % 8 == 0 && a.ldy % 8 == 0 && a.yoff % 8 == 0, "conv1x1: strides must be multiples of 8");
-  TN_REQUIRE(!a.exact || a.pool, "conv1x1: the exact-weights mode is built for the transitions (pool = 1)");
   const dim3 block(256);
   if (a.pool) {
     static const bool narrow = getenv("TN_TRANS_NARROW") != nullptr;   // A/B runs: 128-channel tiles everywhere
@@ -283,13 +284,16 @@ int launch_conv1x1(const Conv1x1Args &a, hipStream_t s) {
     }
   } else if (a.M >= 128 * 512) {
     const dim3 grid((a.M + 127) / 128, a.N / BN_TILE);
-    hipLaunchKernelGGL((conv1x1_kernel<4, false, 128>), grid, block, 0, s, a);
+    if (a.exact) hipLaunchKernelGGL((conv1x1_kernel<4, false, 128, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv1x1_kernel<4, false, 128>), grid, block, 0, s, a);
   } else if (a.M >= 64 * 512) {
     const dim3 grid((a.M + 63) / 64, a.N / BN_TILE);
-    hipLaunchKernelGGL((conv1x1_kernel<2, false, 128>), grid, block, 0, s, a);
+    if (a.exact) hipLaunchKernelGGL((conv1x1_kernel<2, false, 128, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv1x1_kernel<2, false, 128>), grid, block, 0, s, a);
   } else {
     const dim3 grid((a.M + 31) / 32, a.N / BN_TILE);
-    hipLaunchKernelGGL((conv1x1_kernel<1, false, 128>), grid, block, 0, s, a);
+    if (a.exact) hipLaunchKernelGGL((conv1x1_kernel<1, false, 128, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv1x1_kernel<1, false, 128>), grid, block, 0, s, a);
   }
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;

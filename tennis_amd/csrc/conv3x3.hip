@@ -20,7 +20,10 @@ namespace {
 constexpr int TILE_PX = 128;
 constexpr int RED_BYTES = 4 * TILE_PX * 32 * 4;  // 4 waves x 128 px x 32 n fp32 = 64 KiB
 
-template <int V>
+// EX (exact-weights mode, round 6: the un-fused layers of map sizes no fused kernel tiles): w = hi + lo as two packed images,
+// the lo image 2 x 72 x 64 fragments further on (api.hip packs both MFMA layouts of an image back to back, then the next
+// image); every pixel fragment is multiplied with both.
+template <int V, bool EX = false>
 __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3x3Args a, int lds_px) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x;
@@ -127,6 +130,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3x3Args a, int lds_px)
     const int doff = dy * W + dx;
     f16x8 wb;
     if constexpr (V >= 1) wb = wpre[i]; else wb = wp[(long)i * 64];
+    [[maybe_unused]] f16x8 wl;
+    if constexpr (EX) wl = wp[(long)(2 * 72 + i) * 64];
     f16x8 xa[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -137,6 +142,11 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3x3Args a, int lds_px)
 #pragma unroll
     for (int f = 0; f < 4; ++f)
       acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[f], wb, acc[f], 0, 0, 0);
+    if constexpr (EX) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+        acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa[f], wl, acc[f], 0, 0, 0);
+    }
   }
   __syncthreads();  // all waves done reading the staged pixels
 
@@ -196,9 +206,13 @@ int launch_conv3x3(const Conv3x3Args &a, hipStream_t s) {
   TN_SET_ATTR_ONCE_PER_DEVICE(TN_HIP_CHECK(hipFuncSetAttribute((const void *)conv3x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      160 * 1024));
     TN_HIP_CHECK(hipFuncSetAttribute((const void *)conv3x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024));
+    TN_HIP_CHECK(hipFuncSetAttribute((const void *)conv3x3_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      160 * 1024)));
   const dim3 grid((a.M + TILE_PX - 1) / TILE_PX), block(256);
-  if (a.variant == 9)
+  if (a.exact)
+    hipLaunchKernelGGL((conv3x3_kernel<1, true>), grid, block, lds, s, a, lds_px);
+  else if (a.variant == 9)
     hipLaunchKernelGGL(conv3x3_kernel<0>, grid, block, lds, s, a, lds_px);
   else
     hipLaunchKernelGGL(conv3x3_kernel<1>, grid, block, lds, s, a, lds_px);

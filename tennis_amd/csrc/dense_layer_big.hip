@@ -828,14 +828,19 @@ int launch_dense_layer_big(const DenseLayerArgs &a, hipStream_t s) {
   TN_REQUIRE(a.K % 32 == 0 && klast <= 1024 && a.ldc % 8 == 0 && klast + 32 <= a.ldc, "dense_layer: bad channel geometry");
   if (a.exact) {     // hi + lo weights: the default K loop only
     if (a.nchain > 0) {
-      TN_REQUIRE(a.H == a.W && (a.H == 14 || a.H == 7) && a.chain, "dense_layer: layer chaining needs whole-frame tiles (14x14, 7x7)");
+      TN_REQUIRE(a.H == a.W && (a.H == 14 || a.H == 7 || a.H == 16) && a.chain, "dense_layer: layer chaining needs whole-frame tiles (16x16, 14x14, 7x7)");
       if (a.H == 14) return launch_geom<14, 14, 256, 64, 2, true, true>(a, s);
+      if (a.H == 16) return launch_geom<16, 16, 384, 32, 2, true, true>(a, s);
       return launch_geom<7, 7, 64, 64, 2, true, true>(a, s);
     }
     if (a.H == 56 && a.W == 56) return launch_geom<56, 7, 512, 32, 2, false, true>(a, s);
     if (a.H == 28 && a.W == 28) return launch_geom<28, 14, 512, 32, 2, false, true>(a, s);
     if (a.H == 14 && a.W == 14) return launch_geom<14, 14, 256, 64, 2, false, true>(a, s);
     if (a.H == 7 && a.W == 7) return launch_geom<7, 7, 128, 64, 2, false, true>(a, s);
+    // (round 6: the maps of a 512 x 512 input)
+    if (a.H == 64 && a.W == 64) return launch_geom<64, 4, 384, 32, 2, false, true>(a, s);
+    if (a.H == 32 && a.W == 32) return launch_geom<32, 8, 384, 32, 2, false, true>(a, s);
+    if (a.H == 16 && a.W == 16) return launch_geom<16, 16, 384, 32, 2, false, true>(a, s);
     TN_REQUIRE(false, "dense_layer: unsupported spatial size");
   }
   if (a.nchain > 0) {

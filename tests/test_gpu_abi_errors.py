@@ -134,7 +134,8 @@ def test_finetune_errors():
 
 
 def test_encoder_create_ex_flags():
-    """tn_densenet121_create_ex: unknown flags and the exact-weights mode outside the fused 224x224 path are errors."""
+    """tn_densenet121_create_ex: unknown flags are errors; the exact-weights mode exists for every input size (round 6: the
+    un-fused layer kernels and the 64 / 32 / 16 geometries of the tile kernel carry the hi + lo pass too)."""
     import ctypes as C
     from tennis_amd import _lib, weights as W
     ctx = _lib.default_context()
@@ -142,8 +143,9 @@ def test_encoder_create_ex_flags():
     h = C.c_void_p()
     assert ctx.lib.tn_densenet121_create_ex(ctx.handle, arr, len(arr), b"densenet0_", 224, 224, 2, 2, C.byref(h)) != 0
     assert b"unknown flag" in ctx.lib.tn_last_error()
-    assert ctx.lib.tn_densenet121_create_ex(ctx.handle, arr, len(arr), b"densenet0_", 512, 512, 2, _lib.ENC_EXACT_WEIGHTS, C.byref(h)) != 0
-    assert b"TN_ENC_EXACT_WEIGHTS needs the fused 224x224 path" in ctx.lib.tn_last_error()
+    for size in (512, 236):
+        assert ctx.lib.tn_densenet121_create_ex(ctx.handle, arr, len(arr), b"densenet0_", size, size, 2, _lib.ENC_EXACT_WEIGHTS, C.byref(h)) == 0
+        assert ctx.lib.tn_densenet121_destroy(h) == 0
     assert ctx.lib.tn_densenet121_create_ex(ctx.handle, arr, len(arr), b"densenet0_", 224, 224, 2, _lib.ENC_EXACT_WEIGHTS, C.byref(h)) == 0
     assert ctx.lib.tn_densenet121_destroy(h) == 0
 
