@@ -249,7 +249,7 @@ struct tn_encoder {
   std::vector<float> stem_centre;                            // m_c on the host (read_tap / input_means add it back)
   struct DenseLayer { float *s1, *t1; f16 *w1; float *s2, *t2; f16 *w3p; int cin; f16 *w1s = nullptr, *w3s = nullptr; };   // w1s / w3s: fragment images of the strip kernel
   std::vector<DenseLayer> layers[4];
-  struct Trans { float *s, *t; f16 *w; int cin, cout; } trans[3];
+  struct Trans { float *s, *t; f16 *w; int cin, cout; f16 *wfrag = nullptr; } trans[3];      // wfrag: w in MFMA operand order (trans_ws.hip)
   float *head_s, *head_t;
   float *zeros128 = nullptr;   // a BatchNorm shift of zeros (un-fused dense layers: the shift was added by the 1x1)
   f16 *stem_out, *bott, *blockbuf[4];
@@ -544,6 +544,10 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
       T.s = e->pool.upload(s); T.t = e->pool.upload(t);
       T.w = e->exact ? e->pool.upload(split_hi_lo_rows(wt, T.cout, T.cin, T.cin))
                      : e->pool.upload(to_f16(wt, (size_t)T.cout * T.cin));
+      if (!e->exact && T.cout == 512 && T.cin % 64 == 0) {      // the warp-specialised kernel of the last transition (trans_ws.hip decides at launch)
+        const std::vector<f16> wh = to_f16(wt, (size_t)T.cout * T.cin);
+        T.wfrag = e->pool.upload(pack_trans_frags(wh.data(), T.cout, T.cin));
+      }
       ++outer;
     }
   }
@@ -749,6 +753,7 @@ static int encoder_run_range(tn_encoder *e, const void *x0, tn_layout layout, in
       if (cal && (rc = cal_mean(bbuf[b], e->Cb[b], T.cin, T.s, T.t, M))) return rc;
       Conv1x1Args at{bbuf[b], e->Cb[b], T.cin, T.s, T.t, T.w, T.cout, bbuf[b + 1], e->Cb[b + 1], 0, Mo, 1, Hh, Ww};
       at.exact = e->exact;
+      at.wfrag = cal ? nullptr : T.wfrag;
       if (b == 2 && h32) { at.y32 = h32; at.ld32 = e->Cb[3]; }
       tm.begin("transition_conv1x1_avgpool", 2.0 * M * (double)T.cout * T.cin,
                (double)M * T.cin * 2 + (double)Mo * T.cout * 2 + (double)T.cout * T.cin * 2);

@@ -154,8 +154,14 @@ struct Conv1x1Args {
   int clamp = 0;      // the dense layers' BN1 form: scale / shift hold lo / hi, the operand is clamp(x, lo, hi) (no arithmetic, no rounding)
   float *y32 = nullptr;   // [M][ld32] fp32: the result once more, un-rounded (the last transition: what the head reads), columns [0, N)
   int ld32 = 0;
+  const f16 *wfrag = nullptr;   // w once more in MFMA operand order (pack_trans_frags): enables the warp-specialised kernel of trans_ws.hip
 };
 int launch_conv1x1(const Conv1x1Args &a, hipStream_t s);
+// trans_ws.hip: the last transition (N = 512, one frame of <= 64 pooled pixels per workgroup)
+bool trans_ws_supported(const Conv1x1Args &a);
+int launch_trans_ws(const Conv1x1Args &a, hipStream_t s);
+std::vector<f16> pack_trans_frags(const f16 *w, int N, int K);
+int launch_pack_trans_frags(const f16 *w, int N, int K, f16 *out, hipStream_t s);
 
 struct Conv3x3Args {
   const f16 *x;       // [M][128] bottleneck, dense

@@ -259,6 +259,8 @@ int launch_conv1x1(const Conv1x1Args &a, hipStream_t s) {
   TN_REQUIRE(a.K % 32 == 0 && a.N % BN_TILE == 0, "conv1x1: K%32 or N%128");
   TN_REQUIRE(a.ldx % 8 == 0 && a.ldy % 8 == 0 && a.yoff % 8 == 0, "conv1x1: strides must be multiples of 8");
   const dim3 block(256);
+  static const bool no_ws = getenv("TN_NO_TRANS_WS") != nullptr;      // A/B runs
+  if (a.wfrag && !no_ws && trans_ws_supported(a)) return launch_trans_ws(a, s);
   if (a.pool) {
     static const bool narrow = getenv("TN_TRANS_NARROW") != nullptr;   // A/B runs: 128-channel tiles everywhere
     const bool wide = a.N % 256 == 0 && !narrow;

@@ -37,6 +37,20 @@ extern "C" int tn_dbg_conv1x1_dev(tn_ctx *ctx, const void *x_f16, int ldx, int K
   Conv1x1Args a{(const f16 *)x_f16, ldx, K, scale, shift, (const f16 *)w_f16, N, (f16 *)y_f16, ldy, yoff, M, pool, H, W};
   a.variant = variant & 0xffff;
   a.exact = (variant >> 17) & 1;      // bit 17: w is [N][2 K] = [hi | lo] (exact-weights mode)
+  if ((variant >> 18) & 1) {          // bit 18: the warp-specialised transition kernel (trans_ws.hip); the fragment image of w is built per call
+    TN_REQUIRE(trans_ws_supported(a), "tn_dbg_conv1x1_dev: geometry not supported by trans_ws");
+    TN_ON_DEVICE(ctx->device);
+    static f16 *frag = nullptr;
+    static size_t frag_halves = 0;
+    if (frag_halves < (size_t)N * K) {
+      if (frag) (void)hipFree(frag);
+      TN_HIP_CHECK(hipMalloc((void **)&frag, (size_t)N * K * sizeof(f16)));
+      frag_halves = (size_t)N * K;
+    }
+    const int rc = launch_pack_trans_frags(a.w, N, K, frag, ctx->stream);
+    if (rc) return rc;
+    a.wfrag = frag;
+  }
   return launch_conv1x1(a, ctx->stream);
 }
 

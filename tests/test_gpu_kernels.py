@@ -101,6 +101,36 @@ def test_conv1x1_pool(ctx, report, B, H, W, K, N):
     assert err < 2e-2, err
 
 
+@pytest.mark.parametrize("B,H,W,K", [(5, 14, 14, 1024), (3, 16, 16, 1024), (2, 10, 12, 256), (1, 14, 14, 128)])
+def test_transition_warp_specialised_kernel_matches_the_tiled_one(ctx, B, H, W, K):
+    """trans_ws.hip (round 6: the last transition with staging waves and multiplying waves, one frame per workgroup) against
+    conv1x1.hip's tiled form on the same operands: the same operand tiles, the fp32 sums of 32x32x16 MFMAs instead of 16x16x32 ones -
+    equal to one fp16 ulp, the columns outside the output untouched, two runs bit-identical (and the pooled map of a 16 x 16 /
+    10 x 12 frame: 64 / 30 rows of the 64-row tile)."""
+    from tennis_amd import _lib
+    N = 512
+    rng = np.random.default_rng(B * H + K)
+    xd = torch.from_numpy(rng.normal(0, 1.5, (B, H, W, K)).astype(np.float16)).cuda()
+    sd = torch.from_numpy(rng.uniform(0.5, 1.5, K).astype(np.float32)).cuda()
+    td = torch.from_numpy(rng.normal(0, 0.3, K).astype(np.float32)).cuda()
+    wd = torch.from_numpy(rng.normal(0, np.sqrt(2.0 / K), (N, K)).astype(np.float16)).cuda()
+    Mo = B * (H // 2) * (W // 2)
+    ldy = N + 64
+    outs = []
+    for variant in (0, 1 << 18, 1 << 18):
+        yd = torch.full((Mo, ldy), 7.0, dtype=torch.float16, device="cuda")
+        _lib.check(ctx.lib.tn_dbg_conv1x1_dev(ctx.handle, _lib.ptr(xd), K, K, _lib.ptr(sd), _lib.ptr(td), _lib.ptr(wd), N, _lib.ptr(yd),
+                                              ldy, 32, Mo, 1, H, W, variant), "dbg_conv1x1_dev")
+        torch.cuda.synchronize()
+        outs.append(yd.cpu().numpy())
+    assert np.isfinite(outs[0][:, 32:32 + N].astype(np.float32)).all() and np.abs(outs[0][:, 32:32 + N].astype(np.float32)).max() > 0.1
+    assert np.array_equal(outs[1].view(np.uint16), outs[2].view(np.uint16))
+    a, b = outs[0].astype(np.float32), outs[1].astype(np.float32)
+    assert np.array_equal(a[:, :32], b[:, :32]) and np.array_equal(a[:, 32 + N:], b[:, 32 + N:])      # untouched
+    d = np.abs(a - b)
+    assert d.max() <= 2.0 ** -9 * max(1.0, np.abs(a).max()) and (d > 0).mean() < 0.05, (d.max(), (d > 0).mean(), np.abs(a).max())
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 14, 14), (3, 7, 7), (1, 56, 56), (2, 28, 28), (1, 9, 13)])
 def test_conv3x3(ctx, report, B, H, W):
     from tennis_amd import _lib
