@@ -87,7 +87,7 @@ for v in [int(s) for s in args.variants.split(",")]:
             wd = (torch.randn((N, K), device="cuda") * (2.0 / K) ** 0.5).half()
             sc = torch.rand(K, device="cuda") + 0.5; sh = torch.randn(K, device="cuda") * 0.3
             fn = lambda: _lib.check(lib.tn_dbg_conv1x1_dev(ctx.handle, _lib.ptr(x), K, K, _lib.ptr(sc), _lib.ptr(sh),
-                                                           _lib.ptr(wd), N, _lib.ptr(y), N, 0, Mo, 1, hw, hw, v | ((1 << 18) if (args.ws and N == 512) else 0)))
+                                                           _lib.ptr(wd), N, _lib.ptr(y), N, 0, Mo, 1, hw, hw, v | ((1 << 18) if (args.ws and N in (256, 512)) else 0)))
             us = timed(fn, args.iters)
             by = M * K * 2 + Mo * N * 2
             res.append(dict(k="tr", v=v, hw=hw, K=K, us=round(us, 1), tf=round(2.0 * M * N * K / us / 1e6, 1), tbs=round(by / us / 1e6, 2)))

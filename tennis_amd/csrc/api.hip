@@ -544,7 +544,7 @@ extern "C" int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int
       T.s = e->pool.upload(s); T.t = e->pool.upload(t);
       T.w = e->exact ? e->pool.upload(split_hi_lo_rows(wt, T.cout, T.cin, T.cin))
                      : e->pool.upload(to_f16(wt, (size_t)T.cout * T.cin));
-      if (!e->exact && T.cout == 512 && T.cin % 64 == 0) {      // the warp-specialised kernel of the last transition (trans_ws.hip decides at launch)
+      if (!e->exact && (T.cout == 512 || T.cout == 256) && T.cin % 128 == 0) {      // the warp-specialised kernel of the last two transitions (trans_ws.hip decides at launch)
         const std::vector<f16> wh = to_f16(wt, (size_t)T.cout * T.cin);
         T.wfrag = e->pool.upload(pack_trans_frags(wh.data(), T.cout, T.cin));
       }

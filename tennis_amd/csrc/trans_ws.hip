@@ -32,11 +32,18 @@
 namespace {
 
 constexpr int BK = 64;                    // channels per k-tile
-constexpr int BM = 64;                    // tile rows (pooled pixels of one frame, <= 64)
-constexpr int NB = 512;                   // output channels
-constexpr int XT = BM * 128;              // one pixel tile (hi or lo) of a k-tile: 8 KiB
-constexpr int CPITCH = NB * 2 + 16;       // epilogue row: NB halves + 8 of padding
-constexpr int LDS_BYTES = BM * CPITCH > 4 * XT ? BM * CPITCH : 4 * XT;
+// Two tile shapes, each 128 accumulator registers per multiplier wave: 64 pooled pixels x 512 channels (the last transition) and
+// 128 pixels x 256 channels (the second one).  A frame is cut into ceil(P / BM) tiles of equal size PT <= BM (14 x 14 -> 7 x 7:
+// one tile of 49; 28 x 28 -> 14 x 14: two of 98; the 32 x 32 / 16 x 16 maps of a 512 x 512 input: eight of 128 / four of 64).
+template <int BM, int NB>
+struct TG {
+  static constexpr int XT = BM * 128;              // one pixel tile (hi or lo) of a k-tile
+  static constexpr int CPITCH = NB * 2 + 16;       // epilogue row: NB halves + 8 of padding
+  static constexpr int LDS_BYTES = BM * CPITCH > 4 * XT ? BM * CPITCH : 4 * XT;
+  static constexpr int SR = BM / 32;               // tile rows a stager thread owns
+  static constexpr int NCT = NB / 4 / 32, NPT = BM / 32;      // 32-channel x 32-pixel accumulator tiles of a multiplier wave
+  static_assert(NCT * NPT == 8, "128 accumulator registers");
+};
 
 // workgroup barrier that orders LDS traffic only (__syncthreads() also drains the global loads in flight)
 __device__ __forceinline__ void lds_barrier() {
@@ -51,23 +58,26 @@ using ic = std::integral_constant<int, V>;
 // NK: k-tiles known at compile time (K = 1024: 16; 0 = run-time count).  hipcc's wait-count pass puts an s_waitcnt vmcnt(0) at the head
 // of a LOOP whose body carries loads across the back edge (seen in the ISA: the stagers then wait for the tile they requested a
 // moment ago, once per trip) - fully unrolled, every wait is counted exactly and the newest tile stays in flight.
-template <int NK>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void trans_ws_kernel(Conv1x1Args a) {
+template <int NK, int BM, int NB>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void trans_ws_kernel(Conv1x1Args a, int TPF, int PT) {
+  using G = TG<BM, NB>;
+  constexpr int XT = G::XT, CPITCH = G::CPITCH, SR = G::SR, NCT = G::NCT, NPT = G::NPT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
   const int Wo = a.W >> 1, Ho = a.H >> 1, P = Wo * Ho;      // pooled pixels per frame
-  const int frame = blockIdx.x;
+  const int frame = (int)blockIdx.x / TPF, p0 = ((int)blockIdx.x % TPF) * PT;      // this tile: pooled pixels p0 .. p0 + nrow - 1 of the frame
+  const int nrow = P - p0 < PT ? P - p0 : PT;
   const int K = a.K, nk = NK ? NK : K / BK;
 
   if (wid < 4) {
     // ================= stagers: tile i -> buffer i & 1 =================
-    const int c = t & 7, r0 = t >> 3;               // 16-byte chunk column, tile row (and row + 32)
-    const f16 *xsrc[2][4];
+    const int c = t & 7, r0 = t >> 3;               // 16-byte chunk column, tile rows r0 + 32 i
+    const f16 *xsrc[SR][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < SR; ++i) {
       int p = r0 + 32 * i;
-      p = p < P ? p : P - 1;                        // rows past the frame repeat its last pixel (computed, never stored)
+      p = p0 + (p < nrow ? p : nrow - 1);           // rows past the tile repeat its last pixel (computed, never stored)
       const int py = p / Wo, px = p - py * Wo;
       const long base = ((long)(frame * a.H + 2 * py) * a.W + 2 * px);
       xsrc[i][0] = a.x + base * a.ldx;
@@ -75,7 +85,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       xsrc[i][2] = a.x + (base + a.W) * a.ldx;
       xsrc[i][3] = a.x + (base + a.W + 1) * a.ldx;
     }
-    f16x8 xr[2][2][4];
+    f16x8 xr[2][SR][4];
     float scb[2][8], shb[2][8];
     // (unconditional loads, k-tiles past the end repeat the last one: a load under a branch makes hipcc drain the queue at the next use)
     auto load = [&](int kt, auto b_tag) {
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
       sh[0] = t0.x; sh[1] = t0.y; sh[2] = t0.z; sh[3] = t0.w; sh[4] = t1.x; sh[5] = t1.y; sh[6] = t1.z; sh[7] = t1.w;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < SR; ++i)
 #pragma unroll
         for (int s = 0; s < 4; ++s) xr[PB][i][s] = *(const f16x8 *)(xsrc[i][s] + kc);
     };
@@ -96,7 +106,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       constexpr int PB = decltype(b_tag)::value;
       unsigned char *Xs = smem + PB * 2 * XT, *Xl = Xs + XT;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < SR; ++i) {
         f16x8 v, vl;
         if (TN_TWS_EXP & 1) { v = xr[PB][i][0]; vl = xr[PB][i][1]; } else
 #pragma unroll
@@ -131,48 +141,48 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // (scripts/microbench/slotbench.hip): with the 16x16x32 shape this kernel took 45.6 us = the sum of its staging VALU time,
     // its MFMA time and its memory time (knock-out builds, TN_TWS_EXP: 36.0 without the staging arithmetic, 33.3 without the
     // MFMAs, 27.4 without either).
-    const int wn = wid - 4;                          // channels 128 wn .. 128 wn + 127
+    const int wn = wid - 4;                          // channels (NB / 4) wn .. + NB / 4 - 1
     const int r32 = lane & 31, h32 = lane >> 5;
-    f32x16 acc[4][2];                                // [32-channel tile][32-pixel tile]
+    f32x16 acc[NCT][NPT];                            // [32-channel tile][32-pixel tile]
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt)
+      for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
-    // weight fragments (k-step g of 16 channels, channel tile 4 wn + ct) at ((g * (NB / 32) + 4 wn + ct) * 64 + lane) * 16 bytes.
+    // weight fragments (k-step g of 16 channels, channel tile NCT wn + ct) at ((g * (NB / 32) + NCT wn + ct) * 64 + lane) * 16 bytes.
     // A ring of four k-steps = one k-tile: the slot of step s is refilled with step s of the NEXT tile right behind its MFMAs,
     // 2 048 MFMA-cycles ahead of its use (an L2 hit is about half of that); no conditional inside the loop body - a load under a
     // branch makes hipcc's wait-count pass drain the queue at the next use
-    const f16x8 *wf = (const f16x8 *)a.wfrag + (size_t)(wn * 4) * 64 + lane;
-    f16x8 wa[4][4];
+    const f16x8 *wf = (const f16x8 *)a.wfrag + (size_t)(wn * NCT) * 64 + lane;
+    f16x8 wa[4][NCT];
     auto load_w = [&](int kt, auto s_tag) {
       constexpr int S = decltype(s_tag)::value;
       kt = kt < nk ? kt : nk - 1;        // (past the end: the last tile once more)
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) wa[S][ct] = wf[((size_t)(kt * 4 + S) * (NB / 32) + ct) * 64];
+      for (int ct = 0; ct < NCT; ++ct) wa[S][ct] = wf[((size_t)(kt * 4 + S) * (NB / 32) + ct) * 64];
     };
     auto mult = [&](int kt, auto s_tag) {
       constexpr int S = decltype(s_tag)::value;
       const unsigned char *Xs = smem + (kt & 1) * 2 * XT, *Xl = Xs + XT;
-      f16x8 xb[2], xl[2];
+      f16x8 xb[NPT], xl[NPT];
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt) {
+      for (int pt = 0; pt < NPT; ++pt) {
         xb[pt] = *(const f16x8 *)(Xs + swz<128>(pt * 32 + r32, S * 2 + h32));
         xl[pt] = *(const f16x8 *)(Xl + swz<128>(pt * 32 + r32, S * 2 + h32));
       }
       if (TN_TWS_EXP & 2) {
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) acc[0][pt][0] += (float)xb[pt][0] + (float)xl[pt][0] + (float)wa[S][pt][0] + (float)wa[S][2 + pt][0];
+        for (int pt = 0; pt < NPT; ++pt) acc[0][pt][0] += (float)xb[pt][0] + (float)xl[pt][0] + (float)wa[S][pt % NCT][0];
       } else {
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-          for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[S][ct], xb[pt], acc[ct][pt], 0, 0, 0);
+          for (int pt = 0; pt < NPT; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[S][ct], xb[pt], acc[ct][pt], 0, 0, 0);
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-          for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[S][ct], xl[pt], acc[ct][pt], 0, 0, 0);
+          for (int pt = 0; pt < NPT; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[S][ct], xl[pt], acc[ct][pt], 0, 0, 0);
       }
       if (!(TN_TWS_EXP & 4)) load_w(kt + 1, s_tag);
     };
@@ -192,27 +202,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // every multiplier is behind its last fragment read (the loop's last barrier): the tile buffers become the output tile.
     // D: lane holds pixel 32 pt + (l & 31), channels 32 ct + (r & 3) + 8 (r >> 2) + 4 (l >> 5)
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt)
+      for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int m = pt * 32 + r32, n = wn * 128 + ct * 32 + 8 * g + 4 * h32;
+          const int m = pt * 32 + r32, n = wn * (NB / 4) + ct * 32 + 8 * g + 4 * h32;
           f16x4 h;
 #pragma unroll
           for (int r = 0; r < 4; ++r) h[r] = (f16)acc[ct][pt][4 * g + r];
           *(f16x4 *)(smem + m * CPITCH + n * 2) = h;
-          if (a.y32 && m < P)      // the un-rounded result for the head, 16 B per lane
-            *(float4 *)(a.y32 + ((long)frame * P + m) * a.ld32 + n) =
+          if (a.y32 && m < nrow)      // the un-rounded result for the head, 16 B per lane
+            *(float4 *)(a.y32 + ((long)frame * P + p0 + m) * a.ld32 + n) =
                 make_float4(acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]);
         }
   }
   __syncthreads();
   // coalesced rows: 64 threads x 16 B per pixel
-  for (int id = t; id < P * (NB / 8); id += 512) {
+  for (int id = t; id < nrow * (NB / 8); id += 512) {
     const int row = id / (NB / 8), ch = id % (NB / 8);
     const uint4 v = *(const uint4 *)(smem + row * CPITCH + ch * 16);
-    *(uint4 *)(a.y + ((long)frame * P + row) * a.ldy + a.yoff + ch * 8) = v;
+    *(uint4 *)(a.y + ((long)frame * P + p0 + row) * a.ldy + a.yoff + ch * 8) = v;
   }
 }
 
@@ -240,8 +250,8 @@ std::vector<f16> pack_trans_frags(const f16 *w, int N, int K) {
 }
 
 bool trans_ws_supported(const Conv1x1Args &a) {
-  return a.pool && !a.exact && !a.bias && a.N == NB && a.K % (2 * BK) == 0 && a.H % 2 == 0 && a.W % 2 == 0 &&
-         (a.H / 2) * (a.W / 2) <= BM && a.M % ((a.H / 2) * (a.W / 2)) == 0;
+  return a.pool && !a.exact && !a.bias && (a.N == 512 || a.N == 256) && a.K % (2 * BK) == 0 && a.H % 2 == 0 && a.W % 2 == 0 && a.H >= 2 && a.W >= 2 &&
+         a.M % ((a.H / 2) * (a.W / 2)) == 0;
 }
 
 int launch_pack_trans_frags(const f16 *w, int N, int K, f16 *out, hipStream_t s) {
@@ -252,13 +262,18 @@ int launch_pack_trans_frags(const f16 *w, int N, int K, f16 *out, hipStream_t s)
   return TN_OK;
 }
 
-int launch_trans_ws(const Conv1x1Args &a, hipStream_t s) {
-  TN_REQUIRE(trans_ws_supported(a) && a.wfrag, "trans_ws: unsupported geometry");
-  TN_SET_ATTR_ONCE_PER_DEVICE(TN_HIP_CHECK(hipFuncSetAttribute((const void *)trans_ws_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-                              TN_HIP_CHECK(hipFuncSetAttribute((const void *)trans_ws_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)));
-  const int P = (a.H / 2) * (a.W / 2);
-  if (a.K == 16 * BK) hipLaunchKernelGGL(trans_ws_kernel<16>, dim3(a.M / P), dim3(512), LDS_BYTES, s, a);
-  else hipLaunchKernelGGL(trans_ws_kernel<0>, dim3(a.M / P), dim3(512), LDS_BYTES, s, a);
+template <int NK, int BM, int NB>
+static int launch_tws(const Conv1x1Args &a, hipStream_t s) {
+  using G = TG<BM, NB>;
+  TN_SET_ATTR_ONCE_PER_DEVICE(TN_HIP_CHECK(hipFuncSetAttribute((const void *)trans_ws_kernel<NK, BM, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES)));
+  const int P = (a.H / 2) * (a.W / 2), TPF = (P + BM - 1) / BM, PT = (P + TPF - 1) / TPF;
+  hipLaunchKernelGGL((trans_ws_kernel<NK, BM, NB>), dim3(a.M / P * TPF), dim3(512), G::LDS_BYTES, s, a, TPF, PT);
   TN_HIP_CHECK(hipGetLastError());
   return TN_OK;
+}
+
+int launch_trans_ws(const Conv1x1Args &a, hipStream_t s) {
+  TN_REQUIRE(trans_ws_supported(a) && a.wfrag, "trans_ws: unsupported geometry");
+  if (a.N == 512) return a.K == 16 * BK ? launch_tws<16, 64, 512>(a, s) : launch_tws<0, 64, 512>(a, s);
+  return a.K == 8 * BK ? launch_tws<8, 128, 256>(a, s) : launch_tws<0, 128, 256>(a, s);
 }

@@ -101,14 +101,15 @@ def test_conv1x1_pool(ctx, report, B, H, W, K, N):
     assert err < 2e-2, err
 
 
-@pytest.mark.parametrize("B,H,W,K", [(5, 14, 14, 1024), (3, 16, 16, 1024), (2, 10, 12, 256), (1, 14, 14, 128)])
-def test_transition_warp_specialised_kernel_matches_the_tiled_one(ctx, B, H, W, K):
+@pytest.mark.parametrize("B,H,W,K,N", [(5, 14, 14, 1024, 512), (3, 16, 16, 1024, 512), (2, 10, 12, 256, 512), (1, 14, 14, 128, 512),
+                                       (2, 32, 32, 1024, 512), (3, 28, 28, 512, 256), (2, 64, 64, 512, 256), (1, 20, 22, 256, 256)])
+def test_transition_warp_specialised_kernel_matches_the_tiled_one(ctx, B, H, W, K, N):
     """trans_ws.hip (round 6: the last transition with staging waves and multiplying waves, one frame per workgroup) against
     conv1x1.hip's tiled form on the same operands: the same operand tiles, the fp32 sums of 32x32x16 MFMAs instead of 16x16x32 ones -
     equal to one fp16 ulp, the columns outside the output untouched, two runs bit-identical (and the pooled map of a 16 x 16 /
-    10 x 12 frame: 64 / 30 rows of the 64-row tile)."""
+    10 x 12 frame: 64 / 30 rows of the 64-row tile; the 128-pixel x 256-channel tile shape of the second transition: a 14 x 14 pooled
+    map as two tiles of 98 rows, the maps of a 512 x 512 input as eight tiles of 128 / four of 64)."""
     from tennis_amd import _lib
-    N = 512
     rng = np.random.default_rng(B * H + K)
     xd = torch.from_numpy(rng.normal(0, 1.5, (B, H, W, K)).astype(np.float16)).cuda()
     sd = torch.from_numpy(rng.uniform(0.5, 1.5, K).astype(np.float32)).cuda()
