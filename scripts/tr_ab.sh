@@ -1,5 +1,2 @@
-python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "1x1 or transition" 2>&1 | tail -5
-for rep in 1 2 3; do
-echo old; python scripts/kbench.py --kernels tr --iters 50 --blocks 1,2 2>&1 | grep "'k'"
-echo ws; python scripts/kbench.py --kernels tr --iters 50 --blocks 1,2 --ws 2>&1 | grep "'k'"
-done
+python -m pytest tests -x -q -m gpu 2>&1 | tail -8
+for e in TN_NO_TRANS_WS=1 TN_X=1; do echo $e; env $e python scripts/bench_512.py --out gpurun_out/bench_512_$e.json 2>&1 | grep -E "frames_per_s|transition" -A1 | head -8; done
