@@ -22,7 +22,7 @@ if st:
 
 def family(name):
     for key in ("dense_block7_kernel", "dense_block14_kernel", "dense_strip_kernel<56", "dense_strip_kernel<28", "dense_layer_kernel<56", "dense_layer_kernel<28", "dense_layer_kernel<14", "dense_layer_kernel<7",
-                "dense_block", "stem_pool_kernel", "conv1x1_kernel", "head_kernel", "stem_kernel", "maxpool_kernel"):
+                "dense_block", "stem_pool_kernel", "trans_ws_kernel", "conv1x1_kernel", "head_kernel", "stem_kernel", "maxpool_kernel"):
         if key in name:
             return key
     return None
