@@ -85,7 +85,8 @@ int tn_densenet121_create(tn_ctx *ctx, const tn_param *params, int n_params, con
  * kept as two fp16 numbers each (hi + lo, 22 bits of the fp32 weight) and every product is formed with both: features
  * within 1e-3 of the fp32 reference evaluated on the UN-rounded weights (reference models/vision/definitions.py:27-33
  * evaluates fp32 parameters), at twice the MFMA work of those layers.  Without the flag the weights are rounded to
- * fp16 once (the served fp16 model).  224 x 224 input only (the fused kernels). */
+ * fp16 once (the served fp16 model).  Any input size since round 6 (maps no fused kernel tiles run their layers un-fused with the
+ * same hi + lo pass; flat frames at 448 x 448 / 512 x 512 keep a tail of 1.2e-3 that is the fp16 activation path's: DESIGN.md section 4). */
 #define TN_ENC_EXACT_WEIGHTS 1
 int tn_densenet121_create_ex(tn_ctx *ctx, const tn_param *params, int n_params, const char *prefix, int height, int width,
                              int max_batch, int flags, tn_encoder **out);
