@@ -40,12 +40,15 @@ extern "C" int tn_dbg_conv1x1_dev(tn_ctx *ctx, const void *x_f16, int ldx, int K
   if ((variant >> 18) & 1) {          // bit 18: the warp-specialised transition kernel (trans_ws.hip); the fragment image of w is built per call
     TN_REQUIRE(trans_ws_supported(a), "tn_dbg_conv1x1_dev: geometry not supported by trans_ws");
     TN_ON_DEVICE(ctx->device);
-    static f16 *frag = nullptr;
-    static size_t frag_halves = 0;
-    if (frag_halves < (size_t)N * K) {
+    static f16 *frags[64] = {};             // (a test hook: one scratch image per device, grown on demand, never freed; not thread-safe)
+    static size_t frag_halves[64] = {};
+    TN_REQUIRE(ctx->device >= 0 && ctx->device < 64, "tn_dbg_conv1x1_dev: device index out of range");
+    f16 *&frag = frags[ctx->device];
+    if (frag_halves[ctx->device] < (size_t)N * K) {
       if (frag) (void)hipFree(frag);
+      frag = nullptr; frag_halves[ctx->device] = 0;
       TN_HIP_CHECK(hipMalloc((void **)&frag, (size_t)N * K * sizeof(f16)));
-      frag_halves = (size_t)N * K;
+      frag_halves[ctx->device] = (size_t)N * K;
     }
     const int rc = launch_pack_trans_frags(a.w, N, K, frag, ctx->stream);
     if (rc) return rc;
