@@ -1,2 +1,2 @@
-python -m pytest tests -x -q -m gpu 2>&1 | tail -8
-for e in TN_NO_TRANS_WS=1 TN_X=1; do echo $e; env $e python scripts/bench_512.py --out gpurun_out/bench_512_$e.json 2>&1 | grep -E "frames_per_s|transition" -A1 | head -8; done
+for e in 31 16; do echo "exp $e"; TN_B7_MSPLIT=1 python scripts/kbench.py --kernels b7 --iters 20 --stamps --lib _ab/libtennis_b7m$e.so 2>&1 | grep -E "totals|'k'|l 0|l 1 |l 8|l15"; done
+TN_B7_MSPLIT=1 python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "block7" 2>&1 | tail -2
