@@ -1,24 +1,28 @@
-// The LAST transition of DenseNet-121 (BatchNorm - ReLU - Conv1x1 (1024 -> 512) - AvgPool 2x2 on the 14 x 14 map; reference call
-// site models/vision/definitions.py:30 -> gluoncv DenseNet _make_transition) as a WARP-SPECIALISED kernel (round 6).
+// The last two transitions of DenseNet-121 (BatchNorm - ReLU - Conv1x1 - AvgPool 2x2: 512 -> 256 on the 28 x 28 map, 1024 -> 512 on
+// the 14 x 14 one; reference call site models/vision/definitions.py:30 -> gluoncv DenseNet _make_transition) as a WARP-SPECIALISED
+// kernel (round 6).
 //
 // conv1x1.hip runs a transition as a tiled GEMM whose waves alternate between two phases behind two barriers per k-tile: staging
 // (load, BN + ReLU, average of the four source pixels, hi + lo split, LDS store: ~390 VALU instructions per wave and k-tile) and
-// multiplying (64 MFMAs).  The SQ counters of that kernel on this transition (profiles/r06_d_transitions_sq_pmc.txt): VALU 28 %,
-// MFMA 18 %, LDS 6 %, waiting 48 % of a wave's life - the two phases never overlap, and neither wider tiles, nor more waves, nor a
-// deeper prefetch, nor the 32x32 MFMA shape changed the 50 us it takes (docs/kernels.md).  Here the two phases are two KINDS of
-// wave:
+// multiplying (64 MFMAs).  The SQ counters of that kernel on the last transition (profiles/r06_d_transitions_sq_pmc.txt): VALU
+// 28 %, MFMA 18 %, LDS 6 %, waiting 48 % of a wave's life - the two phases never overlap, and neither wider tiles, nor more waves,
+// nor a deeper prefetch, nor the 32x32 MFMA shape changed the 50 us it takes (docs/kernels.md).  Here the two phases are two KINDS
+// of wave:
 //
-// * a workgroup = one frame (49 pooled pixels in a 64-row tile) x all 512 output channels, one workgroup per CU (256 frames = 256
-//   CUs: no tile-count remainder), eight waves = two per SIMD;
+// * a workgroup = one tile of a frame's pooled pixels x ALL output channels (TG below: 64 pixels x 512 channels - a 7 x 7 frame is
+//   one tile of 49 rows - or 128 x 256 - a 14 x 14 frame is two tiles of 98), eight waves = two per SIMD, one workgroup per CU;
 // * waves 0 - 3 STAGE: global -> registers two k-tiles ahead, BN + ReLU + average + hi / lo split exactly as conv1x1.hip does it
 //   (same arithmetic, same order: the operand tiles are the same bits), LDS store into one of two tile buffers;
 // * waves 4 - 7 MULTIPLY: pixel fragments from the other tile buffer, weight fragments straight from global memory in MFMA
-//   operand order (pack_trans_frags: 1 KiB per wave-load, one k-tile ahead in registers; the 1 MB of weights is L2-resident and the
-//   LDS holds nothing but the pixel tiles), 64 v_mfma_f32_32x32x16_f16 per k-tile into 128 accumulator registers (128 channels x
-//   64 pixels; the fp32 sums run in a different order than the tiled kernel's 16x16x32 ones: results agree to an fp16 ulp);
-// * ONE barrier per k-tile: a stager's VALU instructions issue in the shadow of the multiplier wave that shares its SIMD.
+//   operand order (pack_trans_frags: 1 KiB per wave-load, one k-tile ahead in registers; the weights are L2-resident and the LDS
+//   holds nothing but the pixel tiles), 64 v_mfma_f32_32x32x16_f16 per k-tile into 128 accumulator registers (the fp32 sums run
+//   in a different order than the tiled kernel's 16x16x32 ones: results agree to an fp16 ulp);
+// * ONE barrier per k-tile: a stager's VALU instructions issue beside the multiplier wave that shares its SIMD.
 //
-// The pixel tile is pooled once per frame (conv1x1.hip: once per 256-channel column tile, i.e. twice).
+// The pixel tile is pooled once (conv1x1.hip: once per 256-channel column tile).  Measured at batch 256: 70 -> 63 us and 55 -> 44 us
+// alone; knock-out builds of the last transition: 29 us with neither staging arithmetic nor MFMAs - the kernel's memory time, at
+// the boxes' practical read rate - so the two kinds of wave still add more than they hide.  Inside the pipelined step the gain is
+// not visible (139.8 k against 139.7 k frames/s): there a kernel costs the CU-time it occupies, and this one holds a CU alone.
 #include <type_traits>
 #include <utility>
 #include <vector>
